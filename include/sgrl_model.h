@@ -1,0 +1,153 @@
+/* sgrl_model.h -- packed morphology + task description shared by the HIP engine (libsgrl_hip.so)
+ * and the CPU oracle (oracle/libsgrl_oracle.so).  Plain C, no dependencies.
+ *
+ * A morphology is two flat blobs produced by sgrl_amd.model_pack.pack_model():
+ *   int32  ib[]:  header (SGRL_NHDR ints) followed by the integer tables, in the order of the
+ *                 SGRL_INT_FIELDS list below;
+ *   double fb[]:  SGRL_NFHDR scalars followed by the float tables in SGRL_F64_FIELDS order.
+ * This replaces what the reference obtains from MuJoCo's compiled `mjModel` through mujoco-py
+ * (reference src/environments/ModularEnv.py:12 `MujocoEnv.__init__(self, xml, 4)`) plus the
+ * per-file task constants of reference src/environments/<name>.py:15-44,150-164.
+ */
+#ifndef SGRL_MODEL_H
+#define SGRL_MODEL_H
+
+#include <stdint.h>
+
+#ifdef __HIPCC__
+#define SGRL_HD __host__ __device__ inline
+#else
+#define SGRL_HD static inline
+#endif
+
+#define SGRL_MAGIC 0x5347524C
+
+/* ---- integer header -------------------------------------------------------------------------- */
+enum {
+  SGRL_H_MAGIC = 0,
+  SGRL_H_NBODY,      /* bodies incl. world (index 0); limbs L = nbody-1 */
+  SGRL_H_NJNT,
+  SGRL_H_NQ,
+  SGRL_H_NV,
+  SGRL_H_NU,
+  SGRL_H_NGEOM,
+  SGRL_H_NPAIR,
+  SGRL_H_INTEGRATOR, /* 0 Euler (implicit joint damping), 1 RK4 */
+  SGRL_H_FRAME_SKIP, /* 4 */
+  SGRL_H_DONE_RULE,  /* 0 walker/humanoid, 1 hopper, 2 cheetah */
+  SGRL_H_TARGET_V2,  /* 0: radius 10000 about origin; 1: radius U(10,20) about current position */
+  SGRL_H_RESET_VEL_NORMAL, /* 0 uniform, 1 normal (cheetah) */
+  SGRL_H_NHEIGHT_BODIES,   /* cheetah: bodies whose z also bounds the height (0..2) */
+  SGRL_H_HEIGHT_BODY0,
+  SGRL_H_HEIGHT_BODY1,
+  SGRL_H_MAX_ROWS,   /* cap on constraint rows per evaluation */
+  SGRL_H_PGS_ITERS,  /* maximum number of projected Gauss-Seidel sweeps per evaluation */
+  SGRL_NHDR = 24
+};
+
+/* ---- float header ---------------------------------------------------------------------------- */
+enum {
+  SGRL_F_TIMESTEP = 0,
+  SGRL_F_GRAV_X, SGRL_F_GRAV_Y, SGRL_F_GRAV_Z,
+  SGRL_F_HEIGHT_LO, SGRL_F_HEIGHT_HI, SGRL_F_ANG_LIMIT,
+  SGRL_F_ALIVE_BONUS, SGRL_F_HEADING_WEIGHT, SGRL_F_CTRL_COST,
+  SGRL_F_RESET_POS_NOISE, SGRL_F_RESET_VEL_NOISE,
+  SGRL_F_PGS_TOL,    /* stop when max_i |(A_ii+R_i) df_i| < tol * (1 + max_i |b_i|) over one sweep */
+  SGRL_NFHDR = 16
+};
+
+enum { SGRL_GEOM_PLANE = 0, SGRL_GEOM_SPHERE = 2, SGRL_GEOM_CAPSULE = 3 };
+enum { SGRL_JNT_FREE = 0, SGRL_JNT_HINGE = 3 };
+
+typedef struct SgrlModelView {
+  const int32_t* hdr;
+  const double* fhdr;
+  int nbody, njnt, nq, nv, nu, ngeom, npair;
+  /* int tables */
+  const int32_t *body_parent, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_limbtype;
+  const int32_t *jnt_type, *jnt_body, *jnt_qposadr, *jnt_dofadr, *jnt_limited;
+  const int32_t *dof_body, *dof_jnt, *dof_parent;
+  const int32_t *geom_type, *geom_body;
+  const int32_t *pair_g1, *pair_g2, *pair_condim;
+  const int32_t *act_dof, *act_slot;
+  /* float tables */
+  const double *qpos0;
+  const double *body_pos, *body_quat, *body_ipos, *body_inertia, *body_mass, *body_invweight0;
+  const double *jnt_pos, *jnt_axis, *jnt_range, *jnt_stiffness, *jnt_solref, *jnt_solimp, *jnt_margin;
+  const double *dof_armature, *dof_damping, *dof_invweight0;
+  const double *geom_pos, *geom_quat, *geom_size;
+  const double *pair_mu, *pair_margin, *pair_solref, *pair_solimp;
+  const double *act_gear, *act_ctrlrange;
+  int n_int, n_f64; /* total blob lengths */
+} SgrlModelView;
+
+/* Set up table pointers into the blobs.  Returns 0, or -1 when the magic is wrong. */
+SGRL_HD int sgrl_model_view(const int32_t* ib, const double* fb, SgrlModelView* v) {
+  if (ib[SGRL_H_MAGIC] != SGRL_MAGIC) return -1;
+  v->hdr = ib;
+  v->fhdr = fb;
+  const int nb = ib[SGRL_H_NBODY], nj = ib[SGRL_H_NJNT], nq = ib[SGRL_H_NQ], nv = ib[SGRL_H_NV];
+  const int nu = ib[SGRL_H_NU], ng = ib[SGRL_H_NGEOM], np = ib[SGRL_H_NPAIR];
+  v->nbody = nb; v->njnt = nj; v->nq = nq; v->nv = nv; v->nu = nu; v->ngeom = ng; v->npair = np;
+  const int32_t* p = ib + SGRL_NHDR;
+  v->body_parent = p; p += nb;
+  v->body_jntadr = p; p += nb;
+  v->body_jntnum = p; p += nb;
+  v->body_dofadr = p; p += nb;
+  v->body_dofnum = p; p += nb;
+  v->body_limbtype = p; p += nb;
+  v->jnt_type = p; p += nj;
+  v->jnt_body = p; p += nj;
+  v->jnt_qposadr = p; p += nj;
+  v->jnt_dofadr = p; p += nj;
+  v->jnt_limited = p; p += nj;
+  v->dof_body = p; p += nv;
+  v->dof_jnt = p; p += nv;
+  v->dof_parent = p; p += nv;
+  v->geom_type = p; p += ng;
+  v->geom_body = p; p += ng;
+  v->pair_g1 = p; p += np;
+  v->pair_g2 = p; p += np;
+  v->pair_condim = p; p += np;
+  v->act_dof = p; p += nu;
+  v->act_slot = p; p += nu;
+  v->n_int = (int)(p - ib);
+  const double* f = fb + SGRL_NFHDR;
+  v->qpos0 = f; f += nq;
+  v->body_pos = f; f += 3 * nb;
+  v->body_quat = f; f += 4 * nb;
+  v->body_ipos = f; f += 3 * nb;
+  v->body_inertia = f; f += 6 * nb;
+  v->body_mass = f; f += nb;
+  v->body_invweight0 = f; f += 2 * nb;
+  v->jnt_pos = f; f += 3 * nj;
+  v->jnt_axis = f; f += 3 * nj;
+  v->jnt_range = f; f += 2 * nj;
+  v->jnt_stiffness = f; f += nj;
+  v->jnt_solref = f; f += 2 * nj;
+  v->jnt_solimp = f; f += 5 * nj;
+  v->jnt_margin = f; f += nj;
+  v->dof_armature = f; f += nv;
+  v->dof_damping = f; f += nv;
+  v->dof_invweight0 = f; f += nv;
+  v->geom_pos = f; f += 3 * ng;
+  v->geom_quat = f; f += 4 * ng;
+  v->geom_size = f; f += 3 * ng;
+  v->pair_mu = f; f += np;
+  v->pair_margin = f; f += np;
+  v->pair_solref = f; f += 2 * np;
+  v->pair_solimp = f; f += 5 * np;
+  v->act_gear = f; f += nu;
+  v->act_ctrlrange = f; f += 2 * nu;
+  v->n_f64 = (int)(f - fb);
+  return 0;
+}
+
+/* Per-environment persistent state (one per env; SoA in the HIP engine, AoS in the oracle):
+ *   qpos[nq], qvel[nv]                 generalized state (quaternion normalised by kinematics, as mj 2.1.0 does)
+ *   torso_xy_stale[2]                  torso xpos[:2] left by the last forward pass (reference <env>.py:22 reads it
+ *                                      BEFORE do_simulation, i.e. it lags qpos by one RK stage)
+ *   target[2], step_count, episode     task state
+ */
+
+#endif /* SGRL_MODEL_H */

@@ -1,0 +1,54 @@
+"""Pack a compiled `mjcf.Model` + `EnvSpec` into the (int32, float64) blobs of include/sgrl_model.h."""
+import numpy as np
+
+from . import mjcf
+from .env_spec import env_spec_for
+
+# must match the enums in include/sgrl_model.h
+NHDR = 24
+NFHDR = 16
+(H_MAGIC, H_NBODY, H_NJNT, H_NQ, H_NV, H_NU, H_NGEOM, H_NPAIR, H_INTEGRATOR, H_FRAME_SKIP, H_DONE_RULE,
+ H_TARGET_V2, H_RESET_VEL_NORMAL, H_NHEIGHT_BODIES, H_HEIGHT_BODY0, H_HEIGHT_BODY1, H_MAX_ROWS,
+ H_PGS_ITERS) = range(18)
+(F_TIMESTEP, F_GRAV_X, F_GRAV_Y, F_GRAV_Z, F_HEIGHT_LO, F_HEIGHT_HI, F_ANG_LIMIT, F_ALIVE_BONUS,
+ F_HEADING_WEIGHT, F_CTRL_COST, F_RESET_POS_NOISE, F_RESET_VEL_NOISE, F_PGS_TOL) = range(13)
+
+DEFAULT_MAX_ROWS = 64
+DEFAULT_PGS_ITERS = 300
+DEFAULT_PGS_TOL = 1e-10
+
+
+def pack_model(model, spec=None, env_name=None, max_rows=DEFAULT_MAX_ROWS, pgs_iters=DEFAULT_PGS_ITERS,
+               pgs_tol=DEFAULT_PGS_TOL):
+    """Return (ib int32[...], fb float64[...])."""
+    if spec is None:
+        spec = env_spec_for(env_name or model.name)
+    hdr = np.zeros(NHDR, dtype=np.int32)
+    hdr[H_MAGIC] = mjcf.MAGIC
+    hdr[H_NBODY], hdr[H_NJNT], hdr[H_NQ], hdr[H_NV] = model.nbody, model.njnt, model.nq, model.nv
+    hdr[H_NU], hdr[H_NGEOM], hdr[H_NPAIR] = model.nu, model.ngeom, model.npair
+    hdr[H_INTEGRATOR] = model.integrator
+    hdr[H_FRAME_SKIP] = spec.frame_skip
+    hdr[H_DONE_RULE] = spec.done_rule
+    hdr[H_TARGET_V2] = 1 if spec.target_v2 else 0
+    hdr[H_RESET_VEL_NORMAL] = 1 if spec.reset_vel_normal else 0
+    hb = [model.body_names.index(n) for n in spec.height_bodies if n in model.body_names]
+    hdr[H_NHEIGHT_BODIES] = len(hb)
+    for i, b in enumerate(hb[:2]):
+        hdr[H_HEIGHT_BODY0 + i] = b
+    hdr[H_MAX_ROWS] = max_rows
+    hdr[H_PGS_ITERS] = pgs_iters
+    ints = [hdr]
+    for k in mjcf.Model.INT_FIELDS:
+        ints.append(np.asarray(getattr(model, k), dtype=np.int32).ravel())
+    fh = np.zeros(NFHDR, dtype=np.float64)
+    fh[F_TIMESTEP] = model.timestep
+    fh[F_GRAV_X:F_GRAV_Z + 1] = model.gravity
+    fh[F_HEIGHT_LO], fh[F_HEIGHT_HI], fh[F_ANG_LIMIT] = spec.height_lo, spec.height_hi, spec.ang_limit
+    fh[F_ALIVE_BONUS], fh[F_HEADING_WEIGHT], fh[F_CTRL_COST] = spec.alive_bonus, spec.heading_weight, spec.ctrl_cost
+    fh[F_RESET_POS_NOISE], fh[F_RESET_VEL_NOISE] = spec.reset_pos_noise, spec.reset_vel_noise
+    fh[F_PGS_TOL] = pgs_tol
+    fls = [fh]
+    for k in mjcf.Model.F64_FIELDS:
+        fls.append(np.asarray(getattr(model, k), dtype=np.float64).ravel())
+    return np.ascontiguousarray(np.concatenate(ints)), np.ascontiguousarray(np.concatenate(fls))
