@@ -1,0 +1,337 @@
+"""Physical known-answer tests for the CPU oracle's rigid-body step (oracle/physics.c).
+
+The reference's physics is MuJoCo 2.1.0 (un-vendored, absent here): parity with it is UNPINNED.  These tests pin
+the restatement to physics instead: mass matrix vs an independent Jacobian formulation, free-fall, conservation
+laws, resting-contact force balance against the closed-form soft-constraint law, symmetry and frame invariance."""
+import numpy as np
+import pytest
+
+from helpers import oracle_model, WALKERS
+from oracle import physics_ref
+from sgrl_amd import mjcf, model_pack
+from sgrl_amd.env_spec import env_spec_for
+
+CHAIN_XML = """<mujoco><compiler angle="degree" coordinate="local" inertiafromgeom="true"/>
+<default><joint limited="true" armature="0" damping="0"/><geom contype="1" conaffinity="0" density="800"/></default>
+<option integrator="RK4" timestep="0.002" gravity="{g}"/>
+<worldbody><geom type="plane" size="5 5 1" conaffinity="1" pos="0 0 -50"/>
+ <body name="torso" pos="0 0 2"><joint name="root" type="free"/><geom type="capsule" fromto="0 0 0.2 0 0 -0.2" size="0.06"/>
+  <body name="l_thigh" pos="0 0.1 -0.2">
+   <joint name="l_thigh_joint_x" axis="1 0 0" range="-170 170"/><joint name="l_thigh_joint_y" axis="0 -1 0" range="-170 170"/>
+   <joint name="l_thigh_joint_z" axis="0 0 1" range="-170 170"/>
+   <geom type="capsule" fromto="0 0 0 0.05 0 -0.4" size="0.05"/>
+   <body name="l_shin" pos="0.05 0 -0.4" quat="0.98 0.1 0.05 0.1">
+    <joint name="l_shin_joint_x" axis="1 0 0" range="-170 170"/><joint name="l_shin_joint_y" axis="2 1 1" range="-170 170"/>
+    <joint name="l_shin_joint_z" axis="0 0 1" range="-170 170" pos="0 0.02 0.01"/>
+    <geom type="capsule" pos="0 0 -0.2" size="0.04 0.15" axisangle="0 1 0 20"/><geom type="sphere" pos="0.1 0 -0.4" size="0.06"/>
+   </body></body>
+  <body name="r_foot" pos="0 -0.1 -0.2">
+   <joint name="r_foot_joint_x" axis="1 0 0" range="-170 170"/><joint name="r_foot_joint_y" axis="0 -1 0" range="-170 170"/>
+   <joint name="r_foot_joint_z" axis="0 0 1" range="-170 170"/>
+   <geom type="capsule" fromto="0 0 0 0 -0.1 -0.3" size="0.05"/></body>
+ </body></worldbody>
+<actuator><motor joint="l_thigh_joint_x" gear="10"/><motor joint="l_thigh_joint_y" gear="10"/><motor joint="l_thigh_joint_z" gear="10"/>
+<motor joint="l_shin_joint_x" gear="10"/><motor joint="l_shin_joint_y" gear="10"/><motor joint="l_shin_joint_z" gear="10"/>
+<motor joint="r_foot_joint_x" gear="10"/><motor joint="r_foot_joint_y" gear="10"/><motor joint="r_foot_joint_z" gear="10"/></actuator></mujoco>"""
+
+BALL_XML = """<mujoco><compiler angle="degree" coordinate="local" inertiafromgeom="true"/>
+<default><geom contype="1" conaffinity="0" condim="3" friction="{mu} .1 .1"/></default>
+<option integrator="{integ}" timestep="0.002"/>
+<worldbody><geom type="plane" size="5 5 1" conaffinity="1"/>
+ <body name="torso" pos="0 0 0.3"><joint name="root" type="free"/><geom type="sphere" size="0.1" density="1000"/></body>
+</worldbody><actuator/></mujoco>"""
+
+
+def _compile(tmp_path, text, fname="3d_walker_7_full.xml", **kw):
+    p = tmp_path / fname
+    p.write_text(text)
+    m = mjcf.compile_mjcf(str(p))
+    ib, fb = model_pack.pack_model(m, spec=env_spec_for("3d_walker_7_full"), **kw)
+    return m, physics_ref.OracleModel(ib, fb)
+
+
+def _momenta(m, om, q, v):
+    """linear momentum, angular momentum about the origin from finite kinematics (independent of the oracle's RNE)."""
+    M, jacs = mjcf.mass_matrix_np(m, q)
+    xpos, xquat, _, _ = mjcf.kinematics_np(m, q)
+    P = np.zeros(3)
+    Lm = np.zeros(3)
+    for b in range(1, m.nbody):
+        jp, jr = jacs[b]
+        r = mjcf.quat_to_mat(xquat[b])
+        com = xpos[b] + r @ m.body_ipos[b]
+        ib = m.body_inertia[b]
+        inert = r @ np.array([[ib[0], ib[3], ib[4]], [ib[3], ib[1], ib[5]], [ib[4], ib[5], ib[2]]]) @ r.T
+        vc = jp @ v
+        w = jr @ v
+        P += m.body_mass[b] * vc
+        Lm += np.cross(com, m.body_mass[b] * vc) + inert @ w
+    return P, Lm
+
+
+@pytest.mark.parametrize("name", ["3d_walker_7_full", "3d_hopper_5_full", "3d_humanoid_9_full", "3d_cheetah_14_full"])
+def test_mass_matrix_matches_jacobian_formulation(name):
+    m, om = oracle_model(name)
+    rng = np.random.RandomState(1)
+    for _ in range(3):
+        q = m.qpos0.copy()
+        q[:3] += rng.normal(size=3)
+        q[2] += 20.0
+        q[3:7] = rng.normal(size=4)
+        q[3:7] /= np.linalg.norm(q[3:7])
+        q[7:] = rng.uniform(-0.7, 0.7, size=m.nq - 7)
+        _, M, d = om.forward(q, rng.normal(size=m.nv), np.zeros(m.nu))
+        Mj, _ = mjcf.mass_matrix_np(m, d["qpos"])
+        assert np.abs(M - Mj).max() < 1e-11 * np.abs(Mj).max()
+        assert np.allclose(M, M.T) and np.linalg.eigvalsh(M).min() > 0
+
+
+def test_capsule_mass_modes():
+    # documented [3P-knowledge]: closed-source line used pi (r^2 l + r^3); gym's Hopper torso mass 3.5343 under it
+    assert abs(1000 * mjcf.capsule_volume(0.05, 0.2, "mujoco210") - 3.53429174) < 1e-6
+    assert abs(1000 * mjcf.capsule_volume(0.05, 0.2, "exact") - 3.66519143) < 1e-6
+
+
+def test_free_fall_of_the_centre_of_mass(tmp_path):
+    m, om = _compile(tmp_path, CHAIN_XML.format(g="0 0 -9.81"))
+    rng = np.random.RandomState(2)
+    q = m.qpos0.copy()
+    q[7:] = rng.uniform(-0.5, 0.5, size=m.nq - 7)
+    v = rng.normal(size=m.nv) * 0.5
+    mass = m.body_mass.sum()
+
+    def com(qq):
+        xpos, xquat, _, _ = mjcf.kinematics_np(m, qq)
+        return sum(m.body_mass[b] * (xpos[b] + mjcf.quat_to_mat(xquat[b]) @ m.body_ipos[b]) for b in range(1, m.nbody)) / mass
+    P0, _ = _momenta(m, om, q, v)
+    c0 = com(q)
+    n = 250
+    q1, v1, _ = om.mj_step(q, v, np.zeros(m.nu), n)
+    t = n * m.timestep
+    expect = c0 + P0 / mass * t + 0.5 * np.array([0, 0, -9.81]) * t * t
+    # the quaternion update with an averaged angular velocity (mj_integratePos inside RK4) is 2nd order in h:
+    # measured error 3.7e-8 at h=0.002, shrinking 4x per halving of h
+    np.testing.assert_allclose(com(q1), expect, atol=1e-7)
+
+
+def test_momentum_and_energy_conservation_in_zero_gravity(tmp_path):
+    """Conserved quantities drift only by the integrator's truncation error, which vanishes as h^4 (RK4)."""
+    errs = []
+    for dt, n in ((0.002, 200), (0.001, 400), (0.0005, 800)):
+        m, om = _compile(tmp_path, CHAIN_XML.format(g="0 0 0").replace('timestep="0.002"', 'timestep="%g"' % dt))
+        rng = np.random.RandomState(3)
+        q = m.qpos0.copy()
+        q[7:] = rng.uniform(-0.3, 0.3, size=m.nq - 7)
+        v = rng.normal(size=m.nv)
+        P0, L0 = _momenta(m, om, q, v)
+        ke0, _ = om.energy(q, v)
+        q1, v1, _ = om.mj_step(q, v, np.zeros(m.nu), n)
+        P1, L1 = _momenta(m, om, q1, v1)
+        ke1, _ = om.energy(q1, v1)
+        errs.append((np.abs(P1 - P0).max(), np.abs(L1 - L0).max(), abs(ke1 - ke0) / ke0))
+        assert np.abs(q1[7:] - q[7:]).max() > 0.2  # it actually moved
+    errs = np.array(errs)
+    assert (errs[2] < [3e-5, 5e-5, 2e-6]).all(), errs
+    assert (errs[0] / errs[1] > 10).all() and (errs[1] / errs[2] > 10).all(), errs  # ~16x per halving
+
+
+def test_energy_conservation_under_gravity(tmp_path):
+    m, om = _compile(tmp_path, CHAIN_XML.format(g="0 0 -9.81"))
+    rng = np.random.RandomState(4)
+    q = m.qpos0.copy()
+    q[7:] = rng.uniform(-0.3, 0.3, size=m.nq - 7)
+    v = rng.normal(size=m.nv)
+    e0 = sum(om.energy(q, v))
+    q1, v1, _ = om.mj_step(q, v, np.zeros(m.nu), 300)
+    e1 = sum(om.energy(q1, v1))
+    assert abs(e1 - e0) < 5e-4 * abs(om.energy(q, v)[0])  # RK4 truncation at h=0.002 with ~1 rad/s joint rates
+
+
+def test_limp_body_in_free_fall_has_no_joint_acceleration(tmp_path):
+    m, om = _compile(tmp_path, CHAIN_XML.format(g="0 0 -9.81"))
+    q = m.qpos0.copy()
+    q[7:] = 0.3
+    qacc, _, d = om.forward(q, np.zeros(m.nv), np.zeros(m.nu))
+    assert d["nrow"] == 0
+    np.testing.assert_allclose(qacc[:3], [0, 0, -9.81], atol=1e-10)
+    np.testing.assert_allclose(qacc[3:], 0, atol=1e-9)
+
+
+def test_actuator_gear_and_ctrl_clamp(tmp_path):
+    m, om = _compile(tmp_path, CHAIN_XML.format(g="0 0 0"))
+    q = m.qpos0.copy()
+    c = np.zeros(m.nu)
+    c[4] = 0.5
+    a1, M, _ = om.forward(q, np.zeros(m.nv), c)
+    tau = np.zeros(m.nv)
+    tau[m.act_dof[4]] = 10 * 0.5
+    np.testing.assert_allclose(M @ a1, tau, atol=1e-9)
+    # no ctrllimited in this file -> unclamped
+    c[4] = 3.0
+    a3, _, _ = om.forward(q, np.zeros(m.nv), c)
+    np.testing.assert_allclose(a3, 6 * a1, atol=1e-9)
+    # shipped walkers clamp to [-1, 1]
+    mw, ow = oracle_model("3d_walker_7_full")
+    q = mw.qpos0.copy()
+    q[2] += 5
+    cw = np.zeros(mw.nu)
+    cw[1] = 1.0
+    b1, _, _ = ow.forward(q, np.zeros(mw.nv), cw)
+    cw[1] = 7.0
+    b7, _, _ = ow.forward(q, np.zeros(mw.nv), cw)
+    np.testing.assert_allclose(b1, b7, atol=1e-12)
+
+
+@pytest.mark.parametrize("mu,integ", [(0.7, "RK4"), (1.0, "Euler")])
+def test_resting_sphere_force_balance_and_penetration(tmp_path, mu, integ):
+    m, om = _compile(tmp_path, BALL_XML.format(mu=mu, integ=integ))
+    q = m.qpos0.copy()
+    v = np.zeros(m.nv)
+    q, v, _ = om.mj_step(q, v, np.zeros(0), 1500)
+    assert np.abs(v).max() < 1e-7
+    mass = m.body_mass[1]
+    # closed form from the soft-constraint law at rest: f_i = K*imp*|r| / Rpy for each of the 4 pyramid edges, sum = m g
+    solref, solimp = (0.02, 1.0), (0.9, 0.95, 0.001, 0.5, 2.0)
+    K = 1.0 / (solimp[1] ** 2 * solref[0] ** 2 * solref[1] ** 2)
+
+    def imp_of(r):
+        x = abs(r) / solimp[2]
+        if x >= 1:
+            return solimp[1]
+        y = x ** 2 / 0.5 if x <= 0.5 else 1 - (1 - x) ** 2 / 0.5
+        return solimp[0] + y * (solimp[1] - solimp[0])
+    pen = 0.1 - q[2]
+    assert pen > 0
+    imp = imp_of(pen)
+    tran = 1.0 / mass
+    Rpy = 2 * mu * mu * (1 - imp) / imp * tran * (1 + mu * mu)
+    total = 4 * K * imp * pen / Rpy
+    assert abs(total - mass * 9.81) < 1e-6 * mass * 9.81
+    assert abs(m.body_invweight0[1, 0] - tran) < 1e-12
+    # and the forward pass at that state reports zero acceleration
+    a, _, d = om.forward(q, v, np.zeros(0))
+    assert d["ncon"] == 1 and d["nrow"] == 4
+    assert np.abs(a).max() < 1e-6
+
+
+def test_sliding_sphere_decelerates_with_coulomb_friction(tmp_path):
+    mu = 0.5
+    m, om = _compile(tmp_path, BALL_XML.format(mu=mu, integ="RK4"))
+    q = m.qpos0.copy()
+    v = np.zeros(m.nv)
+    q, v, _ = om.mj_step(q, v, np.zeros(0), 1500)
+    v = np.zeros(m.nv)
+    v[0] = 2.0   # slide along +x (pyramid edge direction -x/+x), no spin yet
+    a, _, _ = om.forward(q, v, np.zeros(0))
+    # fast sliding saturates the pyramid: only the edge opposing the motion carries force, so the contact force is
+    # f*(n - mu*t): tangential deceleration = mu * (vertical acceleration + g), exactly
+    assert a[0] < 0 and a[2] > -9.81
+    assert abs(abs(a[0]) - mu * (a[2] + 9.81)) < 1e-8 * abs(a[0])
+    assert abs(a[1]) < 1e-9
+    # slow sliding stays inside the cone
+    v[0] = 1e-4
+    a, _, _ = om.forward(q, v, np.zeros(0))
+    assert abs(a[0]) < mu * (a[2] + 9.81)
+
+
+def test_left_right_symmetry_of_the_walker():
+    m, om = oracle_model("3d_walker_7_full")
+    q = m.qpos0.copy()
+    q[2] += 3.0
+    # right leg = limbs 1..3 (dofs 6..14), left leg = limbs 4..6 (dofs 15..23); mirrored axes make equal angles mirror poses
+    ang = np.array([0.1, 0.4, -0.2, 0.01, -0.5, 0.0, 0.0, 0.2, -0.1])
+    q[7:16] = ang
+    q[16:25] = ang
+    v = np.zeros(m.nv)
+    c = np.zeros(m.nu)
+    c[:9] = [0.3, -0.2, 0.1, 0, 0.5, 0, 0, -0.4, 0.2]
+    c[9:] = c[:9]
+    a, _, _ = om.forward(q, v, c)
+    np.testing.assert_allclose(a[6:15], a[15:24], atol=1e-7)
+    assert abs(a[1]) < 1e-7 and abs(a[3]) < 1e-7 and abs(a[5]) < 1e-7  # (PGS tolerance) no lateral / roll / yaw acceleration
+
+
+def test_yaw_invariance_of_joint_accelerations():
+    m, om = oracle_model("3d_walker_5_foot")
+    rng = np.random.RandomState(7)
+    q = m.qpos0.copy()
+    q[2] = 1.25   # feet touching the floor -> contacts active
+    q[7:] = rng.uniform(-0.2, 0.2, size=m.nq - 7)
+    v = rng.normal(size=m.nv) * 0.3
+    c = rng.uniform(-1, 1, size=m.nu)
+    a0, _, d0 = om.forward(q, v, c)
+    assert d0["ncon"] > 0
+    th = 0.83
+    rz = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+    q2, v2 = q.copy(), v.copy()
+    q2[:3] = rz @ q[:3]
+    q2[3:7] = mjcf.quat_mul(np.array([np.cos(th / 2), 0, 0, np.sin(th / 2)]), q[3:7])
+    v2[:3] = rz @ v[:3]
+    a1, _, d1 = om.forward(q2, v2, c)
+    assert d1["ncon"] == d0["ncon"]
+    # hinge and body-frame angular accelerations are frame independent; linear acceleration rotates.
+    # (tolerance: the 4-sided friction pyramid is aligned with the capsule axis, which co-rotates)
+    np.testing.assert_allclose(a1[3:], a0[3:], atol=1e-6)
+    np.testing.assert_allclose(a1[:3], rz @ a0[:3], atol=1e-6)
+
+
+def test_joint_limit_pushes_back():
+    m, om = oracle_model("3d_walker_7_full")
+    q = m.qpos0.copy()
+    q[2] += 3
+    j = m.joint_names.index("right_thigh_joint_y")
+    qa, d = m.jnt_qposadr[j], m.jnt_dofadr[j]
+    q[qa] = m.jnt_range[j, 1] + 0.05
+    # also pull the (always violated at q=0) knee joints inside their range so only this limit is active
+    for jn in ("right_shin_joint_y", "left_shin_joint_y"):
+        jj = m.joint_names.index(jn)
+        q[m.jnt_qposadr[jj]] = -0.5
+    a, _, info = om.forward(q, np.zeros(m.nv), np.zeros(m.nu))
+    assert info["nrow"] == 1
+    assert a[d] < -1.0
+    q[qa] = m.jnt_range[j, 0] - 0.05
+    a, _, info = om.forward(q, np.zeros(m.nv), np.zeros(m.nu))
+    assert info["nrow"] == 1 and a[d] > 1.0
+
+
+def test_pgs_reaches_the_dual_optimum():
+    """KKT check of the converged solve via a long run: qacc from the default tolerance equals a 20000-sweep solve."""
+    m, om = oracle_model("3d_walker_7_full")
+    m2, oref = oracle_model("3d_walker_7_full", pgs_iters=20000, pgs_tol=0.0, max_rows=320)
+    env = physics_ref.OracleEnv(om, seed=3)
+    env.reset()
+    rng = np.random.RandomState(0)
+    worst = 0
+    for t in range(120):
+        a = rng.uniform(-1, 1, size=3 * om.L)
+        if t % 6 == 0:
+            x1, _, d1 = om.forward(env.qpos, env.qvel, a[3:])
+            x2, _, d2 = oref.forward(env.qpos, env.qvel, a[3:])
+            worst = max(worst, np.abs(x1 - x2).max() / (np.abs(x2).max() + 1e-9))
+        env.step(a)
+    assert worst < 5e-9
+
+
+def test_random_rollouts_stay_finite_and_terminate():
+    for name in WALKERS + ["3d_hopper_3_shin", "3d_humanoid_9_full", "3d_cheetah_14_full"]:
+        m, om = oracle_model(name)
+        env = physics_ref.OracleEnv(om, seed=11, env_id=1, max_episode_steps=1000)
+        env.reset()
+        rng = np.random.RandomState(5)
+        dones = 0
+        for t in range(150):
+            obs, r, done, info = env.step(rng.uniform(-1, 1, size=3 * om.L))
+            assert np.isfinite(obs).all() and np.isfinite(r), name
+            assert info["overflow"] == 0, name
+            dones += done
+        assert dones >= 1, name  # random actions make every morphology fall within 150 steps
+
+
+def test_time_limit_truncation():
+    m, om = oracle_model("3d_walker_7_full")
+    env = physics_ref.OracleEnv(om, seed=1, max_episode_steps=3)
+    env.reset()
+    z = np.zeros(3 * om.L)
+    flags = [env.step(z)[2:] for _ in range(3)]
+    assert [f[0] for f in flags] == [False, False, True]
+    assert flags[2][1]["TimeLimit.truncated"]
