@@ -21,6 +21,7 @@
 #endif
 
 #define SGRL_MAGIC 0x5347524C
+#define SGRL_MAXDEPTH 8
 
 /* ---- integer header -------------------------------------------------------------------------- */
 enum {
@@ -53,6 +54,7 @@ enum {
   SGRL_F_ALIVE_BONUS, SGRL_F_HEADING_WEIGHT, SGRL_F_CTRL_COST,
   SGRL_F_RESET_POS_NOISE, SGRL_F_RESET_VEL_NOISE,
   SGRL_F_PGS_TOL,    /* stop when max_i |(A_ii+R_i) df_i| < tol * (1 + max_i |b_i|) over one sweep */
+  SGRL_F_TOTAL_MASS, /* sum of body masses (derived) */
   SGRL_NFHDR = 16
 };
 
@@ -70,6 +72,12 @@ typedef struct SgrlModelView {
   const int32_t *geom_type, *geom_body;
   const int32_t *pair_g1, *pair_g2, *pair_condim;
   const int32_t *act_dof, *act_slot;
+  /* derived by the packer (not part of the compiled asset): */
+  const int32_t *body_depth;   /* [nbody] number of bodies on the path torso..b (torso = 1) */
+  const int32_t *body_path;    /* [nbody*8] path[0] = 1 (torso) ... path[depth-1] = b, padded with -1 */
+  const int32_t *body_subend;  /* [nbody] bodies are in pre-order: subtree(b) = [b, subend[b]) */
+  const int32_t *body_dofmask; /* [nbody*2] 64-bit mask (lo, hi) of the dofs that move body b */
+  const int32_t *dof_act;      /* [nv] actuator driving this dof or -1 */
   /* float tables */
   const double *qpos0;
   const double *body_pos, *body_quat, *body_ipos, *body_inertia, *body_mass, *body_invweight0;
@@ -111,6 +119,11 @@ SGRL_HD int sgrl_model_view(const int32_t* ib, const double* fb, SgrlModelView* 
   v->pair_condim = p; p += np;
   v->act_dof = p; p += nu;
   v->act_slot = p; p += nu;
+  v->body_depth = p; p += nb;
+  v->body_path = p; p += 8 * nb;
+  v->body_subend = p; p += nb;
+  v->body_dofmask = p; p += 2 * nb;
+  v->dof_act = p; p += nv;
   v->n_int = (int)(p - ib);
   const double* f = fb + SGRL_NFHDR;
   v->qpos0 = f; f += nq;

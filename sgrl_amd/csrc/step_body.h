@@ -1,0 +1,1084 @@
+// step_body.h -- the batched rollout engine's per-environment step, written against a tiny
+// wavefront-execution interface `W` (see wave_hip.h for the gfx950 implementation).
+//
+// One environment is advanced by ONE 64-lane wavefront; all per-environment working data lives in
+// an LDS slab `S` (doubles) + `I` (ints).  The computation replaces, per environment,
+//   ModularEnv.step / do_simulation(a, 4) / _get_obs / reset_model
+//   (reference src/environments/3d_walker_7_full.py:15-164 and family variants) and the worker-side
+//   auto-reset of reference src/subproc_vec_env.py:12-15,
+// i.e. 4 x mj_step (RK4 or semi-implicit Euler) of MuJoCo-style articulated rigid-body dynamics:
+// kinematics -> CRBA mass matrix -> Cholesky -> RNE bias -> collision -> soft-constraint rows ->
+// projected Gauss-Seidel -> integrate, then the 41-float-per-limb observation scatter, reward,
+// termination and counter-RNG reset.
+//
+// Parallel decomposition (lane = body | dof | contact pair | constraint row, depending on phase):
+//   kinematics / velocities  : lane b walks its own root->b chain (no barriers inside)
+//   composite inertias       : lane b sums its pre-order-contiguous subtree
+//   mass matrix              : lane i fills row i along its dof-ancestor chain
+//   Cholesky                 : left-looking, lane i owns row i, one barrier per column
+//   half-solves Y = L^-1 J'  : lane r owns constraint row r (+ one extra row for the smooth force)
+//   PGS                      : lane d owns v[d] = (Y' f)[d]; row residual = wave reduction
+//   observation              : lane per output float, coalesced store
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/sgrl_model.h"
+
+#ifdef __HIPCC__
+#define SGRL_DEV __device__ __forceinline__
+#else
+#define SGRL_DEV inline
+#endif
+
+namespace sgrl {
+
+constexpr double kMinVal = 1e-15;
+constexpr double kMinImp = 0.0001;
+constexpr double kMaxImp = 0.9999;
+constexpr double kPi = 3.14159265358979323846;
+
+// ------------------------------------------------------------------------------------------------
+// LDS layout (offsets in doubles for S, in ints for I)
+struct Layout {
+  int nb, nj, nq, nv, nu, np, ncon, maxrows, ld, ldy;
+  // S
+  int qpos, qvel, q0, v0, xv, fq, dvacc, daacc, ctrl, act;
+  int xpos, xquat, xmat, xipos, xanchor, xaxis;
+  int cinert, crb, cdof, cfrc;
+  int L, dinv, qfs, ys, xtmp, qacc, vpgs;
+  int con_pos, con_frame, con_dist;
+  int Y, eR, earef, eb, ef, ediag;
+  int misc;  // 16 scalars
+  int Mfull; // Euler only: copy of M (lower triangle incl. diag)
+  int s_total;
+  // I
+  int con_valid, row_kind, row_src, row_sub, icnt;
+  int i_total;
+};
+
+SGRL_HD void make_layout(const int32_t* hdr, Layout* o) {
+  const int nb = hdr[SGRL_H_NBODY], nj = hdr[SGRL_H_NJNT], nq = hdr[SGRL_H_NQ], nv = hdr[SGRL_H_NV];
+  const int nu = hdr[SGRL_H_NU], np = hdr[SGRL_H_NPAIR];
+  o->nb = nb; o->nj = nj; o->nq = nq; o->nv = nv; o->nu = nu; o->np = np;
+  o->ncon = 2 * np;
+  o->maxrows = hdr[SGRL_H_MAX_ROWS];
+  o->ld = nv | 1;
+  o->ldy = nv | 1;
+  int p = 0;
+  o->qpos = p; p += nq; o->qvel = p; p += nv; o->q0 = p; p += nq; o->v0 = p; p += nv;
+  o->xv = p; p += nv; o->fq = p; p += nv; o->dvacc = p; p += nv; o->daacc = p; p += nv;
+  o->ctrl = p; p += nu + 1; o->act = p; p += 3 * (nb - 1);
+  o->xpos = p; p += 3 * nb; o->xquat = p; p += 4 * nb; o->xmat = p; p += 9 * nb; o->xipos = p; p += 3 * nb;
+  o->xanchor = p; p += 3 * nj; o->xaxis = p; p += 3 * nj;
+  o->cinert = p; p += 10 * nb; o->crb = p; p += 10 * nb; o->cdof = p; p += 6 * nv; o->cfrc = p; p += 6 * nb;
+  o->L = p; p += nv * o->ld; o->dinv = p; p += nv;
+  o->qfs = p; p += nv; o->ys = p; p += nv; o->xtmp = p; p += nv; o->qacc = p; p += nv; o->vpgs = p; p += nv;
+  o->con_pos = p; p += 3 * o->ncon; o->con_frame = p; p += 9 * o->ncon; o->con_dist = p; p += o->ncon;
+  o->Y = p; p += (o->maxrows + 1) * o->ldy;
+  o->eR = p; p += o->maxrows; o->earef = p; p += o->maxrows; o->eb = p; p += o->maxrows;
+  o->ef = p; p += o->maxrows; o->ediag = p; p += o->maxrows;
+  o->misc = p; p += 16;
+  o->Mfull = p;
+  if (hdr[SGRL_H_INTEGRATOR] == 0) p += nv * o->ld;
+  o->s_total = p;
+  int q = 0;
+  o->con_valid = q; q += o->ncon;
+  o->row_kind = q; q += o->maxrows; o->row_src = q; q += o->maxrows; o->row_sub = q; q += o->maxrows;
+  o->icnt = q; q += 8;
+  o->i_total = q;
+}
+
+SGRL_HD int layout_bytes(const Layout* o) { return o->s_total * 8 + ((o->i_total + 1) & ~1) * 4; }
+
+// misc slots
+enum { MS_COM = 0, /* 3 */ MS_REWARD = 4, MS_DIST = 5, MS_PREQUAT = 6 /* 4 */, MS_PREPOS = 10 /* 2 */ };
+// icnt slots
+enum { IC_NROW = 0, IC_NROW_WANTED = 1, IC_OVERFLOW = 2, IC_DONE = 3, IC_TRUNC = 4 };
+enum { ROW_LIMIT_LO = 0, ROW_LIMIT_HI = 1, ROW_CON1 = 2, ROW_PYR = 3 };
+
+// ------------------------------------------------------------------------------------------------
+// small vector helpers (register arrays with static indexing)
+SGRL_DEV void cross3(double* r, const double* a, const double* b) {
+  const double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+SGRL_DEV double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+SGRL_DEV double dot6(const double* a, const double* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+}
+SGRL_DEV void quat_mul(double* r, const double* a, const double* b) {
+  const double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  const double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  const double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  const double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+SGRL_DEV void quat_normalize(double* q) {
+  const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < kMinVal) { q[0] = 1; q[1] = 0; q[2] = 0; q[3] = 0; return; }
+  const double s = 1.0 / n;
+  q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s;
+}
+SGRL_DEV void quat2mat(double* m, const double* q) {
+  const double q00 = q[0] * q[0], q11 = q[1] * q[1], q22 = q[2] * q[2], q33 = q[3] * q[3];
+  m[0] = q00 + q11 - q22 - q33; m[4] = q00 - q11 + q22 - q33; m[8] = q00 - q11 - q22 + q33;
+  m[1] = 2 * (q[1] * q[2] - q[0] * q[3]); m[2] = 2 * (q[1] * q[3] + q[0] * q[2]);
+  m[3] = 2 * (q[1] * q[2] + q[0] * q[3]); m[5] = 2 * (q[2] * q[3] - q[0] * q[1]);
+  m[6] = 2 * (q[1] * q[3] - q[0] * q[2]); m[7] = 2 * (q[2] * q[3] + q[0] * q[1]);
+}
+SGRL_DEV void mat_vec(double* r, const double* m, const double* v) {
+  const double x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2];
+  const double y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2];
+  const double z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+SGRL_DEV void axisangle2quat(double* q, const double* axis, double angle) {
+  if (angle == 0.0) { q[0] = 1; q[1] = 0; q[2] = 0; q[3] = 0; return; }
+  const double s = sin(0.5 * angle);
+  q[0] = cos(0.5 * angle); q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+// spatial inertia (Ixx Iyy Izz Ixy Ixz Iyz | hx hy hz | m) times motion [w; v] -> force [tau; F]
+SGRL_DEV void inert_mul(double* f, const double* I, const double* mv) {
+  const double* w = mv; const double* v = mv + 3; const double* h = I + 6;
+  double hv[3], hw[3];
+  cross3(hv, h, v); cross3(hw, h, w);
+  f[0] = I[0] * w[0] + I[3] * w[1] + I[4] * w[2] + hv[0];
+  f[1] = I[3] * w[0] + I[1] * w[1] + I[5] * w[2] + hv[1];
+  f[2] = I[4] * w[0] + I[5] * w[1] + I[2] * w[2] + hv[2];
+  f[3] = I[9] * v[0] - hw[0]; f[4] = I[9] * v[1] - hw[1]; f[5] = I[9] * v[2] - hw[2];
+}
+SGRL_DEV void cross_motion(double* r, const double* vel, const double* m) {
+  double a[3], b[3], c[3];
+  cross3(a, vel, m); cross3(b, vel, m + 3); cross3(c, vel + 3, m);
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2];
+  r[3] = b[0] + c[0]; r[4] = b[1] + c[1]; r[5] = b[2] + c[2];
+}
+SGRL_DEV void cross_force(double* r, const double* vel, const double* f) {
+  double a[3], b[3], c[3];
+  cross3(a, vel, f); cross3(b, vel + 3, f + 3); cross3(c, vel, f + 3);
+  r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2];
+  r[3] = c[0]; r[4] = c[1]; r[5] = c[2];
+}
+SGRL_DEV void ld3(double* r, const double* p) { r[0] = p[0]; r[1] = p[1]; r[2] = p[2]; }
+SGRL_DEV void ld6(double* r, const double* p) { r[0] = p[0]; r[1] = p[1]; r[2] = p[2]; r[3] = p[3]; r[4] = p[4]; r[5] = p[5]; }
+SGRL_DEV bool dof_in_mask(const int32_t* mask2, int d) {
+  const uint32_t w = (uint32_t)(d < 32 ? mask2[0] : mask2[1]);
+  return (w >> (d & 31)) & 1u;
+}
+
+// counter RNG shared bit-for-bit with the CPU oracle (Philox4x32-10)
+SGRL_DEV double rng_uniform01(uint64_t seed, uint32_t env_id, uint32_t episode, uint32_t stream, uint32_t idx) {
+  uint32_t c0 = idx >> 2, c1 = episode, c2 = stream, c3 = (uint32_t)(seed >> 32);
+  uint32_t k0 = (uint32_t)seed, k1 = env_id;
+  for (int r = 0; r < 10; r++) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  const uint32_t lane = idx & 3u;
+  const uint32_t x = lane == 0 ? c0 : (lane == 1 ? c1 : (lane == 2 ? c2 : c3));
+  return ((double)x + 0.5) * (1.0 / 4294967296.0);
+}
+
+// ------------------------------------------------------------------------------------------------
+template <class W>
+struct Engine {
+  W& w;
+  const SgrlModelView& m;
+  const Layout& o;
+  double* S;
+  int32_t* I;
+
+  SGRL_DEV Engine(W& w_, const SgrlModelView& m_, const Layout& o_, double* S_, int32_t* I_)
+      : w(w_), m(m_), o(o_), S(S_), I(I_) {}
+
+  // ---- position stage -------------------------------------------------------------------------
+  SGRL_DEV void kinematics() {
+    // root quaternion normalised in place first (mj_kinematics of 2.1.0 [3P-knowledge]; oracle/physics.c kinematics())
+    w.lanes(1, [&](int) {
+      double q[4] = {S[o.qpos + 3], S[o.qpos + 4], S[o.qpos + 5], S[o.qpos + 6]};
+      quat_normalize(q);
+      S[o.qpos + 3] = q[0]; S[o.qpos + 4] = q[1]; S[o.qpos + 5] = q[2]; S[o.qpos + 6] = q[3];
+    });
+    w.lanes(o.nb, [&](int b) {
+      if (b == 0) {
+        for (int k = 0; k < 3; k++) S[o.xpos + k] = 0;
+        S[o.xquat] = 1; S[o.xquat + 1] = 0; S[o.xquat + 2] = 0; S[o.xquat + 3] = 0;
+        for (int k = 0; k < 9; k++) S[o.xmat + k] = (k % 4 == 0) ? 1.0 : 0.0;
+        return;
+      }
+      double pos[3], quat[4], mat[9];
+      const int depth = m.body_depth[b];
+      // level 0 = torso with the free joint
+      for (int k = 0; k < 3; k++) pos[k] = S[o.qpos + k];
+      for (int k = 0; k < 4; k++) quat[k] = S[o.qpos + 3 + k];
+      if (b == 1) {
+        for (int k = 0; k < 3; k++) { S[o.xanchor + k] = pos[k]; S[o.xaxis + k] = (k == 2) ? 1.0 : 0.0; }
+      }
+      quat_normalize(quat);
+      quat2mat(mat, quat);
+      for (int lvl = 1; lvl < depth; lvl++) {
+        const int c = m.body_path[8 * b + lvl];
+        double t[3], bp[3], bq[4], qn[4];
+        ld3(bp, m.body_pos + 3 * c);
+        mat_vec(t, mat, bp);
+        for (int k = 0; k < 3; k++) pos[k] += t[k];
+        for (int k = 0; k < 4; k++) bq[k] = m.body_quat[4 * c + k];
+        quat_mul(qn, quat, bq);
+        for (int k = 0; k < 4; k++) quat[k] = qn[k];
+        const int j0 = m.body_jntadr[c], jn = m.body_jntnum[c];
+        for (int j = j0; j < j0 + jn; j++) {
+          double r[9], jp[3], ja[3], anchor[3], axis[3], ql[4], v[3];
+          quat2mat(r, quat);
+          ld3(jp, m.jnt_pos + 3 * j); ld3(ja, m.jnt_axis + 3 * j);
+          mat_vec(t, r, jp);
+          for (int k = 0; k < 3; k++) anchor[k] = pos[k] + t[k];
+          mat_vec(axis, r, ja);
+          if (c == b) for (int k = 0; k < 3; k++) { S[o.xanchor + 3 * j + k] = anchor[k]; S[o.xaxis + 3 * j + k] = axis[k]; }
+          const int qa = m.jnt_qposadr[j];
+          axisangle2quat(ql, ja, S[o.qpos + qa] - m.qpos0[qa]);
+          quat_mul(qn, quat, ql);
+          for (int k = 0; k < 4; k++) quat[k] = qn[k];
+          quat2mat(r, quat);
+          mat_vec(v, r, jp);
+          for (int k = 0; k < 3; k++) pos[k] = anchor[k] - v[k];
+        }
+        quat_normalize(quat);
+        quat2mat(mat, quat);
+      }
+      for (int k = 0; k < 3; k++) S[o.xpos + 3 * b + k] = pos[k];
+      for (int k = 0; k < 4; k++) S[o.xquat + 4 * b + k] = quat[k];
+      for (int k = 0; k < 9; k++) S[o.xmat + 9 * b + k] = mat[k];
+      double ip[3], t[3];
+      ld3(ip, m.body_ipos + 3 * b);
+      mat_vec(t, mat, ip);
+      for (int k = 0; k < 3; k++) S[o.xipos + 3 * b + k] = pos[k] + t[k];
+    });
+  }
+
+  SGRL_DEV void com_pos() {
+    const double mt = m.fhdr[SGRL_F_TOTAL_MASS];
+    for (int k = 0; k < 3; k++) {
+      const double c = w.sum(o.nb, [&](int b) { return b == 0 ? 0.0 : m.body_mass[b] * S[o.xipos + 3 * b + k]; });
+      w.lanes(1, [&](int) { S[o.misc + MS_COM + k] = c / mt; });
+    }
+    w.lanes(o.nb > o.nv ? o.nb : o.nv, [&](int i) {
+      double com[3];
+      ld3(com, S + o.misc + MS_COM);
+      if (i >= 1 && i < o.nb) {
+        const int b = i;
+        double R[9], Wm[9], RI[9];
+        for (int k = 0; k < 9; k++) R[k] = S[o.xmat + 9 * b + k];
+        const double* ib = m.body_inertia + 6 * b;
+        const double Im[9] = {ib[0], ib[3], ib[4], ib[3], ib[1], ib[5], ib[4], ib[5], ib[2]};
+        for (int r = 0; r < 3; r++)
+          for (int c = 0; c < 3; c++) RI[3 * r + c] = R[3 * r] * Im[c] + R[3 * r + 1] * Im[3 + c] + R[3 * r + 2] * Im[6 + c];
+        for (int r = 0; r < 3; r++)
+          for (int c = 0; c < 3; c++) Wm[3 * r + c] = RI[3 * r] * R[3 * c] + RI[3 * r + 1] * R[3 * c + 1] + RI[3 * r + 2] * R[3 * c + 2];
+        double d[3];
+        const double mass = m.body_mass[b];
+        for (int k = 0; k < 3; k++) d[k] = S[o.xipos + 3 * b + k] - com[k];
+        const double dd = dot3(d, d);
+        double* ci = S + o.cinert + 10 * b;
+        ci[0] = Wm[0] + mass * (dd - d[0] * d[0]); ci[1] = Wm[4] + mass * (dd - d[1] * d[1]);
+        ci[2] = Wm[8] + mass * (dd - d[2] * d[2]);
+        ci[3] = Wm[1] - mass * d[0] * d[1]; ci[4] = Wm[2] - mass * d[0] * d[2]; ci[5] = Wm[5] - mass * d[1] * d[2];
+        ci[6] = mass * d[0]; ci[7] = mass * d[1]; ci[8] = mass * d[2]; ci[9] = mass;
+      }
+      if (i < o.nv) {
+        const int d = i, j = m.dof_jnt[d], b = m.dof_body[d];
+        double* c = S + o.cdof + 6 * d;
+        if (m.jnt_type[j] == SGRL_JNT_FREE) {
+          const int k = d - m.jnt_dofadr[j];
+          if (k < 3) {
+            c[0] = 0; c[1] = 0; c[2] = 0; c[3] = (k == 0); c[4] = (k == 1); c[5] = (k == 2);
+          } else {
+            const int kk = k - 3;
+            double ax[3] = {S[o.xmat + 9 * b + kk], S[o.xmat + 9 * b + 3 + kk], S[o.xmat + 9 * b + 6 + kk]};
+            double off[3], cr[3];
+            for (int t = 0; t < 3; t++) off[t] = com[t] - S[o.xpos + 3 * b + t];
+            cross3(cr, ax, off);
+            c[0] = ax[0]; c[1] = ax[1]; c[2] = ax[2]; c[3] = cr[0]; c[4] = cr[1]; c[5] = cr[2];
+          }
+        } else {
+          double ax[3], off[3], cr[3];
+          ld3(ax, S + o.xaxis + 3 * j);
+          for (int t = 0; t < 3; t++) off[t] = com[t] - S[o.xanchor + 3 * j + t];
+          cross3(cr, ax, off);
+          c[0] = ax[0]; c[1] = ax[1]; c[2] = ax[2]; c[3] = cr[0]; c[4] = cr[1]; c[5] = cr[2];
+        }
+      }
+    });
+  }
+
+  SGRL_DEV void crba_and_factor() {
+    const int nv = o.nv, ld = o.ld;
+    // composite inertias: subtree(b) = [b, subend[b]) in pre-order; and zero the lower triangle of M
+    w.lanes(o.nb > nv ? o.nb : nv, [&](int i) {
+      if (i >= 1 && i < o.nb) {
+        double acc[10];
+        for (int k = 0; k < 10; k++) acc[k] = 0;
+        const int e = m.body_subend[i];
+        for (int c = i; c < e; c++)
+          for (int k = 0; k < 10; k++) acc[k] += S[o.cinert + 10 * c + k];
+        for (int k = 0; k < 10; k++) S[o.crb + 10 * i + k] = acc[k];
+      }
+      if (i < nv) for (int k = 0; k <= i; k++) S[o.L + i * ld + k] = 0;
+    });
+    w.lanes(nv, [&](int i) {
+      double buf[6], ci[10], cd[6];
+      const int b = m.dof_body[i];
+      for (int k = 0; k < 10; k++) ci[k] = S[o.crb + 10 * b + k];
+      ld6(cd, S + o.cdof + 6 * i);
+      inert_mul(buf, ci, cd);
+      S[o.L + i * ld + i] = dot6(cd, buf) + m.dof_armature[i];
+      for (int j = m.dof_parent[i]; j >= 0; j = m.dof_parent[j]) {
+        double cj[6];
+        ld6(cj, S + o.cdof + 6 * j);
+        S[o.L + i * ld + j] = dot6(cj, buf);
+      }
+    });
+    if (m.hdr[SGRL_H_INTEGRATOR] == 0) {  // Euler needs M again for (M + h D)
+      w.lanes(nv, [&](int i) { for (int k = 0; k <= i; k++) S[o.Mfull + i * ld + k] = S[o.L + i * ld + k]; });
+    }
+    cholesky(o.L);
+  }
+
+  // in-place lower Cholesky of the matrix at S[base] (lower triangle, row stride ld); diag reciprocals -> dinv
+  SGRL_DEV void cholesky(int base) {
+    const int nv = o.nv, ld = o.ld;
+    // root-free column sweeps: C[i][j] = M[i][j] - sum_k C[i][k] C[j][k] / C[k][k]; one barrier per column
+    for (int j = 0; j < nv; j++) {
+      w.lanes_from(j, nv, [&](int i) {
+        double s = S[base + i * ld + j];
+        for (int k = 0; k < j; k++) s -= S[base + i * ld + k] * S[base + j * ld + k] * S[o.xtmp + k];
+        if (i == j) { if (s < kMinVal) s = kMinVal; S[o.xtmp + j] = 1.0 / s; }
+        S[base + i * ld + j] = s;
+      });
+    }
+    // L[i][j] = C[i][j] / sqrt(C[j][j])
+    w.lanes(nv, [&](int i) {
+      for (int j = 0; j < i; j++) S[base + i * ld + j] *= sqrt(S[o.xtmp + j]);
+      S[o.dinv + i] = sqrt(S[o.xtmp + i]);
+    });
+  }
+
+  // x (at S[xo], nv values) <- L^-T x, destroying nothing else; lane-parallel column sweeps
+  SGRL_DEV void solve_upper_inplace(int base, int xo) {
+    const int nv = o.nv, ld = o.ld;
+    for (int i = nv - 1; i >= 0; i--) {
+      const double xi = S[xo + i] * S[o.dinv + i];
+      w.lanes(i + 1, [&](int k) {
+        if (k == i) S[xo + i] = xi; else S[xo + k] -= S[base + i * ld + k] * xi;
+      });
+    }
+  }
+  // serial-in-lane forward substitution of one vector stored at S[xo..] (used with lane = right-hand side)
+  SGRL_DEV void solve_lower_row(int base, int xo) {
+    const int nv = o.nv, ld = o.ld;
+    for (int i = 0; i < nv; i++) {
+      double s = S[xo + i];
+      for (int k = 0; k < i; k++) s -= S[base + i * ld + k] * S[xo + k];
+      S[xo + i] = s * S[o.dinv + i];
+    }
+  }
+
+  // ---- collision ------------------------------------------------------------------------------
+  SGRL_DEV void geom_pose(int g, double* pos, double* mat) {
+    const int b = m.geom_body[g];
+    double t[3], gp[3], gq[4], gm[9], xm[9];
+    ld3(gp, m.geom_pos + 3 * g);
+    for (int k = 0; k < 9; k++) xm[k] = S[o.xmat + 9 * b + k];
+    mat_vec(t, xm, gp);
+    for (int k = 0; k < 3; k++) pos[k] = S[o.xpos + 3 * b + k] + t[k];
+    for (int k = 0; k < 4; k++) gq[k] = m.geom_quat[4 * g + k];
+    quat2mat(gm, gq);
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) mat[3 * r + c] = xm[3 * r] * gm[c] + xm[3 * r + 1] * gm[3 + c] + xm[3 * r + 2] * gm[6 + c];
+  }
+  SGRL_DEV void make_frame(double* fr) {
+    const double n2 = sqrt(dot3(fr + 3, fr + 3));
+    if (n2 < 0.5) {
+      fr[3] = 0; fr[4] = 0; fr[5] = 0;
+      if (fr[1] < 0.5 && fr[1] > -0.5) fr[4] = 1; else fr[5] = 1;
+    }
+    const double d = dot3(fr, fr + 3);
+    for (int k = 0; k < 3; k++) fr[3 + k] -= d * fr[k];
+    const double n = sqrt(dot3(fr + 3, fr + 3));
+    if (n < kMinVal) { fr[3] = 1; fr[4] = 0; fr[5] = 0; }
+    else for (int k = 0; k < 3; k++) fr[3 + k] /= n;
+    cross3(fr + 6, fr, fr + 3);
+  }
+  SGRL_DEV void put_contact(int slot, bool valid, double dist, const double* pos, const double* normal, const double* tangent) {
+    I[o.con_valid + slot] = valid ? 1 : 0;
+    if (!valid) return;
+    double fr[9];
+    for (int k = 0; k < 3; k++) { fr[k] = normal[k]; fr[3 + k] = tangent ? tangent[k] : 0.0; }
+    make_frame(fr);
+    S[o.con_dist + slot] = dist;
+    for (int k = 0; k < 3; k++) S[o.con_pos + 3 * slot + k] = pos[k];
+    for (int k = 0; k < 9; k++) S[o.con_frame + 9 * slot + k] = fr[k];
+  }
+  SGRL_DEV void plane_sphere(int slot, double margin, const double* ppos, const double* n, const double* c, double r, const double* tangent) {
+    const double d[3] = {c[0] - ppos[0], c[1] - ppos[1], c[2] - ppos[2]};
+    const double dist = dot3(d, n) - r;
+    double pos[3];
+    for (int k = 0; k < 3; k++) pos[k] = c[k] - n[k] * (r + 0.5 * dist);
+    put_contact(slot, dist < margin, dist, pos, n, tangent);
+  }
+  SGRL_DEV void collide() {
+    w.lanes(o.np, [&](int p) {
+      const int g1 = m.pair_g1[p], g2 = m.pair_g2[p];
+      double p1[3], m1[9], p2[3], m2[9];
+      geom_pose(g1, p1, m1); geom_pose(g2, p2, m2);
+      const double margin = m.pair_margin[p];
+      const int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
+      if (t1 == SGRL_GEOM_PLANE) {
+        const double n[3] = {m1[2], m1[5], m1[8]};
+        if (t2 == SGRL_GEOM_SPHERE) {
+          plane_sphere(2 * p, margin, p1, n, p2, m.geom_size[3 * g2], nullptr);
+          I[o.con_valid + 2 * p + 1] = 0;
+        } else {
+          const double ax[3] = {m2[2], m2[5], m2[8]};
+          const double h = m.geom_size[3 * g2 + 1], r = m.geom_size[3 * g2];
+          double ca[3], cb[3];
+          for (int k = 0; k < 3; k++) { ca[k] = p2[k] + ax[k] * h; cb[k] = p2[k] - ax[k] * h; }
+          plane_sphere(2 * p, margin, p1, n, ca, r, ax);
+          plane_sphere(2 * p + 1, margin, p1, n, cb, r, ax);
+        }
+      } else {
+        const double a1[3] = {m1[2], m1[5], m1[8]}, a2[3] = {m2[2], m2[5], m2[8]};
+        const double h1 = m.geom_size[3 * g1 + 1], h2 = m.geom_size[3 * g2 + 1];
+        const double r1 = m.geom_size[3 * g1], r2 = m.geom_size[3 * g2];
+        const double d[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+        const double bb = dot3(a1, a2), c = dot3(a1, d), f = dot3(a2, d);
+        const double den = 1.0 - bb * bb;
+        double s, t;
+        if (den > 1e-12) s = (bb * f - c) / den; else s = 0;
+        if (s > h1) s = h1;
+        if (s < -h1) s = -h1;
+        t = bb * s + f;
+        if (t > h2) { t = h2; s = bb * t - c; if (s > h1) s = h1; if (s < -h1) s = -h1; }
+        else if (t < -h2) { t = -h2; s = bb * t - c; if (s > h1) s = h1; if (s < -h1) s = -h1; }
+        double c1[3], nn[3];
+        for (int k = 0; k < 3; k++) { c1[k] = p1[k] + s * a1[k]; nn[k] = (p2[k] + t * a2[k]) - c1[k]; }
+        const double len = sqrt(dot3(nn, nn));
+        const double dist = len - r1 - r2;
+        if (len < kMinVal) { nn[0] = 1; nn[1] = 0; nn[2] = 0; } else for (int k = 0; k < 3; k++) nn[k] /= len;
+        double pos[3];
+        for (int k = 0; k < 3; k++) pos[k] = c1[k] + nn[k] * (r1 + 0.5 * dist);
+        put_contact(2 * p, dist < margin, dist, pos, nn, nullptr);
+        I[o.con_valid + 2 * p + 1] = 0;
+      }
+    });
+  }
+
+  // ---- velocity stage: cvel / cacc along each body's own chain, RNE bias, smooth force ------------
+  SGRL_DEV void bias_and_smooth_force() {
+    w.lanes(o.nb, [&](int b) {
+      if (b == 0) { for (int k = 0; k < 6; k++) S[o.cfrc + k] = 0; return; }
+      double cv[6] = {0, 0, 0, 0, 0, 0};
+      double ca[6] = {0, 0, 0, -m.fhdr[SGRL_F_GRAV_X], -m.fhdr[SGRL_F_GRAV_Y], -m.fhdr[SGRL_F_GRAV_Z]};
+      const int depth = m.body_depth[b];
+      for (int lvl = 0; lvl < depth; lvl++) {
+        const int c = m.body_path[8 * b + lvl];
+        const int j0 = m.body_jntadr[c], jn = m.body_jntnum[c];
+        for (int j = j0; j < j0 + jn; j++) {
+          const int d0 = m.jnt_dofadr[j];
+          if (m.jnt_type[j] == SGRL_JNT_FREE) {
+            for (int d = 0; d < 3; d++) {
+              const double qv = S[o.qvel + d0 + d];
+              for (int k = 0; k < 6; k++) cv[k] += S[o.cdof + 6 * (d0 + d) + k] * qv;
+            }
+            double cd[3][6], dd[6];
+            for (int d = 0; d < 3; d++) ld6(cd[d], S + o.cdof + 6 * (d0 + 3 + d));
+            for (int d = 0; d < 3; d++) {
+              cross_motion(dd, cv, cd[d]);
+              const double qv = S[o.qvel + d0 + 3 + d];
+              for (int k = 0; k < 6; k++) ca[k] += dd[k] * qv;
+            }
+            for (int d = 0; d < 3; d++) {
+              const double qv = S[o.qvel + d0 + 3 + d];
+              for (int k = 0; k < 6; k++) cv[k] += cd[d][k] * qv;
+            }
+          } else {
+            double cd[6], dd[6];
+            ld6(cd, S + o.cdof + 6 * d0);
+            cross_motion(dd, cv, cd);
+            const double qv = S[o.qvel + d0];
+            for (int k = 0; k < 6; k++) { ca[k] += dd[k] * qv; cv[k] += cd[k] * qv; }
+          }
+        }
+      }
+      double ci[10], f1[6], iv[6], f2[6];
+      for (int k = 0; k < 10; k++) ci[k] = S[o.cinert + 10 * b + k];
+      inert_mul(f1, ci, ca);
+      inert_mul(iv, ci, cv);
+      cross_force(f2, cv, iv);
+      for (int k = 0; k < 6; k++) S[o.cfrc + 6 * b + k] = f1[k] + f2[k];
+    });
+    w.lanes(o.nv, [&](int d) {
+      const int b = m.dof_body[d], e = m.body_subend[b];
+      double f[6] = {0, 0, 0, 0, 0, 0}, cd[6];
+      for (int c = b; c < e; c++)
+        for (int k = 0; k < 6; k++) f[k] += S[o.cfrc + 6 * c + k];
+      ld6(cd, S + o.cdof + 6 * d);
+      const double bias = dot6(cd, f);
+      const int j = m.dof_jnt[d];
+      double passive = -m.dof_damping[d] * S[o.qvel + d];
+      if (m.jnt_type[j] == SGRL_JNT_HINGE) {
+        const int qa = m.jnt_qposadr[j];
+        passive -= m.jnt_stiffness[j] * (S[o.qpos + qa] - m.qpos0[qa]);
+      }
+      double q = passive - bias;
+      const int u = m.dof_act[d];
+      if (u >= 0) {
+        double c = S[o.ctrl + u];
+        const double lo = m.act_ctrlrange[2 * u], hi = m.act_ctrlrange[2 * u + 1];
+        if (c < lo) c = lo;
+        if (c > hi) c = hi;
+        q += m.act_gear[u] * c;
+      }
+      S[o.qfs + d] = q;
+    });
+  }
+
+  // ---- constraint rows ------------------------------------------------------------------------
+  SGRL_DEV double impedance(const double* solimp, double x_raw) {
+    double dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
+    if (dmin < kMinImp) dmin = kMinImp;
+    if (dmin > kMaxImp) dmin = kMaxImp;
+    if (dmax < kMinImp) dmax = kMinImp;
+    if (dmax > kMaxImp) dmax = kMaxImp;
+    if (width < 0) width = 0;
+    if (mid < kMinImp) mid = kMinImp;
+    if (mid > kMaxImp) mid = kMaxImp;
+    if (power < 1) power = 1;
+    if (dmin == dmax || width <= kMinVal) return 0.5 * (dmin + dmax);
+    const double x = fabs(x_raw) / width;
+    if (x >= 1) return dmax;
+    if (x <= 0) return dmin;
+    double y;
+    if (power == 1) y = x;
+    else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
+    else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
+    return dmin + y * (dmax - dmin);
+  }
+  SGRL_DEV void kb(const double* solref, const double* solimp, double* K, double* B) {
+    double dmax = solimp[1];
+    if (dmax < kMinImp) dmax = kMinImp;
+    if (dmax > kMaxImp) dmax = kMaxImp;
+    double tc = solref[0];
+    const double dr = solref[1], h2 = 2 * m.fhdr[SGRL_F_TIMESTEP];
+    if (tc < h2) tc = h2;
+    *K = 1.0 / (dmax * dmax * tc * tc * dr * dr);
+    *B = 2.0 / (dmax * tc);
+  }
+
+  // row table (serial, lane 0): limits in joint order, then contacts in slot order; same cap rule as the oracle
+  SGRL_DEV void enumerate_rows() {
+    w.lanes(1, [&](int) {
+      int nrow = 0, wanted = 0;
+      const int maxrows = o.maxrows;
+      for (int j = 0; j < o.nj; j++) {
+        if (!m.jnt_limited[j]) continue;
+        const double q = S[o.qpos + m.jnt_qposadr[j]];
+        for (int side = -1; side <= 1; side += 2) {
+          const double dist = side * (m.jnt_range[2 * j + (side + 1) / 2] - q);
+          if (dist >= m.jnt_margin[j]) continue;
+          wanted++;
+          if (nrow >= maxrows) continue;
+          I[o.row_kind + nrow] = side < 0 ? ROW_LIMIT_LO : ROW_LIMIT_HI;
+          I[o.row_src + nrow] = j; I[o.row_sub + nrow] = 0;
+          nrow++;
+        }
+      }
+      for (int s = 0; s < o.ncon; s++) {
+        if (!I[o.con_valid + s]) continue;
+        const int p = s >> 1, dim = m.pair_condim[p];
+        const int nr = (dim == 1) ? 1 : 2 * (dim - 1);
+        wanted += nr;
+        if (nrow + nr > maxrows) continue;
+        for (int k = 0; k < nr; k++) {
+          I[o.row_kind + nrow] = dim == 1 ? ROW_CON1 : ROW_PYR;
+          I[o.row_src + nrow] = s; I[o.row_sub + nrow] = k;
+          nrow++;
+        }
+      }
+      I[o.icnt + IC_NROW] = nrow; I[o.icnt + IC_NROW_WANTED] = wanted;
+      if (wanted > nrow) I[o.icnt + IC_OVERFLOW] += 1;
+    });
+  }
+
+  SGRL_DEV void build_rows_and_halfsolve() {
+    const int nv = o.nv, ldy = o.ldy;
+    const int nrow = I[o.icnt + IC_NROW];
+    w.lanes(nrow + 1, [&](int r) {
+      double* Yr = S + o.Y + r * ldy;
+      if (r == nrow) {  // extra right-hand side: the smooth force
+        for (int d = 0; d < nv; d++) Yr[d] = S[o.qfs + d];
+        solve_lower_row(o.L, o.Y + r * ldy);
+        for (int d = 0; d < nv; d++) S[o.ys + d] = Yr[d];
+        return;
+      }
+      const int kind = I[o.row_kind + r], src = I[o.row_src + r], sub = I[o.row_sub + r];
+      double R, aref;
+      if (kind == ROW_LIMIT_LO || kind == ROW_LIMIT_HI) {
+        const int j = src, side = kind == ROW_LIMIT_LO ? -1 : 1, dof = m.jnt_dofadr[j];
+        for (int d = 0; d < nv; d++) Yr[d] = 0;
+        Yr[dof] = -side;
+        const double q = S[o.qpos + m.jnt_qposadr[j]];
+        const double margin = m.jnt_margin[j];
+        const double dist = side * (m.jnt_range[2 * j + (side + 1) / 2] - q);
+        double si[5], sr[2], K, B;
+        for (int k = 0; k < 5; k++) si[k] = m.jnt_solimp[5 * j + k];
+        sr[0] = m.jnt_solref[2 * j]; sr[1] = m.jnt_solref[2 * j + 1];
+        const double imp = impedance(si, dist - margin);
+        kb(sr, si, &K, &B);
+        R = (1 - imp) / imp * m.dof_invweight0[dof];
+        if (R < kMinVal) R = kMinVal;
+        aref = -B * (-side * S[o.qvel + dof]) - K * imp * (dist - margin);
+      } else {
+        const int s = src, p = s >> 1;
+        const int b1 = m.geom_body[m.pair_g1[p]], b2 = m.geom_body[m.pair_g2[p]];
+        const double margin = m.pair_margin[p], dist = S[o.con_dist + s], mu = m.pair_mu[p];
+        double fr[9], off[3], dir[3];
+        for (int k = 0; k < 9; k++) fr[k] = S[o.con_frame + 9 * s + k];
+        for (int k = 0; k < 3; k++) off[k] = S[o.con_pos + 3 * s + k] - S[o.misc + MS_COM + k];
+        if (kind == ROW_CON1) {
+          for (int k = 0; k < 3; k++) dir[k] = fr[k];
+        } else {
+          const int t = 1 + (sub >> 1);
+          const double sg = (sub & 1) ? -mu : mu;
+          for (int k = 0; k < 3; k++) dir[k] = fr[k] + sg * fr[3 * t + k];
+        }
+        const int32_t* mk1 = m.body_dofmask + 2 * b1;
+        const int32_t* mk2 = m.body_dofmask + 2 * b2;
+        double vel = 0;
+        for (int d = 0; d < nv; d++) {
+          double sgn = 0;
+          if (b2 > 0 && dof_in_mask(mk2, d)) sgn += 1.0;
+          if (b1 > 0 && dof_in_mask(mk1, d)) sgn -= 1.0;
+          double val = 0;
+          if (sgn != 0) {
+            double cd[6], v[3];
+            ld6(cd, S + o.cdof + 6 * d);
+            cross3(v, cd, off);
+            v[0] += cd[3]; v[1] += cd[4]; v[2] += cd[5];
+            val = sgn * dot3(dir, v);
+          }
+          Yr[d] = val;
+          vel += val * S[o.qvel + d];
+        }
+        double si[5], sr[2], K, B;
+        for (int k = 0; k < 5; k++) si[k] = m.pair_solimp[5 * p + k];
+        sr[0] = m.pair_solref[2 * p]; sr[1] = m.pair_solref[2 * p + 1];
+        const double imp = impedance(si, dist - margin);
+        kb(sr, si, &K, &B);
+        const double tran = m.body_invweight0[2 * b1] + m.body_invweight0[2 * b2];
+        if (kind == ROW_CON1) {
+          R = (1 - imp) / imp * tran;
+          if (R < kMinVal) R = kMinVal;
+        } else {
+          double R0 = (1 - imp) / imp * (tran + mu * mu * tran);
+          if (R0 < kMinVal) R0 = kMinVal;
+          R = 2 * mu * mu * R0;
+          if (R < kMinVal) R = kMinVal;
+        }
+        aref = -B * vel - K * imp * (dist - margin);
+      }
+      S[o.eR + r] = R; S[o.earef + r] = aref;
+      solve_lower_row(o.L, o.Y + r * ldy);
+      double s2 = 0;
+      for (int d = 0; d < nv; d++) s2 += Yr[d] * Yr[d];
+      S[o.ediag + r] = s2 + R;
+      S[o.ef + r] = 0;
+    });
+    w.lanes(nrow > nv ? nrow : nv, [&](int r) {
+      if (r < nrow) {
+        const double* Yr = S + o.Y + r * ldy;
+        double s = 0;
+        for (int d = 0; d < nv; d++) s += Yr[d] * S[o.ys + d];
+        S[o.eb + r] = s - S[o.earef + r];
+      }
+      if (r < nv) S[o.vpgs + r] = 0;
+    });
+  }
+
+  SGRL_DEV void pgs_and_finish() {
+    const int nv = o.nv, ldy = o.ldy;
+    const int nrow = I[o.icnt + IC_NROW];
+    if (nrow > 0) {
+      const int iters = m.hdr[SGRL_H_PGS_ITERS];
+      double bmax = w.maxabs(nrow, [&](int r) { return S[o.eb + r]; });
+      const double thresh = m.fhdr[SGRL_F_PGS_TOL] * (1.0 + bmax);
+      for (int it = 0; it < iters; it++) {
+        double change = 0;
+        for (int r = 0; r < nrow; r++) {
+          const double dotv = w.sum(nv, [&](int d) { return S[o.Y + r * ldy + d] * S[o.vpgs + d]; });
+          const double f = S[o.ef + r], R = S[o.eR + r], dg = S[o.ediag + r];
+          const double res = S[o.eb + r] + R * f + dotv;
+          double fn = f - res / dg;
+          if (fn < 0) fn = 0;
+          const double df = fn - f;
+          if (df != 0) {
+            w.lanes(nv, [&](int d) {
+              S[o.vpgs + d] += S[o.Y + r * ldy + d] * df;
+              if (d == 0) S[o.ef + r] = fn;
+            });
+            const double c = fabs(df) * dg;
+            if (c > change) change = c;
+          }
+        }
+        if (change < thresh) break;
+      }
+    }
+    // qacc = L^-T (ys + Y' f)
+    w.lanes(nv, [&](int d) { S[o.qacc + d] = S[o.ys + d] + (nrow > 0 ? S[o.vpgs + d] : 0.0); });
+    solve_upper_inplace(o.L, o.qacc);
+  }
+
+  SGRL_DEV void forward() {
+    kinematics();
+    com_pos();
+    crba_and_factor();
+    collide();
+    bias_and_smooth_force();
+    enumerate_rows();
+    build_rows_and_halfsolve();
+    pgs_and_finish();
+  }
+
+  // ---- integration ----------------------------------------------------------------------------
+  // S[dst..] <- S[src..] (+) h * S[vel..]
+  SGRL_DEV void integrate_pos(int dst, int src, int vel, double h) {
+    w.lanes(o.nj, [&](int j) {
+      const int qa = m.jnt_qposadr[j], d = m.jnt_dofadr[j];
+      if (m.jnt_type[j] == SGRL_JNT_FREE) {
+        for (int k = 0; k < 3; k++) S[dst + qa + k] = S[src + qa + k] + h * S[vel + d + k];
+        double ax[3] = {S[vel + d + 3], S[vel + d + 4], S[vel + d + 5]};
+        const double n = sqrt(dot3(ax, ax));
+        double ang;
+        if (n < kMinVal) { ax[0] = 1; ax[1] = 0; ax[2] = 0; ang = 0; }
+        else { ax[0] /= n; ax[1] /= n; ax[2] /= n; ang = h * n; }
+        double qr[4], qn[4], q[4] = {S[src + qa + 3], S[src + qa + 4], S[src + qa + 5], S[src + qa + 6]};
+        axisangle2quat(qr, ax, ang);
+        quat_normalize(q);
+        quat_mul(qn, q, qr);
+        for (int k = 0; k < 4; k++) S[dst + qa + 3 + k] = qn[k];
+      } else {
+        S[dst + qa] = S[src + qa] + h * S[vel + d];
+      }
+    });
+  }
+
+  SGRL_DEV void mj_step() {
+    const int nv = o.nv, nq = o.nq, ld = o.ld;
+    const double h = m.fhdr[SGRL_F_TIMESTEP];
+    forward();
+    if (m.hdr[SGRL_H_INTEGRATOR] == 1) {
+      // RK4; the kinematics left in LDS afterwards are those of the 4th stage (what _get_obs reads)
+      w.lanes(nq > nv ? nq : nv, [&](int i) {
+        if (i < nq) S[o.q0 + i] = S[o.qpos + i];
+        if (i < nv) {
+          S[o.v0 + i] = S[o.qvel + i]; S[o.xv + i] = S[o.qvel + i]; S[o.fq + i] = S[o.qacc + i];
+          S[o.dvacc + i] = (1.0 / 6) * S[o.qvel + i]; S[o.daacc + i] = (1.0 / 6) * S[o.qacc + i];
+        }
+      });
+      for (int st = 1; st < 4; st++) {
+        const double a = (st == 3) ? 1.0 : 0.5;
+        const double bw = (st == 3) ? (1.0 / 6) : (1.0 / 3);
+        integrate_pos(o.qpos, o.q0, o.xv, a * h);
+        w.lanes(nv, [&](int d) {
+          const double v = S[o.v0 + d] + a * h * S[o.fq + d];
+          S[o.qvel + d] = v; S[o.xv + d] = v;
+          S[o.dvacc + d] += bw * v;
+        });
+        forward();
+        w.lanes(nv, [&](int d) { S[o.fq + d] = S[o.qacc + d]; S[o.daacc + d] += bw * S[o.qacc + d]; });
+      }
+      integrate_pos(o.qpos, o.q0, o.dvacc, h);
+      w.lanes(nv, [&](int d) { S[o.qvel + d] = S[o.v0 + d] + h * S[o.daacc + d]; });
+    } else {
+      // semi-implicit Euler with implicit joint damping: (M + h D) a = M qacc
+      w.lanes(nv, [&](int i) {
+        double s = 0;
+        for (int j = 0; j < nv; j++) s += (j <= i ? S[o.Mfull + i * ld + j] : S[o.Mfull + j * ld + i]) * S[o.qacc + j];
+        S[o.fq + i] = s;
+      });
+      w.lanes(nv, [&](int i) { S[o.Mfull + i * ld + i] += h * m.dof_damping[i]; });
+      cholesky(o.Mfull);
+      w.lanes(1, [&](int) { solve_lower_row(o.Mfull, o.fq); });
+      solve_upper_inplace(o.Mfull, o.fq);
+      w.lanes(nv, [&](int d) { S[o.qvel + d] += h * S[o.fq + d]; });
+      integrate_pos(o.qpos, o.qpos, o.qvel, h);
+    }
+  }
+
+  // ---- observation / reward / done --------------------------------------------------------------
+  // body-origin velocities from the kinematics in LDS and S[qvel]: xvelr -> cfrc[6b..], xvelp -> cfrc[6b+3..]
+  SGRL_DEV void body_velocities() {
+    w.lanes(o.nb, [&](int b) {
+      double cv[6] = {0, 0, 0, 0, 0, 0};
+      if (b > 0) {
+        for (int d = m.body_dofadr[b] + m.body_dofnum[b] - 1; d >= 0; d = m.dof_parent[d]) {
+          const double qv = S[o.qvel + d];
+          for (int k = 0; k < 6; k++) cv[k] += S[o.cdof + 6 * d + k] * qv;
+        }
+        double off[3], t[3];
+        for (int k = 0; k < 3; k++) off[k] = S[o.xpos + 3 * b + k] - S[o.misc + MS_COM + k];
+        cross3(t, cv, off);
+        cv[3] += t[0]; cv[4] += t[1]; cv[5] += t[2];
+      }
+      for (int k = 0; k < 6; k++) S[o.cfrc + 6 * b + k] = cv[k];
+    });
+  }
+
+  SGRL_DEV double obs_element(int b, int k) const {
+    // b = body id (1..nb-1), k = 0..40; reference <env>.py:116-140
+    const double R2D = 180.0 / kPi;
+    if (k < 3) return S[o.xpos + 3 * b + k] - S[o.xpos + 3 + k];
+    if (k < 5) return 0.0;
+    if (k == 5) return -9.81;
+    if (k < 8) {
+      const double dx = S[o.misc + 12] - S[o.xpos + 3], dy = S[o.misc + 13] - S[o.xpos + 4];
+      const double dn = sqrt(dx * dx + dy * dy);
+      return (k == 6 ? dx : dy) / dn;
+    }
+    if (k == 8) return 0.0;
+    if (k < 12) { const double v = S[o.cfrc + 6 * b + 3 + (k - 9)]; return v < -10 ? -10 : (v > 10 ? 10 : v); }
+    if (k < 15) return S[o.cfrc + 6 * b + (k - 12)];
+    if (b == 1) {
+      if (k < 27) return 0.0;
+      if (k < 36) return 0.5;
+    } else {
+      const int j0 = m.body_jntadr[b];
+      if (k < 24) return S[o.xaxis + 3 * (j0 + (k - 15) / 3) + (k - 15) % 3];
+      if (k < 27) return S[o.qpos + m.jnt_qposadr[j0 + (k - 24)]];
+      if (k < 36) {
+        const int jj = (k - 27) / 3, which = (k - 27) % 3, j = j0 + jj;
+        const double lo = m.jnt_range[2 * j] * R2D, hi = m.jnt_range[2 * j + 1] * R2D;
+        if (which == 0) return (S[o.qpos + m.jnt_qposadr[j]] * R2D - lo) / (hi - lo);
+        if (which == 1) return (180.0 + lo) / 360.0;
+        return (180.0 + hi) / 360.0;
+      }
+    }
+    if (k < 40) return (m.body_limbtype[b] == (k - 36) + 1) ? 1.0 : 0.0;
+    return S[o.xpos + 3 * b + 2];
+  }
+
+  // obs from the kinematics/velocities in LDS; target must be in misc[12..13]
+  SGRL_DEV void write_obs(float* obs32, double* obs64, int obs_max_len) {
+    const int n = 41 * (o.nb - 1);
+    w.lanes(obs_max_len, [&](int i) {
+      double v = 0.0;
+      if (i < n) v = obs_element(1 + i / 41, i % 41);
+      if (obs32) obs32[i] = (float)v;
+      if (obs64) obs64[i] = v;
+    });
+  }
+
+  // reward + done (serial scalar arithmetic on lane 0).  `act` = policy-ordered action in S[o.act]
+  SGRL_DEV void reward_done() {
+    w.lanes(1, [&](int) {
+      const double* q = S + o.misc + MS_PREQUAT;
+      const double qw = q[0], x = q[1], y = q[2], z = q[3];
+      const double r00 = 1 - 2 * y * y - 2 * z * z, r10 = 2 * x * y + 2 * z * qw;
+      const double r20 = 2 * x * z - 2 * y * qw, r21 = 2 * y * z + 2 * x * qw, r22 = 1 - 2 * x * x - 2 * y * y;
+      const double heading = atan2(r10, r00);
+      const double pitch = atan2(-r20, sqrt(r21 * r21 + r22 * r22));
+      const double roll = atan2(r21, r22);
+      const double tx = S[o.misc + 12], ty = S[o.misc + 13];
+      const double pbx = S[o.misc + MS_PREPOS], pby = S[o.misc + MS_PREPOS + 1];
+      const double dist_before = sqrt((tx - pbx) * (tx - pbx) + (ty - pby) * (ty - pby));
+      const double pax = S[o.xpos + 3], pay = S[o.xpos + 4];
+      const double dist_after = sqrt((tx - pax) * (tx - pax) + (ty - pay) * (ty - pay));
+      const double dt = m.fhdr[SGRL_F_TIMESTEP] * m.hdr[SGRL_H_FRAME_SKIP];
+      double height = S[o.qpos + 2];
+      double r = (dist_before - dist_after) / dt;
+      if (m.fhdr[SGRL_F_HEADING_WEIGHT] != 0.0) r += ((pax - pbx) * cos(heading) + (pay - pby) * sin(heading)) / dt;
+      if (m.fhdr[SGRL_F_ALIVE_BONUS] != 0.0) r += m.fhdr[SGRL_F_ALIVE_BONUS];
+      double sq = 0;
+      for (int u = 0; u < o.nu; u++) sq += S[o.ctrl + u] * S[o.ctrl + u];
+      r -= m.fhdr[SGRL_F_CTRL_COST] * sq;
+      S[o.misc + MS_REWARD] = r; S[o.misc + MS_DIST] = dist_after;
+      const double lo = m.fhdr[SGRL_F_HEIGHT_LO], hi = m.fhdr[SGRL_F_HEIGHT_HI], al = m.fhdr[SGRL_F_ANG_LIMIT];
+      const int rule = m.hdr[SGRL_H_DONE_RULE];
+      bool ok;
+      if (rule == 0) {
+        ok = height > lo && height < hi && fabs(pitch) < al && fabs(roll) < al;
+      } else if (rule == 1) {
+        const double* qq = S + o.qpos + 3;
+        const double ang = 2 * atan2(sqrt(qq[1] * qq[1] + qq[2] * qq[2]), sqrt(qq[0] * qq[0] + qq[3] * qq[3]));
+        bool fin = true, small = true;
+        for (int i = 0; i < o.nq; i++) if (!isfinite(S[o.qpos + i])) fin = false;
+        for (int i = 0; i < o.nv; i++) if (!isfinite(S[o.qvel + i])) fin = false;
+        for (int i = 3; i < o.nq; i++) if (!(fabs(S[o.qpos + i]) < 100)) small = false;
+        for (int i = 0; i < o.nv; i++) if (!(fabs(S[o.qvel + i]) < 100)) small = false;
+        ok = fin && small && height > lo && fabs(ang) < al;
+      } else {
+        for (int i = 0; i < m.hdr[SGRL_H_NHEIGHT_BODIES]; i++) {
+          const double zb = S[o.xpos + 3 * m.hdr[SGRL_H_HEIGHT_BODY0 + i] + 2];
+          if (zb < height) height = zb;
+        }
+        double s2 = 0;
+        for (int i = 0; i < o.nv; i++) s2 += S[o.qvel + i] * S[o.qvel + i];
+        ok = height > lo && fabs(pitch) < al && fabs(roll) < al && s2 > 1;
+      }
+      I[o.icnt + IC_DONE] = ok ? 0 : 1;
+    });
+  }
+
+  // reset_model with the counter RNG (draw order of reference <env>.py:150-164); leaves fresh kinematics in LDS
+  SGRL_DEV void reset_state(uint64_t seed, uint32_t env_id, uint32_t episode) {
+    const int nq = o.nq, nv = o.nv;
+    const double pn = m.fhdr[SGRL_F_RESET_POS_NOISE], vn = m.fhdr[SGRL_F_RESET_VEL_NOISE];
+    const bool normal = m.hdr[SGRL_H_RESET_VEL_NORMAL] != 0;
+    w.lanes(nq > nv ? nq : nv, [&](int i) {
+      if (i < nq) {
+        double q = m.qpos0[i];
+        if (i == 3 || i == 6) {
+          const double rad = (-kPi + 2 * kPi * rng_uniform01(seed, env_id, episode, 0, 0)) / 2;
+          q = (i == 3) ? cos(rad) : sin(rad);
+        }
+        S[o.qpos + i] = q + (-pn + 2 * pn * rng_uniform01(seed, env_id, episode, 0, 1 + i));
+      }
+      if (i < nv) {
+        if (normal) {
+          const double u1 = rng_uniform01(seed, env_id, episode, 0, 1 + nq + 2 * i);
+          const double u2 = rng_uniform01(seed, env_id, episode, 0, 2 + nq + 2 * i);
+          S[o.qvel + i] = vn * sqrt(-2.0 * log(u1)) * cos(2 * kPi * u2);
+        } else {
+          S[o.qvel + i] = -vn + 2 * vn * rng_uniform01(seed, env_id, episode, 0, 1 + nq + i);
+        }
+      }
+      if (i == 0) {
+        const uint32_t base = 1 + nq + (normal ? 2 * nv : nv);
+        const double r = -kPi + 2 * kPi * rng_uniform01(seed, env_id, episode, 0, base);
+        double len = 10000.0;
+        if (m.hdr[SGRL_H_TARGET_V2]) len = 10.0 + 10.0 * rng_uniform01(seed, env_id, episode, 0, base + 1);
+        S[o.misc + 12] = cos(r) * len; S[o.misc + 13] = sin(r) * len;
+      }
+    });
+  }
+
+  // kinematics + velocities at the current S[qpos], S[qvel]  (gym set_state -> sim.forward)
+  SGRL_DEV void refresh_kinematics() {
+    kinematics();
+    com_pos();
+    body_velocities();
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Per-environment persistent record in HBM (array of records; one wave reads/writes one record contiguously):
+//   double rec[stride]: qpos[nq] | qvel[nv] | torso_xy_stale[2] | target[2]
+//   int32  cnt[4]:      step_count, episode, overflow_total, reserved
+struct StepIO {
+  double* rec;           // this env's record
+  int32_t* cnt;          // this env's counters
+  const float* action;   // [action_max_len] policy-ordered, first 3 = torso dummies
+  float* obs32;          // [obs_max_len] or null
+  double* obs64;         // [obs_max_len] or null
+  float* reward; uint8_t* done; float* dist; uint8_t* truncated;  // scalars for this env (nullable)
+  double* reward64;      // nullable
+  int obs_max_len;
+  uint64_t seed; uint32_t env_id; int max_episode_steps; int auto_reset;
+};
+
+template <class W>
+SGRL_DEV void load_state(Engine<W>& e, const StepIO& io) {
+  const Layout& o = e.o;
+  e.w.lanes(o.nq + o.nv + 4, [&](int i) {
+    const double v = io.rec[i];
+    if (i < o.nq) e.S[o.qpos + i] = v;
+    else if (i < o.nq + o.nv) e.S[o.qvel + (i - o.nq)] = v;
+    else if (i < o.nq + o.nv + 2) e.S[o.misc + MS_PREPOS + (i - o.nq - o.nv)] = v;
+    else e.S[o.misc + 12 + (i - o.nq - o.nv - 2)] = v;
+  });
+}
+template <class W>
+SGRL_DEV void store_state(Engine<W>& e, const StepIO& io, bool fresh_xy) {
+  const Layout& o = e.o;
+  e.w.lanes(o.nq + o.nv + 4, [&](int i) {
+    double v;
+    if (i < o.nq) v = e.S[o.qpos + i];
+    else if (i < o.nq + o.nv) v = e.S[o.qvel + (i - o.nq)];
+    else if (i < o.nq + o.nv + 2) v = e.S[o.xpos + 3 + (i - o.nq - o.nv)];
+    else v = e.S[o.misc + 12 + (i - o.nq - o.nv - 2)];
+    io.rec[i] = v;
+  });
+  (void)fresh_xy;
+}
+
+// VecEnv.reset() for one env
+template <class W>
+SGRL_DEV void env_reset(W& w, const SgrlModelView& m, const Layout& o, double* S, int32_t* I, const StepIO& io, bool bump_episode) {
+  Engine<W> e(w, m, o, S, I);
+  int32_t episode = io.cnt[1];
+  if (bump_episode) episode += 1;
+  e.reset_state(io.seed, io.env_id, (uint32_t)episode);
+  e.refresh_kinematics();
+  e.write_obs(io.obs32, io.obs64, io.obs_max_len);
+  store_state(e, io, true);
+  w.lanes(1, [&](int) { io.cnt[0] = 0; io.cnt[1] = episode; });
+}
+
+// make the record consistent after an external set_state (qpos/qvel/target already in the record)
+template <class W>
+SGRL_DEV void env_refresh(W& w, const SgrlModelView& m, const Layout& o, double* S, int32_t* I, const StepIO& io) {
+  Engine<W> e(w, m, o, S, I);
+  load_state(e, io);
+  e.refresh_kinematics();
+  e.write_obs(io.obs32, io.obs64, io.obs_max_len);
+  store_state(e, io, true);
+}
+
+// VecEnv.step() for one env (reference subproc_vec_env.py:12-15 + <env>.py:15-44)
+template <class W>
+SGRL_DEV void env_step(W& w, const SgrlModelView& m, const Layout& o, double* S, int32_t* I, const StepIO& io) {
+  Engine<W> e(w, m, o, S, I);
+  load_state(e, io);
+  w.lanes(o.nu > 8 ? o.nu : 8, [&](int u) {
+    if (u < o.nu) { const int s = m.act_slot[u]; S[o.ctrl + u] = s >= 0 ? (double)io.action[s] : 0.0; }
+    if (u < 4) S[o.misc + MS_PREQUAT + u] = S[o.qpos + 3 + u];
+    if (u == 4) I[o.icnt + IC_OVERFLOW] = 0;
+  });
+  const int fs = m.hdr[SGRL_H_FRAME_SKIP];
+  for (int s = 0; s < fs; s++) e.mj_step();
+  e.body_velocities();
+  e.reward_done();
+  e.write_obs(io.obs32, io.obs64, io.obs_max_len);
+  // bookkeeping: target resampling (<env>.py:41-43), time limit (gym TimeLimit), outputs
+  w.lanes(1, [&](int) {
+    const double dist = S[o.misc + MS_DIST];
+    const double tx = S[o.misc + 12], ty = S[o.misc + 13];
+    const uint32_t ep = (uint32_t)io.cnt[1], sc = (uint32_t)io.cnt[0];
+    if (dist < 1.0 && sqrt(tx * tx + ty * ty) > 1.0) {
+      const double r = -kPi + 2 * kPi * rng_uniform01(io.seed, io.env_id, ep, 1, 2 * sc);
+      if (m.hdr[SGRL_H_TARGET_V2]) {
+        const double len = 10.0 + 10.0 * rng_uniform01(io.seed, io.env_id, ep, 1, 2 * sc + 1);
+        S[o.misc + 12] = S[o.xpos + 3] + cos(r) * len; S[o.misc + 13] = S[o.xpos + 4] + sin(r) * len;
+      } else { S[o.misc + 12] = cos(r) * 10000.0; S[o.misc + 13] = sin(r) * 10000.0; }
+    }
+    int done = I[o.icnt + IC_DONE], trunc = 0;
+    const int steps = io.cnt[0] + 1;
+    if (io.max_episode_steps > 0 && steps >= io.max_episode_steps) { trunc = !done; done = 1; }
+    I[o.icnt + IC_DONE] = done; I[o.icnt + IC_TRUNC] = trunc;
+    io.cnt[0] = steps;
+    io.cnt[2] += I[o.icnt + IC_OVERFLOW];
+    if (io.reward) *io.reward = (float)S[o.misc + MS_REWARD];
+    if (io.reward64) *io.reward64 = S[o.misc + MS_REWARD];
+    if (io.done) *io.done = (uint8_t)done;
+    if (io.dist) *io.dist = (float)dist;
+    if (io.truncated) *io.truncated = (uint8_t)trunc;
+  });
+  store_state(e, io, false);
+  if (I[o.icnt + IC_DONE] && io.auto_reset) env_reset(w, m, o, S, I, io, true);
+}
+
+}  // namespace sgrl

@@ -11,11 +11,63 @@ NFHDR = 16
  H_TARGET_V2, H_RESET_VEL_NORMAL, H_NHEIGHT_BODIES, H_HEIGHT_BODY0, H_HEIGHT_BODY1, H_MAX_ROWS,
  H_PGS_ITERS) = range(18)
 (F_TIMESTEP, F_GRAV_X, F_GRAV_Y, F_GRAV_Z, F_HEIGHT_LO, F_HEIGHT_HI, F_ANG_LIMIT, F_ALIVE_BONUS,
- F_HEADING_WEIGHT, F_CTRL_COST, F_RESET_POS_NOISE, F_RESET_VEL_NOISE, F_PGS_TOL) = range(13)
+ F_HEADING_WEIGHT, F_CTRL_COST, F_RESET_POS_NOISE, F_RESET_VEL_NOISE, F_PGS_TOL, F_TOTAL_MASS) = range(14)
 
 DEFAULT_MAX_ROWS = 64
 DEFAULT_PGS_ITERS = 300
 DEFAULT_PGS_TOL = 1e-10
+
+
+MAXDEPTH = 8
+
+
+def _derived_int_tables(model):
+    """body_depth, body_path, body_subend, body_dofmask, dof_act (see include/sgrl_model.h)."""
+    nb, nv = model.nbody, model.nv
+    depth = np.zeros(nb, dtype=np.int32)
+    path = np.full((nb, MAXDEPTH), -1, dtype=np.int32)
+    subend = np.zeros(nb, dtype=np.int32)
+    mask = np.zeros((nb, 2), dtype=np.int32)
+    for b in range(1, nb):
+        chain = []
+        a = b
+        while a > 0:
+            chain.append(a)
+            a = int(model.body_parent[a])
+        chain.reverse()
+        if len(chain) > MAXDEPTH:
+            raise ValueError("kinematic chain deeper than %d" % MAXDEPTH)
+        depth[b] = len(chain)
+        path[b, :len(chain)] = chain
+        bits = 0
+        for c in chain:
+            for d in range(int(model.body_dofadr[c]), int(model.body_dofadr[c]) + int(model.body_dofnum[c])):
+                bits |= 1 << d
+        lo, hi = bits & 0xFFFFFFFF, (bits >> 32) & 0xFFFFFFFF
+        mask[b] = np.array([lo, hi], dtype=np.uint32).view(np.int32)
+    # pre-order numbering => contiguous subtrees
+    for b in range(nb - 1, 0, -1):
+        subend[b] = max(subend[b], b + 1)
+        p = int(model.body_parent[b])
+        if p > 0:
+            subend[p] = max(subend[p], subend[b])
+    for b in range(1, nb):
+        for c in range(b + 1, nb):
+            inside = c < subend[b]
+            a = c
+            anc = False
+            while a > 0:
+                if a == b:
+                    anc = True
+                a = int(model.body_parent[a])
+            if inside != anc:
+                raise ValueError("bodies are not in pre-order")
+    if nv > 64:
+        raise ValueError("nv > 64 unsupported")
+    dof_act = np.full(nv, -1, dtype=np.int32)
+    for u in range(model.nu):
+        dof_act[int(model.act_dof[u])] = u
+    return [depth, path.ravel(), subend, mask.ravel(), dof_act]
 
 
 def pack_model(model, spec=None, env_name=None, max_rows=DEFAULT_MAX_ROWS, pgs_iters=DEFAULT_PGS_ITERS,
@@ -41,6 +93,7 @@ def pack_model(model, spec=None, env_name=None, max_rows=DEFAULT_MAX_ROWS, pgs_i
     ints = [hdr]
     for k in mjcf.Model.INT_FIELDS:
         ints.append(np.asarray(getattr(model, k), dtype=np.int32).ravel())
+    ints.extend(_derived_int_tables(model))
     fh = np.zeros(NFHDR, dtype=np.float64)
     fh[F_TIMESTEP] = model.timestep
     fh[F_GRAV_X:F_GRAV_Z + 1] = model.gravity
@@ -48,6 +101,7 @@ def pack_model(model, spec=None, env_name=None, max_rows=DEFAULT_MAX_ROWS, pgs_i
     fh[F_ALIVE_BONUS], fh[F_HEADING_WEIGHT], fh[F_CTRL_COST] = spec.alive_bonus, spec.heading_weight, spec.ctrl_cost
     fh[F_RESET_POS_NOISE], fh[F_RESET_VEL_NOISE] = spec.reset_pos_noise, spec.reset_vel_noise
     fh[F_PGS_TOL] = pgs_tol
+    fh[F_TOTAL_MASS] = float(np.sum(model.body_mass[1:]))
     fls = [fh]
     for k in mjcf.Model.F64_FIELDS:
         fls.append(np.asarray(getattr(model, k), dtype=np.float64).ravel())

@@ -1,0 +1,84 @@
+// tests/emu/emu_step.cpp -- TEST HARNESS ONLY (never loaded by the product).
+//
+// Instantiates sgrl_amd/csrc/step_body.h with a *serial lane emulator* so that the exact engine source can be
+// unit-tested on the CPU-only build container against the oracle before it is run on a GPU.  `lanes(n, f)` runs the
+// lane bodies one after another -- in ascending or descending order (set_reverse) -- which also exposes any
+// intra-phase cross-lane dependency (the two orders must agree bit for bit).
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../sgrl_amd/csrc/step_body.h"
+
+namespace {
+bool g_reverse = false;
+
+struct EmuWave {
+  template <class F> void lanes(int n, F f) {
+    if (g_reverse) for (int i = n - 1; i >= 0; i--) f(i);
+    else for (int i = 0; i < n; i++) f(i);
+  }
+  template <class F> void lanes_from(int lo, int hi, F f) {
+    if (g_reverse) for (int i = hi - 1; i >= lo; i--) f(i);
+    else for (int i = lo; i < hi; i++) f(i);
+  }
+  // same association as the device reduction is NOT required (rounding-level differences are expected)
+  template <class F> double sum(int n, F f) { double s = 0; for (int i = 0; i < n; i++) s += f(i); return s; }
+  template <class F> double maxabs(int n, F f) { double s = 0; for (int i = 0; i < n; i++) { double v = std::fabs(f(i)); if (v > s) s = v; } return s; }
+};
+}  // namespace
+
+extern "C" {
+
+void sgrl_emu_set_reverse(int r) { g_reverse = r != 0; }
+
+int sgrl_emu_layout_doubles(const int32_t* ib) { sgrl::Layout o; sgrl::make_layout(ib, &o); return o.s_total; }
+int sgrl_emu_layout_bytes(const int32_t* ib) { sgrl::Layout o; sgrl::make_layout(ib, &o); return sgrl::layout_bytes(&o); }
+
+// forward dynamics at (qpos, qvel, ctrl) -> qacc; also returns nrow / ncon
+int sgrl_emu_forward(const int32_t* ib, const double* fb, double* qpos, const double* qvel, const double* ctrl,
+                     double* qacc, double* diag) {
+  SgrlModelView m;
+  if (sgrl_model_view(ib, fb, &m)) return -1;
+  sgrl::Layout o; sgrl::make_layout(ib, &o);
+  std::vector<double> S(o.s_total, NAN);
+  std::vector<int32_t> I(o.i_total + 2, -12345);
+  EmuWave w;
+  sgrl::Engine<EmuWave> e(w, m, o, S.data(), I.data());
+  for (int i = 0; i < m.nq; i++) S[o.qpos + i] = qpos[i];
+  for (int i = 0; i < m.nv; i++) S[o.qvel + i] = qvel[i];
+  for (int i = 0; i < m.nu; i++) S[o.ctrl + i] = ctrl[i];
+  I[o.icnt + sgrl::IC_OVERFLOW] = 0;
+  e.forward();
+  for (int i = 0; i < m.nv; i++) qacc[i] = S[o.qacc + i];
+  for (int i = 0; i < m.nq; i++) qpos[i] = S[o.qpos + i];
+  if (diag) {
+    int ncon = 0;
+    for (int s = 0; s < o.ncon; s++) ncon += I[o.con_valid + s];
+    diag[0] = ncon; diag[1] = I[o.icnt + sgrl::IC_NROW]; diag[2] = I[o.icnt + sgrl::IC_NROW_WANTED];
+  }
+  return 0;
+}
+
+// generic env call: op 0 = reset, 1 = step, 2 = refresh.  rec/cnt are the persistent record of one env.
+int sgrl_emu_env(int op, const int32_t* ib, const double* fb, double* rec, int32_t* cnt, const float* action,
+                 float* obs32, double* obs64, int obs_max_len, uint64_t seed, uint32_t env_id, int max_episode_steps,
+                 int auto_reset, double* reward64, uint8_t* done, float* dist, uint8_t* truncated) {
+  SgrlModelView m;
+  if (sgrl_model_view(ib, fb, &m)) return -1;
+  sgrl::Layout o; sgrl::make_layout(ib, &o);
+  std::vector<double> S(o.s_total, NAN);
+  std::vector<int32_t> I(o.i_total + 2, -12345);
+  EmuWave w;
+  sgrl::StepIO io;
+  io.rec = rec; io.cnt = cnt; io.action = action; io.obs32 = obs32; io.obs64 = obs64; io.reward = nullptr;
+  io.done = done; io.dist = dist; io.truncated = truncated; io.reward64 = reward64; io.obs_max_len = obs_max_len;
+  io.seed = seed; io.env_id = env_id; io.max_episode_steps = max_episode_steps; io.auto_reset = auto_reset;
+  if (op == 0) sgrl::env_reset(w, m, o, S.data(), I.data(), io, false);
+  else if (op == 1) sgrl::env_step(w, m, o, S.data(), I.data(), io);
+  else sgrl::env_refresh(w, m, o, S.data(), I.data(), io);
+  return 0;
+}
+}
