@@ -1,0 +1,92 @@
+/* sgrl.h -- C ABI of libsgrl_hip.so, the MI355X-native batched rollout engine for the SGRL hot path.
+ *
+ * The reference has no FFI for this path (it is pure Python over mujoco-py / PyTorch); the entry points below
+ * are what a binding for the path would bind, each replacing one reference interface:
+ *
+ *   sgrl_engine_create    <- SubprocVecEnv.__init__(env_fns)            reference src/subproc_vec_env.py:34-52
+ *                            + utils.makeEnvWrapper / registerEnvs       reference src/utils.py:14-80
+ *   sgrl_reset            <- SubprocVecEnv.reset()                       reference src/subproc_vec_env.py:65-68
+ *                            -> ModularEnvWrapper.reset -> reset_model   reference src/wrappers.py:56-65,
+ *                                                                        src/environments/3d_walker_7_full.py:150-164
+ *   sgrl_step             <- SubprocVecEnv.step_async + step_wait        reference src/subproc_vec_env.py:54-63 (+ worker :12-15)
+ *                            -> ModularEnvWrapper.step -> ModularEnv.step -> do_simulation -> _get_obs
+ *                                                                        reference src/wrappers.py:39-54,
+ *                                                                        src/environments/3d_walker_7_full.py:15-148
+ *   sgrl_get_records / sgrl_set_records / sgrl_refresh
+ *                         <- sim.get_state / MujocoEnv.set_state (+ sim.forward)   [gym 0.17.2, 3P]
+ *   sgrl_set_actor_*      <- SEPolicy.forward under torch.no_grad()      reference src/SEActor.py:334-347,
+ *                                                                        src/agent.py:189-198  (see sgrl_set.h)
+ *
+ * Conventions: plain pointers and sizes, no exceptions, int return codes (0 = ok, <0 = error; message via
+ * sgrl_last_error()).  Pointers marked DEV are device (HIP) pointers owned by the caller (e.g. torch
+ * tensor.data_ptr()); HOST pointers are ordinary host memory.  `stream` is a hipStream_t passed as void*
+ * (NULL = default stream).  A handle is not thread-safe; calls on one handle must not overlap.
+ */
+#ifndef SGRL_H
+#define SGRL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sgrl_engine sgrl_engine;
+
+enum {
+  SGRL_OK = 0,
+  SGRL_ERR_ARG = -1,      /* bad argument (null pointer, sizes that do not match the morphologies) */
+  SGRL_ERR_MODEL = -2,    /* malformed model blob */
+  SGRL_ERR_HIP = -3,      /* HIP runtime error (no device, allocation, launch) */
+  SGRL_ERR_LIMIT = -4     /* a morphology exceeds the engine's limits (nv > 64, LDS footprint > 160 KiB) */
+};
+
+/* Create a batch of environments.
+ *   n_morph            number of distinct morphologies
+ *   ib/ib_len, fb/fb_len   HOST: per-morphology model blobs (include/sgrl_model.h; sgrl_amd.model_pack.pack_model)
+ *   morph_count        HOST: envs per morphology; env indices are assigned contiguously in morphology order
+ *   obs_max_len        row length of observation outputs  (reference main.py:108-117: 41 * max_limbs)
+ *   action_max_len     row length of action inputs        (3 * max_limbs; first 3 slots are torso dummies)
+ *   seed, env_id_base  counter-RNG key: env i draws from stream (seed, env_id_base + i, episode)
+ *   max_episode_steps  gym TimeLimit (reference arguments.py:109-114, default 1000); <= 0 disables
+ */
+int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_len, const double* const* fb,
+                       const int32_t* fb_len, const int32_t* morph_count, int obs_max_len, int action_max_len,
+                       uint64_t seed, uint32_t env_id_base, int max_episode_steps, sgrl_engine** out);
+void sgrl_engine_destroy(sgrl_engine* e);
+
+int sgrl_num_envs(const sgrl_engine* e);
+int sgrl_record_stride(const sgrl_engine* e);   /* doubles per env record: max over morphs of nq+nv+4 */
+int sgrl_lds_bytes(const sgrl_engine* e);       /* dynamic LDS per workgroup used by the step kernel */
+
+/* VecEnv.reset(): every env starts a new episode.  obs: DEV float[n_env*obs_max_len]; obs64: DEV double[...] or NULL. */
+int sgrl_reset(sgrl_engine* e, float* obs, double* obs64, void* stream);
+
+/* VecEnv.step(actions).  actions: DEV float[n_env*action_max_len] (policy order, zero padded).
+ * Outputs (DEV, any may be NULL except obs): obs float[n_env*obs_max_len] -- the post-step observation, or the
+ * reset observation for envs that finished and auto_reset != 0 (reference subproc_vec_env.py:12-15);
+ * reward float[n_env]; done uint8[n_env]; dist float[n_env] (info["dist"]); truncated uint8[n_env]
+ * (gym's info["TimeLimit.truncated"]); obs64/reward64: double-precision copies for parity tests. */
+int sgrl_step(sgrl_engine* e, const float* actions, float* obs, float* reward, uint8_t* done, float* dist,
+              uint8_t* truncated, double* obs64, double* reward64, int auto_reset, void* stream);
+
+/* Raw state access (teacher-forced parity, checkpointing).  HOST buffers:
+ *   rec[n_env * stride]: qpos[nq] | qvel[nv] | torso_xy_stale[2] | target[2] (rest of the row unused)
+ *   cnt[n_env * 4]:      step_count, episode, constraint-row overflow count, reserved */
+int sgrl_get_records(sgrl_engine* e, double* rec, int32_t* cnt);
+int sgrl_set_records(sgrl_engine* e, const double* rec, const int32_t* cnt);
+/* After sgrl_set_records: recompute kinematics (gym set_state -> sim.forward) and emit observations. */
+int sgrl_refresh(sgrl_engine* e, float* obs, double* obs64, void* stream);
+
+/* Time `reps` back-to-back step launches with HIP events on `stream`; returns mean milliseconds per launch in
+ * *ms_out (used by bench.py's roofline block; state advances as in sgrl_step). */
+int sgrl_time_steps(sgrl_engine* e, const float* actions, float* obs, float* reward, uint8_t* done, int reps,
+                    void* stream, float* ms_out);
+
+const char* sgrl_last_error(void);
+const char* sgrl_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGRL_H */

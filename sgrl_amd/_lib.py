@@ -1,0 +1,81 @@
+"""Loader for the HIP extension (libsgrl_hip.so, C ABI in include/sgrl.h).
+
+There is deliberately NO CPU fallback: if the shared library is missing, cannot be loaded, or no MI355X is
+visible, every entry point raises.  (The CPU oracle under oracle/ is test infrastructure and is never imported
+from here.)
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsgrl_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ["engine.hip", "set_actor.hip"]
+
+_lib = None
+
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_f64p = ctypes.POINTER(ctypes.c_double)
+
+
+class SgrlError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into sgrl_amd/libsgrl_hip.so (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps += [os.path.join(_HERE, "..", "include", f) for f in ("sgrl.h", "sgrl_model.h", "sgrl_set.h")
+             if os.path.exists(os.path.join(_HERE, "..", "include", f))]
+    if os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SgrlError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(no CPU fallback exists)" % LIB_PATH)
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise SgrlError("cannot load %s: %s" % (LIB_PATH, e))
+    L.sgrl_last_error.restype = ctypes.c_char_p
+    L.sgrl_version.restype = ctypes.c_char_p
+    L.sgrl_engine_create.restype = ctypes.c_int
+    L.sgrl_engine_create.argtypes = [ctypes.c_int, ctypes.POINTER(_i32p), _i32p, ctypes.POINTER(_f64p), _i32p, _i32p,
+                                     ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int,
+                                     ctypes.POINTER(ctypes.c_void_p)]
+    L.sgrl_engine_destroy.argtypes = [ctypes.c_void_p]
+    L.sgrl_engine_destroy.restype = None
+    for name in ("sgrl_num_envs", "sgrl_record_stride", "sgrl_lds_bytes"):
+        getattr(L, name).argtypes = [ctypes.c_void_p]
+        getattr(L, name).restype = ctypes.c_int
+    vp = ctypes.c_void_p
+    L.sgrl_reset.argtypes = [vp, vp, vp, vp]
+    L.sgrl_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int, vp]
+    L.sgrl_refresh.argtypes = [vp, vp, vp, vp]
+    L.sgrl_get_records.argtypes = [vp, vp, vp]
+    L.sgrl_set_records.argtypes = [vp, vp, vp]
+    L.sgrl_time_steps.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float)]
+    _lib = L
+    return L
+
+
+EXPORTS = ["sgrl_engine_create", "sgrl_engine_destroy", "sgrl_num_envs", "sgrl_record_stride", "sgrl_lds_bytes",
+           "sgrl_reset", "sgrl_step", "sgrl_get_records", "sgrl_set_records", "sgrl_refresh", "sgrl_time_steps",
+           "sgrl_last_error", "sgrl_version"]
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SgrlError("%s failed (%d): %s" % (what, rc, lib().sgrl_last_error().decode()))

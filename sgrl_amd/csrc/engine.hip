@@ -1,0 +1,289 @@
+// engine.hip -- HIP kernels + C ABI (include/sgrl.h) of the batched rollout engine.  gfx950 only.
+//
+// Launch geometry: one 64-thread workgroup (= one wavefront) per environment; dynamic LDS = the largest
+// per-environment slab over the morphologies in the batch (step_body.h Layout).  Per-environment persistent
+// state is an array of records in HBM: one wave reads and writes one contiguous record (coalesced), the
+// observation row [env][obs_max_len] is written once with consecutive lanes on consecutive floats.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sgrl.h"
+#include "step_body.h"
+#include "wave_hip.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      return fail(SGRL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                \
+  } while (0)
+
+struct MorphDev {
+  const int32_t* ib;
+  const double* fb;
+};
+
+struct BatchArgs {
+  const MorphDev* morphs;     // [n_morph]
+  const int32_t* env_morph;   // [n_env]
+  double* rec;                // [n_env * stride]
+  int32_t* cnt;               // [n_env * 4]
+  int stride;
+  int n_env;
+  int obs_max_len, action_max_len;
+  uint64_t seed;
+  uint32_t env_id_base;
+  int max_episode_steps;
+};
+
+struct StepOut {
+  const float* actions;
+  float* obs32;
+  double* obs64;
+  float* reward;
+  double* reward64;
+  uint8_t* done;
+  float* dist;
+  uint8_t* truncated;
+  int auto_reset;
+};
+
+extern __shared__ double sgrl_lds[];
+
+__device__ __forceinline__ void setup(const BatchArgs& a, int env, SgrlModelView* m, sgrl::Layout* o, double** S, int32_t** I) {
+  const MorphDev md = a.morphs[a.env_morph[env]];
+  sgrl_model_view(md.ib, md.fb, m);
+  sgrl::make_layout(md.ib, o);
+  *S = sgrl_lds;
+  *I = reinterpret_cast<int32_t*>(sgrl_lds + o->s_total);
+}
+
+__device__ __forceinline__ sgrl::StepIO make_io(const BatchArgs& a, const StepOut& out, int env) {
+  sgrl::StepIO io;
+  io.rec = a.rec + (size_t)env * a.stride;
+  io.cnt = a.cnt + (size_t)env * 4;
+  io.action = out.actions ? out.actions + (size_t)env * a.action_max_len : nullptr;
+  io.obs32 = out.obs32 ? out.obs32 + (size_t)env * a.obs_max_len : nullptr;
+  io.obs64 = out.obs64 ? out.obs64 + (size_t)env * a.obs_max_len : nullptr;
+  io.reward = out.reward ? out.reward + env : nullptr;
+  io.reward64 = out.reward64 ? out.reward64 + env : nullptr;
+  io.done = out.done ? out.done + env : nullptr;
+  io.dist = out.dist ? out.dist + env : nullptr;
+  io.truncated = out.truncated ? out.truncated + env : nullptr;
+  io.obs_max_len = a.obs_max_len;
+  io.seed = a.seed;
+  io.env_id = a.env_id_base + (uint32_t)env;
+  io.max_episode_steps = a.max_episode_steps;
+  io.auto_reset = out.auto_reset;
+  return io;
+}
+
+__global__ __launch_bounds__(64) void k_env_step(BatchArgs a, StepOut out) {
+  const int env = blockIdx.x;
+  SgrlModelView m; sgrl::Layout o; double* S; int32_t* I;
+  setup(a, env, &m, &o, &S, &I);
+  sgrl::HipWave w;
+  const sgrl::StepIO io = make_io(a, out, env);
+  sgrl::env_step(w, m, o, S, I, io);
+}
+
+__global__ __launch_bounds__(64) void k_env_reset(BatchArgs a, StepOut out) {
+  const int env = blockIdx.x;
+  SgrlModelView m; sgrl::Layout o; double* S; int32_t* I;
+  setup(a, env, &m, &o, &S, &I);
+  sgrl::HipWave w;
+  const sgrl::StepIO io = make_io(a, out, env);
+  sgrl::env_reset(w, m, o, S, I, io, true);
+}
+
+__global__ __launch_bounds__(64) void k_env_refresh(BatchArgs a, StepOut out) {
+  const int env = blockIdx.x;
+  SgrlModelView m; sgrl::Layout o; double* S; int32_t* I;
+  setup(a, env, &m, &o, &S, &I);
+  sgrl::HipWave w;
+  const sgrl::StepIO io = make_io(a, out, env);
+  sgrl::env_refresh(w, m, o, S, I, io);
+}
+
+}  // namespace
+
+struct sgrl_engine {
+  int n_morph = 0, n_env = 0, stride = 0, lds_bytes = 0;
+  int obs_max_len = 0, action_max_len = 0;
+  std::vector<int32_t*> d_ib;
+  std::vector<double*> d_fb;
+  MorphDev* d_morphs = nullptr;
+  int32_t* d_env_morph = nullptr;
+  double* d_rec = nullptr;
+  int32_t* d_cnt = nullptr;
+  BatchArgs args{};
+};
+
+extern "C" {
+
+const char* sgrl_last_error(void) { return g_err.c_str(); }
+const char* sgrl_version(void) { return "sgrl-hip 0.1.0 (gfx950)"; }
+
+void sgrl_engine_destroy(sgrl_engine* e) {
+  if (!e) return;
+  for (auto p : e->d_ib) if (p) (void)hipFree(p);
+  for (auto p : e->d_fb) if (p) (void)hipFree(p);
+  if (e->d_morphs) (void)hipFree(e->d_morphs);
+  if (e->d_env_morph) (void)hipFree(e->d_env_morph);
+  if (e->d_rec) (void)hipFree(e->d_rec);
+  if (e->d_cnt) (void)hipFree(e->d_cnt);
+  delete e;
+}
+
+int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_len, const double* const* fb,
+                       const int32_t* fb_len, const int32_t* morph_count, int obs_max_len, int action_max_len,
+                       uint64_t seed, uint32_t env_id_base, int max_episode_steps, sgrl_engine** out) {
+  if (!out) return fail(SGRL_ERR_ARG, "out is null");
+  *out = nullptr;
+  if (n_morph <= 0 || !ib || !ib_len || !fb || !fb_len || !morph_count) return fail(SGRL_ERR_ARG, "null or empty morphology list");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(SGRL_ERR_HIP, "no HIP device visible: libsgrl_hip.so needs an MI355X (there is no CPU fallback)");
+  sgrl_engine* e = new sgrl_engine();
+  e->n_morph = n_morph;
+  e->obs_max_len = obs_max_len;
+  e->action_max_len = action_max_len;
+  std::vector<int32_t> env_morph;
+  std::vector<MorphDev> morphs(n_morph);
+  e->d_ib.assign(n_morph, nullptr);
+  e->d_fb.assign(n_morph, nullptr);
+  int rc = SGRL_OK;
+  for (int k = 0; k < n_morph && rc == SGRL_OK; k++) {
+    SgrlModelView v;
+    if (!ib[k] || !fb[k] || ib_len[k] < SGRL_NHDR || sgrl_model_view(ib[k], fb[k], &v) != 0) { rc = fail(SGRL_ERR_MODEL, "bad magic in model blob " + std::to_string(k)); break; }
+    if (v.n_int != ib_len[k] || v.n_f64 != fb_len[k]) { rc = fail(SGRL_ERR_MODEL, "model blob " + std::to_string(k) + " has unexpected length"); break; }
+    if (v.nv > 64 || v.nbody > 64 || v.npair > 64) { rc = fail(SGRL_ERR_LIMIT, "morphology exceeds 64 dofs/bodies/pairs"); break; }
+    const int L = v.nbody - 1;
+    if (41 * L > obs_max_len || 3 * L > action_max_len) { rc = fail(SGRL_ERR_ARG, "obs_max_len/action_max_len too small for morphology " + std::to_string(k)); break; }
+    if (morph_count[k] < 0) { rc = fail(SGRL_ERR_ARG, "negative morph_count"); break; }
+    sgrl::Layout o;
+    sgrl::make_layout(ib[k], &o);
+    const int bytes = sgrl::layout_bytes(&o);
+    if (bytes > 160 * 1024) { rc = fail(SGRL_ERR_LIMIT, "per-environment LDS slab exceeds 160 KiB"); break; }
+    if (bytes > e->lds_bytes) e->lds_bytes = bytes;
+    const int need = v.nq + v.nv + 4;
+    if (need > e->stride) e->stride = need;
+    for (int i = 0; i < morph_count[k]; i++) env_morph.push_back(k);
+    if (hipMalloc(&e->d_ib[k], sizeof(int32_t) * ib_len[k]) != hipSuccess || hipMalloc(&e->d_fb[k], sizeof(double) * fb_len[k]) != hipSuccess) { rc = fail(SGRL_ERR_HIP, "hipMalloc(model) failed"); break; }
+    (void)hipMemcpy(e->d_ib[k], ib[k], sizeof(int32_t) * ib_len[k], hipMemcpyHostToDevice);
+    (void)hipMemcpy(e->d_fb[k], fb[k], sizeof(double) * fb_len[k], hipMemcpyHostToDevice);
+    morphs[k].ib = e->d_ib[k];
+    morphs[k].fb = e->d_fb[k];
+  }
+  if (rc == SGRL_OK && env_morph.empty()) rc = fail(SGRL_ERR_ARG, "no environments requested");
+  if (rc != SGRL_OK) { sgrl_engine_destroy(e); return rc; }
+  e->n_env = (int)env_morph.size();
+  e->stride = (e->stride + 1) & ~1;
+  bool ok = hipMalloc(&e->d_morphs, sizeof(MorphDev) * n_morph) == hipSuccess &&
+            hipMalloc(&e->d_env_morph, sizeof(int32_t) * e->n_env) == hipSuccess &&
+            hipMalloc(&e->d_rec, sizeof(double) * (size_t)e->n_env * e->stride) == hipSuccess &&
+            hipMalloc(&e->d_cnt, sizeof(int32_t) * (size_t)e->n_env * 4) == hipSuccess;
+  if (!ok) { sgrl_engine_destroy(e); return fail(SGRL_ERR_HIP, "hipMalloc(state) failed"); }
+  (void)hipMemcpy(e->d_morphs, morphs.data(), sizeof(MorphDev) * n_morph, hipMemcpyHostToDevice);
+  (void)hipMemcpy(e->d_env_morph, env_morph.data(), sizeof(int32_t) * e->n_env, hipMemcpyHostToDevice);
+  (void)hipMemset(e->d_rec, 0, sizeof(double) * (size_t)e->n_env * e->stride);
+  (void)hipMemset(e->d_cnt, 0xFF, sizeof(int32_t) * (size_t)e->n_env * 4);  // episode = -1: first reset bumps it to 0
+  if (e->lds_bytes > 48 * 1024) {
+    hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_env_step), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
+    hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_env_reset), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
+    hipError_t a3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_env_refresh), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
+    if (a1 != hipSuccess || a2 != hipSuccess || a3 != hipSuccess) { sgrl_engine_destroy(e); return fail(SGRL_ERR_HIP, "cannot raise the dynamic LDS limit"); }
+  }
+  BatchArgs& a = e->args;
+  a.morphs = e->d_morphs; a.env_morph = e->d_env_morph; a.rec = e->d_rec; a.cnt = e->d_cnt;
+  a.stride = e->stride; a.n_env = e->n_env; a.obs_max_len = obs_max_len; a.action_max_len = action_max_len;
+  a.seed = seed; a.env_id_base = env_id_base; a.max_episode_steps = max_episode_steps;
+  if (hipDeviceSynchronize() != hipSuccess) { sgrl_engine_destroy(e); return fail(SGRL_ERR_HIP, "device error during engine setup"); }
+  *out = e;
+  return SGRL_OK;
+}
+
+int sgrl_num_envs(const sgrl_engine* e) { return e ? e->n_env : SGRL_ERR_ARG; }
+int sgrl_record_stride(const sgrl_engine* e) { return e ? e->stride : SGRL_ERR_ARG; }
+int sgrl_lds_bytes(const sgrl_engine* e) { return e ? e->lds_bytes : SGRL_ERR_ARG; }
+
+int sgrl_reset(sgrl_engine* e, float* obs, double* obs64, void* stream) {
+  if (!e || !obs) return fail(SGRL_ERR_ARG, "sgrl_reset: null engine or obs");
+  StepOut out{};
+  out.obs32 = obs; out.obs64 = obs64;
+  hipLaunchKernelGGL(k_env_reset, dim3(e->n_env), dim3(64), e->lds_bytes, (hipStream_t)stream, e->args, out);
+  HIP_TRY(hipGetLastError());
+  return SGRL_OK;
+}
+
+int sgrl_step(sgrl_engine* e, const float* actions, float* obs, float* reward, uint8_t* done, float* dist,
+              uint8_t* truncated, double* obs64, double* reward64, int auto_reset, void* stream) {
+  if (!e || !actions || !obs) return fail(SGRL_ERR_ARG, "sgrl_step: null engine, actions or obs");
+  StepOut out{};
+  out.actions = actions; out.obs32 = obs; out.obs64 = obs64; out.reward = reward; out.reward64 = reward64;
+  out.done = done; out.dist = dist; out.truncated = truncated; out.auto_reset = auto_reset;
+  hipLaunchKernelGGL(k_env_step, dim3(e->n_env), dim3(64), e->lds_bytes, (hipStream_t)stream, e->args, out);
+  HIP_TRY(hipGetLastError());
+  return SGRL_OK;
+}
+
+int sgrl_refresh(sgrl_engine* e, float* obs, double* obs64, void* stream) {
+  if (!e || !obs) return fail(SGRL_ERR_ARG, "sgrl_refresh: null engine or obs");
+  StepOut out{};
+  out.obs32 = obs; out.obs64 = obs64;
+  hipLaunchKernelGGL(k_env_refresh, dim3(e->n_env), dim3(64), e->lds_bytes, (hipStream_t)stream, e->args, out);
+  HIP_TRY(hipGetLastError());
+  return SGRL_OK;
+}
+
+int sgrl_get_records(sgrl_engine* e, double* rec, int32_t* cnt) {
+  if (!e) return fail(SGRL_ERR_ARG, "null engine");
+  HIP_TRY(hipDeviceSynchronize());
+  if (rec) HIP_TRY(hipMemcpy(rec, e->d_rec, sizeof(double) * (size_t)e->n_env * e->stride, hipMemcpyDeviceToHost));
+  if (cnt) HIP_TRY(hipMemcpy(cnt, e->d_cnt, sizeof(int32_t) * (size_t)e->n_env * 4, hipMemcpyDeviceToHost));
+  return SGRL_OK;
+}
+
+int sgrl_set_records(sgrl_engine* e, const double* rec, const int32_t* cnt) {
+  if (!e) return fail(SGRL_ERR_ARG, "null engine");
+  HIP_TRY(hipDeviceSynchronize());
+  if (rec) HIP_TRY(hipMemcpy(e->d_rec, rec, sizeof(double) * (size_t)e->n_env * e->stride, hipMemcpyHostToDevice));
+  if (cnt) HIP_TRY(hipMemcpy(e->d_cnt, cnt, sizeof(int32_t) * (size_t)e->n_env * 4, hipMemcpyHostToDevice));
+  return SGRL_OK;
+}
+
+int sgrl_time_steps(sgrl_engine* e, const float* actions, float* obs, float* reward, uint8_t* done, int reps,
+                    void* stream, float* ms_out) {
+  if (!e || !actions || !obs || !ms_out || reps <= 0) return fail(SGRL_ERR_ARG, "sgrl_time_steps: bad argument");
+  hipEvent_t t0, t1;
+  HIP_TRY(hipEventCreate(&t0));
+  HIP_TRY(hipEventCreate(&t1));
+  StepOut out{};
+  out.actions = actions; out.obs32 = obs; out.reward = reward; out.done = done; out.auto_reset = 1;
+  HIP_TRY(hipEventRecord(t0, (hipStream_t)stream));
+  for (int r = 0; r < reps; r++)
+    hipLaunchKernelGGL(k_env_step, dim3(e->n_env), dim3(64), e->lds_bytes, (hipStream_t)stream, e->args, out);
+  HIP_TRY(hipEventRecord(t1, (hipStream_t)stream));
+  HIP_TRY(hipEventSynchronize(t1));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+  (void)hipEventDestroy(t0);
+  (void)hipEventDestroy(t1);
+  HIP_TRY(hipGetLastError());
+  *ms_out = ms / reps;
+  return SGRL_OK;
+}
+
+}  // extern "C"

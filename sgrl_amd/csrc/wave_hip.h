@@ -1,0 +1,60 @@
+// wave_hip.h -- gfx950 implementation of the wavefront-execution interface used by step_body.h.
+// One workgroup = one 64-lane wavefront = one environment.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sgrl {
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double read_lane(double x, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+  return __hiloint2double(hi, lo);
+}
+// 64-lane sum with a wave-uniform result: xor butterflies inside each 16-lane row on the DPP network
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), then four v_readlane row totals.
+__device__ __forceinline__ double wave_sum(double x) {
+  x += dpp_move<0xB1>(x);
+  x += dpp_move<0x4E>(x);
+  x += dpp_move<0x141>(x);
+  x += dpp_move<0x140>(x);
+  return (read_lane(x, 0) + read_lane(x, 16)) + (read_lane(x, 32) + read_lane(x, 48));
+}
+__device__ __forceinline__ double wave_max(double x) {
+  x = fmax(x, dpp_move<0xB1>(x));
+  x = fmax(x, dpp_move<0x4E>(x));
+  x = fmax(x, dpp_move<0x141>(x));
+  x = fmax(x, dpp_move<0x140>(x));
+  return fmax(fmax(read_lane(x, 0), read_lane(x, 16)), fmax(read_lane(x, 32), read_lane(x, 48)));
+}
+
+struct HipWave {
+  int lane;
+  __device__ __forceinline__ HipWave() : lane(threadIdx.x & 63) {}
+  template <class F> __device__ __forceinline__ void lanes(int n, F f) {
+    for (int i = lane; i < n; i += 64) f(i);
+    __syncthreads();
+  }
+  template <class F> __device__ __forceinline__ void lanes_from(int lo, int hi, F f) {
+    for (int i = lo + lane; i < hi; i += 64) f(i);
+    __syncthreads();
+  }
+  template <class F> __device__ __forceinline__ double sum(int n, F f) {
+    double p = 0.0;
+    for (int i = lane; i < n; i += 64) p += f(i);
+    return wave_sum(p);
+  }
+  template <class F> __device__ __forceinline__ double maxabs(int n, F f) {
+    double p = 0.0;
+    for (int i = lane; i < n; i += 64) p = fmax(p, fabs(f(i)));
+    return wave_max(p);
+  }
+};
+
+}  // namespace sgrl

