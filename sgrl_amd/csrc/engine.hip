@@ -199,7 +199,11 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
   (void)hipMemcpy(e->d_morphs, morphs.data(), sizeof(MorphDev) * n_morph, hipMemcpyHostToDevice);
   (void)hipMemcpy(e->d_env_morph, env_morph.data(), sizeof(int32_t) * e->n_env, hipMemcpyHostToDevice);
   (void)hipMemset(e->d_rec, 0, sizeof(double) * (size_t)e->n_env * e->stride);
-  (void)hipMemset(e->d_cnt, 0xFF, sizeof(int32_t) * (size_t)e->n_env * 4);  // episode = -1: first reset bumps it to 0
+  {
+    std::vector<int32_t> cnt0((size_t)e->n_env * 4, 0);
+    for (int i = 0; i < e->n_env; i++) cnt0[4 * (size_t)i + 1] = -1;  // episode = -1: the first reset bumps it to 0
+    (void)hipMemcpy(e->d_cnt, cnt0.data(), sizeof(int32_t) * cnt0.size(), hipMemcpyHostToDevice);
+  }
   if (e->lds_bytes > 48 * 1024) {
     hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_env_step), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
     hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_env_reset), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);

@@ -58,7 +58,7 @@ def test_reset_matches_oracle(names):
         q, v, xy, tg = env.state_of(rec, i)
         np.testing.assert_allclose(q, oe.qpos, rtol=0, atol=1e-15)
         np.testing.assert_allclose(v, oe.qvel, rtol=0, atol=1e-15)
-        np.testing.assert_allclose(tg, oe.target, rtol=1e-15)
+        np.testing.assert_allclose(tg, oe.target, rtol=1e-12)  # device vs libm cos/sin
         np.testing.assert_allclose(xy, oe.torso_xy_stale, rtol=0, atol=1e-15)
         assert cnt[i, 0] == 0 and cnt[i, 1] == 0
     assert np.array_equal(env.obs.cpu().numpy(), obs.astype(np.float32))
@@ -75,7 +75,7 @@ def test_teacher_forced_step_parity(names):
         oe.reset()
     rng = np.random.RandomState(0)
     n_done = 0
-    for t in range(40):
+    for t in range(90):
         rec, cnt = env.get_records()
         for i, oe in enumerate(oes):
             m = env.models[env.env_morph[i]]
