@@ -1,0 +1,258 @@
+"""SET (subequivariant transformer) actor behind the reference's nn.Module surface.
+
+`SEPolicy` keeps the constructor signature, attribute names, `forward(state, mode)`, `change_morphology(graph)` and
+-- most importantly -- the exact `state_dict()` keys and shapes of the reference's SEPolicy
+(reference src/SEActor.py:290-356; key inventory in tests/golden/set_state_dict_keys.json), so `save.pth`
+checkpoints written by the reference (`common/trainer.py:256-258`) load unchanged and `agent.py` can construct it
+in place of `SEActor.SEPolicy`.
+
+Two execution paths with identical semantics:
+  * differentiable PyTorch path (training: `agent.update` back-props through the actor, reference agent.py:167-176);
+    node-major [B, L, ...] formulation of reference SEActor.py:82-287 / subequivariant_attentions.py:4-154;
+  * HIP fast path (sgrl_amd/csrc/set_actor.hip through the C ABI of include/sgrl_set.h), taken when autograd is
+    off and the input lives on the GPU -- exactly the situation of `Agent.select_action` (reference agent.py:189-198).
+    It is never silently replaced: if `use_hip` is on and the extension is missing, forward raises.
+"""
+import copy
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+G_NUM = 8          # 3-vectors per limb observation (reference SEActor.py:205)
+Z_DIM = 32         # invariant channel count (30 projected + gravity + direction)
+
+
+class ConcatPositionalEmbedding(nn.Module):
+    """Three traversal-index embeddings concatenated to d_model (reference SEActor.py:18-31)."""
+
+    def __init__(self, d_model, num_positions=3, max_node=15):
+        super().__init__()
+        unit = d_model // num_positions
+        sizes = [unit] * (num_positions - 1) + [unit + d_model % num_positions]
+        self.embeddings = nn.ModuleList([nn.Embedding(max_node, s) for s in sizes])
+
+    def forward(self, positional_indices):
+        return torch.cat([emb(idx) for emb, idx in zip(self.embeddings, positional_indices)], dim=1)
+
+
+def _invariants(x, gdir, proj, lin1, lin2):
+    """x [B,L,3,C] -> (features [B,L,out], F_norm [B,L,1])."""
+    z = torch.cat([proj(x), gdir], dim=-1)
+    gram = torch.einsum("blsa,blsc->blac", z, z)
+    fn = gram.flatten(-2).norm(dim=-1, keepdim=True) + 1.0
+    return lin2(F.relu(lin1(gram.flatten(-2)))), fn
+
+
+class SubequivariantAttention(nn.Module):
+    """Parameters of the reference's MyMultiheadAttention (SEActor.py:34-46) incl. the inherited-but-unused
+    in_proj_* / out_proj tensors, which must exist for state_dict compatibility."""
+
+    def __init__(self, embed_dim, num_heads):
+        super().__init__()
+        self.embed_dim, self.num_heads = embed_dim, num_heads
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+        e2 = 2 * embed_dim
+        self.q_proj = nn.Linear(e2, e2)
+        self.k_proj = nn.Linear(e2, e2)
+        self.v_proj = nn.Linear(e2, e2)
+        self.vg_proj = nn.Linear(embed_dim, e2 - 2 * num_heads, bias=False)
+        self.ng_out = nn.Linear(e2, embed_dim)
+        self.g_out = nn.Linear(e2, embed_dim, bias=False)
+        self.g_proj = nn.Linear(embed_dim, Z_DIM - 2, bias=False)
+        self.linear_g1 = nn.Linear(Z_DIM * Z_DIM, e2)
+        self.linear_g2 = nn.Linear(e2, embed_dim)
+
+    def forward(self, g, ng, gdir, bias=None):
+        B, L = ng.shape[:2]
+        H = self.num_heads
+        hd2 = 2 * (self.embed_dim // H)
+        inv, fn = _invariants(g, gdir, self.g_proj, self.linear_g1, self.linear_g2)
+        c = torch.cat([inv, ng], dim=-1)
+        q = (self.q_proj(c) / fn * float(hd2) ** -0.5).view(B, L, H, hd2)
+        k = (self.k_proj(c) / fn).view(B, L, H, hd2)
+        v = (self.v_proj(c) / fn).view(B, L, H, hd2)
+        vg = self.vg_proj(g).view(B, L, 3, H, hd2 - 2)
+        vg = torch.cat([vg, gdir.unsqueeze(3).expand(B, L, 3, H, 2)], dim=-1)
+        s = torch.einsum("bihd,bjhd->bhij", q, k)
+        if bias is not None:
+            s = s + bias.unsqueeze(0)
+        w = F.softmax(s, dim=-1)
+        o = torch.einsum("bhij,bjhd->bihd", w, v).reshape(B, L, H * hd2)
+        og = torch.einsum("bhij,bjshd->bishd", w, vg).reshape(B, L, 3, H * hd2)
+        return self.g_out(og), self.ng_out(o)
+
+
+class SubequivariantEncoderLayer(nn.Module):
+    """reference MyTransformerEncoderLayer (SEActor.py:69-125)."""
+
+    def __init__(self, d_model, nhead, dim_feedforward):
+        super().__init__()
+        self.self_attn = SubequivariantAttention(d_model, nhead)
+        self.linear1 = nn.Linear(2 * d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.g_proj2 = nn.Linear(d_model, Z_DIM - 2, bias=False)
+        self.g_proj3 = nn.Linear(d_model, Z_DIM - 2, bias=False)
+        self.linear_g1 = nn.Linear(Z_DIM * Z_DIM, dim_feedforward)
+        self.linear_g2 = nn.Linear(dim_feedforward, d_model)
+        self.linear3 = nn.Linear(2 * d_model, dim_feedforward)
+        self.linear4 = nn.Linear(dim_feedforward, Z_DIM * Z_DIM)
+        self.linear5 = nn.Linear(Z_DIM, d_model, bias=False)
+
+    def forward(self, g, ng, gdir, bias=None):
+        g1, ng1 = self.self_attn(g, ng, gdir, bias)
+        g = g + g1
+        ng = self.norm1(ng + ng1)
+        inv, fn = _invariants(g1, gdir, self.g_proj2, self.linear_g1, self.linear_g2)
+        c = torch.cat([inv, ng], dim=-1)
+        mat = (self.linear4(F.relu(self.linear3(c))) / fn).view(*ng.shape[:2], Z_DIM, Z_DIM)
+        z3 = torch.cat([self.g_proj3(g1), gdir], dim=-1)
+        g = g + self.linear5(torch.einsum("blsa,blac->blsc", z3, mat))
+        ng = self.norm2(ng + self.linear2(F.relu(self.linear1(c))) / fn)
+        return g, ng
+
+
+class RepeatTransformerEncoder(nn.Module):
+    """reference SEActor.py:127-167: position embedding added once, relation bias on layer 0 only, final norm."""
+
+    def __init__(self, layer, num_layers, nhead, norm=None, d_rel=3):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(layer) for _ in range(num_layers)])
+        self.num_layers = num_layers
+        self.norm = norm
+        self.nhead = nhead
+        self.rel_encoder = nn.Linear(d_rel, nhead)
+
+    def forward(self, g, ng, gdir, pos, rel):
+        ng = ng + pos.unsqueeze(0)
+        bias = self.rel_encoder(rel).permute(2, 0, 1)   # [H, i, j]
+        for i, layer in enumerate(self.layers):
+            g, ng = layer(g, ng, gdir, bias if i == 0 else None)
+        if self.norm is not None:
+            ng = self.norm(ng)
+        return g, ng
+
+
+class TransformerModel(nn.Module):
+    """reference SEActor.py:170-287 (actor head: output_size = 3, critic head: output_size = 1)."""
+
+    def __init__(self, feature_size, output_size, ninp, nhead, nhid, nlayers, dropout=0.0, condition_decoder=False,
+                 transformer_norm=False, num_positions=0, rel_size=1):
+        super().__init__()
+        self.model_type = "Structure"
+        self.pos_encoder = ConcatPositionalEmbedding(ninp, num_positions=num_positions)
+        layer = SubequivariantEncoderLayer(ninp, nhead, nhid)
+        self.transformer_encoder = RepeatTransformerEncoder(
+            layer, nlayers, nhead, norm=nn.LayerNorm(ninp) if transformer_norm else None, d_rel=rel_size)
+        self.g_num = G_NUM
+        ng_feature_size = feature_size - 3 * G_NUM
+        self.g_encoder = nn.Linear(G_NUM, ninp, bias=False)
+        self.encoder = nn.Linear(ng_feature_size, ninp)
+        self.ninp = ninp
+        self.ninp_att = ninp
+        self.condition_decoder = condition_decoder
+        self.gg_proj = nn.Linear(ninp + G_NUM, Z_DIM - 2, bias=False)
+        self.linear1_g = nn.Linear(Z_DIM * Z_DIM, ninp)
+        self.linear2_g = nn.Linear(ninp, ninp)
+        self.linear1_ng = nn.Linear(ninp + ng_feature_size, ninp)
+        self.linear2_ng = nn.Linear(ninp, ninp)
+        self.output_size = output_size
+        if output_size == 1:
+            self.decoder_ng = nn.Linear(2 * ninp, output_size)
+        else:
+            self.decoder_g = nn.Linear(Z_DIM, 1, bias=False)
+            self.linear1_m = nn.Linear(2 * ninp, 2 * ninp)
+            self.linear2_m = nn.Linear(2 * ninp, Z_DIM * Z_DIM)
+            self.g_proj = nn.Linear(ninp + G_NUM, Z_DIM - 2, bias=False)
+        with torch.no_grad():
+            self.encoder.weight.uniform_(-0.1, 0.1)
+            self.g_encoder.weight.uniform_(-0.1, 0.1)
+
+    def forward(self, x, graph):
+        """x: [B, L, feature] (node-major).  Returns [B, L, output_size]."""
+        B, L, _ = x.shape
+        g0 = x[..., :3 * G_NUM].reshape(B, L, G_NUM, 3).transpose(-1, -2)   # [B,L,3,8]
+        n0 = x[..., 3 * G_NUM:]
+        gdir = g0[..., 1:3]
+        scale = math.sqrt(self.ninp)
+        g = self.g_encoder(g0) * scale
+        ng = self.encoder(n0) * scale
+        pos = self.pos_encoder(graph["traversals"])
+        g, ng = self.transformer_encoder(g, ng, gdir, pos, graph["relation"])
+        out_ng = torch.cat([n0, ng], dim=-1)
+        out_g = torch.cat([g0, g], dim=-1)
+        inv, fn = _invariants(out_g, gdir, self.gg_proj, self.linear1_g, self.linear2_g)
+        hng = self.linear2_ng(F.relu(self.linear1_ng(out_ng)))
+        c = torch.cat([inv, hng], dim=-1)
+        if self.output_size == 1:
+            return self.decoder_ng(c) / fn
+        mat = (self.linear2_m(F.relu(self.linear1_m(c))) / fn).view(B, L, Z_DIM, Z_DIM)
+        zh = torch.cat([self.g_proj(out_g), gdir], dim=-1)
+        vec = self.decoder_g(torch.einsum("blsa,blac->blsc", zh, mat)).squeeze(-1)   # [B,L,3]
+        return torch.einsum("blsk,bls->blk", g0[..., 5:8], vec)
+
+
+class SEPolicy(nn.Module):
+    """Drop-in for reference SEActor.SEPolicy (constructor signature of SEActor.py:293-305)."""
+
+    def __init__(self, state_dim, action_dim, msg_dim, batch_size, max_action, max_children, disable_fold, td, bu,
+                 args=None, device=None, use_hip=True):
+        super().__init__()
+        self.num_limbs = 1
+        self.max_action = max_action
+        self.msg_dim, self.batch_size, self.max_children = msg_dim, batch_size, max_children
+        self.disable_fold = disable_fold
+        self.state_dim, self.action_dim = state_dim, action_dim
+        self.actor = TransformerModel(
+            state_dim, action_dim, args.attention_embedding_size, args.attention_heads, args.attention_hidden_size,
+            args.attention_layers, args.dropout_rate, condition_decoder=args.condition_decoder_on_features,
+            transformer_norm=args.transformer_norm, num_positions=len(args.traversal_types), rel_size=args.rel_size)
+        if device is not None:
+            self.actor.to(device)
+        self.use_hip = use_hip
+        self.graph = None
+        self._hip = None
+
+    def clear_buffer(self):
+        self.action = None
+        self.input_state = None
+
+    def change_morphology(self, graph):
+        self.graph = graph
+        self.parents = graph["parents"]
+        self.num_limbs = len(self.parents)
+
+    def forward(self, state, mode="train"):
+        self.clear_buffer()
+        B = state.shape[0]
+        if self.use_hip and state.is_cuda and not torch.is_grad_enabled():
+            from .set_hip import HipSetActor   # raises SgrlError when the extension is missing (no fallback)
+            if self._hip is None:
+                self._hip = HipSetActor(self)
+            return self._hip.forward_single(state, self.graph)
+        x = state.reshape(B, self.num_limbs, -1)
+        act = self.max_action * torch.tanh(self.actor(x, self.graph))
+        self.action = act.reshape(B, -1)
+        return self.action
+
+
+def default_args(**over):
+    """The reference's SET hyper-parameters (reference arguments.py:180-225, configs/3d.py)."""
+    import types
+    a = types.SimpleNamespace(attention_embedding_size=128, attention_heads=2, attention_hidden_size=256,
+                              attention_layers=3, dropout_rate=0.0, condition_decoder_on_features=0, transformer_norm=1,
+                              traversal_types=["pre", "inlcrs", "postlcrs"], rel_size=3)
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+def make_policy(device=None, use_hip=True, max_action=1.0):
+    return SEPolicy(41, 3, 32, 1, max_action, 3, True, False, False, default_args(), device=device, use_hip=use_hip)
