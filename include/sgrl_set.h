@@ -1,0 +1,81 @@
+/* sgrl_set.h -- C ABI of the SET (subequivariant transformer) actor forward in libsgrl_hip.so.
+ *
+ * Replaces, for inference under torch.no_grad(), the chain
+ *   Agent.select_action                 reference src/agent.py:189-198
+ *   -> SEPolicy.forward                 reference src/SEActor.py:334-347
+ *   -> TransformerModel.forward         reference src/SEActor.py:237-287
+ *   -> RepeatTransformerEncoder.forward reference src/SEActor.py:138-167
+ *   -> MyTransformerEncoderLayer.forward reference src/SEActor.py:82-125
+ *   -> multi_head_attention_forward     reference src/subequivariant_attentions.py:4-154
+ * for a whole batch of environments of mixed morphologies in one call: every per-node linear layer runs over the
+ * nodes of ALL morphologies at once (weights are shared), attention runs per environment over its own limbs.
+ *
+ * Weights: one device float buffer + a host table of SGRL_SET_NW offsets (in floats) in the slot order below.
+ * Layout conventions of the packed tensors (sgrl_amd/set_hip.py does the packing from an nn.Module state_dict):
+ *   Linear weights are row-major [out, in] exactly as torch stores them, except
+ *     QKV_W  = rows of q_proj (pre-multiplied by (2*head_dim)^-0.5), k_proj, v_proj stacked -> [768, 256]; QKV_B alike
+ *     VG_W   = vg_proj.weight padded with 4 zero rows -> [256, 128]
+ *     L1NG_W = linear1_ng.weight padded with 15 zero columns -> [128, 160]
+ */
+#ifndef SGRL_SET_H
+#define SGRL_SET_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sgrl_set sgrl_set;
+
+/* global slots */
+enum {
+  SGRL_SET_EMB0 = 0, SGRL_SET_EMB1, SGRL_SET_EMB2, SGRL_SET_REL_W, SGRL_SET_REL_B, SGRL_SET_FNORM_W, SGRL_SET_FNORM_B,
+  SGRL_SET_GENC, SGRL_SET_ENC_W, SGRL_SET_ENC_B, SGRL_SET_GGPROJ, SGRL_SET_L1G_W, SGRL_SET_L1G_B, SGRL_SET_L2G_W,
+  SGRL_SET_L2G_B, SGRL_SET_L1NG_W, SGRL_SET_L1NG_B, SGRL_SET_L2NG_W, SGRL_SET_L2NG_B, SGRL_SET_DECG, SGRL_SET_L1M_W,
+  SGRL_SET_L1M_B, SGRL_SET_L2M_W, SGRL_SET_L2M_B, SGRL_SET_GPROJ,
+  SGRL_SET_NGLOBAL
+};
+/* per-layer slots (slot = SGRL_SET_NGLOBAL + layer * SGRL_SET_NLAYER + k) */
+enum {
+  SGRL_SET_A_GPROJ = 0, SGRL_SET_A_LG1_W, SGRL_SET_A_LG1_B, SGRL_SET_A_LG2_W, SGRL_SET_A_LG2_B, SGRL_SET_QKV_W,
+  SGRL_SET_QKV_B, SGRL_SET_VG_W, SGRL_SET_NGOUT_W, SGRL_SET_NGOUT_B, SGRL_SET_GOUT_W, SGRL_SET_F_GPROJ2,
+  SGRL_SET_F_GPROJ3, SGRL_SET_F_LG1_W, SGRL_SET_F_LG1_B, SGRL_SET_F_LG2_W, SGRL_SET_F_LG2_B, SGRL_SET_L3_W,
+  SGRL_SET_L3_B, SGRL_SET_L4_W, SGRL_SET_L4_B, SGRL_SET_L5_W, SGRL_SET_L1_W, SGRL_SET_L1_B, SGRL_SET_L2_W,
+  SGRL_SET_L2_B, SGRL_SET_N1_W, SGRL_SET_N1_B, SGRL_SET_N2_W, SGRL_SET_N2_B,
+  SGRL_SET_NLAYER
+};
+#define SGRL_SET_LAYERS 3
+#define SGRL_SET_NW (SGRL_SET_NGLOBAL + SGRL_SET_LAYERS * SGRL_SET_NLAYER)
+
+int sgrl_set_create(sgrl_set** out);
+void sgrl_set_destroy(sgrl_set* s);
+
+/* w: DEV float buffer (kept by reference: the caller keeps it alive); offsets: HOST int64[SGRL_SET_NW]. */
+int sgrl_set_weights(sgrl_set* s, const float* w, const int64_t* offsets, int n_offsets);
+
+/* Batch structure (SEPolicy.change_morphology for every morphology at once, reference SEActor.py:349-355):
+ *   n_morph, morph_L[n_morph] limbs, morph_count[n_morph] envs per morphology (env blocks in this order),
+ *   trav: HOST int32, per morphology 3*L traversal indices (pre, inlcrs, postlcrs), concatenated,
+ *   rel:  HOST float, per morphology L*L*3 relation tensor (graph_dict['relation']), concatenated. */
+int sgrl_set_graph(sgrl_set* s, int n_morph, const int32_t* morph_L, const int32_t* morph_count, const int32_t* trav,
+                   const float* rel);
+
+/* actions[e, 0:3*L_e] = max_action * tanh(actor(obs[e, 0:41*L_e])), rest of the row zero.
+ * obs: DEV float [n_env, obs_ld]; act: DEV float [n_env, act_ld]. */
+int sgrl_set_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_ld, float max_action, void* stream);
+
+int sgrl_set_num_nodes(const sgrl_set* s);
+int64_t sgrl_set_workspace_bytes(const sgrl_set* s);
+/* Time `reps` forwards with HIP events on `stream` (mean ms per forward). */
+int sgrl_set_time_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_ld, float max_action,
+                          int reps, void* stream, float* ms_out);
+/* Debug/parity: copy an intermediate buffer of the LAST forward to the host.  which: 0 g[N,3,128], 1 cat[N,256]
+ * (inv | ng), 2 gram[N,1024], 3 fn[N], 4 qkv[N,768], 5 attng[N,256], 6 attg[N,3,256], 7 mat[N,1024]. */
+int sgrl_set_peek(sgrl_set* s, int which, float* host, int64_t n_floats);
+const char* sgrl_set_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGRL_SET_H */

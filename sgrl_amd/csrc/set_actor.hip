@@ -1,0 +1,633 @@
+// set_actor.hip -- SET actor forward for gfx950 (C ABI: include/sgrl_set.h).
+//
+// All per-node linear layers are batched over the nodes of every morphology (weights are shared) and run on
+// the f32-input matrix cores (v_mfma_f32_32x32x2_f32: exact f32, so results track the reference's f32 PyTorch
+// arithmetic); the per-limb 3x32 Gram invariants, the 3x32 . 32x32 equivariant updates, the per-environment
+// limb attention (<= 14 keys) and layer norms are wave-reduced VALU kernels.
+//
+// Node order: environments in batch order, limbs of one environment contiguous.  Buffers (float32, N = nodes):
+//   g    [N,3,128]  equivariant stream           cat  [N,256] = [invariants | ng]  (ng lives in cat[:,128:])
+//   gram [N,1024]   Z'Z                          fn   [N]      ||Z'Z||_F + 1
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sgrl.h"
+#include "../../include/sgrl_set.h"
+
+namespace {
+
+thread_local std::string g_set_err;
+int sfail(int code, const std::string& msg) { g_set_err = msg; return code; }
+#define SHIP_TRY(expr)                                                                     \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) return sfail(SGRL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int D = 128;
+constexpr int ZD = 32;
+
+// ------------------------------------------------------------------------------------------------
+// f32 MFMA GEMM:  C[M,N] = epi(A[M,K] . W[N,K]^T)      block tile 128x128x32, 4 waves of 64x64
+enum { EPI_RELU = 1, EPI_ROWDIV = 2, EPI_ACC2 = 4 };
+constexpr int BM = 128, BN = 128, BK = 32, LDT = 130;
+
+struct GemmArgs {
+  const float* A; int lda;
+  const float* W; int ldw;
+  const float* bias;
+  float* C; int ldc;
+  int M, N, K;
+  int flags;
+  const float* rowdiv;  // [M]: C = (A.W^T + b) / rowdiv[m]
+  float* C2; int ldc2;  // EPI_ACC2: C2[m][n] += value
+};
+
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
+  __shared__ float As[2][BK][LDT];
+  __shared__ float Ws[2][BK][LDT];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware tile order: consecutive row-tiles that share a column tile land on the same XCD's L2
+  const int tiles_n = (a.N + BN - 1) / BN;
+  // blocks b and b+8 share an XCD (round-robin dispatch): renumber so that each XCD works on a contiguous run of
+  // tiles, i.e. the column tiles of one row tile re-read the same A rows out of ONE L2 (speed only, never correctness)
+  int bid;
+  {
+    const int nt = gridDim.x, per = nt >> 3, rem = nt & 7, x = blockIdx.x & 7, i = blockIdx.x >> 3;
+    bid = (x < rem) ? x * (per + 1) + i : rem * (per + 1) + (x - rem) * per + i;
+  }
+  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kq = t & 7, r0 = t >> 3;
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+  float4 ra[4], rw[4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int row = r0 + 32 * i;
+      const int m = m0 + row, n = n0 + row;
+      ra[i] = (m < a.M) ? *reinterpret_cast<const float4*>(a.A + (size_t)m * a.lda + k0 + 4 * kq) : make_float4(0, 0, 0, 0);
+      rw[i] = (n < a.N) ? *reinterpret_cast<const float4*>(a.W + (size_t)n * a.ldw + k0 + 4 * kq) : make_float4(0, 0, 0, 0);
+    }
+  };
+  auto sstore = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int row = r0 + 32 * i;
+      As[st][4 * kq + 0][row] = ra[i].x; As[st][4 * kq + 1][row] = ra[i].y;
+      As[st][4 * kq + 2][row] = ra[i].z; As[st][4 * kq + 3][row] = ra[i].w;
+      Ws[st][4 * kq + 0][row] = rw[i].x; Ws[st][4 * kq + 1][row] = rw[i].y;
+      Ws[st][4 * kq + 2][row] = rw[i].z; Ws[st][4 * kq + 3][row] = rw[i].w;
+    }
+  };
+  const int nk = a.K / BK;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  const int li = lane & 31, lh = lane >> 5;
+  for (int kt = 0; kt < nk; kt++) {
+    const int st = kt & 1;
+    if (kt + 1 < nk) gload((kt + 1) * BK);
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; kk++) {
+      const int ka = 2 * kk + lh;
+      const float a0 = As[st][ka][wm * 64 + li], a1 = As[st][ka][wm * 64 + 32 + li];
+      const float b0 = Ws[st][ka][wn * 64 + li], b1 = Ws[st][ka][wn * 64 + 32 + li];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (kt + 1 < nk) sstore(st ^ 1);
+    __syncthreads();
+  }
+  // epilogue: C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int ti = 0; ti < 2; ti++) {
+#pragma unroll
+    for (int tj = 0; tj < 2; tj++) {
+      const int n = n0 + wn * 64 + tj * 32 + li;
+      if (n >= a.N) continue;
+      const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int m = m0 + wm * 64 + ti * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (m >= a.M) continue;
+        float v = acc[ti][tj][e] + bv;
+        if (a.flags & EPI_RELU) v = fmaxf(v, 0.f);
+        if (a.flags & EPI_ROWDIV) v = v / a.rowdiv[m];
+        a.C[(size_t)m * a.ldc + n] = v;
+        if (a.flags & EPI_ACC2) a.C2[(size_t)m * a.ldc2 + n] += v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum_f32(float v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// embed: one 128-thread block per node (thread = channel)
+struct NodeTab {
+  const int32_t* node_env;    // [N]
+  const int32_t* node_limb;   // [N]
+  const int32_t* node_mnode;  // [N] index into the per-morphology node tables (trav)
+  const int32_t* trav;        // [3][TM]
+  int TM;
+};
+__global__ __launch_bounds__(128) void k_embed(const float* __restrict__ obs, int obs_ld, NodeTab nt, const float* Wge,
+                                               const float* We, const float* be, const float* e0, const float* e1,
+                                               const float* e2, float* g, float* cat, float* outg, float* outng,
+                                               float* gdir) {
+  __shared__ float o[41];
+  const int n = blockIdx.x, c = threadIdx.x;
+  const int env = nt.node_env[n], limb = nt.node_limb[n], mn = nt.node_mnode[n];
+  if (c < 41) o[c] = obs[(size_t)env * obs_ld + 41 * limb + c];
+  __syncthreads();
+  const float sc = sqrtf(128.f);
+  for (int s = 0; s < 3; s++) {
+    float v = 0.f;
+    for (int j = 0; j < 8; j++) v += Wge[c * 8 + j] * o[3 * j + s];
+    g[((size_t)n * 3 + s) * D + c] = v * sc;
+  }
+  float v = be[c];
+  for (int j = 0; j < 17; j++) v += We[c * 17 + j] * o[24 + j];
+  float pos;
+  if (c < 42) pos = e0[nt.trav[mn] * 42 + c];
+  else if (c < 84) pos = e1[nt.trav[nt.TM + mn] * 42 + (c - 42)];
+  else pos = e2[nt.trav[2 * nt.TM + mn] * 44 + (c - 84)];
+  cat[(size_t)n * 256 + 128 + c] = v * sc + pos;
+  if (c < 24) { const int s = c / 8, j = c % 8; outg[((size_t)n * 3 + s) * 136 + j] = o[3 * j + s]; }
+  if (c < 17) outng[(size_t)n * 160 + c] = o[24 + c];
+  if (c >= 17 && c < 32) outng[(size_t)n * 160 + 128 + c] = 0.f;  // cols 145..159
+  if (c < 6) { const int s = c / 2, e = c % 2; gdir[((size_t)n * 3 + s) * 2 + e] = o[3 * (1 + e) + s]; }
+}
+
+// proj + gram: 8 nodes per 256-thread block.  Z = [X.Wp^T | gdir] (3x32); gram = Z'Z; fn = ||gram||_F + 1.
+// Optional second projection Wq -> Z2 (kept for the equivariant update).
+constexpr int PG_NODES = 8;
+__global__ __launch_bounds__(256) void k_proj_gram(const float* __restrict__ X, int ldx, int C, const float* __restrict__ Wp,
+                                                   const float* __restrict__ Wq, const float* __restrict__ gdir,
+                                                   float* gram, float* fn, float* Z2, int N) {
+  extern __shared__ float sm[];
+  float* Xs = sm;                         // [8][3][C]
+  float* Wps = Xs + PG_NODES * 3 * C;     // [30][C+1]
+  float* Wqs = Wps + 30 * (C + 1);        // [30][C+1] (only if Wq)
+  float* Zs = Wqs + (Wq ? 30 * (C + 1) : 0);  // [8][3][32]
+  float* red = Zs + PG_NODES * 96;        // [8][4]
+  const int t = threadIdx.x, n0 = blockIdx.x * PG_NODES;
+  const int nn = min(PG_NODES, N - n0);
+  for (int i = t; i < PG_NODES * 3 * C; i += 256) {
+    const int row = i / C, c = i % C;
+    Xs[i] = (row < nn * 3) ? X[((size_t)n0 * 3 + row) * ldx + c] : 0.f;
+  }
+  for (int i = t; i < 30 * C; i += 256) {
+    const int r = i / C, c = i % C;
+    Wps[r * (C + 1) + c] = Wp[i];
+    if (Wq) Wqs[r * (C + 1) + c] = Wq[i];
+  }
+  __syncthreads();
+  for (int i = t; i < PG_NODES * 96; i += 256) {
+    const int node = i / 96, s = (i % 96) / 32, a = i % 32;
+    float v = 0.f, v2 = 0.f;
+    if (a < 30) {
+      const float* x = Xs + (node * 3 + s) * C;
+      const float* w = Wps + a * (C + 1);
+      for (int c = 0; c < C; c++) v += x[c] * w[c];
+      if (Wq) { const float* w2 = Wqs + a * (C + 1); for (int c = 0; c < C; c++) v2 += x[c] * w2[c]; }
+    } else if (node < nn) {
+      v = gdir[((size_t)(n0 + node) * 3 + s) * 2 + (a - 30)];
+      v2 = v;
+    }
+    Zs[i] = v;
+    if (Wq && node < nn) Z2[((size_t)(n0 + node) * 3 + s) * ZD + a] = v2;
+  }
+  __syncthreads();
+  // gram: thread handles outputs t + 256*i; node = i / 4
+  const int wave = t >> 6;
+  for (int node = 0; node < PG_NODES; node++) {
+    float sq = 0.f;
+    const float* z = Zs + node * 96;
+    for (int q = 0; q < 4; q++) {
+      const int o = t + 256 * q, aa = o >> 5, bb = o & 31;
+      const float v = z[aa] * z[bb] + z[32 + aa] * z[32 + bb] + z[64 + aa] * z[64 + bb];
+      if (node < nn) gram[(size_t)(n0 + node) * 1024 + o] = v;
+      sq += v * v;
+    }
+    sq = wave_sum_f32(sq);
+    if ((t & 63) == 0) red[node * 4 + wave] = sq;
+  }
+  __syncthreads();
+  if (t < nn) fn[n0 + t] = sqrtf((red[t * 4] + red[t * 4 + 1]) + (red[t * 4 + 2] + red[t * 4 + 3])) + 1.0f;
+}
+
+// relation bias per morphology: relb[off + (h*L + i)*L + j] = rel_encoder(relation[i,j])[h]
+__global__ void k_relbias(const float* rel, const float* Wr, const float* br, float* relb, const int32_t* m_off,
+                          const int32_t* m_L, int n_morph) {
+  const int k = blockIdx.x;
+  if (k >= n_morph) return;
+  const int L = m_L[k], off = m_off[k];
+  for (int i = threadIdx.x; i < 2 * L * L; i += blockDim.x) {
+    const int h = i / (L * L), ij = i % (L * L);
+    const float* r = rel + (size_t)(off / 2) * 3 + ij * 3;  // rel offset = sum L^2 * 3 ; relb offset = sum 2 L^2
+    relb[off + i] = Wr[h * 3] * r[0] + Wr[h * 3 + 1] * r[1] + Wr[h * 3 + 2] * r[2] + br[h];
+  }
+}
+
+// attention: one 256-thread block per environment
+struct EnvTab {
+  const int32_t* env_off;   // [n_env] first node
+  const int32_t* env_L;     // [n_env]
+  const int32_t* env_relb;  // [n_env] offset into relb
+};
+__global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv, const float* __restrict__ vg,
+                                                   const float* __restrict__ gdir, const float* relb, EnvTab et,
+                                                   int use_bias, float* attng, float* attg) {
+  __shared__ float sc[2 * 14 * 14];
+  const int e = blockIdx.x, t = threadIdx.x;
+  const int n0 = et.env_off[e], L = et.env_L[e];
+  for (int idx = t; idx < 2 * L * L; idx += 256) {
+    const int h = idx / (L * L), i = (idx / L) % L, j = idx % L;
+    const float4* q = reinterpret_cast<const float4*>(qkv + (size_t)(n0 + i) * 768 + h * 128);
+    const float4* k = reinterpret_cast<const float4*>(qkv + (size_t)(n0 + j) * 768 + 256 + h * 128);
+    float s = 0.f;
+    for (int d = 0; d < 32; d++) { const float4 a = q[d], b = k[d]; s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+    if (use_bias) s += relb[et.env_relb[e] + idx];
+    sc[idx] = s;
+  }
+  __syncthreads();
+  if (t < 2 * L) {
+    float* row = sc + t * L;
+    float mx = row[0];
+    for (int j = 1; j < L; j++) mx = fmaxf(mx, row[j]);
+    float sum = 0.f;
+    for (int j = 0; j < L; j++) { row[j] = expf(row[j] - mx); sum += row[j]; }
+    for (int j = 0; j < L; j++) row[j] = row[j] / sum;
+  }
+  __syncthreads();
+  for (int idx = t; idx < L * 256; idx += 256) {
+    const int i = idx >> 8, col = idx & 255, h = col >> 7;
+    const float* w = sc + (h * L + i) * L;
+    float s = 0.f;
+    for (int j = 0; j < L; j++) s += w[j] * qkv[(size_t)(n0 + j) * 768 + 512 + col];
+    attng[(size_t)(n0 + i) * 256 + col] = s;
+  }
+  for (int idx = t; idx < L * 768; idx += 256) {
+    const int i = idx / 768, s3 = (idx % 768) >> 8, col = idx & 255, h = col >> 7, d = col & 127;
+    const float* w = sc + (h * L + i) * L;
+    float s = 0.f;
+    if (d < 126) {
+      for (int j = 0; j < L; j++) s += w[j] * vg[((size_t)(n0 + j) * 3 + s3) * 256 + h * 126 + d];
+    } else {
+      for (int j = 0; j < L; j++) s += w[j] * gdir[((size_t)(n0 + j) * 3 + s3) * 2 + (d - 126)];
+    }
+    attg[((size_t)(n0 + i) * 3 + s3) * 256 + col] = s;
+  }
+}
+
+// y = LayerNorm(x + delta) over 128 channels; one wave per row (2 channels per lane)
+__global__ __launch_bounds__(256) void k_add_ln(const float* x, int ldx, const float* delta, int ldd, const float* w,
+                                                const float* b, float* out1, int ld1, float* out2, int ld2, int N) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= N) return;
+  float v0 = x[(size_t)row * ldx + lane], v1 = x[(size_t)row * ldx + 64 + lane];
+  if (delta) { v0 += delta[(size_t)row * ldd + lane]; v1 += delta[(size_t)row * ldd + 64 + lane]; }
+  const float mu = wave_sum_f32(v0 + v1) * (1.f / 128.f);
+  const float d0 = v0 - mu, d1 = v1 - mu;
+  const float var = wave_sum_f32(d0 * d0 + d1 * d1) * (1.f / 128.f);
+  const float inv = 1.0f / sqrtf(var + 1e-5f);
+  const float y0 = d0 * inv * w[lane] + b[lane], y1 = d1 * inv * w[64 + lane] + b[64 + lane];
+  if (out1) { out1[(size_t)row * ld1 + lane] = y0; out1[(size_t)row * ld1 + 64 + lane] = y1; }
+  if (out2) { out2[(size_t)row * ld2 + lane] = y0; out2[(size_t)row * ld2 + 64 + lane] = y1; }
+}
+
+// g[n][s][:] += ((Z[n][s][:] . mat[n]) . W5^T)     4 nodes per 128-thread block
+__global__ __launch_bounds__(128) void k_equiv(const float* __restrict__ Z, const float* __restrict__ mat,
+                                               const float* __restrict__ W5, float* g, int N) {
+  __shared__ float T[4 * 96];
+  const int t = threadIdx.x, n0 = blockIdx.x * 4;
+  for (int q = 0; q < 3; q++) {
+    const int o = t + 128 * q, node = o / 96, s = (o % 96) / 32, c = o % 32;
+    float v = 0.f;
+    if (n0 + node < N) {
+      const float* z = Z + ((size_t)(n0 + node) * 3 + s) * ZD;
+      const float* m = mat + (size_t)(n0 + node) * 1024 + c;
+      for (int a = 0; a < 32; a++) v += z[a] * m[a * 32];
+    }
+    T[o] = v;
+  }
+  __syncthreads();
+  float w[32];
+  for (int c = 0; c < 32; c++) w[c] = W5[t * 32 + c];
+  for (int node = 0; node < 4; node++) {
+    if (n0 + node >= N) break;
+    for (int s = 0; s < 3; s++) {
+      const float* tt = T + node * 96 + s * 32;
+      float v = 0.f;
+      for (int c = 0; c < 32; c++) v += tt[c] * w[c];
+      g[((size_t)(n0 + node) * 3 + s) * D + t] += v;
+    }
+  }
+}
+
+__global__ void k_copy_g(const float* g, float* outg, int rows) {  // outg[row][8 + c] = g[row][c]
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * D) return;
+  outg[(i >> 7) * 136 + 8 + (i & 127)] = g[i];
+}
+
+// head: vec[s] = ((Zh[s] . mat) . wdec); action_k = max_action * tanh(sum_s axis_k[s] * vec[s]); 32 lanes per node
+__global__ __launch_bounds__(128) void k_head_out(const float* __restrict__ Zh, const float* __restrict__ mat,
+                                                  const float* __restrict__ wdec, const float* __restrict__ obs,
+                                                  int obs_ld, NodeTab nt, float* act, int act_ld, float max_action, int N) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 5), c = threadIdx.x & 31;
+  if (n >= N) return;
+  float vec[3];
+  for (int s = 0; s < 3; s++) {
+    const float* z = Zh + ((size_t)n * 3 + s) * ZD;
+    const float* m = mat + (size_t)n * 1024 + c;
+    float v = 0.f;
+    for (int a = 0; a < 32; a++) v += z[a] * m[a * 32];
+    v *= wdec[c];
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
+    vec[s] = v;
+  }
+  if (c < 3) {
+    const int env = nt.node_env[n], limb = nt.node_limb[n];
+    const float* o = obs + (size_t)env * obs_ld + 41 * limb + 3 * (5 + c);
+    const float a = o[0] * vec[0] + o[1] * vec[1] + o[2] * vec[2];
+    act[(size_t)env * act_ld + 3 * limb + c] = max_action * tanhf(a);
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+struct sgrl_set {
+  const float* w = nullptr;
+  int64_t off[SGRL_SET_NW];
+  bool have_w = false, have_graph = false;
+  int n_env = 0, N = 0, n_morph = 0, TM = 0;
+  // device tables
+  int32_t *d_node_env = nullptr, *d_node_limb = nullptr, *d_node_mnode = nullptr, *d_trav = nullptr;
+  int32_t *d_env_off = nullptr, *d_env_L = nullptr, *d_env_relb = nullptr, *d_m_off = nullptr, *d_m_L = nullptr;
+  float *d_rel = nullptr, *d_relb = nullptr;
+  // workspace
+  float* ws = nullptr;
+  int64_t ws_floats = 0;
+  float *g, *cat, *cat2, *gram, *fn, *h256, *qkv, *vg, *attng, *attg, *g1, *z2, *mat, *t256, *t128a, *t128b, *delta,
+      *outg, *outng, *gdir;
+  const float* W(int slot) const { return w + off[slot]; }
+  const float* WL(int layer, int k) const { return w + off[SGRL_SET_NGLOBAL + layer * SGRL_SET_NLAYER + k]; }
+};
+
+namespace {
+
+void free_graph(sgrl_set* s) {
+  void* ptrs[] = {s->d_node_env, s->d_node_limb, s->d_node_mnode, s->d_trav, s->d_env_off, s->d_env_L, s->d_env_relb,
+                  s->d_m_off, s->d_m_L, s->d_rel, s->d_relb, s->ws};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  s->d_node_env = s->d_node_limb = s->d_node_mnode = s->d_trav = s->d_env_off = s->d_env_L = s->d_env_relb = nullptr;
+  s->d_m_off = s->d_m_L = nullptr;
+  s->d_rel = s->d_relb = s->ws = nullptr;
+  s->have_graph = false;
+}
+
+template <class T>
+int upload(T** dst, const std::vector<T>& v) {
+  if (hipMalloc(dst, sizeof(T) * (v.size() ? v.size() : 1)) != hipSuccess) return -1;
+  if (!v.empty() && hipMemcpy(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
+  return 0;
+}
+
+int launch_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc,
+                int M, int N, int K, int flags = 0, const float* rowdiv = nullptr, float* C2 = nullptr, int ldc2 = 0) {
+  if (K % BK != 0 || (lda & 3) || (ldw & 3)) return sfail(SGRL_ERR_ARG, "gemm: K must be a multiple of 32 and rows 16-byte aligned");
+  GemmArgs a{A, lda, W, ldw, bias, C, ldc, M, N, K, flags, rowdiv, C2, ldc2};
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  hipLaunchKernelGGL(k_gemm, dim3(tiles), dim3(256), 0, st, a);
+  return SGRL_OK;
+}
+
+int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_ld, float max_action, hipStream_t st) {
+  const int N = s->N, N3 = 3 * s->N;
+  NodeTab nt{s->d_node_env, s->d_node_limb, s->d_node_mnode, s->d_trav, s->TM};
+  EnvTab et{s->d_env_off, s->d_env_L, s->d_env_relb};
+  (void)hipMemsetAsync(act, 0, sizeof(float) * (size_t)s->n_env * act_ld, st);
+  hipLaunchKernelGGL(k_relbias, dim3(s->n_morph), dim3(256), 0, st, s->d_rel, s->W(SGRL_SET_REL_W), s->W(SGRL_SET_REL_B),
+                     s->d_relb, s->d_m_off, s->d_m_L, s->n_morph);
+  hipLaunchKernelGGL(k_embed, dim3(N), dim3(128), 0, st, obs, obs_ld, nt, s->W(SGRL_SET_GENC), s->W(SGRL_SET_ENC_W),
+                     s->W(SGRL_SET_ENC_B), s->W(SGRL_SET_EMB0), s->W(SGRL_SET_EMB1), s->W(SGRL_SET_EMB2), s->g, s->cat,
+                     s->outg, s->outng, s->gdir);
+  float* ng = s->cat + 128;
+  auto pg = [&](const float* X, int ldx, int C, const float* Wp, const float* Wq, float* z2) {
+    const size_t sh = sizeof(float) * (PG_NODES * 3 * C + 30 * (C + 1) * (Wq ? 2 : 1) + PG_NODES * 96 + PG_NODES * 4);
+    hipLaunchKernelGGL(k_proj_gram, dim3((N + PG_NODES - 1) / PG_NODES), dim3(256), sh, st, X, ldx, C, Wp, Wq, s->gdir,
+                       s->gram, s->fn, z2, N);
+  };
+  const int lnb = (N + 3) / 4;
+  int rc = SGRL_OK;
+#define G(...) do { rc = launch_gemm(st, __VA_ARGS__); if (rc != SGRL_OK) return rc; } while (0)
+  for (int l = 0; l < SGRL_SET_LAYERS; l++) {
+    // --- attention ---
+    pg(s->g, D, D, s->WL(l, SGRL_SET_A_GPROJ), nullptr, nullptr);
+    G(s->gram, 1024, s->WL(l, SGRL_SET_A_LG1_W), 1024, s->WL(l, SGRL_SET_A_LG1_B), s->h256, 256, N, 256, 1024, EPI_RELU);
+    G(s->h256, 256, s->WL(l, SGRL_SET_A_LG2_W), 256, s->WL(l, SGRL_SET_A_LG2_B), s->cat, 256, N, 128, 256);
+    G(s->cat, 256, s->WL(l, SGRL_SET_QKV_W), 256, s->WL(l, SGRL_SET_QKV_B), s->qkv, 768, N, 768, 256, EPI_ROWDIV, s->fn);
+    G(s->g, D, s->WL(l, SGRL_SET_VG_W), D, nullptr, s->vg, 256, N3, 256, D);
+    hipLaunchKernelGGL(k_attention, dim3(s->n_env), dim3(256), 0, st, s->qkv, s->vg, s->gdir, s->d_relb, et, l == 0 ? 1 : 0,
+                       s->attng, s->attg);
+    G(s->attg, 256, s->WL(l, SGRL_SET_GOUT_W), 256, nullptr, s->g1, D, N3, D, 256, EPI_ACC2, nullptr, s->g, D);
+    G(s->attng, 256, s->WL(l, SGRL_SET_NGOUT_W), 256, s->WL(l, SGRL_SET_NGOUT_B), s->delta, D, N, D, 256);
+    hipLaunchKernelGGL(k_add_ln, dim3(lnb), dim3(256), 0, st, ng, 256, s->delta, D, s->WL(l, SGRL_SET_N1_W),
+                       s->WL(l, SGRL_SET_N1_B), ng, 256, (float*)nullptr, 0, N);
+    // --- equivariant feed-forward ---
+    pg(s->g1, D, D, s->WL(l, SGRL_SET_F_GPROJ2), s->WL(l, SGRL_SET_F_GPROJ3), s->z2);
+    G(s->gram, 1024, s->WL(l, SGRL_SET_F_LG1_W), 1024, s->WL(l, SGRL_SET_F_LG1_B), s->h256, 256, N, 256, 1024, EPI_RELU);
+    G(s->h256, 256, s->WL(l, SGRL_SET_F_LG2_W), 256, s->WL(l, SGRL_SET_F_LG2_B), s->cat, 256, N, 128, 256);
+    G(s->cat, 256, s->WL(l, SGRL_SET_L3_W), 256, s->WL(l, SGRL_SET_L3_B), s->t256, 256, N, 256, 256, EPI_RELU);
+    G(s->t256, 256, s->WL(l, SGRL_SET_L4_W), 256, s->WL(l, SGRL_SET_L4_B), s->mat, 1024, N, 1024, 256, EPI_ROWDIV, s->fn);
+    hipLaunchKernelGGL(k_equiv, dim3((N + 3) / 4), dim3(128), 0, st, s->z2, s->mat, s->WL(l, SGRL_SET_L5_W), s->g, N);
+    G(s->cat, 256, s->WL(l, SGRL_SET_L1_W), 256, s->WL(l, SGRL_SET_L1_B), s->t256, 256, N, 256, 256, EPI_RELU);
+    G(s->t256, 256, s->WL(l, SGRL_SET_L2_W), 256, s->WL(l, SGRL_SET_L2_B), s->delta, D, N, D, 256, EPI_ROWDIV, s->fn);
+    hipLaunchKernelGGL(k_add_ln, dim3(lnb), dim3(256), 0, st, ng, 256, s->delta, D, s->WL(l, SGRL_SET_N2_W),
+                       s->WL(l, SGRL_SET_N2_B), ng, 256, (float*)nullptr, 0, N);
+  }
+  // final norm -> outng[:, 17:145]; head
+  hipLaunchKernelGGL(k_add_ln, dim3(lnb), dim3(256), 0, st, ng, 256, (const float*)nullptr, 0, s->W(SGRL_SET_FNORM_W),
+                     s->W(SGRL_SET_FNORM_B), (float*)nullptr, 0, s->outng + 17, 160, N);
+  hipLaunchKernelGGL(k_copy_g, dim3((N3 * D + 255) / 256), dim3(256), 0, st, s->g, s->outg, N3);
+  pg(s->outg, 136, 136, s->W(SGRL_SET_GGPROJ), s->W(SGRL_SET_GPROJ), s->z2);
+  G(s->gram, 1024, s->W(SGRL_SET_L1G_W), 1024, s->W(SGRL_SET_L1G_B), s->t128a, D, N, D, 1024, EPI_RELU);
+  G(s->t128a, D, s->W(SGRL_SET_L2G_W), D, s->W(SGRL_SET_L2G_B), s->cat2, 256, N, D, D);
+  G(s->outng, 160, s->W(SGRL_SET_L1NG_W), 160, s->W(SGRL_SET_L1NG_B), s->t128b, D, N, D, 160, EPI_RELU);
+  G(s->t128b, D, s->W(SGRL_SET_L2NG_W), D, s->W(SGRL_SET_L2NG_B), s->cat2 + 128, 256, N, D, D);
+  G(s->cat2, 256, s->W(SGRL_SET_L1M_W), 256, s->W(SGRL_SET_L1M_B), s->t256, 256, N, 256, 256, EPI_RELU);
+  G(s->t256, 256, s->W(SGRL_SET_L2M_W), 256, s->W(SGRL_SET_L2M_B), s->mat, 1024, N, 1024, 256, EPI_ROWDIV, s->fn);
+  hipLaunchKernelGGL(k_head_out, dim3((N + 3) / 4), dim3(128), 0, st, s->z2, s->mat, s->W(SGRL_SET_DECG), obs, obs_ld, nt,
+                     act, act_ld, max_action, N);
+#undef G
+  if (hipGetLastError() != hipSuccess) return sfail(SGRL_ERR_HIP, "kernel launch failed in sgrl_set_forward");
+  return SGRL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sgrl_set_create(sgrl_set** out) {
+  if (!out) return sfail(SGRL_ERR_ARG, "out is null");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    *out = nullptr;
+    return sfail(SGRL_ERR_HIP, "no HIP device visible: the SET actor fast path needs an MI355X (there is no CPU fallback)");
+  }
+  *out = new sgrl_set();
+  return SGRL_OK;
+}
+
+void sgrl_set_destroy(sgrl_set* s) {
+  if (!s) return;
+  free_graph(s);
+  delete s;
+}
+
+int sgrl_set_weights(sgrl_set* s, const float* w, const int64_t* offsets, int n_offsets) {
+  if (!s || !w || !offsets || n_offsets != SGRL_SET_NW) return sfail(SGRL_ERR_ARG, "sgrl_set_weights: bad argument");
+  s->w = w;
+  std::memcpy(s->off, offsets, sizeof(int64_t) * SGRL_SET_NW);
+  s->have_w = true;
+  return SGRL_OK;
+}
+
+int sgrl_set_graph(sgrl_set* s, int n_morph, const int32_t* morph_L, const int32_t* morph_count, const int32_t* trav,
+                   const float* rel) {
+  if (!s || n_morph <= 0 || !morph_L || !morph_count || !trav || !rel) return sfail(SGRL_ERR_ARG, "sgrl_set_graph: bad argument");
+  SHIP_TRY(hipDeviceSynchronize());
+  free_graph(s);
+  std::vector<int32_t> node_env, node_limb, node_mnode, env_off, env_L, env_relb, m_off, m_L, travT;
+  int TM = 0, relb_off = 0, env = 0, node = 0;
+  std::vector<int> m_node0;
+  for (int k = 0; k < n_morph; k++) {
+    if (morph_L[k] < 2 || morph_L[k] > 14) return sfail(SGRL_ERR_LIMIT, "limb count must be in [2, 14]");
+    m_node0.push_back(TM);
+    m_off.push_back(relb_off);
+    m_L.push_back(morph_L[k]);
+    TM += morph_L[k];
+    relb_off += 2 * morph_L[k] * morph_L[k];
+  }
+  travT.assign(3 * (size_t)TM, 0);
+  std::vector<float> relv;
+  {
+    size_t tp = 0;
+    for (int k = 0; k < n_morph; k++) {
+      const int L = morph_L[k];
+      for (int q = 0; q < 3; q++)
+        for (int i = 0; i < L; i++) {
+          const int v = trav[tp + q * L + i];
+          if (v < 0 || v >= 15) return sfail(SGRL_ERR_ARG, "traversal index out of range");
+          travT[(size_t)q * TM + m_node0[k] + i] = v;
+        }
+      tp += 3 * (size_t)L;
+    }
+    size_t rp = 0;
+    for (int k = 0; k < n_morph; k++) rp += (size_t)morph_L[k] * morph_L[k] * 3;
+    relv.assign(rel, rel + rp);
+  }
+  for (int k = 0; k < n_morph; k++) {
+    for (int c = 0; c < morph_count[k]; c++) {
+      env_off.push_back(node);
+      env_L.push_back(morph_L[k]);
+      env_relb.push_back(m_off[k]);
+      for (int i = 0; i < morph_L[k]; i++) {
+        node_env.push_back(env);
+        node_limb.push_back(i);
+        node_mnode.push_back(m_node0[k] + i);
+        node++;
+      }
+      env++;
+    }
+  }
+  if (node == 0) return sfail(SGRL_ERR_ARG, "no environments");
+  s->n_env = env; s->N = node; s->n_morph = n_morph; s->TM = TM;
+  bool ok = upload(&s->d_node_env, node_env) == 0 && upload(&s->d_node_limb, node_limb) == 0 &&
+            upload(&s->d_node_mnode, node_mnode) == 0 && upload(&s->d_trav, travT) == 0 &&
+            upload(&s->d_env_off, env_off) == 0 && upload(&s->d_env_L, env_L) == 0 && upload(&s->d_env_relb, env_relb) == 0 &&
+            upload(&s->d_m_off, m_off) == 0 && upload(&s->d_m_L, m_L) == 0 && upload(&s->d_rel, relv) == 0;
+  if (ok) ok = hipMalloc(&s->d_relb, sizeof(float) * relb_off) == hipSuccess;
+  // workspace carve-up (floats per node)
+  const int64_t N = node;
+  const int64_t per_node = 384 /*g*/ + 256 + 256 /*cat, cat2*/ + 1024 /*gram*/ + 1 /*fn*/ + 256 /*h256*/ + 768 /*qkv*/ +
+                           768 /*vg*/ + 256 /*attng*/ + 768 /*attg*/ + 384 /*g1*/ + 96 /*z2*/ + 1024 /*mat*/ + 256 /*t256*/ +
+                           128 + 128 + 128 /*t128a,b,delta*/ + 408 /*outg*/ + 160 /*outng*/ + 6 /*gdir*/;
+  s->ws_floats = per_node * N + 64 * 32;
+  if (ok) ok = hipMalloc(&s->ws, sizeof(float) * s->ws_floats) == hipSuccess;
+  if (!ok) { free_graph(s); return sfail(SGRL_ERR_HIP, "device allocation failed in sgrl_set_graph"); }
+  (void)hipMemset(s->ws, 0, sizeof(float) * s->ws_floats);
+  float* p = s->ws;
+  auto take = [&](int64_t n) { float* r = p; p += (n + 31) & ~int64_t(31); return r; };
+  s->g = take(384 * N); s->cat = take(256 * N); s->cat2 = take(256 * N); s->gram = take(1024 * N); s->fn = take(N);
+  s->h256 = take(256 * N); s->qkv = take(768 * N); s->vg = take(768 * N); s->attng = take(256 * N); s->attg = take(768 * N);
+  s->g1 = take(384 * N); s->z2 = take(96 * N); s->mat = take(1024 * N); s->t256 = take(256 * N); s->t128a = take(128 * N);
+  s->t128b = take(128 * N); s->delta = take(128 * N); s->outg = take(408 * N); s->outng = take(160 * N); s->gdir = take(6 * N);
+  if (p - s->ws > s->ws_floats) { free_graph(s); return sfail(SGRL_ERR_LIMIT, "workspace carve-up overflow"); }
+  SHIP_TRY(hipDeviceSynchronize());
+  s->have_graph = true;
+  return SGRL_OK;
+}
+
+int sgrl_set_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_ld, float max_action, void* stream) {
+  if (!s || !obs || !act) return sfail(SGRL_ERR_ARG, "sgrl_set_forward: null argument");
+  if (!s->have_w || !s->have_graph) return sfail(SGRL_ERR_ARG, "sgrl_set_forward: weights or graph not set");
+  return run_forward(s, obs, obs_ld, act, act_ld, max_action, (hipStream_t)stream);
+}
+
+int sgrl_set_time_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_ld, float max_action,
+                          int reps, void* stream, float* ms_out) {
+  if (!s || !obs || !act || !ms_out || reps <= 0) return sfail(SGRL_ERR_ARG, "sgrl_set_time_forward: bad argument");
+  if (!s->have_w || !s->have_graph) return sfail(SGRL_ERR_ARG, "weights or graph not set");
+  hipEvent_t t0, t1;
+  SHIP_TRY(hipEventCreate(&t0));
+  SHIP_TRY(hipEventCreate(&t1));
+  SHIP_TRY(hipEventRecord(t0, (hipStream_t)stream));
+  for (int r = 0; r < reps; r++) {
+    int rc = run_forward(s, obs, obs_ld, act, act_ld, max_action, (hipStream_t)stream);
+    if (rc != SGRL_OK) return rc;
+  }
+  SHIP_TRY(hipEventRecord(t1, (hipStream_t)stream));
+  SHIP_TRY(hipEventSynchronize(t1));
+  float ms = 0;
+  SHIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+  (void)hipEventDestroy(t0);
+  (void)hipEventDestroy(t1);
+  *ms_out = ms / reps;
+  return SGRL_OK;
+}
+
+int sgrl_set_num_nodes(const sgrl_set* s) { return s ? s->N : SGRL_ERR_ARG; }
+int64_t sgrl_set_workspace_bytes(const sgrl_set* s) { return s ? s->ws_floats * 4 : -1; }
+
+int sgrl_set_peek(sgrl_set* s, int which, float* host, int64_t n_floats) {
+  if (!s || !host || !s->have_graph) return sfail(SGRL_ERR_ARG, "sgrl_set_peek: bad argument");
+  const float* src[] = {s->g, s->cat, s->gram, s->fn, s->qkv, s->attng, s->attg, s->mat};
+  const int64_t per[] = {384, 256, 1024, 1, 768, 256, 768, 1024};
+  if (which < 0 || which > 7 || n_floats > per[which] * s->N) return sfail(SGRL_ERR_ARG, "sgrl_set_peek: bad buffer or size");
+  SHIP_TRY(hipDeviceSynchronize());
+  SHIP_TRY(hipMemcpy(host, src[which], sizeof(float) * n_floats, hipMemcpyDeviceToHost));
+  return SGRL_OK;
+}
+
+const char* sgrl_set_last_error(void) { return g_set_err.c_str(); }
+
+}  // extern "C"

@@ -1,0 +1,192 @@
+"""Python front-end of the HIP SET-actor forward (C ABI: include/sgrl_set.h).
+
+`HipSetActor` packs the parameters of an `SEPolicy` (set_policy.py, reference-compatible state_dict) into the flat
+device buffer the kernels expect, re-packing automatically when the parameters change (optimizer steps bump the
+tensors' version counters), describes the batch structure (morphologies x env counts) to the engine and runs
+`actions = max_action * tanh(actor(obs))` for all environments in one call.  No CPU fallback: a missing extension
+or device raises `SgrlError`.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+NGLOBAL, NLAYER, LAYERS = 25, 30, 3
+NW = NGLOBAL + LAYERS * NLAYER
+
+
+def _bind(L):
+    if getattr(L, "_set_bound", False):
+        return
+    vp = ctypes.c_void_p
+    L.sgrl_set_create.argtypes = [ctypes.POINTER(vp)]
+    L.sgrl_set_destroy.argtypes = [vp]
+    L.sgrl_set_destroy.restype = None
+    L.sgrl_set_weights.argtypes = [vp, vp, vp, ctypes.c_int]
+    L.sgrl_set_graph.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp]
+    L.sgrl_set_forward.argtypes = [vp, vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_float, vp]
+    L.sgrl_set_time_forward.argtypes = [vp, vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, vp,
+                                        ctypes.POINTER(ctypes.c_float)]
+    L.sgrl_set_num_nodes.argtypes = [vp]
+    L.sgrl_set_workspace_bytes.argtypes = [vp]
+    L.sgrl_set_workspace_bytes.restype = ctypes.c_int64
+    L.sgrl_set_peek.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int64]
+    L.sgrl_set_last_error.restype = ctypes.c_char_p
+    L._set_bound = True
+
+
+def _check(L, rc, what):
+    if rc != 0:
+        raise _lib.SgrlError("%s failed (%d): %s" % (what, rc, L.sgrl_set_last_error().decode()))
+
+
+def pack_tensors(sd, prefix="actor."):
+    """[(tensor float32, ...)] in slot order (include/sgrl_set.h) from a state_dict-like mapping of torch tensors."""
+    g = lambda k: sd[prefix + k].detach().float()
+    out = [None] * NW
+    out[0:3] = [g("pos_encoder.embeddings.%d.weight" % i) for i in range(3)]
+    out[3], out[4] = g("transformer_encoder.rel_encoder.weight"), g("transformer_encoder.rel_encoder.bias")
+    out[5], out[6] = g("transformer_encoder.norm.weight"), g("transformer_encoder.norm.bias")
+    out[7], out[8], out[9] = g("g_encoder.weight"), g("encoder.weight"), g("encoder.bias")
+    out[10] = g("gg_proj.weight")
+    out[11], out[12], out[13], out[14] = g("linear1_g.weight"), g("linear1_g.bias"), g("linear2_g.weight"), g("linear2_g.bias")
+    w = g("linear1_ng.weight")
+    out[15] = torch.cat([w, w.new_zeros(w.shape[0], 160 - w.shape[1])], dim=1)
+    out[16], out[17], out[18] = g("linear1_ng.bias"), g("linear2_ng.weight"), g("linear2_ng.bias")
+    out[19] = g("decoder_g.weight").reshape(-1)
+    out[20], out[21], out[22], out[23] = g("linear1_m.weight"), g("linear1_m.bias"), g("linear2_m.weight"), g("linear2_m.bias")
+    out[24] = g("g_proj.weight")
+    scaling = float(128) ** -0.5   # (2 * head_dim)^-0.5, reference subequivariant_attentions.py:88
+    for l in range(LAYERS):
+        p = "transformer_encoder.layers.%d." % l
+        a = p + "self_attn."
+        b = NGLOBAL + l * NLAYER
+        vg = g(a + "vg_proj.weight")
+        out[b:b + NLAYER] = [
+            g(a + "g_proj.weight"), g(a + "linear_g1.weight"), g(a + "linear_g1.bias"), g(a + "linear_g2.weight"),
+            g(a + "linear_g2.bias"),
+            torch.cat([g(a + "q_proj.weight") * scaling, g(a + "k_proj.weight"), g(a + "v_proj.weight")], 0),
+            torch.cat([g(a + "q_proj.bias") * scaling, g(a + "k_proj.bias"), g(a + "v_proj.bias")], 0),
+            torch.cat([vg, vg.new_zeros(256 - vg.shape[0], vg.shape[1])], 0),
+            g(a + "ng_out.weight"), g(a + "ng_out.bias"), g(a + "g_out.weight"),
+            g(p + "g_proj2.weight"), g(p + "g_proj3.weight"), g(p + "linear_g1.weight"), g(p + "linear_g1.bias"),
+            g(p + "linear_g2.weight"), g(p + "linear_g2.bias"), g(p + "linear3.weight"), g(p + "linear3.bias"),
+            g(p + "linear4.weight"), g(p + "linear4.bias"), g(p + "linear5.weight"), g(p + "linear1.weight"),
+            g(p + "linear1.bias"), g(p + "linear2.weight"), g(p + "linear2.bias"), g(p + "norm1.weight"),
+            g(p + "norm1.bias"), g(p + "norm2.weight"), g(p + "norm2.bias")]
+    return out
+
+
+class HipSetActor(object):
+    def __init__(self, policy, device=None):
+        if not torch.cuda.is_available():
+            raise _lib.SgrlError("HipSetActor needs an MI355X (no CPU fallback)")
+        self.L = _lib.lib()
+        _bind(self.L)
+        self.policy = policy
+        self.device = torch.device(device) if device is not None else next(policy.parameters()).device
+        if self.device.type != "cuda":
+            raise _lib.SgrlError("the SEPolicy must live on the GPU for the HIP path")
+        h = ctypes.c_void_p()
+        _check(self.L, self.L.sgrl_set_create(ctypes.byref(h)), "sgrl_set_create")
+        self.h = h
+        self._wbuf = None
+        self._wver = None
+        self._cfg_key = None
+        self.n_env = 0
+        self.act_ld = 0
+        self._single_cache = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.L.sgrl_set_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- weights ------------------------------------------------------------------------------------
+    def sync_weights(self, force=False):
+        params = list(self.policy.actor.parameters())
+        ver = (tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        if not force and ver == self._wver:
+            return
+        sd = {"actor." + k: v for k, v in self.policy.actor.state_dict().items()}
+        tens = pack_tensors(sd)
+        offs = np.zeros(NW, dtype=np.int64)
+        pos = 0
+        for i, t in enumerate(tens):
+            offs[i] = pos
+            pos += (t.numel() + 63) // 64 * 64    # keep every tensor 256-byte aligned
+        buf = torch.zeros(pos, dtype=torch.float32, device=self.device)
+        for i, t in enumerate(tens):
+            buf[offs[i]:offs[i] + t.numel()] = t.reshape(-1).to(self.device)
+        torch.cuda.synchronize(self.device)
+        self._wbuf = buf
+        _check(self.L, self.L.sgrl_set_weights(self.h, ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(offs.ctypes.data),
+                                               NW), "sgrl_set_weights")
+        self._wver = ver
+
+    # ---- batch structure ------------------------------------------------------------------------------
+    def configure(self, graphs, counts):
+        """graphs: per-morphology dicts with 'traversals' (3 index vectors) and 'relation' [L,L,3]; counts: envs each."""
+        key = (tuple(id(g) for g in graphs), tuple(int(c) for c in counts))
+        if key == self._cfg_key:
+            return
+        Ls, trav, rel = [], [], []
+        for g in graphs:
+            t = [np.asarray(v.cpu() if torch.is_tensor(v) else v, dtype=np.int32) for v in g["traversals"]]
+            Ls.append(len(t[0]))
+            trav.append(np.concatenate(t))
+            r = g["relation"]
+            rel.append(np.asarray(r.detach().cpu() if torch.is_tensor(r) else r, dtype=np.float32).reshape(-1))
+        Ls = np.asarray(Ls, dtype=np.int32)
+        cnt = np.asarray(counts, dtype=np.int32)
+        trav = np.ascontiguousarray(np.concatenate(trav), dtype=np.int32)
+        rel = np.ascontiguousarray(np.concatenate(rel), dtype=np.float32)
+        vp = lambda a: ctypes.c_void_p(a.ctypes.data)
+        _check(self.L, self.L.sgrl_set_graph(self.h, len(Ls), vp(Ls), vp(cnt), vp(trav), vp(rel)), "sgrl_set_graph")
+        self._cfg_key = key
+        self.n_env = int(cnt.sum())
+        self.max_limbs = int(Ls.max())
+        self.num_nodes = self.L.sgrl_set_num_nodes(self.h)
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def forward_batch(self, obs, out=None, act_ld=None):
+        """obs: float32 CUDA [n_env, obs_ld] (rows zero padded beyond 41*L) -> actions float32 [n_env, act_ld]."""
+        assert obs.is_cuda and obs.dtype == torch.float32 and obs.dim() == 2 and obs.stride(1) == 1
+        assert obs.shape[0] == self.n_env
+        self.sync_weights()
+        act_ld = act_ld or 3 * self.max_limbs
+        if out is None:
+            out = torch.empty((self.n_env, act_ld), dtype=torch.float32, device=self.device)
+        assert out.is_contiguous() and out.shape == (self.n_env, act_ld)
+        _check(self.L, self.L.sgrl_set_forward(self.h, ctypes.c_void_p(obs.data_ptr()), int(obs.stride(0)),
+                                               ctypes.c_void_p(out.data_ptr()), int(act_ld),
+                                               ctypes.c_float(float(self.policy.max_action)), self._stream()),
+               "sgrl_set_forward")
+        return out
+
+    def time_forward(self, obs, out, reps):
+        self.sync_weights()
+        ms = ctypes.c_float(0)
+        _check(self.L, self.L.sgrl_set_time_forward(self.h, ctypes.c_void_p(obs.data_ptr()), int(obs.stride(0)),
+                                                    ctypes.c_void_p(out.data_ptr()), int(out.stride(0)),
+                                                    ctypes.c_float(float(self.policy.max_action)), int(reps),
+                                                    self._stream(), ctypes.byref(ms)), "sgrl_set_time_forward")
+        return float(ms.value)
+
+    def forward_single(self, state, graph):
+        """SEPolicy.forward(state [B, 41*L]) for the current morphology (reference agent.py:197)."""
+        B = state.shape[0]
+        self.configure([graph], [B])
+        return self.forward_batch(state.contiguous().float(), act_ld=3 * len(graph["parents"]))
+
+    def peek(self, which, per_node):
+        out = np.zeros((self.num_nodes, per_node), dtype=np.float32)
+        _check(self.L, self.L.sgrl_set_peek(self.h, which, ctypes.c_void_p(out.ctypes.data), out.size), "sgrl_set_peek")
+        return out

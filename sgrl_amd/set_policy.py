@@ -220,6 +220,12 @@ class SEPolicy(nn.Module):
         self.graph = None
         self._hip = None
 
+    def __getstate__(self):
+        # the HIP handle is per-process device state: never pickled / deep-copied with the module
+        d = self.__dict__.copy()
+        d["_hip"] = None
+        return d
+
     def clear_buffer(self):
         self.action = None
         self.input_state = None

@@ -1,0 +1,149 @@
+"""GPU parity of the HIP SET-actor forward (C ABI of include/sgrl_set.h) against the reference-generated golden
+vectors and the NumPy oracle.  float32 arithmetic on the f32 matrix cores: tolerance 2e-5 absolute on tanh-squashed
+actions of magnitude <= 1 (the reference's own f32-vs-f64 gap on these vectors is ~1e-6)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TRAV = ["pre", "inlcrs", "postlcrs"]
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def ctx(golden_dir):
+    import torch
+    assert torch.cuda.is_available()
+    from oracle.formula import apply_formula_
+    from sgrl_amd.set_policy import make_policy
+    with open(os.path.join(golden_dir, "graphs.json")) as f:
+        graphs = json.load(f)
+    with open(os.path.join(golden_dir, "set_state_dict_keys.json")) as f:
+        keys = json.load(f)
+    z = np.load(os.path.join(golden_dir, "set_forward.npz"))
+    pol = make_policy(device="cuda:0", use_hip=True).eval()
+    apply_formula_(pol)
+    return torch, pol, graphs, keys, z
+
+
+def _gd(torch, g, dev="cuda:0"):
+    from sgrl_amd import graph as G
+    return G.getGraphDict(g["parents"], TRAV, [], device=torch.device(dev))
+
+
+def test_module_fast_path_matches_reference_fixtures(ctx):
+    torch, pol, graphs, keys, z = ctx
+    worst = 0.0
+    for name, g in graphs.items():
+        pol.change_morphology(_gd(torch, g))
+        for B in (1, 5):
+            obs = torch.from_numpy(z["%s/B%d/obs" % (name, B)]).cuda()
+            with torch.no_grad():
+                a = pol(obs)
+            assert a.shape == (B, 3 * len(g["parents"])) and a.is_cuda
+            a = a.cpu().numpy()
+            e64 = np.abs(a - z["%s/B%d/act_f64" % (name, B)]).max()
+            e32 = np.abs(a - z["%s/B%d/act_f32" % (name, B)]).max()
+            worst = max(worst, e64)
+            assert e64 < TOL and e32 < TOL, (name, B, e64, e32)
+    assert pol._hip is not None   # the HIP path ran
+    print("worst |hip - ref_f64| = %.3e" % worst)
+
+
+def test_grad_mode_uses_the_differentiable_path_and_agrees(ctx):
+    torch, pol, graphs, keys, z = ctx
+    g = graphs["3d_walker_7_full"]
+    pol.change_morphology(_gd(torch, g))
+    obs = torch.from_numpy(z["3d_walker_7_full/B5/obs"]).cuda()
+    a_grad = pol(obs)
+    assert a_grad.requires_grad
+    with torch.no_grad():
+        a_hip = pol(obs)
+    assert float((a_grad - a_hip).abs().max()) < TOL
+
+
+def test_mixed_morphology_batch_against_numpy_oracle(ctx):
+    torch, pol, graphs, keys, z = ctx
+    from oracle import set_ref
+    from oracle.formula import synth_obs
+    from sgrl_amd.set_hip import HipSetActor
+    names = sorted(n for n in graphs if "walker" in n)
+    assert len(names) == 8
+    counts = [3, 1, 2, 5, 1, 4, 2, 3]
+    gds = [_gd(torch, graphs[n]) for n in names]
+    act = HipSetActor(pol)
+    act.configure(gds, counts)
+    Lmax = max(len(graphs[n]["parents"]) for n in names)
+    obs = np.zeros((sum(counts), 41 * Lmax), dtype=np.float32)
+    rows = []
+    r = 0
+    for k, n in enumerate(names):
+        L = len(graphs[n]["parents"])
+        o = synth_obs(L, counts[k], 500 + k).astype(np.float32)
+        obs[r:r + counts[k], :41 * L] = o
+        rows.append((r, counts[k], L, o))
+        r += counts[k]
+    out = act.forward_batch(torch.from_numpy(obs).cuda()).cpu().numpy()
+    assert out.shape == (sum(counts), 3 * Lmax)
+    sd = set_ref.formula_state_dict(keys, np.float64)
+    for (r0, c, L, o), n in zip(rows, names):
+        ref = set_ref.set_actor_forward(sd, o.astype(np.float64), graphs[n]["traversals"],
+                                        np.array(graphs[n]["relation"], dtype=np.float32).astype(np.float64))
+        assert np.abs(out[r0:r0 + c, :3 * L] - ref).max() < TOL, n
+        assert (out[r0:r0 + c, 3 * L:] == 0).all()
+
+
+def test_full_size_batch_properties(ctx):
+    """8 walkers x 1024 envs: rows equal the single-env forward; gravity-axis rotation invariance; determinism."""
+    torch, pol, graphs, keys, z = ctx
+    from oracle.formula import synth_obs
+    from sgrl_amd.set_hip import HipSetActor
+    names = sorted(n for n in graphs if "walker" in n)
+    gds = [_gd(torch, graphs[n]) for n in names]
+    act = HipSetActor(pol)
+    act.configure(gds, [1024] * 8)
+    obs = np.zeros((8192, 287), dtype=np.float32)
+    for k, n in enumerate(names):
+        L = len(graphs[n]["parents"])
+        obs[1024 * k:1024 * (k + 1), :41 * L] = synth_obs(L, 1024, 900 + k)
+    x = torch.from_numpy(obs).cuda()
+    a0 = act.forward_batch(x).clone()
+    a1 = act.forward_batch(x).clone()
+    assert torch.equal(a0, a1)
+    assert torch.isfinite(a0).all() and float(a0.abs().max()) <= 1.0
+    # rotate every 3-vector about z
+    th = 0.77
+    rz = torch.tensor([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]], dtype=torch.float32).cuda()
+    xr = x.clone().view(8192, 7, 41)
+    xr[..., :24] = (xr[..., :24].reshape(8192, 7, 8, 3) @ rz.T).reshape(8192, 7, 24)
+    a2 = act.forward_batch(xr.view(8192, 287))
+    assert float((a2 - a0).abs().max()) < 5e-5
+    # single rows through the module surface
+    for i in (0, 1023, 4096, 8191):
+        k = i // 1024
+        L = len(graphs[names[k]]["parents"])
+        pol.change_morphology(gds[k])
+        with torch.no_grad():
+            one = pol(x[i:i + 1, :41 * L])
+        assert float((one[0] - a0[i, :3 * L]).abs().max()) < 1e-6
+
+
+def test_weights_are_repacked_after_an_in_place_update(ctx):
+    torch, pol, graphs, keys, z = ctx
+    import copy
+    p2 = copy.deepcopy(pol)
+    p2._hip = None
+    g = graphs["3d_hopper_3_shin"]
+    p2.change_morphology(_gd(torch, g))
+    obs = torch.from_numpy(z["3d_hopper_3_shin/B5/obs"]).cuda()
+    with torch.no_grad():
+        a = p2(obs).clone()
+        p2.actor.decoder_g.weight.mul_(0.5)
+        b = p2(obs).clone()
+    p2.use_hip = False
+    with torch.no_grad():
+        c = p2(obs)
+    assert float((a - b).abs().max()) > 1e-3
+    assert float((b - c).abs().max()) < TOL
