@@ -1,0 +1,106 @@
+"""Batched rollout driver: the build's counterpart of the reference's per-env Python loop
+(`for i in range(num_envs_train): change_morphology; select_action; ...; envs.step`, reference trainer.py:173-236
+and the random-action warm-up loop trainer.py:90-138), with the same per-environment semantics but ONE engine
+launch and ONE batched SET forward per time step, plus the replay push as a single gather to the learner rank.
+"""
+import numpy as np
+import torch
+
+from . import graph as G
+from .set_hip import HipSetActor
+from .vec_env import BatchedModularVecEnv
+
+TRAV = ["pre", "inlcrs", "postlcrs"]
+
+
+class Rollout(object):
+    """Environments of one rank + the shared SET actor."""
+
+    def __init__(self, env_names, envs_per_morph, policy=None, seed=0, device="cuda:0", rank=0, **env_kw):
+        counts = [envs_per_morph] * len(env_names) if np.isscalar(envs_per_morph) else list(envs_per_morph)
+        n_local = int(sum(counts))
+        self.env = BatchedModularVecEnv(env_names, counts, seed=seed, device=device, env_id_base=rank * n_local, **env_kw)
+        self.device = self.env.device
+        self.policy = policy
+        self.actor = None
+        if policy is not None:
+            self.graph_dicts = [G.getGraphDict(m.parents, TRAV, [], device=self.device) for m in self.env.models]
+            self.actor = HipSetActor(policy, device=self.device)
+            self.actor.configure(self.graph_dicts, counts)
+        n, amax = self.env.num_envs, self.env.action_max_len
+        self.actions = torch.zeros((n, amax), dtype=torch.float32, device=self.device)
+        self.policy_actions = torch.zeros((n, amax), dtype=torch.float32, device=self.device)
+        # padding mask: slots beyond 3*L of each morphology stay zero (reference trainer.py:191-195)
+        self.act_mask = torch.zeros((n, amax), dtype=torch.float32, device=self.device)
+        for k, sl in enumerate(self.env.morph_slices):
+            self.act_mask[sl, :3 * self.env.num_limbs[k]] = 1.0
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(int(seed) * 1000003 + rank)
+        self.obs = None
+
+    def reset(self):
+        self.obs = self.env.reset_device()
+        return self.obs
+
+    def random_actions(self):
+        """i.i.d. U(-1, 1) per slot (reference trainer.py:95-102), zero in the padding slots."""
+        self.actions.uniform_(-1.0, 1.0, generator=self.gen)
+        self.actions.mul_(self.act_mask)
+        return self.actions
+
+    def policy_forward(self, obs=None):
+        """One batched SET forward over every environment (replaces n x Agent.select_action, reference agent.py:189-198)."""
+        return self.actor.forward_batch(self.env.obs if obs is None else obs, out=self.policy_actions,
+                                        act_ld=self.env.action_max_len)
+
+    def add_exploration_noise(self, actions, expl_noise=0.126):
+        """a + N(0, expl_noise) clipped to the action range (reference trainer.py:184-189)."""
+        noise = torch.randn(actions.shape, device=self.device, generator=self.gen) * expl_noise
+        return ((actions + noise).clamp_(-1.0, 1.0)) * self.act_mask
+
+    def step(self, actions):
+        return self.env.step_device(actions)
+
+
+class ReplayGather(object):
+    """The replay-buffer push as ONE collective: every rank contributes a fixed-size block of transitions
+    (obs, action, next_obs, reward, done) -- the arguments of ReplayBuffer.add_transition (reference
+    common/buffer.py:75-84) for each of its environments -- and the learner rank receives them all with a single
+    gather (RCCL over xGMI when the backend is 'nccl'; 'gloo' on CPU for tests)."""
+
+    def __init__(self, n_env_local, obs_max_len, action_max_len, device, dst=0):
+        import torch.distributed as dist
+        self.dist = dist
+        self.dst = dst
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.row = 2 * obs_max_len + action_max_len + 2
+        self.o, self.a = obs_max_len, action_max_len
+        self.block = torch.zeros((n_env_local, self.row), dtype=torch.float32, device=device)
+        self.recv = None
+        if self.rank == dst:
+            self.recv = [torch.zeros_like(self.block) for _ in range(self.world)]
+
+    def pack(self, obs, action, next_obs, reward, done):
+        o, a = self.o, self.a
+        b = self.block
+        b[:, :o] = obs
+        b[:, o:o + a] = action
+        b[:, o + a:2 * o + a] = next_obs
+        b[:, 2 * o + a] = reward
+        b[:, 2 * o + a + 1] = done.to(torch.float32)
+        return b
+
+    def push(self):
+        """Returns the list of per-rank blocks on the learner rank, None elsewhere."""
+        if self.world == 1:
+            return [self.block]
+        self.dist.gather(self.block, self.recv if self.rank == self.dst else None, dst=self.dst)
+        return self.recv
+
+    def unpack(self, block):
+        o, a = self.o, self.a
+        return (block[:, :o], block[:, o:o + a], block[:, o + a:2 * o + a], block[:, 2 * o + a], block[:, 2 * o + a + 1])
+
+    def bytes_per_step(self):
+        return self.block.numel() * 4
