@@ -52,11 +52,15 @@ typedef struct {
   /* contacts */
   int ncon;
   double con_pos[MAXCON][3], con_frame[MAXCON][9], con_dist[MAXCON];
-  int con_pair[MAXCON];
+  int con_pair[MAXCON], con_slot[MAXCON];
   /* constraint rows */
   int nrow, nrow_wanted;
   double J[MAXROW][NVM], Y[MAXROW][NVM];
   double efc_R[MAXROW], efc_aref[MAXROW], efc_b[MAXROW], efc_f[MAXROW];
+  int row_key[MAXROW];
+  /* warm start across the evaluations of one call (same constraint -> previous force) */
+  int prev_n, prev_key[MAXROW];
+  double prev_f[MAXROW];
   double pgs_last_change;
   int pgs_iters_used;
 } Work;
@@ -347,20 +351,20 @@ static void make_frame(double* fr) {
   else for (int k = 0; k < 3; k++) fr[3 + k] /= n;
   cross3(fr + 6, fr, fr + 3);
 }
-static void add_contact(Work* w, int pair, double dist, const double* pos, const double* normal, const double* tangent) {
+static void add_contact(Work* w, int pair, int slot, double dist, const double* pos, const double* normal, const double* tangent) {
   if (w->ncon >= MAXCON) return;
   int c = w->ncon++;
-  w->con_pair[c] = pair; w->con_dist[c] = dist;
+  w->con_pair[c] = pair; w->con_slot[c] = slot; w->con_dist[c] = dist;
   for (int k = 0; k < 3; k++) { w->con_pos[c][k] = pos[k]; w->con_frame[c][k] = normal[k]; w->con_frame[c][3 + k] = tangent ? tangent[k] : 0; }
   make_frame(w->con_frame[c]);
 }
-static void plane_sphere(Work* w, int pair, double margin, const double* ppos, const double* n, const double* c, double r, const double* tangent) {
+static void plane_sphere(Work* w, int pair, int slot, double margin, const double* ppos, const double* n, const double* c, double r, const double* tangent) {
   double d[3] = {c[0] - ppos[0], c[1] - ppos[1], c[2] - ppos[2]};
   double dist = dot3(d, n) - r;
   if (dist >= margin) return;
   double pos[3];
   for (int k = 0; k < 3; k++) pos[k] = c[k] - n[k] * (r + 0.5 * dist);
-  add_contact(w, pair, dist, pos, n, tangent);
+  add_contact(w, pair, slot, dist, pos, n, tangent);
 }
 static void collide(const SgrlModelView* m, Work* w) {
   w->ncon = 0;
@@ -373,13 +377,13 @@ static void collide(const SgrlModelView* m, Work* w) {
     if (t1 == SGRL_GEOM_PLANE) {
       double n[3] = {m1[2], m1[5], m1[8]};
       if (t2 == SGRL_GEOM_SPHERE) {
-        plane_sphere(w, p, margin, p1, n, p2, m->geom_size[3 * g2], 0);
+        plane_sphere(w, p, 2 * p, margin, p1, n, p2, m->geom_size[3 * g2], 0);
       } else {
         double ax[3] = {m2[2], m2[5], m2[8]}, h = m->geom_size[3 * g2 + 1], r = m->geom_size[3 * g2];
         double ca[3], cb[3];
         for (int k = 0; k < 3; k++) { ca[k] = p2[k] + ax[k] * h; cb[k] = p2[k] - ax[k] * h; }
-        plane_sphere(w, p, margin, p1, n, ca, r, ax); /* frames aligned with the capsule axis [3P-knowledge] */
-        plane_sphere(w, p, margin, p1, n, cb, r, ax);
+        plane_sphere(w, p, 2 * p, margin, p1, n, ca, r, ax); /* frames aligned with the capsule axis [3P-knowledge] */
+        plane_sphere(w, p, 2 * p + 1, margin, p1, n, cb, r, ax);
       }
     } else { /* capsule - capsule */
       double a1[3] = {m1[2], m1[5], m1[8]}, a2[3] = {m2[2], m2[5], m2[8]};
@@ -402,7 +406,7 @@ static void collide(const SgrlModelView* m, Work* w) {
       if (len < MINVAL) { nn[0] = 1; nn[1] = 0; nn[2] = 0; } else for (int k = 0; k < 3; k++) nn[k] /= len;
       double pos[3];
       for (int k = 0; k < 3; k++) pos[k] = c1[k] + nn[k] * (r1 + 0.5 * dist);
-      add_contact(w, p, dist, pos, nn, 0);
+      add_contact(w, p, 2 * p, dist, pos, nn, 0);
     }
   }
 }
@@ -477,6 +481,7 @@ static void make_constraints(const SgrlModelView* m, const double* qpos, const d
       if (R < MINVAL) R = MINVAL;
       w->efc_R[r] = R;
       w->efc_aref[r] = -B * (-side * qvel[dof]) - K * imp * (dist - margin);
+      w->row_key[r] = ((side < 0 ? 0 : 1) << 16) | (j << 3);
     }
   }
   /* contacts */
@@ -513,6 +518,7 @@ static void make_constraints(const SgrlModelView* m, const double* qpos, const d
       for (int r = r0; r < r0 + nr; r++) w->efc_R[r] = Rpy;
     }
     for (int r = r0; r < r0 + nr; r++) {
+      w->row_key[r] = ((dim == 1 ? 2 : 3) << 16) | (w->con_slot[c] << 3) | (r - r0);
       double vel = 0;
       for (int d = 0; d < nv; d++) vel += w->J[r][d] * qvel[d];
       w->efc_aref[r] = -B * vel - K * imp * (dist - margin);
@@ -526,33 +532,36 @@ static void solve_constraints(const SgrlModelView* m, Work* w) {
   int nv = m->nv, n = w->nrow, iters = m->hdr[SGRL_H_PGS_ITERS];
   for (int d = 0; d < nv; d++) w->qacc[d] = w->qacc_smooth[d];
   w->pgs_last_change = 0;
-  if (n == 0) return;
+  w->pgs_iters_used = 0;
+  if (n == 0) { w->prev_n = 0; return; }
   for (int r = 0; r < n; r++) {
     double s = 0;
     for (int d = 0; d < nv; d++) { s += w->J[r][d] * w->qacc_smooth[d]; w->Y[r][d] = w->J[r][d]; }
     w->efc_b[r] = s - w->efc_aref[r];
     solve_lower(nv, w->L, w->Y[r]);
-    w->efc_f[r] = 0;
+    double f0 = 0;
+    for (int k = 0; k < w->prev_n; k++) if (w->prev_key[k] == w->row_key[r]) f0 = w->prev_f[k];
+    w->efc_f[r] = f0;
   }
   /* v = Y' f maintained incrementally */
   double v[NVM];
-  for (int d = 0; d < nv; d++) v[d] = 0;
-  double diag[MAXROW];
+  for (int d = 0; d < nv; d++) { double s = 0; for (int r = 0; r < n; r++) s += w->Y[r][d] * w->efc_f[r]; v[d] = s; }
+  double diag[MAXROW], idiag[MAXROW];
   for (int r = 0; r < n; r++) {
     double s = 0;
     for (int d = 0; d < nv; d++) s += w->Y[r][d] * w->Y[r][d];
     diag[r] = s + w->efc_R[r];
+    idiag[r] = 1.0 / diag[r];
   }
   double bmax = 0;
   for (int r = 0; r < n; r++) if (fabs(w->efc_b[r]) > bmax) bmax = fabs(w->efc_b[r]);
   const double thresh = m->fhdr[SGRL_F_PGS_TOL] * (1.0 + bmax);
-  w->pgs_iters_used = 0;
   for (int it = 0; it < iters; it++) {
     double change = 0;
     for (int r = 0; r < n; r++) {
       double res = w->efc_b[r] + w->efc_R[r] * w->efc_f[r];
       for (int d = 0; d < nv; d++) res += w->Y[r][d] * v[d];
-      double fn = w->efc_f[r] - res / diag[r];
+      double fn = w->efc_f[r] - res * idiag[r];
       if (fn < 0) fn = 0;
       double df = fn - w->efc_f[r];
       if (df != 0) {
@@ -565,6 +574,8 @@ static void solve_constraints(const SgrlModelView* m, Work* w) {
     w->pgs_iters_used = it + 1;
     if (change < thresh) break;
   }
+  w->prev_n = n;
+  for (int r = 0; r < n; r++) { w->prev_key[r] = w->row_key[r]; w->prev_f[r] = w->efc_f[r]; }
   solve_upper(nv, w->L, v); /* M^-1 J' f = L^-T (Y' f) */
   for (int d = 0; d < nv; d++) w->qacc[d] += v[d];
 }

@@ -6,6 +6,7 @@
 // observation row [env][obs_max_len] is written once with consecutive lanes on consecutive floats.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -38,6 +39,7 @@ struct MorphDev {
 struct BatchArgs {
   const MorphDev* morphs;     // [n_morph]
   const int32_t* env_morph;   // [n_env]
+  const int32_t* block_env;   // [n_env] workgroup -> env, most expensive morphologies first (tail balance)
   double* rec;                // [n_env * stride]
   int32_t* cnt;               // [n_env * 4]
   int stride;
@@ -91,7 +93,7 @@ __device__ __forceinline__ sgrl::StepIO make_io(const BatchArgs& a, const StepOu
 }
 
 __global__ __launch_bounds__(64) void k_env_step(BatchArgs a, StepOut out) {
-  const int env = blockIdx.x;
+  const int env = a.block_env[blockIdx.x];
   SgrlModelView m; sgrl::Layout o; double* S; int32_t* I;
   setup(a, env, &m, &o, &S, &I);
   sgrl::HipWave w;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(64) void k_env_step(BatchArgs a, StepOut out) {
 }
 
 __global__ __launch_bounds__(64) void k_env_reset(BatchArgs a, StepOut out) {
-  const int env = blockIdx.x;
+  const int env = a.block_env[blockIdx.x];
   SgrlModelView m; sgrl::Layout o; double* S; int32_t* I;
   setup(a, env, &m, &o, &S, &I);
   sgrl::HipWave w;
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(64) void k_env_reset(BatchArgs a, StepOut out) {
 }
 
 __global__ __launch_bounds__(64) void k_env_refresh(BatchArgs a, StepOut out) {
-  const int env = blockIdx.x;
+  const int env = a.block_env[blockIdx.x];
   SgrlModelView m; sgrl::Layout o; double* S; int32_t* I;
   setup(a, env, &m, &o, &S, &I);
   sgrl::HipWave w;
@@ -126,6 +128,7 @@ struct sgrl_engine {
   std::vector<double*> d_fb;
   MorphDev* d_morphs = nullptr;
   int32_t* d_env_morph = nullptr;
+  int32_t* d_block_env = nullptr;
   double* d_rec = nullptr;
   int32_t* d_cnt = nullptr;
   BatchArgs args{};
@@ -142,6 +145,7 @@ void sgrl_engine_destroy(sgrl_engine* e) {
   for (auto p : e->d_fb) if (p) (void)hipFree(p);
   if (e->d_morphs) (void)hipFree(e->d_morphs);
   if (e->d_env_morph) (void)hipFree(e->d_env_morph);
+  if (e->d_block_env) (void)hipFree(e->d_block_env);
   if (e->d_rec) (void)hipFree(e->d_rec);
   if (e->d_cnt) (void)hipFree(e->d_cnt);
   delete e;
@@ -154,8 +158,11 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
   *out = nullptr;
   if (n_morph <= 0 || !ib || !ib_len || !fb || !fb_len || !morph_count) return fail(SGRL_ERR_ARG, "null or empty morphology list");
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-    return fail(SGRL_ERR_HIP, "no HIP device visible: libsgrl_hip.so needs an MI355X (there is no CPU fallback)");
+  (void)hipGetLastError();
+  const hipError_t dev_err = hipGetDeviceCount(&ndev);
+  if (dev_err != hipSuccess || ndev == 0)
+    return fail(SGRL_ERR_HIP, std::string("no HIP device visible: libsgrl_hip.so needs an MI355X (there is no CPU fallback) [") +
+                                  hipGetErrorString(dev_err) + ", " + std::to_string(ndev) + " devices]");
   sgrl_engine* e = new sgrl_engine();
   e->n_morph = n_morph;
   e->obs_max_len = obs_max_len;
@@ -193,11 +200,21 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
   e->stride = (e->stride + 1) & ~1;
   bool ok = hipMalloc(&e->d_morphs, sizeof(MorphDev) * n_morph) == hipSuccess &&
             hipMalloc(&e->d_env_morph, sizeof(int32_t) * e->n_env) == hipSuccess &&
+            hipMalloc(&e->d_block_env, sizeof(int32_t) * e->n_env) == hipSuccess &&
             hipMalloc(&e->d_rec, sizeof(double) * (size_t)e->n_env * e->stride) == hipSuccess &&
             hipMalloc(&e->d_cnt, sizeof(int32_t) * (size_t)e->n_env * 4) == hipSuccess;
   if (!ok) { sgrl_engine_destroy(e); return fail(SGRL_ERR_HIP, "hipMalloc(state) failed"); }
   (void)hipMemcpy(e->d_morphs, morphs.data(), sizeof(MorphDev) * n_morph, hipMemcpyHostToDevice);
   (void)hipMemcpy(e->d_env_morph, env_morph.data(), sizeof(int32_t) * e->n_env, hipMemcpyHostToDevice);
+  {
+    // dispatch order: workgroups are handed out by index, so put the costliest morphologies (most dofs) first
+    std::vector<int32_t> order(e->n_env);
+    for (int i = 0; i < e->n_env; i++) order[i] = i;
+    std::vector<int> cost(n_morph);
+    for (int k = 0; k < n_morph; k++) cost[k] = ib[k][SGRL_H_NV];
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return cost[env_morph[x]] > cost[env_morph[y]]; });
+    (void)hipMemcpy(e->d_block_env, order.data(), sizeof(int32_t) * e->n_env, hipMemcpyHostToDevice);
+  }
   (void)hipMemset(e->d_rec, 0, sizeof(double) * (size_t)e->n_env * e->stride);
   {
     std::vector<int32_t> cnt0((size_t)e->n_env * 4, 0);
@@ -211,7 +228,7 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
     if (a1 != hipSuccess || a2 != hipSuccess || a3 != hipSuccess) { sgrl_engine_destroy(e); return fail(SGRL_ERR_HIP, "cannot raise the dynamic LDS limit"); }
   }
   BatchArgs& a = e->args;
-  a.morphs = e->d_morphs; a.env_morph = e->d_env_morph; a.rec = e->d_rec; a.cnt = e->d_cnt;
+  a.morphs = e->d_morphs; a.env_morph = e->d_env_morph; a.block_env = e->d_block_env; a.rec = e->d_rec; a.cnt = e->d_cnt;
   a.stride = e->stride; a.n_env = e->n_env; a.obs_max_len = obs_max_len; a.action_max_len = action_max_len;
   a.seed = seed; a.env_id_base = env_id_base; a.max_episode_steps = max_episode_steps;
   if (hipDeviceSynchronize() != hipSuccess) { sgrl_engine_destroy(e); return fail(SGRL_ERR_HIP, "device error during engine setup"); }

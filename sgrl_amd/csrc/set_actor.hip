@@ -38,6 +38,7 @@ constexpr int ZD = 32;
 // f32 MFMA GEMM:  C[M,N] = epi(A[M,K] . W[N,K]^T)      block tile 128x128x32, 4 waves of 64x64
 enum { EPI_RELU = 1, EPI_ROWDIV = 2, EPI_ACC2 = 4 };
 constexpr int BM = 128, BN = 128, BK = 32, LDT = 130;
+constexpr int GEMM_LDS_BYTES = 4 * BK * LDT * (int)sizeof(float);
 
 struct GemmArgs {
   const float* A; int lda;
@@ -51,8 +52,9 @@ struct GemmArgs {
 };
 
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
-  __shared__ float As[2][BK][LDT];
-  __shared__ float Ws[2][BK][LDT];
+  extern __shared__ float gemm_lds[];   // 2 stages x (A tile + W tile), k-major [BK][LDT]: 66 560 B
+  float (*As)[BK][LDT] = reinterpret_cast<float (*)[BK][LDT]>(gemm_lds);
+  float (*Ws)[BK][LDT] = reinterpret_cast<float (*)[BK][LDT]>(gemm_lds + 2 * BK * LDT);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware tile order: consecutive row-tiles that share a column tile land on the same XCD's L2
@@ -416,7 +418,7 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw
   if (K % BK != 0 || (lda & 3) || (ldw & 3)) return sfail(SGRL_ERR_ARG, "gemm: K must be a multiple of 32 and rows 16-byte aligned");
   GemmArgs a{A, lda, W, ldw, bias, C, ldc, M, N, K, flags, rowdiv, C2, ldc2};
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-  hipLaunchKernelGGL(k_gemm, dim3(tiles), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_gemm, dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, a);
   return SGRL_OK;
 }
 
@@ -492,6 +494,11 @@ int sgrl_set_create(sgrl_set** out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
     *out = nullptr;
     return sfail(SGRL_ERR_HIP, "no HIP device visible: the SET actor fast path needs an MI355X (there is no CPU fallback)");
+  }
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          GEMM_LDS_BYTES) != hipSuccess) {
+    *out = nullptr;
+    return sfail(SGRL_ERR_HIP, "cannot raise the dynamic LDS limit of the GEMM kernel");
   }
   *out = new sgrl_set();
   return SGRL_OK;

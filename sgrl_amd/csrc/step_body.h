@@ -49,12 +49,12 @@ struct Layout {
   int cinert, crb, cdof, cfrc;
   int L, dinv, qfs, ys, xtmp, qacc, vpgs;
   int con_pos, con_frame, con_dist;
-  int Y, eR, earef, eb, ef, ediag;
+  int Y, eR, earef, eb, ef, ediag, eidg, prev_f;
   int misc;  // 16 scalars
   int Mfull; // Euler only: copy of M (lower triangle incl. diag)
   int s_total;
   // I
-  int con_valid, row_kind, row_src, row_sub, icnt;
+  int con_valid, row_kind, row_src, row_sub, prev_key, icnt;
   int i_total;
 };
 
@@ -79,6 +79,7 @@ SGRL_HD void make_layout(const int32_t* hdr, Layout* o) {
   o->Y = p; p += (o->maxrows + 1) * o->ldy;
   o->eR = p; p += o->maxrows; o->earef = p; p += o->maxrows; o->eb = p; p += o->maxrows;
   o->ef = p; p += o->maxrows; o->ediag = p; p += o->maxrows;
+  o->eidg = p; p += o->maxrows; o->prev_f = p; p += o->maxrows;
   o->misc = p; p += 16;
   o->Mfull = p;
   if (hdr[SGRL_H_INTEGRATOR] == 0) p += nv * o->ld;
@@ -86,6 +87,7 @@ SGRL_HD void make_layout(const int32_t* hdr, Layout* o) {
   int q = 0;
   o->con_valid = q; q += o->ncon;
   o->row_kind = q; q += o->maxrows; o->row_src = q; q += o->maxrows; o->row_sub = q; q += o->maxrows;
+  o->prev_key = q; q += o->maxrows;
   o->icnt = q; q += 8;
   o->i_total = q;
 }
@@ -95,7 +97,7 @@ SGRL_HD int layout_bytes(const Layout* o) { return o->s_total * 8 + ((o->i_total
 // misc slots
 enum { MS_COM = 0, /* 3 */ MS_REWARD = 4, MS_DIST = 5, MS_PREQUAT = 6 /* 4 */, MS_PREPOS = 10 /* 2 */ };
 // icnt slots
-enum { IC_NROW = 0, IC_NROW_WANTED = 1, IC_OVERFLOW = 2, IC_DONE = 3, IC_TRUNC = 4 };
+enum { IC_NROW = 0, IC_NROW_WANTED = 1, IC_OVERFLOW = 2, IC_DONE = 3, IC_TRUNC = 4, IC_PREV_N = 5 };
 enum { ROW_LIMIT_LO = 0, ROW_LIMIT_HI = 1, ROW_CON1 = 2, ROW_PYR = 3 };
 
 // ------------------------------------------------------------------------------------------------
@@ -696,7 +698,13 @@ struct Engine {
       double s2 = 0;
       for (int d = 0; d < nv; d++) s2 += Yr[d] * Yr[d];
       S[o.ediag + r] = s2 + R;
-      S[o.ef + r] = 0;
+      S[o.eidg + r] = 1.0 / (s2 + R);
+      // warm start from the previous evaluation of this env-step: same constraint (kind, source, edge) -> same force
+      const int key = (kind << 16) | (src << 3) | sub;
+      double f0 = 0;
+      const int pn = I[o.icnt + IC_PREV_N];
+      for (int k = 0; k < pn; k++) if (I[o.prev_key + k] == key) f0 = S[o.prev_f + k];
+      S[o.ef + r] = f0;
     });
     w.lanes(nrow > nv ? nrow : nv, [&](int r) {
       if (r < nrow) {
@@ -713,30 +721,20 @@ struct Engine {
     const int nv = o.nv, ldy = o.ldy;
     const int nrow = I[o.icnt + IC_NROW];
     if (nrow > 0) {
-      const int iters = m.hdr[SGRL_H_PGS_ITERS];
-      double bmax = w.maxabs(nrow, [&](int r) { return S[o.eb + r]; });
+      const double bmax = w.maxabs(nrow, [&](int r) { return S[o.eb + r]; });
       const double thresh = m.fhdr[SGRL_F_PGS_TOL] * (1.0 + bmax);
-      for (int it = 0; it < iters; it++) {
-        double change = 0;
-        for (int r = 0; r < nrow; r++) {
-          const double dotv = w.sum(nv, [&](int d) { return S[o.Y + r * ldy + d] * S[o.vpgs + d]; });
-          const double f = S[o.ef + r], R = S[o.eR + r], dg = S[o.ediag + r];
-          const double res = S[o.eb + r] + R * f + dotv;
-          double fn = f - res / dg;
-          if (fn < 0) fn = 0;
-          const double df = fn - f;
-          if (df != 0) {
-            w.lanes(nv, [&](int d) {
-              S[o.vpgs + d] += S[o.Y + r * ldy + d] * df;
-              if (d == 0) S[o.ef + r] = fn;
-            });
-            const double c = fabs(df) * dg;
-            if (c > change) change = c;
-          }
-        }
-        if (change < thresh) break;
-      }
+      // projected Gauss-Seidel on the dual; the policy keeps v = Y'f one entry per lane (registers on the GPU)
+      w.pgs(nrow, nv, S + o.Y, ldy, S + o.eb, S + o.eR, S + o.ediag, S + o.eidg, S + o.ef, S + o.vpgs,
+            m.hdr[SGRL_H_PGS_ITERS], thresh);
     }
+    // remember the solution for the next evaluation's warm start
+    w.lanes(nrow > 0 ? nrow : 1, [&](int r) {
+      if (r < nrow) {
+        I[o.prev_key + r] = (I[o.row_kind + r] << 16) | (I[o.row_src + r] << 3) | I[o.row_sub + r];
+        S[o.prev_f + r] = S[o.ef + r];
+      }
+      if (r == 0) I[o.icnt + IC_PREV_N] = nrow;
+    });
     // qacc = L^-T (ys + Y' f)
     w.lanes(nv, [&](int d) { S[o.qacc + d] = S[o.ys + d] + (nrow > 0 ? S[o.vpgs + d] : 0.0); });
     solve_upper_inplace(o.L, o.qacc);
@@ -1046,7 +1044,7 @@ SGRL_DEV void env_step(W& w, const SgrlModelView& m, const Layout& o, double* S,
   w.lanes(o.nu > 8 ? o.nu : 8, [&](int u) {
     if (u < o.nu) { const int s = m.act_slot[u]; S[o.ctrl + u] = s >= 0 ? (double)io.action[s] : 0.0; }
     if (u < 4) S[o.misc + MS_PREQUAT + u] = S[o.qpos + 3 + u];
-    if (u == 4) I[o.icnt + IC_OVERFLOW] = 0;
+    if (u == 4) { I[o.icnt + IC_OVERFLOW] = 0; I[o.icnt + IC_PREV_N] = 0; }
   });
   const int fs = m.hdr[SGRL_H_FRAME_SKIP];
   for (int s = 0; s < fs; s++) e.mj_step();

@@ -50,6 +50,44 @@ struct HipWave {
     for (int i = lane; i < n; i += 64) p += f(i);
     return wave_sum(p);
   }
+  // Projected Gauss-Seidel on the dual, n <= 64 rows, nv <= 64 dofs, all state in registers:
+  //   lane d keeps v[d] = (Y'f)[d]; lane r keeps (b, R, diag, 1/diag, f) of row r, broadcast with v_readlane;
+  //   the row residual is one DPP wave reduction; Y rows stream from LDS one row ahead of their use.
+  __device__ __forceinline__ void pgs(int n_in, int nv_in, const double* Y, int ldy, const double* b, const double* R,
+                                      const double* dg, const double* idg, double* f, double* v, int iters_in,
+                                      double thresh) {
+    const int n = __builtin_amdgcn_readfirstlane(n_in), nv = __builtin_amdgcn_readfirstlane(nv_in);
+    const int iters = __builtin_amdgcn_readfirstlane(iters_in);
+    const bool rowl = lane < n, dofl = lane < nv;
+    double rb = rowl ? b[lane] : 0.0, rR = rowl ? R[lane] : 0.0, rdg = rowl ? dg[lane] : 0.0;
+    double ridg = rowl ? idg[lane] : 0.0, rf = rowl ? f[lane] : 0.0;
+    double vv = 0.0;
+    for (int r = 0; r < n; r++) {
+      const double fr = read_lane(rf, r);
+      if (dofl) vv += Y[r * ldy + lane] * fr;
+    }
+    for (int it = 0; it < iters; it++) {
+      double change = 0.0;
+      double ynext = dofl ? Y[lane] : 0.0;
+      for (int r = 0; r < n; r++) {
+        const double y = ynext;
+        if (r + 1 < n) ynext = dofl ? Y[(r + 1) * ldy + lane] : 0.0;
+        const double dot = wave_sum(y * vv);
+        const double fr = read_lane(rf, r);
+        const double res = read_lane(rb, r) + read_lane(rR, r) * fr + dot;
+        double fn = fr - res * read_lane(ridg, r);
+        fn = fn < 0.0 ? 0.0 : fn;
+        const double df = fn - fr;
+        vv += y * df;
+        if (lane == r) rf = fn;
+        change = fmax(change, fabs(df) * read_lane(rdg, r));
+      }
+      if (change < thresh) break;
+    }
+    if (rowl) f[lane] = rf;
+    if (dofl) v[lane] = vv;
+    __syncthreads();
+  }
   template <class F> __device__ __forceinline__ double maxabs(int n, F f) {
     double p = 0.0;
     for (int i = lane; i < n; i += 64) p = fmax(p, fabs(f(i)));

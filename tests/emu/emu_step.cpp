@@ -26,6 +26,29 @@ struct EmuWave {
   }
   // same association as the device reduction is NOT required (rounding-level differences are expected)
   template <class F> double sum(int n, F f) { double s = 0; for (int i = 0; i < n; i++) s += f(i); return s; }
+  // projected Gauss-Seidel sweeps (reference semantics of HipWave::pgs): f warm-started, v = Y'f maintained
+  void pgs(int n, int nv, const double* Y, int ldy, const double* b, const double* R, const double* dg,
+           const double* idg, double* f, double* v, int iters, double thresh) {
+    for (int d = 0; d < nv; d++) { double s = 0; for (int r = 0; r < n; r++) s += Y[r * ldy + d] * f[r]; v[d] = s; }
+    for (int it = 0; it < iters; it++) {
+      double change = 0;
+      for (int r = 0; r < n; r++) {
+        double dot = 0;
+        for (int d = 0; d < nv; d++) dot += Y[r * ldy + d] * v[d];
+        const double res = b[r] + R[r] * f[r] + dot;
+        double fn = f[r] - res * idg[r];
+        if (fn < 0) fn = 0;
+        const double df = fn - f[r];
+        if (df != 0) {
+          for (int d = 0; d < nv; d++) v[d] += Y[r * ldy + d] * df;
+          f[r] = fn;
+          const double c = std::fabs(df) * dg[r];
+          if (c > change) change = c;
+        }
+      }
+      if (change < thresh) break;
+    }
+  }
   template <class F> double maxabs(int n, F f) { double s = 0; for (int i = 0; i < n; i++) { double v = std::fabs(f(i)); if (v > s) s = v; } return s; }
 };
 }  // namespace
@@ -51,6 +74,7 @@ int sgrl_emu_forward(const int32_t* ib, const double* fb, double* qpos, const do
   for (int i = 0; i < m.nv; i++) S[o.qvel + i] = qvel[i];
   for (int i = 0; i < m.nu; i++) S[o.ctrl + i] = ctrl[i];
   I[o.icnt + sgrl::IC_OVERFLOW] = 0;
+  I[o.icnt + sgrl::IC_PREV_N] = 0;
   e.forward();
   for (int i = 0; i < m.nv; i++) qacc[i] = S[o.qacc + i];
   for (int i = 0; i < m.nq; i++) qpos[i] = S[o.qpos + i];
