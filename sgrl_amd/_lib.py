@@ -45,6 +45,10 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise SgrlError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(no CPU fallback exists)" % LIB_PATH)
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; this library's DT_NEEDED entry has the same soname.  Import
+    # torch FIRST so that both resolve to the one HIP/HSA runtime torch initialises (two runtimes in one process
+    # see "no ROCm-capable device").  torch is the device-memory / stream plumbing of this package anyway.
+    import torch  # noqa: F401
     try:
         L = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # e.g. libamdhip64 missing

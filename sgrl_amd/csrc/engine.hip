@@ -64,12 +64,23 @@ struct StepOut {
 
 extern __shared__ double sgrl_lds[];
 
+// Stage the morphology tables (a few KB, shared by all envs of the morphology, L2 resident) into this workgroup's
+// LDS and point the model view at the copy: every table lookup of the ~16 dynamics evaluations then costs an LDS
+// access instead of an L2 round trip.
 __device__ __forceinline__ void setup(const BatchArgs& a, int env, SgrlModelView* m, sgrl::Layout* o, double** S, int32_t** I) {
   const MorphDev md = a.morphs[a.env_morph[env]];
-  sgrl_model_view(md.ib, md.fb, m);
-  sgrl::make_layout(md.ib, o);
-  *S = sgrl_lds;
-  *I = reinterpret_cast<int32_t*>(sgrl_lds + o->s_total);
+  SgrlModelView g;
+  sgrl_model_view(md.ib, md.fb, &g);
+  sgrl::make_layout(md.ib, o, g.n_int, g.n_f64);
+  double* s = sgrl_lds;
+  int32_t* ii = reinterpret_cast<int32_t*>(sgrl_lds + o->s_total);
+  const int lane = threadIdx.x;
+  for (int k = lane; k < g.n_f64; k += 64) s[o->model_f + k] = md.fb[k];
+  for (int k = lane; k < g.n_int; k += 64) ii[o->model_i + k] = md.ib[k];
+  __syncthreads();
+  sgrl_model_view(ii + o->model_i, s + o->model_f, m);
+  *S = s;
+  *I = ii;
 }
 
 __device__ __forceinline__ sgrl::StepIO make_io(const BatchArgs& a, const StepOut& out, int env) {
@@ -181,7 +192,7 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
     if (41 * L > obs_max_len || 3 * L > action_max_len) { rc = fail(SGRL_ERR_ARG, "obs_max_len/action_max_len too small for morphology " + std::to_string(k)); break; }
     if (morph_count[k] < 0) { rc = fail(SGRL_ERR_ARG, "negative morph_count"); break; }
     sgrl::Layout o;
-    sgrl::make_layout(ib[k], &o);
+    sgrl::make_layout(ib[k], &o, v.n_int, v.n_f64);
     const int bytes = sgrl::layout_bytes(&o);
     if (bytes > 160 * 1024) { rc = fail(SGRL_ERR_LIMIT, "per-environment LDS slab exceeds 160 KiB"); break; }
     if (bytes > e->lds_bytes) e->lds_bytes = bytes;

@@ -52,13 +52,15 @@ struct Layout {
   int Y, eR, earef, eb, ef, ediag, eidg, prev_f;
   int misc;  // 16 scalars
   int Mfull; // Euler only: copy of M (lower triangle incl. diag)
+  int model_f; // LDS copy of the float model blob (n_f64 doubles)
   int s_total;
   // I
   int con_valid, row_kind, row_src, row_sub, prev_key, icnt;
+  int model_i; // LDS copy of the int model blob (n_int ints)
   int i_total;
 };
 
-SGRL_HD void make_layout(const int32_t* hdr, Layout* o) {
+SGRL_HD void make_layout(const int32_t* hdr, Layout* o, int n_int = 0, int n_f64 = 0) {
   const int nb = hdr[SGRL_H_NBODY], nj = hdr[SGRL_H_NJNT], nq = hdr[SGRL_H_NQ], nv = hdr[SGRL_H_NV];
   const int nu = hdr[SGRL_H_NU], np = hdr[SGRL_H_NPAIR];
   o->nb = nb; o->nj = nj; o->nq = nq; o->nv = nv; o->nu = nu; o->np = np;
@@ -83,12 +85,14 @@ SGRL_HD void make_layout(const int32_t* hdr, Layout* o) {
   o->misc = p; p += 16;
   o->Mfull = p;
   if (hdr[SGRL_H_INTEGRATOR] == 0) p += nv * o->ld;
+  o->model_f = p; p += n_f64;
   o->s_total = p;
   int q = 0;
   o->con_valid = q; q += o->ncon;
   o->row_kind = q; q += o->maxrows; o->row_src = q; q += o->maxrows; o->row_sub = q; q += o->maxrows;
   o->prev_key = q; q += o->maxrows;
   o->icnt = q; q += 8;
+  o->model_i = q; q += n_int;
   o->i_total = q;
 }
 

@@ -11,11 +11,12 @@ per = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 kw = {}
 if len(sys.argv) > 3: kw["max_rows"] = int(sys.argv[3])
+if len(sys.argv) > 4: kw["pgs_iters"] = int(sys.argv[4])
 env = BatchedModularVecEnv(names, per, seed=1, device="cuda:0", **kw)
 print("n_env", env.num_envs, "lds_bytes", env.lds_bytes)
 env.reset_device()
 a = (torch.rand((env.num_envs, env.action_max_len), device="cuda") * 2 - 1).contiguous()
-for _ in range(3): env.step_device(a)
+for _ in range(30): env.step_device(a)
 torch.cuda.synchronize()
 t0 = time.time()
 for _ in range(steps):
