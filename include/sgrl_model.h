@@ -43,6 +43,7 @@ enum {
   SGRL_H_HEIGHT_BODY1,
   SGRL_H_MAX_ROWS,   /* cap on constraint rows per evaluation */
   SGRL_H_PGS_ITERS,  /* maximum number of projected Gauss-Seidel sweeps per evaluation */
+  SGRL_H_SOLVER,     /* 0: projected Gauss-Seidel only; 1: block-pivot direct solve (<= 32 rows) with PGS fallback */
   SGRL_NHDR = 24
 };
 

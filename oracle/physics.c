@@ -527,6 +527,64 @@ static void make_constraints(const SgrlModelView* m, const double* qpos, const d
   }
 }
 
+/* Exact dual LCP solve by block principal pivoting (Judice & Pires) on A = Y Y' + R: guess the free set F from the
+ * warm start, solve A_FF x = -b_F, exchange all indices violating x_F >= 0 / (A x + b)_G >= -thresh (one index after
+ * the violation count stopped shrinking three times), repeat.  Returns 1 when a complementary solution was found. */
+static int lcp_block_pivot(int n, int nv, Work* w, const double* diag, double thresh) {
+  static double A[32][32];
+  double C[32][32], x[32], rhs[32];
+  int F[32], list[32];
+  for (int i = 0; i < n; i++) for (int j = 0; j <= i; j++) {
+    double s = 0;
+    for (int d = 0; d < nv; d++) s += w->Y[i][d] * w->Y[j][d];
+    if (i == j) s += w->efc_R[i];
+    A[i][j] = s; A[j][i] = s;
+  }
+  (void)diag;
+  for (int i = 0; i < n; i++) F[i] = w->efc_f[i] > 0.0;
+  int patience = 3, best = n + 1;
+  for (int iter = 0; iter < 40; iter++) {
+    int nf = 0;
+    for (int i = 0; i < n; i++) if (F[i]) list[nf++] = i;
+    for (int j = 0; j < nf; j++) {            /* Cholesky A_FF = C C' */
+      double s = A[list[j]][list[j]];
+      for (int k = 0; k < j; k++) s -= C[j][k] * C[j][k];
+      if (s < MINVAL) s = MINVAL;
+      C[j][j] = sqrt(s);
+      for (int i = j + 1; i < nf; i++) {
+        double t = A[list[i]][list[j]];
+        for (int k = 0; k < j; k++) t -= C[i][k] * C[j][k];
+        C[i][j] = t / C[j][j];
+      }
+    }
+    for (int i = 0; i < nf; i++) { double s = -w->efc_b[list[i]]; for (int k = 0; k < i; k++) s -= C[i][k] * rhs[k]; rhs[i] = s / C[i][i]; }
+    for (int i = nf - 1; i >= 0; i--) { double s = rhs[i]; for (int k = i + 1; k < nf; k++) s -= C[k][i] * x[k]; x[i] = s / C[i][i]; }
+    int viol[32], nviol = 0, top = -1, pos = 0;
+    for (int i = 0; i < n; i++) {
+      int bad;
+      if (F[i]) { bad = x[pos] < 0.0; pos++; }
+      else {
+        double y = w->efc_b[i];
+        for (int k = 0; k < nf; k++) y += A[i][list[k]] * x[k];
+        bad = y < -thresh;
+      }
+      viol[i] = bad;
+      if (bad) { nviol++; top = i; }
+    }
+    if (nviol == 0) {
+      pos = 0;
+      for (int i = 0; i < n; i++) w->efc_f[i] = F[i] ? x[pos++] : 0.0;
+      w->pgs_iters_used = iter + 1;
+      return 1;
+    }
+    if (nviol < best) { best = nviol; patience = 3; for (int i = 0; i < n; i++) F[i] ^= viol[i]; }
+    else if (patience > 0) { patience--; for (int i = 0; i < n; i++) F[i] ^= viol[i]; }
+    else F[top] ^= 1;
+  }
+  for (int i = 0; i < n; i++) if (w->efc_f[i] < 0) w->efc_f[i] = 0;
+  return 0;
+}
+
 /* dual PGS: min 1/2 f'(A+R)f + f'b, f >= 0, A = J M^-1 J' = Y Y' with Y = (L^-1 J')'               */
 static void solve_constraints(const SgrlModelView* m, Work* w) {
   int nv = m->nv, n = w->nrow, iters = m->hdr[SGRL_H_PGS_ITERS];
@@ -556,6 +614,17 @@ static void solve_constraints(const SgrlModelView* m, Work* w) {
   double bmax = 0;
   for (int r = 0; r < n; r++) if (fabs(w->efc_b[r]) > bmax) bmax = fabs(w->efc_b[r]);
   const double thresh = m->fhdr[SGRL_F_PGS_TOL] * (1.0 + bmax);
+  int solved = 0;
+  {
+    /* same dispatch rule as the engine (step_body.h make_layout): dense form only while the factor fits its scratch */
+    int dead_len = 42 * m->nbody + 3 * m->njnt + 26 * m->npair, na = 0;
+    while (na < 32 && (na + 1) * (na + 2) / 2 <= dead_len) na++;
+    if (m->hdr[SGRL_H_SOLVER] == 1 && n <= na) solved = lcp_block_pivot(n, nv, w, diag, thresh);
+  }
+  if (solved) {
+    for (int d = 0; d < nv; d++) { double s = 0; for (int r = 0; r < n; r++) s += w->Y[r][d] * w->efc_f[r]; v[d] = s; }
+    iters = 0;
+  }
   for (int it = 0; it < iters; it++) {
     double change = 0;
     for (int r = 0; r < n; r++) {

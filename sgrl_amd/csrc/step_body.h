@@ -38,6 +38,8 @@ constexpr double kMinVal = 1e-15;
 constexpr double kMinImp = 0.0001;
 constexpr double kMaxImp = 0.9999;
 constexpr double kPi = 3.14159265358979323846;
+constexpr int kNAMax = 32;
+constexpr int kBppMaxIter = 40;  // largest row count solved in the dense A = Y Y' + R form (packed lower triangle in LDS)
 
 // ------------------------------------------------------------------------------------------------
 // LDS layout (offsets in doubles for S, in ints for I)
@@ -47,15 +49,16 @@ struct Layout {
   int qpos, qvel, q0, v0, xv, fq, dvacc, daacc, ctrl, act;
   int xpos, xquat, xmat, xipos, xanchor, xaxis;
   int cinert, crb, cdof, cfrc;
+  int dead, dead_len, na_max;
   int L, dinv, qfs, ys, xtmp, qacc, vpgs;
   int con_pos, con_frame, con_dist;
-  int Y, eR, earef, eb, ef, ediag, eidg, prev_f;
+  int Y, eR, earef, eb, ef, ediag, eidg, prev_f, Apk;
   int misc;  // 16 scalars
   int Mfull; // Euler only: copy of M (lower triangle incl. diag)
   int model_f; // LDS copy of the float model blob (n_f64 doubles)
   int s_total;
   // I
-  int con_valid, row_kind, row_src, row_sub, prev_key, icnt;
+  int con_valid, row_kind, row_src, row_sub, prev_key, flist, icnt;
   int model_i; // LDS copy of the int model blob (n_int ints)
   int i_total;
 };
@@ -72,16 +75,26 @@ SGRL_HD void make_layout(const int32_t* hdr, Layout* o, int n_int = 0, int n_f64
   o->qpos = p; p += nq; o->qvel = p; p += nv; o->q0 = p; p += nq; o->v0 = p; p += nv;
   o->xv = p; p += nv; o->fq = p; p += nv; o->dvacc = p; p += nv; o->daacc = p; p += nv;
   o->ctrl = p; p += nu + 1; o->act = p; p += 3 * (nb - 1);
-  o->xpos = p; p += 3 * nb; o->xquat = p; p += 4 * nb; o->xmat = p; p += 9 * nb; o->xipos = p; p += 3 * nb;
-  o->xanchor = p; p += 3 * nj; o->xaxis = p; p += 3 * nj;
-  o->cinert = p; p += 10 * nb; o->crb = p; p += 10 * nb; o->cdof = p; p += 6 * nv; o->cfrc = p; p += 6 * nb;
+  o->xpos = p; p += 3 * nb; o->xaxis = p; p += 3 * nj; o->cdof = p; p += 6 * nv;
+  // "dead zone": everything below is no longer needed once the constraint rows of an evaluation are built, so the
+  // LCP solver reuses the span as scratch for its Cholesky factor
+  o->dead = p;
+  o->xquat = p; p += 4 * nb; o->xmat = p; p += 9 * nb; o->xipos = p; p += 3 * nb; o->xanchor = p; p += 3 * nj;
+  o->cinert = p; p += 10 * nb; o->crb = p; p += 10 * nb; o->cfrc = p; p += 6 * nb;
+  o->con_pos = p; p += 3 * o->ncon; o->con_frame = p; p += 9 * o->ncon; o->con_dist = p; p += o->ncon;
+  o->dead_len = p - o->dead;
+  {
+    int na = 0;
+    while (na < kNAMax && (na + 1) * (na + 2) / 2 <= o->dead_len) na++;
+    o->na_max = na;
+  }
   o->L = p; p += nv * o->ld; o->dinv = p; p += nv;
   o->qfs = p; p += nv; o->ys = p; p += nv; o->xtmp = p; p += nv; o->qacc = p; p += nv; o->vpgs = p; p += nv;
-  o->con_pos = p; p += 3 * o->ncon; o->con_frame = p; p += 9 * o->ncon; o->con_dist = p; p += o->ncon;
   o->Y = p; p += (o->maxrows + 1) * o->ldy;
   o->eR = p; p += o->maxrows; o->earef = p; p += o->maxrows; o->eb = p; p += o->maxrows;
   o->ef = p; p += o->maxrows; o->ediag = p; p += o->maxrows;
   o->eidg = p; p += o->maxrows; o->prev_f = p; p += o->maxrows;
+  o->Apk = p; p += kNAMax * (kNAMax + 1) / 2;
   o->misc = p; p += 16;
   o->Mfull = p;
   if (hdr[SGRL_H_INTEGRATOR] == 0) p += nv * o->ld;
@@ -91,6 +104,7 @@ SGRL_HD void make_layout(const int32_t* hdr, Layout* o, int n_int = 0, int n_f64
   o->con_valid = q; q += o->ncon;
   o->row_kind = q; q += o->maxrows; o->row_src = q; q += o->maxrows; o->row_sub = q; q += o->maxrows;
   o->prev_key = q; q += o->maxrows;
+  o->flist = q; q += o->maxrows;
   o->icnt = q; q += 8;
   o->model_i = q; q += n_int;
   o->i_total = q;
@@ -101,7 +115,7 @@ SGRL_HD int layout_bytes(const Layout* o) { return o->s_total * 8 + ((o->i_total
 // misc slots
 enum { MS_COM = 0, /* 3 */ MS_REWARD = 4, MS_DIST = 5, MS_PREQUAT = 6 /* 4 */, MS_PREPOS = 10 /* 2 */ };
 // icnt slots
-enum { IC_NROW = 0, IC_NROW_WANTED = 1, IC_OVERFLOW = 2, IC_DONE = 3, IC_TRUNC = 4, IC_PREV_N = 5 };
+enum { IC_NROW = 0, IC_NROW_WANTED = 1, IC_OVERFLOW = 2, IC_DONE = 3, IC_TRUNC = 4, IC_PREV_N = 5, IC_SWEEPS = 6, IC_ROWSUM = 7 };
 enum { ROW_LIMIT_LO = 0, ROW_LIMIT_HI = 1, ROW_CON1 = 2, ROW_PYR = 3 };
 
 // ------------------------------------------------------------------------------------------------
@@ -169,6 +183,20 @@ SGRL_DEV void cross_force(double* r, const double* vel, const double* f) {
 }
 SGRL_DEV void ld3(double* r, const double* p) { r[0] = p[0]; r[1] = p[1]; r[2] = p[2]; }
 SGRL_DEV void ld6(double* r, const double* p) { r[0] = p[0]; r[1] = p[1]; r[2] = p[2]; r[3] = p[3]; r[4] = p[4]; r[5] = p[5]; }
+SGRL_DEV int popcount64(uint64_t x) {
+#ifdef __HIPCC__
+  return __popcll(x);
+#else
+  return __builtin_popcountll(x);
+#endif
+}
+SGRL_DEV int clz64(uint64_t x) {
+#ifdef __HIPCC__
+  return __clzll((long long)x);
+#else
+  return __builtin_clzll(x);
+#endif
+}
 SGRL_DEV bool dof_in_mask(const int32_t* mask2, int d) {
   const uint32_t w = (uint32_t)(d < 32 ? mask2[0] : mask2[1]);
   return (w >> (d & 31)) & 1u;
@@ -721,15 +749,117 @@ struct Engine {
     });
   }
 
+  // Exact solve of the dual LCP  0 <= f  _|_  A f + b >= 0  (A = Y Y' + R, SPD, packed lower triangle at o.Apk) by
+  // block principal pivoting (Judice & Pires): guess the free set F, solve A_FF x = -b_F by a lane-parallel root-free
+  // Cholesky, exchange every index that violates x_F >= 0 or (A x + b)_G >= 0 (a single index once the number of
+  // violations has stopped shrinking), repeat.  The free set is warm-started from the previous evaluation.  The
+  // result is the same unique optimum projected Gauss-Seidel converges to; PGS remains the fallback.
+  SGRL_DEV bool lcp_block_pivot(int n, double thresh, int* iters_out) {
+    const int cpk = o.dead, wv = o.earef, xw = o.prev_f;
+    uint64_t F = w.ballot(n, [&](int i) { return S[o.ef + i] > 0.0; });
+    int patience = 3, best = n + 1;
+    for (int iter = 0; iter < kBppMaxIter; iter++) {
+      const int nf = popcount64(F);
+      w.lanes(n, [&](int i) {
+        if ((F >> i) & 1ull) {
+          const int pos = popcount64(F & ((1ull << i) - 1ull));
+          I[o.flist + pos] = i;
+          S[xw + pos] = -S[o.eb + i];
+        }
+      });
+      // root-free Cholesky of A_FF: C[i][j] = A[fi][fj] - sum_k C[i][k] C[j][k] w[k], w[k] = 1 / C[k][k]
+      for (int j = 0; j < nf; j++) {
+        w.lanes_from(j, nf, [&](int i) {
+          const int fi = I[o.flist + i], fj = I[o.flist + j];
+          double s = S[o.Apk + fi * (fi + 1) / 2 + fj];   // fi >= fj because the list is ascending
+          const double* ci = S + cpk + i * (i + 1) / 2;
+          const double* cj = S + cpk + j * (j + 1) / 2;
+          for (int k = 0; k < j; k++) s -= ci[k] * cj[k] * S[wv + k];
+          if (i == j) { if (s < kMinVal) s = kMinVal; S[wv + j] = 1.0 / s; }
+          S[cpk + i * (i + 1) / 2 + j] = s;
+        });
+      }
+      // forward substitution (column sweeps), diagonal scaling, backward substitution
+      for (int j = 0; j < nf; j++) {
+        const double zj = S[xw + j] * S[wv + j];
+        w.lanes_from(j + 1, nf, [&](int i) { S[xw + i] -= S[cpk + i * (i + 1) / 2 + j] * zj; });
+      }
+      w.lanes(nf, [&](int i) { S[xw + i] *= S[wv + i]; });
+      for (int j = nf - 1; j > 0; j--) {
+        const double xj = S[xw + j];
+        w.lanes(j, [&](int k) { S[xw + k] -= S[cpk + j * (j + 1) / 2 + k] * S[wv + k] * xj; });
+      }
+      // violations: x_i < 0 on F, (A x + b)_i < -thresh on the complement
+      const uint64_t V = w.ballot(n, [&](int i) {
+        if ((F >> i) & 1ull) return S[xw + popcount64(F & ((1ull << i) - 1ull))] < 0.0;
+        double y = S[o.eb + i];
+        for (int k = 0; k < nf; k++) {
+          const int fk = I[o.flist + k];
+          y += (i >= fk ? S[o.Apk + i * (i + 1) / 2 + fk] : S[o.Apk + fk * (fk + 1) / 2 + i]) * S[xw + k];
+        }
+        return y < -thresh;
+      });
+      if (V == 0) {
+        w.lanes(n, [&](int i) {
+          S[o.ef + i] = ((F >> i) & 1ull) ? S[xw + popcount64(F & ((1ull << i) - 1ull))] : 0.0;
+        });
+        *iters_out = iter + 1;
+        return true;
+      }
+      const int nviol = popcount64(V);
+      if (nviol < best) { best = nviol; patience = 3; F ^= V; }
+      else if (patience > 0) { patience--; F ^= V; }
+      else { F ^= (1ull << (63 - clz64(V))); }   // backup rule: only the highest violating index
+    }
+    // not converged (never observed): leave a feasible point for the Gauss-Seidel fallback
+    w.lanes(n, [&](int i) { if (S[o.ef + i] < 0.0) S[o.ef + i] = 0.0; });
+    *iters_out = kBppMaxIter;
+    return false;
+  }
+
   SGRL_DEV void pgs_and_finish() {
     const int nv = o.nv, ldy = o.ldy;
     const int nrow = I[o.icnt + IC_NROW];
+    int sweeps = 0;
     if (nrow > 0) {
       const double bmax = w.maxabs(nrow, [&](int r) { return S[o.eb + r]; });
       const double thresh = m.fhdr[SGRL_F_PGS_TOL] * (1.0 + bmax);
-      // projected Gauss-Seidel on the dual; the policy keeps v = Y'f one entry per lane (registers on the GPU)
-      w.pgs(nrow, nv, S + o.Y, ldy, S + o.eb, S + o.eR, S + o.ediag, S + o.eidg, S + o.ef, S + o.vpgs,
-            m.hdr[SGRL_H_PGS_ITERS], thresh);
+      if (nrow <= o.na_max) {
+        // dense form: A = Y Y' + diag(R) once (packed lower triangle), then each row update is one broadcast of the
+        // row's residual and one rank-1 residual update  r += A[:, j] * df  -- no reduction on the critical path
+        const int npair = nrow * (nrow + 1) / 2;
+        w.lanes(npair, [&](int p) {
+          int i = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
+          while ((i + 1) * (i + 2) / 2 <= p) i++;
+          while (i * (i + 1) / 2 > p) i--;
+          const int j = p - i * (i + 1) / 2;
+          const double* yi = S + o.Y + i * ldy;
+          const double* yj = S + o.Y + j * ldy;
+          double a = 0;
+          int d = 0;
+          for (; d + 4 <= nv; d += 4) {
+            const double a0 = yi[d], a1 = yi[d + 1], a2 = yi[d + 2], a3 = yi[d + 3];
+            const double b0 = yj[d], b1 = yj[d + 1], b2 = yj[d + 2], b3 = yj[d + 3];
+            a += a0 * b0; a += a1 * b1; a += a2 * b2; a += a3 * b3;
+          }
+          for (; d < nv; d++) a += yi[d] * yj[d];
+          if (i == j) a += S[o.eR + i];
+          S[o.Apk + p] = a;
+        });
+        bool solved = false;
+        if (m.hdr[SGRL_H_SOLVER] == 1) solved = lcp_block_pivot(nrow, thresh, &sweeps);
+        if (!solved)
+          sweeps = w.pgs_dense(nrow, S + o.Apk, S + o.eb, S + o.ediag, S + o.eidg, S + o.ef, m.hdr[SGRL_H_PGS_ITERS], thresh);
+        w.lanes(nv, [&](int d) {
+          double v = 0;
+          for (int r = 0; r < nrow; r++) v += S[o.Y + r * ldy + d] * S[o.ef + r];
+          S[o.vpgs + d] = v;
+        });
+      } else {
+        // many rows: matrix-free form, the policy keeps v = Y'f one entry per lane
+        sweeps = w.pgs(nrow, nv, S + o.Y, ldy, S + o.eb, S + o.eR, S + o.ediag, S + o.eidg, S + o.ef, S + o.vpgs,
+                       m.hdr[SGRL_H_PGS_ITERS], thresh);
+      }
     }
     // remember the solution for the next evaluation's warm start
     w.lanes(nrow > 0 ? nrow : 1, [&](int r) {
@@ -737,7 +867,7 @@ struct Engine {
         I[o.prev_key + r] = (I[o.row_kind + r] << 16) | (I[o.row_src + r] << 3) | I[o.row_sub + r];
         S[o.prev_f + r] = S[o.ef + r];
       }
-      if (r == 0) I[o.icnt + IC_PREV_N] = nrow;
+      if (r == 0) { I[o.icnt + IC_PREV_N] = nrow; I[o.icnt + IC_SWEEPS] += sweeps; I[o.icnt + IC_ROWSUM] += sweeps * nrow; }
     });
     // qacc = L^-T (ys + Y' f)
     w.lanes(nv, [&](int d) { S[o.qacc + d] = S[o.ys + d] + (nrow > 0 ? S[o.vpgs + d] : 0.0); });
@@ -1048,7 +1178,7 @@ SGRL_DEV void env_step(W& w, const SgrlModelView& m, const Layout& o, double* S,
   w.lanes(o.nu > 8 ? o.nu : 8, [&](int u) {
     if (u < o.nu) { const int s = m.act_slot[u]; S[o.ctrl + u] = s >= 0 ? (double)io.action[s] : 0.0; }
     if (u < 4) S[o.misc + MS_PREQUAT + u] = S[o.qpos + 3 + u];
-    if (u == 4) { I[o.icnt + IC_OVERFLOW] = 0; I[o.icnt + IC_PREV_N] = 0; }
+    if (u == 4) { I[o.icnt + IC_OVERFLOW] = 0; I[o.icnt + IC_PREV_N] = 0; I[o.icnt + IC_SWEEPS] = 0; I[o.icnt + IC_ROWSUM] = 0; }
   });
   const int fs = m.hdr[SGRL_H_FRAME_SKIP];
   for (int s = 0; s < fs; s++) e.mj_step();
@@ -1073,6 +1203,7 @@ SGRL_DEV void env_step(W& w, const SgrlModelView& m, const Layout& o, double* S,
     I[o.icnt + IC_DONE] = done; I[o.icnt + IC_TRUNC] = trunc;
     io.cnt[0] = steps;
     io.cnt[2] += I[o.icnt + IC_OVERFLOW];
+    io.cnt[3] = I[o.icnt + IC_ROWSUM];   // diagnostics: PGS row updates of this env-step
     if (io.reward) *io.reward = (float)S[o.misc + MS_REWARD];
     if (io.reward64) *io.reward64 = S[o.misc + MS_REWARD];
     if (io.done) *io.done = (uint8_t)done;

@@ -53,7 +53,7 @@ struct HipWave {
   // Projected Gauss-Seidel on the dual, n <= 64 rows, nv <= 64 dofs, all state in registers:
   //   lane d keeps v[d] = (Y'f)[d]; lane r keeps (b, R, diag, 1/diag, f) of row r, broadcast with v_readlane;
   //   the row residual is one DPP wave reduction; Y rows stream from LDS one row ahead of their use.
-  __device__ __forceinline__ void pgs(int n_in, int nv_in, const double* Y, int ldy, const double* b, const double* R,
+  __device__ __forceinline__ int pgs(int n_in, int nv_in, const double* Y, int ldy, const double* b, const double* R,
                                       const double* dg, const double* idg, double* f, double* v, int iters_in,
                                       double thresh) {
     const int n = __builtin_amdgcn_readfirstlane(n_in), nv = __builtin_amdgcn_readfirstlane(nv_in);
@@ -66,7 +66,8 @@ struct HipWave {
       const double fr = read_lane(rf, r);
       if (dofl) vv += Y[r * ldy + lane] * fr;
     }
-    for (int it = 0; it < iters; it++) {
+    int it = 0;
+    for (; it < iters; it++) {
       double change = 0.0;
       double ynext = dofl ? Y[lane] : 0.0;
       for (int r = 0; r < n; r++) {
@@ -82,11 +83,50 @@ struct HipWave {
         if (lane == r) rf = fn;
         change = fmax(change, fabs(df) * read_lane(rdg, r));
       }
-      if (change < thresh) break;
+      if (change < thresh) { it++; break; }
     }
     if (rowl) f[lane] = rf;
     if (dofl) v[lane] = vv;
     __syncthreads();
+    return it;
+  }
+  // Dense-form PGS (n <= 32 rows): lane i keeps the residual r_i = (A f + b)_i and f_i in registers.  One row update =
+  // two v_readlane broadcasts, five scalar-like f64 ops and one fma per lane; A columns stream from LDS one ahead.
+  __device__ __forceinline__ int pgs_dense(int n_in, const double* A, const double* b, const double* dg,
+                                            const double* idg, double* f, int iters_in, double thresh) {
+    const int n = __builtin_amdgcn_readfirstlane(n_in), iters = __builtin_amdgcn_readfirstlane(iters_in);
+    const bool rowl = lane < n;
+    const int tri = lane * (lane + 1) / 2;
+    auto at = [&](int j) -> double {   // A[lane][j], packed lower triangle
+      return rowl ? (lane >= j ? A[tri + j] : A[j * (j + 1) / 2 + lane]) : 0.0;
+    };
+    double rf = rowl ? f[lane] : 0.0, rdg = rowl ? dg[lane] : 0.0, ridg = rowl ? idg[lane] : 0.0;
+    double rr = rowl ? b[lane] : 0.0;
+    for (int j = 0; j < n; j++) rr += at(j) * read_lane(rf, j);
+    int it = 0;
+    for (; it < iters; it++) {
+      double change = 0.0;
+      double anext = at(0);
+      for (int j = 0; j < n; j++) {
+        const double a = anext;
+        if (j + 1 < n) anext = at(j + 1);
+        const double fj = read_lane(rf, j);
+        double fn = fj - read_lane(rr, j) * read_lane(ridg, j);
+        fn = fn < 0.0 ? 0.0 : fn;
+        const double df = fn - fj;
+        rr += a * df;
+        if (lane == j) rf = fn;
+        change = fmax(change, fabs(df) * read_lane(rdg, j));
+      }
+      if (change < thresh) { it++; break; }
+    }
+    if (rowl) f[lane] = rf;
+    __syncthreads();
+    return it;
+  }
+  template <class F> __device__ __forceinline__ uint64_t ballot(int n, F f) {
+    const bool p = (lane < n) ? (bool)f(lane) : false;
+    return (uint64_t)__ballot(p);
   }
   template <class F> __device__ __forceinline__ double maxabs(int n, F f) {
     double p = 0.0;

@@ -9,13 +9,14 @@ NHDR = 24
 NFHDR = 16
 (H_MAGIC, H_NBODY, H_NJNT, H_NQ, H_NV, H_NU, H_NGEOM, H_NPAIR, H_INTEGRATOR, H_FRAME_SKIP, H_DONE_RULE,
  H_TARGET_V2, H_RESET_VEL_NORMAL, H_NHEIGHT_BODIES, H_HEIGHT_BODY0, H_HEIGHT_BODY1, H_MAX_ROWS,
- H_PGS_ITERS) = range(18)
+ H_PGS_ITERS, H_SOLVER) = range(19)
 (F_TIMESTEP, F_GRAV_X, F_GRAV_Y, F_GRAV_Z, F_HEIGHT_LO, F_HEIGHT_HI, F_ANG_LIMIT, F_ALIVE_BONUS,
  F_HEADING_WEIGHT, F_CTRL_COST, F_RESET_POS_NOISE, F_RESET_VEL_NOISE, F_PGS_TOL, F_TOTAL_MASS) = range(14)
 
-DEFAULT_MAX_ROWS = 64
+DEFAULT_MAX_ROWS = 48
 DEFAULT_PGS_ITERS = 300
 DEFAULT_PGS_TOL = 1e-10
+DEFAULT_SOLVER = 1
 
 
 MAXDEPTH = 8
@@ -71,7 +72,7 @@ def _derived_int_tables(model):
 
 
 def pack_model(model, spec=None, env_name=None, max_rows=DEFAULT_MAX_ROWS, pgs_iters=DEFAULT_PGS_ITERS,
-               pgs_tol=DEFAULT_PGS_TOL):
+               pgs_tol=DEFAULT_PGS_TOL, solver=DEFAULT_SOLVER):
     """Return (ib int32[...], fb float64[...])."""
     if spec is None:
         spec = env_spec_for(env_name or model.name)
@@ -90,6 +91,7 @@ def pack_model(model, spec=None, env_name=None, max_rows=DEFAULT_MAX_ROWS, pgs_i
         hdr[H_HEIGHT_BODY0 + i] = b
     hdr[H_MAX_ROWS] = max_rows
     hdr[H_PGS_ITERS] = pgs_iters
+    hdr[H_SOLVER] = solver
     ints = [hdr]
     for k in mjcf.Model.INT_FIELDS:
         ints.append(np.asarray(getattr(model, k), dtype=np.int32).ravel())

@@ -10,12 +10,12 @@ from sgrl_amd.env_spec import env_spec_for
 
 @functools.lru_cache(maxsize=None)
 def packed(env_name, max_rows=model_pack.DEFAULT_MAX_ROWS, pgs_iters=model_pack.DEFAULT_PGS_ITERS,
-           pgs_tol=model_pack.DEFAULT_PGS_TOL):
+           pgs_tol=model_pack.DEFAULT_PGS_TOL, solver=model_pack.DEFAULT_SOLVER):
     """(model, ib, fb) for an environment name (v2 names share the v1 morphology)."""
     xml_name = env_name.replace("_v2_", "_")
     m = mjcf.load_asset(xml_name)
     ib, fb = model_pack.pack_model(m, spec=env_spec_for(env_name), max_rows=max_rows, pgs_iters=pgs_iters,
-                                   pgs_tol=pgs_tol)
+                                   pgs_tol=pgs_tol, solver=solver)
     return m, ib, fb
 
 

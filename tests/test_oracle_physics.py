@@ -296,20 +296,27 @@ def test_joint_limit_pushes_back():
 
 def test_pgs_reaches_the_dual_optimum():
     """KKT check of the converged solve via a long run: qacc from the default tolerance equals a 20000-sweep solve."""
-    m, om = oracle_model("3d_walker_7_full")
-    m2, oref = oracle_model("3d_walker_7_full", pgs_iters=20000, pgs_tol=0.0, max_rows=320)
+    m, om = oracle_model("3d_walker_7_full")                      # default: block-pivot direct solve
+    m2, oref = oracle_model("3d_walker_7_full", pgs_iters=20000, pgs_tol=0.0, max_rows=320, solver=0)   # pure PGS
+    m3, opgs = oracle_model("3d_walker_7_full", solver=0)           # PGS at the default tolerance
     env = physics_ref.OracleEnv(om, seed=3)
     env.reset()
     rng = np.random.RandomState(0)
-    worst = 0
+    worst = worst_pgs = 0
+    nrow_max = 0
     for t in range(120):
         a = rng.uniform(-1, 1, size=3 * om.L)
         if t % 6 == 0:
             x1, _, d1 = om.forward(env.qpos, env.qvel, a[3:])
             x2, _, d2 = oref.forward(env.qpos, env.qvel, a[3:])
+            x3, _, d3 = opgs.forward(env.qpos, env.qvel, a[3:])
             worst = max(worst, np.abs(x1 - x2).max() / (np.abs(x2).max() + 1e-9))
+            worst_pgs = max(worst_pgs, np.abs(x3 - x2).max() / (np.abs(x2).max() + 1e-9))
+            nrow_max = max(nrow_max, d1["nrow"])
         env.step(a)
-    assert worst < 5e-9
+    assert nrow_max >= 8
+    assert worst < 1e-10        # the direct solve is the optimum (to rounding of the 20000-sweep reference)
+    assert worst_pgs < 5e-9     # and plain PGS at tol 1e-10 lands within a few 1e-10 of it
 
 
 def test_random_rollouts_stay_finite_and_terminate():

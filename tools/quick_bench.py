@@ -28,4 +28,7 @@ print("ms/step %.3f env-steps/s %.0f" % (dt / steps * 1e3, env.num_envs * steps 
 ms = env.time_steps(a, 10)
 print("hip-event ms/launch %.3f -> %.0f env-steps/s" % (ms, env.num_envs / ms * 1e3))
 rec, cnt = env.get_records()
+import numpy as np
+for k, sl in enumerate(env.morph_slices):
+    print("  %-36s row-updates/env-step mean %7.0f max %7d" % (names[k], cnt[sl, 3].mean(), cnt[sl, 3].max()))
 print("overflow envs", int((cnt[:, 2] > 0).sum()), "episodes mean", cnt[:, 1].mean())
