@@ -46,7 +46,7 @@ def cpu_baseline(names, seed, budget_s=12.0):
     import numpy as np
     cores = os.cpu_count() or 1
     per_morph = 16
-    steps = 150
+    steps = 400
     jobs = [(n, i, seed, steps) for n in names for i in range(per_morph)]
     from concurrent.futures import ProcessPoolExecutor
     from oracle import physics_ref
@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--envs-per-morph", type=int, default=1024)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preroll", type=int, default=200,
+                    help="untimed rollout steps run during set-up so that episodes are desynchronised and the timed "
+                         "steps see the stationary mix of flight / stance / fallen states (not warm-up of the code)")
     args = ap.parse_args()
     import faulthandler
     faulthandler.dump_traceback_later(900, exit=True)   # never hang a GPU box: dump stacks and exit
@@ -149,6 +152,8 @@ def main():
             gather.push()
 
     ro.reset()
+    for _ in range(args.preroll):          # synthetic-state preparation: reach the stationary episode mix
+        ro.step(ro.random_actions())
     for _ in range(args.warmup):
         one_step()
 
@@ -176,8 +181,15 @@ def main():
         ms_set = ro.actor.time_forward(env.obs, ro.policy_actions, 5)
         bytes_step = algorithmic_bytes_per_env_step(env)
         achieved = bytes_step * n_local / (ms_step * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):   # FETCH_SIZE/WRITE_SIZE of k_env_step from separate rocprofv3 --pmc passes of this command
+            with open(pmc) as f:
+                pj = json.load(f)
+            if pj.get("envs_per_gpu") == n_local:
+                traffic = pj.get("k_env_step_bytes_per_launch")
         extra["roofline"] = {"bound": "hbm", "kernel": "k_env_step", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                              "algorithmic_bytes_per_launch": int(bytes_step * n_local),
                              "ms_per_launch": round(ms_step, 4),
                              "note": "latency/VALU-bound FP64 rigid-body kernel: ~2 KB of HBM traffic per env-step "

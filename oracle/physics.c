@@ -531,16 +531,16 @@ static void make_constraints(const SgrlModelView* m, const double* qpos, const d
  * warm start, solve A_FF x = -b_F, exchange all indices violating x_F >= 0 / (A x + b)_G >= -thresh (one index after
  * the violation count stopped shrinking three times), repeat.  Returns 1 when a complementary solution was found. */
 static int lcp_block_pivot(int n, int nv, Work* w, const double* diag, double thresh) {
-  static double A[32][32];
-  double C[32][32], x[32], rhs[32];
-  int F[32], list[32];
+  static double A[64][64];
+  static double C[64][64];
+  double x[64], rhs[64];
+  int F[64], list[64];
   for (int i = 0; i < n; i++) for (int j = 0; j <= i; j++) {
     double s = 0;
     for (int d = 0; d < nv; d++) s += w->Y[i][d] * w->Y[j][d];
     if (i == j) s += w->efc_R[i];
     A[i][j] = s; A[j][i] = s;
   }
-  (void)diag;
   for (int i = 0; i < n; i++) F[i] = w->efc_f[i] > 0.0;
   int patience = 3, best = n + 1;
   for (int iter = 0; iter < 40; iter++) {
@@ -559,10 +559,10 @@ static int lcp_block_pivot(int n, int nv, Work* w, const double* diag, double th
     }
     for (int i = 0; i < nf; i++) { double s = -w->efc_b[list[i]]; for (int k = 0; k < i; k++) s -= C[i][k] * rhs[k]; rhs[i] = s / C[i][i]; }
     for (int i = nf - 1; i >= 0; i--) { double s = rhs[i]; for (int k = i + 1; k < nf; k++) s -= C[k][i] * x[k]; x[i] = s / C[i][i]; }
-    int viol[32], nviol = 0, top = -1, pos = 0;
+    int viol[64], nviol = 0, top = -1, pos = 0;
     for (int i = 0; i < n; i++) {
       int bad;
-      if (F[i]) { bad = x[pos] < 0.0; pos++; }
+      if (F[i]) { bad = x[pos] < -thresh / diag[i]; pos++; }
       else {
         double y = w->efc_b[i];
         for (int k = 0; k < nf; k++) y += A[i][list[k]] * x[k];
@@ -616,10 +616,8 @@ static void solve_constraints(const SgrlModelView* m, Work* w) {
   const double thresh = m->fhdr[SGRL_F_PGS_TOL] * (1.0 + bmax);
   int solved = 0;
   {
-    /* same dispatch rule as the engine (step_body.h make_layout): dense form only while the factor fits its scratch */
-    int dead_len = 42 * m->nbody + 3 * m->njnt + 26 * m->npair, na = 0;
-    while (na < 32 && (na + 1) * (na + 2) / 2 <= dead_len) na++;
-    if (m->hdr[SGRL_H_SOLVER] == 1 && n <= na) solved = lcp_block_pivot(n, nv, w, diag, thresh);
+    /* same dispatch rule as the engine: exact block-pivot solve up to 64 rows, Gauss-Seidel beyond */
+    if (m->hdr[SGRL_H_SOLVER] == 1 && n <= 64) solved = lcp_block_pivot(n, nv, w, diag, thresh);
   }
   if (solved) {
     for (int d = 0; d < nv; d++) { double s = 0; for (int r = 0; r < n; r++) s += w->Y[r][d] * w->efc_f[r]; v[d] = s; }

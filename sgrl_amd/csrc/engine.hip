@@ -42,6 +42,7 @@ struct BatchArgs {
   const int32_t* block_env;   // [n_env] workgroup -> env, most expensive morphologies first (tail balance)
   double* rec;                // [n_env * stride]
   int32_t* cnt;               // [n_env * 4]
+  double* scratch;            // [n_env * kScratchDoubles] HBM slabs for the rare > 32-row constraint solves
   int stride;
   int n_env;
   int obs_max_len, action_max_len;
@@ -96,6 +97,7 @@ __device__ __forceinline__ sgrl::StepIO make_io(const BatchArgs& a, const StepOu
   io.dist = out.dist ? out.dist + env : nullptr;
   io.truncated = out.truncated ? out.truncated + env : nullptr;
   io.obs_max_len = a.obs_max_len;
+  io.scratch = a.scratch ? a.scratch + (size_t)env * sgrl::kScratchDoubles : nullptr;
   io.seed = a.seed;
   io.env_id = a.env_id_base + (uint32_t)env;
   io.max_episode_steps = a.max_episode_steps;
@@ -103,13 +105,24 @@ __device__ __forceinline__ sgrl::StepIO make_io(const BatchArgs& a, const StepOu
   return io;
 }
 
+#ifdef SGRL_PHASE_PROF
+__device__ unsigned long long g_phase_prof[16 * 65536];
+#endif
+
 __global__ __launch_bounds__(64) void k_env_step(BatchArgs a, StepOut out) {
   const int env = a.block_env[blockIdx.x];
   SgrlModelView m; sgrl::Layout o; double* S; int32_t* I;
   setup(a, env, &m, &o, &S, &I);
   sgrl::HipWave w;
+#ifdef SGRL_PHASE_PROF
+  w.prof = g_phase_prof + 16 * (size_t)(env & 65535);
+  const long long t_begin = __builtin_readcyclecounter();
+#endif
   const sgrl::StepIO io = make_io(a, out, env);
   sgrl::env_step(w, m, o, S, I, io);
+#ifdef SGRL_PHASE_PROF
+  if (w.lane == 0) w.prof[15] += (unsigned long long)(__builtin_readcyclecounter() - t_begin);
+#endif
 }
 
 __global__ __launch_bounds__(64) void k_env_reset(BatchArgs a, StepOut out) {
@@ -142,6 +155,7 @@ struct sgrl_engine {
   int32_t* d_block_env = nullptr;
   double* d_rec = nullptr;
   int32_t* d_cnt = nullptr;
+  double* d_scratch = nullptr;
   BatchArgs args{};
 };
 
@@ -149,6 +163,14 @@ extern "C" {
 
 const char* sgrl_last_error(void) { return g_err.c_str(); }
 const char* sgrl_version(void) { return "sgrl-hip 0.1.0 (gfx950)"; }
+#ifdef SGRL_PHASE_PROF
+int sgrl_phase_prof(unsigned long long* host, int n_env, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (host && hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phase_prof), sizeof(unsigned long long) * 16 * (size_t)n_env) != hipSuccess) return -2;
+  if (reset) { static unsigned long long z[16 * 65536]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_prof), z, sizeof(z)) != hipSuccess) return -3; }
+  return 0;
+}
+#endif
 
 void sgrl_engine_destroy(sgrl_engine* e) {
   if (!e) return;
@@ -159,6 +181,7 @@ void sgrl_engine_destroy(sgrl_engine* e) {
   if (e->d_block_env) (void)hipFree(e->d_block_env);
   if (e->d_rec) (void)hipFree(e->d_rec);
   if (e->d_cnt) (void)hipFree(e->d_cnt);
+  if (e->d_scratch) (void)hipFree(e->d_scratch);
   delete e;
 }
 
@@ -213,7 +236,8 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
             hipMalloc(&e->d_env_morph, sizeof(int32_t) * e->n_env) == hipSuccess &&
             hipMalloc(&e->d_block_env, sizeof(int32_t) * e->n_env) == hipSuccess &&
             hipMalloc(&e->d_rec, sizeof(double) * (size_t)e->n_env * e->stride) == hipSuccess &&
-            hipMalloc(&e->d_cnt, sizeof(int32_t) * (size_t)e->n_env * 4) == hipSuccess;
+            hipMalloc(&e->d_cnt, sizeof(int32_t) * (size_t)e->n_env * 4) == hipSuccess &&
+            hipMalloc(&e->d_scratch, sizeof(double) * (size_t)e->n_env * sgrl::kScratchDoubles) == hipSuccess;
   if (!ok) { sgrl_engine_destroy(e); return fail(SGRL_ERR_HIP, "hipMalloc(state) failed"); }
   (void)hipMemcpy(e->d_morphs, morphs.data(), sizeof(MorphDev) * n_morph, hipMemcpyHostToDevice);
   (void)hipMemcpy(e->d_env_morph, env_morph.data(), sizeof(int32_t) * e->n_env, hipMemcpyHostToDevice);
@@ -239,7 +263,7 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
     if (a1 != hipSuccess || a2 != hipSuccess || a3 != hipSuccess) { sgrl_engine_destroy(e); return fail(SGRL_ERR_HIP, "cannot raise the dynamic LDS limit"); }
   }
   BatchArgs& a = e->args;
-  a.morphs = e->d_morphs; a.env_morph = e->d_env_morph; a.block_env = e->d_block_env; a.rec = e->d_rec; a.cnt = e->d_cnt;
+  a.morphs = e->d_morphs; a.env_morph = e->d_env_morph; a.block_env = e->d_block_env; a.rec = e->d_rec; a.cnt = e->d_cnt; a.scratch = e->d_scratch;
   a.stride = e->stride; a.n_env = e->n_env; a.obs_max_len = obs_max_len; a.action_max_len = action_max_len;
   a.seed = seed; a.env_id_base = env_id_base; a.max_episode_steps = max_episode_steps;
   if (hipDeviceSynchronize() != hipSuccess) { sgrl_engine_destroy(e); return fail(SGRL_ERR_HIP, "device error during engine setup"); }

@@ -39,7 +39,8 @@ constexpr double kMinImp = 0.0001;
 constexpr double kMaxImp = 0.9999;
 constexpr double kPi = 3.14159265358979323846;
 constexpr int kNAMax = 32;
-constexpr int kBppMaxIter = 40;  // largest row count solved in the dense A = Y Y' + R form (packed lower triangle in LDS)
+constexpr int kBppMaxIter = 40;
+constexpr int kScratchDoubles = 64 * 65;   // per-env HBM slab: A and its factor for up to 64 rows  // largest row count solved in the dense A = Y Y' + R form (packed lower triangle in LDS)
 
 // ------------------------------------------------------------------------------------------------
 // LDS layout (offsets in doubles for S, in ints for I)
@@ -58,7 +59,7 @@ struct Layout {
   int model_f; // LDS copy of the float model blob (n_f64 doubles)
   int s_total;
   // I
-  int con_valid, row_kind, row_src, row_sub, prev_key, flist, icnt;
+  int con_valid, row_kind, row_src, row_sub, prev_key, flist, ecnt, icnt;
   int model_i; // LDS copy of the int model blob (n_int ints)
   int i_total;
 };
@@ -105,6 +106,7 @@ SGRL_HD void make_layout(const int32_t* hdr, Layout* o, int n_int = 0, int n_f64
   o->row_kind = q; q += o->maxrows; o->row_src = q; q += o->maxrows; o->row_sub = q; q += o->maxrows;
   o->prev_key = q; q += o->maxrows;
   o->flist = q; q += o->maxrows;
+  o->ecnt = q; q += 2 * nj + o->ncon;
   o->icnt = q; q += 8;
   o->model_i = q; q += n_int;
   o->i_total = q;
@@ -156,8 +158,9 @@ SGRL_DEV void mat_vec(double* r, const double* m, const double* v) {
 }
 SGRL_DEV void axisangle2quat(double* q, const double* axis, double angle) {
   if (angle == 0.0) { q[0] = 1; q[1] = 0; q[2] = 0; q[3] = 0; return; }
-  const double s = sin(0.5 * angle);
-  q[0] = cos(0.5 * angle); q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+  double s, c;
+  sincos(0.5 * angle, &s, &c);
+  q[0] = c; q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
 }
 // spatial inertia (Ixx Iyy Izz Ixy Ixz Iyz | hx hy hz | m) times motion [w; v] -> force [tau; F]
 SGRL_DEV void inert_mul(double* f, const double* I, const double* mv) {
@@ -226,6 +229,7 @@ struct Engine {
   const Layout& o;
   double* S;
   int32_t* I;
+  double* big_scratch = nullptr;   // optional per-env HBM slab: 2 * 64*65/2 doubles
 
   SGRL_DEV Engine(W& w_, const SgrlModelView& m_, const Layout& o_, double* S_, int32_t* I_)
       : w(w_), m(m_), o(o_), S(S_), I(I_) {}
@@ -389,7 +393,17 @@ struct Engine {
     for (int j = 0; j < nv; j++) {
       w.lanes_from(j, nv, [&](int i) {
         double s = S[base + i * ld + j];
-        for (int k = 0; k < j; k++) s -= S[base + i * ld + k] * S[base + j * ld + k] * S[o.xtmp + k];
+        const double* ci = S + base + i * ld;
+        const double* cj = S + base + j * ld;
+        const double* wt = S + o.xtmp;
+        int k = 0;
+        for (; k + 4 <= j; k += 4) {   // four independent LDS triples in flight per wait
+          const double a0 = ci[k], a1 = ci[k + 1], a2 = ci[k + 2], a3 = ci[k + 3];
+          const double b0 = cj[k], b1 = cj[k + 1], b2 = cj[k + 2], b3 = cj[k + 3];
+          const double w0 = wt[k], w1 = wt[k + 1], w2 = wt[k + 2], w3 = wt[k + 3];
+          s -= a0 * b0 * w0; s -= a1 * b1 * w1; s -= a2 * b2 * w2; s -= a3 * b3 * w3;
+        }
+        for (; k < j; k++) s -= ci[k] * cj[k] * wt[k];
         if (i == j) { if (s < kMinVal) s = kMinVal; S[o.xtmp + j] = 1.0 / s; }
         S[base + i * ld + j] = s;
       });
@@ -416,7 +430,15 @@ struct Engine {
     const int nv = o.nv, ld = o.ld;
     for (int i = 0; i < nv; i++) {
       double s = S[xo + i];
-      for (int k = 0; k < i; k++) s -= S[base + i * ld + k] * S[xo + k];
+      const double* li = S + base + i * ld;
+      const double* x = S + xo;
+      int k = 0;
+      for (; k + 4 <= i; k += 4) {
+        const double a0 = li[k], a1 = li[k + 1], a2 = li[k + 2], a3 = li[k + 3];
+        const double x0 = x[k], x1 = x[k + 1], x2 = x[k + 2], x3 = x[k + 3];
+        s -= a0 * x0; s -= a1 * x1; s -= a2 * x2; s -= a3 * x3;
+      }
+      for (; k < i; k++) s -= li[k] * x[k];
       S[xo + i] = s * S[o.dinv + i];
     }
   }
@@ -615,6 +637,40 @@ struct Engine {
 
   // row table (serial, lane 0): limits in joint order, then contacts in slot order; same cap rule as the oracle
   SGRL_DEV void enumerate_rows() {
+    // lane-parallel: item t = (joint, side) for t < 2*nj, contact slot otherwise; rows wanted per item, then every
+    // lane takes the prefix sum of the items before it.  Falls back to the serial walk only when the cap would bite.
+    const int nitem = 2 * o.nj + o.ncon;
+    w.lanes(nitem, [&](int t) {
+      int c = 0;
+      if (t < 2 * o.nj) {
+        const int j = t >> 1, side = (t & 1) ? 1 : -1;
+        if (m.jnt_limited[j]) {
+          const double q = S[o.qpos + m.jnt_qposadr[j]];
+          const double dist = side * (m.jnt_range[2 * j + (side + 1) / 2] - q);
+          if (dist < m.jnt_margin[j]) c = 1;
+        }
+      } else {
+        const int sl = t - 2 * o.nj;
+        if (I[o.con_valid + sl]) { const int dim = m.pair_condim[sl >> 1]; c = (dim == 1) ? 1 : 2 * (dim - 1); }
+      }
+      I[o.ecnt + t] = c;
+    });
+    w.lanes(nitem, [&](int t) {
+      int pre = 0;
+      for (int u = 0; u < t; u++) pre += I[o.ecnt + u];
+      const int c = I[o.ecnt + t];
+      if (t == nitem - 1) I[o.icnt + IC_NROW_WANTED] = pre + c;
+      if (c > 0 && pre + c <= o.maxrows) {
+        for (int k = 0; k < c; k++) {
+          if (t < 2 * o.nj) { I[o.row_kind + pre] = (t & 1) ? ROW_LIMIT_HI : ROW_LIMIT_LO; I[o.row_src + pre] = t >> 1; I[o.row_sub + pre] = 0; }
+          else { I[o.row_kind + pre + k] = (c == 1) ? ROW_CON1 : ROW_PYR; I[o.row_src + pre + k] = t - 2 * o.nj; I[o.row_sub + pre + k] = k; }
+        }
+      }
+    });
+    if (I[o.icnt + IC_NROW_WANTED] <= o.maxrows) {
+      w.lanes(1, [&](int) { I[o.icnt + IC_NROW] = I[o.icnt + IC_NROW_WANTED]; });
+      return;
+    }
     w.lanes(1, [&](int) {
       int nrow = 0, wanted = 0;
       const int maxrows = o.maxrows;
@@ -754,8 +810,8 @@ struct Engine {
   // Cholesky, exchange every index that violates x_F >= 0 or (A x + b)_G >= 0 (a single index once the number of
   // violations has stopped shrinking), repeat.  The free set is warm-started from the previous evaluation.  The
   // result is the same unique optimum projected Gauss-Seidel converges to; PGS remains the fallback.
-  SGRL_DEV bool lcp_block_pivot(int n, double thresh, int* iters_out) {
-    const int cpk = o.dead, wv = o.earef, xw = o.prev_f;
+  SGRL_DEV bool lcp_block_pivot(int n, double thresh, const double* A, double* C, int* iters_out) {
+    const int wv = o.earef, xw = o.prev_f;
     uint64_t F = w.ballot(n, [&](int i) { return S[o.ef + i] > 0.0; });
     int patience = 3, best = n + 1;
     for (int iter = 0; iter < kBppMaxIter; iter++) {
@@ -771,31 +827,39 @@ struct Engine {
       for (int j = 0; j < nf; j++) {
         w.lanes_from(j, nf, [&](int i) {
           const int fi = I[o.flist + i], fj = I[o.flist + j];
-          double s = S[o.Apk + fi * (fi + 1) / 2 + fj];   // fi >= fj because the list is ascending
-          const double* ci = S + cpk + i * (i + 1) / 2;
-          const double* cj = S + cpk + j * (j + 1) / 2;
-          for (int k = 0; k < j; k++) s -= ci[k] * cj[k] * S[wv + k];
+          double s = A[fi * (fi + 1) / 2 + fj];   // fi >= fj because the list is ascending
+          const double* ci = C + i * (i + 1) / 2;
+          const double* cj = C + j * (j + 1) / 2;
+          const double* wt = S + wv;
+          int k = 0;
+          for (; k + 4 <= j; k += 4) {
+            const double a0 = ci[k], a1 = ci[k + 1], a2 = ci[k + 2], a3 = ci[k + 3];
+            const double b0 = cj[k], b1 = cj[k + 1], b2 = cj[k + 2], b3 = cj[k + 3];
+            const double w0 = wt[k], w1 = wt[k + 1], w2 = wt[k + 2], w3 = wt[k + 3];
+            s -= a0 * b0 * w0; s -= a1 * b1 * w1; s -= a2 * b2 * w2; s -= a3 * b3 * w3;
+          }
+          for (; k < j; k++) s -= ci[k] * cj[k] * wt[k];
           if (i == j) { if (s < kMinVal) s = kMinVal; S[wv + j] = 1.0 / s; }
-          S[cpk + i * (i + 1) / 2 + j] = s;
+          C[i * (i + 1) / 2 + j] = s;
         });
       }
       // forward substitution (column sweeps), diagonal scaling, backward substitution
       for (int j = 0; j < nf; j++) {
         const double zj = S[xw + j] * S[wv + j];
-        w.lanes_from(j + 1, nf, [&](int i) { S[xw + i] -= S[cpk + i * (i + 1) / 2 + j] * zj; });
+        w.lanes_from(j + 1, nf, [&](int i) { S[xw + i] -= C[i * (i + 1) / 2 + j] * zj; });
       }
       w.lanes(nf, [&](int i) { S[xw + i] *= S[wv + i]; });
       for (int j = nf - 1; j > 0; j--) {
         const double xj = S[xw + j];
-        w.lanes(j, [&](int k) { S[xw + k] -= S[cpk + j * (j + 1) / 2 + k] * S[wv + k] * xj; });
+        w.lanes(j, [&](int k) { S[xw + k] -= C[j * (j + 1) / 2 + k] * S[wv + k] * xj; });
       }
       // violations: x_i < 0 on F, (A x + b)_i < -thresh on the complement
       const uint64_t V = w.ballot(n, [&](int i) {
-        if ((F >> i) & 1ull) return S[xw + popcount64(F & ((1ull << i) - 1ull))] < 0.0;
+        if ((F >> i) & 1ull) return S[xw + popcount64(F & ((1ull << i) - 1ull))] < -thresh * S[o.eidg + i];
         double y = S[o.eb + i];
         for (int k = 0; k < nf; k++) {
           const int fk = I[o.flist + k];
-          y += (i >= fk ? S[o.Apk + i * (i + 1) / 2 + fk] : S[o.Apk + fk * (fk + 1) / 2 + i]) * S[xw + k];
+          y += (i >= fk ? A[i * (i + 1) / 2 + fk] : A[fk * (fk + 1) / 2 + i]) * S[xw + k];
         }
         return y < -thresh;
       });
@@ -817,14 +881,9 @@ struct Engine {
     return false;
   }
 
-  SGRL_DEV void pgs_and_finish() {
+  // dense-form dual solve: assemble A = Y Y' + diag(R) (packed lower triangle), block-pivot LCP solve, v = Y' f
+  SGRL_DEV void solve_dense(int nrow, double thresh, double* A, double* C, int* sweeps, int* diag_code) {
     const int nv = o.nv, ldy = o.ldy;
-    const int nrow = I[o.icnt + IC_NROW];
-    int sweeps = 0;
-    if (nrow > 0) {
-      const double bmax = w.maxabs(nrow, [&](int r) { return S[o.eb + r]; });
-      const double thresh = m.fhdr[SGRL_F_PGS_TOL] * (1.0 + bmax);
-      if (nrow <= o.na_max) {
         // dense form: A = Y Y' + diag(R) once (packed lower triangle), then each row update is one broadcast of the
         // row's residual and one rank-1 residual update  r += A[:, j] * df  -- no reduction on the critical path
         const int npair = nrow * (nrow + 1) / 2;
@@ -844,19 +903,38 @@ struct Engine {
           }
           for (; d < nv; d++) a += yi[d] * yj[d];
           if (i == j) a += S[o.eR + i];
-          S[o.Apk + p] = a;
+          A[p] = a;
         });
         bool solved = false;
-        if (m.hdr[SGRL_H_SOLVER] == 1) solved = lcp_block_pivot(nrow, thresh, &sweeps);
+        if (m.hdr[SGRL_H_SOLVER] == 1) solved = lcp_block_pivot(nrow, thresh, A, C, sweeps);
+        if (!solved) *diag_code |= 1 << 8;   // diagnostics: block pivoting gave up
         if (!solved)
-          sweeps = w.pgs_dense(nrow, S + o.Apk, S + o.eb, S + o.ediag, S + o.eidg, S + o.ef, m.hdr[SGRL_H_PGS_ITERS], thresh);
+          *sweeps = w.pgs_dense(nrow, A, S + o.eb, S + o.ediag, S + o.eidg, S + o.ef, m.hdr[SGRL_H_PGS_ITERS], thresh);
         w.lanes(nv, [&](int d) {
           double v = 0;
           for (int r = 0; r < nrow; r++) v += S[o.Y + r * ldy + d] * S[o.ef + r];
           S[o.vpgs + d] = v;
         });
+  }
+
+  SGRL_DEV void pgs_and_finish() {
+    const int nv = o.nv, ldy = o.ldy;
+    const int nrow = I[o.icnt + IC_NROW];
+    int sweeps = 0, diag_code = 0;
+    if (nrow > 0) {
+      const double bmax = w.maxabs(nrow, [&](int r) { return S[o.eb + r]; });
+      const double thresh = m.fhdr[SGRL_F_PGS_TOL] * (1.0 + bmax);
+      if (nrow <= o.na_max) {
+        solve_dense(nrow, thresh, S + o.Apk, S + o.dead, &sweeps, &diag_code);          // A and factor in LDS
+      } else if (big_scratch != nullptr && nrow <= 64) {
+        // rare (a few envs per 8192-env launch): more rows than the LDS scratch holds -> same exact solve with A and
+        // the factor in this environment's HBM scratch slab instead of hundreds of Gauss-Seidel sweeps
+        const int tri = nrow * (nrow + 1) / 2;
+        solve_dense(nrow, thresh, big_scratch, big_scratch + tri, &sweeps, &diag_code);
+        diag_code |= 1 << 16;
       } else {
         // many rows: matrix-free form, the policy keeps v = Y'f one entry per lane
+        diag_code = 1;                     // diagnostics: evaluation solved by the matrix-free PGS path
         sweeps = w.pgs(nrow, nv, S + o.Y, ldy, S + o.eb, S + o.eR, S + o.ediag, S + o.eidg, S + o.ef, S + o.vpgs,
                        m.hdr[SGRL_H_PGS_ITERS], thresh);
       }
@@ -867,22 +945,28 @@ struct Engine {
         I[o.prev_key + r] = (I[o.row_kind + r] << 16) | (I[o.row_src + r] << 3) | I[o.row_sub + r];
         S[o.prev_f + r] = S[o.ef + r];
       }
-      if (r == 0) { I[o.icnt + IC_PREV_N] = nrow; I[o.icnt + IC_SWEEPS] += sweeps; I[o.icnt + IC_ROWSUM] += sweeps * nrow; }
+      if (r == 0) { I[o.icnt + IC_PREV_N] = nrow; I[o.icnt + IC_SWEEPS] += sweeps; I[o.icnt + IC_ROWSUM] += diag_code; }
     });
     // qacc = L^-T (ys + Y' f)
     w.lanes(nv, [&](int d) { S[o.qacc + d] = S[o.ys + d] + (nrow > 0 ? S[o.vpgs + d] : 0.0); });
     solve_upper_inplace(o.L, o.qacc);
   }
 
+#ifdef SGRL_PHASE_PROF
+#define SGRL_TICK(id) w.tick(id)
+#else
+#define SGRL_TICK(id)
+#endif
   SGRL_DEV void forward() {
-    kinematics();
-    com_pos();
-    crba_and_factor();
-    collide();
-    bias_and_smooth_force();
-    enumerate_rows();
-    build_rows_and_halfsolve();
-    pgs_and_finish();
+    SGRL_TICK(-1);
+    kinematics();               SGRL_TICK(0);
+    com_pos();                  SGRL_TICK(1);
+    crba_and_factor();          SGRL_TICK(2);
+    collide();                  SGRL_TICK(3);
+    bias_and_smooth_force();    SGRL_TICK(4);
+    enumerate_rows();           SGRL_TICK(5);
+    build_rows_and_halfsolve(); SGRL_TICK(6);
+    pgs_and_finish();           SGRL_TICK(7);
   }
 
   // ---- integration ----------------------------------------------------------------------------
@@ -1119,6 +1203,7 @@ struct StepIO {
   float* reward; uint8_t* done; float* dist; uint8_t* truncated;  // scalars for this env (nullable)
   double* reward64;      // nullable
   int obs_max_len;
+  double* scratch;       // per-env HBM slab (SGRL_SCRATCH_DOUBLES doubles) or null
   uint64_t seed; uint32_t env_id; int max_episode_steps; int auto_reset;
 };
 
@@ -1174,6 +1259,7 @@ SGRL_DEV void env_refresh(W& w, const SgrlModelView& m, const Layout& o, double*
 template <class W>
 SGRL_DEV void env_step(W& w, const SgrlModelView& m, const Layout& o, double* S, int32_t* I, const StepIO& io) {
   Engine<W> e(w, m, o, S, I);
+  e.big_scratch = io.scratch;
   load_state(e, io);
   w.lanes(o.nu > 8 ? o.nu : 8, [&](int u) {
     if (u < o.nu) { const int s = m.act_slot[u]; S[o.ctrl + u] = s >= 0 ? (double)io.action[s] : 0.0; }
@@ -1203,7 +1289,7 @@ SGRL_DEV void env_step(W& w, const SgrlModelView& m, const Layout& o, double* S,
     I[o.icnt + IC_DONE] = done; I[o.icnt + IC_TRUNC] = trunc;
     io.cnt[0] = steps;
     io.cnt[2] += I[o.icnt + IC_OVERFLOW];
-    io.cnt[3] = I[o.icnt + IC_ROWSUM];   // diagnostics: PGS row updates of this env-step
+    io.cnt[3] = I[o.icnt + IC_ROWSUM];   // diagnostics: (#block-pivot failures << 8) | #evaluations on the matrix-free PGS path
     if (io.reward) *io.reward = (float)S[o.misc + MS_REWARD];
     if (io.reward64) *io.reward64 = S[o.misc + MS_REWARD];
     if (io.done) *io.done = (uint8_t)done;

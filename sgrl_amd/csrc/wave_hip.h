@@ -36,6 +36,16 @@ __device__ __forceinline__ double wave_max(double x) {
 
 struct HipWave {
   int lane;
+#ifdef SGRL_PHASE_PROF
+  // diagnostic build only (tools/phase_prof.py): s_memtime deltas per phase of Engine::forward, lane 0 accumulates
+  long long t_last = 0;
+  unsigned long long* prof = nullptr;   // [16] per workgroup
+  __device__ __forceinline__ void tick(int id) {
+    const long long t = __builtin_readcyclecounter();
+    if (id >= 0 && prof && lane == 0) prof[id] += (unsigned long long)(t - t_last);
+    t_last = __builtin_readcyclecounter();
+  }
+#endif
   __device__ __forceinline__ HipWave() : lane(threadIdx.x & 63) {}
   template <class F> __device__ __forceinline__ void lanes(int n, F f) {
     for (int i = lane; i < n; i += 64) f(i);

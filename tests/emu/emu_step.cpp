@@ -95,6 +95,8 @@ int sgrl_emu_forward(const int32_t* ib, const double* fb, double* qpos, const do
   std::vector<int32_t> I(o.i_total + 2, -12345);
   EmuWave w;
   sgrl::Engine<EmuWave> e(w, m, o, S.data(), I.data());
+  static std::vector<double> fscratch(sgrl::kScratchDoubles);
+  e.big_scratch = fscratch.data();
   for (int i = 0; i < m.nq; i++) S[o.qpos + i] = qpos[i];
   for (int i = 0; i < m.nv; i++) S[o.qvel + i] = qvel[i];
   for (int i = 0; i < m.nu; i++) S[o.ctrl + i] = ctrl[i];
@@ -124,6 +126,8 @@ int sgrl_emu_env(int op, const int32_t* ib, const double* fb, double* rec, int32
   sgrl::StepIO io;
   io.rec = rec; io.cnt = cnt; io.action = action; io.obs32 = obs32; io.obs64 = obs64; io.reward = nullptr;
   io.done = done; io.dist = dist; io.truncated = truncated; io.reward64 = reward64; io.obs_max_len = obs_max_len;
+  static std::vector<double> scratch(sgrl::kScratchDoubles);
+  io.scratch = scratch.data();
   io.seed = seed; io.env_id = env_id; io.max_episode_steps = max_episode_steps; io.auto_reset = auto_reset;
   if (op == 0) sgrl::env_reset(w, m, o, S.data(), I.data(), io, false);
   else if (op == 1) sgrl::env_step(w, m, o, S.data(), I.data(), io);

@@ -16,7 +16,10 @@ env = BatchedModularVecEnv(names, per, seed=1, device="cuda:0", **kw)
 print("n_env", env.num_envs, "lds_bytes", env.lds_bytes)
 env.reset_device()
 a = (torch.rand((env.num_envs, env.action_max_len), device="cuda") * 2 - 1).contiguous()
-for _ in range(30): env.step_device(a)
+WARM = int(os.environ.get('WARM', '30'))
+for _ in range(WARM):
+    a = (torch.rand((env.num_envs, env.action_max_len), device='cuda') * 2 - 1).contiguous()
+    env.step_device(a)
 torch.cuda.synchronize()
 t0 = time.time()
 for _ in range(steps):
@@ -30,5 +33,7 @@ print("hip-event ms/launch %.3f -> %.0f env-steps/s" % (ms, env.num_envs / ms * 
 rec, cnt = env.get_records()
 import numpy as np
 for k, sl in enumerate(env.morph_slices):
-    print("  %-36s row-updates/env-step mean %7.0f max %7d" % (names[k], cnt[sl, 3].mean(), cnt[sl, 3].max()))
+    c3 = cnt[sl, 3]
+    print("  %-36s envs with matrix-free-PGS evals %5d (max evals %2d) | envs with block-pivot failures %4d" % (
+        names[k], int(((c3 & 255) > 0).sum()), int((c3 & 255).max()), int(((c3 >> 8) > 0).sum())))
 print("overflow envs", int((cnt[:, 2] > 0).sum()), "episodes mean", cnt[:, 1].mean())
