@@ -37,7 +37,10 @@ constexpr int ZD = 32;
 // ------------------------------------------------------------------------------------------------
 // f32 MFMA GEMM:  C[M,N] = epi(A[M,K] . W[N,K]^T)      block tile 128x128x32, 4 waves of 64x64
 enum { EPI_RELU = 1, EPI_ROWDIV = 2, EPI_ACC2 = 4 };
-constexpr int BM = 128, BN = 128, BK = 32, LDT = 130;
+constexpr int BM = 128, BN = 128, BK = 16, LDT = 130;
+constexpr int TPR = BK / 4;          // threads per tile row (one float4 each)
+constexpr int RPP = 256 / TPR;       // rows covered per pass
+constexpr int NPASS = BM / RPP;      // passes to cover the 128 rows
 constexpr int GEMM_LDS_BYTES = 4 * BK * LDT * (int)sizeof(float);
 
 struct GemmArgs {
@@ -51,6 +54,7 @@ struct GemmArgs {
   float* C2; int ldc2;  // EPI_ACC2: C2[m][n] += value
 };
 
+template <int FLAGS>
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
   extern __shared__ float gemm_lds[];   // 2 stages x (A tile + W tile), k-major [BK][LDT]: 66 560 B
   float (*As)[BK][LDT] = reinterpret_cast<float (*)[BK][LDT]>(gemm_lds);
@@ -68,14 +72,14 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
   }
   const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int kq = t & 7, r0 = t >> 3;
+  const int kq = t % TPR, r0 = t / TPR;
   f32x16 acc[2][2];
   for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
-  float4 ra[4], rw[4];
+  float4 ra[NPASS], rw[NPASS];
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int row = r0 + 32 * i;
+    for (int i = 0; i < NPASS; i++) {
+      const int row = r0 + RPP * i;
       const int m = m0 + row, n = n0 + row;
       ra[i] = (m < a.M) ? *reinterpret_cast<const float4*>(a.A + (size_t)m * a.lda + k0 + 4 * kq) : make_float4(0, 0, 0, 0);
       rw[i] = (n < a.N) ? *reinterpret_cast<const float4*>(a.W + (size_t)n * a.ldw + k0 + 4 * kq) : make_float4(0, 0, 0, 0);
@@ -83,8 +87,8 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
   };
   auto sstore = [&](int st) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int row = r0 + 32 * i;
+    for (int i = 0; i < NPASS; i++) {
+      const int row = r0 + RPP * i;
       As[st][4 * kq + 0][row] = ra[i].x; As[st][4 * kq + 1][row] = ra[i].y;
       As[st][4 * kq + 2][row] = ra[i].z; As[st][4 * kq + 3][row] = ra[i].w;
       Ws[st][4 * kq + 0][row] = rw[i].x; Ws[st][4 * kq + 1][row] = rw[i].y;
@@ -95,26 +99,46 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
   gload(0);
   sstore(0);
   __syncthreads();
+  if (nk > 1) gload(BK);
   const int li = lane & 31, lh = lane >> 5;
   for (int kt = 0; kt < nk; kt++) {
     const int st = kt & 1;
-    if (kt + 1 < nk) gload((kt + 1) * BK);
+    // the registers hold tile kt+1: push it into the idle LDS stage FIRST so the writes drain underneath this tile's
+    // MFMAs, then start fetching tile kt+2
+    if (kt + 1 < nk) sstore(st ^ 1);
+    if (kt + 2 < nk) gload((kt + 2) * BK);
+    // operand fetch for k-pair kk+1 is issued before the four MFMAs of k-pair kk (LDS latency under the matrix pipe)
+    float a0 = As[st][lh][wm * 64 + li], a1 = As[st][lh][wm * 64 + 32 + li];
+    float b0 = Ws[st][lh][wn * 64 + li], b1 = Ws[st][lh][wn * 64 + 32 + li];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; kk++) {
-      const int ka = 2 * kk + lh;
-      const float a0 = As[st][ka][wm * 64 + li], a1 = As[st][ka][wm * 64 + 32 + li];
-      const float b0 = Ws[st][ka][wn * 64 + li], b1 = Ws[st][ka][wn * 64 + 32 + li];
+      float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+      if (kk + 1 < BK / 2) {
+        const int ka = 2 * (kk + 1) + lh;
+        na0 = As[st][ka][wm * 64 + li]; na1 = As[st][ka][wm * 64 + 32 + li];
+        nb0 = Ws[st][ka][wn * 64 + li]; nb1 = Ws[st][ka][wn * 64 + 32 + li];
+      }
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
-    if (kt + 1 < nk) sstore(st ^ 1);
     __syncthreads();
   }
-  // epilogue: C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  // epilogue: C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+  // FLAGS is a compile-time constant: no per-element branches, the 16 row divisors of a tile are fetched together.
 #pragma unroll
   for (int ti = 0; ti < 2; ti++) {
+    const int mb = m0 + wm * 64 + ti * 32 + 4 * lh;
+    float rdiv[16];
+    if (FLAGS & EPI_ROWDIV) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int m = mb + (e & 3) + 8 * (e >> 2);
+        rdiv[e] = (m < a.M) ? a.rowdiv[m] : 1.f;
+      }
+    }
 #pragma unroll
     for (int tj = 0; tj < 2; tj++) {
       const int n = n0 + wn * 64 + tj * 32 + li;
@@ -122,13 +146,13 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
       const float bv = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
       for (int e = 0; e < 16; e++) {
-        const int m = m0 + wm * 64 + ti * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int m = mb + (e & 3) + 8 * (e >> 2);
         if (m >= a.M) continue;
         float v = acc[ti][tj][e] + bv;
-        if (a.flags & EPI_RELU) v = fmaxf(v, 0.f);
-        if (a.flags & EPI_ROWDIV) v = v / a.rowdiv[m];
+        if (FLAGS & EPI_RELU) v = fmaxf(v, 0.f);
+        if (FLAGS & EPI_ROWDIV) v = v / rdiv[e];
         a.C[(size_t)m * a.ldc + n] = v;
-        if (a.flags & EPI_ACC2) a.C2[(size_t)m * a.ldc2 + n] += v;
+        if (FLAGS & EPI_ACC2) a.C2[(size_t)m * a.ldc2 + n] += v;
       }
     }
   }
@@ -418,7 +442,13 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw
   if (K % BK != 0 || (lda & 3) || (ldw & 3)) return sfail(SGRL_ERR_ARG, "gemm: K must be a multiple of 32 and rows 16-byte aligned");
   GemmArgs a{A, lda, W, ldw, bias, C, ldc, M, N, K, flags, rowdiv, C2, ldc2};
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-  hipLaunchKernelGGL(k_gemm, dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, a);
+  switch (flags) {
+    case 0: hipLaunchKernelGGL(k_gemm<0>, dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, a); break;
+    case EPI_RELU: hipLaunchKernelGGL(k_gemm<EPI_RELU>, dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, a); break;
+    case EPI_ROWDIV: hipLaunchKernelGGL(k_gemm<EPI_ROWDIV>, dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, a); break;
+    case EPI_ACC2: hipLaunchKernelGGL(k_gemm<EPI_ACC2>, dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, a); break;
+    default: return sfail(SGRL_ERR_ARG, "gemm: unsupported epilogue combination");
+  }
   return SGRL_OK;
 }
 
@@ -495,8 +525,10 @@ int sgrl_set_create(sgrl_set** out) {
     *out = nullptr;
     return sfail(SGRL_ERR_HIP, "no HIP device visible: the SET actor fast path needs an MI355X (there is no CPU fallback)");
   }
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          GEMM_LDS_BYTES) != hipSuccess) {
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<0>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<EPI_RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<EPI_ROWDIV>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<EPI_ACC2>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES) != hipSuccess) {
     *out = nullptr;
     return sfail(SGRL_ERR_HIP, "cannot raise the dynamic LDS limit of the GEMM kernel");
   }
