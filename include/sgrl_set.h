@@ -16,6 +16,8 @@
  *     QKV_W  = rows of q_proj (pre-multiplied by (2*head_dim)^-0.5), k_proj, v_proj stacked -> [768, 256]; QKV_B alike
  *     VG_W   = vg_proj.weight padded with 4 zero rows -> [256, 128]
  *     L1NG_W = linear1_ng.weight padded with 15 zero columns -> [128, 160]
+ *     A_LG1_W, F_LG1_W, L1G_W (the layers fed by the symmetric 32x32 Gram matrix) are folded onto the packed lower
+ *              triangle: W'[n][a(a+1)/2+b] = W[n][32a+b] + W[n][32b+a] (b < a), W[n][33a] (b = a); 528 -> 544 columns
  */
 #ifndef SGRL_SET_H
 #define SGRL_SET_H
@@ -71,7 +73,7 @@ int64_t sgrl_set_workspace_bytes(const sgrl_set* s);
 int sgrl_set_time_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_ld, float max_action,
                           int reps, void* stream, float* ms_out);
 /* Debug/parity: copy an intermediate buffer of the LAST forward to the host.  which: 0 g[N,3,128], 1 cat[N,256]
- * (inv | ng), 2 gram[N,1024], 3 fn[N], 4 qkv[N,768], 5 attng[N,256], 6 attg[N,3,256], 7 mat[N,1024]. */
+ * (inv | ng), 2 gram[N,544] (packed lower triangle), 3 fn[N], 4 qkv[N,768], 5 attng[N,256], 6 attg[N,3,256], 7 mat[N,1024]. */
 int sgrl_set_peek(sgrl_set* s, int which, float* host, int64_t n_floats);
 const char* sgrl_set_last_error(void);
 

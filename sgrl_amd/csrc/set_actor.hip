@@ -33,6 +33,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int D = 128;
 constexpr int ZD = 32;
+// The 32x32 Gram matrix Z'Z is symmetric: only its lower triangle (528 values, padded to GK) is materialised and the
+// 1024-wide weight rows of the layers that consume it are folded accordingly at pack time (sgrl_amd/set_hip.py).
+constexpr int GTRI = ZD * (ZD + 1) / 2;   // 528
+constexpr int GK = 544;                    // GTRI padded to a multiple of the GEMM K tile
 
 // ------------------------------------------------------------------------------------------------
 // f32 MFMA GEMM:  C[M,N] = epi(A[M,K] . W[N,K]^T)      block tile 128x128x32, 4 waves of 64x64
@@ -212,6 +216,7 @@ __global__ __launch_bounds__(256) void k_proj_gram(const float* __restrict__ X, 
   float* Wqs = Wps + 30 * (C + 1);        // [30][C+1] (only if Wq)
   float* Zs = Wqs + (Wq ? 30 * (C + 1) : 0);  // [8][3][32]
   float* red = Zs + PG_NODES * 96;        // [8][4]
+  short* tab = reinterpret_cast<short*>(red + PG_NODES * 4);   // [528] (a << 8 | b)
   const int t = threadIdx.x, n0 = blockIdx.x * PG_NODES;
   const int nn = min(PG_NODES, N - n0);
   for (int i = t; i < PG_NODES * 3 * C; i += 256) {
@@ -240,16 +245,26 @@ __global__ __launch_bounds__(256) void k_proj_gram(const float* __restrict__ X, 
     if (Wq && node < nn) Z2[((size_t)(n0 + node) * 3 + s) * ZD + a] = v2;
   }
   __syncthreads();
-  // gram: thread handles outputs t + 256*i; node = i / 4
+  // packed lower triangle of the Gram matrix: output o = a(a+1)/2 + b (b <= a); ||G||_F^2 counts off-diagonals twice
   const int wave = t >> 6;
+  for (int i = t; i < GTRI; i += 256) {
+    int aa = (int)((sqrtf(8.f * i + 1.f) - 1.f) * 0.5f);
+    while ((aa + 1) * (aa + 2) / 2 <= i) aa++;
+    while (aa * (aa + 1) / 2 > i) aa--;
+    tab[i] = (short)((aa << 8) | (i - aa * (aa + 1) / 2));
+  }
+  __syncthreads();
   for (int node = 0; node < PG_NODES; node++) {
     float sq = 0.f;
     const float* z = Zs + node * 96;
-    for (int q = 0; q < 4; q++) {
-      const int o = t + 256 * q, aa = o >> 5, bb = o & 31;
-      const float v = z[aa] * z[bb] + z[32 + aa] * z[32 + bb] + z[64 + aa] * z[64 + bb];
-      if (node < nn) gram[(size_t)(n0 + node) * 1024 + o] = v;
-      sq += v * v;
+    for (int o = t; o < GK; o += 256) {
+      float v = 0.f;
+      if (o < GTRI) {
+        const int aa = tab[o] >> 8, bb = tab[o] & 255;
+        v = z[aa] * z[bb] + z[32 + aa] * z[32 + bb] + z[64 + aa] * z[64 + bb];
+        sq += (aa == bb ? 1.f : 2.f) * v * v;
+      }
+      if (node < nn) gram[(size_t)(n0 + node) * GK + o] = v;
     }
     sq = wave_sum_f32(sq);
     if ((t & 63) == 0) red[node * 4 + wave] = sq;
@@ -439,7 +454,7 @@ int upload(T** dst, const std::vector<T>& v) {
 
 int launch_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc,
                 int M, int N, int K, int flags = 0, const float* rowdiv = nullptr, float* C2 = nullptr, int ldc2 = 0) {
-  if (K % BK != 0 || (lda & 3) || (ldw & 3)) return sfail(SGRL_ERR_ARG, "gemm: K must be a multiple of 32 and rows 16-byte aligned");
+  if (K % BK != 0 || (lda & 3) || (ldw & 3)) return sfail(SGRL_ERR_ARG, "gemm: K must be a multiple of 16 and rows 16-byte aligned");
   GemmArgs a{A, lda, W, ldw, bias, C, ldc, M, N, K, flags, rowdiv, C2, ldc2};
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   switch (flags) {
@@ -464,7 +479,7 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
                      s->outg, s->outng, s->gdir);
   float* ng = s->cat + 128;
   auto pg = [&](const float* X, int ldx, int C, const float* Wp, const float* Wq, float* z2) {
-    const size_t sh = sizeof(float) * (PG_NODES * 3 * C + 30 * (C + 1) * (Wq ? 2 : 1) + PG_NODES * 96 + PG_NODES * 4);
+    const size_t sh = sizeof(float) * (PG_NODES * 3 * C + 30 * (C + 1) * (Wq ? 2 : 1) + PG_NODES * 96 + PG_NODES * 4) + sizeof(short) * GTRI;
     hipLaunchKernelGGL(k_proj_gram, dim3((N + PG_NODES - 1) / PG_NODES), dim3(256), sh, st, X, ldx, C, Wp, Wq, s->gdir,
                        s->gram, s->fn, z2, N);
   };
@@ -474,7 +489,7 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   for (int l = 0; l < SGRL_SET_LAYERS; l++) {
     // --- attention ---
     pg(s->g, D, D, s->WL(l, SGRL_SET_A_GPROJ), nullptr, nullptr);
-    G(s->gram, 1024, s->WL(l, SGRL_SET_A_LG1_W), 1024, s->WL(l, SGRL_SET_A_LG1_B), s->h256, 256, N, 256, 1024, EPI_RELU);
+    G(s->gram, GK, s->WL(l, SGRL_SET_A_LG1_W), GK, s->WL(l, SGRL_SET_A_LG1_B), s->h256, 256, N, 256, GK, EPI_RELU);
     G(s->h256, 256, s->WL(l, SGRL_SET_A_LG2_W), 256, s->WL(l, SGRL_SET_A_LG2_B), s->cat, 256, N, 128, 256);
     G(s->cat, 256, s->WL(l, SGRL_SET_QKV_W), 256, s->WL(l, SGRL_SET_QKV_B), s->qkv, 768, N, 768, 256, EPI_ROWDIV, s->fn);
     G(s->g, D, s->WL(l, SGRL_SET_VG_W), D, nullptr, s->vg, 256, N3, 256, D);
@@ -486,7 +501,7 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
                        s->WL(l, SGRL_SET_N1_B), ng, 256, (float*)nullptr, 0, N);
     // --- equivariant feed-forward ---
     pg(s->g1, D, D, s->WL(l, SGRL_SET_F_GPROJ2), s->WL(l, SGRL_SET_F_GPROJ3), s->z2);
-    G(s->gram, 1024, s->WL(l, SGRL_SET_F_LG1_W), 1024, s->WL(l, SGRL_SET_F_LG1_B), s->h256, 256, N, 256, 1024, EPI_RELU);
+    G(s->gram, GK, s->WL(l, SGRL_SET_F_LG1_W), GK, s->WL(l, SGRL_SET_F_LG1_B), s->h256, 256, N, 256, GK, EPI_RELU);
     G(s->h256, 256, s->WL(l, SGRL_SET_F_LG2_W), 256, s->WL(l, SGRL_SET_F_LG2_B), s->cat, 256, N, 128, 256);
     G(s->cat, 256, s->WL(l, SGRL_SET_L3_W), 256, s->WL(l, SGRL_SET_L3_B), s->t256, 256, N, 256, 256, EPI_RELU);
     G(s->t256, 256, s->WL(l, SGRL_SET_L4_W), 256, s->WL(l, SGRL_SET_L4_B), s->mat, 1024, N, 1024, 256, EPI_ROWDIV, s->fn);
@@ -501,7 +516,7 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
                      s->W(SGRL_SET_FNORM_B), (float*)nullptr, 0, s->outng + 17, 160, N);
   hipLaunchKernelGGL(k_copy_g, dim3((N3 * D + 255) / 256), dim3(256), 0, st, s->g, s->outg, N3);
   pg(s->outg, 136, 136, s->W(SGRL_SET_GGPROJ), s->W(SGRL_SET_GPROJ), s->z2);
-  G(s->gram, 1024, s->W(SGRL_SET_L1G_W), 1024, s->W(SGRL_SET_L1G_B), s->t128a, D, N, D, 1024, EPI_RELU);
+  G(s->gram, GK, s->W(SGRL_SET_L1G_W), GK, s->W(SGRL_SET_L1G_B), s->t128a, D, N, D, GK, EPI_RELU);
   G(s->t128a, D, s->W(SGRL_SET_L2G_W), D, s->W(SGRL_SET_L2G_B), s->cat2, 256, N, D, D);
   G(s->outng, 160, s->W(SGRL_SET_L1NG_W), 160, s->W(SGRL_SET_L1NG_B), s->t128b, D, N, D, 160, EPI_RELU);
   G(s->t128b, D, s->W(SGRL_SET_L2NG_W), D, s->W(SGRL_SET_L2NG_B), s->cat2 + 128, 256, N, D, D);
@@ -660,7 +675,7 @@ int64_t sgrl_set_workspace_bytes(const sgrl_set* s) { return s ? s->ws_floats * 
 int sgrl_set_peek(sgrl_set* s, int which, float* host, int64_t n_floats) {
   if (!s || !host || !s->have_graph) return sfail(SGRL_ERR_ARG, "sgrl_set_peek: bad argument");
   const float* src[] = {s->g, s->cat, s->gram, s->fn, s->qkv, s->attng, s->attg, s->mat};
-  const int64_t per[] = {384, 256, 1024, 1, 768, 256, 768, 1024};
+  const int64_t per[] = {384, 256, GK, 1, 768, 256, 768, 1024};
   if (which < 0 || which > 7 || n_floats > per[which] * s->N) return sfail(SGRL_ERR_ARG, "sgrl_set_peek: bad buffer or size");
   SHIP_TRY(hipDeviceSynchronize());
   SHIP_TRY(hipMemcpy(host, src[which], sizeof(float) * n_floats, hipMemcpyDeviceToHost));

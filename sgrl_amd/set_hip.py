@@ -42,6 +42,18 @@ def _check(L, rc, what):
         raise _lib.SgrlError("%s failed (%d): %s" % (what, rc, L.sgrl_set_last_error().decode()))
 
 
+def fold_gram_weight(w):
+    """[out, 1024] weight acting on vec(G) of a symmetric 32x32 G -> [out, 544] acting on its packed lower triangle."""
+    out_f = w.shape[0]
+    w3 = w.reshape(out_f, 32, 32)
+    sym = w3 + w3.transpose(1, 2)
+    idx_a, idx_b = torch.tril_indices(32, 32)          # row-major lower triangle: k = a(a+1)/2 + b
+    f = sym[:, idx_a, idx_b].clone()
+    diag = idx_a == idx_b
+    f[:, diag] = w3[:, idx_a[diag], idx_b[diag]]
+    return torch.cat([f, f.new_zeros(out_f, 544 - f.shape[1])], dim=1).contiguous()
+
+
 def pack_tensors(sd, prefix="actor."):
     """[(tensor float32, ...)] in slot order (include/sgrl_set.h) from a state_dict-like mapping of torch tensors."""
     g = lambda k: sd[prefix + k].detach().float()
@@ -51,7 +63,7 @@ def pack_tensors(sd, prefix="actor."):
     out[5], out[6] = g("transformer_encoder.norm.weight"), g("transformer_encoder.norm.bias")
     out[7], out[8], out[9] = g("g_encoder.weight"), g("encoder.weight"), g("encoder.bias")
     out[10] = g("gg_proj.weight")
-    out[11], out[12], out[13], out[14] = g("linear1_g.weight"), g("linear1_g.bias"), g("linear2_g.weight"), g("linear2_g.bias")
+    out[11], out[12], out[13], out[14] = fold_gram_weight(g("linear1_g.weight")), g("linear1_g.bias"), g("linear2_g.weight"), g("linear2_g.bias")
     w = g("linear1_ng.weight")
     out[15] = torch.cat([w, w.new_zeros(w.shape[0], 160 - w.shape[1])], dim=1)
     out[16], out[17], out[18] = g("linear1_ng.bias"), g("linear2_ng.weight"), g("linear2_ng.bias")
@@ -65,13 +77,13 @@ def pack_tensors(sd, prefix="actor."):
         b = NGLOBAL + l * NLAYER
         vg = g(a + "vg_proj.weight")
         out[b:b + NLAYER] = [
-            g(a + "g_proj.weight"), g(a + "linear_g1.weight"), g(a + "linear_g1.bias"), g(a + "linear_g2.weight"),
+            g(a + "g_proj.weight"), fold_gram_weight(g(a + "linear_g1.weight")), g(a + "linear_g1.bias"), g(a + "linear_g2.weight"),
             g(a + "linear_g2.bias"),
             torch.cat([g(a + "q_proj.weight") * scaling, g(a + "k_proj.weight"), g(a + "v_proj.weight")], 0),
             torch.cat([g(a + "q_proj.bias") * scaling, g(a + "k_proj.bias"), g(a + "v_proj.bias")], 0),
             torch.cat([vg, vg.new_zeros(256 - vg.shape[0], vg.shape[1])], 0),
             g(a + "ng_out.weight"), g(a + "ng_out.bias"), g(a + "g_out.weight"),
-            g(p + "g_proj2.weight"), g(p + "g_proj3.weight"), g(p + "linear_g1.weight"), g(p + "linear_g1.bias"),
+            g(p + "g_proj2.weight"), g(p + "g_proj3.weight"), fold_gram_weight(g(p + "linear_g1.weight")), g(p + "linear_g1.bias"),
             g(p + "linear_g2.weight"), g(p + "linear_g2.bias"), g(p + "linear3.weight"), g(p + "linear3.bias"),
             g(p + "linear4.weight"), g(p + "linear4.bias"), g(p + "linear5.weight"), g(p + "linear1.weight"),
             g(p + "linear1.bias"), g(p + "linear2.weight"), g(p + "linear2.bias"), g(p + "norm1.weight"),
