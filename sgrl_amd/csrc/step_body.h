@@ -200,6 +200,14 @@ SGRL_DEV int clz64(uint64_t x) {
   return __builtin_clzll(x);
 #endif
 }
+// p = a(a+1)/2 + b with b <= a  ->  (a, b)
+SGRL_DEV void tri_decode(int p, int* a_out, int* b_out) {
+  // float sqrt is within one of the exact root for p < 2^20; two branch-free corrections make it exact
+  int a = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
+  a += ((a + 1) * (a + 2) / 2 <= p) ? 1 : 0;
+  a -= (a * (a + 1) / 2 > p) ? 1 : 0;
+  *a_out = a; *b_out = p - a * (a + 1) / 2;
+}
 SGRL_DEV bool dof_in_mask(const int32_t* mask2, int d) {
   const uint32_t w = (uint32_t)(d < 32 ? mask2[0] : mask2[1]);
   return (w >> (d & 31)) & 1u;
@@ -389,29 +397,30 @@ struct Engine {
   // in-place lower Cholesky of the matrix at S[base] (lower triangle, row stride ld); diag reciprocals -> dinv
   SGRL_DEV void cholesky(int base) {
     const int nv = o.nv, ld = o.ld;
-    // root-free column sweeps: C[i][j] = M[i][j] - sum_k C[i][k] C[j][k] / C[k][k]; one barrier per column
-    for (int j = 0; j < nv; j++) {
-      w.lanes_from(j, nv, [&](int i) {
-        double s = S[base + i * ld + j];
-        const double* ci = S + base + i * ld;
-        const double* cj = S + base + j * ld;
-        const double* wt = S + o.xtmp;
-        int k = 0;
-        for (; k + 4 <= j; k += 4) {   // four independent LDS triples in flight per wait
-          const double a0 = ci[k], a1 = ci[k + 1], a2 = ci[k + 2], a3 = ci[k + 3];
-          const double b0 = cj[k], b1 = cj[k + 1], b2 = cj[k + 2], b3 = cj[k + 3];
-          const double w0 = wt[k], w1 = wt[k + 1], w2 = wt[k + 2], w3 = wt[k + 3];
-          s -= a0 * b0 * w0; s -= a1 * b1 * w1; s -= a2 * b2 * w2; s -= a3 * b3 * w3;
-        }
-        for (; k < j; k++) s -= ci[k] * cj[k] * wt[k];
-        if (i == j) { if (s < kMinVal) s = kMinVal; S[o.xtmp + j] = 1.0 / s; }
-        S[base + i * ld + j] = s;
+    // right-looking root-free elimination: after pivot j every trailing entry (i, k), j < k <= i, takes ONE fused
+    // update  M_ik -= M_ij M_kj / M_jj  -- constant depth per pivot (one barrier), all lanes busy on the triangle
+    for (int j = 0; j < nv - 1; j++) {
+      double pj = S[base + j * ld + j];
+      if (pj < kMinVal) pj = kMinVal;
+      const double wj = 1.0 / pj;
+      const int sdim = nv - j - 1;
+      w.lanes(sdim * (sdim + 1) / 2, [&](int p) {
+        int a, b;
+        tri_decode(p, &a, &b);
+        const int i = j + 1 + a, k = j + 1 + b;
+        S[base + i * ld + k] -= S[base + i * ld + j] * S[base + k * ld + j] * wj;
       });
     }
-    // L[i][j] = C[i][j] / sqrt(C[j][j])
-    w.lanes(nv, [&](int i) {
-      for (int j = 0; j < i; j++) S[base + i * ld + j] *= sqrt(S[o.xtmp + j]);
-      S[o.dinv + i] = sqrt(S[o.xtmp + i]);
+    // L[i][j] = C[i][j] / sqrt(C[j][j]),  dinv[j] = 1 / sqrt(C[j][j])
+    w.lanes(nv, [&](int j) {
+      double pj = S[base + j * ld + j];
+      if (pj < kMinVal) pj = kMinVal;
+      S[o.dinv + j] = sqrt(1.0 / pj);
+    });
+    w.lanes(nv * (nv - 1) / 2, [&](int p) {
+      int a, b;
+      tri_decode(p, &a, &b);          // strict lower triangle: i = a + 1 > j = b
+      S[base + (a + 1) * ld + b] *= S[o.dinv + b];
     });
   }
 
@@ -711,8 +720,6 @@ struct Engine {
       double* Yr = S + o.Y + r * ldy;
       if (r == nrow) {  // extra right-hand side: the smooth force
         for (int d = 0; d < nv; d++) Yr[d] = S[o.qfs + d];
-        solve_lower_row(o.L, o.Y + r * ldy);
-        for (int d = 0; d < nv; d++) S[o.ys + d] = Yr[d];
         return;
       }
       const int kind = I[o.row_kind + r], src = I[o.row_src + r], sub = I[o.row_sub + r];
@@ -782,11 +789,6 @@ struct Engine {
         aref = -B * vel - K * imp * (dist - margin);
       }
       S[o.eR + r] = R; S[o.earef + r] = aref;
-      solve_lower_row(o.L, o.Y + r * ldy);
-      double s2 = 0;
-      for (int d = 0; d < nv; d++) s2 += Yr[d] * Yr[d];
-      S[o.ediag + r] = s2 + R;
-      S[o.eidg + r] = 1.0 / (s2 + R);
       // warm start from the previous evaluation of this env-step: same constraint (kind, source, edge) -> same force
       const int key = (kind << 16) | (src << 3) | sub;
       double f0 = 0;
@@ -794,9 +796,41 @@ struct Engine {
       for (int k = 0; k < pn; k++) if (I[o.prev_key + k] == key) f0 = S[o.prev_f + k];
       S[o.ef + r] = f0;
     });
+    // half-solve Y <- L^-1 Y for ALL right-hand sides at once (rows + the smooth force): per pivot column j every
+    // (rhs, i > j) pair takes one fused update -- constant depth per column instead of a serial nv^2/2 loop per lane
+    {
+      const int nrhs = nrow + 1;
+      int rp = 1;
+      while (rp < nrhs) rp <<= 1;                 // rhs index = item & (rp - 1), row offset = item / rp
+      int sh = 0;
+      while ((1 << sh) < rp) sh++;
+      for (int j = 0; j < nv - 1; j++) {
+        const double dj = S[o.dinv + j];
+        w.lanes(rp * (nv - j - 1), [&](int t) {
+          const int r = t & (rp - 1), i = j + 1 + (t >> sh);
+          if (r < nrhs) {
+            double* Yr = S + o.Y + r * ldy;
+            Yr[i] -= S[o.L + i * o.ld + j] * (Yr[j] * dj);
+          }
+        });
+      }
+      w.lanes(rp * nv, [&](int t) {
+        const int r = t & (rp - 1), d = t >> sh;
+        if (r < nrhs) {
+          const double y = S[o.Y + r * ldy + d] * S[o.dinv + d];
+          S[o.Y + r * ldy + d] = y;
+          if (r == nrow) S[o.ys + d] = y;
+        }
+      });
+    }
     w.lanes(nrow > nv ? nrow : nv, [&](int r) {
       if (r < nrow) {
         const double* Yr = S + o.Y + r * ldy;
+        double s2 = 0;
+        for (int d = 0; d < nv; d++) s2 += Yr[d] * Yr[d];
+        const double Rr = S[o.eR + r];
+        S[o.ediag + r] = s2 + Rr;
+        S[o.eidg + r] = 1.0 / (s2 + Rr);
         double s = 0;
         for (int d = 0; d < nv; d++) s += Yr[d] * S[o.ys + d];
         S[o.eb + r] = s - S[o.earef + r];
@@ -823,26 +857,31 @@ struct Engine {
           S[xw + pos] = -S[o.eb + i];
         }
       });
-      // root-free Cholesky of A_FF: C[i][j] = A[fi][fj] - sum_k C[i][k] C[j][k] w[k], w[k] = 1 / C[k][k]
-      for (int j = 0; j < nf; j++) {
-        w.lanes_from(j, nf, [&](int i) {
-          const int fi = I[o.flist + i], fj = I[o.flist + j];
-          double s = A[fi * (fi + 1) / 2 + fj];   // fi >= fj because the list is ascending
-          const double* ci = C + i * (i + 1) / 2;
-          const double* cj = C + j * (j + 1) / 2;
-          const double* wt = S + wv;
-          int k = 0;
-          for (; k + 4 <= j; k += 4) {
-            const double a0 = ci[k], a1 = ci[k + 1], a2 = ci[k + 2], a3 = ci[k + 3];
-            const double b0 = cj[k], b1 = cj[k + 1], b2 = cj[k + 2], b3 = cj[k + 3];
-            const double w0 = wt[k], w1 = wt[k + 1], w2 = wt[k + 2], w3 = wt[k + 3];
-            s -= a0 * b0 * w0; s -= a1 * b1 * w1; s -= a2 * b2 * w2; s -= a3 * b3 * w3;
-          }
-          for (; k < j; k++) s -= ci[k] * cj[k] * wt[k];
-          if (i == j) { if (s < kMinVal) s = kMinVal; S[wv + j] = 1.0 / s; }
-          C[i * (i + 1) / 2 + j] = s;
+      // root-free right-looking Cholesky of A_FF (compact, packed lower triangle): one fused update per trailing
+      // entry per pivot;  w[k] = 1 / C[k][k]
+      w.lanes(nf * (nf + 1) / 2, [&](int p) {
+        int i, j;
+        tri_decode(p, &i, &j);
+        const int fi = I[o.flist + i], fj = I[o.flist + j];   // fi >= fj: the list is ascending
+        C[p] = A[fi * (fi + 1) / 2 + fj];
+      });
+      for (int j = 0; j < nf - 1; j++) {
+        double pj = C[j * (j + 1) / 2 + j];
+        if (pj < kMinVal) pj = kMinVal;
+        const double wj = 1.0 / pj;
+        const int sdim = nf - j - 1;
+        w.lanes(sdim * (sdim + 1) / 2, [&](int p) {
+          int a, b;
+          tri_decode(p, &a, &b);
+          const int i = j + 1 + a, k = j + 1 + b;
+          C[i * (i + 1) / 2 + k] -= C[i * (i + 1) / 2 + j] * C[k * (k + 1) / 2 + j] * wj;
         });
       }
+      w.lanes(nf, [&](int j) {
+        double pj = C[j * (j + 1) / 2 + j];
+        if (pj < kMinVal) pj = kMinVal;
+        S[wv + j] = 1.0 / pj;
+      });
       // forward substitution (column sweeps), diagonal scaling, backward substitution
       for (int j = 0; j < nf; j++) {
         const double zj = S[xw + j] * S[wv + j];
