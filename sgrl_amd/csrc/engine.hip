@@ -157,7 +157,35 @@ struct sgrl_engine {
   int32_t* d_cnt = nullptr;
   double* d_scratch = nullptr;
   BatchArgs args{};
+  // Launch groups: morphologies whose LDS slab admits the same number of workgroups per CU share one launch (its
+  // dynamic LDS = the group's largest slab), so a 23-morphology mix is not dragged to the occupancy of its biggest
+  // member.  Groups run concurrently on their own streams, forked from / joined to the caller's stream by events.
+  struct Group { int first = 0, count = 0, lds = 0; hipStream_t stream = nullptr; hipEvent_t done = nullptr; };
+  std::vector<Group> groups;
+  hipEvent_t fork = nullptr;
+  std::vector<int> morph_lds;
 };
+
+namespace {
+template <class K>
+int launch_groups(sgrl_engine* e, K kernel, const StepOut& out, hipStream_t user) {
+  if (e->groups.size() == 1) {
+    hipLaunchKernelGGL(kernel, dim3(e->n_env), dim3(64), e->groups[0].lds, user, e->args, out);
+  } else {
+    if (hipEventRecord(e->fork, user) != hipSuccess) return fail(SGRL_ERR_HIP, "hipEventRecord(fork) failed");
+    for (auto& g : e->groups) {
+      BatchArgs a = e->args;
+      a.block_env = e->args.block_env + g.first;
+      (void)hipStreamWaitEvent(g.stream, e->fork, 0);
+      hipLaunchKernelGGL(kernel, dim3(g.count), dim3(64), g.lds, g.stream, a, out);
+      (void)hipEventRecord(g.done, g.stream);
+      (void)hipStreamWaitEvent(user, g.done, 0);
+    }
+  }
+  if (hipGetLastError() != hipSuccess) return fail(SGRL_ERR_HIP, "kernel launch failed");
+  return SGRL_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -182,6 +210,8 @@ void sgrl_engine_destroy(sgrl_engine* e) {
   if (e->d_rec) (void)hipFree(e->d_rec);
   if (e->d_cnt) (void)hipFree(e->d_cnt);
   if (e->d_scratch) (void)hipFree(e->d_scratch);
+  for (auto& g : e->groups) { if (g.stream) (void)hipStreamDestroy(g.stream); if (g.done) (void)hipEventDestroy(g.done); }
+  if (e->fork) (void)hipEventDestroy(e->fork);
   delete e;
 }
 
@@ -219,6 +249,7 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
     const int bytes = sgrl::layout_bytes(&o);
     if (bytes > 160 * 1024) { rc = fail(SGRL_ERR_LIMIT, "per-environment LDS slab exceeds 160 KiB"); break; }
     if (bytes > e->lds_bytes) e->lds_bytes = bytes;
+    e->morph_lds.push_back(bytes);
     const int need = v.nq + v.nv + 4;
     if (need > e->stride) e->stride = need;
     for (int i = 0; i < morph_count[k]; i++) env_morph.push_back(k);
@@ -242,15 +273,38 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
   (void)hipMemcpy(e->d_morphs, morphs.data(), sizeof(MorphDev) * n_morph, hipMemcpyHostToDevice);
   (void)hipMemcpy(e->d_env_morph, env_morph.data(), sizeof(int32_t) * e->n_env, hipMemcpyHostToDevice);
   {
-    // dispatch order: workgroups are handed out by index, so put the costliest morphologies (most dofs) first
+    // dispatch order: group by LDS occupancy class (fewest workgroups per CU first = costliest), inside a group the
+    // morphologies with the most dofs first -- workgroups are handed out by index, this balances the tail
     std::vector<int32_t> order(e->n_env);
     for (int i = 0; i < e->n_env; i++) order[i] = i;
-    std::vector<int> cost(n_morph);
-    for (int k = 0; k < n_morph; k++) cost[k] = ib[k][SGRL_H_NV];
-    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return cost[env_morph[x]] > cost[env_morph[y]]; });
+    std::vector<int> cost(n_morph), cls(n_morph);
+    for (int k = 0; k < n_morph; k++) {
+      cost[k] = ib[k][SGRL_H_NV];
+      int per_cu = (160 * 1024) / e->morph_lds[k];
+      cls[k] = per_cu > 8 ? 8 : per_cu;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+      const int mx = env_morph[x], my = env_morph[y];
+      if (cls[mx] != cls[my]) return cls[mx] < cls[my];
+      return cost[mx] > cost[my];
+    });
     (void)hipMemcpy(e->d_block_env, order.data(), sizeof(int32_t) * e->n_env, hipMemcpyHostToDevice);
+    for (int i = 0; i < e->n_env;) {
+      sgrl_engine::Group g;
+      g.first = i;
+      const int c = cls[env_morph[order[i]]];
+      while (i < e->n_env && cls[env_morph[order[i]]] == c) { g.lds = std::max(g.lds, e->morph_lds[env_morph[order[i]]]); i++; }
+      g.count = i - g.first;
+      e->groups.push_back(g);
+    }
+    if (e->groups.size() > 1) {
+      bool sok = hipEventCreateWithFlags(&e->fork, hipEventDisableTiming) == hipSuccess;
+      for (auto& g : e->groups)
+        sok = sok && hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&g.done, hipEventDisableTiming) == hipSuccess;
+      if (!sok) { sgrl_engine_destroy(e); return fail(SGRL_ERR_HIP, "cannot create launch-group streams"); }
+    }
   }
-  (void)hipMemset(e->d_rec, 0, sizeof(double) * (size_t)e->n_env * e->stride);
   {
     std::vector<int32_t> cnt0((size_t)e->n_env * 4, 0);
     for (int i = 0; i < e->n_env; i++) cnt0[4 * (size_t)i + 1] = -1;  // episode = -1: the first reset bumps it to 0
@@ -279,9 +333,7 @@ int sgrl_reset(sgrl_engine* e, float* obs, double* obs64, void* stream) {
   if (!e || !obs) return fail(SGRL_ERR_ARG, "sgrl_reset: null engine or obs");
   StepOut out{};
   out.obs32 = obs; out.obs64 = obs64;
-  hipLaunchKernelGGL(k_env_reset, dim3(e->n_env), dim3(64), e->lds_bytes, (hipStream_t)stream, e->args, out);
-  HIP_TRY(hipGetLastError());
-  return SGRL_OK;
+  return launch_groups(e, k_env_reset, out, (hipStream_t)stream);
 }
 
 int sgrl_step(sgrl_engine* e, const float* actions, float* obs, float* reward, uint8_t* done, float* dist,
@@ -290,18 +342,14 @@ int sgrl_step(sgrl_engine* e, const float* actions, float* obs, float* reward, u
   StepOut out{};
   out.actions = actions; out.obs32 = obs; out.obs64 = obs64; out.reward = reward; out.reward64 = reward64;
   out.done = done; out.dist = dist; out.truncated = truncated; out.auto_reset = auto_reset;
-  hipLaunchKernelGGL(k_env_step, dim3(e->n_env), dim3(64), e->lds_bytes, (hipStream_t)stream, e->args, out);
-  HIP_TRY(hipGetLastError());
-  return SGRL_OK;
+  return launch_groups(e, k_env_step, out, (hipStream_t)stream);
 }
 
 int sgrl_refresh(sgrl_engine* e, float* obs, double* obs64, void* stream) {
   if (!e || !obs) return fail(SGRL_ERR_ARG, "sgrl_refresh: null engine or obs");
   StepOut out{};
   out.obs32 = obs; out.obs64 = obs64;
-  hipLaunchKernelGGL(k_env_refresh, dim3(e->n_env), dim3(64), e->lds_bytes, (hipStream_t)stream, e->args, out);
-  HIP_TRY(hipGetLastError());
-  return SGRL_OK;
+  return launch_groups(e, k_env_refresh, out, (hipStream_t)stream);
 }
 
 int sgrl_get_records(sgrl_engine* e, double* rec, int32_t* cnt) {
@@ -329,8 +377,10 @@ int sgrl_time_steps(sgrl_engine* e, const float* actions, float* obs, float* rew
   StepOut out{};
   out.actions = actions; out.obs32 = obs; out.reward = reward; out.done = done; out.auto_reset = 1;
   HIP_TRY(hipEventRecord(t0, (hipStream_t)stream));
-  for (int r = 0; r < reps; r++)
-    hipLaunchKernelGGL(k_env_step, dim3(e->n_env), dim3(64), e->lds_bytes, (hipStream_t)stream, e->args, out);
+  for (int r = 0; r < reps; r++) {
+    const int rc = launch_groups(e, k_env_step, out, (hipStream_t)stream);
+    if (rc != SGRL_OK) return rc;
+  }
   HIP_TRY(hipEventRecord(t1, (hipStream_t)stream));
   HIP_TRY(hipEventSynchronize(t1));
   float ms = 0;

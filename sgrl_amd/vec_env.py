@@ -62,7 +62,7 @@ def resolve_models(env_names, xml_paths=None):
 
 class BatchedModularVecEnv(VecEnv):
     def __init__(self, env_names, envs_per_morph, obs_max_len=None, seed=0, device=None, max_episode_steps=1000,
-                 xml_paths=None, env_id_base=0, max_rows=model_pack.DEFAULT_MAX_ROWS,
+                 xml_paths=None, env_id_base=0, max_rows=None,
                  pgs_iters=model_pack.DEFAULT_PGS_ITERS, pgs_tol=model_pack.DEFAULT_PGS_TOL):
         """env_names: morphology / environment names (e.g. '3d_walker_7_full'), in the order the reference sorts them
         (main.py:99); envs_per_morph: int or list; env i of morphology k has global index sum(counts[:k]) + i."""
@@ -95,7 +95,9 @@ class BatchedModularVecEnv(VecEnv):
         VecEnv.__init__(self, n, Box(-np.inf, np.inf, (41 * L0,), np.float64), Box(-1.0, 1.0, (3 * (L0 - 1),), np.float32))
         self.waiting = False
         self.closed = False
-        self._blobs = [model_pack.pack_model(m, spec=env_spec_for(nm), max_rows=max_rows, pgs_iters=pgs_iters,
+        # constraint-row cap per morphology: multi-geom bodies (humanoid, cheetah) can touch the floor in many places
+        rows_of = lambda m: max_rows if max_rows is not None else (64 if m.ngeom > 10 else model_pack.DEFAULT_MAX_ROWS)
+        self._blobs = [model_pack.pack_model(m, spec=env_spec_for(nm), max_rows=rows_of(m), pgs_iters=pgs_iters,
                                              pgs_tol=pgs_tol) for m, nm in zip(self.models, self.env_names)]
         L = _lib.lib()
         k = len(self._blobs)
