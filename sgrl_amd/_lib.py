@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsgrl_hip.so")
+LIB_PATH = os.environ.get("SGRL_HIP_LIB", os.path.join(_HERE, "libsgrl_hip.so"))   # override: A/B benchmarking of builds
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["engine.hip", "set_actor.hip"]
 

@@ -281,7 +281,8 @@ struct Engine {
           double r[9], jp[3], ja[3], anchor[3], axis[3], ql[4], v[3];
           quat2mat(r, quat);
           ld3(jp, m.jnt_pos + 3 * j); ld3(ja, m.jnt_axis + 3 * j);
-          mat_vec(t, r, jp);
+          const bool at_origin = (jp[0] == 0.0 && jp[1] == 0.0 && jp[2] == 0.0);   // global-coordinate MJCFs
+          if (at_origin) { t[0] = 0; t[1] = 0; t[2] = 0; } else mat_vec(t, r, jp);
           for (int k = 0; k < 3; k++) anchor[k] = pos[k] + t[k];
           mat_vec(axis, r, ja);
           if (c == b) for (int k = 0; k < 3; k++) { S[o.xanchor + 3 * j + k] = anchor[k]; S[o.xaxis + 3 * j + k] = axis[k]; }
@@ -289,9 +290,11 @@ struct Engine {
           axisangle2quat(ql, ja, S[o.qpos + qa] - m.qpos0[qa]);
           quat_mul(qn, quat, ql);
           for (int k = 0; k < 4; k++) quat[k] = qn[k];
-          quat2mat(r, quat);
-          mat_vec(v, r, jp);
-          for (int k = 0; k < 3; k++) pos[k] = anchor[k] - v[k];
+          if (!at_origin) {
+            quat2mat(r, quat);
+            mat_vec(v, r, jp);
+            for (int k = 0; k < 3; k++) pos[k] = anchor[k] - v[k];
+          }
         }
         quat_normalize(quat);
         quat2mat(mat, quat);
@@ -629,6 +632,7 @@ struct Engine {
     if (x <= 0) return dmin;
     double y;
     if (power == 1) y = x;
+    else if (power == 2) y = (x <= mid) ? (x * x) / mid : 1 - ((1 - x) * (1 - x)) / (1 - mid);   // the MJCF default
     else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
     else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
     return dmin + y * (dmax - dmin);
