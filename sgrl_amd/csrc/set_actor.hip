@@ -44,7 +44,7 @@ enum { EPI_RELU = 1, EPI_ROWDIV = 2, EPI_ACC2 = 4 };
 constexpr int BM = 128, BN = 128, BK = 16, LDT = 130;
 constexpr int TPR = BK / 4;          // threads per tile row (one float4 each)
 constexpr int RPP = 256 / TPR;       // rows covered per pass
-constexpr int NPASS = BM / RPP;      // passes to cover the 128 rows
+
 constexpr int GEMM_LDS_BYTES = 4 * BK * LDT * (int)sizeof(float);
 
 struct GemmArgs {
@@ -58,14 +58,18 @@ struct GemmArgs {
   float* C2; int ldc2;  // EPI_ACC2: C2[m][n] += value
 };
 
-template <int FLAGS>
+// TM = 32-row MFMA tiles per wave in the M direction: block tile (64*TM) x 128.  TM = 1 halves the tile for the
+// N = 128 GEMMs, whose 280 full tiles would otherwise quantise badly onto 256 CUs.
+template <int FLAGS, int TM>
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
-  extern __shared__ float gemm_lds[];   // 2 stages x (A tile + W tile), k-major [BK][LDT]: 66 560 B
+  constexpr int BMT = 64 * TM;
+  constexpr int NPA = BMT / RPP;       // A-tile load passes
+  constexpr int NPW = BN / RPP;        // W-tile load passes
+  extern __shared__ float gemm_lds[];   // 2 stages x (A tile + W tile), k-major [BK][LDT]
   float (*As)[BK][LDT] = reinterpret_cast<float (*)[BK][LDT]>(gemm_lds);
   float (*Ws)[BK][LDT] = reinterpret_cast<float (*)[BK][LDT]>(gemm_lds + 2 * BK * LDT);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  // XCD-aware tile order: consecutive row-tiles that share a column tile land on the same XCD's L2
   const int tiles_n = (a.N + BN - 1) / BN;
   // blocks b and b+8 share an XCD (round-robin dispatch): renumber so that each XCD works on a contiguous run of
   // tiles, i.e. the column tiles of one row tile re-read the same A rows out of ONE L2 (speed only, never correctness)
@@ -75,26 +79,33 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
     bid = (x < rem) ? x * (per + 1) + i : rem * (per + 1) + (x - rem) * per + i;
   }
   const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = tile_m * BMT, n0 = tile_n * BN;
   const int kq = t % TPR, r0 = t / TPR;
-  f32x16 acc[2][2];
-  for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
-  float4 ra[NPASS], rw[NPASS];
+  f32x16 acc[TM][2];
+  for (int i = 0; i < TM; i++) for (int j = 0; j < 2; j++) for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+  float4 ra[NPA], rw[NPW];
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < NPASS; i++) {
-      const int row = r0 + RPP * i;
-      const int m = m0 + row, n = n0 + row;
+    for (int i = 0; i < NPA; i++) {
+      const int m = m0 + r0 + RPP * i;
       ra[i] = (m < a.M) ? *reinterpret_cast<const float4*>(a.A + (size_t)m * a.lda + k0 + 4 * kq) : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NPW; i++) {
+      const int n = n0 + r0 + RPP * i;
       rw[i] = (n < a.N) ? *reinterpret_cast<const float4*>(a.W + (size_t)n * a.ldw + k0 + 4 * kq) : make_float4(0, 0, 0, 0);
     }
   };
   auto sstore = [&](int st) {
 #pragma unroll
-    for (int i = 0; i < NPASS; i++) {
+    for (int i = 0; i < NPA; i++) {
       const int row = r0 + RPP * i;
       As[st][4 * kq + 0][row] = ra[i].x; As[st][4 * kq + 1][row] = ra[i].y;
       As[st][4 * kq + 2][row] = ra[i].z; As[st][4 * kq + 3][row] = ra[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < NPW; i++) {
+      const int row = r0 + RPP * i;
       Ws[st][4 * kq + 0][row] = rw[i].x; Ws[st][4 * kq + 1][row] = rw[i].y;
       Ws[st][4 * kq + 2][row] = rw[i].z; Ws[st][4 * kq + 3][row] = rw[i].w;
     }
@@ -105,36 +116,46 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
   __syncthreads();
   if (nk > 1) gload(BK);
   const int li = lane & 31, lh = lane >> 5;
+  const int arow = wm * 32 * TM + li, bcol = wn * 64 + li;
   for (int kt = 0; kt < nk; kt++) {
     const int st = kt & 1;
     // the registers hold tile kt+1: push it into the idle LDS stage FIRST so the writes drain underneath this tile's
     // MFMAs, then start fetching tile kt+2
     if (kt + 1 < nk) sstore(st ^ 1);
     if (kt + 2 < nk) gload((kt + 2) * BK);
-    // operand fetch for k-pair kk+1 is issued before the four MFMAs of k-pair kk (LDS latency under the matrix pipe)
-    float a0 = As[st][lh][wm * 64 + li], a1 = As[st][lh][wm * 64 + 32 + li];
-    float b0 = Ws[st][lh][wn * 64 + li], b1 = Ws[st][lh][wn * 64 + 32 + li];
+    // operand fetch for k-pair kk+1 is issued before the MFMAs of k-pair kk (LDS latency under the matrix pipe)
+    float av[TM], bv[2];
+#pragma unroll
+    for (int i = 0; i < TM; i++) av[i] = As[st][lh][arow + 32 * i];
+    bv[0] = Ws[st][lh][bcol]; bv[1] = Ws[st][lh][bcol + 32];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; kk++) {
-      float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+      float na[TM], nb[2];
+#pragma unroll
+      for (int i = 0; i < TM; i++) na[i] = 0.f;
+      nb[0] = 0.f; nb[1] = 0.f;
       if (kk + 1 < BK / 2) {
         const int ka = 2 * (kk + 1) + lh;
-        na0 = As[st][ka][wm * 64 + li]; na1 = As[st][ka][wm * 64 + 32 + li];
-        nb0 = Ws[st][ka][wn * 64 + li]; nb1 = Ws[st][ka][wn * 64 + 32 + li];
+#pragma unroll
+        for (int i = 0; i < TM; i++) na[i] = As[st][ka][arow + 32 * i];
+        nb[0] = Ws[st][ka][bcol]; nb[1] = Ws[st][ka][bcol + 32];
       }
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[0], acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[1], acc[i][1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; i++) av[i] = na[i];
+      bv[0] = nb[0]; bv[1] = nb[1];
     }
     __syncthreads();
   }
   // epilogue: C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
   // FLAGS is a compile-time constant: no per-element branches, the 16 row divisors of a tile are fetched together.
 #pragma unroll
-  for (int ti = 0; ti < 2; ti++) {
-    const int mb = m0 + wm * 64 + ti * 32 + 4 * lh;
+  for (int ti = 0; ti < TM; ti++) {
+    const int mb = m0 + wm * 32 * TM + ti * 32 + 4 * lh;
     float rdiv[16];
     if (FLAGS & EPI_ROWDIV) {
 #pragma unroll
@@ -147,12 +168,12 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
     for (int tj = 0; tj < 2; tj++) {
       const int n = n0 + wn * 64 + tj * 32 + li;
       if (n >= a.N) continue;
-      const float bv = a.bias ? a.bias[n] : 0.f;
+      const float bvv = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
       for (int e = 0; e < 16; e++) {
         const int m = mb + (e & 3) + 8 * (e >> 2);
         if (m >= a.M) continue;
-        float v = acc[ti][tj][e] + bv;
+        float v = acc[ti][tj][e] + bvv;
         if (FLAGS & EPI_RELU) v = fmaxf(v, 0.f);
         if (FLAGS & EPI_ROWDIV) v = v / rdiv[e];
         a.C[(size_t)m * a.ldc + n] = v;
@@ -456,14 +477,21 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw
                 int M, int N, int K, int flags = 0, const float* rowdiv = nullptr, float* C2 = nullptr, int ldc2 = 0) {
   if (K % BK != 0 || (lda & 3) || (ldw & 3)) return sfail(SGRL_ERR_ARG, "gemm: K must be a multiple of 16 and rows 16-byte aligned");
   GemmArgs a{A, lda, W, ldw, bias, C, ldc, M, N, K, flags, rowdiv, C2, ldc2};
-  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  const int tiles_n = (N + BN - 1) / BN;
+  const int full = ((M + 127) / 128) * tiles_n;
+  const bool half = full < 2 * 256;      // fewer than two full tiles per CU: use 64-row tiles
+  const int tiles = half ? ((M + 63) / 64) * tiles_n : full;
+#define SGRL_LAUNCH(F)                                                                                        \
+  if (half) hipLaunchKernelGGL((k_gemm<F, 1>), dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, a);               \
+  else hipLaunchKernelGGL((k_gemm<F, 2>), dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, a)
   switch (flags) {
-    case 0: hipLaunchKernelGGL(k_gemm<0>, dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, a); break;
-    case EPI_RELU: hipLaunchKernelGGL(k_gemm<EPI_RELU>, dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, a); break;
-    case EPI_ROWDIV: hipLaunchKernelGGL(k_gemm<EPI_ROWDIV>, dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, a); break;
-    case EPI_ACC2: hipLaunchKernelGGL(k_gemm<EPI_ACC2>, dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, a); break;
+    case 0: SGRL_LAUNCH(0); break;
+    case EPI_RELU: SGRL_LAUNCH(EPI_RELU); break;
+    case EPI_ROWDIV: SGRL_LAUNCH(EPI_ROWDIV); break;
+    case EPI_ACC2: SGRL_LAUNCH(EPI_ACC2); break;
     default: return sfail(SGRL_ERR_ARG, "gemm: unsupported epilogue combination");
   }
+#undef SGRL_LAUNCH
   return SGRL_OK;
 }
 
@@ -540,10 +568,12 @@ int sgrl_set_create(sgrl_set** out) {
     *out = nullptr;
     return sfail(SGRL_ERR_HIP, "no HIP device visible: the SET actor fast path needs an MI355X (there is no CPU fallback)");
   }
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<0>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<EPI_RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<EPI_ROWDIV>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<EPI_ACC2>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES) != hipSuccess) {
+  bool attr_ok = true;
+#define SGRL_ATTR(F, T) attr_ok = attr_ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<F, T>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES) == hipSuccess
+  SGRL_ATTR(0, 1); SGRL_ATTR(0, 2); SGRL_ATTR(EPI_RELU, 1); SGRL_ATTR(EPI_RELU, 2);
+  SGRL_ATTR(EPI_ROWDIV, 1); SGRL_ATTR(EPI_ROWDIV, 2); SGRL_ATTR(EPI_ACC2, 1); SGRL_ATTR(EPI_ACC2, 2);
+#undef SGRL_ATTR
+  if (!attr_ok) {
     *out = nullptr;
     return sfail(SGRL_ERR_HIP, "cannot raise the dynamic LDS limit of the GEMM kernel");
   }
