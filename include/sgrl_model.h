@@ -90,13 +90,15 @@ typedef struct SgrlModelView {
   int n_int, n_f64; /* total blob lengths */
 } SgrlModelView;
 
-/* Set up table pointers into the blobs.  Returns 0, or -1 when the magic is wrong. */
-SGRL_HD int sgrl_model_view(const int32_t* ib, const double* fb, SgrlModelView* v) {
-  if (ib[SGRL_H_MAGIC] != SGRL_MAGIC) return -1;
+/* Set up table pointers into the blobs (ib, fb).  The table sizes are read from `hdr_src`, which may be a different
+ * copy of the same header: the HIP engine passes the copy in global memory there (scalar loads -> the whole view
+ * stays in scalar registers) while ib/fb point at the LDS copy of the tables.  Returns 0, or -1 on a bad magic. */
+SGRL_HD int sgrl_model_view_from(const int32_t* hdr_src, const int32_t* ib, const double* fb, SgrlModelView* v) {
+  if (hdr_src[SGRL_H_MAGIC] != SGRL_MAGIC) return -1;
   v->hdr = ib;
   v->fhdr = fb;
-  const int nb = ib[SGRL_H_NBODY], nj = ib[SGRL_H_NJNT], nq = ib[SGRL_H_NQ], nv = ib[SGRL_H_NV];
-  const int nu = ib[SGRL_H_NU], ng = ib[SGRL_H_NGEOM], np = ib[SGRL_H_NPAIR];
+  const int nb = hdr_src[SGRL_H_NBODY], nj = hdr_src[SGRL_H_NJNT], nq = hdr_src[SGRL_H_NQ], nv = hdr_src[SGRL_H_NV];
+  const int nu = hdr_src[SGRL_H_NU], ng = hdr_src[SGRL_H_NGEOM], np = hdr_src[SGRL_H_NPAIR];
   v->nbody = nb; v->njnt = nj; v->nq = nq; v->nv = nv; v->nu = nu; v->ngeom = ng; v->npair = np;
   const int32_t* p = ib + SGRL_NHDR;
   v->body_parent = p; p += nb;
@@ -155,6 +157,10 @@ SGRL_HD int sgrl_model_view(const int32_t* ib, const double* fb, SgrlModelView* 
   v->act_ctrlrange = f; f += 2 * nu;
   v->n_f64 = (int)(f - fb);
   return 0;
+}
+
+SGRL_HD int sgrl_model_view(const int32_t* ib, const double* fb, SgrlModelView* v) {
+  return sgrl_model_view_from(ib, ib, fb, v);
 }
 
 /* Per-environment persistent state (one per env; SoA in the HIP engine, AoS in the oracle):

@@ -79,7 +79,7 @@ __device__ __forceinline__ void setup(const BatchArgs& a, int env, SgrlModelView
   for (int k = lane; k < g.n_f64; k += 64) s[o->model_f + k] = md.fb[k];
   for (int k = lane; k < g.n_int; k += 64) ii[o->model_i + k] = md.ib[k];
   __syncthreads();
-  sgrl_model_view(ii + o->model_i, s + o->model_f, m);
+  sgrl_model_view_from(md.ib, ii + o->model_i, s + o->model_f, m);   // sizes via scalar loads, tables in LDS
   *S = s;
   *I = ii;
 }

@@ -221,3 +221,28 @@ def test_full_size_batch_properties():
         assert cntA[i, 1] == oe.counters[1] and cntA[i, 0] == oe.counters[0]
         assert np.abs(q - oe.qpos).max() < 1e-6 * (1 + np.abs(oe.qpos).max())
         assert np.abs(v - oe.qvel).max() < 1e-6 * (1 + np.abs(oe.qvel).max())
+
+
+def test_mixed_families_use_separate_launch_groups_and_still_match_the_oracle():
+    """hopper (33 KB LDS slab), walker (40 KB) and cheetah (96 KB) fall into different occupancy classes: the engine
+    issues one launch per class on forked streams.  Same parity as a single launch."""
+    torch = _torch()
+    names = ["3d_cheetah_14_full", "3d_hopper_3_shin", "3d_walker_7_full"]
+    env = _make(names, 3)
+    assert env.lds_bytes > 80 * 1024
+    env.reset_device()
+    oes = _oracle_envs(env, names, 5)
+    for oe in oes:
+        oe.reset()
+    rng = np.random.RandomState(2)
+    for t in range(30):
+        a = rng.uniform(-1, 1, size=(env.num_envs, env.action_max_len)).astype(np.float32)
+        env.step_device(torch.from_numpy(a).cuda())
+        torch.cuda.synchronize()
+        obs = env.obs64.cpu().numpy()
+        done = env.done.cpu().numpy()
+        for i, oe in enumerate(oes):
+            o, r, d, info = oe.step(a[i].astype(np.float64))
+            assert bool(done[i]) == d, (t, i)
+            assert np.abs(obs[i, :o.size] - o).max() < 1e-5 * (1 + np.abs(o).max()), (t, i)
+            assert (obs[i, o.size:] == 0).all()
