@@ -281,7 +281,7 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
     for (int k = 0; k < n_morph; k++) {
       cost[k] = ib[k][SGRL_H_NV];
       int per_cu = (160 * 1024) / e->morph_lds[k];
-      cls[k] = per_cu > 8 ? 8 : per_cu;
+      cls[k] = per_cu > 4 ? 4 : per_cu;   // the kernel's register budget admits one wave per SIMD = 4 workgroups per CU anyway
     }
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
       const int mx = env_morph[x], my = env_morph[y];

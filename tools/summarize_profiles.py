@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Turn raw gpurun_out rocprofv3 outputs into the small tracked summaries under profiles/ (usage: tag stats_dir fetch_dir write_dir bench_log)."""
+import csv, collections, glob, json, re, shutil, sys
+import numpy as np
+tag, stats_dir, fetch_dir, write_dir, bench_log = sys.argv[1:6]
+shutil.copy(glob.glob(stats_dir + "/*/*kernel_stats.csv")[0], "profiles/%s_kernel_stats.csv" % tag)
+means = {}
+for name, d in (("fetch", fetch_dir), ("write", write_dir)):
+    rows = list(csv.DictReader(open(glob.glob(d + "/*/*counter_collection.csv")[0])))
+    acc = collections.defaultdict(list)
+    for r in rows:
+        m = re.search(r"(k_[a-z_0-9]+)[<(]", r["Kernel_Name"])
+        acc[m.group(1) if m else r["Kernel_Name"][:60]].append(float(r["Counter_Value"]))
+    with open("profiles/%s_pmc_%s_size_summary.csv" % (tag, name), "w") as f:
+        f.write("kernel,counter,launches,mean_KB,min_KB,max_KB\n")
+        for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+            f.write('"%s",%s,%d,%.1f,%.1f,%.1f\n' % (k, rows[0]["Counter_Name"], len(v), np.mean(v), np.min(v), np.max(v)))
+    means[name] = (float(np.mean(acc["k_env_step"])), len(acc["k_env_step"]))
+line = open(bench_log).read().strip().split("\n")[-1]
+open("profiles/%s_bench.json" % tag, "w").write(line + "\n")
+out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 5 --warmup 3 --no-cpu-baseline (two separate passes)",
+       "envs_per_gpu": json.loads(line)["config"]["envs_per_gpu"], "kernel": "k_env_step",
+       "FETCH_SIZE_KB_per_launch_mean": round(means["fetch"][0], 1), "WRITE_SIZE_KB_per_launch_mean": round(means["write"][0], 1),
+       "launches": means["fetch"][1], "k_env_step_bytes_per_launch": int((means["fetch"][0] + means["write"][0]) * 1024),
+       "note": "raw counters x 1024; MI355X_MICROARCH.md: FETCH_SIZE reads 1/2 of the bytes of WIDE (16 B/lane) coalesced streaming "
+               "reads; this kernel reads 8 B/lane records, for which the guide gives no calibration, so no correction is applied."}
+json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
+print(json.dumps(out)[:300])
