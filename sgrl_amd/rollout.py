@@ -104,3 +104,48 @@ class ReplayGather(object):
 
     def bytes_per_step(self):
         return self.block.numel() * 4
+
+
+class RoundCollector(object):
+    """Collection-round bookkeeping of the reference trainer for ALL environments at once (tensors on any device).
+
+    The reference keeps stepping every env (auto-reset) but stores and counts only the FIRST episode of each env per
+    round; a round ends when every env has finished once, then the TD3 updates run and `envs.reset()` starts the next
+    round (reference src/trainer.py:155-160, 205-275; same rule in warmup, :108-138).  Per step and env i:
+        done_bool = curr_done[i];  if episode_timesteps[i] + 1 == max_episode_steps: done_bool = 0, curr_done[i] = True
+        if not done_list[i]:  episode_timesteps[i] += 1;  store (obs, action, next_obs, reward, done_bool);
+                              done_list[i] |= curr_done[i]
+    """
+
+    def __init__(self, n_env, max_episode_steps=1000, device="cpu"):
+        self.n = n_env
+        self.max_episode_steps = int(max_episode_steps)
+        self.device = torch.device(device)
+        self.begin_round()
+
+    def begin_round(self):
+        self.done_list = torch.zeros(self.n, dtype=torch.bool, device=self.device)
+        self.episode_timesteps = torch.zeros(self.n, dtype=torch.long, device=self.device)
+        self.episode_reward = torch.zeros(self.n, dtype=torch.float32, device=self.device)
+        self._reward_buf = torch.zeros(self.n, dtype=torch.float32, device=self.device)
+
+    def record(self, reward, curr_done):
+        """reward float[n], curr_done bool/uint8[n] as returned by VecEnv.step.  Returns (store_mask bool[n],
+        done_to_store float[n], round_finished bool).  Rows where store_mask is False are dropped (trainer.py:218)."""
+        curr_done = curr_done.to(torch.bool).clone()
+        done_bool = curr_done.to(torch.float32)
+        timeout = (self.episode_timesteps + 1) == self.max_episode_steps
+        done_bool = torch.where(timeout, torch.zeros_like(done_bool), done_bool)
+        curr_done |= timeout
+        self._reward_buf += reward.to(torch.float32)
+        first = curr_done & (self.episode_reward == 0)
+        self.episode_reward = torch.where(first, self._reward_buf, self.episode_reward)
+        self._reward_buf = torch.where(first, torch.zeros_like(self._reward_buf), self._reward_buf)
+        store = ~self.done_list
+        self.episode_timesteps += store.to(torch.long)
+        self.done_list |= store & curr_done
+        return store, done_bool, bool(self.done_list.all())
+
+    def per_morph_iter(self):
+        """Number of TD3 updates per morphology after the round (reference trainer.py:244)."""
+        return int(self.episode_timesteps.sum().item()) // self.n
