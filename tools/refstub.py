@@ -124,9 +124,18 @@ def install():
 
     gym = types.ModuleType("gym")
     gym.Wrapper = _Wrapper
+    gym.Space = object
+    gym.Env = object
     gym.make = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("gym.make is not available in the stub"))
     gym_spaces = types.ModuleType("gym.spaces")
     gym_spaces.Box = _Box
+    gym_spaces.Discrete = type("Discrete", (), {})
+    gym_box = types.ModuleType("gym.spaces.box")
+    gym_box.Box = _Box
+    gym_disc = types.ModuleType("gym.spaces.discrete")
+    gym_disc.Discrete = gym_spaces.Discrete
+    gym_spaces.box = gym_box
+    gym_spaces.discrete = gym_disc
     gym.spaces = gym_spaces
     gym_utils = types.ModuleType("gym.utils")
     gym_utils.EzPickle = _EzPickle
@@ -146,6 +155,8 @@ def install():
         "xmltodict": xd,
         "gym": gym,
         "gym.spaces": gym_spaces,
+        "gym.spaces.box": gym_box,
+        "gym.spaces.discrete": gym_disc,
         "gym.utils": gym_utils,
         "gym.envs": gym_envs,
         "gym.envs.registration": gym_reg,
