@@ -262,3 +262,56 @@ def default_args(**over):
 
 def make_policy(device=None, use_hip=True, max_action=1.0):
     return SEPolicy(41, 3, 32, 1, max_action, 3, True, False, False, default_args(), device=device, use_hip=use_hip)
+
+
+class SECritic(nn.Module):
+    """Twin SET critics behind the reference's module surface (reference src/SECritic.py:8-124): same constructor
+    signature, `critic1` / `critic2` state_dict prefixes, `forward(state, action) -> (q1, q2)` with per-limb Q values
+    [B, L], `Q1`, `change_morphology`.  Training-side code: plain differentiable PyTorch."""
+
+    def __init__(self, state_dim, action_dim, msg_dim, batch_size, max_children, disable_fold, td, bu, args=None,
+                 device=None):
+        super().__init__()
+        self.num_limbs = 1
+        self.msg_dim, self.batch_size, self.max_children = msg_dim, batch_size, max_children
+        self.disable_fold = disable_fold
+        self.state_dim, self.action_dim = state_dim, action_dim
+
+        def make():
+            return TransformerModel(
+                state_dim + action_dim, 1, args.attention_embedding_size, args.attention_heads,
+                args.attention_hidden_size, args.attention_layers, args.dropout_rate,
+                condition_decoder=args.condition_decoder_on_features, transformer_norm=args.transformer_norm,
+                num_positions=len(args.traversal_types), rel_size=args.rel_size)
+        self.critic1 = make()
+        self.critic2 = make()
+        if device is not None:
+            self.to(device)
+        self.graph = None
+
+    def _input(self, state, action):
+        B = state.shape[0]
+        assert state.shape[1] == self.state_dim * self.num_limbs, \
+            "state.shape[1] expects {} but got {}".format(self.state_dim * self.num_limbs, state.shape[1])
+        return torch.cat([state.reshape(B, self.num_limbs, -1), action.reshape(B, self.num_limbs, -1)], dim=2)
+
+    def forward(self, state, action):
+        x = self._input(state, action)
+        B = x.shape[0]
+        return self.critic1(x, self.graph).reshape(B, -1), self.critic2(x, self.graph).reshape(B, -1)
+
+    def Q1(self, state, action):
+        x = self._input(state, action)
+        return self.critic1(x, self.graph).reshape(x.shape[0], -1)
+
+    def clear_buffer(self):
+        pass
+
+    def change_morphology(self, graph):
+        self.graph = graph
+        self.parents = graph["parents"]
+        self.num_limbs = len(self.parents)
+
+
+def make_critic(device=None):
+    return SECritic(41, 3, 32, 1, 3, True, False, False, default_args(), device=device)
