@@ -69,17 +69,24 @@ extern __shared__ double sgrl_lds[];
 // LDS and point the model view at the copy: every table lookup of the ~16 dynamics evaluations then costs an LDS
 // access instead of an L2 round trip.
 __device__ __forceinline__ void setup(const BatchArgs& a, int env, SgrlModelView* m, sgrl::Layout* o, double** S, int32_t** I) {
-  const MorphDev md = a.morphs[a.env_morph[env]];
+  const int mi = __builtin_amdgcn_readfirstlane(a.env_morph[env]);
+  const MorphDev md = a.morphs[mi];
+  // The header is wave-uniform, but it arrives through vector loads (global memory the kernel also writes), so the
+  // compiler would keep every table offset derived from it as a per-lane value (~150 registers).  readfirstlane makes
+  // the sizes scalar: the whole layout / model view then lives in SGPRs.
+  int32_t hdr[SGRL_NHDR];
+#pragma unroll
+  for (int k = 0; k < SGRL_NHDR; k++) hdr[k] = __builtin_amdgcn_readfirstlane(md.ib[k]);
   SgrlModelView g;
-  sgrl_model_view(md.ib, md.fb, &g);
-  sgrl::make_layout(md.ib, o, g.n_int, g.n_f64);
+  sgrl_model_view_from(hdr, md.ib, md.fb, &g);
+  sgrl::make_layout(hdr, o, g.n_int, g.n_f64);
   double* s = sgrl_lds;
   int32_t* ii = reinterpret_cast<int32_t*>(sgrl_lds + o->s_total);
   const int lane = threadIdx.x;
   for (int k = lane; k < g.n_f64; k += 64) s[o->model_f + k] = md.fb[k];
   for (int k = lane; k < g.n_int; k += 64) ii[o->model_i + k] = md.ib[k];
   __syncthreads();
-  sgrl_model_view_from(md.ib, ii + o->model_i, s + o->model_f, m);   // sizes via scalar loads, tables in LDS
+  sgrl_model_view_from(hdr, ii + o->model_i, s + o->model_f, m);   // scalar sizes, tables in LDS
   *S = s;
   *I = ii;
 }
@@ -110,7 +117,7 @@ __device__ unsigned long long g_phase_prof[16 * 65536];
 #endif
 
 __global__ __launch_bounds__(64) void k_env_step(BatchArgs a, StepOut out) {
-  const int env = a.block_env[blockIdx.x];
+  const int env = __builtin_amdgcn_readfirstlane(a.block_env[blockIdx.x]);
   SgrlModelView m; sgrl::Layout o; double* S; int32_t* I;
   setup(a, env, &m, &o, &S, &I);
   sgrl::HipWave w;
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(64) void k_env_step(BatchArgs a, StepOut out) {
 }
 
 __global__ __launch_bounds__(64) void k_env_reset(BatchArgs a, StepOut out) {
-  const int env = a.block_env[blockIdx.x];
+  const int env = __builtin_amdgcn_readfirstlane(a.block_env[blockIdx.x]);
   SgrlModelView m; sgrl::Layout o; double* S; int32_t* I;
   setup(a, env, &m, &o, &S, &I);
   sgrl::HipWave w;
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(64) void k_env_reset(BatchArgs a, StepOut out) {
 }
 
 __global__ __launch_bounds__(64) void k_env_refresh(BatchArgs a, StepOut out) {
-  const int env = a.block_env[blockIdx.x];
+  const int env = __builtin_amdgcn_readfirstlane(a.block_env[blockIdx.x]);
   SgrlModelView m; sgrl::Layout o; double* S; int32_t* I;
   setup(a, env, &m, &o, &S, &I);
   sgrl::HipWave w;
