@@ -63,6 +63,10 @@ struct StepOut {
   int auto_reset;
 };
 
+#ifndef SGRL_STAGE_FLOATS
+#define SGRL_STAGE_FLOATS 0
+#endif
+
 extern __shared__ double sgrl_lds[];
 
 // Stage the morphology tables (a few KB, shared by all envs of the morphology, L2 resident) into this workgroup's
@@ -79,14 +83,16 @@ __device__ __forceinline__ void setup(const BatchArgs& a, int env, SgrlModelView
   for (int k = 0; k < SGRL_NHDR; k++) hdr[k] = __builtin_amdgcn_readfirstlane(md.ib[k]);
   SgrlModelView g;
   sgrl_model_view_from(hdr, md.ib, md.fb, &g);
-  sgrl::make_layout(hdr, o, g.n_int, g.n_f64);
+  // integer tables (paths, masks, parents: walked in inner loops) are staged in LDS; the float tables are read once
+  // per evaluation per lane and stay in L2 -- the 6 KB they would cost in LDS buy a fifth workgroup per CU instead
+  sgrl::make_layout(hdr, o, g.n_int, SGRL_STAGE_FLOATS ? g.n_f64 : 0);
   double* s = sgrl_lds;
   int32_t* ii = reinterpret_cast<int32_t*>(sgrl_lds + o->s_total);
   const int lane = threadIdx.x;
-  for (int k = lane; k < g.n_f64; k += 64) s[o->model_f + k] = md.fb[k];
+  if (SGRL_STAGE_FLOATS) for (int k = lane; k < g.n_f64; k += 64) s[o->model_f + k] = md.fb[k];
   for (int k = lane; k < g.n_int; k += 64) ii[o->model_i + k] = md.ib[k];
   __syncthreads();
-  sgrl_model_view_from(hdr, ii + o->model_i, s + o->model_f, m);   // scalar sizes, tables in LDS
+  sgrl_model_view_from(hdr, ii + o->model_i, SGRL_STAGE_FLOATS ? s + o->model_f : md.fb, m);   // scalar sizes
   *S = s;
   *I = ii;
 }
@@ -252,7 +258,7 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
     if (41 * L > obs_max_len || 3 * L > action_max_len) { rc = fail(SGRL_ERR_ARG, "obs_max_len/action_max_len too small for morphology " + std::to_string(k)); break; }
     if (morph_count[k] < 0) { rc = fail(SGRL_ERR_ARG, "negative morph_count"); break; }
     sgrl::Layout o;
-    sgrl::make_layout(ib[k], &o, v.n_int, v.n_f64);
+    sgrl::make_layout(ib[k], &o, v.n_int, SGRL_STAGE_FLOATS ? v.n_f64 : 0);
     const int bytes = sgrl::layout_bytes(&o);
     if (bytes > 160 * 1024) { rc = fail(SGRL_ERR_LIMIT, "per-environment LDS slab exceeds 160 KiB"); break; }
     if (bytes > e->lds_bytes) e->lds_bytes = bytes;
@@ -288,7 +294,7 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
     for (int k = 0; k < n_morph; k++) {
       cost[k] = ib[k][SGRL_H_NV];
       int per_cu = (160 * 1024) / e->morph_lds[k];
-      cls[k] = per_cu > 4 ? 4 : per_cu;   // the kernel's register budget admits one wave per SIMD = 4 workgroups per CU anyway
+      cls[k] = per_cu > 8 ? 8 : per_cu;   // register budget (233 VGPRs): two waves per SIMD = 8 workgroups per CU at most
     }
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
       const int mx = env_morph[x], my = env_morph[y];

@@ -95,7 +95,11 @@ SGRL_HD void make_layout(const int32_t* hdr, Layout* o, int n_int = 0, int n_f64
   o->eR = p; p += o->maxrows; o->earef = p; p += o->maxrows; o->eb = p; p += o->maxrows;
   o->ef = p; p += o->maxrows; o->ediag = p; p += o->maxrows;
   o->eidg = p; p += o->maxrows; o->prev_f = p; p += o->maxrows;
-  o->Apk = p; p += kNAMax * (kNAMax + 1) / 2;
+  {
+    const int na_cap = o->maxrows < kNAMax ? o->maxrows : kNAMax;   // the dense LDS path never sees more rows than this
+    o->Apk = p; p += na_cap * (na_cap + 1) / 2;
+    if (o->na_max > na_cap) o->na_max = na_cap;
+  }
   o->misc = p; p += 16;
   o->Mfull = p;
   if (hdr[SGRL_H_INTEGRATOR] == 0) p += nv * o->ld;

@@ -71,6 +71,17 @@ def _derived_int_tables(model):
     return [depth, path.ravel(), subend, mask.ravel(), dof_act]
 
 
+def worst_case_rows(model):
+    """Upper bound on simultaneously active constraint rows: one per limited joint + every contact of every pair."""
+    rows = int(np.sum(np.asarray(model.jnt_limited) != 0))
+    for k in range(model.npair):
+        g2 = int(model.pair_g2[k])
+        ncon = 2 if (int(model.geom_type[int(model.pair_g1[k])]) == mjcf.GEOM_PLANE and int(model.geom_type[g2]) == mjcf.GEOM_CAPSULE) else 1
+        dim = int(model.pair_condim[k])
+        rows += ncon * (1 if dim == 1 else 2 * (dim - 1))
+    return rows
+
+
 def pack_model(model, spec=None, env_name=None, max_rows=DEFAULT_MAX_ROWS, pgs_iters=DEFAULT_PGS_ITERS,
                pgs_tol=DEFAULT_PGS_TOL, solver=DEFAULT_SOLVER):
     """Return (ib int32[...], fb float64[...])."""
@@ -89,7 +100,7 @@ def pack_model(model, spec=None, env_name=None, max_rows=DEFAULT_MAX_ROWS, pgs_i
     hdr[H_NHEIGHT_BODIES] = len(hb)
     for i, b in enumerate(hb[:2]):
         hdr[H_HEIGHT_BODY0 + i] = b
-    hdr[H_MAX_ROWS] = max_rows
+    hdr[H_MAX_ROWS] = min(int(max_rows), max(1, worst_case_rows(model)))   # small morphologies need less LDS
     hdr[H_PGS_ITERS] = pgs_iters
     hdr[H_SOLVER] = solver
     ints = [hdr]
