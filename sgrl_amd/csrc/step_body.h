@@ -51,9 +51,9 @@ struct Layout {
   int xpos, xquat, xmat, xipos, xanchor, xaxis;
   int cinert, crb, cdof, cfrc;
   int dead, dead_len, na_max;
-  int L, dinv, qfs, ys, xtmp, qacc, vpgs;
+  int L, dinv, qfs, ys, qacc, vpgs;
   int con_pos, con_frame, con_dist;
-  int Y, eR, earef, eb, ef, ediag, eidg, prev_f, Apk;
+  int Y, eR, earef, eb, ef, ediag, eidg, prev_f;
   int misc;  // 16 scalars
   int Mfull; // Euler only: copy of M (lower triangle incl. diag)
   int model_f; // LDS copy of the float model blob (n_f64 doubles)
@@ -75,7 +75,7 @@ SGRL_HD void make_layout(const int32_t* hdr, Layout* o, int n_int = 0, int n_f64
   int p = 0;
   o->qpos = p; p += nq; o->qvel = p; p += nv; o->q0 = p; p += nq; o->v0 = p; p += nv;
   o->xv = p; p += nv; o->fq = p; p += nv; o->dvacc = p; p += nv; o->daacc = p; p += nv;
-  o->ctrl = p; p += nu + 1; o->act = p; p += 3 * (nb - 1);
+  o->ctrl = p; p += nu + 1;
   o->xpos = p; p += 3 * nb; o->xaxis = p; p += 3 * nj; o->cdof = p; p += 6 * nv;
   // "dead zone": everything below is no longer needed once the constraint rows of an evaluation are built, so the
   // LCP solver reuses the span as scratch for its Cholesky factor
@@ -89,20 +89,15 @@ SGRL_HD void make_layout(const int32_t* hdr, Layout* o, int n_int = 0, int n_f64
     while (na < kNAMax && (na + 1) * (na + 2) / 2 <= o->dead_len) na++;
     o->na_max = na;
   }
-  o->L = p; p += nv * o->ld; o->dinv = p; p += nv;
-  o->qfs = p; p += nv; o->ys = p; p += nv; o->xtmp = p; p += nv; o->qacc = p; p += nv; o->vpgs = p; p += nv;
+  o->L = p; p += nv * (nv + 1) / 2; o->dinv = p; p += nv;
+  o->qfs = p; p += nv; o->ys = p; p += nv; o->qacc = p; p += nv; o->vpgs = p; p += nv;
   o->Y = p; p += (o->maxrows + 1) * o->ldy;
   o->eR = p; p += o->maxrows; o->earef = p; p += o->maxrows; o->eb = p; p += o->maxrows;
   o->ef = p; p += o->maxrows; o->ediag = p; p += o->maxrows;
   o->eidg = p; p += o->maxrows; o->prev_f = p; p += o->maxrows;
-  {
-    const int na_cap = o->maxrows < kNAMax ? o->maxrows : kNAMax;   // the dense LDS path never sees more rows than this
-    o->Apk = p; p += na_cap * (na_cap + 1) / 2;
-    if (o->na_max > na_cap) o->na_max = na_cap;
-  }
   o->misc = p; p += 16;
   o->Mfull = p;
-  if (hdr[SGRL_H_INTEGRATOR] == 0) p += nv * o->ld;
+  if (hdr[SGRL_H_INTEGRATOR] == 0) p += nv * (nv + 1) / 2;
   o->model_f = p; p += n_f64;
   o->s_total = p;
   int q = 0;
@@ -204,6 +199,7 @@ SGRL_DEV int clz64(uint64_t x) {
   return __builtin_clzll(x);
 #endif
 }
+SGRL_DEV int tri(int i) { return i * (i + 1) / 2; }   // packed lower triangle: (i, j) at tri(i) + j
 // p = a(a+1)/2 + b with b <= a  ->  (a, b)
 SGRL_DEV void tri_decode(int p, int* a_out, int* b_out) {
   // float sqrt is within one of the exact root for p < 2^20; two branch-free corrections make it exact
@@ -369,7 +365,7 @@ struct Engine {
   }
 
   SGRL_DEV void crba_and_factor() {
-    const int nv = o.nv, ld = o.ld;
+    const int nv = o.nv;
     // composite inertias: subtree(b) = [b, subend[b]) in pre-order; and zero the lower triangle of M
     w.lanes(o.nb > nv ? o.nb : nv, [&](int i) {
       if (i >= 1 && i < o.nb) {
@@ -380,7 +376,7 @@ struct Engine {
           for (int k = 0; k < 10; k++) acc[k] += S[o.cinert + 10 * c + k];
         for (int k = 0; k < 10; k++) S[o.crb + 10 * i + k] = acc[k];
       }
-      if (i < nv) for (int k = 0; k <= i; k++) S[o.L + i * ld + k] = 0;
+      if (i < nv) for (int k = 0; k <= i; k++) S[o.L + tri(i) + k] = 0;
     });
     w.lanes(nv, [&](int i) {
       double buf[6], ci[10], cd[6];
@@ -388,26 +384,26 @@ struct Engine {
       for (int k = 0; k < 10; k++) ci[k] = S[o.crb + 10 * b + k];
       ld6(cd, S + o.cdof + 6 * i);
       inert_mul(buf, ci, cd);
-      S[o.L + i * ld + i] = dot6(cd, buf) + m.dof_armature[i];
+      S[o.L + tri(i) + i] = dot6(cd, buf) + m.dof_armature[i];
       for (int j = m.dof_parent[i]; j >= 0; j = m.dof_parent[j]) {
         double cj[6];
         ld6(cj, S + o.cdof + 6 * j);
-        S[o.L + i * ld + j] = dot6(cj, buf);
+        S[o.L + tri(i) + j] = dot6(cj, buf);
       }
     });
     if (m.hdr[SGRL_H_INTEGRATOR] == 0) {  // Euler needs M again for (M + h D)
-      w.lanes(nv, [&](int i) { for (int k = 0; k <= i; k++) S[o.Mfull + i * ld + k] = S[o.L + i * ld + k]; });
+      w.lanes(nv, [&](int i) { for (int k = 0; k <= i; k++) S[o.Mfull + tri(i) + k] = S[o.L + tri(i) + k]; });
     }
     cholesky(o.L);
   }
 
-  // in-place lower Cholesky of the matrix at S[base] (lower triangle, row stride ld); diag reciprocals -> dinv
+  // in-place lower Cholesky of the matrix at S[base] (packed lower triangle); diag reciprocals -> dinv
   SGRL_DEV void cholesky(int base) {
-    const int nv = o.nv, ld = o.ld;
+    const int nv = o.nv;
     // right-looking root-free elimination: after pivot j every trailing entry (i, k), j < k <= i, takes ONE fused
     // update  M_ik -= M_ij M_kj / M_jj  -- constant depth per pivot (one barrier), all lanes busy on the triangle
     for (int j = 0; j < nv - 1; j++) {
-      double pj = S[base + j * ld + j];
+      double pj = S[base + tri(j) + j];
       if (pj < kMinVal) pj = kMinVal;
       const double wj = 1.0 / pj;
       const int sdim = nv - j - 1;
@@ -415,38 +411,38 @@ struct Engine {
         int a, b;
         tri_decode(p, &a, &b);
         const int i = j + 1 + a, k = j + 1 + b;
-        S[base + i * ld + k] -= S[base + i * ld + j] * S[base + k * ld + j] * wj;
+        S[base + tri(i) + k] -= S[base + tri(i) + j] * S[base + tri(k) + j] * wj;
       });
     }
     // L[i][j] = C[i][j] / sqrt(C[j][j]),  dinv[j] = 1 / sqrt(C[j][j])
     w.lanes(nv, [&](int j) {
-      double pj = S[base + j * ld + j];
+      double pj = S[base + tri(j) + j];
       if (pj < kMinVal) pj = kMinVal;
       S[o.dinv + j] = sqrt(1.0 / pj);
     });
     w.lanes(nv * (nv - 1) / 2, [&](int p) {
       int a, b;
       tri_decode(p, &a, &b);          // strict lower triangle: i = a + 1 > j = b
-      S[base + (a + 1) * ld + b] *= S[o.dinv + b];
+      S[base + tri(a + 1) + b] *= S[o.dinv + b];
     });
   }
 
   // x (at S[xo], nv values) <- L^-T x, destroying nothing else; lane-parallel column sweeps
   SGRL_DEV void solve_upper_inplace(int base, int xo) {
-    const int nv = o.nv, ld = o.ld;
+    const int nv = o.nv;
     for (int i = nv - 1; i >= 0; i--) {
       const double xi = S[xo + i] * S[o.dinv + i];
       w.lanes(i + 1, [&](int k) {
-        if (k == i) S[xo + i] = xi; else S[xo + k] -= S[base + i * ld + k] * xi;
+        if (k == i) S[xo + i] = xi; else S[xo + k] -= S[base + tri(i) + k] * xi;
       });
     }
   }
   // serial-in-lane forward substitution of one vector stored at S[xo..] (used with lane = right-hand side)
   SGRL_DEV void solve_lower_row(int base, int xo) {
-    const int nv = o.nv, ld = o.ld;
+    const int nv = o.nv;
     for (int i = 0; i < nv; i++) {
       double s = S[xo + i];
-      const double* li = S + base + i * ld;
+      const double* li = S + base + tri(i);
       const double* x = S + xo;
       int k = 0;
       for (; k + 4 <= i; k += 4) {
@@ -818,7 +814,7 @@ struct Engine {
           const int r = t & (rp - 1), i = j + 1 + (t >> sh);
           if (r < nrhs) {
             double* Yr = S + o.Y + r * ldy;
-            Yr[i] -= S[o.L + i * o.ld + j] * (Yr[j] * dj);
+            Yr[i] -= S[o.L + tri(i) + j] * (Yr[j] * dj);
           }
         });
       }
@@ -847,13 +843,16 @@ struct Engine {
     });
   }
 
-  // Exact solve of the dual LCP  0 <= f  _|_  A f + b >= 0  (A = Y Y' + R, SPD, packed lower triangle at o.Apk) by
-  // block principal pivoting (Judice & Pires): guess the free set F, solve A_FF x = -b_F by a lane-parallel root-free
-  // Cholesky, exchange every index that violates x_F >= 0 or (A x + b)_G >= 0 (a single index once the number of
-  // violations has stopped shrinking), repeat.  The free set is warm-started from the previous evaluation.  The
-  // result is the same unique optimum projected Gauss-Seidel converges to; PGS remains the fallback.
-  SGRL_DEV bool lcp_block_pivot(int n, double thresh, const double* A, double* C, int* iters_out) {
+  // Exact solve of the dual LCP  0 <= f  _|_  A f + b >= 0  (A = Y Y' + R, SPD) by block principal pivoting (Judice &
+  // Pires): guess the free set F, solve A_FF x = -b_F by a lane-parallel root-free Cholesky, exchange every index that
+  // violates x_F >= 0 or (A x + b)_G >= 0 (a single index once the number of violations has stopped shrinking), repeat.
+  // A is never stored: the principal block A_FF is formed straight from the half-solved rows Y into the factor's
+  // scratch C (packed lower triangle), and the complement test uses  (A x)_G = Y_G (Y_F' x).  The free set is
+  // warm-started from the previous evaluation.  On success S[vpgs] = Y' f.  The result is the same unique optimum
+  // projected Gauss-Seidel converges to; PGS remains the fallback.
+  SGRL_DEV bool lcp_block_pivot(int n, double thresh, double* C, int* iters_out) {
     const int wv = o.earef, xw = o.prev_f;
+    const int nv = o.nv, ldy = o.ldy;
     uint64_t F = w.ballot(n, [&](int i) { return S[o.ef + i] > 0.0; });
     int patience = 3, best = n + 1;
     for (int iter = 0; iter < kBppMaxIter; iter++) {
@@ -865,14 +864,25 @@ struct Engine {
           S[xw + pos] = -S[o.eb + i];
         }
       });
-      // root-free right-looking Cholesky of A_FF (compact, packed lower triangle): one fused update per trailing
-      // entry per pivot;  w[k] = 1 / C[k][k]
+      // A_FF = Y_F Y_F' + diag(R_F), compact packed lower triangle
       w.lanes(nf * (nf + 1) / 2, [&](int p) {
         int i, j;
         tri_decode(p, &i, &j);
-        const int fi = I[o.flist + i], fj = I[o.flist + j];   // fi >= fj: the list is ascending
-        C[p] = A[fi * (fi + 1) / 2 + fj];
+        const int fi = I[o.flist + i], fj = I[o.flist + j];
+        const double* yi = S + o.Y + fi * ldy;
+        const double* yj = S + o.Y + fj * ldy;
+        double a = 0;
+        int d = 0;
+        for (; d + 4 <= nv; d += 4) {
+          const double a0 = yi[d], a1 = yi[d + 1], a2 = yi[d + 2], a3 = yi[d + 3];
+          const double b0 = yj[d], b1 = yj[d + 1], b2 = yj[d + 2], b3 = yj[d + 3];
+          a += a0 * b0; a += a1 * b1; a += a2 * b2; a += a3 * b3;
+        }
+        for (; d < nv; d++) a += yi[d] * yj[d];
+        if (i == j) a += S[o.eR + fi];
+        C[p] = a;
       });
+      // root-free right-looking Cholesky of A_FF: one fused update per trailing entry per pivot;  w[k] = 1 / C[k][k]
       for (int j = 0; j < nf - 1; j++) {
         double pj = C[j * (j + 1) / 2 + j];
         if (pj < kMinVal) pj = kMinVal;
@@ -900,14 +910,17 @@ struct Engine {
         const double xj = S[xw + j];
         w.lanes(j, [&](int k) { S[xw + k] -= C[j * (j + 1) / 2 + k] * S[wv + k] * xj; });
       }
-      // violations: x_i < 0 on F, (A x + b)_i < -thresh on the complement
+      // u = Y_F' x  (= Y' f for the candidate f);  violations: x_i < 0 on F, (Y_i u + b_i) < -thresh on the complement
+      w.lanes(nv, [&](int d) {
+        double u = 0;
+        for (int k = 0; k < nf; k++) u += S[o.Y + I[o.flist + k] * ldy + d] * S[xw + k];
+        S[o.vpgs + d] = u;
+      });
       const uint64_t V = w.ballot(n, [&](int i) {
         if ((F >> i) & 1ull) return S[xw + popcount64(F & ((1ull << i) - 1ull))] < -thresh * S[o.eidg + i];
+        const double* yi = S + o.Y + i * ldy;
         double y = S[o.eb + i];
-        for (int k = 0; k < nf; k++) {
-          const int fk = I[o.flist + k];
-          y += (i >= fk ? A[i * (i + 1) / 2 + fk] : A[fk * (fk + 1) / 2 + i]) * S[xw + k];
-        }
+        for (int d = 0; d < nv; d++) y += yi[d] * S[o.vpgs + d];
         return y < -thresh;
       });
       if (V == 0) {
@@ -928,40 +941,18 @@ struct Engine {
     return false;
   }
 
-  // dense-form dual solve: assemble A = Y Y' + diag(R) (packed lower triangle), block-pivot LCP solve, v = Y' f
-  SGRL_DEV void solve_dense(int nrow, double thresh, double* A, double* C, int* sweeps, int* diag_code) {
-    const int nv = o.nv, ldy = o.ldy;
-        // dense form: A = Y Y' + diag(R) once (packed lower triangle), then each row update is one broadcast of the
-        // row's residual and one rank-1 residual update  r += A[:, j] * df  -- no reduction on the critical path
-        const int npair = nrow * (nrow + 1) / 2;
-        w.lanes(npair, [&](int p) {
-          int i = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
-          while ((i + 1) * (i + 2) / 2 <= p) i++;
-          while (i * (i + 1) / 2 > p) i--;
-          const int j = p - i * (i + 1) / 2;
-          const double* yi = S + o.Y + i * ldy;
-          const double* yj = S + o.Y + j * ldy;
-          double a = 0;
-          int d = 0;
-          for (; d + 4 <= nv; d += 4) {
-            const double a0 = yi[d], a1 = yi[d + 1], a2 = yi[d + 2], a3 = yi[d + 3];
-            const double b0 = yj[d], b1 = yj[d + 1], b2 = yj[d + 2], b3 = yj[d + 3];
-            a += a0 * b0; a += a1 * b1; a += a2 * b2; a += a3 * b3;
-          }
-          for (; d < nv; d++) a += yi[d] * yj[d];
-          if (i == j) a += S[o.eR + i];
-          A[p] = a;
-        });
-        bool solved = false;
-        if (m.hdr[SGRL_H_SOLVER] == 1) solved = lcp_block_pivot(nrow, thresh, A, C, sweeps);
-        if (!solved) *diag_code |= 1 << 8;   // diagnostics: block pivoting gave up
-        if (!solved)
-          *sweeps = w.pgs_dense(nrow, A, S + o.eb, S + o.ediag, S + o.eidg, S + o.ef, m.hdr[SGRL_H_PGS_ITERS], thresh);
-        w.lanes(nv, [&](int d) {
-          double v = 0;
-          for (int r = 0; r < nrow; r++) v += S[o.Y + r * ldy + d] * S[o.ef + r];
-          S[o.vpgs + d] = v;
-        });
+  // dual solve with the factor scratch at C: block pivoting, matrix-free Gauss-Seidel if that is disabled or gave up
+  SGRL_DEV void solve_dual(int nrow, double thresh, double* C, int* sweeps, int* diag_code) {
+    bool solved = false;
+    if (m.hdr[SGRL_H_SOLVER] == 1) {
+      solved = lcp_block_pivot(nrow, thresh, C, sweeps);
+      if (!solved) *diag_code |= 1 << 8;   // diagnostics: block pivoting gave up
+    }
+    if (!solved) {
+      *diag_code |= 1;                     // diagnostics: evaluation solved by the matrix-free PGS path
+      *sweeps = w.pgs(nrow, o.nv, S + o.Y, o.ldy, S + o.eb, S + o.eR, S + o.ediag, S + o.eidg, S + o.ef, S + o.vpgs,
+                      m.hdr[SGRL_H_PGS_ITERS], thresh);
+    }
   }
 
   SGRL_DEV void pgs_and_finish() {
@@ -972,16 +963,14 @@ struct Engine {
       const double bmax = w.maxabs(nrow, [&](int r) { return S[o.eb + r]; });
       const double thresh = m.fhdr[SGRL_F_PGS_TOL] * (1.0 + bmax);
       if (nrow <= o.na_max) {
-        solve_dense(nrow, thresh, S + o.Apk, S + o.dead, &sweeps, &diag_code);          // A and factor in LDS
+        solve_dual(nrow, thresh, S + o.dead, &sweeps, &diag_code);          // factor scratch in LDS
       } else if (big_scratch != nullptr && nrow <= 64) {
-        // rare (a few envs per 8192-env launch): more rows than the LDS scratch holds -> same exact solve with A and
-        // the factor in this environment's HBM scratch slab instead of hundreds of Gauss-Seidel sweeps
-        const int tri = nrow * (nrow + 1) / 2;
-        solve_dense(nrow, thresh, big_scratch, big_scratch + tri, &sweeps, &diag_code);
+        // rare (a few envs per 8192-env launch): more rows than the LDS scratch holds -> same exact solve with the
+        // factor in this environment's HBM scratch slab instead of hundreds of Gauss-Seidel sweeps
+        solve_dual(nrow, thresh, big_scratch, &sweeps, &diag_code);
         diag_code |= 1 << 16;
       } else {
-        // many rows: matrix-free form, the policy keeps v = Y'f one entry per lane
-        diag_code = 1;                     // diagnostics: evaluation solved by the matrix-free PGS path
+        diag_code = 1;
         sweeps = w.pgs(nrow, nv, S + o.Y, ldy, S + o.eb, S + o.eR, S + o.ediag, S + o.eidg, S + o.ef, S + o.vpgs,
                        m.hdr[SGRL_H_PGS_ITERS], thresh);
       }
@@ -1040,7 +1029,7 @@ struct Engine {
   }
 
   SGRL_DEV void mj_step() {
-    const int nv = o.nv, nq = o.nq, ld = o.ld;
+    const int nv = o.nv, nq = o.nq;
     const double h = m.fhdr[SGRL_F_TIMESTEP];
     forward();
     if (m.hdr[SGRL_H_INTEGRATOR] == 1) {
@@ -1070,10 +1059,10 @@ struct Engine {
       // semi-implicit Euler with implicit joint damping: (M + h D) a = M qacc
       w.lanes(nv, [&](int i) {
         double s = 0;
-        for (int j = 0; j < nv; j++) s += (j <= i ? S[o.Mfull + i * ld + j] : S[o.Mfull + j * ld + i]) * S[o.qacc + j];
+        for (int j = 0; j < nv; j++) s += (j <= i ? S[o.Mfull + tri(i) + j] : S[o.Mfull + tri(j) + i]) * S[o.qacc + j];
         S[o.fq + i] = s;
       });
-      w.lanes(nv, [&](int i) { S[o.Mfull + i * ld + i] += h * m.dof_damping[i]; });
+      w.lanes(nv, [&](int i) { S[o.Mfull + tri(i) + i] += h * m.dof_damping[i]; });
       cholesky(o.Mfull);
       w.lanes(1, [&](int) { solve_lower_row(o.Mfull, o.fq); });
       solve_upper_inplace(o.Mfull, o.fq);
@@ -1145,7 +1134,7 @@ struct Engine {
     });
   }
 
-  // reward + done (serial scalar arithmetic on lane 0).  `act` = policy-ordered action in S[o.act]
+  // reward + done (serial scalar arithmetic on lane 0)
   SGRL_DEV void reward_done() {
     w.lanes(1, [&](int) {
       const double* q = S + o.misc + MS_PREQUAT;

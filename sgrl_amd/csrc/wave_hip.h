@@ -100,40 +100,6 @@ struct HipWave {
     __syncthreads();
     return it;
   }
-  // Dense-form PGS (n <= 32 rows): lane i keeps the residual r_i = (A f + b)_i and f_i in registers.  One row update =
-  // two v_readlane broadcasts, five scalar-like f64 ops and one fma per lane; A columns stream from LDS one ahead.
-  __device__ __forceinline__ int pgs_dense(int n_in, const double* A, const double* b, const double* dg,
-                                            const double* idg, double* f, int iters_in, double thresh) {
-    const int n = __builtin_amdgcn_readfirstlane(n_in), iters = __builtin_amdgcn_readfirstlane(iters_in);
-    const bool rowl = lane < n;
-    const int tri = lane * (lane + 1) / 2;
-    auto at = [&](int j) -> double {   // A[lane][j], packed lower triangle
-      return rowl ? (lane >= j ? A[tri + j] : A[j * (j + 1) / 2 + lane]) : 0.0;
-    };
-    double rf = rowl ? f[lane] : 0.0, rdg = rowl ? dg[lane] : 0.0, ridg = rowl ? idg[lane] : 0.0;
-    double rr = rowl ? b[lane] : 0.0;
-    for (int j = 0; j < n; j++) rr += at(j) * read_lane(rf, j);
-    int it = 0;
-    for (; it < iters; it++) {
-      double change = 0.0;
-      double anext = at(0);
-      for (int j = 0; j < n; j++) {
-        const double a = anext;
-        if (j + 1 < n) anext = at(j + 1);
-        const double fj = read_lane(rf, j);
-        double fn = fj - read_lane(rr, j) * read_lane(ridg, j);
-        fn = fn < 0.0 ? 0.0 : fn;
-        const double df = fn - fj;
-        rr += a * df;
-        if (lane == j) rf = fn;
-        change = fmax(change, fabs(df) * read_lane(rdg, j));
-      }
-      if (change < thresh) { it++; break; }
-    }
-    if (rowl) f[lane] = rf;
-    __syncthreads();
-    return it;
-  }
   template <class F> __device__ __forceinline__ uint64_t ballot(int n, F f) {
     const bool p = (lane < n) ? (bool)f(lane) : false;
     return (uint64_t)__ballot(p);

@@ -50,29 +50,6 @@ struct EmuWave {
     }
     return iters;
   }
-  // dense-form sweeps: r = A f + b kept per row, A packed lower triangle
-  int pgs_dense(int n, const double* A, const double* b, const double* dg, const double* idg, double* f, int iters,
-                 double thresh) {
-    auto at = [&](int i, int j) { return i >= j ? A[i * (i + 1) / 2 + j] : A[j * (j + 1) / 2 + i]; };
-    std::vector<double> r(n);
-    for (int i = 0; i < n; i++) { double s = b[i]; for (int j = 0; j < n; j++) s += at(i, j) * f[j]; r[i] = s; }
-    for (int it = 0; it < iters; it++) {
-      double change = 0;
-      for (int j = 0; j < n; j++) {
-        double fn = f[j] - r[j] * idg[j];
-        if (fn < 0) fn = 0;
-        const double df = fn - f[j];
-        if (df != 0) {
-          for (int i = 0; i < n; i++) r[i] += at(i, j) * df;
-          f[j] = fn;
-          const double c = std::fabs(df) * dg[j];
-          if (c > change) change = c;
-        }
-      }
-      if (change < thresh) return it + 1;
-    }
-    return iters;
-  }
   template <class F> uint64_t ballot(int n, F f) { uint64_t m = 0; for (int i = 0; i < n; i++) if (f(i)) m |= (1ull << i); return m; }
   template <class F> double maxabs(int n, F f) { double s = 0; for (int i = 0; i < n; i++) { double v = std::fabs(f(i)); if (v > s) s = v; } return s; }
 };
