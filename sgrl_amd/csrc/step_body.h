@@ -229,6 +229,12 @@ SGRL_DEV double rng_uniform01(uint64_t seed, uint32_t env_id, uint32_t episode, 
   return ((double)x + 0.5) * (1.0 / 4294967296.0);
 }
 
+#ifdef SGRL_PHASE_PROF
+#define SGRL_TICK(id) w.tick(id)
+#else
+#define SGRL_TICK(id)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 template <class W>
 struct Engine {
@@ -394,7 +400,9 @@ struct Engine {
     if (m.hdr[SGRL_H_INTEGRATOR] == 0) {  // Euler needs M again for (M + h D)
       w.lanes(nv, [&](int i) { for (int k = 0; k <= i; k++) S[o.Mfull + tri(i) + k] = S[o.L + tri(i) + k]; });
     }
+    SGRL_TICK(2);
     cholesky(o.L);
+    SGRL_TICK(8);
   }
 
   // in-place lower Cholesky of the matrix at S[base] (packed lower triangle); diag reciprocals -> dinv
@@ -427,33 +435,9 @@ struct Engine {
     });
   }
 
-  // x (at S[xo], nv values) <- L^-T x, destroying nothing else; lane-parallel column sweeps
-  SGRL_DEV void solve_upper_inplace(int base, int xo) {
-    const int nv = o.nv;
-    for (int i = nv - 1; i >= 0; i--) {
-      const double xi = S[xo + i] * S[o.dinv + i];
-      w.lanes(i + 1, [&](int k) {
-        if (k == i) S[xo + i] = xi; else S[xo + k] -= S[base + tri(i) + k] * xi;
-      });
-    }
-  }
-  // serial-in-lane forward substitution of one vector stored at S[xo..] (used with lane = right-hand side)
-  SGRL_DEV void solve_lower_row(int base, int xo) {
-    const int nv = o.nv;
-    for (int i = 0; i < nv; i++) {
-      double s = S[xo + i];
-      const double* li = S + base + tri(i);
-      const double* x = S + xo;
-      int k = 0;
-      for (; k + 4 <= i; k += 4) {
-        const double a0 = li[k], a1 = li[k + 1], a2 = li[k + 2], a3 = li[k + 3];
-        const double x0 = x[k], x1 = x[k + 1], x2 = x[k + 2], x3 = x[k + 3];
-        s -= a0 * x0; s -= a1 * x1; s -= a2 * x2; s -= a3 * x3;
-      }
-      for (; k < i; k++) s -= li[k] * x[k];
-      S[xo + i] = s * S[o.dinv + i];
-    }
-  }
+  // x (at S[xo], nv values) <- L^-T x  /  L^-1 x
+  SGRL_DEV void solve_upper_inplace(int base, int xo) { w.trsv_upper(o.nv, S + base, S + o.dinv, S + xo); }
+  SGRL_DEV void solve_lower_inplace(int base, int xo) { w.trsv_lower(o.nv, S + base, S + o.dinv, S + xo); }
 
   // ---- collision ------------------------------------------------------------------------------
   SGRL_DEV void geom_pose(int g, double* pos, double* mat) {
@@ -800,33 +784,11 @@ struct Engine {
       for (int k = 0; k < pn; k++) if (I[o.prev_key + k] == key) f0 = S[o.prev_f + k];
       S[o.ef + r] = f0;
     });
-    // half-solve Y <- L^-1 Y for ALL right-hand sides at once (rows + the smooth force): per pivot column j every
-    // (rhs, i > j) pair takes one fused update -- constant depth per column instead of a serial nv^2/2 loop per lane
-    {
-      const int nrhs = nrow + 1;
-      int rp = 1;
-      while (rp < nrhs) rp <<= 1;                 // rhs index = item & (rp - 1), row offset = item / rp
-      int sh = 0;
-      while ((1 << sh) < rp) sh++;
-      for (int j = 0; j < nv - 1; j++) {
-        const double dj = S[o.dinv + j];
-        w.lanes(rp * (nv - j - 1), [&](int t) {
-          const int r = t & (rp - 1), i = j + 1 + (t >> sh);
-          if (r < nrhs) {
-            double* Yr = S + o.Y + r * ldy;
-            Yr[i] -= S[o.L + tri(i) + j] * (Yr[j] * dj);
-          }
-        });
-      }
-      w.lanes(rp * nv, [&](int t) {
-        const int r = t & (rp - 1), d = t >> sh;
-        if (r < nrhs) {
-          const double y = S[o.Y + r * ldy + d] * S[o.dinv + d];
-          S[o.Y + r * ldy + d] = y;
-          if (r == nrow) S[o.ys + d] = y;
-        }
-      });
-    }
+    SGRL_TICK(6);
+    // half-solve Y <- L^-1 Y for all right-hand sides (rows + the smooth force), one lane per right-hand side
+    w.trsm_lower_rows(nrow + 1, nv, S + o.L, S + o.dinv, S + o.Y, ldy);
+    w.lanes(nv, [&](int d) { S[o.ys + d] = S[o.Y + nrow * ldy + d]; });
+    SGRL_TICK(9);
     w.lanes(nrow > nv ? nrow : nv, [&](int r) {
       if (r < nrow) {
         const double* Yr = S + o.Y + r * ldy;
@@ -941,20 +903,6 @@ struct Engine {
     return false;
   }
 
-  // dual solve with the factor scratch at C: block pivoting, matrix-free Gauss-Seidel if that is disabled or gave up
-  SGRL_DEV void solve_dual(int nrow, double thresh, double* C, int* sweeps, int* diag_code) {
-    bool solved = false;
-    if (m.hdr[SGRL_H_SOLVER] == 1) {
-      solved = lcp_block_pivot(nrow, thresh, C, sweeps);
-      if (!solved) *diag_code |= 1 << 8;   // diagnostics: block pivoting gave up
-    }
-    if (!solved) {
-      *diag_code |= 1;                     // diagnostics: evaluation solved by the matrix-free PGS path
-      *sweeps = w.pgs(nrow, o.nv, S + o.Y, o.ldy, S + o.eb, S + o.eR, S + o.ediag, S + o.eidg, S + o.ef, S + o.vpgs,
-                      m.hdr[SGRL_H_PGS_ITERS], thresh);
-    }
-  }
-
   SGRL_DEV void pgs_and_finish() {
     const int nv = o.nv, ldy = o.ldy;
     const int nrow = I[o.icnt + IC_NROW];
@@ -962,19 +910,26 @@ struct Engine {
     if (nrow > 0) {
       const double bmax = w.maxabs(nrow, [&](int r) { return S[o.eb + r]; });
       const double thresh = m.fhdr[SGRL_F_PGS_TOL] * (1.0 + bmax);
-      if (nrow <= o.na_max) {
-        solve_dual(nrow, thresh, S + o.dead, &sweeps, &diag_code);          // factor scratch in LDS
-      } else if (big_scratch != nullptr && nrow <= 64) {
-        // rare (a few envs per 8192-env launch): more rows than the LDS scratch holds -> same exact solve with the
-        // factor in this environment's HBM scratch slab instead of hundreds of Gauss-Seidel sweeps
-        solve_dual(nrow, thresh, big_scratch, &sweeps, &diag_code);
-        diag_code |= 1 << 16;
-      } else {
-        diag_code = 1;
+      bool solved = false;
+      if (m.hdr[SGRL_H_SOLVER] == 1) {
+        if (nrow <= o.na_max) {
+          solved = lcp_block_pivot(nrow, thresh, S + o.dead, &sweeps);         // factor scratch in LDS
+          if (!solved) diag_code |= 1 << 8;                                     // diagnostics: block pivoting gave up
+        } else if (big_scratch != nullptr && nrow <= 64) {
+          // rare (a few envs per 8192-env launch): more rows than the LDS scratch holds -> same exact solve with the
+          // factor in this environment's HBM scratch slab instead of hundreds of Gauss-Seidel sweeps
+          solved = lcp_block_pivot(nrow, thresh, big_scratch, &sweeps);
+          diag_code |= (1 << 16) | (solved ? 0 : 1 << 8);
+        }
+      }
+      if (!solved) {
+        // matrix-free projected Gauss-Seidel, the policy keeps v = Y'f one entry per lane (also the SOLVER = 0 path)
+        diag_code |= 1;
         sweeps = w.pgs(nrow, nv, S + o.Y, ldy, S + o.eb, S + o.eR, S + o.ediag, S + o.eidg, S + o.ef, S + o.vpgs,
                        m.hdr[SGRL_H_PGS_ITERS], thresh);
       }
     }
+    SGRL_TICK(7);
     // remember the solution for the next evaluation's warm start
     w.lanes(nrow > 0 ? nrow : 1, [&](int r) {
       if (r < nrow) {
@@ -988,11 +943,6 @@ struct Engine {
     solve_upper_inplace(o.L, o.qacc);
   }
 
-#ifdef SGRL_PHASE_PROF
-#define SGRL_TICK(id) w.tick(id)
-#else
-#define SGRL_TICK(id)
-#endif
   SGRL_DEV void forward() {
     SGRL_TICK(-1);
     kinematics();               SGRL_TICK(0);
@@ -1001,8 +951,8 @@ struct Engine {
     collide();                  SGRL_TICK(3);
     bias_and_smooth_force();    SGRL_TICK(4);
     enumerate_rows();           SGRL_TICK(5);
-    build_rows_and_halfsolve(); SGRL_TICK(6);
-    pgs_and_finish();           SGRL_TICK(7);
+    build_rows_and_halfsolve(); SGRL_TICK(10);
+    pgs_and_finish();           SGRL_TICK(11);
   }
 
   // ---- integration ----------------------------------------------------------------------------
@@ -1031,28 +981,38 @@ struct Engine {
   SGRL_DEV void mj_step() {
     const int nv = o.nv, nq = o.nq;
     const double h = m.fhdr[SGRL_F_TIMESTEP];
-    forward();
-    if (m.hdr[SGRL_H_INTEGRATOR] == 1) {
-      // RK4; the kinematics left in LDS afterwards are those of the 4th stage (what _get_obs reads)
-      w.lanes(nq > nv ? nq : nv, [&](int i) {
-        if (i < nq) S[o.q0 + i] = S[o.qpos + i];
-        if (i < nv) {
-          S[o.v0 + i] = S[o.qvel + i]; S[o.xv + i] = S[o.qvel + i]; S[o.fq + i] = S[o.qacc + i];
-          S[o.dvacc + i] = (1.0 / 6) * S[o.qvel + i]; S[o.daacc + i] = (1.0 / 6) * S[o.qacc + i];
-        }
-      });
-      for (int st = 1; st < 4; st++) {
+    const bool rk4 = m.hdr[SGRL_H_INTEGRATOR] == 1;
+    {
+      // RK4 (four stages) or Euler (one); the kinematics left in LDS afterwards are those of the last stage (what
+      // _get_obs reads).  One loop with a single inlined copy of forward() keeps the kernel's code near the I-cache.
+#pragma unroll 1
+      for (int st = 0; st < (rk4 ? 4 : 1); st++) {
         const double a = (st == 3) ? 1.0 : 0.5;
         const double bw = (st == 3) ? (1.0 / 6) : (1.0 / 3);
-        integrate_pos(o.qpos, o.q0, o.xv, a * h);
-        w.lanes(nv, [&](int d) {
-          const double v = S[o.v0 + d] + a * h * S[o.fq + d];
-          S[o.qvel + d] = v; S[o.xv + d] = v;
-          S[o.dvacc + d] += bw * v;
-        });
+        if (st > 0) {
+          integrate_pos(o.qpos, o.q0, o.xv, a * h);
+          w.lanes(nv, [&](int d) {
+            const double v = S[o.v0 + d] + a * h * S[o.fq + d];
+            S[o.qvel + d] = v; S[o.xv + d] = v;
+            S[o.dvacc + d] += bw * v;
+          });
+        }
         forward();
-        w.lanes(nv, [&](int d) { S[o.fq + d] = S[o.qacc + d]; S[o.daacc + d] += bw * S[o.qacc + d]; });
+        if (!rk4) break;
+        if (st == 0) {
+          w.lanes(nq > nv ? nq : nv, [&](int i) {
+            if (i < nq) S[o.q0 + i] = S[o.qpos + i];
+            if (i < nv) {
+              S[o.v0 + i] = S[o.qvel + i]; S[o.xv + i] = S[o.qvel + i]; S[o.fq + i] = S[o.qacc + i];
+              S[o.dvacc + i] = (1.0 / 6) * S[o.qvel + i]; S[o.daacc + i] = (1.0 / 6) * S[o.qacc + i];
+            }
+          });
+        } else {
+          w.lanes(nv, [&](int d) { S[o.fq + d] = S[o.qacc + d]; S[o.daacc + d] += bw * S[o.qacc + d]; });
+        }
       }
+    }
+    if (rk4) {
       integrate_pos(o.qpos, o.q0, o.dvacc, h);
       w.lanes(nv, [&](int d) { S[o.qvel + d] = S[o.v0 + d] + h * S[o.daacc + d]; });
     } else {
@@ -1064,7 +1024,7 @@ struct Engine {
       });
       w.lanes(nv, [&](int i) { S[o.Mfull + tri(i) + i] += h * m.dof_damping[i]; });
       cholesky(o.Mfull);
-      w.lanes(1, [&](int) { solve_lower_row(o.Mfull, o.fq); });
+      solve_lower_inplace(o.Mfull, o.fq);
       solve_upper_inplace(o.Mfull, o.fq);
       w.lanes(nv, [&](int d) { S[o.qvel + d] += h * S[o.fq + d]; });
       integrate_pos(o.qpos, o.qpos, o.qvel, h);
@@ -1303,6 +1263,7 @@ SGRL_DEV void env_step(W& w, const SgrlModelView& m, const Layout& o, double* S,
     if (u == 4) { I[o.icnt + IC_OVERFLOW] = 0; I[o.icnt + IC_PREV_N] = 0; I[o.icnt + IC_SWEEPS] = 0; I[o.icnt + IC_ROWSUM] = 0; }
   });
   const int fs = m.hdr[SGRL_H_FRAME_SKIP];
+#pragma unroll 1
   for (int s = 0; s < fs; s++) e.mj_step();
   e.body_velocities();
   e.reward_done();

@@ -100,6 +100,71 @@ struct HipWave {
     __syncthreads();
     return it;
   }
+  // ---- triangular solves on a packed lower triangle in LDS (entry (i, j) at i(i+1)/2 + j), n <= 64 ---------------------
+  // The serial recurrences run on registers: lane = matrix row (or right-hand side), pivots / solution entries are
+  // broadcast with v_readlane, so the dependent chain per step is a few ALU ops instead of an LDS round trip.
+  //
+  // x <- L^-1 x (lane i keeps x_i; column j of L streams from LDS one step ahead)
+  __device__ __forceinline__ double trsv_lower_reg(int n, const double* P, double dv, double x) {
+    const double* row = P + lane * (lane + 1) / 2;
+    double lnext = (lane > 0 && lane < n) ? row[0] : 0.0;
+    for (int j = 0; j < n; j++) {
+      const double lj = lnext;
+      if (j + 1 < n) lnext = (lane > j + 1 && lane < n) ? row[j + 1] : 0.0;
+      const double xj = read_lane(x, j) * read_lane(dv, j);
+      x = lane == j ? xj : (lane > j ? x - lj * xj : x);
+    }
+    return x;
+  }
+  // x <- L^-T x (lane k keeps x_k; row i of L streams from LDS one step ahead)
+  __device__ __forceinline__ double trsv_upper_reg(int n, const double* P, double dv, double x) {
+    double lnext = (n > 0 && lane < n - 1) ? P[(n - 1) * n / 2 + lane] : 0.0;
+    for (int i = n - 1; i >= 0; i--) {
+      const double li = lnext;
+      if (i > 0) lnext = lane < i - 1 ? P[(i - 1) * i / 2 + lane] : 0.0;
+      const double xi = read_lane(x, i) * read_lane(dv, i);
+      x = lane == i ? xi : (lane < i ? x - li * xi : x);
+    }
+    return x;
+  }
+  __device__ __forceinline__ void trsv_lower(int n_in, const double* P, const double* dinv, double* xs) {
+    const int n = __builtin_amdgcn_readfirstlane(n_in);
+    const double dv = lane < n ? dinv[lane] : 0.0;
+    const double x = trsv_lower_reg(n, P, dv, lane < n ? xs[lane] : 0.0);
+    if (lane < n) xs[lane] = x;
+    __syncthreads();
+  }
+  __device__ __forceinline__ void trsv_upper(int n_in, const double* P, const double* dinv, double* xs) {
+    const int n = __builtin_amdgcn_readfirstlane(n_in);
+    const double dv = lane < n ? dinv[lane] : 0.0;
+    const double x = trsv_upper_reg(n, P, dv, lane < n ? xs[lane] : 0.0);
+    if (lane < n) xs[lane] = x;
+    __syncthreads();
+  }
+  // Y_r <- L^-1 Y_r for the rows r < nrhs (row stride ldy): lane = right-hand side, its row never leaves the lane, the
+  // L entries are LDS broadcasts; left-looking so that each entry is written once
+  __device__ __forceinline__ void trsm_lower_rows(int nrhs_in, int n_in, const double* P, const double* dinv, double* Y,
+                                                  int ldy) {
+    const int n = __builtin_amdgcn_readfirstlane(n_in), nrhs = __builtin_amdgcn_readfirstlane(nrhs_in);
+    for (int r0 = 0; r0 < nrhs; r0 += 64) {
+      const bool act = r0 + lane < nrhs;
+      double* y = Y + (act ? r0 + lane : nrhs - 1) * ldy;
+      for (int i = 0; i < n; i++) {
+        const double* Li = P + i * (i + 1) / 2;
+        double s0 = y[i], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int j = 0;
+        for (; j + 4 <= i; j += 4) {
+          const double a0 = Li[j], a1 = Li[j + 1], a2 = Li[j + 2], a3 = Li[j + 3];
+          const double b0 = y[j], b1 = y[j + 1], b2 = y[j + 2], b3 = y[j + 3];
+          s0 -= a0 * b0; s1 -= a1 * b1; s2 -= a2 * b2; s3 -= a3 * b3;
+        }
+        for (; j < i; j++) s0 -= Li[j] * y[j];
+        const double yi = ((s0 + s1) + (s2 + s3)) * dinv[i];
+        if (act) y[i] = yi;
+      }
+    }
+    __syncthreads();
+  }
   template <class F> __device__ __forceinline__ uint64_t ballot(int n, F f) {
     const bool p = (lane < n) ? (bool)f(lane) : false;
     return (uint64_t)__ballot(p);

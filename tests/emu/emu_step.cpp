@@ -50,6 +50,24 @@ struct EmuWave {
     }
     return iters;
   }
+  // triangular solves on a packed lower triangle (reference semantics of the HipWave register versions)
+  void trsv_lower(int n, const double* P, const double* dinv, double* x) {
+    for (int i = 0; i < n; i++) {
+      double s = x[i];
+      for (int j = 0; j < i; j++) s -= P[i * (i + 1) / 2 + j] * x[j];
+      x[i] = s * dinv[i];
+    }
+  }
+  void trsv_upper(int n, const double* P, const double* dinv, double* x) {
+    for (int i = n - 1; i >= 0; i--) {
+      double s = x[i];
+      for (int k = i + 1; k < n; k++) s -= P[k * (k + 1) / 2 + i] * x[k];
+      x[i] = s * dinv[i];
+    }
+  }
+  void trsm_lower_rows(int nrhs, int n, const double* P, const double* dinv, double* Y, int ldy) {
+    for (int r = 0; r < nrhs; r++) trsv_lower(n, P, dinv, Y + r * ldy);
+  }
   template <class F> uint64_t ballot(int n, F f) { uint64_t m = 0; for (int i = 0; i < n; i++) if (f(i)) m |= (1ull << i); return m; }
   template <class F> double maxabs(int n, F f) { double s = 0; for (int i = 0; i < n; i++) { double v = std::fabs(f(i)); if (v > s) s = v; } return s; }
 };
