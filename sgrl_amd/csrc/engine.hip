@@ -122,7 +122,7 @@ __device__ __forceinline__ sgrl::StepIO make_io(const BatchArgs& a, const StepOu
 __device__ unsigned long long g_phase_prof[16 * 65536];
 #endif
 
-__global__ __launch_bounds__(64) void k_env_step(BatchArgs a, StepOut out) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_env_step(BatchArgs a, StepOut out) {
   const int env = __builtin_amdgcn_readfirstlane(a.block_env[blockIdx.x]);
   SgrlModelView m; sgrl::Layout o; double* S; int32_t* I;
   setup(a, env, &m, &o, &S, &I);

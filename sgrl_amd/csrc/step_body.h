@@ -401,13 +401,15 @@ struct Engine {
       w.lanes(nv, [&](int i) { for (int k = 0; k <= i; k++) S[o.Mfull + tri(i) + k] = S[o.L + tri(i) + k]; });
     }
     SGRL_TICK(2);
-    cholesky(o.L);
+    cholesky<true>(o.L);
     SGRL_TICK(8);
   }
 
   // in-place lower Cholesky of the matrix at S[base] (packed lower triangle); diag reciprocals -> dinv
+  template <bool REG = false>
   SGRL_DEV void cholesky(int base) {
     const int nv = o.nv;
+    if (REG && w.chol_packed(nv, S + base, S + o.dinv, kMinVal)) return;   // register version where the policy has one
     // right-looking root-free elimination: after pivot j every trailing entry (i, k), j < k <= i, takes ONE fused
     // update  M_ik -= M_ij M_kj / M_jj  -- constant depth per pivot (one barrier), all lanes busy on the triangle
     for (int j = 0; j < nv - 1; j++) {

@@ -51,6 +51,7 @@ struct EmuWave {
     return iters;
   }
   // triangular solves on a packed lower triangle (reference semantics of the HipWave register versions)
+  bool chol_packed(int, double*, double*, double) { return false; }   // the emulator always takes the generic path
   void trsv_lower(int n, const double* P, const double* dinv, double* x) {
     for (int i = 0; i < n; i++) {
       double s = x[i];
