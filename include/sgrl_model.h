@@ -62,45 +62,64 @@ enum {
 enum { SGRL_GEOM_PLANE = 0, SGRL_GEOM_SPHERE = 2, SGRL_GEOM_CAPSULE = 3 };
 enum { SGRL_JNT_FREE = 0, SGRL_JNT_HINGE = 3 };
 
+/* Address-space qualifiers of the four kinds of pointers in the view.  Empty for host code and the oracle.  The HIP
+ * engine defines them before including this header: header copies and float tables in constant memory (uniform
+ * reads become scalar loads, the rest plain global loads that do not touch the LDS queue), int tables in LDS. */
+#ifndef SGRL_CONST_AS
+#define SGRL_CONST_AS
+#endif
+#ifndef SGRL_ITAB_AS
+#define SGRL_ITAB_AS
+#endif
+#ifndef SGRL_FTAB_AS
+#define SGRL_FTAB_AS
+#endif
+typedef const SGRL_CONST_AS int32_t* sgrl_hdr_t;
+typedef const SGRL_CONST_AS double* sgrl_fhdr_t;
+typedef const SGRL_ITAB_AS int32_t* sgrl_itab_t;
+typedef const SGRL_FTAB_AS double* sgrl_ftab_t;
+
 typedef struct SgrlModelView {
-  const int32_t* hdr;
-  const double* fhdr;
+  sgrl_hdr_t hdr;
+  sgrl_fhdr_t fhdr;
   int nbody, njnt, nq, nv, nu, ngeom, npair;
   /* int tables */
-  const int32_t *body_parent, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_limbtype;
-  const int32_t *jnt_type, *jnt_body, *jnt_qposadr, *jnt_dofadr, *jnt_limited;
-  const int32_t *dof_body, *dof_jnt, *dof_parent;
-  const int32_t *geom_type, *geom_body;
-  const int32_t *pair_g1, *pair_g2, *pair_condim;
-  const int32_t *act_dof, *act_slot;
+  sgrl_itab_t body_parent, body_jntadr, body_jntnum, body_dofadr, body_dofnum, body_limbtype;
+  sgrl_itab_t jnt_type, jnt_body, jnt_qposadr, jnt_dofadr, jnt_limited;
+  sgrl_itab_t dof_body, dof_jnt, dof_parent;
+  sgrl_itab_t geom_type, geom_body;
+  sgrl_itab_t pair_g1, pair_g2, pair_condim;
+  sgrl_itab_t act_dof, act_slot;
   /* derived by the packer (not part of the compiled asset): */
-  const int32_t *body_depth;   /* [nbody] number of bodies on the path torso..b (torso = 1) */
-  const int32_t *body_path;    /* [nbody*8] path[0] = 1 (torso) ... path[depth-1] = b, padded with -1 */
-  const int32_t *body_subend;  /* [nbody] bodies are in pre-order: subtree(b) = [b, subend[b]) */
-  const int32_t *body_dofmask; /* [nbody*2] 64-bit mask (lo, hi) of the dofs that move body b */
-  const int32_t *dof_act;      /* [nv] actuator driving this dof or -1 */
+  sgrl_itab_t body_depth;   /* [nbody] number of bodies on the path torso..b (torso = 1) */
+  sgrl_itab_t body_path;    /* [nbody*8] path[0] = 1 (torso) ... path[depth-1] = b, padded with -1 */
+  sgrl_itab_t body_subend;  /* [nbody] bodies are in pre-order: subtree(b) = [b, subend[b]) */
+  sgrl_itab_t body_dofmask; /* [nbody*2] 64-bit mask (lo, hi) of the dofs that move body b */
+  sgrl_itab_t dof_act;      /* [nv] actuator driving this dof or -1 */
   /* float tables */
-  const double *qpos0;
-  const double *body_pos, *body_quat, *body_ipos, *body_inertia, *body_mass, *body_invweight0;
-  const double *jnt_pos, *jnt_axis, *jnt_range, *jnt_stiffness, *jnt_solref, *jnt_solimp, *jnt_margin;
-  const double *dof_armature, *dof_damping, *dof_invweight0;
-  const double *geom_pos, *geom_quat, *geom_size;
-  const double *pair_mu, *pair_margin, *pair_solref, *pair_solimp;
-  const double *act_gear, *act_ctrlrange;
+  sgrl_ftab_t qpos0;
+  sgrl_ftab_t body_pos, body_quat, body_ipos, body_inertia, body_mass, body_invweight0;
+  sgrl_ftab_t jnt_pos, jnt_axis, jnt_range, jnt_stiffness, jnt_solref, jnt_solimp, jnt_margin;
+  sgrl_ftab_t dof_armature, dof_damping, dof_invweight0;
+  sgrl_ftab_t geom_pos, geom_quat, geom_size;
+  sgrl_ftab_t pair_mu, pair_margin, pair_solref, pair_solimp;
+  sgrl_ftab_t act_gear, act_ctrlrange;
   int n_int, n_f64; /* total blob lengths */
 } SgrlModelView;
 
-/* Set up table pointers into the blobs (ib, fb).  The table sizes are read from `hdr_src`, which may be a different
- * copy of the same header: the HIP engine passes the copy in global memory there (scalar loads -> the whole view
- * stays in scalar registers) while ib/fb point at the LDS copy of the tables.  Returns 0, or -1 on a bad magic. */
-SGRL_HD int sgrl_model_view_from(const int32_t* hdr_src, const int32_t* ib, const double* fb, SgrlModelView* v) {
+/* Set up table pointers into the blobs (ib, fb).  The table sizes and the two headers the view exposes are read from
+ * `hdr_src` / `fhdr_src`, which may be different copies of the same blobs: the HIP engine passes the copies in
+ * constant memory there (scalar loads -> sizes, offsets and every header constant stay in scalar registers) while ib
+ * points at the LDS copy of the int tables.  Returns 0, or -1 on a bad magic. */
+SGRL_HD int sgrl_model_view_from(sgrl_hdr_t hdr_src, sgrl_fhdr_t fhdr_src, sgrl_itab_t ib, sgrl_ftab_t fb,
+                                 SgrlModelView* v) {
   if (hdr_src[SGRL_H_MAGIC] != SGRL_MAGIC) return -1;
-  v->hdr = ib;
-  v->fhdr = fb;
+  v->hdr = hdr_src;
+  v->fhdr = fhdr_src;
   const int nb = hdr_src[SGRL_H_NBODY], nj = hdr_src[SGRL_H_NJNT], nq = hdr_src[SGRL_H_NQ], nv = hdr_src[SGRL_H_NV];
   const int nu = hdr_src[SGRL_H_NU], ng = hdr_src[SGRL_H_NGEOM], np = hdr_src[SGRL_H_NPAIR];
   v->nbody = nb; v->njnt = nj; v->nq = nq; v->nv = nv; v->nu = nu; v->ngeom = ng; v->npair = np;
-  const int32_t* p = ib + SGRL_NHDR;
+  sgrl_itab_t p = ib + SGRL_NHDR;
   v->body_parent = p; p += nb;
   v->body_jntadr = p; p += nb;
   v->body_jntnum = p; p += nb;
@@ -128,7 +147,7 @@ SGRL_HD int sgrl_model_view_from(const int32_t* hdr_src, const int32_t* ib, cons
   v->body_dofmask = p; p += 2 * nb;
   v->dof_act = p; p += nv;
   v->n_int = (int)(p - ib);
-  const double* f = fb + SGRL_NFHDR;
+  sgrl_ftab_t f = fb + SGRL_NFHDR;
   v->qpos0 = f; f += nq;
   v->body_pos = f; f += 3 * nb;
   v->body_quat = f; f += 4 * nb;
@@ -159,8 +178,17 @@ SGRL_HD int sgrl_model_view_from(const int32_t* hdr_src, const int32_t* ib, cons
   return 0;
 }
 
+/* Blob lengths implied by a header (the same sums sgrl_model_view_from walks; tests/test_abi.py checks them against
+ * the packer for every shipped morphology). */
+SGRL_HD void sgrl_model_blob_sizes(const int32_t* hdr, int* n_int, int* n_f64) {
+  const int nb = hdr[SGRL_H_NBODY], nj = hdr[SGRL_H_NJNT], nq = hdr[SGRL_H_NQ], nv = hdr[SGRL_H_NV];
+  const int nu = hdr[SGRL_H_NU], ng = hdr[SGRL_H_NGEOM], np = hdr[SGRL_H_NPAIR];
+  *n_int = SGRL_NHDR + 18 * nb + 5 * nj + 4 * nv + 2 * ng + 3 * np + 2 * nu;
+  *n_f64 = SGRL_NFHDR + nq + 19 * nb + 17 * nj + 3 * nv + 10 * ng + 9 * np + 3 * nu;
+}
+
 SGRL_HD int sgrl_model_view(const int32_t* ib, const double* fb, SgrlModelView* v) {
-  return sgrl_model_view_from(ib, ib, fb, v);
+  return sgrl_model_view_from((sgrl_hdr_t)ib, (sgrl_fhdr_t)fb, (sgrl_itab_t)ib, (sgrl_ftab_t)fb, v);
 }
 
 /* Per-environment persistent state (one per env; SoA in the HIP engine, AoS in the oracle):

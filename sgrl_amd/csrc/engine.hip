@@ -12,6 +12,20 @@
 #include <string>
 #include <vector>
 
+#ifndef SGRL_STAGE_FLOATS
+#define SGRL_STAGE_FLOATS 0   // 1: also stage the float model tables in LDS (costs ~6 KB of slab per workgroup)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+// address spaces of the model view (include/sgrl_model.h): header copies in constant memory (uniform -> s_load),
+// int tables in LDS, float tables in constant memory (or LDS when staged)
+#define SGRL_CONST_AS __attribute__((address_space(4)))
+#define SGRL_ITAB_AS __attribute__((address_space(3)))
+#if SGRL_STAGE_FLOATS
+#define SGRL_FTAB_AS __attribute__((address_space(3)))
+#else
+#define SGRL_FTAB_AS __attribute__((address_space(4)))
+#endif
+#endif
 #include "../../include/sgrl.h"
 #include "step_body.h"
 #include "wave_hip.h"
@@ -63,9 +77,6 @@ struct StepOut {
   int auto_reset;
 };
 
-#ifndef SGRL_STAGE_FLOATS
-#define SGRL_STAGE_FLOATS 0
-#endif
 
 extern __shared__ double sgrl_lds[];
 
@@ -81,18 +92,25 @@ __device__ __forceinline__ void setup(const BatchArgs& a, int env, SgrlModelView
   int32_t hdr[SGRL_NHDR];
 #pragma unroll
   for (int k = 0; k < SGRL_NHDR; k++) hdr[k] = __builtin_amdgcn_readfirstlane(md.ib[k]);
-  SgrlModelView g;
-  sgrl_model_view_from(hdr, md.ib, md.fb, &g);
+  int n_int, n_f64;
+  sgrl_model_blob_sizes(hdr, &n_int, &n_f64);
   // integer tables (paths, masks, parents: walked in inner loops) are staged in LDS; the float tables are read once
   // per evaluation per lane and stay in L2 -- the 6 KB they would cost in LDS buy a fifth workgroup per CU instead
-  sgrl::make_layout(hdr, o, g.n_int, SGRL_STAGE_FLOATS ? g.n_f64 : 0);
+  sgrl::make_layout(hdr, o, n_int, SGRL_STAGE_FLOATS ? n_f64 : 0);
   double* s = sgrl_lds;
   int32_t* ii = reinterpret_cast<int32_t*>(sgrl_lds + o->s_total);
   const int lane = threadIdx.x;
-  if (SGRL_STAGE_FLOATS) for (int k = lane; k < g.n_f64; k += 64) s[o->model_f + k] = md.fb[k];
-  for (int k = lane; k < g.n_int; k += 64) ii[o->model_i + k] = md.ib[k];
+  if (SGRL_STAGE_FLOATS) for (int k = lane; k < n_f64; k += 64) s[o->model_f + k] = md.fb[k];
+  for (int k = lane; k < n_int; k += 64) ii[o->model_i + k] = md.ib[k];
   __syncthreads();
-  sgrl_model_view_from(hdr, ii + o->model_i, SGRL_STAGE_FLOATS ? s + o->model_f : md.fb, m);   // scalar sizes
+  // the view: sizes from the scalar header, header constants through constant-memory pointers (scalar loads), int
+  // tables from the LDS copy
+#if SGRL_STAGE_FLOATS
+  sgrl_ftab_t ftab = (sgrl_ftab_t)(s + o->model_f);
+#else
+  sgrl_ftab_t ftab = (sgrl_ftab_t)md.fb;
+#endif
+  sgrl_model_view_from((sgrl_hdr_t)md.ib, (sgrl_fhdr_t)md.fb, (sgrl_itab_t)(ii + o->model_i), ftab, m);
   *S = s;
   *I = ii;
 }

@@ -208,7 +208,7 @@ SGRL_DEV void tri_decode(int p, int* a_out, int* b_out) {
   a -= (a * (a + 1) / 2 > p) ? 1 : 0;
   *a_out = a; *b_out = p - a * (a + 1) / 2;
 }
-SGRL_DEV bool dof_in_mask(const int32_t* mask2, int d) {
+SGRL_DEV bool dof_in_mask(sgrl_itab_t mask2, int d) {
   const uint32_t w = (uint32_t)(d < 32 ? mask2[0] : mask2[1]);
   return (w >> (d & 31)) & 1u;
 }
@@ -328,7 +328,7 @@ struct Engine {
         const int b = i;
         double R[9], Wm[9], RI[9];
         for (int k = 0; k < 9; k++) R[k] = S[o.xmat + 9 * b + k];
-        const double* ib = m.body_inertia + 6 * b;
+        sgrl_ftab_t ib = m.body_inertia + 6 * b;
         const double Im[9] = {ib[0], ib[3], ib[4], ib[3], ib[1], ib[5], ib[4], ib[5], ib[2]};
         for (int r = 0; r < 3; r++)
           for (int c = 0; c < 3; c++) RI[3 * r + c] = R[3 * r] * Im[c] + R[3 * r + 1] * Im[3 + c] + R[3 * r + 2] * Im[6 + c];
@@ -743,8 +743,8 @@ struct Engine {
           const double sg = (sub & 1) ? -mu : mu;
           for (int k = 0; k < 3; k++) dir[k] = fr[k] + sg * fr[3 * t + k];
         }
-        const int32_t* mk1 = m.body_dofmask + 2 * b1;
-        const int32_t* mk2 = m.body_dofmask + 2 * b2;
+        sgrl_itab_t mk1 = m.body_dofmask + 2 * b1;
+        sgrl_itab_t mk2 = m.body_dofmask + 2 * b2;
         double vel = 0;
         for (int d = 0; d < nv; d++) {
           double sgn = 0;

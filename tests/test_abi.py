@@ -67,3 +67,19 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "libsgrl_oracle" not in text and "libsgrl_emu" not in text, f
+
+
+def test_blob_size_formula_in_the_header_matches_the_packer():
+    """include/sgrl_model.h sgrl_model_blob_sizes() (used by the kernel prologue) restates the packer's table sizes."""
+    import re
+    from sgrl_amd import mjcf, model_pack
+    from sgrl_amd.env_spec import env_spec_for
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sgrl_model.h")).read()
+    fi = re.search(r"\*n_int = SGRL_NHDR \+ ([^;]+);", text).group(1)
+    ff = re.search(r"\*n_f64 = SGRL_NFHDR \+ ([^;]+);", text).group(1)
+    for n in mjcf.list_assets():
+        m = mjcf.load_asset(n)
+        ib, fb = model_pack.pack_model(m, spec=env_spec_for(n))
+        env = dict(nb=int(ib[1]), nj=int(ib[2]), nq=int(ib[3]), nv=int(ib[4]), nu=int(ib[5]), ng=int(ib[6]), np=int(ib[7]))
+        assert 24 + eval(fi, {}, env) == len(ib), n
+        assert 16 + eval(ff, {}, env) == len(fb), n
