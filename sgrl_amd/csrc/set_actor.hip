@@ -37,6 +37,8 @@ constexpr int ZD = 32;
 // 1024-wide weight rows of the layers that consume it are folded accordingly at pack time (sgrl_amd/set_hip.py).
 constexpr int GTRI = ZD * (ZD + 1) / 2;   // 528
 constexpr int GK = 544;                    // GTRI padded to a multiple of the GEMM K tile
+constexpr int ZLD = 64;                    // row stride of the stacked projection output [Z (30) .. | Z2 (30) ..]
+constexpr int OGLD = 144;                  // row stride of outg: 136 channels padded to the GEMM K tile
 
 // ------------------------------------------------------------------------------------------------
 // f32 MFMA GEMM:  C[M,N] = epi(A[M,K] . W[N,K]^T)      block tile 128x128x32, 4 waves of 64x64
@@ -219,69 +221,64 @@ __global__ __launch_bounds__(128) void k_embed(const float* __restrict__ obs, in
   else if (c < 84) pos = e1[nt.trav[nt.TM + mn] * 42 + (c - 42)];
   else pos = e2[nt.trav[2 * nt.TM + mn] * 44 + (c - 84)];
   cat[(size_t)n * 256 + 128 + c] = v * sc + pos;
-  if (c < 24) { const int s = c / 8, j = c % 8; outg[((size_t)n * 3 + s) * 136 + j] = o[3 * j + s]; }
+  if (c < 24) { const int s = c / 8, j = c % 8; outg[((size_t)n * 3 + s) * OGLD + j] = o[3 * j + s]; }
   if (c < 17) outng[(size_t)n * 160 + c] = o[24 + c];
   if (c >= 17 && c < 32) outng[(size_t)n * 160 + 128 + c] = 0.f;  // cols 145..159
   if (c < 6) { const int s = c / 2, e = c % 2; gdir[((size_t)n * 3 + s) * 2 + e] = o[3 * (1 + e) + s]; }
 }
 
-// proj + gram: 8 nodes per 256-thread block.  Z = [X.Wp^T | gdir] (3x32); gram = Z'Z; fn = ||gram||_F + 1.
-// Optional second projection Wq -> Z2 (kept for the equivariant update).
-constexpr int PG_NODES = 8;
-__global__ __launch_bounds__(256) void k_proj_gram(const float* __restrict__ X, int ldx, int C, const float* __restrict__ Wp,
-                                                   const float* __restrict__ Wq, const float* __restrict__ gdir,
-                                                   float* gram, float* fn, float* Z2, int N) {
-  extern __shared__ float sm[];
-  float* Xs = sm;                         // [8][3][C]
-  float* Wps = Xs + PG_NODES * 3 * C;     // [30][C+1]
-  float* Wqs = Wps + 30 * (C + 1);        // [30][C+1] (only if Wq)
-  float* Zs = Wqs + (Wq ? 30 * (C + 1) : 0);  // [8][3][32]
-  float* red = Zs + PG_NODES * 96;        // [8][4]
-  short* tab = reinterpret_cast<short*>(red + PG_NODES * 4);   // [528] (a << 8 | b)
-  const int t = threadIdx.x, n0 = blockIdx.x * PG_NODES;
-  const int nn = min(PG_NODES, N - n0);
-  for (int i = t; i < PG_NODES * 3 * C; i += 256) {
-    const int row = i / C, c = i % C;
-    Xs[i] = (row < nn * 3) ? X[((size_t)n0 * 3 + row) * ldx + c] : 0.f;
+// The two 30-row projections of a site stacked into one zero-padded GEMM operand out[64][Cpad]:
+// rows 0..29 = Wp, rows 32..61 = Wq (if any), columns C..Cpad-1 = 0.
+__global__ void k_stack_proj(const float* __restrict__ Wp, const float* __restrict__ Wq, int C, int Cpad, float* out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 64 * Cpad; i += gridDim.x * blockDim.x) {
+    const int r = i / Cpad, c = i % Cpad;
+    float v = 0.f;
+    if (c < C) {
+      if (r < 30) v = Wp[r * C + c];
+      else if (Wq && r >= 32 && r < 62) v = Wq[(r - 32) * C + c];
+    }
+    out[i] = v;
   }
-  for (int i = t; i < 30 * C; i += 256) {
-    const int r = i / C, c = i % C;
-    Wps[r * (C + 1) + c] = Wp[i];
-    if (Wq) Wqs[r * (C + 1) + c] = Wq[i];
-  }
-  __syncthreads();
-  for (int i = t; i < PG_NODES * 96; i += 256) {
+}
+
+// gram: 8 nodes per 256-thread block.  Z = [X.Wp^T (from the MFMA GEMM, row stride ZLD) | gdir] (3x32); packed lower
+// triangle of Z'Z -> gram; fn = ||Z'Z||_F + 1.  With Z2 != null the second projection [X.Wq^T | gdir] is written out
+// compactly (kept for the equivariant update).  tri[o] = (a << 8 | b) of packed entry o, 0xFFFF for the K padding.
+constexpr int GR_NODES = 8;
+__global__ __launch_bounds__(256) void k_gram(const float* __restrict__ Zall, const float* __restrict__ gdir,
+                                              const unsigned short* __restrict__ tri, float* gram, float* fn, float* Z2,
+                                              int N) {
+  __shared__ float Zs[GR_NODES * 96];
+  __shared__ float red[GR_NODES * 4];
+  const int t = threadIdx.x, n0 = blockIdx.x * GR_NODES;
+  const int nn = min(GR_NODES, N - n0);
+  for (int i = t; i < GR_NODES * 96; i += 256) {
     const int node = i / 96, s = (i % 96) / 32, a = i % 32;
-    float v = 0.f, v2 = 0.f;
-    if (a < 30) {
-      const float* x = Xs + (node * 3 + s) * C;
-      const float* w = Wps + a * (C + 1);
-      for (int c = 0; c < C; c++) v += x[c] * w[c];
-      if (Wq) { const float* w2 = Wqs + a * (C + 1); for (int c = 0; c < C; c++) v2 += x[c] * w2[c]; }
-    } else if (node < nn) {
-      v = gdir[((size_t)(n0 + node) * 3 + s) * 2 + (a - 30)];
-      v2 = v;
+    float v = 0.f;
+    if (node < nn) {
+      const size_t row = (size_t)(n0 + node) * 3 + s;
+      float v2;
+      if (a < 30) { v = Zall[row * ZLD + a]; v2 = Z2 ? Zall[row * ZLD + 32 + a] : 0.f; }
+      else { v = gdir[row * 2 + (a - 30)]; v2 = v; }
+      if (Z2) Z2[row * ZD + a] = v2;
     }
     Zs[i] = v;
-    if (Wq && node < nn) Z2[((size_t)(n0 + node) * 3 + s) * ZD + a] = v2;
   }
+  unsigned short tb[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { const int o = t + 256 * k; tb[k] = o < GK ? tri[o] : (unsigned short)0xFFFF; }
   __syncthreads();
-  // packed lower triangle of the Gram matrix: output o = a(a+1)/2 + b (b <= a); ||G||_F^2 counts off-diagonals twice
   const int wave = t >> 6;
-  for (int i = t; i < GTRI; i += 256) {
-    int aa = (int)((sqrtf(8.f * i + 1.f) - 1.f) * 0.5f);
-    while ((aa + 1) * (aa + 2) / 2 <= i) aa++;
-    while (aa * (aa + 1) / 2 > i) aa--;
-    tab[i] = (short)((aa << 8) | (i - aa * (aa + 1) / 2));
-  }
-  __syncthreads();
-  for (int node = 0; node < PG_NODES; node++) {
+  for (int node = 0; node < GR_NODES; node++) {
     float sq = 0.f;
     const float* z = Zs + node * 96;
-    for (int o = t; o < GK; o += 256) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int o = t + 256 * k;
+      if (o >= GK) continue;
       float v = 0.f;
-      if (o < GTRI) {
-        const int aa = tab[o] >> 8, bb = tab[o] & 255;
+      if (tb[k] != 0xFFFF) {
+        const int aa = tb[k] >> 8, bb = tb[k] & 255;
         v = z[aa] * z[bb] + z[32 + aa] * z[32 + bb] + z[64 + aa] * z[64 + bb];
         sq += (aa == bb ? 1.f : 2.f) * v * v;
       }
@@ -406,7 +403,7 @@ __global__ __launch_bounds__(128) void k_equiv(const float* __restrict__ Z, cons
 __global__ void k_copy_g(const float* g, float* outg, int rows) {  // outg[row][8 + c] = g[row][c]
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)rows * D) return;
-  outg[(i >> 7) * 136 + 8 + (i & 127)] = g[i];
+  outg[(size_t)(i >> 7) * OGLD + 8 + (i & 127)] = g[i];
 }
 
 // head: vec[s] = ((Zh[s] . mat) . wdec); action_k = max_action * tanh(sum_s axis_k[s] * vec[s]); 32 lanes per node
@@ -449,7 +446,11 @@ struct sgrl_set {
   float* ws = nullptr;
   int64_t ws_floats = 0;
   float *g, *cat, *cat2, *gram, *fn, *h256, *qkv, *vg, *attng, *attg, *g1, *z2, *mat, *t256, *t128a, *t128b, *delta,
-      *outg, *outng, *gdir;
+      *outg, *outng, *gdir, *zall;
+  // stacked projection weights of the 7 proj+gram sites (rebuilt on the forward stream after sgrl_set_weights)
+  float* wstack = nullptr;
+  unsigned short* d_tri = nullptr;
+  bool stack_dirty = true;
   const float* W(int slot) const { return w + off[slot]; }
   const float* WL(int layer, int k) const { return w + off[SGRL_SET_NGLOBAL + layer * SGRL_SET_NLAYER + k]; }
 };
@@ -506,17 +507,31 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
                      s->W(SGRL_SET_ENC_B), s->W(SGRL_SET_EMB0), s->W(SGRL_SET_EMB1), s->W(SGRL_SET_EMB2), s->g, s->cat,
                      s->outg, s->outng, s->gdir);
   float* ng = s->cat + 128;
-  auto pg = [&](const float* X, int ldx, int C, const float* Wp, const float* Wq, float* z2) {
-    const size_t sh = sizeof(float) * (PG_NODES * 3 * C + 30 * (C + 1) * (Wq ? 2 : 1) + PG_NODES * 96 + PG_NODES * 4) + sizeof(short) * GTRI;
-    hipLaunchKernelGGL(k_proj_gram, dim3((N + PG_NODES - 1) / PG_NODES), dim3(256), sh, st, X, ldx, C, Wp, Wq, s->gdir,
-                       s->gram, s->fn, z2, N);
-  };
-  const int lnb = (N + 3) / 4;
   int rc = SGRL_OK;
 #define G(...) do { rc = launch_gemm(st, __VA_ARGS__); if (rc != SGRL_OK) return rc; } while (0)
+  // proj + gram site: Z (and Z2) = X . [Wp; Wq]^T on the matrix cores (stacked, zero-padded weights), then the packed
+  // Gram triangle per node
+  auto site_w = [&](int site) { return s->wstack + (size_t)site * 64 * 128; };   // site 6 (the head, Cpad 144) is last
+  if (s->stack_dirty) {
+    for (int l = 0; l < SGRL_SET_LAYERS; l++) {
+      hipLaunchKernelGGL(k_stack_proj, dim3(32), dim3(256), 0, st, s->WL(l, SGRL_SET_A_GPROJ), (const float*)nullptr, D, D, site_w(2 * l));
+      hipLaunchKernelGGL(k_stack_proj, dim3(32), dim3(256), 0, st, s->WL(l, SGRL_SET_F_GPROJ2), s->WL(l, SGRL_SET_F_GPROJ3), D, D, site_w(2 * l + 1));
+    }
+    hipLaunchKernelGGL(k_stack_proj, dim3(36), dim3(256), 0, st, s->W(SGRL_SET_GGPROJ), s->W(SGRL_SET_GPROJ), 136, OGLD, site_w(6));
+    s->stack_dirty = false;
+  }
+  auto pg = [&](const float* X, int ldx, int K, int site, float* z2) -> int {
+    int r = launch_gemm(st, X, ldx, site_w(site), K, nullptr, s->zall, ZLD, N3, z2 ? 64 : 32, K);
+    if (r != SGRL_OK) return r;
+    hipLaunchKernelGGL(k_gram, dim3((N + GR_NODES - 1) / GR_NODES), dim3(256), 0, st, s->zall, s->gdir, s->d_tri, s->gram,
+                       s->fn, z2, N);
+    return SGRL_OK;
+  };
+#define PG(...) do { rc = pg(__VA_ARGS__); if (rc != SGRL_OK) return rc; } while (0)
+  const int lnb = (N + 3) / 4;
   for (int l = 0; l < SGRL_SET_LAYERS; l++) {
     // --- attention ---
-    pg(s->g, D, D, s->WL(l, SGRL_SET_A_GPROJ), nullptr, nullptr);
+    PG(s->g, D, D, 2 * l, nullptr);
     G(s->gram, GK, s->WL(l, SGRL_SET_A_LG1_W), GK, s->WL(l, SGRL_SET_A_LG1_B), s->h256, 256, N, 256, GK, EPI_RELU);
     G(s->h256, 256, s->WL(l, SGRL_SET_A_LG2_W), 256, s->WL(l, SGRL_SET_A_LG2_B), s->cat, 256, N, 128, 256);
     G(s->cat, 256, s->WL(l, SGRL_SET_QKV_W), 256, s->WL(l, SGRL_SET_QKV_B), s->qkv, 768, N, 768, 256, EPI_ROWDIV, s->fn);
@@ -528,7 +543,7 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
     hipLaunchKernelGGL(k_add_ln, dim3(lnb), dim3(256), 0, st, ng, 256, s->delta, D, s->WL(l, SGRL_SET_N1_W),
                        s->WL(l, SGRL_SET_N1_B), ng, 256, (float*)nullptr, 0, N);
     // --- equivariant feed-forward ---
-    pg(s->g1, D, D, s->WL(l, SGRL_SET_F_GPROJ2), s->WL(l, SGRL_SET_F_GPROJ3), s->z2);
+    PG(s->g1, D, D, 2 * l + 1, s->z2);
     G(s->gram, GK, s->WL(l, SGRL_SET_F_LG1_W), GK, s->WL(l, SGRL_SET_F_LG1_B), s->h256, 256, N, 256, GK, EPI_RELU);
     G(s->h256, 256, s->WL(l, SGRL_SET_F_LG2_W), 256, s->WL(l, SGRL_SET_F_LG2_B), s->cat, 256, N, 128, 256);
     G(s->cat, 256, s->WL(l, SGRL_SET_L3_W), 256, s->WL(l, SGRL_SET_L3_B), s->t256, 256, N, 256, 256, EPI_RELU);
@@ -543,7 +558,7 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   hipLaunchKernelGGL(k_add_ln, dim3(lnb), dim3(256), 0, st, ng, 256, (const float*)nullptr, 0, s->W(SGRL_SET_FNORM_W),
                      s->W(SGRL_SET_FNORM_B), (float*)nullptr, 0, s->outng + 17, 160, N);
   hipLaunchKernelGGL(k_copy_g, dim3((N3 * D + 255) / 256), dim3(256), 0, st, s->g, s->outg, N3);
-  pg(s->outg, 136, 136, s->W(SGRL_SET_GGPROJ), s->W(SGRL_SET_GPROJ), s->z2);
+  PG(s->outg, OGLD, OGLD, 6, s->z2);
   G(s->gram, GK, s->W(SGRL_SET_L1G_W), GK, s->W(SGRL_SET_L1G_B), s->t128a, D, N, D, GK, EPI_RELU);
   G(s->t128a, D, s->W(SGRL_SET_L2G_W), D, s->W(SGRL_SET_L2G_B), s->cat2, 256, N, D, D);
   G(s->outng, 160, s->W(SGRL_SET_L1NG_W), 160, s->W(SGRL_SET_L1NG_B), s->t128b, D, N, D, 160, EPI_RELU);
@@ -553,6 +568,7 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   hipLaunchKernelGGL(k_head_out, dim3((N + 3) / 4), dim3(128), 0, st, s->z2, s->mat, s->W(SGRL_SET_DECG), obs, obs_ld, nt,
                      act, act_ld, max_action, N);
 #undef G
+#undef PG
   if (hipGetLastError() != hipSuccess) return sfail(SGRL_ERR_HIP, "kernel launch failed in sgrl_set_forward");
   return SGRL_OK;
 }
@@ -577,13 +593,28 @@ int sgrl_set_create(sgrl_set** out) {
     *out = nullptr;
     return sfail(SGRL_ERR_HIP, "cannot raise the dynamic LDS limit of the GEMM kernel");
   }
-  *out = new sgrl_set();
+  sgrl_set* s = new sgrl_set();
+  // index table of the packed Gram triangle: entry o = a(a+1)/2 + b  ->  (a << 8 | b); the K padding is marked 0xFFFF
+  std::vector<unsigned short> tri(GK, (unsigned short)0xFFFF);
+  for (int a = 0, o = 0; a < ZD; a++) for (int b = 0; b <= a; b++, o++) tri[o] = (unsigned short)((a << 8) | b);
+  const size_t wstack_floats = 6 * 64 * 128 + 64 * OGLD;
+  if (hipMalloc(&s->wstack, sizeof(float) * wstack_floats) != hipSuccess || hipMalloc(&s->d_tri, sizeof(unsigned short) * GK) != hipSuccess ||
+      hipMemcpy(s->d_tri, tri.data(), sizeof(unsigned short) * GK, hipMemcpyHostToDevice) != hipSuccess) {
+    if (s->wstack) (void)hipFree(s->wstack);
+    if (s->d_tri) (void)hipFree(s->d_tri);
+    delete s;
+    *out = nullptr;
+    return sfail(SGRL_ERR_HIP, "device allocation failed in sgrl_set_create");
+  }
+  *out = s;
   return SGRL_OK;
 }
 
 void sgrl_set_destroy(sgrl_set* s) {
   if (!s) return;
   free_graph(s);
+  if (s->wstack) (void)hipFree(s->wstack);
+  if (s->d_tri) (void)hipFree(s->d_tri);
   delete s;
 }
 
@@ -592,6 +623,7 @@ int sgrl_set_weights(sgrl_set* s, const float* w, const int64_t* offsets, int n_
   s->w = w;
   std::memcpy(s->off, offsets, sizeof(int64_t) * SGRL_SET_NW);
   s->have_w = true;
+  s->stack_dirty = true;   // the stacked projection operands are rebuilt by the next forward, on its stream
   return SGRL_OK;
 }
 
@@ -654,7 +686,7 @@ int sgrl_set_graph(sgrl_set* s, int n_morph, const int32_t* morph_L, const int32
   const int64_t N = node;
   const int64_t per_node = 384 /*g*/ + 256 + 256 /*cat, cat2*/ + 1024 /*gram*/ + 1 /*fn*/ + 256 /*h256*/ + 768 /*qkv*/ +
                            768 /*vg*/ + 256 /*attng*/ + 768 /*attg*/ + 384 /*g1*/ + 96 /*z2*/ + 1024 /*mat*/ + 256 /*t256*/ +
-                           128 + 128 + 128 /*t128a,b,delta*/ + 408 /*outg*/ + 160 /*outng*/ + 6 /*gdir*/;
+                           128 + 128 + 128 /*t128a,b,delta*/ + 3 * OGLD /*outg*/ + 160 /*outng*/ + 6 /*gdir*/ + 3 * ZLD /*zall*/;
   s->ws_floats = per_node * N + 64 * 32;
   if (ok) ok = hipMalloc(&s->ws, sizeof(float) * s->ws_floats) == hipSuccess;
   if (!ok) { free_graph(s); return sfail(SGRL_ERR_HIP, "device allocation failed in sgrl_set_graph"); }
@@ -664,7 +696,7 @@ int sgrl_set_graph(sgrl_set* s, int n_morph, const int32_t* morph_L, const int32
   s->g = take(384 * N); s->cat = take(256 * N); s->cat2 = take(256 * N); s->gram = take(1024 * N); s->fn = take(N);
   s->h256 = take(256 * N); s->qkv = take(768 * N); s->vg = take(768 * N); s->attng = take(256 * N); s->attg = take(768 * N);
   s->g1 = take(384 * N); s->z2 = take(96 * N); s->mat = take(1024 * N); s->t256 = take(256 * N); s->t128a = take(128 * N);
-  s->t128b = take(128 * N); s->delta = take(128 * N); s->outg = take(408 * N); s->outng = take(160 * N); s->gdir = take(6 * N);
+  s->t128b = take(128 * N); s->delta = take(128 * N); s->outg = take(3 * OGLD * N); s->outng = take(160 * N); s->gdir = take(6 * N); s->zall = take(3 * ZLD * N);
   if (p - s->ws > s->ws_floats) { free_graph(s); return sfail(SGRL_ERR_LIMIT, "workspace carve-up overflow"); }
   SHIP_TRY(hipDeviceSynchronize());
   s->have_graph = true;
