@@ -192,8 +192,11 @@ def main():
                              "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                              "algorithmic_bytes_per_launch": int(bytes_step * n_local),
                              "ms_per_launch": round(ms_step, 4),
+                             "dispatches_per_launch": env.launch_groups,
                              "note": "latency/VALU-bound FP64 rigid-body kernel: ~2 KB of HBM traffic per env-step "
-                                     "against ~1e6 FP64 operations; see DESIGN.md (roofline)"}
+                                     "against ~1e6 FP64 operations; see DESIGN.md (roofline).  One launch = one "
+                                     "sgrl_step = dispatches_per_launch concurrent k_env_step dispatches (one per LDS "
+                                     "occupancy class); ms_per_launch is the HIP-event time of the whole launch"}
         nodes = ro.actor.num_nodes
         extra["set_actor"] = {"ms_per_forward": round(ms_set, 4), "us_per_env_step": round(ms_set * 1e3 / n_local, 4),
                               "nodes": nodes, "tflops": round(nodes * 10.07e6 / (ms_set * 1e-3) / 1e12, 2),

@@ -58,6 +58,7 @@ void sgrl_engine_destroy(sgrl_engine* e);
 int sgrl_num_envs(const sgrl_engine* e);
 int sgrl_record_stride(const sgrl_engine* e);   /* doubles per env record: max over morphs of nq+nv+4 */
 int sgrl_lds_bytes(const sgrl_engine* e);       /* dynamic LDS per workgroup used by the step kernel */
+int sgrl_launch_groups(const sgrl_engine* e);   /* concurrent k_env_step dispatches one sgrl_step issues (one per LDS occupancy class) */
 
 /* VecEnv.reset(): every env starts a new episode.  obs: DEV float[n_env*obs_max_len]; obs64: DEV double[...] or NULL. */
 int sgrl_reset(sgrl_engine* e, float* obs, double* obs64, void* stream);

@@ -61,7 +61,7 @@ def lib():
                                      ctypes.POINTER(ctypes.c_void_p)]
     L.sgrl_engine_destroy.argtypes = [ctypes.c_void_p]
     L.sgrl_engine_destroy.restype = None
-    for name in ("sgrl_num_envs", "sgrl_record_stride", "sgrl_lds_bytes"):
+    for name in ("sgrl_num_envs", "sgrl_record_stride", "sgrl_lds_bytes", "sgrl_launch_groups"):
         getattr(L, name).argtypes = [ctypes.c_void_p]
         getattr(L, name).restype = ctypes.c_int
     vp = ctypes.c_void_p
@@ -75,7 +75,7 @@ def lib():
     return L
 
 
-EXPORTS = ["sgrl_engine_create", "sgrl_engine_destroy", "sgrl_num_envs", "sgrl_record_stride", "sgrl_lds_bytes",
+EXPORTS = ["sgrl_engine_create", "sgrl_engine_destroy", "sgrl_num_envs", "sgrl_record_stride", "sgrl_lds_bytes", "sgrl_launch_groups",
            "sgrl_reset", "sgrl_step", "sgrl_get_records", "sgrl_set_records", "sgrl_refresh", "sgrl_time_steps",
            "sgrl_last_error", "sgrl_version"]
 

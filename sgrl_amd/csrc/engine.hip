@@ -359,6 +359,7 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
 int sgrl_num_envs(const sgrl_engine* e) { return e ? e->n_env : SGRL_ERR_ARG; }
 int sgrl_record_stride(const sgrl_engine* e) { return e ? e->stride : SGRL_ERR_ARG; }
 int sgrl_lds_bytes(const sgrl_engine* e) { return e ? e->lds_bytes : SGRL_ERR_ARG; }
+int sgrl_launch_groups(const sgrl_engine* e) { return e ? (int)e->groups.size() : SGRL_ERR_ARG; }
 
 int sgrl_reset(sgrl_engine* e, float* obs, double* obs64, void* stream) {
   if (!e || !obs) return fail(SGRL_ERR_ARG, "sgrl_reset: null engine or obs");

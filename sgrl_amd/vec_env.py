@@ -114,6 +114,7 @@ class BatchedModularVecEnv(VecEnv):
         self._L = L
         self.stride = L.sgrl_record_stride(h)
         self.lds_bytes = L.sgrl_lds_bytes(h)
+        self.launch_groups = L.sgrl_launch_groups(h)
         dev = self.device
         self.obs = torch.zeros((n, self.obs_max_len), dtype=torch.float32, device=dev)
         self.rew = torch.zeros(n, dtype=torch.float32, device=dev)
