@@ -733,8 +733,8 @@ struct Engine {
         const int s = src, p = s >> 1;
         const int b1 = m.geom_body[m.pair_g1[p]], b2 = m.geom_body[m.pair_g2[p]];
         const double margin = m.pair_margin[p], dist = S[o.con_dist + s], mu = m.pair_mu[p];
-        double fr[9], off[3], dir[3];
-        for (int k = 0; k < 9; k++) fr[k] = S[o.con_frame + 9 * s + k];
+        double off[3], dir[3];
+        const double* fr = S + o.con_frame + 9 * s;     // rows: normal, tangent 1, tangent 2
         for (int k = 0; k < 3; k++) off[k] = S[o.con_pos + 3 * s + k] - S[o.misc + MS_COM + k];
         if (kind == ROW_CON1) {
           for (int k = 0; k < 3; k++) dir[k] = fr[k];
@@ -946,6 +946,7 @@ struct Engine {
   }
 
   SGRL_DEV void forward() {
+    w.fence_lane();
     SGRL_TICK(-1);
     kinematics();               SGRL_TICK(0);
     com_pos();                  SGRL_TICK(1);

@@ -47,6 +47,9 @@ struct HipWave {
   }
 #endif
   __device__ __forceinline__ HipWave() : lane(threadIdx.x & 63) {}
+  // Called at the top of every dynamics evaluation: makes the lane id opaque again so that lane-dependent address
+  // arithmetic is not hoisted out of the stage / frame-skip loops (it would stay live across them and spill).
+  __device__ __forceinline__ void fence_lane() { asm volatile("" : "+v"(lane)); }
   template <class F> __device__ __forceinline__ void lanes(int n, F f) {
     for (int i = lane; i < n; i += 64) f(i);
     __syncthreads();

@@ -16,6 +16,7 @@ namespace {
 bool g_reverse = false;
 
 struct EmuWave {
+  void fence_lane() {}
   template <class F> void lanes(int n, F f) {
     if (g_reverse) for (int i = n - 1; i >= 0; i--) f(i);
     else for (int i = 0; i < n; i++) f(i);

@@ -3,10 +3,10 @@
 import csv, collections, glob, json, re, shutil, sys
 import numpy as np
 tag, stats_dir, fetch_dir, write_dir, bench_log = sys.argv[1:6]
-shutil.copy(glob.glob(stats_dir + "/*/*kernel_stats.csv")[0], "profiles/%s_kernel_stats.csv" % tag)
+shutil.copy(glob.glob(stats_dir + "/**/*kernel_stats.csv", recursive=True)[0], "profiles/%s_kernel_stats.csv" % tag)
 means = {}
 for name, d in (("fetch", fetch_dir), ("write", write_dir)):
-    rows = list(csv.DictReader(open(glob.glob(d + "/*/*counter_collection.csv")[0])))
+    rows = list(csv.DictReader(open(glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0])))
     acc = collections.defaultdict(list)
     for r in rows:
         m = re.search(r"(k_[a-z_0-9]+)[<(]", r["Kernel_Name"])
@@ -20,7 +20,7 @@ line = open(bench_log).read().strip().split("\n")[-1]
 open("profiles/%s_bench.json" % tag, "w").write(line + "\n")
 groups = int(json.loads(line)["roofline"].get("dispatches_per_launch", 1))
 # one launch (sgrl_step) = `groups` concurrent k_env_step dispatches: wall span per launch from the kernel trace
-tr = [r for r in csv.DictReader(open(glob.glob(stats_dir + "/*/*kernel_trace.csv")[0])) if "k_env_step" in r["Kernel_Name"]]
+tr = [r for r in csv.DictReader(open(glob.glob(stats_dir + "/**/*kernel_trace.csv", recursive=True)[0])) if "k_env_step" in r["Kernel_Name"]]
 tr.sort(key=lambda r: int(r["Start_Timestamp"]))
 spans, durs = [], []
 for i in range(0, len(tr) - groups + 1, groups):
