@@ -256,6 +256,17 @@ struct Engine {
       quat_normalize(q);
       S[o.qpos + 3] = q[0]; S[o.qpos + 4] = q[1]; S[o.qpos + 5] = q[2]; S[o.qpos + 6] = q[3];
     });
+    // joint rotations first, one lane per hinge (the sincos of a chain would otherwise be evaluated serially, and once
+    // per descendant); parked in the contact-frame array, which is dead until collide() refills it
+    const int jq = o.con_frame;
+    w.lanes(o.nj, [&](int j) {
+      if (m.jnt_type[j] == SGRL_JNT_FREE) return;
+      double ja[3], ql[4];
+      ld3(ja, m.jnt_axis + 3 * j);
+      const int qa = m.jnt_qposadr[j];
+      axisangle2quat(ql, ja, S[o.qpos + qa] - m.qpos0[qa]);
+      for (int k = 0; k < 4; k++) S[jq + 4 * j + k] = ql[k];
+    });
     w.lanes(o.nb, [&](int b) {
       if (b == 0) {
         for (int k = 0; k < 3; k++) S[o.xpos + k] = 0;
@@ -292,8 +303,7 @@ struct Engine {
           for (int k = 0; k < 3; k++) anchor[k] = pos[k] + t[k];
           mat_vec(axis, r, ja);
           if (c == b) for (int k = 0; k < 3; k++) { S[o.xanchor + 3 * j + k] = anchor[k]; S[o.xaxis + 3 * j + k] = axis[k]; }
-          const int qa = m.jnt_qposadr[j];
-          axisangle2quat(ql, ja, S[o.qpos + qa] - m.qpos0[qa]);
+          for (int k = 0; k < 4; k++) ql[k] = S[jq + 4 * j + k];
           quat_mul(qn, quat, ql);
           for (int k = 0; k < 4; k++) quat[k] = qn[k];
           if (!at_origin) {
