@@ -171,6 +171,14 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
       const int n = n0 + wn * 64 + tj * 32 + li;
       if (n >= a.N) continue;
       const float bvv = a.bias ? a.bias[n] : 0.f;
+      float old2[16];
+      if (FLAGS & EPI_ACC2) {   // all sixteen second-destination reads in flight before the first store
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int m = mb + (e & 3) + 8 * (e >> 2);
+          old2[e] = (m < a.M) ? a.C2[(size_t)m * a.ldc2 + n] : 0.f;
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 16; e++) {
         const int m = mb + (e & 3) + 8 * (e >> 2);
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
         if (FLAGS & EPI_RELU) v = fmaxf(v, 0.f);
         if (FLAGS & EPI_ROWDIV) v = v / rdiv[e];
         a.C[(size_t)m * a.ldc + n] = v;
-        if (FLAGS & EPI_ACC2) a.C2[(size_t)m * a.ldc2 + n] += v;
+        if (FLAGS & EPI_ACC2) a.C2[(size_t)m * a.ldc2 + n] = old2[e] + v;
       }
     }
   }
