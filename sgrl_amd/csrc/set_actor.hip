@@ -324,14 +324,23 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   __shared__ float sc[2 * 14 * 14];
   const int e = blockIdx.x, t = threadIdx.x;
   const int n0 = et.env_off[e], L = et.env_L[e];
-  for (int idx = t; idx < 2 * L * L; idx += 256) {
-    const int h = idx / (L * L), i = (idx / L) % L, j = idx % L;
-    const float4* q = reinterpret_cast<const float4*>(qkv + (size_t)(n0 + i) * 768 + h * 128);
-    const float4* k = reinterpret_cast<const float4*>(qkv + (size_t)(n0 + j) * 768 + 256 + h * 128);
-    float s = 0.f;
-    for (int d = 0; d < 32; d++) { const float4 a = q[d], b = k[d]; s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
-    if (use_bias) s += relb[et.env_relb[e] + idx];
-    sc[idx] = s;
+  // scores: eight lanes per (head, i, j) dot product -- each group reads its q / k rows as four coalesced 128-byte
+  // segments, partial sums folded with three xor shuffles (all 256 threads busy instead of 2 L^2 <= 98)
+  {
+    const int sub = t & 7;
+    for (int idx = t >> 3; idx < 2 * L * L; idx += 32) {
+      const int h = idx / (L * L), i = (idx / L) % L, j = idx % L;
+      const float4* q = reinterpret_cast<const float4*>(qkv + (size_t)(n0 + i) * 768 + h * 128);
+      const float4* k = reinterpret_cast<const float4*>(qkv + (size_t)(n0 + j) * 768 + 256 + h * 128);
+      float s = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const float4 a = q[sub + 8 * u], b = k[sub + 8 * u];
+        s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+      }
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+      if (sub == 0) sc[idx] = use_bias ? s + relb[et.env_relb[e] + idx] : s;
+    }
   }
   __syncthreads();
   if (t < 2 * L) {
