@@ -108,3 +108,52 @@ def test_reference_style_warmup_and_policy_loops():
         obs_list = new_obs_list
     assert actor._hip is not None   # select_action ran on the HIP path
     envs_train.close()
+
+
+def test_batched_evaluator_on_the_engine_matches_a_per_env_replay_of_the_reference_loop():
+    """sgrl_amd.evaluate.BatchedEvaluator over Rollout (device tensors, thousands of envs at once) vs the reference's
+    per-env bookkeeping (trainer.py:80-146) replayed in plain Python on the recorded reward / done streams."""
+    import torch
+    from sgrl_amd.evaluate import BatchedEvaluator
+    from sgrl_amd.rollout import Rollout
+    from sgrl_amd.set_policy import make_policy
+    names = sorted(["3d_hopper_3_shin", "3d_hopper_4_lower_shin", "3d_hopper_5_full"])
+    torch.manual_seed(0)
+    ro = Rollout(names, 8, policy=make_policy(device="cuda:0").eval(), seed=3, device="cuda:0", max_episode_steps=60)
+
+    class Rec(object):
+        def __init__(self): self.trajs = []
+        def reset(self):
+            self.trajs.append([])
+            return ro.reset()
+        def step(self, a):
+            obs, rew, done, dist = ro.step(a)
+            self.trajs[-1].append((rew.double().cpu().numpy().copy(), done.cpu().numpy().astype(bool).copy()))
+            return obs, rew, done, dist
+
+    rec = Rec()
+    out = BatchedEvaluator(rec, ro.policy_forward, num_eval_trajectories=2, max_trajectory_length=80, max_episode_steps=60).evaluate()
+    n = ro.env.num_envs
+    rets, lens = [], []
+    for traj in rec.trajs:
+        done_list, ep_rew, ep_t, buf = [False] * n, [0.0] * n, [0] * n, [0.0] * n
+        for rew, cur in traj:
+            cur = list(cur)
+            for i in range(n):
+                buf[i] += rew[i]
+                if ep_t[i] + 1 == 60:
+                    cur[i] = True
+                if cur[i] and ep_rew[i] == 0:
+                    ep_rew[i] = buf[i]
+                    buf[i] = 0
+                if not done_list[i]:
+                    ep_t[i] += 1
+                    done_list[i] = done_list[i] or cur[i]
+            if all(done_list):
+                lens.extend(ep_t)
+                rets.extend(ep_rew)
+                break
+    assert len(lens) == 2 * n                      # the 60-step time limit guarantees completion within 80 steps
+    assert out["performance/eval_length"] == pytest.approx(np.mean(lens), rel=1e-12)
+    assert out["performance/eval_return"] == pytest.approx(np.mean(rets), rel=1e-9)
+    assert np.isfinite(out["performance/eval_return"])
