@@ -462,12 +462,15 @@ struct sgrl_set {
   // workspace
   float* ws = nullptr;
   int64_t ws_floats = 0;
-  float *g, *cat, *cat2, *gram, *fn, *h256, *qkv, *vg, *attng, *attg, *g1, *z2, *mat, *t256, *t128a, *t128b, *delta,
+  float *g, *cat, *cat2, *gram, *fn, *h256, *qkv, *vg, *attng, *attg, *g1, *z2, *mat, *t256, *t256b, *t128a, *t128b, *delta,
       *outg, *outng, *gdir, *zall;
   // stacked projection weights of the 7 proj+gram sites (rebuilt on the forward stream after sgrl_set_weights)
   float* wstack = nullptr;
   unsigned short* d_tri = nullptr;
   bool stack_dirty = true;
+  // side stream for the GEMM chains that do not depend on each other (their epilogues / tile tails overlap)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   const float* W(int slot) const { return w + off[slot]; }
   const float* WL(int layer, int k) const { return w + off[SGRL_SET_NGLOBAL + layer * SGRL_SET_NLAYER + k]; }
 };
@@ -546,44 +549,59 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   };
 #define PG(...) do { rc = pg(__VA_ARGS__); if (rc != SGRL_OK) return rc; } while (0)
   const int lnb = (N + 3) / 4;
+  // Independent GEMM chains go to the side stream: fork() makes it wait for everything issued so far on `st`, join()
+  // makes `st` wait for it.  The chains' store-heavy epilogues and partial last tile waves overlap each other.
+  hipStream_t sd = s->side;
+  auto fork = [&]() { (void)hipEventRecord(s->ev_fork, st); (void)hipStreamWaitEvent(sd, s->ev_fork, 0); };
+  auto join = [&]() { (void)hipEventRecord(s->ev_join, sd); (void)hipStreamWaitEvent(st, s->ev_join, 0); };
+#define GS(...) do { rc = launch_gemm(sd, __VA_ARGS__); if (rc != SGRL_OK) return rc; } while (0)
   for (int l = 0; l < SGRL_SET_LAYERS; l++) {
     // --- attention ---
+    fork();
+    GS(s->g, D, s->WL(l, SGRL_SET_VG_W), D, nullptr, s->vg, 256, N3, 256, D);
     PG(s->g, D, D, 2 * l, nullptr);
     G(s->gram, GK, s->WL(l, SGRL_SET_A_LG1_W), GK, s->WL(l, SGRL_SET_A_LG1_B), s->h256, 256, N, 256, GK, EPI_RELU);
     G(s->h256, 256, s->WL(l, SGRL_SET_A_LG2_W), 256, s->WL(l, SGRL_SET_A_LG2_B), s->cat, 256, N, 128, 256);
     G(s->cat, 256, s->WL(l, SGRL_SET_QKV_W), 256, s->WL(l, SGRL_SET_QKV_B), s->qkv, 768, N, 768, 256, EPI_ROWDIV, s->fn);
-    G(s->g, D, s->WL(l, SGRL_SET_VG_W), D, nullptr, s->vg, 256, N3, 256, D);
+    join();
     hipLaunchKernelGGL(k_attention, dim3(s->n_env), dim3(256), 0, st, s->qkv, s->vg, s->gdir, s->d_relb, et, l == 0 ? 1 : 0,
                        s->attng, s->attg);
+    fork();
+    GS(s->attng, 256, s->WL(l, SGRL_SET_NGOUT_W), 256, s->WL(l, SGRL_SET_NGOUT_B), s->delta, D, N, D, 256);
     G(s->attg, 256, s->WL(l, SGRL_SET_GOUT_W), 256, nullptr, s->g1, D, N3, D, 256, EPI_ACC2, nullptr, s->g, D);
-    G(s->attng, 256, s->WL(l, SGRL_SET_NGOUT_W), 256, s->WL(l, SGRL_SET_NGOUT_B), s->delta, D, N, D, 256);
+    join();
     hipLaunchKernelGGL(k_add_ln, dim3(lnb), dim3(256), 0, st, ng, 256, s->delta, D, s->WL(l, SGRL_SET_N1_W),
                        s->WL(l, SGRL_SET_N1_B), ng, 256, (float*)nullptr, 0, N);
     // --- equivariant feed-forward ---
     PG(s->g1, D, D, 2 * l + 1, s->z2);
     G(s->gram, GK, s->WL(l, SGRL_SET_F_LG1_W), GK, s->WL(l, SGRL_SET_F_LG1_B), s->h256, 256, N, 256, GK, EPI_RELU);
     G(s->h256, 256, s->WL(l, SGRL_SET_F_LG2_W), 256, s->WL(l, SGRL_SET_F_LG2_B), s->cat, 256, N, 128, 256);
+    fork();
+    GS(s->cat, 256, s->WL(l, SGRL_SET_L1_W), 256, s->WL(l, SGRL_SET_L1_B), s->t256b, 256, N, 256, 256, EPI_RELU);
+    GS(s->t256b, 256, s->WL(l, SGRL_SET_L2_W), 256, s->WL(l, SGRL_SET_L2_B), s->delta, D, N, D, 256, EPI_ROWDIV, s->fn);
     G(s->cat, 256, s->WL(l, SGRL_SET_L3_W), 256, s->WL(l, SGRL_SET_L3_B), s->t256, 256, N, 256, 256, EPI_RELU);
     G(s->t256, 256, s->WL(l, SGRL_SET_L4_W), 256, s->WL(l, SGRL_SET_L4_B), s->mat, 1024, N, 1024, 256, EPI_ROWDIV, s->fn);
     hipLaunchKernelGGL(k_equiv, dim3((N + 3) / 4), dim3(128), 0, st, s->z2, s->mat, s->WL(l, SGRL_SET_L5_W), s->g, N);
-    G(s->cat, 256, s->WL(l, SGRL_SET_L1_W), 256, s->WL(l, SGRL_SET_L1_B), s->t256, 256, N, 256, 256, EPI_RELU);
-    G(s->t256, 256, s->WL(l, SGRL_SET_L2_W), 256, s->WL(l, SGRL_SET_L2_B), s->delta, D, N, D, 256, EPI_ROWDIV, s->fn);
+    join();
     hipLaunchKernelGGL(k_add_ln, dim3(lnb), dim3(256), 0, st, ng, 256, s->delta, D, s->WL(l, SGRL_SET_N2_W),
                        s->WL(l, SGRL_SET_N2_B), ng, 256, (float*)nullptr, 0, N);
   }
   // final norm -> outng[:, 17:145]; head
   hipLaunchKernelGGL(k_add_ln, dim3(lnb), dim3(256), 0, st, ng, 256, (const float*)nullptr, 0, s->W(SGRL_SET_FNORM_W),
                      s->W(SGRL_SET_FNORM_B), (float*)nullptr, 0, s->outng + 17, 160, N);
+  fork();
+  GS(s->outng, 160, s->W(SGRL_SET_L1NG_W), 160, s->W(SGRL_SET_L1NG_B), s->t128b, D, N, D, 160, EPI_RELU);
+  GS(s->t128b, D, s->W(SGRL_SET_L2NG_W), D, s->W(SGRL_SET_L2NG_B), s->cat2 + 128, 256, N, D, D);
   hipLaunchKernelGGL(k_copy_g, dim3((N3 * D + 255) / 256), dim3(256), 0, st, s->g, s->outg, N3);
   PG(s->outg, OGLD, OGLD, 6, s->z2);
   G(s->gram, GK, s->W(SGRL_SET_L1G_W), GK, s->W(SGRL_SET_L1G_B), s->t128a, D, N, D, GK, EPI_RELU);
   G(s->t128a, D, s->W(SGRL_SET_L2G_W), D, s->W(SGRL_SET_L2G_B), s->cat2, 256, N, D, D);
-  G(s->outng, 160, s->W(SGRL_SET_L1NG_W), 160, s->W(SGRL_SET_L1NG_B), s->t128b, D, N, D, 160, EPI_RELU);
-  G(s->t128b, D, s->W(SGRL_SET_L2NG_W), D, s->W(SGRL_SET_L2NG_B), s->cat2 + 128, 256, N, D, D);
+  join();
   G(s->cat2, 256, s->W(SGRL_SET_L1M_W), 256, s->W(SGRL_SET_L1M_B), s->t256, 256, N, 256, 256, EPI_RELU);
   G(s->t256, 256, s->W(SGRL_SET_L2M_W), 256, s->W(SGRL_SET_L2M_B), s->mat, 1024, N, 1024, 256, EPI_ROWDIV, s->fn);
   hipLaunchKernelGGL(k_head_out, dim3((N + 3) / 4), dim3(128), 0, st, s->z2, s->mat, s->W(SGRL_SET_DECG), obs, obs_ld, nt,
                      act, act_ld, max_action, N);
+#undef GS
 #undef G
 #undef PG
   if (hipGetLastError() != hipSuccess) return sfail(SGRL_ERR_HIP, "kernel launch failed in sgrl_set_forward");
@@ -615,6 +633,13 @@ int sgrl_set_create(sgrl_set** out) {
   std::vector<unsigned short> tri(GK, (unsigned short)0xFFFF);
   for (int a = 0, o = 0; a < ZD; a++) for (int b = 0; b <= a; b++, o++) tri[o] = (unsigned short)((a << 8) | b);
   const size_t wstack_floats = 6 * 64 * 128 + 64 * OGLD;
+  if (hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) {
+    delete s;
+    *out = nullptr;
+    return sfail(SGRL_ERR_HIP, "cannot create the side stream of the SET actor");
+  }
   if (hipMalloc(&s->wstack, sizeof(float) * wstack_floats) != hipSuccess || hipMalloc(&s->d_tri, sizeof(unsigned short) * GK) != hipSuccess ||
       hipMemcpy(s->d_tri, tri.data(), sizeof(unsigned short) * GK, hipMemcpyHostToDevice) != hipSuccess) {
     if (s->wstack) (void)hipFree(s->wstack);
@@ -632,6 +657,9 @@ void sgrl_set_destroy(sgrl_set* s) {
   free_graph(s);
   if (s->wstack) (void)hipFree(s->wstack);
   if (s->d_tri) (void)hipFree(s->d_tri);
+  if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); }
+  if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+  if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   delete s;
 }
 
@@ -702,7 +730,7 @@ int sgrl_set_graph(sgrl_set* s, int n_morph, const int32_t* morph_L, const int32
   // workspace carve-up (floats per node)
   const int64_t N = node;
   const int64_t per_node = 384 /*g*/ + 256 + 256 /*cat, cat2*/ + 1024 /*gram*/ + 1 /*fn*/ + 256 /*h256*/ + 768 /*qkv*/ +
-                           768 /*vg*/ + 256 /*attng*/ + 768 /*attg*/ + 384 /*g1*/ + 96 /*z2*/ + 1024 /*mat*/ + 256 /*t256*/ +
+                           768 /*vg*/ + 256 /*attng*/ + 768 /*attg*/ + 384 /*g1*/ + 96 /*z2*/ + 1024 /*mat*/ + 256 + 256 /*t256, t256b*/ +
                            128 + 128 + 128 /*t128a,b,delta*/ + 3 * OGLD /*outg*/ + 160 /*outng*/ + 6 /*gdir*/ + 3 * ZLD /*zall*/;
   s->ws_floats = per_node * N + 64 * 32;
   if (ok) ok = hipMalloc(&s->ws, sizeof(float) * s->ws_floats) == hipSuccess;
@@ -712,7 +740,7 @@ int sgrl_set_graph(sgrl_set* s, int n_morph, const int32_t* morph_L, const int32
   auto take = [&](int64_t n) { float* r = p; p += (n + 31) & ~int64_t(31); return r; };
   s->g = take(384 * N); s->cat = take(256 * N); s->cat2 = take(256 * N); s->gram = take(1024 * N); s->fn = take(N);
   s->h256 = take(256 * N); s->qkv = take(768 * N); s->vg = take(768 * N); s->attng = take(256 * N); s->attg = take(768 * N);
-  s->g1 = take(384 * N); s->z2 = take(96 * N); s->mat = take(1024 * N); s->t256 = take(256 * N); s->t128a = take(128 * N);
+  s->g1 = take(384 * N); s->z2 = take(96 * N); s->mat = take(1024 * N); s->t256 = take(256 * N); s->t256b = take(256 * N); s->t128a = take(128 * N);
   s->t128b = take(128 * N); s->delta = take(128 * N); s->outg = take(3 * OGLD * N); s->outng = take(160 * N); s->gdir = take(6 * N); s->zall = take(3 * ZLD * N);
   if (p - s->ws > s->ws_floats) { free_graph(s); return sfail(SGRL_ERR_LIMIT, "workspace carve-up overflow"); }
   SHIP_TRY(hipDeviceSynchronize());
