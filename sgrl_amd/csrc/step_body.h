@@ -239,14 +239,33 @@ SGRL_DEV double rng_uniform01(uint64_t seed, uint32_t env_id, uint32_t episode, 
 template <class W>
 struct Engine {
   W& w;
-  const SgrlModelView& m;
+  SgrlModelView m;             // own copy: the int-table pointers are re-fenced every evaluation (fence_view)
   const Layout& o;
   double* S;
   int32_t* I;
   double* big_scratch = nullptr;   // optional per-env HBM slab: 2 * 64*65/2 doubles
+  bool linv = false;               // this evaluation's S[o.L] holds L^-1 (explicit inverse of the factor), not L
 
   SGRL_DEV Engine(W& w_, const SgrlModelView& m_, const Layout& o_, double* S_, int32_t* I_)
       : w(w_), m(m_), o(o_), S(S_), I(I_) {}
+
+  // The int tables live in LDS: an access needs their (uniform) base in a VGPR.  Left alone, the compiler materialises
+  // all ~26 bases as VGPRs once and keeps them live across the whole step (then spills them); making the bases opaque
+  // at the top of every evaluation confines those copies to where they are used.
+  SGRL_DEV void fence_view() {
+    m.body_parent = w.fenced(m.body_parent); m.body_jntadr = w.fenced(m.body_jntadr);
+    m.body_jntnum = w.fenced(m.body_jntnum); m.body_dofadr = w.fenced(m.body_dofadr);
+    m.body_dofnum = w.fenced(m.body_dofnum); m.body_limbtype = w.fenced(m.body_limbtype);
+    m.jnt_type = w.fenced(m.jnt_type); m.jnt_body = w.fenced(m.jnt_body);
+    m.jnt_qposadr = w.fenced(m.jnt_qposadr); m.jnt_dofadr = w.fenced(m.jnt_dofadr);
+    m.jnt_limited = w.fenced(m.jnt_limited); m.dof_body = w.fenced(m.dof_body); m.dof_jnt = w.fenced(m.dof_jnt);
+    m.dof_parent = w.fenced(m.dof_parent); m.geom_type = w.fenced(m.geom_type);
+    m.geom_body = w.fenced(m.geom_body); m.pair_g1 = w.fenced(m.pair_g1); m.pair_g2 = w.fenced(m.pair_g2);
+    m.pair_condim = w.fenced(m.pair_condim); m.act_dof = w.fenced(m.act_dof); m.act_slot = w.fenced(m.act_slot);
+    m.body_depth = w.fenced(m.body_depth); m.body_path = w.fenced(m.body_path);
+    m.body_subend = w.fenced(m.body_subend); m.body_dofmask = w.fenced(m.body_dofmask);
+    m.dof_act = w.fenced(m.dof_act);
+  }
 
   // ---- position stage -------------------------------------------------------------------------
   SGRL_DEV void kinematics() {
@@ -411,7 +430,10 @@ struct Engine {
       w.lanes(nv, [&](int i) { for (int k = 0; k <= i; k++) S[o.Mfull + tri(i) + k] = S[o.L + tri(i) + k]; });
     }
     SGRL_TICK(2);
-    cholesky<true>(o.L);
+    // small systems: Cholesky and the explicit inverse of the factor in one register sweep (wave policy); the
+    // triangular solves below then become recurrence-free dot products.  Otherwise factor in place.
+    linv = w.chol_inv_packed(nv, S + o.L, kMinVal);
+    if (!linv) cholesky<true>(o.L);
     SGRL_TICK(8);
   }
 
@@ -798,7 +820,28 @@ struct Engine {
     });
     SGRL_TICK(6);
     // half-solve Y <- L^-1 Y for all right-hand sides (rows + the smooth force), one lane per right-hand side
-    w.trsm_lower_rows(nrow + 1, nv, S + o.L, S + o.dinv, S + o.Y, ldy);
+    if (linv) {
+      // Y_r = L^-1 J_r as a triangular matrix product: one lane per right-hand side, entries from the last to the first
+      // so that the row is overwritten in place (Y_r[d] needs J_r[0..d] only)
+      if (!w.trmm_rows(nrow + 1, nv, S + o.L, S + o.Y, ldy))      // register version where the policy has one
+      w.lanes(nrow + 1, [&](int r) {
+        double* Yr = S + o.Y + r * ldy;
+        for (int d = nv - 1; d >= 0; d--) {
+          const double* Ld = S + o.L + tri(d);
+          double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+          int c = 0;
+          for (; c + 4 <= d + 1; c += 4) {
+            const double a0 = Ld[c], a1 = Ld[c + 1], a2 = Ld[c + 2], a3 = Ld[c + 3];
+            const double b0 = Yr[c], b1 = Yr[c + 1], b2 = Yr[c + 2], b3 = Yr[c + 3];
+            s0 += a0 * b0; s1 += a1 * b1; s2 += a2 * b2; s3 += a3 * b3;
+          }
+          for (; c <= d; c++) s0 += Ld[c] * Yr[c];
+          Yr[d] = (s0 + s1) + (s2 + s3);
+        }
+      });
+    } else {
+      w.trsm_lower_rows(nrow + 1, nv, S + o.L, S + o.dinv, S + o.Y, ldy);
+    }
     w.lanes(nv, [&](int d) { S[o.ys + d] = S[o.Y + nrow * ldy + d]; });
     SGRL_TICK(9);
     w.lanes(nrow > nv ? nrow : nv, [&](int r) {
@@ -951,12 +994,25 @@ struct Engine {
       if (r == 0) { I[o.icnt + IC_PREV_N] = nrow; I[o.icnt + IC_SWEEPS] += sweeps; I[o.icnt + IC_ROWSUM] += diag_code; }
     });
     // qacc = L^-T (ys + Y' f)
-    w.lanes(nv, [&](int d) { S[o.qacc + d] = S[o.ys + d] + (nrow > 0 ? S[o.vpgs + d] : 0.0); });
-    solve_upper_inplace(o.L, o.qacc);
+    if (linv) {
+      // qacc = L^-T w as a matrix-vector product with the explicit inverse (w parked in vpgs: no in-place hazard)
+      w.lanes(nv, [&](int d) { S[o.vpgs + d] = S[o.ys + d] + (nrow > 0 ? S[o.vpgs + d] : 0.0); });
+      w.lanes(nv, [&](int k) {
+        double s0 = 0, s1 = 0;
+        int i = k;
+        for (; i + 1 < nv; i += 2) { s0 += S[o.L + tri(i) + k] * S[o.vpgs + i]; s1 += S[o.L + tri(i + 1) + k] * S[o.vpgs + i + 1]; }
+        if (i < nv) s0 += S[o.L + tri(i) + k] * S[o.vpgs + i];
+        S[o.qacc + k] = s0 + s1;
+      });
+    } else {
+      w.lanes(nv, [&](int d) { S[o.qacc + d] = S[o.ys + d] + (nrow > 0 ? S[o.vpgs + d] : 0.0); });
+      solve_upper_inplace(o.L, o.qacc);
+    }
   }
 
   SGRL_DEV void forward() {
     w.fence_lane();
+    fence_view();
     SGRL_TICK(-1);
     kinematics();               SGRL_TICK(0);
     com_pos();                  SGRL_TICK(1);

@@ -50,6 +50,12 @@ struct HipWave {
   // Called at the top of every dynamics evaluation: makes the lane id opaque again so that lane-dependent address
   // arithmetic is not hoisted out of the stage / frame-skip loops (it would stay live across them and spill).
   __device__ __forceinline__ void fence_lane() { asm volatile("" : "+v"(lane)); }
+  // same for a wave-uniform value held in scalar registers (e.g. the LDS base of a table)
+  template <class T> __device__ __forceinline__ T fenced(T v) {   // 32-bit values on the device (LDS pointers, ints)
+    int t = __builtin_amdgcn_readfirstlane((int)(unsigned)(__UINTPTR_TYPE__)v);
+    asm volatile("" : "+s"(t));
+    return (T)(__UINTPTR_TYPE__)(unsigned)t;
+  }
   template <class F> __device__ __forceinline__ void lanes(int n, F f) {
     for (int i = lane; i < n; i += 64) f(i);
     __syncthreads();
@@ -139,6 +145,110 @@ struct HipWave {
     }
     __syncthreads();
   }
+  // Cholesky AND explicit inverse of the factor in one register-resident sweep: lane i owns row i of M (-> L) and row
+  // i of the identity (-> L^-1).  At pivot j the finished row j of L^-1 is broadcast entry by entry and every later
+  // lane folds it in with the same multiplier l_ij it uses for the trailing update -- the inverse costs no extra
+  // dependent steps, only issue slots.  On return P holds L^-1 (packed lower triangle INCLUDING its diagonal): the
+  // triangular solves of the caller become plain dot products with no recurrence.
+  template <int NMAX>
+  __device__ __forceinline__ void chol_inv_reg(int n, double* P, double minval) {
+    const bool act = lane < n;
+    const int li = act ? lane : 0;
+    double* rowp = P + li * (li + 1) / 2;
+    // ONE register array for both matrices: row entry k of M lives in a[k + 1] until pivot k has consumed it, entry c of
+    // the inverse row is born in a[c] at pivot c -- the slot the M entry c - 1 has just vacated.  NMAX + 1 doubles.
+    double a[NMAX + 1];
+#pragma unroll
+    for (int k = 0; k < NMAX; k++) a[k + 1] = rowp[k < li ? k : li];      // k > i re-reads the diagonal: unused filler
+    double mydj = 0.0;
+#pragma unroll
+    for (int j = 0; j < NMAX; j++) {
+      if (j < n) {
+        const double c = a[j + 1];
+        double pj = read_lane(c, j);
+        pj = pj < minval ? minval : pj;
+        const double dj = rsqrt(pj);
+        const double l = c * dj;
+        mydj = lane == j ? dj : mydj;
+        const double lm = lane > j ? l * dj : 0.0;       // multiplier for the (unscaled) row j of the inverse
+        a[j] = lane == j ? 1.0 : 0.0;                    // column j of the identity enters now
+#pragma unroll
+        for (int c2 = 0; c2 <= j; c2++) a[c2] -= lm * read_lane(a[c2], j);
+#pragma unroll
+        for (int k = j + 1; k < NMAX; k++) a[k + 1] -= l * read_lane(l, k);
+      }
+    }
+    if (act) {
+#pragma unroll
+      for (int k = NMAX - 1; k >= 0; k--) rowp[k < li ? k : li] = a[k] * mydj;   // k > i lands on the diagonal slot first, k = i fixes it
+    }
+    __syncthreads();
+  }
+  __device__ __forceinline__ bool chol_inv_packed(int n_in, double* P, double minval) {
+    const int n = __builtin_amdgcn_readfirstlane(n_in);
+    if (n <= 12) chol_inv_reg<12>(n, P, minval);
+    else if (n <= 18) chol_inv_reg<18>(n, P, minval);
+    else if (n <= 24) chol_inv_reg<24>(n, P, minval);
+    else return false;
+    return true;
+  }
+  // Y_r <- T Y_r for the rows r < nrhs, T = packed lower-triangular matrix (the explicit L^-1).  Two lanes share one
+  // right-hand side: lane h of the pair keeps the entries c = h (mod 2) of the row in registers and accumulates its half
+  // of every output; the halves meet over one DPP exchange.  Every entry of T is an LDS read shared by all pairs, all
+  // outputs accumulate independently (no recurrence: pure issue throughput), 32 right-hand sides per pass.
+  template <int NMAX>
+  __device__ __forceinline__ void trmm_rows_reg(int nrhs, int n, const double* T, double* Y, int ldy) {
+    constexpr int NH = (NMAX + 1) / 2;
+    const int h = lane & 1;
+    for (int r0 = 0; r0 < nrhs; r0 += 32) {
+      const int r = r0 + (lane >> 1);
+      const bool act = r < nrhs;
+      double* y = Y + (act ? r : nrhs - 1) * ldy;
+      double jr[NH];
+#pragma unroll
+      for (int u = 0; u < NH; u++) {
+        const int c = 2 * u + h;
+        const double v = y[c < n ? c : n - 1];
+        jr[u] = c < n ? v : 0.0;
+      }
+      // two outputs (d, d - 1) per straight-line block: four independent accumulation chains; blocks whose rows lie
+      // beyond n are skipped by a uniform branch
+#pragma unroll
+      for (int d = (NMAX - 1) | 1; d >= 1; d -= 2) {
+        if (d - 1 < n) {
+          const double* Td = T + d * (d + 1) / 2 + h;        // this lane's columns of row d: c = 2u + h
+          const double* Te = T + (d - 1) * d / 2 + h;
+          double s0 = 0.0, s1 = 0.0, e0 = 0.0, e1 = 0.0;
+#pragma unroll
+          for (int u = 0; u < NH; u++) {
+            // row d (odd) has columns 0..d: both lanes own u <= (d - 1) / 2.  Row d - 1 (even) ends at column d - 1:
+            // its last pair u = (d - 1) / 2 exists for h = 0 only.
+            if (2 * u + 1 <= d) {
+              const double td = Td[2 * u], te = Te[2 * u];
+              const double tem = (2 * u + 1 <= d - 1) ? te : (h == 0 ? te : 0.0);
+              if (u & 1) { s1 += td * jr[u]; e1 += tem * jr[u]; } else { s0 += td * jr[u]; e0 += tem * jr[u]; }
+            }
+          }
+          double sd = s0 + s1, se = e0 + e1;
+          sd += dpp_move<0xB1>(sd);                          // quad_perm [1,0,3,2]: the partner lane's half
+          se += dpp_move<0xB1>(se);
+          if (act) { if (h == 0) y[d - 1] = se; else if (d < n) y[d] = sd; }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  __device__ __forceinline__ bool trmm_rows(int nrhs_in, int n_in, const double* T, double* Y, int ldy) {
+#ifdef SGRL_NO_TRMM
+    return false;
+#endif
+    const int n = __builtin_amdgcn_readfirstlane(n_in), nrhs = __builtin_amdgcn_readfirstlane(nrhs_in);
+    if (n <= 12) trmm_rows_reg<12>(nrhs, n, T, Y, ldy);
+    else if (n <= 18) trmm_rows_reg<18>(nrhs, n, T, Y, ldy);
+    else if (n <= 24) trmm_rows_reg<24>(nrhs, n, T, Y, ldy);
+    else return false;
+    return true;
+  }
   // true when the register factorisation covers n (the caller falls back to its LDS version otherwise)
   __device__ __forceinline__ bool chol_packed(int n_in, double* P, double* dinv, double minval) {
     const int n = __builtin_amdgcn_readfirstlane(n_in);
@@ -185,29 +295,46 @@ struct HipWave {
     if (lane < n) xs[lane] = x;
     __syncthreads();
   }
-  // Y_r <- L^-1 Y_r for the rows r < nrhs (row stride ldy): lane = right-hand side, its row never leaves the lane, the
-  // L entries are LDS broadcasts; left-looking so that each entry is written once
-  __device__ __forceinline__ void trsm_lower_rows(int nrhs_in, int n_in, const double* P, const double* dinv, double* Y,
-                                                  int ldy) {
-    const int n = __builtin_amdgcn_readfirstlane(n_in), nrhs = __builtin_amdgcn_readfirstlane(nrhs_in);
-    for (int r0 = 0; r0 < nrhs; r0 += 64) {
-      const bool act = r0 + lane < nrhs;
-      double* y = Y + (act ? r0 + lane : nrhs - 1) * ldy;
+  // Y_r <- L^-1 Y_r for the rows r < nrhs (row stride ldy), left-looking so that each entry is written once.  SPLIT
+  // lanes share one right-hand side: lane q of the group takes the terms j = q (mod SPLIT) of every dot product and the
+  // partial sums are folded on the DPP network, so 64 / SPLIT right-hand sides advance per pass.  The newest entry
+  // y_{i-1} is taken from a register (every lane of the group has it) instead of waiting for its LDS round trip.
+  template <int SPLIT>
+  __device__ __forceinline__ void trsm_rows_split(int nrhs, int n, const double* P, const double* dinv, double* Y, int ldy) {
+    constexpr int PER = 64 / SPLIT;
+    const int q = lane & (SPLIT - 1);
+    for (int r0 = 0; r0 < nrhs; r0 += PER) {
+      const int r = r0 + lane / SPLIT;
+      const bool act = r < nrhs;
+      double* y = Y + (act ? r : nrhs - 1) * ldy;
+      double yprev = 0.0;
       for (int i = 0; i < n; i++) {
         const double* Li = P + i * (i + 1) / 2;
-        double s0 = y[i], s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        int j = 0;
-        for (; j + 4 <= i; j += 4) {
-          const double a0 = Li[j], a1 = Li[j + 1], a2 = Li[j + 2], a3 = Li[j + 3];
-          const double b0 = y[j], b1 = y[j + 1], b2 = y[j + 2], b3 = y[j + 3];
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int j = q;
+        for (; j + 3 * SPLIT < i - 1; j += 4 * SPLIT) {
+          const double a0 = Li[j], a1 = Li[j + SPLIT], a2 = Li[j + 2 * SPLIT], a3 = Li[j + 3 * SPLIT];
+          const double b0 = y[j], b1 = y[j + SPLIT], b2 = y[j + 2 * SPLIT], b3 = y[j + 3 * SPLIT];
           s0 -= a0 * b0; s1 -= a1 * b1; s2 -= a2 * b2; s3 -= a3 * b3;
         }
-        for (; j < i; j++) s0 -= Li[j] * y[j];
-        const double yi = ((s0 + s1) + (s2 + s3)) * dinv[i];
-        if (act) y[i] = yi;
+        for (; j < i - 1; j += SPLIT) s0 -= Li[j] * y[j];
+        double sum = (s0 + s1) + (s2 + s3);
+        if (SPLIT >= 2) sum += dpp_move<0xB1>(sum);      // quad_perm [1,0,3,2]
+        if (SPLIT >= 4) sum += dpp_move<0x4E>(sum);      // quad_perm [2,3,0,1]
+        double t = y[i] + sum;
+        if (i > 0) t -= Li[i - 1] * yprev;
+        yprev = t * dinv[i];
+        if (act && q == 0) y[i] = yprev;
       }
     }
     __syncthreads();
+  }
+  __device__ __forceinline__ void trsm_lower_rows(int nrhs_in, int n_in, const double* P, const double* dinv, double* Y,
+                                                  int ldy) {
+    const int n = __builtin_amdgcn_readfirstlane(n_in), nrhs = __builtin_amdgcn_readfirstlane(nrhs_in);
+    if (nrhs <= 16) trsm_rows_split<4>(nrhs, n, P, dinv, Y, ldy);
+    else if (nrhs <= 32) trsm_rows_split<2>(nrhs, n, P, dinv, Y, ldy);
+    else trsm_rows_split<1>(nrhs, n, P, dinv, Y, ldy);
   }
   template <class F> __device__ __forceinline__ uint64_t ballot(int n, F f) {
     const bool p = (lane < n) ? (bool)f(lane) : false;

@@ -14,9 +14,11 @@
 
 namespace {
 bool g_reverse = false;
+bool g_linv = true;   // exercise the explicit-inverse path (what HipWave takes for nv <= 24); 0 = always the L path
 
 struct EmuWave {
   void fence_lane() {}
+  template <class T> T fenced(T v) { return v; }
   template <class F> void lanes(int n, F f) {
     if (g_reverse) for (int i = n - 1; i >= 0; i--) f(i);
     else for (int i = 0; i < n; i++) f(i);
@@ -52,7 +54,35 @@ struct EmuWave {
     return iters;
   }
   // triangular solves on a packed lower triangle (reference semantics of the HipWave register versions)
-  bool chol_packed(int, double*, double*, double) { return false; }   // the emulator always takes the generic path
+  bool chol_packed(int, double*, double*, double) { return false; }
+  bool trmm_rows(int, int, const double*, double*, int) { return false; }   // the emulator takes the generic lanes() form
+  // reference semantics of HipWave::chol_inv_packed: P <- L^-1 (packed, with diagonal)
+  bool chol_inv_packed(int n, double* P, double minval) {
+    if (!g_linv || n > 24) return false;
+    std::vector<double> dinv(n);
+    chol_ref(n, P, dinv.data(), minval);
+    std::vector<double> X((size_t)n * n, 0.0);
+    for (int c = 0; c < n; c++) {
+      for (int i = c; i < n; i++) {
+        double s = (i == c) ? 1.0 : 0.0;
+        for (int j = c; j < i; j++) s -= P[i * (i + 1) / 2 + j] * X[(size_t)j * n + c];
+        X[(size_t)i * n + c] = s * dinv[i];
+      }
+    }
+    for (int i = 0; i < n; i++) for (int c = 0; c <= i; c++) P[i * (i + 1) / 2 + c] = X[(size_t)i * n + c];
+    return true;
+  }
+  static void chol_ref(int n, double* P, double* dinv, double minval) {
+    for (int j = 0; j < n; j++) {
+      double pj = P[j * (j + 1) / 2 + j];
+      if (pj < minval) pj = minval;
+      const double dj = 1.0 / std::sqrt(pj);
+      dinv[j] = dj;
+      for (int i = j + 1; i < n; i++) P[i * (i + 1) / 2 + j] *= dj;
+      for (int i = j + 1; i < n; i++)
+        for (int k = j + 1; k <= i; k++) P[i * (i + 1) / 2 + k] -= P[i * (i + 1) / 2 + j] * P[k * (k + 1) / 2 + j];
+    }
+  }   // the emulator always takes the generic path
   void trsv_lower(int n, const double* P, const double* dinv, double* x) {
     for (int i = 0; i < n; i++) {
       double s = x[i];
@@ -78,6 +108,7 @@ struct EmuWave {
 extern "C" {
 
 void sgrl_emu_set_reverse(int r) { g_reverse = r != 0; }
+void sgrl_emu_set_linv(int v) { g_linv = v != 0; }
 
 int sgrl_emu_layout_doubles(const int32_t* ib) { sgrl::Layout o; sgrl::make_layout(ib, &o); return o.s_total; }
 int sgrl_emu_layout_bytes(const int32_t* ib) { sgrl::Layout o; sgrl::make_layout(ib, &o); return sgrl::layout_bytes(&o); }

@@ -91,3 +91,8 @@ def forward(ib, fb, qpos, qvel, ctrl):
 
 def set_reverse(flag):
     lib().sgrl_emu_set_reverse(int(bool(flag)))
+
+
+def set_linv(flag):
+    """True (default): small systems take the explicit-inverse path, as HipWave does; False: always the L path."""
+    lib().sgrl_emu_set_linv(int(bool(flag)))

@@ -86,3 +86,30 @@ def test_rng_matches_oracle_bit_for_bit():
         # normal draws go through libm log/cos in both builds here
         np.testing.assert_allclose(e1.qvel, e2.qvel, rtol=0, atol=1e-15)
         np.testing.assert_allclose(e1.qpos, e2.qpos, rtol=0, atol=1e-15)
+
+
+@pytest.mark.parametrize("name", ["3d_walker_7_full", "3d_hopper_4_lower_shin"])
+def test_explicit_inverse_path_and_factor_path_agree(name):
+    """nv <= 24: the engine source has two formulations of the mass-matrix solves (explicit L^-1 products, which the
+    HIP wave policy selects, and in-place L substitutions).  Both must follow the oracle, and each other to rounding."""
+    m, ib, fb = packed(name)
+    _, om = oracle_model(name)
+    outs = []
+    for linv in (True, False):
+        emu_ref.set_linv(linv)
+        try:
+            e1 = physics_ref.OracleEnv(om, seed=11, env_id=2)
+            e2 = emu_ref.EmuEnv(ib, fb, seed=11, env_id=2)
+            e1.reset(); e2.reset()
+            rng = np.random.RandomState(4)
+            tr = []
+            for t in range(60):
+                a = rng.uniform(-1, 1, size=3 * om.L).astype(np.float32)
+                o1, r1, d1, _ = e1.step(a.astype(np.float64))
+                o2, r2, d2, _ = e2.step(a)
+                assert d1 == d2 and np.abs(o1 - o2).max() < 1e-9
+                tr.append(o2.copy())
+            outs.append(np.array(tr))
+        finally:
+            emu_ref.set_linv(True)
+    assert np.abs(outs[0] - outs[1]).max() < 1e-9
