@@ -271,7 +271,8 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
     SgrlModelView v;
     if (!ib[k] || !fb[k] || ib_len[k] < SGRL_NHDR || sgrl_model_view(ib[k], fb[k], &v) != 0) { rc = fail(SGRL_ERR_MODEL, "bad magic in model blob " + std::to_string(k)); break; }
     if (v.n_int != ib_len[k] || v.n_f64 != fb_len[k]) { rc = fail(SGRL_ERR_MODEL, "model blob " + std::to_string(k) + " has unexpected length"); break; }
-    if (4 * v.njnt > 18 * v.npair) { rc = fail(SGRL_ERR_LIMIT, "model " + std::to_string(k) + ": joint rotations do not fit the contact-frame scratch (4 njnt > 18 npair)"); break; }
+    if (7 * v.njnt > 26 * v.npair) { rc = fail(SGRL_ERR_LIMIT, "model " + std::to_string(k) + ": joint rotations / axes do not fit the contact scratch (7 njnt > 26 npair)"); break; }
+    if (3 * v.njnt > 10 * v.nbody) { rc = fail(SGRL_ERR_LIMIT, "model " + std::to_string(k) + ": joint positions do not fit the inertia scratch (3 njnt > 10 nbody)"); break; }
     if (v.nv > 64 || v.nbody > 64 || v.npair > 64) { rc = fail(SGRL_ERR_LIMIT, "morphology exceeds 64 dofs/bodies/pairs"); break; }
     const int L = v.nbody - 1;
     if (41 * L > obs_max_len || 3 * L > action_max_len) { rc = fail(SGRL_ERR_ARG, "obs_max_len/action_max_len too small for morphology " + std::to_string(k)); break; }

@@ -275,16 +275,23 @@ struct Engine {
       quat_normalize(q);
       S[o.qpos + 3] = q[0]; S[o.qpos + 4] = q[1]; S[o.qpos + 5] = q[2]; S[o.qpos + 6] = q[3];
     });
-    // joint rotations first, one lane per hinge (the sincos of a chain would otherwise be evaluated serially, and once
-    // per descendant); parked in the contact-frame array, which is dead until collide() refills it
-    const int jq = o.con_frame;
-    w.lanes(o.nj, [&](int j) {
-      if (m.jnt_type[j] == SGRL_JNT_FREE) return;
+    // First, in parallel: one lane per hinge evaluates its rotation (the sincos of a chain would otherwise run serially,
+    // once per descendant), and the model constants the chain walk needs are copied from the float tables (L2) into
+    // LDS.  Parked in arrays that are dead until later phases refill them: 7 doubles per joint (rotation quaternion,
+    // axis) in the contact block, 7 per body (pos, quat) in the composite-inertia array.
+    const int jq = o.con_pos, bq = o.crb, jpq = o.cinert;     // jpq: 3 doubles per joint (position in the body frame)
+    w.lanes(o.nj > o.nb ? o.nj : o.nb, [&](int j) {
+      if (j < o.nb && j >= 1) {
+        for (int k = 0; k < 3; k++) S[bq + 10 * j + k] = m.body_pos[3 * j + k];
+        for (int k = 0; k < 4; k++) S[bq + 10 * j + 3 + k] = m.body_quat[4 * j + k];
+      }
+      if (j >= o.nj || m.jnt_type[j] == SGRL_JNT_FREE) return;
       double ja[3], ql[4];
       ld3(ja, m.jnt_axis + 3 * j);
       const int qa = m.jnt_qposadr[j];
       axisangle2quat(ql, ja, S[o.qpos + qa] - m.qpos0[qa]);
-      for (int k = 0; k < 4; k++) S[jq + 4 * j + k] = ql[k];
+      for (int k = 0; k < 4; k++) S[jq + 7 * j + k] = ql[k];
+      for (int k = 0; k < 3; k++) { S[jq + 7 * j + 4 + k] = ja[k]; S[jpq + 3 * j + k] = m.jnt_pos[3 * j + k]; }
     });
     w.lanes(o.nb, [&](int b) {
       if (b == 0) {
@@ -305,24 +312,24 @@ struct Engine {
       quat2mat(mat, quat);
       for (int lvl = 1; lvl < depth; lvl++) {
         const int c = m.body_path[8 * b + lvl];
-        double t[3], bp[3], bq[4], qn[4];
-        ld3(bp, m.body_pos + 3 * c);
+        double t[3], bp[3], bqv[4], qn[4];
+        ld3(bp, S + bq + 10 * c);
         mat_vec(t, mat, bp);
         for (int k = 0; k < 3; k++) pos[k] += t[k];
-        for (int k = 0; k < 4; k++) bq[k] = m.body_quat[4 * c + k];
-        quat_mul(qn, quat, bq);
+        for (int k = 0; k < 4; k++) bqv[k] = S[bq + 10 * c + 3 + k];
+        quat_mul(qn, quat, bqv);
         for (int k = 0; k < 4; k++) quat[k] = qn[k];
         const int j0 = m.body_jntadr[c], jn = m.body_jntnum[c];
         for (int j = j0; j < j0 + jn; j++) {
           double r[9], jp[3], ja[3], anchor[3], axis[3], ql[4], v[3];
           quat2mat(r, quat);
-          ld3(jp, m.jnt_pos + 3 * j); ld3(ja, m.jnt_axis + 3 * j);
+          ld3(jp, S + jpq + 3 * j); ld3(ja, S + jq + 7 * j + 4);
           const bool at_origin = (jp[0] == 0.0 && jp[1] == 0.0 && jp[2] == 0.0);   // global-coordinate MJCFs
           if (at_origin) { t[0] = 0; t[1] = 0; t[2] = 0; } else mat_vec(t, r, jp);
           for (int k = 0; k < 3; k++) anchor[k] = pos[k] + t[k];
           mat_vec(axis, r, ja);
           if (c == b) for (int k = 0; k < 3; k++) { S[o.xanchor + 3 * j + k] = anchor[k]; S[o.xaxis + 3 * j + k] = axis[k]; }
-          for (int k = 0; k < 4; k++) ql[k] = S[jq + 4 * j + k];
+          for (int k = 0; k < 4; k++) ql[k] = S[jq + 7 * j + k];
           quat_mul(qn, quat, ql);
           for (int k = 0; k < 4; k++) quat[k] = qn[k];
           if (!at_origin) {
