@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; e++) {
         const int m = mb + (e & 3) + 8 * (e >> 2);
-        rdiv[e] = (m < a.M) ? a.rowdiv[m] : 1.f;
+        rdiv[e] = 1.0f / ((m < a.M) ? a.rowdiv[m] : 1.f);     // one reciprocal per row, applied by multiplication below
       }
     }
 #pragma unroll
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
         if (m >= a.M) continue;
         float v = acc[ti][tj][e] + bvv;
         if (FLAGS & EPI_RELU) v = fmaxf(v, 0.f);
-        if (FLAGS & EPI_ROWDIV) v = v / rdiv[e];
+        if (FLAGS & EPI_ROWDIV) v = v * rdiv[e];
         a.C[(size_t)m * a.ldc + n] = v;
         if (FLAGS & EPI_ACC2) a.C2[(size_t)m * a.ldc2 + n] = old2[e] + v;
       }
