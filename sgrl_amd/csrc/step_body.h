@@ -440,15 +440,13 @@ struct Engine {
     // small systems: Cholesky and the explicit inverse of the factor in one register sweep (wave policy); the
     // triangular solves below then become recurrence-free dot products.  Otherwise factor in place.
     linv = w.chol_inv_packed(nv, S + o.L, kMinVal);
-    if (!linv) cholesky<true>(o.L);
+    if (!linv) cholesky(o.L);
     SGRL_TICK(8);
   }
 
   // in-place lower Cholesky of the matrix at S[base] (packed lower triangle); diag reciprocals -> dinv
-  template <bool REG = false>
   SGRL_DEV void cholesky(int base) {
     const int nv = o.nv;
-    if (REG && w.chol_packed(nv, S + base, S + o.dinv, kMinVal)) return;   // register version where the policy has one
     // right-looking root-free elimination: after pivot j every trailing entry (i, k), j < k <= i, takes ONE fused
     // update  M_ik -= M_ij M_kj / M_jj  -- constant depth per pivot (one barrier), all lanes busy on the triangle
     for (int j = 0; j < nv - 1; j++) {

@@ -113,38 +113,6 @@ struct HipWave {
   // The serial recurrences run on registers: lane = matrix row (or right-hand side), pivots / solution entries are
   // broadcast with v_readlane, so the dependent chain per step is a few ALU ops instead of an LDS round trip.
   //
-  // In-place Cholesky of a packed lower triangle held in registers: lane i owns row i (NMAX entries, static indexing
-  // after full unrolling), the pivot column l = P(:, j) / sqrt(p_jj) is broadcast entry by entry with v_readlane.  No
-  // LDS traffic and no predication between the initial load and the final store: entries above the diagonal are
-  // computed but never used.  On return P(i, j) = L_ij for j < i, dinv[j] = 1 / L_jj, the diagonal slots are scratch.
-  template <int NMAX>
-  __device__ __forceinline__ void chol_reg(int n, double* P, double* dinv, double minval) {
-    const bool act = lane < n;
-    const int li = act ? lane : 0;
-    double* rowp = P + li * (li + 1) / 2;
-    double row[NMAX];
-#pragma unroll
-    for (int k = 0; k < NMAX; k++) row[k] = rowp[k < li ? k : li];      // k > i re-reads the diagonal: unused filler
-#pragma unroll
-    for (int j = 0; j < NMAX; j++) {
-      if (j < n) {
-        const double c = row[j];
-        double pj = read_lane(c, j);
-        pj = pj < minval ? minval : pj;
-        const double dj = rsqrt(pj);
-        const double l = c * dj;
-        row[j] = l;
-        if (lane == j) dinv[j] = dj;
-#pragma unroll
-        for (int k = j + 1; k < NMAX; k++) row[k] -= l * read_lane(l, k);
-      }
-    }
-    if (act) {
-#pragma unroll
-      for (int k = 0; k < NMAX - 1; k++) rowp[k < li ? k : li] = row[k];   // k >= i lands on the (unused) diagonal slot
-    }
-    __syncthreads();
-  }
   // Cholesky AND explicit inverse of the factor in one register-resident sweep: lane i owns row i of M (-> L) and row
   // i of the identity (-> L^-1).  At pivot j the finished row j of L^-1 is broadcast entry by entry and every later
   // lane folds it in with the same multiplier l_ij it uses for the trailing update -- the inverse costs no extra
@@ -184,6 +152,7 @@ struct HipWave {
     }
     __syncthreads();
   }
+  // true when a register version covers n (the caller falls back to its LDS factorisation otherwise)
   __device__ __forceinline__ bool chol_inv_packed(int n_in, double* P, double minval) {
     const int n = __builtin_amdgcn_readfirstlane(n_in);
     if (n <= 12) chol_inv_reg<12>(n, P, minval);
@@ -246,15 +215,6 @@ struct HipWave {
     if (n <= 12) trmm_rows_reg<12>(nrhs, n, T, Y, ldy);
     else if (n <= 18) trmm_rows_reg<18>(nrhs, n, T, Y, ldy);
     else if (n <= 24) trmm_rows_reg<24>(nrhs, n, T, Y, ldy);
-    else return false;
-    return true;
-  }
-  // true when the register factorisation covers n (the caller falls back to its LDS version otherwise)
-  __device__ __forceinline__ bool chol_packed(int n_in, double* P, double* dinv, double minval) {
-    const int n = __builtin_amdgcn_readfirstlane(n_in);
-    if (n <= 12) chol_reg<12>(n, P, dinv, minval);
-    else if (n <= 18) chol_reg<18>(n, P, dinv, minval);
-    else if (n <= 24) chol_reg<24>(n, P, dinv, minval);
     else return false;
     return true;
   }

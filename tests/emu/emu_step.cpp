@@ -54,7 +54,6 @@ struct EmuWave {
     return iters;
   }
   // triangular solves on a packed lower triangle (reference semantics of the HipWave register versions)
-  bool chol_packed(int, double*, double*, double) { return false; }
   bool trmm_rows(int, int, const double*, double*, int) { return false; }   // the emulator takes the generic lanes() form
   // reference semantics of HipWave::chol_inv_packed: P <- L^-1 (packed, with diagonal)
   bool chol_inv_packed(int n, double* P, double minval) {

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(64) void k_probe(int n, int nrhs, int reps, const d
     if (w.lane < n) x[w.lane] = 0.01 * w.lane;
     __syncthreads();
     long long t0 = __builtin_readcyclecounter();
-    if (!w.chol_packed(n, P, dinv, 1e-15)) { if (w.lane == 0) out[3] = 1; }
+    (void)dinv;   // (the in-place register Cholesky this slot used to time was superseded by chol_inv_packed)
     long long t1 = __builtin_readcyclecounter();
     w.trsm_lower_rows(nrhs, n, P, dinv, Y, ldy);
     long long t2 = __builtin_readcyclecounter();
