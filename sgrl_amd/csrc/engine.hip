@@ -313,7 +313,10 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
     std::vector<int> cost(n_morph), cls(n_morph);
     for (int k = 0; k < n_morph; k++) {
       cost[k] = ib[k][SGRL_H_NV];
-      int per_cu = (160 * 1024) / e->morph_lds[k];
+      // LDS is handed out in 1280-byte granules (measured with tools/occupancy_probe.py: a 27 064-byte slab fits five
+      // times into the 160 KB of a CU, not six)
+      const int granule = 1280;
+      int per_cu = (160 * 1024) / (((e->morph_lds[k] + granule - 1) / granule) * granule);
       cls[k] = per_cu > 8 ? 8 : per_cu;   // register budget (<= 256 VGPRs): two waves per SIMD = 8 workgroups per CU at most
     }
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
@@ -332,9 +335,19 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
     }
     if (e->groups.size() > 1) {
       bool sok = hipEventCreateWithFlags(&e->fork, hipEventDisableTiming) == hipSuccess;
-      for (auto& g : e->groups)
-        sok = sok && hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking) == hipSuccess &&
+      // Stream priorities: the groups are ordered costliest first (largest slabs, longest-running workgroups).  With
+      // equal priorities the many small workgroups of the light groups fragment the LDS and the heavy group trickles in
+      // and finishes last with the chip half empty; with the heavy group preferred its workgroups all start at once
+      // and the light ones fill the gaps.
+      int prio_least = 0, prio_greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);   // numerically lower = higher priority
+      int gi = 0;
+      for (auto& g : e->groups) {
+        int prio = prio_greatest + gi++;
+        if (prio > prio_least) prio = prio_least;
+        sok = sok && hipStreamCreateWithPriority(&g.stream, hipStreamNonBlocking, prio) == hipSuccess &&
               hipEventCreateWithFlags(&g.done, hipEventDisableTiming) == hipSuccess;
+      }
       if (!sok) { sgrl_engine_destroy(e); return fail(SGRL_ERR_HIP, "cannot create launch-group streams"); }
     }
   }

@@ -51,9 +51,9 @@ struct Layout {
   int xpos, xquat, xmat, xipos, xanchor, xaxis;
   int cinert, crb, cdof, cfrc;
   int dead, dead_len, na_max;
-  int L, dinv, qfs, ys, qacc, vpgs;
+  int L, dinv, qfs, qacc, vpgs;
   int con_pos, con_frame, con_dist;
-  int Y, eR, earef, eb, ef, ediag, eidg, prev_f;
+  int Y, eR, earef, eb, ef, eidg, prev_f;
   int misc;  // 16 scalars
   int Mfull; // Euler only: copy of M (lower triangle incl. diag)
   int model_f; // LDS copy of the float model blob (n_f64 doubles)
@@ -90,10 +90,10 @@ SGRL_HD void make_layout(const int32_t* hdr, Layout* o, int n_int = 0, int n_f64
     o->na_max = na;
   }
   o->L = p; p += nv * (nv + 1) / 2; o->dinv = p; p += nv;
-  o->qfs = p; p += nv; o->ys = p; p += nv; o->qacc = p; p += nv; o->vpgs = p; p += nv;
+  o->qfs = p; p += nv; o->qacc = p; p += nv; o->vpgs = p; p += nv;
   o->Y = p; p += (o->maxrows + 1) * o->ldy;
   o->eR = p; p += o->maxrows; o->earef = p; p += o->maxrows; o->eb = p; p += o->maxrows;
-  o->ef = p; p += o->maxrows; o->ediag = p; p += o->maxrows;
+  o->ef = p; p += o->maxrows;
   o->eidg = p; p += o->maxrows; o->prev_f = p; p += o->maxrows;
   o->misc = p; p += 16;
   o->Mfull = p;
@@ -847,7 +847,6 @@ struct Engine {
     } else {
       w.trsm_lower_rows(nrow + 1, nv, S + o.L, S + o.dinv, S + o.Y, ldy);
     }
-    w.lanes(nv, [&](int d) { S[o.ys + d] = S[o.Y + nrow * ldy + d]; });
     SGRL_TICK(9);
     w.lanes(nrow > nv ? nrow : nv, [&](int r) {
       if (r < nrow) {
@@ -855,10 +854,10 @@ struct Engine {
         double s2 = 0;
         for (int d = 0; d < nv; d++) s2 += Yr[d] * Yr[d];
         const double Rr = S[o.eR + r];
-        S[o.ediag + r] = s2 + Rr;
         S[o.eidg + r] = 1.0 / (s2 + Rr);
         double s = 0;
-        for (int d = 0; d < nv; d++) s += Yr[d] * S[o.ys + d];
+        const double* ys = S + o.Y + nrow * ldy;      // the half-solved smooth force: the extra right-hand side
+        for (int d = 0; d < nv; d++) s += Yr[d] * ys[d];
         S[o.eb + r] = s - S[o.earef + r];
       }
       if (r < nv) S[o.vpgs + r] = 0;
@@ -872,12 +871,14 @@ struct Engine {
   // scratch C (packed lower triangle), and the complement test uses  (A x)_G = Y_G (Y_F' x).  The free set is
   // warm-started from the previous evaluation.  On success S[vpgs] = Y' f.  The result is the same unique optimum
   // projected Gauss-Seidel converges to; PGS remains the fallback.
+  template <bool SMALL>
   SGRL_DEV bool lcp_block_pivot(int n, double thresh, double* C, int* iters_out) {
     const int wv = o.earef, xw = o.prev_f;
     const int nv = o.nv, ldy = o.ldy;
     uint64_t F = w.ballot(n, [&](int i) { return S[o.ef + i] > 0.0; });
     int patience = 3, best = n + 1;
     for (int iter = 0; iter < kBppMaxIter; iter++) {
+      w.fence_lane();            // nothing lane-dependent is carried across pivoting rounds (registers)
       const int nf = popcount64(F);
       w.lanes(n, [&](int i) {
         if ((F >> i) & 1ull) {
@@ -904,33 +905,48 @@ struct Engine {
         if (i == j) a += S[o.eR + fi];
         C[p] = a;
       });
-      // root-free right-looking Cholesky of A_FF: one fused update per trailing entry per pivot;  w[k] = 1 / C[k][k]
-      for (int j = 0; j < nf - 1; j++) {
-        double pj = C[j * (j + 1) / 2 + j];
-        if (pj < kMinVal) pj = kMinVal;
-        const double wj = 1.0 / pj;
-        const int sdim = nf - j - 1;
-        w.lanes(sdim * (sdim + 1) / 2, [&](int p) {
-          int a, b;
-          tri_decode(p, &a, &b);
-          const int i = j + 1 + a, k = j + 1 + b;
-          C[i * (i + 1) / 2 + k] -= C[i * (i + 1) / 2 + j] * C[k * (k + 1) / 2 + j] * wj;
+      // factor A_FF and solve.  Small free sets in LDS: Cholesky + explicit inverse of the factor on registers (wave
+      // policy), then x = T'(T rhs) as two recurrence-free products; otherwise the lane-parallel root-free elimination
+      if (SMALL && w.chol_inv_packed(nf, C, kMinVal)) {
+        w.lanes(nf, [&](int i) {
+          double z = 0;
+          for (int c = 0; c <= i; c++) z += C[i * (i + 1) / 2 + c] * S[xw + c];
+          S[wv + i] = z;
         });
-      }
-      w.lanes(nf, [&](int j) {
-        double pj = C[j * (j + 1) / 2 + j];
-        if (pj < kMinVal) pj = kMinVal;
-        S[wv + j] = 1.0 / pj;
-      });
-      // forward substitution (column sweeps), diagonal scaling, backward substitution
-      for (int j = 0; j < nf; j++) {
-        const double zj = S[xw + j] * S[wv + j];
-        w.lanes_from(j + 1, nf, [&](int i) { S[xw + i] -= C[i * (i + 1) / 2 + j] * zj; });
-      }
-      w.lanes(nf, [&](int i) { S[xw + i] *= S[wv + i]; });
-      for (int j = nf - 1; j > 0; j--) {
-        const double xj = S[xw + j];
-        w.lanes(j, [&](int k) { S[xw + k] -= C[j * (j + 1) / 2 + k] * S[wv + k] * xj; });
+        w.lanes(nf, [&](int k) {
+          double x = 0;
+          for (int i = k; i < nf; i++) x += C[i * (i + 1) / 2 + k] * S[wv + i];
+          S[xw + k] = x;
+        });
+      } else {
+        // root-free right-looking Cholesky of A_FF: one fused update per trailing entry per pivot;  w[k] = 1 / C[k][k]
+        for (int j = 0; j < nf - 1; j++) {
+          double pj = C[j * (j + 1) / 2 + j];
+          if (pj < kMinVal) pj = kMinVal;
+          const double wj = 1.0 / pj;
+          const int sdim = nf - j - 1;
+          w.lanes(sdim * (sdim + 1) / 2, [&](int p) {
+            int a, b;
+            tri_decode(p, &a, &b);
+            const int i = j + 1 + a, k = j + 1 + b;
+            C[i * (i + 1) / 2 + k] -= C[i * (i + 1) / 2 + j] * C[k * (k + 1) / 2 + j] * wj;
+          });
+        }
+        w.lanes(nf, [&](int j) {
+          double pj = C[j * (j + 1) / 2 + j];
+          if (pj < kMinVal) pj = kMinVal;
+          S[wv + j] = 1.0 / pj;
+        });
+        // forward substitution (column sweeps), diagonal scaling, backward substitution
+        for (int j = 0; j < nf; j++) {
+          const double zj = S[xw + j] * S[wv + j];
+          w.lanes_from(j + 1, nf, [&](int i) { S[xw + i] -= C[i * (i + 1) / 2 + j] * zj; });
+        }
+        w.lanes(nf, [&](int i) { S[xw + i] *= S[wv + i]; });
+        for (int j = nf - 1; j > 0; j--) {
+          const double xj = S[xw + j];
+          w.lanes(j, [&](int k) { S[xw + k] -= C[j * (j + 1) / 2 + k] * S[wv + k] * xj; });
+        }
       }
       // u = Y_F' x  (= Y' f for the candidate f);  violations: x_i < 0 on F, (Y_i u + b_i) < -thresh on the complement
       w.lanes(nv, [&](int d) {
@@ -973,19 +989,19 @@ struct Engine {
       bool solved = false;
       if (m.hdr[SGRL_H_SOLVER] == 1) {
         if (nrow <= o.na_max) {
-          solved = lcp_block_pivot(nrow, thresh, S + o.dead, &sweeps);         // factor scratch in LDS
+          solved = lcp_block_pivot<true>(nrow, thresh, S + o.dead, &sweeps);         // factor scratch in LDS
           if (!solved) diag_code |= 1 << 8;                                     // diagnostics: block pivoting gave up
         } else if (big_scratch != nullptr && nrow <= 64) {
           // rare (a few envs per 8192-env launch): more rows than the LDS scratch holds -> same exact solve with the
           // factor in this environment's HBM scratch slab instead of hundreds of Gauss-Seidel sweeps
-          solved = lcp_block_pivot(nrow, thresh, big_scratch, &sweeps);
+          solved = lcp_block_pivot<false>(nrow, thresh, big_scratch, &sweeps);
           diag_code |= (1 << 16) | (solved ? 0 : 1 << 8);
         }
       }
       if (!solved) {
         // matrix-free projected Gauss-Seidel, the policy keeps v = Y'f one entry per lane (also the SOLVER = 0 path)
         diag_code |= 1;
-        sweeps = w.pgs(nrow, nv, S + o.Y, ldy, S + o.eb, S + o.eR, S + o.ediag, S + o.eidg, S + o.ef, S + o.vpgs,
+        sweeps = w.pgs(nrow, nv, S + o.Y, ldy, S + o.eb, S + o.eR, S + o.eidg, S + o.ef, S + o.vpgs,
                        m.hdr[SGRL_H_PGS_ITERS], thresh);
       }
     }
@@ -1001,7 +1017,7 @@ struct Engine {
     // qacc = L^-T (ys + Y' f)
     if (linv) {
       // qacc = L^-T w as a matrix-vector product with the explicit inverse (w parked in vpgs: no in-place hazard)
-      w.lanes(nv, [&](int d) { S[o.vpgs + d] = S[o.ys + d] + (nrow > 0 ? S[o.vpgs + d] : 0.0); });
+      w.lanes(nv, [&](int d) { S[o.vpgs + d] = S[o.Y + nrow * ldy + d] + (nrow > 0 ? S[o.vpgs + d] : 0.0); });
       w.lanes(nv, [&](int k) {
         double s0 = 0, s1 = 0;
         int i = k;
@@ -1010,7 +1026,7 @@ struct Engine {
         S[o.qacc + k] = s0 + s1;
       });
     } else {
-      w.lanes(nv, [&](int d) { S[o.qacc + d] = S[o.ys + d] + (nrow > 0 ? S[o.vpgs + d] : 0.0); });
+      w.lanes(nv, [&](int d) { S[o.qacc + d] = S[o.Y + nrow * ldy + d] + (nrow > 0 ? S[o.vpgs + d] : 0.0); });
       solve_upper_inplace(o.L, o.qacc);
     }
   }

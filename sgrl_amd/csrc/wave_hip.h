@@ -73,13 +73,14 @@ struct HipWave {
   //   lane d keeps v[d] = (Y'f)[d]; lane r keeps (b, R, diag, 1/diag, f) of row r, broadcast with v_readlane;
   //   the row residual is one DPP wave reduction; Y rows stream from LDS one row ahead of their use.
   __device__ __forceinline__ int pgs(int n_in, int nv_in, const double* Y, int ldy, const double* b, const double* R,
-                                      const double* dg, const double* idg, double* f, double* v, int iters_in,
+                                      const double* idg, double* f, double* v, int iters_in,
                                       double thresh) {
     const int n = __builtin_amdgcn_readfirstlane(n_in), nv = __builtin_amdgcn_readfirstlane(nv_in);
     const int iters = __builtin_amdgcn_readfirstlane(iters_in);
     const bool rowl = lane < n, dofl = lane < nv;
-    double rb = rowl ? b[lane] : 0.0, rR = rowl ? R[lane] : 0.0, rdg = rowl ? dg[lane] : 0.0;
+    double rb = rowl ? b[lane] : 0.0, rR = rowl ? R[lane] : 0.0;
     double ridg = rowl ? idg[lane] : 0.0, rf = rowl ? f[lane] : 0.0;
+    const double rdg = rowl ? 1.0 / ridg : 0.0;       // the row's diagonal A_ii + R_i (only its reciprocal is stored)
     double vv = 0.0;
     for (int r = 0; r < n; r++) {
       const double fr = read_lane(rf, r);

@@ -30,7 +30,7 @@ struct EmuWave {
   // same association as the device reduction is NOT required (rounding-level differences are expected)
   template <class F> double sum(int n, F f) { double s = 0; for (int i = 0; i < n; i++) s += f(i); return s; }
   // projected Gauss-Seidel sweeps (reference semantics of HipWave::pgs): f warm-started, v = Y'f maintained
-  int pgs(int n, int nv, const double* Y, int ldy, const double* b, const double* R, const double* dg,
+  int pgs(int n, int nv, const double* Y, int ldy, const double* b, const double* R,
            const double* idg, double* f, double* v, int iters, double thresh) {
     for (int d = 0; d < nv; d++) { double s = 0; for (int r = 0; r < n; r++) s += Y[r * ldy + d] * f[r]; v[d] = s; }
     for (int it = 0; it < iters; it++) {
@@ -45,7 +45,7 @@ struct EmuWave {
         if (df != 0) {
           for (int d = 0; d < nv; d++) v[d] += Y[r * ldy + d] * df;
           f[r] = fn;
-          const double c = std::fabs(df) * dg[r];
+          const double c = std::fabs(df) / idg[r];
           if (c > change) change = c;
         }
       }
