@@ -352,23 +352,39 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
     for (int j = 0; j < L; j++) row[j] = row[j] / sum;
   }
   __syncthreads();
-  for (int idx = t; idx < L * 256; idx += 256) {
-    const int i = idx >> 8, col = idx & 255, h = col >> 7;
-    const float* w = sc + (h * L + i) * L;
-    float s = 0.f;
-    for (int j = 0; j < L; j++) s += w[j] * qkv[(size_t)(n0 + j) * 768 + 512 + col];
-    attng[(size_t)(n0 + i) * 256 + col] = s;
-  }
-  for (int idx = t; idx < L * 768; idx += 256) {
-    const int i = idx / 768, s3 = (idx % 768) >> 8, col = idx & 255, h = col >> 7, d = col & 127;
-    const float* w = sc + (h * L + i) * L;
-    float s = 0.f;
-    if (d < 126) {
-      for (int j = 0; j < L; j++) s += w[j] * vg[((size_t)(n0 + j) * 3 + s3) * 256 + h * 126 + d];
-    } else {
-      for (int j = 0; j < L; j++) s += w[j] * gdir[((size_t)(n0 + j) * 3 + s3) * 2 + (d - 126)];
+  // A.V with the value column in registers: a thread owns one output column (256 of the invariant values, then 3 x 256
+  // of the geometric ones), reads its L value entries ONCE and produces the L outputs of that column -- the attention
+  // weights come from LDS (broadcast within a head)
+  constexpr int LMAX = 14;
+  {
+    const int col = t, h = col >> 7;
+    float v[LMAX];
+#pragma unroll
+    for (int j = 0; j < LMAX; j++) v[j] = j < L ? qkv[(size_t)(n0 + j) * 768 + 512 + col] : 0.f;
+    for (int i = 0; i < L; i++) {
+      const float* w = sc + (h * L + i) * L;
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < LMAX; j++) if (j < L) s += w[j] * v[j];
+      attng[(size_t)(n0 + i) * 256 + col] = s;
     }
-    attg[((size_t)(n0 + i) * 3 + s3) * 256 + col] = s;
+  }
+  for (int s3 = 0; s3 < 3; s3++) {
+    const int col = t, h = col >> 7, d = col & 127;
+    float v[LMAX];
+#pragma unroll
+    for (int j = 0; j < LMAX; j++) {
+      float x = 0.f;
+      if (j < L) x = d < 126 ? vg[((size_t)(n0 + j) * 3 + s3) * 256 + h * 126 + d] : gdir[((size_t)(n0 + j) * 3 + s3) * 2 + (d - 126)];
+      v[j] = x;
+    }
+    for (int i = 0; i < L; i++) {
+      const float* w = sc + (h * L + i) * L;
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < LMAX; j++) if (j < L) s += w[j] * v[j];
+      attg[((size_t)(n0 + i) * 3 + s3) * 256 + col] = s;
+    }
   }
 }
 
