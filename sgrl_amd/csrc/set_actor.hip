@@ -60,19 +60,23 @@ struct GemmArgs {
   float* C2; int ldc2;  // EPI_ACC2: C2[m][n] += value
 };
 
-// TM = 32-row MFMA tiles per wave in the M direction: block tile (64*TM) x 128.  TM = 1 halves the tile for the
-// N = 128 GEMMs, whose 280 full tiles would otherwise quantise badly onto 256 CUs.
-template <int FLAGS, int TM>
+// TM = 32-row MFMA tiles per wave in the M direction, WN = waves side by side in the N direction (each 64 columns):
+// block tile (32*TM*4/WN) x (64*WN).  <TM 2, WN 2> = 128 x 128; <1, 2> = 64 x 128 halves the tile for the N = 128 GEMMs,
+// whose 280 full tiles would otherwise quantise badly onto 256 CUs; <1, 1> = 128 x 64 for the narrow projections
+// (N <= 64), which would waste half or more of a 128-column tile.
+template <int FLAGS, int TM, int WN = 2>
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
-  constexpr int BMT = 64 * TM;
+  constexpr int BNT = 64 * WN;
+  constexpr int BMT = 32 * TM * (4 / WN);
+  static_assert(BMT <= 128 && BNT <= 128, "LDS tiles hold at most 128 rows");
   constexpr int NPA = BMT / RPP;       // A-tile load passes
-  constexpr int NPW = BN / RPP;        // W-tile load passes
+  constexpr int NPW = BNT / RPP;       // W-tile load passes
   extern __shared__ float gemm_lds[];   // 2 stages x (A tile + W tile), k-major [BK][LDT]
   float (*As)[BK][LDT] = reinterpret_cast<float (*)[BK][LDT]>(gemm_lds);
   float (*Ws)[BK][LDT] = reinterpret_cast<float (*)[BK][LDT]>(gemm_lds + 2 * BK * LDT);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_n = (a.N + BN - 1) / BN;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = (a.N + BNT - 1) / BNT;
   // blocks b and b+8 share an XCD (round-robin dispatch): renumber so that each XCD works on a contiguous run of
   // tiles, i.e. the column tiles of one row tile re-read the same A rows out of ONE L2 (speed only, never correctness)
   int bid;
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
     bid = (x < rem) ? x * (per + 1) + i : rem * (per + 1) + (x - rem) * per + i;
   }
   const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
-  const int m0 = tile_m * BMT, n0 = tile_n * BN;
+  const int m0 = tile_m * BMT, n0 = tile_n * BNT;
   const int kq = t % TPR, r0 = t / TPR;
   f32x16 acc[TM][2];
   for (int i = 0; i < TM; i++) for (int j = 0; j < 2; j++) for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
@@ -514,6 +518,10 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw
                 int M, int N, int K, int flags = 0, const float* rowdiv = nullptr, float* C2 = nullptr, int ldc2 = 0) {
   if (K % BK != 0 || (lda & 3) || (ldw & 3)) return sfail(SGRL_ERR_ARG, "gemm: K must be a multiple of 16 and rows 16-byte aligned");
   GemmArgs a{A, lda, W, ldw, bias, C, ldc, M, N, K, flags, rowdiv, C2, ldc2};
+  if (N <= 64 && flags == 0) {           // narrow projections: 128 x 64 tiles (four waves stacked in M)
+    hipLaunchKernelGGL((k_gemm<0, 1, 1>), dim3((M + 127) / 128), dim3(256), GEMM_LDS_BYTES, st, a);
+    return SGRL_OK;
+  }
   const int tiles_n = (N + BN - 1) / BN;
   const int full = ((M + 127) / 128) * tiles_n;
   const bool half = full < 2 * 256;      // fewer than two full tiles per CU: use 64-row tiles
@@ -637,6 +645,7 @@ int sgrl_set_create(sgrl_set** out) {
   }
   bool attr_ok = true;
 #define SGRL_ATTR(F, T) attr_ok = attr_ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<F, T>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES) == hipSuccess
+  attr_ok = attr_ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<0, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES) == hipSuccess;
   SGRL_ATTR(0, 1); SGRL_ATTR(0, 2); SGRL_ATTR(EPI_RELU, 1); SGRL_ATTR(EPI_RELU, 2);
   SGRL_ATTR(EPI_ROWDIV, 1); SGRL_ATTR(EPI_ROWDIV, 2); SGRL_ATTR(EPI_ACC2, 1); SGRL_ATTR(EPI_ACC2, 2);
 #undef SGRL_ATTR
