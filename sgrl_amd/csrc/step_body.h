@@ -40,12 +40,12 @@ constexpr double kMaxImp = 0.9999;
 constexpr double kPi = 3.14159265358979323846;
 constexpr int kNAMax = 32;
 constexpr int kBppMaxIter = 40;
-constexpr int kScratchDoubles = 64 * 65;   // per-env HBM slab: A and its factor for up to 64 rows  // largest row count solved in the dense A = Y Y' + R form (packed lower triangle in LDS)
+constexpr int kScratchDoubles = 5632;   // per-env HBM slab: A and its factor for up to 64 rows  // largest row count solved in the dense A = Y Y' + R form (packed lower triangle in LDS)
 
 // ------------------------------------------------------------------------------------------------
 // LDS layout (offsets in doubles for S, in ints for I)
 struct Layout {
-  int nb, nj, nq, nv, nu, np, ncon, maxrows, ld, ldy;
+  int nb, nj, nq, nv, nu, np, ncon, maxrows, lrows, ld, ldy;
   // S
   int qpos, qvel, q0, v0, xv, fq, dvacc, daacc, ctrl, act;
   int xpos, xquat, xmat, xipos, xanchor, xaxis;
@@ -91,10 +91,14 @@ SGRL_HD void make_layout(const int32_t* hdr, Layout* o, int n_int = 0, int n_f64
   }
   o->L = p; p += nv * (nv + 1) / 2; o->dinv = p; p += nv;
   o->qfs = p; p += nv; o->qacc = p; p += nv; o->vpgs = p; p += nv;
-  o->Y = p; p += (o->maxrows + 1) * o->ldy;
-  o->eR = p; p += o->maxrows; o->earef = p; p += o->maxrows; o->eb = p; p += o->maxrows;
-  o->ef = p; p += o->maxrows;
-  o->eidg = p; p += o->maxrows; o->prev_f = p; p += o->maxrows;
+  // The constraint-row arrays in LDS hold `lrows` rows: as many as the factor scratch (dead zone) can serve.  The rare
+  // evaluations with more rows (up to maxrows <= 64) run their whole constraint stage out of the environment's HBM slab
+  // instead (Engine::Rows) -- sizing the slab for the common case buys one or two more workgroups per CU.
+  o->lrows = o->maxrows < o->na_max ? o->maxrows : o->na_max;
+  o->Y = p; p += (o->lrows + 1) * o->ldy;
+  o->eR = p; p += o->lrows; o->earef = p; p += o->lrows; o->eb = p; p += o->lrows;
+  o->ef = p; p += o->lrows;
+  o->eidg = p; p += o->lrows; o->prev_f = p; p += o->maxrows;
   o->misc = p; p += 16;
   o->Mfull = p;
   if (hdr[SGRL_H_INTEGRATOR] == 0) p += nv * (nv + 1) / 2;
@@ -102,9 +106,9 @@ SGRL_HD void make_layout(const int32_t* hdr, Layout* o, int n_int = 0, int n_f64
   o->s_total = p;
   int q = 0;
   o->con_valid = q; q += o->ncon;
-  o->row_kind = q; q += o->maxrows; o->row_src = q; q += o->maxrows; o->row_sub = q; q += o->maxrows;
+  o->row_kind = q; q += o->lrows; o->row_src = q; q += o->lrows; o->row_sub = q; q += o->lrows;
   o->prev_key = q; q += o->maxrows;
-  o->flist = q; q += o->maxrows;
+  o->flist = q; q += o->lrows;
   o->ecnt = q; q += 2 * nj + o->ncon;
   o->icnt = q; q += 8;
   o->model_i = q; q += n_int;
@@ -672,7 +676,30 @@ struct Engine {
   }
 
   // row table (serial, lane 0): limits in joint order, then contacts in slot order; same cap rule as the oracle
-  SGRL_DEV void enumerate_rows() {
+  // The arrays of one evaluation's constraint rows: in the LDS slab (common case) or in the environment's HBM scratch
+  // slab (more rows than the LDS arrays hold).  Every constraint-stage function is inlined once per variant, so the
+  // compiler sees LDS or global pointers, never generic ones.
+  struct Rows {
+    double *Y, *eR, *earef, *eb, *ef, *eidg, *C;
+    int32_t *kind, *src, *sub, *flist;
+  };
+  SGRL_DEV Rows rows_lds() const {
+    return Rows{S + o.Y, S + o.eR, S + o.earef, S + o.eb, S + o.ef, S + o.eidg, S + o.dead,
+                I + o.row_kind, I + o.row_src, I + o.row_sub, I + o.flist};
+  }
+  SGRL_DEV Rows rows_hbm() const {   // slab: C[2080] | Y[65 * 47] | 5 x 64 doubles | 4 x 64 ints
+    double* p = big_scratch;
+    Rows r;
+    r.C = p; p += 2080;
+    r.Y = p; p += 65 * 47;
+    r.eR = p; p += 64; r.earef = p; p += 64; r.eb = p; p += 64; r.ef = p; p += 64; r.eidg = p; p += 64;
+    int32_t* q = reinterpret_cast<int32_t*>(p);
+    r.kind = q; r.src = q + 64; r.sub = q + 128; r.flist = q + 192;
+    return r;
+  }
+
+  // number of rows this evaluation wants (before the cap): lane-parallel count per item + a wave sum
+  SGRL_DEV int count_rows() {
     // lane-parallel: item t = (joint, side) for t < 2*nj, contact slot otherwise; rows wanted per item, then every
     // lane takes the prefix sum of the items before it.  Falls back to the serial walk only when the cap would bite.
     const int nitem = 2 * o.nj + o.ncon;
@@ -691,25 +718,29 @@ struct Engine {
       }
       I[o.ecnt + t] = c;
     });
-    w.lanes(nitem, [&](int t) {
-      int pre = 0;
-      for (int u = 0; u < t; u++) pre += I[o.ecnt + u];
-      const int c = I[o.ecnt + t];
-      if (t == nitem - 1) I[o.icnt + IC_NROW_WANTED] = pre + c;
-      if (c > 0 && pre + c <= o.maxrows) {
+    return (int)w.sum(nitem, [&](int t) { return (double)I[o.ecnt + t]; });     // small integers: exact in f64
+  }
+
+  // row table (kind, source, sub-index) into the arrays of R; sets IC_NROW / IC_NROW_WANTED and counts overflows
+  SGRL_DEV void fill_rows(const Rows& R, int wanted_total, int cap) {
+    const int nitem = 2 * o.nj + o.ncon;
+    if (wanted_total <= cap) {
+      w.lanes(nitem, [&](int t) {
+        int pre = 0;
+        for (int u = 0; u < t; u++) pre += I[o.ecnt + u];
+        const int c = I[o.ecnt + t];
+        if (t == 0) { I[o.icnt + IC_NROW_WANTED] = wanted_total; I[o.icnt + IC_NROW] = wanted_total; }
         for (int k = 0; k < c; k++) {
-          if (t < 2 * o.nj) { I[o.row_kind + pre] = (t & 1) ? ROW_LIMIT_HI : ROW_LIMIT_LO; I[o.row_src + pre] = t >> 1; I[o.row_sub + pre] = 0; }
-          else { I[o.row_kind + pre + k] = (c == 1) ? ROW_CON1 : ROW_PYR; I[o.row_src + pre + k] = t - 2 * o.nj; I[o.row_sub + pre + k] = k; }
+          if (t < 2 * o.nj) { R.kind[pre] = (t & 1) ? ROW_LIMIT_HI : ROW_LIMIT_LO; R.src[pre] = t >> 1; R.sub[pre] = 0; }
+          else { R.kind[pre + k] = (c == 1) ? ROW_CON1 : ROW_PYR; R.src[pre + k] = t - 2 * o.nj; R.sub[pre + k] = k; }
         }
-      }
-    });
-    if (I[o.icnt + IC_NROW_WANTED] <= o.maxrows) {
-      w.lanes(1, [&](int) { I[o.icnt + IC_NROW] = I[o.icnt + IC_NROW_WANTED]; });
+      });
       return;
     }
+    // the cap bites (never observed at the shipped caps): serial walk that drops what does not fit
     w.lanes(1, [&](int) {
       int nrow = 0, wanted = 0;
-      const int maxrows = o.maxrows;
+      const int maxrows = cap;
       for (int j = 0; j < o.nj; j++) {
         if (!m.jnt_limited[j]) continue;
         const double q = S[o.qpos + m.jnt_qposadr[j]];
@@ -718,8 +749,8 @@ struct Engine {
           if (dist >= m.jnt_margin[j]) continue;
           wanted++;
           if (nrow >= maxrows) continue;
-          I[o.row_kind + nrow] = side < 0 ? ROW_LIMIT_LO : ROW_LIMIT_HI;
-          I[o.row_src + nrow] = j; I[o.row_sub + nrow] = 0;
+          R.kind[nrow] = side < 0 ? ROW_LIMIT_LO : ROW_LIMIT_HI;
+          R.src[nrow] = j; R.sub[nrow] = 0;
           nrow++;
         }
       }
@@ -730,8 +761,8 @@ struct Engine {
         wanted += nr;
         if (nrow + nr > maxrows) continue;
         for (int k = 0; k < nr; k++) {
-          I[o.row_kind + nrow] = dim == 1 ? ROW_CON1 : ROW_PYR;
-          I[o.row_src + nrow] = s; I[o.row_sub + nrow] = k;
+          R.kind[nrow] = dim == 1 ? ROW_CON1 : ROW_PYR;
+          R.src[nrow] = s; R.sub[nrow] = k;
           nrow++;
         }
       }
@@ -740,17 +771,18 @@ struct Engine {
     });
   }
 
-  SGRL_DEV void build_rows_and_halfsolve() {
+  template <bool BIG>
+  SGRL_DEV void build_rows_and_halfsolve(const Rows& R) {
     const int nv = o.nv, ldy = o.ldy;
     const int nrow = I[o.icnt + IC_NROW];
     w.lanes(nrow + 1, [&](int r) {
-      double* Yr = S + o.Y + r * ldy;
+      double* Yr = R.Y + r * ldy;
       if (r == nrow) {  // extra right-hand side: the smooth force
         for (int d = 0; d < nv; d++) Yr[d] = S[o.qfs + d];
         return;
       }
-      const int kind = I[o.row_kind + r], src = I[o.row_src + r], sub = I[o.row_sub + r];
-      double R, aref;
+      const int kind = R.kind[r], src = R.src[r], sub = R.sub[r];
+      double Rreg, aref;
       if (kind == ROW_LIMIT_LO || kind == ROW_LIMIT_HI) {
         const int j = src, side = kind == ROW_LIMIT_LO ? -1 : 1, dof = m.jnt_dofadr[j];
         for (int d = 0; d < nv; d++) Yr[d] = 0;
@@ -763,8 +795,8 @@ struct Engine {
         sr[0] = m.jnt_solref[2 * j]; sr[1] = m.jnt_solref[2 * j + 1];
         const double imp = impedance(si, dist - margin);
         kb(sr, si, &K, &B);
-        R = (1 - imp) / imp * m.dof_invweight0[dof];
-        if (R < kMinVal) R = kMinVal;
+        Rreg = (1 - imp) / imp * m.dof_invweight0[dof];
+        if (Rreg < kMinVal) Rreg = kMinVal;
         aref = -B * (-side * S[o.qvel + dof]) - K * imp * (dist - margin);
       } else {
         const int s = src, p = s >> 1;
@@ -805,32 +837,32 @@ struct Engine {
         kb(sr, si, &K, &B);
         const double tran = m.body_invweight0[2 * b1] + m.body_invweight0[2 * b2];
         if (kind == ROW_CON1) {
-          R = (1 - imp) / imp * tran;
-          if (R < kMinVal) R = kMinVal;
+          Rreg = (1 - imp) / imp * tran;
+          if (Rreg < kMinVal) Rreg = kMinVal;
         } else {
           double R0 = (1 - imp) / imp * (tran + mu * mu * tran);
           if (R0 < kMinVal) R0 = kMinVal;
-          R = 2 * mu * mu * R0;
-          if (R < kMinVal) R = kMinVal;
+          Rreg = 2 * mu * mu * R0;
+          if (Rreg < kMinVal) Rreg = kMinVal;
         }
         aref = -B * vel - K * imp * (dist - margin);
       }
-      S[o.eR + r] = R; S[o.earef + r] = aref;
+      R.eR[r] = Rreg; R.earef[r] = aref;
       // warm start from the previous evaluation of this env-step: same constraint (kind, source, edge) -> same force
       const int key = (kind << 16) | (src << 3) | sub;
       double f0 = 0;
       const int pn = I[o.icnt + IC_PREV_N];
       for (int k = 0; k < pn; k++) if (I[o.prev_key + k] == key) f0 = S[o.prev_f + k];
-      S[o.ef + r] = f0;
+      R.ef[r] = f0;
     });
     SGRL_TICK(6);
     // half-solve Y <- L^-1 Y for all right-hand sides (rows + the smooth force), one lane per right-hand side
     if (linv) {
       // Y_r = L^-1 J_r as a triangular matrix product: one lane per right-hand side, entries from the last to the first
       // so that the row is overwritten in place (Y_r[d] needs J_r[0..d] only)
-      if (!w.trmm_rows(nrow + 1, nv, S + o.L, S + o.Y, ldy))      // register version where the policy has one
+      if (BIG || !w.trmm_rows(nrow + 1, nv, S + o.L, R.Y, ldy))      // register version where the policy has one (LDS rows)
       w.lanes(nrow + 1, [&](int r) {
-        double* Yr = S + o.Y + r * ldy;
+        double* Yr = R.Y + r * ldy;
         for (int d = nv - 1; d >= 0; d--) {
           const double* Ld = S + o.L + tri(d);
           double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
@@ -845,20 +877,20 @@ struct Engine {
         }
       });
     } else {
-      w.trsm_lower_rows(nrow + 1, nv, S + o.L, S + o.dinv, S + o.Y, ldy);
+      w.trsm_lower_rows(nrow + 1, nv, S + o.L, S + o.dinv, R.Y, ldy);
     }
     SGRL_TICK(9);
     w.lanes(nrow > nv ? nrow : nv, [&](int r) {
       if (r < nrow) {
-        const double* Yr = S + o.Y + r * ldy;
+        const double* Yr = R.Y + r * ldy;
         double s2 = 0;
         for (int d = 0; d < nv; d++) s2 += Yr[d] * Yr[d];
-        const double Rr = S[o.eR + r];
-        S[o.eidg + r] = 1.0 / (s2 + Rr);
+        const double Rr = R.eR[r];
+        R.eidg[r] = 1.0 / (s2 + Rr);
         double s = 0;
-        const double* ys = S + o.Y + nrow * ldy;      // the half-solved smooth force: the extra right-hand side
+        const double* ys = R.Y + nrow * ldy;      // the half-solved smooth force: the extra right-hand side
         for (int d = 0; d < nv; d++) s += Yr[d] * ys[d];
-        S[o.eb + r] = s - S[o.earef + r];
+        R.eb[r] = s - R.earef[r];
       }
       if (r < nv) S[o.vpgs + r] = 0;
     });
@@ -872,10 +904,12 @@ struct Engine {
   // warm-started from the previous evaluation.  On success S[vpgs] = Y' f.  The result is the same unique optimum
   // projected Gauss-Seidel converges to; PGS remains the fallback.
   template <bool SMALL>
-  SGRL_DEV bool lcp_block_pivot(int n, double thresh, double* C, int* iters_out) {
-    const int wv = o.earef, xw = o.prev_f;
+  SGRL_DEV bool lcp_block_pivot(const Rows& R, int n, double thresh, int* iters_out) {
+    double* const C = R.C;
+    double* const wvp = R.earef;          // scratch: reciprocal pivots / intermediate vector
+    double* const xwp = S + o.prev_f;     // scratch: right-hand side -> solution (compact, free-set order)
     const int nv = o.nv, ldy = o.ldy;
-    uint64_t F = w.ballot(n, [&](int i) { return S[o.ef + i] > 0.0; });
+    uint64_t F = w.ballot(n, [&](int i) { return R.ef[i] > 0.0; });
     int patience = 3, best = n + 1;
     for (int iter = 0; iter < kBppMaxIter; iter++) {
       w.fence_lane();            // nothing lane-dependent is carried across pivoting rounds (registers)
@@ -883,17 +917,17 @@ struct Engine {
       w.lanes(n, [&](int i) {
         if ((F >> i) & 1ull) {
           const int pos = popcount64(F & ((1ull << i) - 1ull));
-          I[o.flist + pos] = i;
-          S[xw + pos] = -S[o.eb + i];
+          R.flist[pos] = i;
+          xwp[pos] = -R.eb[i];
         }
       });
       // A_FF = Y_F Y_F' + diag(R_F), compact packed lower triangle
       w.lanes(nf * (nf + 1) / 2, [&](int p) {
         int i, j;
         tri_decode(p, &i, &j);
-        const int fi = I[o.flist + i], fj = I[o.flist + j];
-        const double* yi = S + o.Y + fi * ldy;
-        const double* yj = S + o.Y + fj * ldy;
+        const int fi = R.flist[i], fj = R.flist[j];
+        const double* yi = R.Y + fi * ldy;
+        const double* yj = R.Y + fj * ldy;
         double a = 0;
         int d = 0;
         for (; d + 4 <= nv; d += 4) {
@@ -902,7 +936,7 @@ struct Engine {
           a += a0 * b0; a += a1 * b1; a += a2 * b2; a += a3 * b3;
         }
         for (; d < nv; d++) a += yi[d] * yj[d];
-        if (i == j) a += S[o.eR + fi];
+        if (i == j) a += R.eR[fi];
         C[p] = a;
       });
       // factor A_FF and solve.  Small free sets in LDS: Cholesky + explicit inverse of the factor on registers (wave
@@ -910,13 +944,13 @@ struct Engine {
       if (SMALL && w.chol_inv_packed(nf, C, kMinVal)) {
         w.lanes(nf, [&](int i) {
           double z = 0;
-          for (int c = 0; c <= i; c++) z += C[i * (i + 1) / 2 + c] * S[xw + c];
-          S[wv + i] = z;
+          for (int c = 0; c <= i; c++) z += C[i * (i + 1) / 2 + c] * xwp[c];
+          wvp[i] = z;
         });
         w.lanes(nf, [&](int k) {
           double x = 0;
-          for (int i = k; i < nf; i++) x += C[i * (i + 1) / 2 + k] * S[wv + i];
-          S[xw + k] = x;
+          for (int i = k; i < nf; i++) x += C[i * (i + 1) / 2 + k] * wvp[i];
+          xwp[k] = x;
         });
       } else {
         // root-free right-looking Cholesky of A_FF: one fused update per trailing entry per pivot;  w[k] = 1 / C[k][k]
@@ -935,35 +969,35 @@ struct Engine {
         w.lanes(nf, [&](int j) {
           double pj = C[j * (j + 1) / 2 + j];
           if (pj < kMinVal) pj = kMinVal;
-          S[wv + j] = 1.0 / pj;
+          wvp[j] = 1.0 / pj;
         });
         // forward substitution (column sweeps), diagonal scaling, backward substitution
         for (int j = 0; j < nf; j++) {
-          const double zj = S[xw + j] * S[wv + j];
-          w.lanes_from(j + 1, nf, [&](int i) { S[xw + i] -= C[i * (i + 1) / 2 + j] * zj; });
+          const double zj = xwp[j] * wvp[j];
+          w.lanes_from(j + 1, nf, [&](int i) { xwp[i] -= C[i * (i + 1) / 2 + j] * zj; });
         }
-        w.lanes(nf, [&](int i) { S[xw + i] *= S[wv + i]; });
+        w.lanes(nf, [&](int i) { xwp[i] *= wvp[i]; });
         for (int j = nf - 1; j > 0; j--) {
-          const double xj = S[xw + j];
-          w.lanes(j, [&](int k) { S[xw + k] -= C[j * (j + 1) / 2 + k] * S[wv + k] * xj; });
+          const double xj = xwp[j];
+          w.lanes(j, [&](int k) { xwp[k] -= C[j * (j + 1) / 2 + k] * wvp[k] * xj; });
         }
       }
       // u = Y_F' x  (= Y' f for the candidate f);  violations: x_i < 0 on F, (Y_i u + b_i) < -thresh on the complement
       w.lanes(nv, [&](int d) {
         double u = 0;
-        for (int k = 0; k < nf; k++) u += S[o.Y + I[o.flist + k] * ldy + d] * S[xw + k];
+        for (int k = 0; k < nf; k++) u += R.Y[R.flist[k] * ldy + d] * xwp[k];
         S[o.vpgs + d] = u;
       });
       const uint64_t V = w.ballot(n, [&](int i) {
-        if ((F >> i) & 1ull) return S[xw + popcount64(F & ((1ull << i) - 1ull))] < -thresh * S[o.eidg + i];
-        const double* yi = S + o.Y + i * ldy;
-        double y = S[o.eb + i];
+        if ((F >> i) & 1ull) return xwp[popcount64(F & ((1ull << i) - 1ull))] < -thresh * R.eidg[i];
+        const double* yi = R.Y + i * ldy;
+        double y = R.eb[i];
         for (int d = 0; d < nv; d++) y += yi[d] * S[o.vpgs + d];
         return y < -thresh;
       });
       if (V == 0) {
         w.lanes(n, [&](int i) {
-          S[o.ef + i] = ((F >> i) & 1ull) ? S[xw + popcount64(F & ((1ull << i) - 1ull))] : 0.0;
+          R.ef[i] = ((F >> i) & 1ull) ? xwp[popcount64(F & ((1ull << i) - 1ull))] : 0.0;
         });
         *iters_out = iter + 1;
         return true;
@@ -974,34 +1008,35 @@ struct Engine {
       else { F ^= (1ull << (63 - clz64(V))); }   // backup rule: only the highest violating index
     }
     // not converged (never observed): leave a feasible point for the Gauss-Seidel fallback
-    w.lanes(n, [&](int i) { if (S[o.ef + i] < 0.0) S[o.ef + i] = 0.0; });
+    w.lanes(n, [&](int i) { if (R.ef[i] < 0.0) R.ef[i] = 0.0; });
     *iters_out = kBppMaxIter;
     return false;
   }
 
-  SGRL_DEV void pgs_and_finish() {
+  template <bool BIG>
+  SGRL_DEV void pgs_and_finish(const Rows& R) {
     const int nv = o.nv, ldy = o.ldy;
     const int nrow = I[o.icnt + IC_NROW];
     int sweeps = 0, diag_code = 0;
     if (nrow > 0) {
-      const double bmax = w.maxabs(nrow, [&](int r) { return S[o.eb + r]; });
+      const double bmax = w.maxabs(nrow, [&](int r) { return R.eb[r]; });
       const double thresh = m.fhdr[SGRL_F_PGS_TOL] * (1.0 + bmax);
       bool solved = false;
       if (m.hdr[SGRL_H_SOLVER] == 1) {
-        if (nrow <= o.na_max) {
-          solved = lcp_block_pivot<true>(nrow, thresh, S + o.dead, &sweeps);         // factor scratch in LDS
+        if (!BIG) {
+          solved = lcp_block_pivot<true>(R, nrow, thresh, &sweeps);             // rows and factor scratch in LDS
           if (!solved) diag_code |= 1 << 8;                                     // diagnostics: block pivoting gave up
-        } else if (big_scratch != nullptr && nrow <= 64) {
-          // rare (a few envs per 8192-env launch): more rows than the LDS scratch holds -> same exact solve with the
-          // factor in this environment's HBM scratch slab instead of hundreds of Gauss-Seidel sweeps
-          solved = lcp_block_pivot<false>(nrow, thresh, big_scratch, &sweeps);
+        } else if (nrow <= 64) {
+          // rare (a few envs per 8192-env launch): more rows than the LDS arrays hold -> the same exact solve with
+          // rows and factor in this environment's HBM scratch slab
+          solved = lcp_block_pivot<false>(R, nrow, thresh, &sweeps);
           diag_code |= (1 << 16) | (solved ? 0 : 1 << 8);
         }
       }
       if (!solved) {
         // matrix-free projected Gauss-Seidel, the policy keeps v = Y'f one entry per lane (also the SOLVER = 0 path)
         diag_code |= 1;
-        sweeps = w.pgs(nrow, nv, S + o.Y, ldy, S + o.eb, S + o.eR, S + o.eidg, S + o.ef, S + o.vpgs,
+        sweeps = w.pgs(nrow, nv, R.Y, ldy, R.eb, R.eR, R.eidg, R.ef, S + o.vpgs,
                        m.hdr[SGRL_H_PGS_ITERS], thresh);
       }
     }
@@ -1009,15 +1044,15 @@ struct Engine {
     // remember the solution for the next evaluation's warm start
     w.lanes(nrow > 0 ? nrow : 1, [&](int r) {
       if (r < nrow) {
-        I[o.prev_key + r] = (I[o.row_kind + r] << 16) | (I[o.row_src + r] << 3) | I[o.row_sub + r];
-        S[o.prev_f + r] = S[o.ef + r];
+        I[o.prev_key + r] = (R.kind[r] << 16) | (R.src[r] << 3) | R.sub[r];
+        S[o.prev_f + r] = R.ef[r];
       }
       if (r == 0) { I[o.icnt + IC_PREV_N] = nrow; I[o.icnt + IC_SWEEPS] += sweeps; I[o.icnt + IC_ROWSUM] += diag_code; }
     });
     // qacc = L^-T (ys + Y' f)
     if (linv) {
       // qacc = L^-T w as a matrix-vector product with the explicit inverse (w parked in vpgs: no in-place hazard)
-      w.lanes(nv, [&](int d) { S[o.vpgs + d] = S[o.Y + nrow * ldy + d] + (nrow > 0 ? S[o.vpgs + d] : 0.0); });
+      w.lanes(nv, [&](int d) { S[o.vpgs + d] = R.Y[nrow * ldy + d] + (nrow > 0 ? S[o.vpgs + d] : 0.0); });
       w.lanes(nv, [&](int k) {
         double s0 = 0, s1 = 0;
         int i = k;
@@ -1026,7 +1061,7 @@ struct Engine {
         S[o.qacc + k] = s0 + s1;
       });
     } else {
-      w.lanes(nv, [&](int d) { S[o.qacc + d] = S[o.Y + nrow * ldy + d] + (nrow > 0 ? S[o.vpgs + d] : 0.0); });
+      w.lanes(nv, [&](int d) { S[o.qacc + d] = R.Y[nrow * ldy + d] + (nrow > 0 ? S[o.vpgs + d] : 0.0); });
       solve_upper_inplace(o.L, o.qacc);
     }
   }
@@ -1040,9 +1075,18 @@ struct Engine {
     crba_and_factor();          SGRL_TICK(2);
     collide();                  SGRL_TICK(3);
     bias_and_smooth_force();    SGRL_TICK(4);
-    enumerate_rows();           SGRL_TICK(5);
-    build_rows_and_halfsolve(); SGRL_TICK(10);
-    pgs_and_finish();           SGRL_TICK(11);
+    const int wanted = count_rows();
+    if (wanted > o.lrows && big_scratch != nullptr) {
+      const Rows R = rows_hbm();
+      fill_rows(R, wanted, o.maxrows);           SGRL_TICK(5);
+      build_rows_and_halfsolve<true>(R);         SGRL_TICK(10);
+      pgs_and_finish<true>(R);                   SGRL_TICK(11);
+    } else {
+      const Rows R = rows_lds();
+      fill_rows(R, wanted, o.lrows);             SGRL_TICK(5);
+      build_rows_and_halfsolve<false>(R);        SGRL_TICK(10);
+      pgs_and_finish<false>(R);                  SGRL_TICK(11);
+    }
   }
 
   // ---- integration ----------------------------------------------------------------------------
