@@ -64,7 +64,8 @@ struct Layout {
   int i_total;
 };
 
-SGRL_HD void make_layout(const int32_t* hdr, Layout* o, int n_int = 0, int n_f64 = 0) {
+// lrows_cut: rows taken off the natural size of the LDS row arrays (make_layout picks it)
+SGRL_HD void make_layout_rows(const int32_t* hdr, Layout* o, int n_int, int n_f64, int lrows_cut) {
   const int nb = hdr[SGRL_H_NBODY], nj = hdr[SGRL_H_NJNT], nq = hdr[SGRL_H_NQ], nv = hdr[SGRL_H_NV];
   const int nu = hdr[SGRL_H_NU], np = hdr[SGRL_H_NPAIR];
   o->nb = nb; o->nj = nj; o->nq = nq; o->nv = nv; o->nu = nu; o->np = np;
@@ -94,7 +95,7 @@ SGRL_HD void make_layout(const int32_t* hdr, Layout* o, int n_int = 0, int n_f64
   // The constraint-row arrays in LDS hold `lrows` rows: as many as the factor scratch (dead zone) can serve.  The rare
   // evaluations with more rows (up to maxrows <= 64) run their whole constraint stage out of the environment's HBM slab
   // instead (Engine::Rows) -- sizing the slab for the common case buys one or two more workgroups per CU.
-  o->lrows = o->maxrows < o->na_max ? o->maxrows : o->na_max;
+  o->lrows = (o->maxrows < o->na_max ? o->maxrows : o->na_max) - lrows_cut;
   o->Y = p; p += (o->lrows + 1) * o->ldy;
   o->eR = p; p += o->lrows; o->earef = p; p += o->lrows; o->eb = p; p += o->lrows;
   o->ef = p; p += o->lrows;
@@ -116,6 +117,25 @@ SGRL_HD void make_layout(const int32_t* hdr, Layout* o, int n_int = 0, int n_f64
 }
 
 SGRL_HD int layout_bytes(const Layout* o) { return o->s_total * 8 + ((o->i_total + 1) & ~1) * 4; }
+
+// LDS is allocated in 1280-byte granules, 160 KB per CU, and the register budget admits 8 workgroups per CU.
+SGRL_HD int workgroups_per_cu(int lds_bytes) {
+  const int per = (160 * 1024) / (((lds_bytes + 1279) / 1280) * 1280);
+  return per > 8 ? 8 : per;
+}
+
+// The layout with the LDS row arrays at their natural size (what the factor scratch can serve) -- or up to three rows
+// shorter when that is what it takes to fit one more workgroup per CU (e.g. cheetah_14: 54 000 B -> 53 584 B = 3 per CU).
+// Evaluations with more rows than the arrays hold use the HBM slab either way.
+SGRL_HD void make_layout(const int32_t* hdr, Layout* o, int n_int = 0, int n_f64 = 0) {
+  make_layout_rows(hdr, o, n_int, n_f64, 0);
+  const int base = workgroups_per_cu(layout_bytes(o));
+  for (int cut = 1; cut <= 3 && o->lrows > 16; cut++) {
+    Layout t;
+    make_layout_rows(hdr, &t, n_int, n_f64, cut);
+    if (workgroups_per_cu(layout_bytes(&t)) > base) { *o = t; return; }
+  }
+}
 
 // misc slots
 enum { MS_COM = 0, /* 3 */ MS_REWARD = 4, MS_DIST = 5, MS_PREQUAT = 6 /* 4 */, MS_PREPOS = 10 /* 2 */ };
