@@ -524,7 +524,7 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw
   }
   const int tiles_n = (N + BN - 1) / BN;
   const int full = ((M + 127) / 128) * tiles_n;
-  const bool half = full < 2 * 256;      // fewer than two full tiles per CU: use 64-row tiles
+  const bool half = full < 4 * 256;      // fewer than four full tiles per CU: 64-row tiles quantise better onto 256 CUs
   const int tiles = half ? ((M + 63) / 64) * tiles_n : full;
 #define SGRL_LAUNCH(F)                                                                                        \
   if (half) hipLaunchKernelGGL((k_gemm<F, 1>), dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, a);               \
