@@ -67,6 +67,14 @@ int sgrl_set_graph(sgrl_set* s, int n_morph, const int32_t* morph_L, const int32
  * obs: DEV float [n_env, obs_ld]; act: DEV float [n_env, act_ld]. */
 int sgrl_set_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_ld, float max_action, void* stream);
 
+/* Critic variant of the same network (reference src/SECritic.py:8-124: TransformerModel with feature_size 44 = 41
+ * state + 3 action values per limb, scalar head):  q[e, l] = critic(obs[e], action[e])[l] for the limbs of env e, rest
+ * of the row zero.  Weights in the same slot table, packed from a critic's state_dict: ENC_W = encoder.weight [128,20],
+ * L1NG_W = linear1_ng.weight [128,148] padded to 160 columns, DECG = decoder_ng.weight [256], L1M_B = decoder_ng.bias [1];
+ * the slots L1M_W, L2M_W, L2M_B and GPROJ are not read.  One handle serves one network (actor OR one critic). */
+int sgrl_set_forward_q(sgrl_set* s, const float* obs, int obs_ld, const float* action, int action_ld, float* q, int q_ld,
+                       void* stream);
+
 int sgrl_set_num_nodes(const sgrl_set* s);
 int64_t sgrl_set_workspace_bytes(const sgrl_set* s);
 /* Time `reps` forwards with HIP events on `stream` (mean ms per forward). */

@@ -211,14 +211,17 @@ struct NodeTab {
   const int32_t* trav;        // [3][TM]
   int TM;
 };
-__global__ __launch_bounds__(128) void k_embed(const float* __restrict__ obs, int obs_ld, NodeTab nt, const float* Wge,
-                                               const float* We, const float* be, const float* e0, const float* e1,
-                                               const float* e2, float* g, float* cat, float* outg, float* outng,
-                                               float* gdir) {
-  __shared__ float o[41];
+__global__ __launch_bounds__(128) void k_embed(const float* __restrict__ obs, int obs_ld, const float* __restrict__ action,
+                                               int act_ld, int ngf, NodeTab nt, const float* Wge, const float* We,
+                                               const float* be, const float* e0, const float* e1, const float* e2, float* g,
+                                               float* cat, float* outg, float* outng, float* gdir) {
+  // per-limb input row: 24 geometric values (8 three-vectors) | ngf non-geometric ones -- 17 from the observation and,
+  // for the critic (ngf = 20), the limb's 3 action slots appended (reference SECritic.py:80-83)
+  __shared__ float o[44];
   const int n = blockIdx.x, c = threadIdx.x;
   const int env = nt.node_env[n], limb = nt.node_limb[n], mn = nt.node_mnode[n];
   if (c < 41) o[c] = obs[(size_t)env * obs_ld + 41 * limb + c];
+  else if (c < 44) o[c] = action ? action[(size_t)env * act_ld + 3 * limb + (c - 41)] : 0.f;
   __syncthreads();
   const float sc = sqrtf(128.f);
   for (int s = 0; s < 3; s++) {
@@ -227,15 +230,15 @@ __global__ __launch_bounds__(128) void k_embed(const float* __restrict__ obs, in
     g[((size_t)n * 3 + s) * D + c] = v * sc;
   }
   float v = be[c];
-  for (int j = 0; j < 17; j++) v += We[c * 17 + j] * o[24 + j];
+  for (int j = 0; j < ngf; j++) v += We[c * ngf + j] * o[24 + j];
   float pos;
   if (c < 42) pos = e0[nt.trav[mn] * 42 + c];
   else if (c < 84) pos = e1[nt.trav[nt.TM + mn] * 42 + (c - 42)];
   else pos = e2[nt.trav[2 * nt.TM + mn] * 44 + (c - 84)];
   cat[(size_t)n * 256 + 128 + c] = v * sc + pos;
   if (c < 24) { const int s = c / 8, j = c % 8; outg[((size_t)n * 3 + s) * OGLD + j] = o[3 * j + s]; }
-  if (c < 17) outng[(size_t)n * 160 + c] = o[24 + c];
-  if (c >= 17 && c < 32) outng[(size_t)n * 160 + 128 + c] = 0.f;  // cols 145..159
+  if (c < ngf) outng[(size_t)n * 160 + c] = o[24 + c];
+  if (c >= ngf && c < 32) outng[(size_t)n * 160 + 128 + c] = 0.f;  // cols 128 + ngf .. 159
   if (c < 6) { const int s = c / 2, e = c % 2; gdir[((size_t)n * 3 + s) * 2 + e] = o[3 * (1 + e) + s]; }
 }
 
@@ -467,6 +470,18 @@ __global__ __launch_bounds__(128) void k_head_out(const float* __restrict__ Zh, 
   }
 }
 
+
+// critic head: q[env][limb] = (w . c[n] + b) / fn[n]   (reference SEActor.py:279-281 with output_size = 1); one wave per node
+__global__ __launch_bounds__(256) void k_q_head(const float* __restrict__ c, const float* __restrict__ w, const float* __restrict__ b,
+                                                const float* __restrict__ fn, NodeTab nt, float* q, int q_ld, int N) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  const float* row = c + (size_t)n * 256;
+  float v = row[lane] * w[lane] + row[64 + lane] * w[64 + lane] + row[128 + lane] * w[128 + lane] + row[192 + lane] * w[192 + lane];
+  v = wave_sum_f32(v);
+  if (lane == 0) q[(size_t)nt.node_env[n] * q_ld + nt.node_limb[n]] = (v + b[0]) / fn[n];
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -488,6 +503,7 @@ struct sgrl_set {
   float* wstack = nullptr;
   unsigned short* d_tri = nullptr;
   bool stack_dirty = true;
+  bool stack_critic = false;   // mode the stacked operands were built for
   // side stream for the GEMM chains that do not depend on each other (their epilogues / tile tails overlap)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -540,14 +556,18 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw
   return SGRL_OK;
 }
 
-int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_ld, float max_action, hipStream_t st) {
+// critic = false: actions[e, 0:3L] = max_action * tanh(actor(obs)).  critic = true: `action` holds the per-limb action
+// slots that complete the critic's input rows and `act` receives the per-limb Q values (row stride act_ld).
+int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_ld, float max_action, hipStream_t st,
+                bool critic = false, const float* action = nullptr, int action_ld = 0) {
   const int N = s->N, N3 = 3 * s->N;
+  const int ngf = critic ? 20 : 17;
   NodeTab nt{s->d_node_env, s->d_node_limb, s->d_node_mnode, s->d_trav, s->TM};
   EnvTab et{s->d_env_off, s->d_env_L, s->d_env_relb};
   (void)hipMemsetAsync(act, 0, sizeof(float) * (size_t)s->n_env * act_ld, st);
   hipLaunchKernelGGL(k_relbias, dim3(s->n_morph), dim3(256), 0, st, s->d_rel, s->W(SGRL_SET_REL_W), s->W(SGRL_SET_REL_B),
                      s->d_relb, s->d_m_off, s->d_m_L, s->n_morph);
-  hipLaunchKernelGGL(k_embed, dim3(N), dim3(128), 0, st, obs, obs_ld, nt, s->W(SGRL_SET_GENC), s->W(SGRL_SET_ENC_W),
+  hipLaunchKernelGGL(k_embed, dim3(N), dim3(128), 0, st, obs, obs_ld, action, action_ld, ngf, nt, s->W(SGRL_SET_GENC), s->W(SGRL_SET_ENC_W),
                      s->W(SGRL_SET_ENC_B), s->W(SGRL_SET_EMB0), s->W(SGRL_SET_EMB1), s->W(SGRL_SET_EMB2), s->g, s->cat,
                      s->outg, s->outng, s->gdir);
   float* ng = s->cat + 128;
@@ -556,12 +576,13 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   // proj + gram site: Z (and Z2) = X . [Wp; Wq]^T on the matrix cores (stacked, zero-padded weights), then the packed
   // Gram triangle per node
   auto site_w = [&](int site) { return s->wstack + (size_t)site * 64 * 128; };   // site 6 (the head, Cpad 144) is last
-  if (s->stack_dirty) {
+  if (s->stack_dirty || s->stack_critic != critic) {
+    s->stack_critic = critic;
     for (int l = 0; l < SGRL_SET_LAYERS; l++) {
       hipLaunchKernelGGL(k_stack_proj, dim3(32), dim3(256), 0, st, s->WL(l, SGRL_SET_A_GPROJ), (const float*)nullptr, D, D, site_w(2 * l));
       hipLaunchKernelGGL(k_stack_proj, dim3(32), dim3(256), 0, st, s->WL(l, SGRL_SET_F_GPROJ2), s->WL(l, SGRL_SET_F_GPROJ3), D, D, site_w(2 * l + 1));
     }
-    hipLaunchKernelGGL(k_stack_proj, dim3(36), dim3(256), 0, st, s->W(SGRL_SET_GGPROJ), s->W(SGRL_SET_GPROJ), 136, OGLD, site_w(6));
+    hipLaunchKernelGGL(k_stack_proj, dim3(36), dim3(256), 0, st, s->W(SGRL_SET_GGPROJ), critic ? (const float*)nullptr : s->W(SGRL_SET_GPROJ), 136, OGLD, site_w(6));
     s->stack_dirty = false;
   }
   auto pg = [&](const float* X, int ldx, int K, int site, float* z2) -> int {
@@ -612,19 +633,25 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   }
   // final norm -> outng[:, 17:145]; head
   hipLaunchKernelGGL(k_add_ln, dim3(lnb), dim3(256), 0, st, ng, 256, (const float*)nullptr, 0, s->W(SGRL_SET_FNORM_W),
-                     s->W(SGRL_SET_FNORM_B), (float*)nullptr, 0, s->outng + 17, 160, N);
+                     s->W(SGRL_SET_FNORM_B), (float*)nullptr, 0, s->outng + ngf, 160, N);
   fork();
   GS(s->outng, 160, s->W(SGRL_SET_L1NG_W), 160, s->W(SGRL_SET_L1NG_B), s->t128b, D, N, D, 160, EPI_RELU);
   GS(s->t128b, D, s->W(SGRL_SET_L2NG_W), D, s->W(SGRL_SET_L2NG_B), s->cat2 + 128, 256, N, D, D);
   hipLaunchKernelGGL(k_copy_g, dim3((N3 * D + 255) / 256), dim3(256), 0, st, s->g, s->outg, N3);
-  PG(s->outg, OGLD, OGLD, 6, s->z2);
+  PG(s->outg, OGLD, OGLD, 6, critic ? (float*)nullptr : s->z2);
   G(s->gram, GK, s->W(SGRL_SET_L1G_W), GK, s->W(SGRL_SET_L1G_B), s->t128a, D, N, D, GK, EPI_RELU);
   G(s->t128a, D, s->W(SGRL_SET_L2G_W), D, s->W(SGRL_SET_L2G_B), s->cat2, 256, N, D, D);
   join();
-  G(s->cat2, 256, s->W(SGRL_SET_L1M_W), 256, s->W(SGRL_SET_L1M_B), s->t256, 256, N, 256, 256, EPI_RELU);
-  G(s->t256, 256, s->W(SGRL_SET_L2M_W), 256, s->W(SGRL_SET_L2M_B), s->mat, 1024, N, 1024, 256, EPI_ROWDIV, s->fn);
-  hipLaunchKernelGGL(k_head_out, dim3((N + 3) / 4), dim3(128), 0, st, s->z2, s->mat, s->W(SGRL_SET_DECG), obs, obs_ld, nt,
-                     act, act_ld, max_action, N);
+  if (critic) {
+    // slots reused by the critic head: DECG = decoder_ng.weight [256], L1M_B = decoder_ng.bias [1]
+    hipLaunchKernelGGL(k_q_head, dim3((N + 3) / 4), dim3(256), 0, st, s->cat2, s->W(SGRL_SET_DECG), s->W(SGRL_SET_L1M_B), s->fn,
+                       nt, act, act_ld, N);
+  } else {
+    G(s->cat2, 256, s->W(SGRL_SET_L1M_W), 256, s->W(SGRL_SET_L1M_B), s->t256, 256, N, 256, 256, EPI_RELU);
+    G(s->t256, 256, s->W(SGRL_SET_L2M_W), 256, s->W(SGRL_SET_L2M_B), s->mat, 1024, N, 1024, 256, EPI_ROWDIV, s->fn);
+    hipLaunchKernelGGL(k_head_out, dim3((N + 3) / 4), dim3(128), 0, st, s->z2, s->mat, s->W(SGRL_SET_DECG), obs, obs_ld, nt,
+                       act, act_ld, max_action, N);
+  }
 #undef GS
 #undef G
 #undef PG
@@ -777,6 +804,13 @@ int sgrl_set_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int 
   if (!s || !obs || !act) return sfail(SGRL_ERR_ARG, "sgrl_set_forward: null argument");
   if (!s->have_w || !s->have_graph) return sfail(SGRL_ERR_ARG, "sgrl_set_forward: weights or graph not set");
   return run_forward(s, obs, obs_ld, act, act_ld, max_action, (hipStream_t)stream);
+}
+
+int sgrl_set_forward_q(sgrl_set* s, const float* obs, int obs_ld, const float* action, int action_ld, float* q, int q_ld,
+                       void* stream) {
+  if (!s || !obs || !action || !q) return sfail(SGRL_ERR_ARG, "sgrl_set_forward_q: null argument");
+  if (!s->have_w || !s->have_graph) return sfail(SGRL_ERR_ARG, "sgrl_set_forward_q: weights or graph not set");
+  return run_forward(s, obs, obs_ld, q, q_ld, 0.f, (hipStream_t)stream, true, action, action_ld);
 }
 
 int sgrl_set_time_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_ld, float max_action,

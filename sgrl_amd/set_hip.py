@@ -27,6 +27,7 @@ def _bind(L):
     L.sgrl_set_weights.argtypes = [vp, vp, vp, ctypes.c_int]
     L.sgrl_set_graph.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp]
     L.sgrl_set_forward.argtypes = [vp, vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_float, vp]
+    L.sgrl_set_forward_q.argtypes = [vp, vp, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_int, vp]
     L.sgrl_set_time_forward.argtypes = [vp, vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, vp,
                                         ctypes.POINTER(ctypes.c_float)]
     L.sgrl_set_num_nodes.argtypes = [vp]
@@ -54,8 +55,9 @@ def fold_gram_weight(w):
     return torch.cat([f, f.new_zeros(out_f, 544 - f.shape[1])], dim=1).contiguous()
 
 
-def pack_tensors(sd, prefix="actor."):
-    """[(tensor float32, ...)] in slot order (include/sgrl_set.h) from a state_dict-like mapping of torch tensors."""
+def pack_tensors(sd, prefix="actor.", critic=False):
+    """[(tensor float32, ...)] in slot order (include/sgrl_set.h) from a state_dict-like mapping of torch tensors.
+    critic=True packs a critic TransformerModel (scalar head: decoder_ng in the DECG / L1M_B slots, see sgrl_set.h)."""
     g = lambda k: sd[prefix + k].detach().float()
     out = [None] * NW
     out[0:3] = [g("pos_encoder.embeddings.%d.weight" % i) for i in range(3)]
@@ -67,9 +69,14 @@ def pack_tensors(sd, prefix="actor."):
     w = g("linear1_ng.weight")
     out[15] = torch.cat([w, w.new_zeros(w.shape[0], 160 - w.shape[1])], dim=1)
     out[16], out[17], out[18] = g("linear1_ng.bias"), g("linear2_ng.weight"), g("linear2_ng.bias")
-    out[19] = g("decoder_g.weight").reshape(-1)
-    out[20], out[21], out[22], out[23] = g("linear1_m.weight"), g("linear1_m.bias"), g("linear2_m.weight"), g("linear2_m.bias")
-    out[24] = g("g_proj.weight")
+    if critic:
+        z = w.new_zeros(1)
+        out[19], out[21] = g("decoder_ng.weight").reshape(-1), g("decoder_ng.bias").reshape(-1)
+        out[20], out[22], out[23], out[24] = z, z, z, z
+    else:
+        out[19] = g("decoder_g.weight").reshape(-1)
+        out[20], out[21], out[22], out[23] = g("linear1_m.weight"), g("linear1_m.bias"), g("linear2_m.weight"), g("linear2_m.bias")
+        out[24] = g("g_proj.weight")
     scaling = float(128) ** -0.5   # (2 * head_dim)^-0.5, reference subequivariant_attentions.py:88
     for l in range(LAYERS):
         p = "transformer_encoder.layers.%d." % l
@@ -92,13 +99,18 @@ def pack_tensors(sd, prefix="actor."):
 
 
 class HipSetActor(object):
-    def __init__(self, policy, device=None):
+    """HIP forward of one SET network: the actor of an `SEPolicy` (default) or, with `net=` / `critic=True`, one critic
+    `TransformerModel` of an `SECritic` (see `HipSetCritic`)."""
+
+    def __init__(self, policy, device=None, net=None, critic=False):
         if not torch.cuda.is_available():
             raise _lib.SgrlError("HipSetActor needs an MI355X (no CPU fallback)")
         self.L = _lib.lib()
         _bind(self.L)
         self.policy = policy
-        self.device = torch.device(device) if device is not None else next(policy.parameters()).device
+        self.net = net if net is not None else policy.actor
+        self.critic = bool(critic)
+        self.device = torch.device(device) if device is not None else next(self.net.parameters()).device
         if self.device.type != "cuda":
             raise _lib.SgrlError("the SEPolicy must live on the GPU for the HIP path")
         h = ctypes.c_void_p()
@@ -121,12 +133,12 @@ class HipSetActor(object):
 
     # ---- weights ------------------------------------------------------------------------------------
     def sync_weights(self, force=False):
-        params = list(self.policy.actor.parameters())
+        params = list(self.net.parameters())
         ver = (tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
         if not force and ver == self._wver:
             return
-        sd = {"actor." + k: v for k, v in self.policy.actor.state_dict().items()}
-        tens = pack_tensors(sd)
+        sd = {"actor." + k: v for k, v in self.net.state_dict().items()}
+        tens = pack_tensors(sd, critic=self.critic)
         offs = np.zeros(NW, dtype=np.int64)
         pos = 0
         for i, t in enumerate(tens):
@@ -183,6 +195,22 @@ class HipSetActor(object):
                "sgrl_set_forward")
         return out
 
+    def forward_q(self, obs, action, out=None, q_ld=None):
+        """critic network: obs [n_env, obs_ld], action [n_env, act_ld] (3 slots per limb) -> per-limb Q [n_env, q_ld]."""
+        assert self.critic, "forward_q needs a handle created with critic=True"
+        for t in (obs, action):
+            assert t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.shape[0] == self.n_env
+        self.sync_weights()
+        q_ld = q_ld or self.max_limbs
+        if out is None:
+            out = torch.empty((self.n_env, q_ld), dtype=torch.float32, device=self.device)
+        assert out.is_contiguous() and out.shape == (self.n_env, q_ld)
+        _check(self.L, self.L.sgrl_set_forward_q(self.h, ctypes.c_void_p(obs.data_ptr()), int(obs.stride(0)),
+                                                 ctypes.c_void_p(action.data_ptr()), int(action.stride(0)),
+                                                 ctypes.c_void_p(out.data_ptr()), int(q_ld), self._stream()),
+               "sgrl_set_forward_q")
+        return out
+
     def time_forward(self, obs, out, reps):
         self.sync_weights()
         ms = ctypes.c_float(0)
@@ -202,3 +230,30 @@ class HipSetActor(object):
         out = np.zeros((self.num_nodes, per_node), dtype=np.float32)
         _check(self.L, self.L.sgrl_set_peek(self.h, which, ctypes.c_void_p(out.ctypes.data), out.size), "sgrl_set_peek")
         return out
+
+
+class HipSetCritic(object):
+    """Twin critics of an `SECritic` on the HIP path (inference only: the TD3 target values, reference agent.py:136-148):
+    two handles, one per TransformerModel, sharing the batch structure."""
+
+    def __init__(self, critic_module, device=None):
+        self.q1 = HipSetActor(critic_module, device=device, net=critic_module.critic1, critic=True)
+        self.q2 = HipSetActor(critic_module, device=device, net=critic_module.critic2, critic=True)
+
+    def configure(self, graphs, counts):
+        self.q1.configure(graphs, counts)
+        self.q2.configure(graphs, counts)
+
+    def forward_batch(self, obs, action, q_ld=None, which=(1, 2)):
+        out = []
+        if 1 in which:
+            out.append(self.q1.forward_q(obs, action, q_ld=q_ld))
+        if 2 in which:
+            out.append(self.q2.forward_q(obs, action, q_ld=q_ld))
+        return tuple(out)
+
+    def forward_single(self, state, action, graph, which=(1, 2)):
+        """SECritic.forward(state [B, 41 L], action [B, 3 L]) for one morphology -> per-limb Q [B, L] each."""
+        B, L = state.shape[0], len(graph["parents"])
+        self.configure([graph], [B])
+        return self.forward_batch(state.contiguous().float(), action.contiguous().float(), q_ld=L, which=which)

@@ -270,9 +270,11 @@ class SECritic(nn.Module):
     [B, L], `Q1`, `change_morphology`.  Training-side code: plain differentiable PyTorch."""
 
     def __init__(self, state_dim, action_dim, msg_dim, batch_size, max_children, disable_fold, td, bu, args=None,
-                 device=None):
+                 device=None, use_hip=True):
         super().__init__()
         self.num_limbs = 1
+        self.use_hip = use_hip
+        self._hip = None
         self.msg_dim, self.batch_size, self.max_children = msg_dim, batch_size, max_children
         self.disable_fold = disable_fold
         self.state_dim, self.action_dim = state_dim, action_dim
@@ -295,12 +297,30 @@ class SECritic(nn.Module):
             "state.shape[1] expects {} but got {}".format(self.state_dim * self.num_limbs, state.shape[1])
         return torch.cat([state.reshape(B, self.num_limbs, -1), action.reshape(B, self.num_limbs, -1)], dim=2)
 
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d["_hip"] = None          # per-process device handles: never pickled / deep-copied with the module
+        return d
+
+    def _hip_path(self, state):
+        return self.use_hip and state.is_cuda and not torch.is_grad_enabled()
+
+    def _hip_handles(self):
+        from .set_hip import HipSetCritic   # raises SgrlError when the extension is missing (no fallback)
+        if self._hip is None:
+            self._hip = HipSetCritic(self)
+        return self._hip
+
     def forward(self, state, action):
+        if self._hip_path(state):           # target values under no_grad (reference agent.py:136-148): HIP kernels
+            return self._hip_handles().forward_single(state, action, self.graph)
         x = self._input(state, action)
         B = x.shape[0]
         return self.critic1(x, self.graph).reshape(B, -1), self.critic2(x, self.graph).reshape(B, -1)
 
     def Q1(self, state, action):
+        if self._hip_path(state):
+            return self._hip_handles().forward_single(state, action, self.graph, which=(1,))[0]
         x = self._input(state, action)
         return self.critic1(x, self.graph).reshape(x.shape[0], -1)
 
@@ -313,5 +333,5 @@ class SECritic(nn.Module):
         self.num_limbs = len(self.parents)
 
 
-def make_critic(device=None):
-    return SECritic(41, 3, 32, 1, 3, True, False, False, default_args(), device=device)
+def make_critic(device=None, use_hip=True):
+    return SECritic(41, 3, 32, 1, 3, True, False, False, default_args(), device=device, use_hip=use_hip)

@@ -147,3 +147,44 @@ def test_weights_are_repacked_after_an_in_place_update(ctx):
         c = p2(obs)
     assert float((a - b).abs().max()) > 1e-3
     assert float((b - c).abs().max()) < TOL
+
+
+def test_critic_hip_path_matches_reference_fixtures_and_torch_path():
+    """SECritic under no_grad on the GPU runs the HIP kernels (sgrl_set_forward_q); values against the fixtures produced
+    by executing the reference's SECritic (tests/golden/critic_forward.npz) and against the module's PyTorch path."""
+    import torch
+    from oracle.formula import apply_formula_
+    from sgrl_amd import graph as G, mjcf
+    from sgrl_amd.set_policy import make_critic
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "critic_forward.npz"))
+    crit = make_critic(device="cuda:0").eval()
+    apply_formula_(crit)
+    for name in sorted({k.split("/")[0] for k in z.files}):
+        m = mjcf.load_asset(name)
+        crit.change_morphology(G.getGraphDict(m.parents, ["pre", "inlcrs", "postlcrs"], [], device=torch.device("cuda:0")))
+        obs, act = torch.from_numpy(z[name + "/obs"]).cuda(), torch.from_numpy(z[name + "/act"]).cuda()
+        with torch.no_grad():
+            q1, q2 = crit(obs, act)                       # HIP path
+            q1b = crit.Q1(obs, act)
+        assert crit._hip is not None and q1.shape == (4, m.num_limbs)
+        crit.use_hip = False
+        with torch.no_grad():
+            t1, t2 = crit(obs, act)                       # PyTorch path, same weights
+        crit.use_hip = True
+        scale = np.abs(z[name + "/q1"]).max()
+        for got, ref in ((q1, z[name + "/q1"]), (q2, z[name + "/q2"]), (q1b, z[name + "/q1"])):
+            assert np.abs(got.cpu().numpy() - ref).max() < 2e-4 * scale, name
+        assert float((q1 - t1).abs().max()) < 2e-4 * scale and float((q2 - t2).abs().max()) < 2e-4 * scale
+    # in-place parameter update -> re-pack
+    with torch.no_grad():
+        crit.critic1.decoder_ng.bias.add_(0.5)
+        q1c = crit.Q1(obs, act)
+    crit.use_hip = False
+    with torch.no_grad():
+        t1c = crit.Q1(obs, act)
+    assert float((q1c - t1c).abs().max()) < 2e-4 * max(1.0, float(t1c.abs().max()))
+    assert float((q1c - q1).abs().max()) > 1e-3          # the bias reaches the output through 1 / fn
+    # grad mode keeps the differentiable path
+    crit.use_hip = True
+    q = crit.Q1(obs, act.clone().requires_grad_(True))
+    assert q.requires_grad
