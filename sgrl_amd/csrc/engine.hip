@@ -275,6 +275,7 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
     if (7 * v.njnt > 26 * v.npair) { rc = fail(SGRL_ERR_LIMIT, "model " + std::to_string(k) + ": joint rotations / axes do not fit the contact scratch (7 njnt > 26 npair)"); break; }
     if (3 * v.njnt > 10 * v.nbody) { rc = fail(SGRL_ERR_LIMIT, "model " + std::to_string(k) + ": joint positions do not fit the inertia scratch (3 njnt > 10 nbody)"); break; }
     if (v.nv > 64 || v.nbody > 64 || v.npair > 64) { rc = fail(SGRL_ERR_LIMIT, "morphology exceeds 64 dofs/bodies/pairs"); break; }
+    if ((v.nv | 1) > sgrl::kSlabLdy || ib[k][SGRL_H_MAX_ROWS] > sgrl::kSlabRows) { rc = fail(SGRL_ERR_LIMIT, "morphology exceeds the HBM constraint slab (nv <= 46, max_rows <= 64)"); break; }
     const int L = v.nbody - 1;
     if (41 * L > obs_max_len || 3 * L > action_max_len) { rc = fail(SGRL_ERR_ARG, "obs_max_len/action_max_len too small for morphology " + std::to_string(k)); break; }
     if (morph_count[k] < 0) { rc = fail(SGRL_ERR_ARG, "negative morph_count"); break; }

@@ -40,6 +40,8 @@ constexpr double kMaxImp = 0.9999;
 constexpr double kPi = 3.14159265358979323846;
 constexpr int kNAMax = 32;
 constexpr int kBppMaxIter = 40;
+constexpr int kSlabRows = 64;                     // most constraint rows an evaluation may have (HBM slab path)
+constexpr int kSlabLdy = 47;                      // largest Y row stride served: nv <= 46
 constexpr int kScratchDoubles = 5632;   // per-env HBM slab: A and its factor for up to 64 rows  // largest row count solved in the dense A = Y Y' + R form (packed lower triangle in LDS)
 
 // ------------------------------------------------------------------------------------------------
@@ -707,14 +709,17 @@ struct Engine {
     return Rows{S + o.Y, S + o.eR, S + o.earef, S + o.eb, S + o.ef, S + o.eidg, S + o.dead,
                 I + o.row_kind, I + o.row_src, I + o.row_sub, I + o.flist};
   }
-  SGRL_DEV Rows rows_hbm() const {   // slab: C[2080] | Y[65 * 47] | 5 x 64 doubles | 4 x 64 ints
+  SGRL_DEV Rows rows_hbm() const {   // slab: C[64*65/2] | Y[65][47] | 5 x 64 doubles | 4 x 64 ints
+    static_assert(kSlabRows * (kSlabRows + 1) / 2 + (kSlabRows + 1) * kSlabLdy + 5 * kSlabRows + 4 * kSlabRows / 2 <= kScratchDoubles,
+                  "HBM slab layout exceeds kScratchDoubles");
     double* p = big_scratch;
     Rows r;
-    r.C = p; p += 2080;
-    r.Y = p; p += 65 * 47;
-    r.eR = p; p += 64; r.earef = p; p += 64; r.eb = p; p += 64; r.ef = p; p += 64; r.eidg = p; p += 64;
+    r.C = p; p += kSlabRows * (kSlabRows + 1) / 2;
+    r.Y = p; p += (kSlabRows + 1) * kSlabLdy;
+    r.eR = p; p += kSlabRows; r.earef = p; p += kSlabRows; r.eb = p; p += kSlabRows; r.ef = p; p += kSlabRows;
+    r.eidg = p; p += kSlabRows;
     int32_t* q = reinterpret_cast<int32_t*>(p);
-    r.kind = q; r.src = q + 64; r.sub = q + 128; r.flist = q + 192;
+    r.kind = q; r.src = q + kSlabRows; r.sub = q + 2 * kSlabRows; r.flist = q + 3 * kSlabRows;
     return r;
   }
 

@@ -248,3 +248,11 @@ def test_mixed_families_use_separate_launch_groups_and_still_match_the_oracle():
             assert bool(done[i]) == d, (t, i)
             assert np.abs(obs[i, :o.size] - o).max() < 1e-5 * (1 + np.abs(o).max()), (t, i)
             assert (obs[i, o.size:] == 0).all()
+
+
+def test_limits_are_rejected_loudly():
+    """max_rows beyond what the HBM constraint slab serves is an error at create time, not silent contact dropping."""
+    from sgrl_amd._lib import SgrlError
+    from sgrl_amd.vec_env import BatchedModularVecEnv
+    with pytest.raises(SgrlError):
+        BatchedModularVecEnv(["3d_cheetah_14_full"], 2, seed=0, device="cuda:0", max_rows=80)
