@@ -225,6 +225,7 @@ def main():
         out.update(extra)
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()                     # rank 0's post-run kernel timings are done before any rank tears NCCL down
         dist.destroy_process_group()
 
 
