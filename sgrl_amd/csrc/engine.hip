@@ -330,13 +330,14 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
     for (int i = 0; i < e->n_env;) {
       sgrl_engine::Group g;
       g.first = i;
-      // From 6 workgroups per CU up a group also takes the next class: losing one of seven or eight workgroups on the
-      // lighter morphologies costs nothing measurable (walker mix: ONE dispatch at 7 per CU is as fast as two at 7 and
-      // 8), while at the low end (cheetahs at 3, 4 per CU) one workgroup less is a quarter of the occupancy.
+      // A batch whose costliest class already has 6+ workgroups per CU runs that class and the next as ONE dispatch:
+      // losing one of seven or eight workgroups on the lighter morphologies costs nothing measurable (walker mix: one
+      // dispatch at 7 per CU is as fast as two at 7 and 8).  Batches with heavier members (humanoid 5-6, cheetah 3-4 per
+      // CU) keep one dispatch per class: measured 7 % faster on the 23-morphology cwhh batch.
       const int c = cls[env_morph[order[i]]];
-      int top = c >= 6 ? c + 1 : c;
-      // SGRL_GROUP_POLICY=0: never merge (measured 7 % faster on the 23-morphology cwhh batch), =2: always merge adjacent
-      // classes (8 % faster on a cheetah-only batch); the default is the best of the three on the walker mix
+      const int c_min = cls[env_morph[order[0]]];
+      int top = (c == c_min && c >= 6) ? c + 1 : c;
+      // SGRL_GROUP_POLICY=0: never merge, =2: always merge adjacent classes (8 % faster on a cheetah-only batch)
       if (const char* pol = getenv("SGRL_GROUP_POLICY")) top = pol[0] == '0' ? c : (pol[0] == '2' ? c + 1 : top);
       while (i < e->n_env && cls[env_morph[order[i]]] <= top) { g.lds = std::max(g.lds, e->morph_lds[env_morph[order[i]]]); i++; }
       g.count = i - g.first;
