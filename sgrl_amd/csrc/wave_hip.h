@@ -156,8 +156,11 @@ struct HipWave {
   // true when a register version covers n (the caller falls back to its LDS factorisation otherwise)
   __device__ __forceinline__ bool chol_inv_packed(int n_in, double* P, double minval) {
     const int n = __builtin_amdgcn_readfirstlane(n_in);
-    if (n <= 12) chol_inv_reg<12>(n, P, minval);
+    if (n <= 9) chol_inv_reg<9>(n, P, minval);            // one instance per dof count of the shipped nv <= 24 morphologies
+    else if (n <= 12) chol_inv_reg<12>(n, P, minval);
+    else if (n <= 15) chol_inv_reg<15>(n, P, minval);
     else if (n <= 18) chol_inv_reg<18>(n, P, minval);
+    else if (n <= 21) chol_inv_reg<21>(n, P, minval);
     else if (n <= 24) chol_inv_reg<24>(n, P, minval);
     else return false;
     return true;
@@ -213,8 +216,11 @@ struct HipWave {
     return false;
 #endif
     const int n = __builtin_amdgcn_readfirstlane(n_in), nrhs = __builtin_amdgcn_readfirstlane(nrhs_in);
-    if (n <= 12) trmm_rows_reg<12>(nrhs, n, T, Y, ldy);
+    if (n <= 9) trmm_rows_reg<9>(nrhs, n, T, Y, ldy);
+    else if (n <= 12) trmm_rows_reg<12>(nrhs, n, T, Y, ldy);
+    else if (n <= 15) trmm_rows_reg<15>(nrhs, n, T, Y, ldy);
     else if (n <= 18) trmm_rows_reg<18>(nrhs, n, T, Y, ldy);
+    else if (n <= 21) trmm_rows_reg<21>(nrhs, n, T, Y, ldy);
     else if (n <= 24) trmm_rows_reg<24>(nrhs, n, T, Y, ldy);
     else return false;
     return true;
