@@ -162,10 +162,17 @@ SGRL_DEV void quat_mul(double* r, const double* a, const double* b) {
   const double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
   r[0] = w; r[1] = x; r[2] = y; r[3] = z;
 }
+SGRL_DEV double inv_sqrt(double x) {
+#ifdef __HIPCC__
+  return rsqrt(x);        // one transcendental + refinement instead of sqrt followed by a division (dependent chain)
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
 SGRL_DEV void quat_normalize(double* q) {
-  const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  if (n < kMinVal) { q[0] = 1; q[1] = 0; q[2] = 0; q[3] = 0; return; }
-  const double s = 1.0 / n;
+  const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (n2 < kMinVal * kMinVal) { q[0] = 1; q[1] = 0; q[2] = 0; q[3] = 0; return; }
+  const double s = inv_sqrt(n2);
   q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s;
 }
 SGRL_DEV void quat2mat(double* m, const double* q) {
