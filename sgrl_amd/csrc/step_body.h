@@ -126,13 +126,14 @@ SGRL_HD int workgroups_per_cu(int lds_bytes) {
   return per > 8 ? 8 : per;
 }
 
-// The layout with the LDS row arrays at their natural size (what the factor scratch can serve) -- or up to three rows
-// shorter when that is what it takes to fit one more workgroup per CU (e.g. cheetah_14: 54 000 B -> 53 584 B = 3 per CU).
-// Evaluations with more rows than the arrays hold use the HBM slab either way.
+// The layout with the LDS row arrays at their natural size (what the factor scratch can serve) -- or up to eight rows
+// shorter (never below 20) when that is what it takes to fit one more workgroup per CU: walker_7 22 392 B (32 rows, 7 per
+// CU) -> 20 344 B (24 rows, 8 per CU), measured 10 % faster on the walker mix although more evaluations (25..32 rows) then
+// take the HBM slab path.  Evaluations with more rows than the arrays hold use the slab either way: nothing is dropped.
 SGRL_HD void make_layout(const int32_t* hdr, Layout* o, int n_int = 0, int n_f64 = 0) {
   make_layout_rows(hdr, o, n_int, n_f64, 0);
   const int base = workgroups_per_cu(layout_bytes(o));
-  for (int cut = 1; cut <= 3 && o->lrows > 16; cut++) {
+  for (int cut = 1; cut <= 8 && o->lrows - cut >= 20; cut++) {
     Layout t;
     make_layout_rows(hdr, &t, n_int, n_f64, cut);
     if (workgroups_per_cu(layout_bytes(&t)) > base) { *o = t; return; }
