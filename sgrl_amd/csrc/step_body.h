@@ -938,7 +938,6 @@ struct Engine {
   // projected Gauss-Seidel converges to; PGS remains the fallback.
   template <bool SMALL>
   SGRL_DEV bool lcp_block_pivot(const Rows& R, int n, double thresh, int* iters_out) {
-    double* const C = R.C;
     double* const wvp = R.earef;          // scratch: reciprocal pivots / intermediate vector
     double* const xwp = S + o.prev_f;     // scratch: right-hand side -> solution (compact, free-set order)
     const int nv = o.nv, ldy = o.ldy;
@@ -947,6 +946,9 @@ struct Engine {
     for (int iter = 0; iter < kBppMaxIter; iter++) {
       w.fence_lane();            // nothing lane-dependent is carried across pivoting rounds (registers)
       const int nf = popcount64(F);
+      // factor scratch: the slab's own (LDS dead zone for the LDS rows).  Slab-path evaluations borrow the LDS dead zone
+      // too whenever the free set is small enough for it -- the elimination then runs out of LDS, not global memory.
+      double* const C = (!SMALL && nf <= o.na_max) ? S + o.dead : R.C;
       w.lanes(n, [&](int i) {
         if ((F >> i) & 1ull) {
           const int pos = popcount64(F & ((1ull << i) - 1ull));
