@@ -8,17 +8,23 @@
 //   auto-reset of reference src/subproc_vec_env.py:12-15,
 // i.e. 4 x mj_step (RK4 or semi-implicit Euler) of MuJoCo-style articulated rigid-body dynamics:
 // kinematics -> CRBA mass matrix -> Cholesky -> RNE bias -> collision -> soft-constraint rows ->
-// projected Gauss-Seidel -> integrate, then the 41-float-per-limb observation scatter, reward,
-// termination and counter-RNG reset.
+// dual LCP (block principal pivoting, projected Gauss-Seidel as fallback) -> integrate, then the
+// 41-float-per-limb observation scatter, reward, termination and counter-RNG reset.
 //
 // Parallel decomposition (lane = body | dof | contact pair | constraint row, depending on phase):
+//   joint rotations          : lane per hinge (sincos once per joint), constants staged in dead LDS arrays
 //   kinematics / velocities  : lane b walks its own root->b chain (no barriers inside)
 //   composite inertias       : lane b sums its pre-order-contiguous subtree
-//   mass matrix              : lane i fills row i along its dof-ancestor chain
-//   Cholesky                 : left-looking, lane i owns row i, one barrier per column
-//   half-solves Y = L^-1 J'  : lane r owns constraint row r (+ one extra row for the smooth force)
-//   PGS                      : lane d owns v[d] = (Y' f)[d]; row residual = wave reduction
+//   mass matrix              : lane i fills row i (packed lower triangle) along its dof-ancestor chain
+//   Cholesky                 : wave policy: registers, with the explicit inverse of the factor (nv <= 24);
+//                              else right-looking root-free elimination in LDS, one phase per pivot
+//   half-solves Y = L^-1 J'  : with L^-1: triangular matrix product (no recurrence); else lane r owns
+//                              constraint row r (+ one extra row for the smooth force)
+//   dual LCP                 : free set as a 64-bit ballot mask; A_FF formed from Y; factor + solve per round
+//   PGS (fallback)           : lane d owns v[d] = (Y' f)[d]; row residual = wave reduction
 //   observation              : lane per output float, coalesced store
+// Constraint rows live in LDS for the common case and in a per-environment HBM slab when an evaluation
+// has more rows than the LDS arrays hold (struct Rows): the stage is inlined once per variant.
 #pragma once
 
 #include <math.h>
@@ -38,11 +44,11 @@ constexpr double kMinVal = 1e-15;
 constexpr double kMinImp = 0.0001;
 constexpr double kMaxImp = 0.9999;
 constexpr double kPi = 3.14159265358979323846;
-constexpr int kNAMax = 32;
-constexpr int kBppMaxIter = 40;
+constexpr int kNAMax = 32;                        // most rows whose factor the LDS scratch (dead zone) is asked to hold
+constexpr int kBppMaxIter = 40;                   // block-pivot rounds before giving up (-> Gauss-Seidel)
 constexpr int kSlabRows = 64;                     // most constraint rows an evaluation may have (HBM slab path)
 constexpr int kSlabLdy = 47;                      // largest Y row stride served: nv <= 46
-constexpr int kScratchDoubles = 5632;   // per-env HBM slab: A and its factor for up to 64 rows  // largest row count solved in the dense A = Y Y' + R form (packed lower triangle in LDS)
+constexpr int kScratchDoubles = 5632;              // per-env HBM slab (Engine::rows_hbm): factor | Y | row arrays for 64 rows
 
 // ------------------------------------------------------------------------------------------------
 // LDS layout (offsets in doubles for S, in ints for I)
