@@ -65,7 +65,7 @@ struct GemmArgs {
 // whose 280 full tiles would otherwise quantise badly onto 256 CUs; <1, 1> = 128 x 64 for the narrow projections
 // (N <= 64), which would waste half or more of a 128-column tile.
 template <int FLAGS, int TM, int WN = 2>
-__global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_gemm(GemmArgs a) {
   constexpr int BNT = 64 * WN;
   constexpr int BMT = 32 * TM * (4 / WN);
   static_assert(BMT <= 128 && BNT <= 128, "LDS tiles hold at most 128 rows");
