@@ -53,8 +53,38 @@ enum {
 int sgrl_set_create(sgrl_set** out);
 void sgrl_set_destroy(sgrl_set* s);
 
-/* w: DEV float buffer (kept by reference: the caller keeps it alive); offsets: HOST int64[SGRL_SET_NW]. */
+/* w: DEV float buffer (kept by reference: the caller keeps it alive); offsets: HOST int64[SGRL_SET_NW].
+ * Static variant: the caller packs once and promises not to change the values behind `w`. */
 int sgrl_set_weights(sgrl_set* s, const float* w, const int64_t* offsets, int n_offsets);
+
+/* Live variant -- what an nn.Module binding should use (reference agent.py: the same modules are updated in place by
+ * the optimizers, agent.py:155-176, and by functional.soft_update_network's `target_param.data.copy_(...)`,
+ * common/functional.py:7-10, which no version counter reveals): the handle keeps the parameters' DEVICE addresses and
+ * rebuilds its flat weight buffer from them at the top of EVERY forward, on the forward's stream (one kernel, ~46 MB of
+ * traffic).  A segment describes one run of the flat buffer:
+ *   COPY   dst[i] = i < a ? src0[i] * scale : 0                        (plain tensors, QKV stacking, zero row padding)
+ *   PADCOL src0 [rows, a] -> dst [rows, b], zero columns appended      (L1NG_W)
+ *   FOLD   src0 [rows, 1024] -> dst [rows, 544] Gram-triangle folding  (A_LG1_W, F_LG1_W, L1G_W; see above)
+ *   STACK  dst [64, b]: rows 0..29 = src0 [30, a], rows 32..61 = src1 [30, a] or zero, columns a..b-1 zero
+ *          (the two 30-row projections of a proj+Gram site as ONE zero-padded GEMM operand)
+ * offsets: HOST int64[SGRL_SET_NW + SGRL_SET_NSITES] -- the slot table followed by the offsets of the seven stacked
+ * projection operands (sites 2l = attention g_proj of layer l [64,128]; 2l+1 = g_proj2 | g_proj3 [64,128];
+ * 6 = gg_proj | g_proj (actor) [64,144]).  The segments must cover [0, total_floats) entirely.  Parameter storage must
+ * stay allocated while the handle is bound; re-bind after anything that moves it (module.to(), new tensors). */
+enum { SGRL_PACK_COPY = 0, SGRL_PACK_PADCOL = 1, SGRL_PACK_FOLD = 2, SGRL_PACK_STACK = 3 };
+typedef struct sgrl_pack_seg {
+  int64_t dst;        /* first float of the run in the flat buffer */
+  const void* src0;   /* DEV float* */
+  const void* src1;   /* DEV float* or null (STACK) */
+  int32_t n;          /* floats in the run */
+  int32_t kind;
+  int32_t a, b;
+  float scale;        /* COPY */
+  int32_t reserved;
+} sgrl_pack_seg;
+#define SGRL_SET_NSITES 7
+int sgrl_set_bind_params(sgrl_set* s, const sgrl_pack_seg* segs, int n_segs, const int64_t* offsets, int n_offsets,
+                         int64_t total_floats);
 
 /* Batch structure (SEPolicy.change_morphology for every morphology at once, reference SEActor.py:349-355):
  *   n_morph, morph_L[n_morph] limbs, morph_count[n_morph] envs per morphology (env blocks in this order),
@@ -62,9 +92,15 @@ int sgrl_set_weights(sgrl_set* s, const float* w, const int64_t* offsets, int n_
  *   rel:  HOST float, per morphology L*L*3 relation tensor (graph_dict['relation']), concatenated. */
 int sgrl_set_graph(sgrl_set* s, int n_morph, const int32_t* morph_L, const int32_t* morph_count, const int32_t* trav,
                    const float* rel);
+/* The handle remembers the batch structures it has seen (keyed on the CONTENT of the arguments, up to
+ * SGRL_SET_GRAPH_CACHE of them): switching back to one -- the reference changes morphology before every select_action
+ * and every update, trainer.py:173-176,246-247 -- swaps a few pointers, with no device synchronisation, allocation or
+ * upload.  The workspace is shared and only ever grows. */
+#define SGRL_SET_GRAPH_CACHE 128
 
 /* actions[e, 0:3*L_e] = max_action * tanh(actor(obs[e, 0:41*L_e])), rest of the row zero.
- * obs: DEV float [n_env, obs_ld]; act: DEV float [n_env, act_ld]. */
+ * obs: DEV float [n_env, obs_ld]; act: DEV float [n_env, act_ld].  SGRL_ERR_ARG unless obs_ld >= 41 * Lmax and
+ * act_ld >= 3 * Lmax (Lmax = most limbs of the configured morphologies); likewise action_ld / q_ld (>= Lmax) below. */
 int sgrl_set_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_ld, float max_action, void* stream);
 
 /* Critic variant of the same network (reference src/SECritic.py:8-124: TransformerModel with feature_size 44 = 41

@@ -208,10 +208,10 @@ int launch_groups(sgrl_engine* e, K kernel, const StepOut& out, hipStream_t user
     for (auto& g : e->groups) {
       BatchArgs a = e->args;
       a.block_env = e->args.block_env + g.first;
-      (void)hipStreamWaitEvent(g.stream, e->fork, 0);
+      if (hipStreamWaitEvent(g.stream, e->fork, 0) != hipSuccess) return fail(SGRL_ERR_HIP, "hipStreamWaitEvent(fork) failed");
       hipLaunchKernelGGL(kernel, dim3(g.count), dim3(64), g.lds, g.stream, a, out);
-      (void)hipEventRecord(g.done, g.stream);
-      (void)hipStreamWaitEvent(user, g.done, 0);
+      if (hipEventRecord(g.done, g.stream) != hipSuccess || hipStreamWaitEvent(user, g.done, 0) != hipSuccess)
+        return fail(SGRL_ERR_HIP, "cannot join a launch group back to the caller's stream");
     }
   }
   if (hipGetLastError() != hipSuccess) return fail(SGRL_ERR_HIP, "kernel launch failed");
@@ -366,11 +366,17 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
     for (int i = 0; i < e->n_env; i++) cnt0[4 * (size_t)i + 1] = -1;  // episode = -1: the first reset bumps it to 0
     (void)hipMemcpy(e->d_cnt, cnt0.data(), sizeof(int32_t) * cnt0.size(), hipMemcpyHostToDevice);
   }
-  if (e->lds_bytes > 48 * 1024) {
-    hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_env_step), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
-    hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_env_reset), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
-    hipError_t a3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_env_refresh), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
-    if (a1 != hipSuccess || a2 != hipSuccess || a3 != hipSuccess) { sgrl_engine_destroy(e); return fail(SGRL_ERR_HIP, "cannot raise the dynamic LDS limit"); }
+  {
+    // hipFuncAttributeMaxDynamicSharedMemorySize is process-global per kernel: only ever RAISE it (a second engine with a
+    // smaller slab must not lower the limit under the first one's launches)
+    static int g_lds_limit = 48 * 1024;
+    if (e->lds_bytes > g_lds_limit) {
+      hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_env_step), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
+      hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_env_reset), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
+      hipError_t a3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_env_refresh), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
+      if (a1 != hipSuccess || a2 != hipSuccess || a3 != hipSuccess) { sgrl_engine_destroy(e); return fail(SGRL_ERR_HIP, "cannot raise the dynamic LDS limit"); }
+      g_lds_limit = e->lds_bytes;
+    }
   }
   BatchArgs& a = e->args;
   a.morphs = e->d_morphs; a.env_morph = e->d_env_morph; a.block_env = e->d_block_env; a.rec = e->d_rec; a.cnt = e->d_cnt; a.scratch = e->d_scratch;

@@ -10,6 +10,7 @@
 //   gram [N,1024]   Z'Z                          fn   [N]      ||Z'Z||_F + 1
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -256,6 +257,53 @@ __global__ void k_stack_proj(const float* __restrict__ Wp, const float* __restri
   }
 }
 
+// Live weight pack (sgrl_set_bind_params): every forward rebuilds the flat weight buffer from the parameters' OWN
+// storage, so in-place updates of any kind (optimizer steps, `target.data.copy_(...)` soft updates, load_state_dict)
+// are seen by the very next forward -- there is no host-side change detection to go stale.  ~46 MB of traffic (27 MB
+// read, 19 MB written): a few tens of microseconds per forward.  One block handles one PACK_CHUNK-element run of one segment.
+constexpr int PACK_CHUNK = 4096;
+__global__ __launch_bounds__(256) void k_pack(const sgrl_pack_seg* __restrict__ segs, const int2* __restrict__ chunks,
+                                              const unsigned short* __restrict__ tri, float* w) {
+  const int2 ch = chunks[blockIdx.x];
+  const sgrl_pack_seg sg = segs[ch.x];
+  const float* s0 = static_cast<const float*>(sg.src0);
+  const float* s1 = static_cast<const float*>(sg.src1);
+  const int end = min(ch.y + PACK_CHUNK, sg.n);
+  for (int i = ch.y + (int)threadIdx.x; i < end; i += 256) {
+    float v = 0.f;
+    switch (sg.kind) {
+      case SGRL_PACK_COPY:      // first `a` elements from src0 (scaled), zeros after (row padding)
+        if (i < sg.a) v = s0[i] * sg.scale;
+        break;
+      case SGRL_PACK_PADCOL: {  // [rows, a] -> [rows, b], zero columns appended
+        const int r = i / sg.b, c = i % sg.b;
+        if (c < sg.a) v = s0[(size_t)r * sg.a + c];
+        break;
+      }
+      case SGRL_PACK_FOLD: {    // [rows, 1024] acting on vec(G), G symmetric 32x32 -> [rows, 544] on its packed lower triangle
+        const int r = i / GK, k = i % GK;
+        const unsigned short t = tri[k];
+        if (t != 0xFFFF) {
+          const int aa = t >> 8, bb = t & 255;
+          const float* row = s0 + (size_t)r * (ZD * ZD);
+          v = (aa == bb) ? row[aa * ZD + bb] : row[aa * ZD + bb] + row[bb * ZD + aa];
+        }
+        break;
+      }
+      case SGRL_PACK_STACK: {   // out[64][b]: rows 0..29 = src0 [30, a], rows 32..61 = src1 [30, a] (if any), rest zero
+        const int r = i / sg.b, c = i % sg.b;
+        if (c < sg.a) {
+          if (r < 30) v = s0[r * sg.a + c];
+          else if (s1 && r >= 32 && r < 62) v = s1[(r - 32) * sg.a + c];
+        }
+        break;
+      }
+      default: break;
+    }
+    w[sg.dst + i] = v;
+  }
+}
+
 // gram: 8 nodes per 256-thread block.  Z = [X.Wp^T (from the MFMA GEMM, row stride ZLD) | gdir] (3x32); packed lower
 // triangle of Z'Z -> gram; fn = ||Z'Z||_F + 1.  With Z2 != null the second projection [X.Wq^T | gdir] is written out
 // compactly (kept for the equivariant update).  tri[o] = (a << 8 | b) of packed entry o, 0xFFFF for the K padding.
@@ -485,25 +533,53 @@ __global__ __launch_bounds__(256) void k_q_head(const float* __restrict__ c, con
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
+// One batch structure (sgrl_set_graph): the device tables of a (morphologies x env counts) configuration.
+struct GraphCfg {
+  std::vector<int32_t> key_i;   // n_morph | L[] | count[] | trav[]
+  std::vector<float> key_f;     // rel[]
+  int n_env = 0, N = 0, n_morph = 0, TM = 0, Lmax = 0;
+  int32_t *d_node_env = nullptr, *d_node_limb = nullptr, *d_node_mnode = nullptr, *d_trav = nullptr;
+  int32_t *d_env_off = nullptr, *d_env_L = nullptr, *d_env_relb = nullptr, *d_m_off = nullptr, *d_m_L = nullptr;
+  float *d_rel = nullptr, *d_relb = nullptr;
+  uint64_t last_use = 0;
+  void release() {
+    void* ptrs[] = {d_node_env, d_node_limb, d_node_mnode, d_trav, d_env_off, d_env_L, d_env_relb, d_m_off, d_m_L, d_rel, d_relb};
+    for (void* q : ptrs) if (q) (void)hipFree(q);
+  }
+};
+
 struct sgrl_set {
   const float* w = nullptr;
   int64_t off[SGRL_SET_NW];
   bool have_w = false, have_graph = false;
-  int n_env = 0, N = 0, n_morph = 0, TM = 0;
-  // device tables
+  // current batch structure (copied out of the cache entry by use_cfg)
+  int n_env = 0, N = 0, n_morph = 0, TM = 0, Lmax = 0;
   int32_t *d_node_env = nullptr, *d_node_limb = nullptr, *d_node_mnode = nullptr, *d_trav = nullptr;
   int32_t *d_env_off = nullptr, *d_env_L = nullptr, *d_env_relb = nullptr, *d_m_off = nullptr, *d_m_L = nullptr;
   float *d_rel = nullptr, *d_relb = nullptr;
-  // workspace
+  std::vector<GraphCfg*> cfgs;
+  uint64_t use_clock = 0;
+  // workspace: shared by all batch structures, grows only; carved for the current N
   float* ws = nullptr;
   int64_t ws_floats = 0;
+  int carved_N = 0;
+  bool ws_dirty = false;        // the carve-up changed: padding columns must be re-zeroed (next forward, on its stream)
   float *g, *cat, *cat2, *gram, *fn, *h256, *qkv, *vg, *attng, *attg, *g1, *z2, *mat, *t256, *t256b, *t128a, *t128b, *delta,
       *outg, *outng, *gdir, *zall;
-  // stacked projection weights of the 7 proj+gram sites (rebuilt on the forward stream after sgrl_set_weights)
+  // stacked projection weights of the 7 proj+gram sites: static weights -> own buffer rebuilt on the forward stream after
+  // sgrl_set_weights; live weights -> part of the flat buffer, rebuilt by k_pack with everything else
   float* wstack = nullptr;
+  const float* site_ptr[SGRL_SET_NSITES];
   unsigned short* d_tri = nullptr;
   bool stack_dirty = true;
   bool stack_critic = false;   // mode the stacked operands were built for
+  // live weights (sgrl_set_bind_params)
+  bool live = false;
+  float* wflat = nullptr;
+  int64_t wflat_floats = 0;
+  sgrl_pack_seg* d_segs = nullptr;
+  int2* d_chunks = nullptr;
+  int n_chunks = 0;
   // side stream for the GEMM chains that do not depend on each other (their epilogues / tile tails overlap)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -513,13 +589,18 @@ struct sgrl_set {
 
 namespace {
 
-void free_graph(sgrl_set* s) {
-  void* ptrs[] = {s->d_node_env, s->d_node_limb, s->d_node_mnode, s->d_trav, s->d_env_off, s->d_env_L, s->d_env_relb,
-                  s->d_m_off, s->d_m_L, s->d_rel, s->d_relb, s->ws};
-  for (void* p : ptrs) if (p) (void)hipFree(p);
-  s->d_node_env = s->d_node_limb = s->d_node_mnode = s->d_trav = s->d_env_off = s->d_env_L = s->d_env_relb = nullptr;
-  s->d_m_off = s->d_m_L = nullptr;
-  s->d_rel = s->d_relb = s->ws = nullptr;
+constexpr int64_t kPerNodeFloats = 384 /*g*/ + 256 + 256 /*cat, cat2*/ + 1024 /*gram*/ + 1 /*fn*/ + 256 /*h256*/ + 768 /*qkv*/ +
+                                   768 /*vg*/ + 256 /*attng*/ + 768 /*attg*/ + 384 /*g1*/ + 96 /*z2*/ + 1024 /*mat*/ + 256 + 256 /*t256, t256b*/ +
+                                   128 + 128 + 128 /*t128a,b,delta*/ + 3 * OGLD /*outg*/ + 160 /*outng*/ + 6 /*gdir*/ + 3 * ZLD /*zall*/;
+constexpr int kWsArrays = 22;
+
+int64_t ws_floats_for(int64_t N) { return kPerNodeFloats * N + 32 * kWsArrays; }
+
+void free_graphs(sgrl_set* s) {
+  for (GraphCfg* c : s->cfgs) { c->release(); delete c; }
+  s->cfgs.clear();
+  if (s->ws) (void)hipFree(s->ws);
+  s->ws = nullptr; s->ws_floats = 0; s->carved_N = 0;
   s->have_graph = false;
 }
 
@@ -528,6 +609,36 @@ int upload(T** dst, const std::vector<T>& v) {
   if (hipMalloc(dst, sizeof(T) * (v.size() ? v.size() : 1)) != hipSuccess) return -1;
   if (!v.empty() && hipMemcpy(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
   return 0;
+}
+
+// point the handle at a cached batch structure; (re)carve the shared workspace for its node count
+int use_cfg(sgrl_set* s, GraphCfg* c) {
+  const int64_t N = c->N;
+  const int64_t need = ws_floats_for(N);
+  if (need > s->ws_floats) {
+    if (s->ws) (void)hipFree(s->ws);       // hipFree waits for the device: no kernel still reads the old block
+    s->ws = nullptr; s->ws_floats = 0; s->carved_N = 0;
+    if (hipMalloc(&s->ws, sizeof(float) * need) != hipSuccess) return sfail(SGRL_ERR_HIP, "device allocation failed (SET workspace)");
+    s->ws_floats = need;
+  }
+  if (s->carved_N != c->N) {
+    float* p = s->ws;
+    auto take = [&](int64_t n) { float* r = p; p += (n + 31) & ~int64_t(31); return r; };
+    s->g = take(384 * N); s->cat = take(256 * N); s->cat2 = take(256 * N); s->gram = take(1024 * N); s->fn = take(N);
+    s->h256 = take(256 * N); s->qkv = take(768 * N); s->vg = take(768 * N); s->attng = take(256 * N); s->attg = take(768 * N);
+    s->g1 = take(384 * N); s->z2 = take(96 * N); s->mat = take(1024 * N); s->t256 = take(256 * N); s->t256b = take(256 * N); s->t128a = take(128 * N);
+    s->t128b = take(128 * N); s->delta = take(128 * N); s->outg = take(3 * OGLD * N); s->outng = take(160 * N); s->gdir = take(6 * N); s->zall = take(3 * ZLD * N);
+    if (p - s->ws > s->ws_floats) return sfail(SGRL_ERR_LIMIT, "workspace carve-up overflow");
+    s->carved_N = c->N;
+    s->ws_dirty = true;
+  }
+  s->n_env = c->n_env; s->N = c->N; s->n_morph = c->n_morph; s->TM = c->TM; s->Lmax = c->Lmax;
+  s->d_node_env = c->d_node_env; s->d_node_limb = c->d_node_limb; s->d_node_mnode = c->d_node_mnode; s->d_trav = c->d_trav;
+  s->d_env_off = c->d_env_off; s->d_env_L = c->d_env_L; s->d_env_relb = c->d_env_relb; s->d_m_off = c->d_m_off; s->d_m_L = c->d_m_L;
+  s->d_rel = c->d_rel; s->d_relb = c->d_relb;
+  c->last_use = ++s->use_clock;
+  s->have_graph = true;
+  return SGRL_OK;
 }
 
 int launch_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc,
@@ -565,6 +676,12 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   NodeTab nt{s->d_node_env, s->d_node_limb, s->d_node_mnode, s->d_trav, s->TM};
   EnvTab et{s->d_env_off, s->d_env_L, s->d_env_relb};
   (void)hipMemsetAsync(act, 0, sizeof(float) * (size_t)s->n_env * act_ld, st);
+  if (s->ws_dirty) {     // new carve-up of the shared workspace: the K-padding columns of its arrays must read zero
+    (void)hipMemsetAsync(s->ws, 0, sizeof(float) * s->ws_floats, st);
+    s->ws_dirty = false;
+  }
+  if (s->live)           // live weights: flat buffer (and the stacked projection operands in it) rebuilt from the parameters
+    hipLaunchKernelGGL(k_pack, dim3(s->n_chunks), dim3(256), 0, st, s->d_segs, s->d_chunks, s->d_tri, s->wflat);
   hipLaunchKernelGGL(k_relbias, dim3(s->n_morph), dim3(256), 0, st, s->d_rel, s->W(SGRL_SET_REL_W), s->W(SGRL_SET_REL_B),
                      s->d_relb, s->d_m_off, s->d_m_L, s->n_morph);
   hipLaunchKernelGGL(k_embed, dim3(N), dim3(128), 0, st, obs, obs_ld, action, action_ld, ngf, nt, s->W(SGRL_SET_GENC), s->W(SGRL_SET_ENC_W),
@@ -575,14 +692,17 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
 #define G(...) do { rc = launch_gemm(st, __VA_ARGS__); if (rc != SGRL_OK) return rc; } while (0)
   // proj + gram site: Z (and Z2) = X . [Wp; Wq]^T on the matrix cores (stacked, zero-padded weights), then the packed
   // Gram triangle per node
-  auto site_w = [&](int site) { return s->wstack + (size_t)site * 64 * 128; };   // site 6 (the head, Cpad 144) is last
-  if (s->stack_dirty || s->stack_critic != critic) {
+  auto site_w = [&](int site) -> const float* {   // site 6 (the head, Cpad 144) is last
+    return s->live ? s->site_ptr[site] : s->wstack + (size_t)site * 64 * 128;
+  };
+  if (!s->live && (s->stack_dirty || s->stack_critic != critic)) {
     s->stack_critic = critic;
+    auto sw = [&](int site) { return s->wstack + (size_t)site * 64 * 128; };
     for (int l = 0; l < SGRL_SET_LAYERS; l++) {
-      hipLaunchKernelGGL(k_stack_proj, dim3(32), dim3(256), 0, st, s->WL(l, SGRL_SET_A_GPROJ), (const float*)nullptr, D, D, site_w(2 * l));
-      hipLaunchKernelGGL(k_stack_proj, dim3(32), dim3(256), 0, st, s->WL(l, SGRL_SET_F_GPROJ2), s->WL(l, SGRL_SET_F_GPROJ3), D, D, site_w(2 * l + 1));
+      hipLaunchKernelGGL(k_stack_proj, dim3(32), dim3(256), 0, st, s->WL(l, SGRL_SET_A_GPROJ), (const float*)nullptr, D, D, sw(2 * l));
+      hipLaunchKernelGGL(k_stack_proj, dim3(32), dim3(256), 0, st, s->WL(l, SGRL_SET_F_GPROJ2), s->WL(l, SGRL_SET_F_GPROJ3), D, D, sw(2 * l + 1));
     }
-    hipLaunchKernelGGL(k_stack_proj, dim3(36), dim3(256), 0, st, s->W(SGRL_SET_GGPROJ), critic ? (const float*)nullptr : s->W(SGRL_SET_GPROJ), 136, OGLD, site_w(6));
+    hipLaunchKernelGGL(k_stack_proj, dim3(36), dim3(256), 0, st, s->W(SGRL_SET_GGPROJ), critic ? (const float*)nullptr : s->W(SGRL_SET_GPROJ), 136, OGLD, sw(6));
     s->stack_dirty = false;
   }
   auto pg = [&](const float* X, int ldx, int K, int site, float* z2) -> int {
@@ -706,10 +826,14 @@ int sgrl_set_create(sgrl_set** out) {
 
 void sgrl_set_destroy(sgrl_set* s) {
   if (!s) return;
-  free_graph(s);
+  if (s->side) (void)hipStreamSynchronize(s->side);
+  free_graphs(s);
   if (s->wstack) (void)hipFree(s->wstack);
   if (s->d_tri) (void)hipFree(s->d_tri);
-  if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); }
+  if (s->wflat) (void)hipFree(s->wflat);
+  if (s->d_segs) (void)hipFree(s->d_segs);
+  if (s->d_chunks) (void)hipFree(s->d_chunks);
+  if (s->side) (void)hipStreamDestroy(s->side);
   if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   delete s;
@@ -720,28 +844,92 @@ int sgrl_set_weights(sgrl_set* s, const float* w, const int64_t* offsets, int n_
   s->w = w;
   std::memcpy(s->off, offsets, sizeof(int64_t) * SGRL_SET_NW);
   s->have_w = true;
+  s->live = false;
   s->stack_dirty = true;   // the stacked projection operands are rebuilt by the next forward, on its stream
+  return SGRL_OK;
+}
+
+int sgrl_set_bind_params(sgrl_set* s, const sgrl_pack_seg* segs, int n_segs, const int64_t* offsets, int n_offsets,
+                         int64_t total_floats) {
+  if (!s || !segs || n_segs <= 0 || !offsets || n_offsets != SGRL_SET_NW + SGRL_SET_NSITES || total_floats <= 0)
+    return sfail(SGRL_ERR_ARG, "sgrl_set_bind_params: bad argument");
+  // the segments must tile [0, total_floats) exactly (sorted by dst): every float of the buffer is rewritten per forward
+  std::vector<int> order(n_segs);
+  for (int i = 0; i < n_segs; i++) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](int x, int y) { return segs[x].dst < segs[y].dst; });
+  int64_t pos = 0;
+  std::vector<int2> chunks;
+  for (int oi = 0; oi < n_segs; oi++) {
+    const sgrl_pack_seg& g = segs[order[oi]];
+    if (g.dst != pos || g.n <= 0 || !g.src0) return sfail(SGRL_ERR_ARG, "sgrl_set_bind_params: segments must tile the buffer without gaps");
+    bool ok = false;
+    switch (g.kind) {
+      case SGRL_PACK_COPY: ok = g.a >= 0 && g.a <= g.n; break;
+      case SGRL_PACK_PADCOL: ok = g.a > 0 && g.b >= g.a && g.n % g.b == 0; break;
+      case SGRL_PACK_FOLD: ok = g.n % GK == 0; break;
+      case SGRL_PACK_STACK: ok = g.a > 0 && g.b >= g.a && g.n == 64 * g.b; break;
+      default: break;
+    }
+    if (!ok) return sfail(SGRL_ERR_ARG, "sgrl_set_bind_params: inconsistent segment " + std::to_string(order[oi]));
+    for (int st = 0; st < g.n; st += PACK_CHUNK) chunks.push_back(make_int2(order[oi], st));
+    pos += g.n;
+  }
+  if (pos != total_floats) return sfail(SGRL_ERR_ARG, "sgrl_set_bind_params: segments do not add up to total_floats");
+  for (int k = 0; k < n_offsets; k++)
+    if (offsets[k] < 0 || offsets[k] >= total_floats || (offsets[k] & 3)) return sfail(SGRL_ERR_ARG, "sgrl_set_bind_params: bad offset");
+  // replace the previous binding (a forward may still be reading it: hipFree waits for the device)
+  if (s->wflat) (void)hipFree(s->wflat);
+  if (s->d_segs) (void)hipFree(s->d_segs);
+  if (s->d_chunks) (void)hipFree(s->d_chunks);
+  s->wflat = nullptr; s->d_segs = nullptr; s->d_chunks = nullptr; s->live = false; s->have_w = false;
+  if (hipMalloc(&s->wflat, sizeof(float) * total_floats) != hipSuccess ||
+      hipMalloc(&s->d_segs, sizeof(sgrl_pack_seg) * n_segs) != hipSuccess ||
+      hipMalloc(&s->d_chunks, sizeof(int2) * chunks.size()) != hipSuccess ||
+      hipMemcpy(s->d_segs, segs, sizeof(sgrl_pack_seg) * n_segs, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(s->d_chunks, chunks.data(), sizeof(int2) * chunks.size(), hipMemcpyHostToDevice) != hipSuccess)
+    return sfail(SGRL_ERR_HIP, "device allocation failed in sgrl_set_bind_params");
+  s->wflat_floats = total_floats;
+  s->n_chunks = (int)chunks.size();
+  s->w = s->wflat;
+  std::memcpy(s->off, offsets, sizeof(int64_t) * SGRL_SET_NW);
+  for (int k = 0; k < SGRL_SET_NSITES; k++) s->site_ptr[k] = s->wflat + offsets[SGRL_SET_NW + k];
+  s->live = true;
+  s->have_w = true;
   return SGRL_OK;
 }
 
 int sgrl_set_graph(sgrl_set* s, int n_morph, const int32_t* morph_L, const int32_t* morph_count, const int32_t* trav,
                    const float* rel) {
   if (!s || n_morph <= 0 || !morph_L || !morph_count || !trav || !rel) return sfail(SGRL_ERR_ARG, "sgrl_set_graph: bad argument");
-  SHIP_TRY(hipDeviceSynchronize());
-  free_graph(s);
-  std::vector<int32_t> node_env, node_limb, node_mnode, env_off, env_L, env_relb, m_off, m_L, travT;
-  int TM = 0, relb_off = 0, env = 0, node = 0;
-  std::vector<int> m_node0;
+  // content key of the request
+  std::vector<int32_t> key_i;
+  size_t ntrav = 0, nrel = 0;
   for (int k = 0; k < n_morph; k++) {
     if (morph_L[k] < 2 || morph_L[k] > 14) return sfail(SGRL_ERR_LIMIT, "limb count must be in [2, 14]");
+    if (morph_count[k] < 0) return sfail(SGRL_ERR_ARG, "negative morph_count");
+    ntrav += 3 * (size_t)morph_L[k];
+    nrel += 3 * (size_t)morph_L[k] * morph_L[k];
+  }
+  key_i.push_back(n_morph);
+  key_i.insert(key_i.end(), morph_L, morph_L + n_morph);
+  key_i.insert(key_i.end(), morph_count, morph_count + n_morph);
+  key_i.insert(key_i.end(), trav, trav + ntrav);
+  for (GraphCfg* c : s->cfgs)
+    if (c->key_i == key_i && c->key_f.size() == nrel && std::memcmp(c->key_f.data(), rel, sizeof(float) * nrel) == 0)
+      return use_cfg(s, c);        // seen before: no allocation, upload or synchronisation
+  // new batch structure: build and upload its tables once
+  std::vector<int32_t> node_env, node_limb, node_mnode, env_off, env_L, env_relb, m_off, m_L, travT;
+  int TM = 0, relb_off = 0, env = 0, node = 0, Lmax = 0;
+  std::vector<int> m_node0;
+  for (int k = 0; k < n_morph; k++) {
     m_node0.push_back(TM);
     m_off.push_back(relb_off);
     m_L.push_back(morph_L[k]);
     TM += morph_L[k];
     relb_off += 2 * morph_L[k] * morph_L[k];
+    if (morph_L[k] > Lmax) Lmax = morph_L[k];
   }
   travT.assign(3 * (size_t)TM, 0);
-  std::vector<float> relv;
   {
     size_t tp = 0;
     for (int k = 0; k < n_morph; k++) {
@@ -754,9 +942,6 @@ int sgrl_set_graph(sgrl_set* s, int n_morph, const int32_t* morph_L, const int32
         }
       tp += 3 * (size_t)L;
     }
-    size_t rp = 0;
-    for (int k = 0; k < n_morph; k++) rp += (size_t)morph_L[k] * morph_L[k] * 3;
-    relv.assign(rel, rel + rp);
   }
   for (int k = 0; k < n_morph; k++) {
     for (int c = 0; c < morph_count[k]; c++) {
@@ -773,36 +958,32 @@ int sgrl_set_graph(sgrl_set* s, int n_morph, const int32_t* morph_L, const int32
     }
   }
   if (node == 0) return sfail(SGRL_ERR_ARG, "no environments");
-  s->n_env = env; s->N = node; s->n_morph = n_morph; s->TM = TM;
-  bool ok = upload(&s->d_node_env, node_env) == 0 && upload(&s->d_node_limb, node_limb) == 0 &&
-            upload(&s->d_node_mnode, node_mnode) == 0 && upload(&s->d_trav, travT) == 0 &&
-            upload(&s->d_env_off, env_off) == 0 && upload(&s->d_env_L, env_L) == 0 && upload(&s->d_env_relb, env_relb) == 0 &&
-            upload(&s->d_m_off, m_off) == 0 && upload(&s->d_m_L, m_L) == 0 && upload(&s->d_rel, relv) == 0;
-  if (ok) ok = hipMalloc(&s->d_relb, sizeof(float) * relb_off) == hipSuccess;
-  // workspace carve-up (floats per node)
-  const int64_t N = node;
-  const int64_t per_node = 384 /*g*/ + 256 + 256 /*cat, cat2*/ + 1024 /*gram*/ + 1 /*fn*/ + 256 /*h256*/ + 768 /*qkv*/ +
-                           768 /*vg*/ + 256 /*attng*/ + 768 /*attg*/ + 384 /*g1*/ + 96 /*z2*/ + 1024 /*mat*/ + 256 + 256 /*t256, t256b*/ +
-                           128 + 128 + 128 /*t128a,b,delta*/ + 3 * OGLD /*outg*/ + 160 /*outng*/ + 6 /*gdir*/ + 3 * ZLD /*zall*/;
-  s->ws_floats = per_node * N + 64 * 32;
-  if (ok) ok = hipMalloc(&s->ws, sizeof(float) * s->ws_floats) == hipSuccess;
-  if (!ok) { free_graph(s); return sfail(SGRL_ERR_HIP, "device allocation failed in sgrl_set_graph"); }
-  (void)hipMemset(s->ws, 0, sizeof(float) * s->ws_floats);
-  float* p = s->ws;
-  auto take = [&](int64_t n) { float* r = p; p += (n + 31) & ~int64_t(31); return r; };
-  s->g = take(384 * N); s->cat = take(256 * N); s->cat2 = take(256 * N); s->gram = take(1024 * N); s->fn = take(N);
-  s->h256 = take(256 * N); s->qkv = take(768 * N); s->vg = take(768 * N); s->attng = take(256 * N); s->attg = take(768 * N);
-  s->g1 = take(384 * N); s->z2 = take(96 * N); s->mat = take(1024 * N); s->t256 = take(256 * N); s->t256b = take(256 * N); s->t128a = take(128 * N);
-  s->t128b = take(128 * N); s->delta = take(128 * N); s->outg = take(3 * OGLD * N); s->outng = take(160 * N); s->gdir = take(6 * N); s->zall = take(3 * ZLD * N);
-  if (p - s->ws > s->ws_floats) { free_graph(s); return sfail(SGRL_ERR_LIMIT, "workspace carve-up overflow"); }
-  SHIP_TRY(hipDeviceSynchronize());
-  s->have_graph = true;
-  return SGRL_OK;
+  if ((int)s->cfgs.size() >= SGRL_SET_GRAPH_CACHE) {      // evict the least recently used structure
+    size_t lru = 0;
+    for (size_t i = 1; i < s->cfgs.size(); i++) if (s->cfgs[i]->last_use < s->cfgs[lru]->last_use) lru = i;
+    s->cfgs[lru]->release();                              // hipFree waits for the device
+    delete s->cfgs[lru];
+    s->cfgs.erase(s->cfgs.begin() + lru);
+  }
+  GraphCfg* c = new GraphCfg();
+  c->key_i = std::move(key_i);
+  c->key_f.assign(rel, rel + nrel);
+  c->n_env = env; c->N = node; c->n_morph = n_morph; c->TM = TM; c->Lmax = Lmax;
+  bool ok = upload(&c->d_node_env, node_env) == 0 && upload(&c->d_node_limb, node_limb) == 0 &&
+            upload(&c->d_node_mnode, node_mnode) == 0 && upload(&c->d_trav, travT) == 0 &&
+            upload(&c->d_env_off, env_off) == 0 && upload(&c->d_env_L, env_L) == 0 && upload(&c->d_env_relb, env_relb) == 0 &&
+            upload(&c->d_m_off, m_off) == 0 && upload(&c->d_m_L, m_L) == 0 && upload(&c->d_rel, c->key_f) == 0;
+  if (ok) ok = hipMalloc(&c->d_relb, sizeof(float) * relb_off) == hipSuccess;
+  if (!ok) { c->release(); delete c; return sfail(SGRL_ERR_HIP, "device allocation failed in sgrl_set_graph"); }
+  s->cfgs.push_back(c);
+  return use_cfg(s, c);
 }
 
 int sgrl_set_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_ld, float max_action, void* stream) {
   if (!s || !obs || !act) return sfail(SGRL_ERR_ARG, "sgrl_set_forward: null argument");
   if (!s->have_w || !s->have_graph) return sfail(SGRL_ERR_ARG, "sgrl_set_forward: weights or graph not set");
+  if (obs_ld < 41 * s->Lmax || act_ld < 3 * s->Lmax)
+    return sfail(SGRL_ERR_ARG, "sgrl_set_forward: obs_ld < 41 * Lmax or act_ld < 3 * Lmax (rows too narrow for the largest morphology)");
   return run_forward(s, obs, obs_ld, act, act_ld, max_action, (hipStream_t)stream);
 }
 
@@ -810,6 +991,8 @@ int sgrl_set_forward_q(sgrl_set* s, const float* obs, int obs_ld, const float* a
                        void* stream) {
   if (!s || !obs || !action || !q) return sfail(SGRL_ERR_ARG, "sgrl_set_forward_q: null argument");
   if (!s->have_w || !s->have_graph) return sfail(SGRL_ERR_ARG, "sgrl_set_forward_q: weights or graph not set");
+  if (obs_ld < 41 * s->Lmax || action_ld < 3 * s->Lmax || q_ld < s->Lmax)
+    return sfail(SGRL_ERR_ARG, "sgrl_set_forward_q: obs_ld < 41 * Lmax, action_ld < 3 * Lmax or q_ld < Lmax");
   return run_forward(s, obs, obs_ld, q, q_ld, 0.f, (hipStream_t)stream, true, action, action_ld);
 }
 
@@ -817,6 +1000,7 @@ int sgrl_set_time_forward(sgrl_set* s, const float* obs, int obs_ld, float* act,
                           int reps, void* stream, float* ms_out) {
   if (!s || !obs || !act || !ms_out || reps <= 0) return sfail(SGRL_ERR_ARG, "sgrl_set_time_forward: bad argument");
   if (!s->have_w || !s->have_graph) return sfail(SGRL_ERR_ARG, "weights or graph not set");
+  if (obs_ld < 41 * s->Lmax || act_ld < 3 * s->Lmax) return sfail(SGRL_ERR_ARG, "sgrl_set_time_forward: rows too narrow for the largest morphology");
   hipEvent_t t0, t1;
   SHIP_TRY(hipEventCreate(&t0));
   SHIP_TRY(hipEventCreate(&t1));

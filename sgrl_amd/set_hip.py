@@ -1,10 +1,12 @@
 """Python front-end of the HIP SET-actor forward (C ABI: include/sgrl_set.h).
 
-`HipSetActor` packs the parameters of an `SEPolicy` (set_policy.py, reference-compatible state_dict) into the flat
-device buffer the kernels expect, re-packing automatically when the parameters change (optimizer steps bump the
-tensors' version counters), describes the batch structure (morphologies x env counts) to the engine and runs
-`actions = max_action * tanh(actor(obs))` for all environments in one call.  No CPU fallback: a missing extension
-or device raises `SgrlError`.
+`HipSetActor` binds the parameters of an `SEPolicy` (set_policy.py, reference-compatible state_dict) to a handle:
+it hands the library the DEVICE ADDRESSES of the parameters and a packing plan (`plan_segments`), and the library
+rebuilds its flat weight buffer from the live storage at the top of every forward -- so optimizer steps, the
+reference's `target_param.data.copy_(...)` soft updates (common/functional.py:7-10, invisible to version counters)
+and `load_state_dict` are all seen by the next call.  It also describes the batch structure (morphologies x env
+counts) to the engine and runs `actions = max_action * tanh(actor(obs))` for all environments in one call.
+No CPU fallback: a missing extension or device raises `SgrlError`.
 """
 import ctypes
 
@@ -25,6 +27,7 @@ def _bind(L):
     L.sgrl_set_destroy.argtypes = [vp]
     L.sgrl_set_destroy.restype = None
     L.sgrl_set_weights.argtypes = [vp, vp, vp, ctypes.c_int]
+    L.sgrl_set_bind_params.argtypes = [vp, vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int64]
     L.sgrl_set_graph.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp]
     L.sgrl_set_forward.argtypes = [vp, vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_float, vp]
     L.sgrl_set_forward_q.argtypes = [vp, vp, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_int, vp]
@@ -98,6 +101,124 @@ def pack_tensors(sd, prefix="actor.", critic=False):
     return out
 
 
+NSITES = 7
+PACK_COPY, PACK_PADCOL, PACK_FOLD, PACK_STACK = 0, 1, 2, 3
+# struct sgrl_pack_seg (include/sgrl_set.h)
+SEG_DTYPE = np.dtype([("dst", "<i8"), ("src0", "<u8"), ("src1", "<u8"), ("n", "<i4"), ("kind", "<i4"), ("a", "<i4"),
+                      ("b", "<i4"), ("scale", "<f4"), ("reserved", "<i4")])
+assert SEG_DTYPE.itemsize == 48
+
+
+def plan_segments(net, critic=False):
+    """The packing plan of one SET network: (segments, offsets[NW + NSITES], total_floats, sources).
+
+    Same layout as `pack_tensors` (slot order of include/sgrl_set.h, every slot 256-byte aligned) followed by the seven
+    stacked projection operands, expressed as runs whose SOURCE is the parameter's own storage (`data_ptr()`), so the
+    library can rebuild the buffer on the device whenever it wants."""
+    sd = dict(net.named_parameters())
+    segs, srcs, offs, pos = [], [], np.zeros(NW + NSITES, dtype=np.int64), [0]
+
+    def p(name):
+        t = sd[name]
+        assert t.dtype == torch.float32 and t.is_contiguous(), "SET parameters must be contiguous float32: " + name
+        return t
+
+    def emit(kind, t0, n, a=0, b=0, scale=1.0, t1=None):
+        segs.append((pos[0], t0.data_ptr(), 0 if t1 is None else t1.data_ptr(), n, kind, a, b, scale, 0))
+        srcs.append((t0, t1))
+        pos[0] += n
+
+    anchor = p("g_encoder.weight")
+
+    def align():
+        fill = (-pos[0]) % 64
+        if fill:
+            emit(PACK_COPY, anchor, fill, a=0)
+
+    def copy(name, scale=1.0, n=None):
+        t = p(name)
+        emit(PACK_COPY, t, t.numel() if n is None else n, a=t.numel(), scale=scale)
+
+    def fold(name):
+        t = p(name)
+        assert t.shape[1] == 1024
+        emit(PACK_FOLD, t, t.shape[0] * 544)
+
+    def padcol(name, cols):
+        t = p(name)
+        emit(PACK_PADCOL, t, t.shape[0] * cols, a=t.shape[1], b=cols)
+
+    def zero():
+        emit(PACK_COPY, anchor, 64, a=0)
+
+    def slot(i, fn, *args, **kw):
+        align()
+        offs[i] = pos[0]
+        fn(*args, **kw)
+
+    for i in range(3):
+        slot(i, copy, "pos_encoder.embeddings.%d.weight" % i)
+    slot(3, copy, "transformer_encoder.rel_encoder.weight"); slot(4, copy, "transformer_encoder.rel_encoder.bias")
+    slot(5, copy, "transformer_encoder.norm.weight"); slot(6, copy, "transformer_encoder.norm.bias")
+    slot(7, copy, "g_encoder.weight"); slot(8, copy, "encoder.weight"); slot(9, copy, "encoder.bias")
+    slot(10, copy, "gg_proj.weight")
+    slot(11, fold, "linear1_g.weight"); slot(12, copy, "linear1_g.bias")
+    slot(13, copy, "linear2_g.weight"); slot(14, copy, "linear2_g.bias")
+    slot(15, padcol, "linear1_ng.weight", 160); slot(16, copy, "linear1_ng.bias")
+    slot(17, copy, "linear2_ng.weight"); slot(18, copy, "linear2_ng.bias")
+    if critic:
+        slot(19, copy, "decoder_ng.weight"); slot(20, zero); slot(21, copy, "decoder_ng.bias")
+        slot(22, zero); slot(23, zero); slot(24, zero)
+    else:
+        slot(19, copy, "decoder_g.weight")
+        slot(20, copy, "linear1_m.weight"); slot(21, copy, "linear1_m.bias")
+        slot(22, copy, "linear2_m.weight"); slot(23, copy, "linear2_m.bias")
+        slot(24, copy, "g_proj.weight")
+    scaling = float(128) ** -0.5   # (2 * head_dim)^-0.5, reference subequivariant_attentions.py:88
+    for l in range(LAYERS):
+        lp = "transformer_encoder.layers.%d." % l
+        at = lp + "self_attn."
+        b0 = NGLOBAL + l * NLAYER
+
+        def qkv(kind):
+            copy(at + "q_proj." + kind, scale=scaling); copy(at + "k_proj." + kind); copy(at + "v_proj." + kind)
+        slot(b0 + 0, copy, at + "g_proj.weight")
+        slot(b0 + 1, fold, at + "linear_g1.weight"); slot(b0 + 2, copy, at + "linear_g1.bias")
+        slot(b0 + 3, copy, at + "linear_g2.weight"); slot(b0 + 4, copy, at + "linear_g2.bias")
+        slot(b0 + 5, qkv, "weight"); slot(b0 + 6, qkv, "bias")
+        slot(b0 + 7, copy, at + "vg_proj.weight", n=256 * 128)
+        slot(b0 + 8, copy, at + "ng_out.weight"); slot(b0 + 9, copy, at + "ng_out.bias")
+        slot(b0 + 10, copy, at + "g_out.weight")
+        slot(b0 + 11, copy, lp + "g_proj2.weight"); slot(b0 + 12, copy, lp + "g_proj3.weight")
+        slot(b0 + 13, fold, lp + "linear_g1.weight"); slot(b0 + 14, copy, lp + "linear_g1.bias")
+        slot(b0 + 15, copy, lp + "linear_g2.weight"); slot(b0 + 16, copy, lp + "linear_g2.bias")
+        slot(b0 + 17, copy, lp + "linear3.weight"); slot(b0 + 18, copy, lp + "linear3.bias")
+        slot(b0 + 19, copy, lp + "linear4.weight"); slot(b0 + 20, copy, lp + "linear4.bias")
+        slot(b0 + 21, copy, lp + "linear5.weight")
+        slot(b0 + 22, copy, lp + "linear1.weight"); slot(b0 + 23, copy, lp + "linear1.bias")
+        slot(b0 + 24, copy, lp + "linear2.weight"); slot(b0 + 25, copy, lp + "linear2.bias")
+        slot(b0 + 26, copy, lp + "norm1.weight"); slot(b0 + 27, copy, lp + "norm1.bias")
+        slot(b0 + 28, copy, lp + "norm2.weight"); slot(b0 + 29, copy, lp + "norm2.bias")
+
+    def stack(w0, w1, cols, cpad):
+        t0 = p(w0)
+        assert tuple(t0.shape) == (30, cols)
+        emit(PACK_STACK, t0, 64 * cpad, a=cols, b=cpad, t1=None if w1 is None else p(w1))
+
+    for l in range(LAYERS):
+        lp = "transformer_encoder.layers.%d." % l
+        slot(NW + 2 * l, stack, lp + "self_attn.g_proj.weight", None, 128, 128)
+        slot(NW + 2 * l + 1, stack, lp + "g_proj2.weight", lp + "g_proj3.weight", 128, 128)
+    slot(NW + 6, stack, "gg_proj.weight", None if critic else "g_proj.weight", 136, 144)
+    align()
+    return np.array(segs, dtype=SEG_DTYPE), offs, pos[0], srcs
+
+
+def graph_key(graph):
+    """Content key of a graph dict (the parents vector determines traversals and relation: sgrl_amd/graph.py)."""
+    return tuple(int(v) for v in graph["parents"])
+
+
 class HipSetActor(object):
     """HIP forward of one SET network: the actor of an `SEPolicy` (default) or, with `net=` / `critic=True`, one critic
     `TransformerModel` of an `SECritic` (see `HipSetCritic`)."""
@@ -116,12 +237,11 @@ class HipSetActor(object):
         h = ctypes.c_void_p()
         _check(self.L, self.L.sgrl_set_create(ctypes.byref(h)), "sgrl_set_create")
         self.h = h
-        self._wbuf = None
-        self._wver = None
+        self._bound = None
         self._cfg_key = None
+        self._cfg_info = {}
         self.n_env = 0
         self.act_ld = 0
-        self._single_cache = {}
 
     def __del__(self):
         try:
@@ -133,43 +253,42 @@ class HipSetActor(object):
 
     # ---- weights ------------------------------------------------------------------------------------
     def sync_weights(self, force=False):
-        params = list(self.net.parameters())
-        ver = (tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
-        if not force and ver == self._wver:
+        """Bind the handle to the parameters' storage.  The VALUES are re-read by the library on every forward; this only
+        has to run again when a parameter's storage moves (module.to(), re-created tensors)."""
+        ptrs = tuple(p.data_ptr() for p in self.net.parameters())
+        if not force and ptrs == self._bound:
             return
-        sd = {"actor." + k: v for k, v in self.net.state_dict().items()}
-        tens = pack_tensors(sd, critic=self.critic)
-        offs = np.zeros(NW, dtype=np.int64)
-        pos = 0
-        for i, t in enumerate(tens):
-            offs[i] = pos
-            pos += (t.numel() + 63) // 64 * 64    # keep every tensor 256-byte aligned
-        buf = torch.zeros(pos, dtype=torch.float32, device=self.device)
-        for i, t in enumerate(tens):
-            buf[offs[i]:offs[i] + t.numel()] = t.reshape(-1).to(self.device)
-        torch.cuda.synchronize(self.device)
-        self._wbuf = buf
-        _check(self.L, self.L.sgrl_set_weights(self.h, ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(offs.ctypes.data),
-                                               NW), "sgrl_set_weights")
-        self._wver = ver
+        segs, offs, total, srcs = plan_segments(self.net, critic=self.critic)
+        if not all(t.is_cuda for t, _ in srcs):
+            raise _lib.SgrlError("the SET network must live on the GPU for the HIP path")
+        _check(self.L, self.L.sgrl_set_bind_params(self.h, ctypes.c_void_p(segs.ctypes.data), len(segs),
+                                                   ctypes.c_void_p(offs.ctypes.data), len(offs), ctypes.c_int64(total)),
+               "sgrl_set_bind_params")
+        self._bound = ptrs
 
     # ---- batch structure ------------------------------------------------------------------------------
     def configure(self, graphs, counts):
-        """graphs: per-morphology dicts with 'traversals' (3 index vectors) and 'relation' [L,L,3]; counts: envs each."""
-        key = (tuple(id(g) for g in graphs), tuple(int(c) for c in counts))
+        """graphs: per-morphology dicts with 'parents', 'traversals' (3 index vectors) and 'relation' [L,L,3]; counts:
+        envs each.  Structures seen before are switched to without any device work (the library caches them by content)."""
+        key = (tuple(graph_key(g) for g in graphs), tuple(int(c) for c in counts))
         if key == self._cfg_key:
             return
-        Ls, trav, rel = [], [], []
-        for g in graphs:
-            t = [np.asarray(v.cpu() if torch.is_tensor(v) else v, dtype=np.int32) for v in g["traversals"]]
-            Ls.append(len(t[0]))
-            trav.append(np.concatenate(t))
-            r = g["relation"]
-            rel.append(np.asarray(r.detach().cpu() if torch.is_tensor(r) else r, dtype=np.float32).reshape(-1))
-        Ls = np.asarray(Ls, dtype=np.int32)
-        cnt = np.asarray(counts, dtype=np.int32)
-        trav = np.ascontiguousarray(np.concatenate(trav), dtype=np.int32)
-        rel = np.ascontiguousarray(np.concatenate(rel), dtype=np.float32)
+        args = self._cfg_info.get(key)
+        if args is None:
+            Ls, trav, rel = [], [], []
+            for g in graphs:
+                t = [np.asarray(v.cpu() if torch.is_tensor(v) else v, dtype=np.int32) for v in g["traversals"]]
+                Ls.append(len(t[0]))
+                trav.append(np.concatenate(t))
+                r = g["relation"]
+                rel.append(np.asarray(r.detach().cpu() if torch.is_tensor(r) else r, dtype=np.float32).reshape(-1))
+            args = (np.asarray(Ls, dtype=np.int32), np.asarray(counts, dtype=np.int32),
+                    np.ascontiguousarray(np.concatenate(trav), dtype=np.int32),
+                    np.ascontiguousarray(np.concatenate(rel), dtype=np.float32))
+            if len(self._cfg_info) >= 128:
+                self._cfg_info.clear()
+            self._cfg_info[key] = args
+        Ls, cnt, trav, rel = args
         vp = lambda a: ctypes.c_void_p(a.ctypes.data)
         _check(self.L, self.L.sgrl_set_graph(self.h, len(Ls), vp(Ls), vp(cnt), vp(trav), vp(rel)), "sgrl_set_graph")
         self._cfg_key = key
@@ -184,8 +303,10 @@ class HipSetActor(object):
         """obs: float32 CUDA [n_env, obs_ld] (rows zero padded beyond 41*L) -> actions float32 [n_env, act_ld]."""
         assert obs.is_cuda and obs.dtype == torch.float32 and obs.dim() == 2 and obs.stride(1) == 1
         assert obs.shape[0] == self.n_env
+        assert obs.shape[1] >= 41 * self.max_limbs, "observation rows narrower than 41 * max_limbs"
         self.sync_weights()
         act_ld = act_ld or 3 * self.max_limbs
+        assert act_ld >= 3 * self.max_limbs, "action rows narrower than 3 * max_limbs"
         if out is None:
             out = torch.empty((self.n_env, act_ld), dtype=torch.float32, device=self.device)
         assert out.is_contiguous() and out.shape == (self.n_env, act_ld)
@@ -200,8 +321,10 @@ class HipSetActor(object):
         assert self.critic, "forward_q needs a handle created with critic=True"
         for t in (obs, action):
             assert t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.shape[0] == self.n_env
+        assert obs.shape[1] >= 41 * self.max_limbs and action.shape[1] >= 3 * self.max_limbs
         self.sync_weights()
         q_ld = q_ld or self.max_limbs
+        assert q_ld >= self.max_limbs
         if out is None:
             out = torch.empty((self.n_env, q_ld), dtype=torch.float32, device=self.device)
         assert out.is_contiguous() and out.shape == (self.n_env, q_ld)

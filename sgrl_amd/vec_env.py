@@ -124,6 +124,7 @@ class BatchedModularVecEnv(VecEnv):
         self._act = torch.zeros((n, self.action_max_len), dtype=torch.float32, device=dev)
         self.obs64 = None
         self.rew64 = None
+        self._overflow_seen = np.zeros(n, dtype=np.int64)
 
     # ---- device surface ---------------------------------------------------------------------------
     def _stream(self):
@@ -176,6 +177,19 @@ class BatchedModularVecEnv(VecEnv):
             cp = ctypes.c_void_p(cnt.ctypes.data)
         _lib.check(self._L.sgrl_set_records(self._h, ctypes.c_void_p(rec.ctypes.data), cp), "sgrl_set_records")
 
+    def get_counters(self):
+        """int32 [n, 4] per env: step count, episode, constraint evaluations that hit the row cap (rows dropped), solver
+        diagnostics of the last step."""
+        cnt = np.zeros((self.num_envs, 4), dtype=np.int32)
+        _lib.check(self._L.sgrl_get_records(self._h, None, ctypes.c_void_p(cnt.ctypes.data)), "sgrl_get_records")
+        return cnt
+
+    def row_overflow_envs(self):
+        """Number of environments in which at least one dynamics evaluation wanted more constraint rows than `max_rows`
+        (the extra contacts were dropped for that evaluation -- MuJoCo's nconmax/njmax analogue).  Zero on every
+        shipped configuration at the default caps; check it after a run with custom caps or new morphologies."""
+        return int((self.get_counters()[:, 2] > 0).sum())
+
     def refresh_device(self):
         _lib.check(self._L.sgrl_refresh(self._h, self._p(self.obs), self._p(self.obs64), self._stream()), "sgrl_refresh")
         return self.obs
@@ -206,10 +220,20 @@ class BatchedModularVecEnv(VecEnv):
         dones = self.done.cpu().numpy().astype(bool)
         dist = self.dist.cpu().numpy()
         trunc = self.trunc.cpu().numpy()
-        infos = tuple({"dist": float(dist[i]), **({"TimeLimit.truncated": True} if trunc[i] else {})}
-                      for i in range(self.num_envs))
+        infos = [{"dist": float(dist[i]), **({"TimeLimit.truncated": True} if trunc[i] else {})}
+                 for i in range(self.num_envs)]
+        # truncated contact sets must not go unnoticed: report newly dropped constraint rows in the info dict + a warning
+        over = self.get_counters()[:, 2].astype(np.int64)
+        new = np.nonzero(over > self._overflow_seen)[0]
+        if new.size:
+            import warnings
+            for i in new:
+                infos[i]["constraint_rows_dropped"] = int(over[i] - self._overflow_seen[i])
+            warnings.warn("%d environment(s) exceeded max_rows in this step: contacts were dropped (raise max_rows)" % new.size,
+                          RuntimeWarning)
+            self._overflow_seen = np.maximum(self._overflow_seen, over)
         self.waiting = False
-        return obs, rews, dones, infos
+        return obs, rews, dones, tuple(infos)
 
     def reset_task(self):
         raise NotImplementedError("reset_task is not defined by the reference ModularEnv either (would raise in the worker)")

@@ -188,3 +188,100 @@ def test_critic_hip_path_matches_reference_fixtures_and_torch_path():
     crit.use_hip = True
     q = crit.Q1(obs, act.clone().requires_grad_(True))
     assert q.requires_grad
+
+
+def _soft_update_like_the_reference(source, target, tau):
+    """common/functional.py:7-10 of the reference, verbatim semantics: writes through `.data` (no version bump)."""
+    for target_param, local_param in zip(target.parameters(), source.parameters()):
+        target_param.data.copy_(tau * local_param.data + (1 - tau) * target_param.data)
+
+
+def test_reference_style_soft_update_reaches_the_hip_path(ctx):
+    """agent.py:104-105,185-187: actor_target / critic_target are only ever written by soft_update_network, then read
+    under no_grad (agent.py:136-148) -- the HIP path.  Neither `_version` nor `data_ptr()` changes; the values must."""
+    torch, pol, graphs, keys, z = ctx
+    import copy
+    from sgrl_amd.set_policy import make_critic
+    from oracle.formula import apply_formula_
+    g = graphs["3d_walker_5_foot"]
+    gd = _gd(torch, g)
+    obs = torch.from_numpy(z["3d_walker_5_foot/B5/obs"]).cuda()
+    actor = copy.deepcopy(pol); actor._hip = None
+    target = copy.deepcopy(pol); target._hip = None
+    with torch.no_grad():
+        for p in actor.parameters():
+            p.mul_(1.25)
+    actor.change_morphology(gd); target.change_morphology(gd)
+    with torch.no_grad():
+        t0 = target(obs).clone()                     # first HIP forward binds the handle
+    vers = [p._version for p in target.parameters()]
+    for it in range(3):
+        _soft_update_like_the_reference(actor, target, 0.3)
+        with torch.no_grad():
+            hip = target(obs).clone()
+        target.use_hip = False
+        with torch.no_grad():
+            ref = target(obs)
+        target.use_hip = True
+        assert float((hip - ref).abs().max()) < TOL, it
+    assert vers == [p._version for p in target.parameters()]      # the update really was invisible to version counters
+    assert float((hip - t0).abs().max()) > 1e-3
+    # same for the twin critics
+    crit = make_critic(device="cuda:0").eval(); apply_formula_(crit)
+    crit_t = make_critic(device="cuda:0").eval(); apply_formula_(crit_t)
+    with torch.no_grad():
+        for p in crit.parameters():
+            p.mul_(0.8)
+    crit_t.change_morphology(gd)
+    act = (torch.rand((5, 3 * len(g["parents"])), device="cuda") * 2 - 1)
+    with torch.no_grad():
+        q0 = crit_t(obs, act)[0].clone()
+    _soft_update_like_the_reference(crit, crit_t, 0.5)
+    with torch.no_grad():
+        q1, q2 = crit_t(obs, act)
+    crit_t.use_hip = False
+    with torch.no_grad():
+        r1, r2 = crit_t(obs, act)
+    scale = max(1.0, float(r1.abs().max()))
+    assert float((q1 - r1).abs().max()) < 2e-4 * scale and float((q2 - r2).abs().max()) < 2e-4 * scale
+    assert float((q1 - q0).abs().max()) > 1e-4
+
+
+def test_morphology_and_batch_switching_is_cached_by_content(ctx):
+    """trainer.py:173-200: change_morphology + select_action per env per step.  Switching between structures the handle
+    has seen must give the same numbers as a fresh handle, also when the graph dicts are NEW objects (content key)."""
+    torch, pol, graphs, keys, z = ctx
+    names = ["3d_walker_7_full", "3d_hopper_3_shin", "3d_humanoid_9_full", "3d_cheetah_14_full", "3d_walker_2_right_leg_left_knee"]
+    first = {}
+    for rnd in range(3):
+        for n in names:
+            for B in (1, 5):
+                pol.change_morphology(_gd(torch, graphs[n]))       # a new dict object every time
+                obs = torch.from_numpy(z["%s/B%d/obs" % (n, B)]).cuda()
+                with torch.no_grad():
+                    a = pol(obs).cpu().numpy()
+                assert np.abs(a - z["%s/B%d/act_f64" % (n, B)]).max() < TOL, (rnd, n, B)
+                if rnd == 0:
+                    first[(n, B)] = a
+                else:
+                    assert np.array_equal(a, first[(n, B)]), (rnd, n, B)
+
+
+def test_too_narrow_rows_are_rejected(ctx):
+    torch, pol, graphs, keys, z = ctx
+    from sgrl_amd.set_hip import HipSetActor
+    from sgrl_amd._lib import SgrlError
+    act = HipSetActor(pol)
+    act.configure([_gd(torch, graphs["3d_walker_7_full"])], [2])
+    obs = torch.zeros((2, 287), device="cuda")
+    with pytest.raises(AssertionError):
+        act.forward_batch(obs[:, :200].contiguous())
+    with pytest.raises(AssertionError):
+        act.forward_batch(obs, act_ld=12)
+    # and the raw ABI refuses as well
+    import ctypes
+    out = torch.zeros((2, 21), device="cuda")
+    act.sync_weights()
+    rc = act.L.sgrl_set_forward(act.h, ctypes.c_void_p(obs.data_ptr()), 200, ctypes.c_void_p(out.data_ptr()), 21,
+                                ctypes.c_float(1.0), act._stream())
+    assert rc != 0 and b"Lmax" in act.L.sgrl_set_last_error()

@@ -1,0 +1,96 @@
+"""The live weight-packing plan (sgrl_amd/set_hip.plan_segments, executed on the device by k_pack in set_actor.hip)
+must reproduce the flat buffer `pack_tensors` builds on the host: same offsets, same values, no gaps.  The kernel's
+arithmetic per segment kind is restated here in NumPy (it is pure index work plus one multiply)."""
+import numpy as np
+import pytest
+import torch
+
+from sgrl_amd import set_hip
+from sgrl_amd.set_policy import make_critic, make_policy
+
+
+def _run_plan(segs, srcs, total):
+    out = np.full(total, np.nan, dtype=np.float32)
+    tril_a, tril_b = np.tril_indices(32)      # row-major lower triangle: k = a(a+1)/2 + b
+    for sg, (t0, t1) in zip(segs, srcs):
+        n, kind, a, b = int(sg["n"]), int(sg["kind"]), int(sg["a"]), int(sg["b"])
+        s0 = t0.detach().numpy().reshape(-1)
+        v = np.zeros(n, dtype=np.float32)
+        if kind == set_hip.PACK_COPY:
+            v[:a] = s0[:a] * np.float32(sg["scale"])
+        elif kind == set_hip.PACK_PADCOL:
+            v = v.reshape(-1, b)
+            v[:, :a] = s0.reshape(-1, a)
+        elif kind == set_hip.PACK_FOLD:
+            w3 = s0.reshape(-1, 32, 32)
+            v = v.reshape(-1, 544)
+            f = w3[:, tril_a, tril_b] + w3[:, tril_b, tril_a]
+            diag = tril_a == tril_b
+            f[:, diag] = w3[:, tril_a[diag], tril_b[diag]]
+            v[:, :528] = f
+        elif kind == set_hip.PACK_STACK:
+            v = v.reshape(64, b)
+            v[:30, :a] = s0.reshape(30, a)
+            if t1 is not None:
+                v[32:62, :a] = t1.detach().numpy().reshape(30, a)
+        else:
+            raise AssertionError(kind)
+        d = int(sg["dst"])
+        assert np.isnan(out[d:d + n]).all(), "segments overlap"
+        out[d:d + n] = v.reshape(-1)
+    assert not np.isnan(out).any(), "segments leave gaps"
+    return out
+
+
+@pytest.mark.parametrize("critic", [False, True])
+def test_plan_reproduces_the_host_pack(critic):
+    torch.manual_seed(3)
+    if critic:
+        net = make_critic(use_hip=False).critic2
+    else:
+        net = make_policy(use_hip=False).actor
+    segs, offs, total, srcs = set_hip.plan_segments(net, critic=critic)
+    assert segs.dtype.itemsize == 48 and total % 64 == 0
+    flat = _run_plan(segs, srcs, total)
+    sd = {"actor." + k: v for k, v in net.state_dict().items()}
+    tens = set_hip.pack_tensors(sd, critic=critic)
+    pos = 0
+    for i, t in enumerate(tens):
+        assert offs[i] == pos, i
+        ref = t.reshape(-1).numpy()
+        np.testing.assert_array_equal(flat[pos:pos + ref.size], ref, err_msg="slot %d" % i)
+        pad = (-ref.size) % 64
+        assert (flat[pos + ref.size:pos + ref.size + pad] == 0).all()
+        pos += ref.size + pad
+    # the seven stacked projection operands follow the slot table
+    for k in range(set_hip.NSITES):
+        cpad = 144 if k == 6 else 128
+        blk = flat[offs[set_hip.NW + k]:offs[set_hip.NW + k] + 64 * cpad].reshape(64, cpad)
+        assert (blk[30:32] == 0).all() and (blk[62:] == 0).all()
+        if k == 6:
+            np.testing.assert_array_equal(blk[:30, :136], net.gg_proj.weight.detach().numpy())
+            assert (blk[:, 136:] == 0).all()
+            if critic:
+                assert (blk[32:] == 0).all()
+            else:
+                np.testing.assert_array_equal(blk[32:62, :136], net.g_proj.weight.detach().numpy())
+        else:
+            layer = net.transformer_encoder.layers[k // 2]
+            if k % 2 == 0:
+                np.testing.assert_array_equal(blk[:30], layer.self_attn.g_proj.weight.detach().numpy())
+                assert (blk[32:] == 0).all()
+            else:
+                np.testing.assert_array_equal(blk[:30], layer.g_proj2.weight.detach().numpy())
+                np.testing.assert_array_equal(blk[32:62], layer.g_proj3.weight.detach().numpy())
+
+
+def test_plan_sources_are_the_live_parameter_storage():
+    net = make_policy(use_hip=False).actor
+    segs, offs, total, srcs = set_hip.plan_segments(net)
+    ptrs = {p.data_ptr() for p in net.parameters()}
+    assert {int(s) for s in segs["src0"]} <= ptrs
+    # a reference-style soft update writes through .data: storage (and therefore the plan) is unchanged
+    before = [p.data_ptr() for p in net.parameters()]
+    for p in net.parameters():
+        p.data.copy_(0.5 * p.data)
+    assert before == [p.data_ptr() for p in net.parameters()]
