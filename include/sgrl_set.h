@@ -117,8 +117,15 @@ int64_t sgrl_set_workspace_bytes(const sgrl_set* s);
 int sgrl_set_time_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_ld, float max_action,
                           int reps, void* stream, float* ms_out);
 /* Debug/parity: copy an intermediate buffer of the LAST forward to the host.  which: 0 g[N,3,128], 1 cat[N,256]
- * (inv | ng), 2 gram[N,544] (packed lower triangle), 3 fn[N], 4 qkv[N,768], 5 attng[N,256], 6 attg[N,3,256], 7 mat[N,1024]. */
+ * (inv | ng), 2 gram[N,544] (packed lower triangle), 3 fn[N], 4 qkv[N,768], 5 attng[N,256], 6 attg[N,3,256], 7 mat[N,1024],
+ * 8 g1[N,3,128] (attention's vector output), 9 delta[N,128] (attention's / FFN's scalar output before the residual norm),
+ * 10 outng[N,160] (input features | final-norm ng | zero padding). */
 int sgrl_set_peek(sgrl_set* s, int which, float* host, int64_t n_floats);
+/* Parity probes (tests only): make the following forwards return after stage 2l (attention block of layer l done: g1 and
+ * delta hold MyMultiheadAttention's two outputs, reference SEActor.py:48-66) or 2l+1 (layer l done: g and cat[:,128:] hold
+ * MyTransformerEncoderLayer's outputs, SEActor.py:82-125); the action / Q output of such a forward is not written.
+ * stage = -1 restores the full forward. */
+int sgrl_set_debug_stop_after(sgrl_set* s, int stage);
 const char* sgrl_set_last_error(void);
 
 #ifdef __cplusplus

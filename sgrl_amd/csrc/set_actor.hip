@@ -573,6 +573,7 @@ struct sgrl_set {
   unsigned short* d_tri = nullptr;
   bool stack_dirty = true;
   bool stack_critic = false;   // mode the stacked operands were built for
+  int stop_after = -1;         // parity probes: leave run_forward after this stage (sgrl_set_debug_stop_after)
   // live weights (sgrl_set_bind_params)
   bool live = false;
   float* wflat = nullptr;
@@ -735,6 +736,7 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
     GS(s->attng, 256, s->WL(l, SGRL_SET_NGOUT_W), 256, s->WL(l, SGRL_SET_NGOUT_B), s->delta, D, N, D, 256);
     G(s->attg, 256, s->WL(l, SGRL_SET_GOUT_W), 256, nullptr, s->g1, D, N3, D, 256, EPI_ACC2, nullptr, s->g, D);
     join();
+    if (s->stop_after == 2 * l) return SGRL_OK;      // probe: g1 = attention's vector output, delta = its scalar output
     hipLaunchKernelGGL(k_add_ln, dim3(lnb), dim3(256), 0, st, ng, 256, s->delta, D, s->WL(l, SGRL_SET_N1_W),
                        s->WL(l, SGRL_SET_N1_B), ng, 256, (float*)nullptr, 0, N);
     // --- equivariant feed-forward ---
@@ -750,6 +752,7 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
     join();
     hipLaunchKernelGGL(k_add_ln, dim3(lnb), dim3(256), 0, st, ng, 256, s->delta, D, s->WL(l, SGRL_SET_N2_W),
                        s->WL(l, SGRL_SET_N2_B), ng, 256, (float*)nullptr, 0, N);
+    if (s->stop_after == 2 * l + 1) return SGRL_OK;  // probe: g / ng (= cat[:, 128:]) are this layer's outputs
   }
   // final norm -> outng[:, 17:145]; head
   hipLaunchKernelGGL(k_add_ln, dim3(lnb), dim3(256), 0, st, ng, 256, (const float*)nullptr, 0, s->W(SGRL_SET_FNORM_W),
@@ -1024,11 +1027,17 @@ int64_t sgrl_set_workspace_bytes(const sgrl_set* s) { return s ? s->ws_floats * 
 
 int sgrl_set_peek(sgrl_set* s, int which, float* host, int64_t n_floats) {
   if (!s || !host || !s->have_graph) return sfail(SGRL_ERR_ARG, "sgrl_set_peek: bad argument");
-  const float* src[] = {s->g, s->cat, s->gram, s->fn, s->qkv, s->attng, s->attg, s->mat};
-  const int64_t per[] = {384, 256, GK, 1, 768, 256, 768, 1024};
-  if (which < 0 || which > 7 || n_floats > per[which] * s->N) return sfail(SGRL_ERR_ARG, "sgrl_set_peek: bad buffer or size");
+  const float* src[] = {s->g, s->cat, s->gram, s->fn, s->qkv, s->attng, s->attg, s->mat, s->g1, s->delta, s->outng};
+  const int64_t per[] = {384, 256, GK, 1, 768, 256, 768, 1024, 384, 128, 160};
+  if (which < 0 || which > 10 || n_floats > per[which] * s->N) return sfail(SGRL_ERR_ARG, "sgrl_set_peek: bad buffer or size");
   SHIP_TRY(hipDeviceSynchronize());
   SHIP_TRY(hipMemcpy(host, src[which], sizeof(float) * n_floats, hipMemcpyDeviceToHost));
+  return SGRL_OK;
+}
+
+int sgrl_set_debug_stop_after(sgrl_set* s, int stage) {
+  if (!s || stage < -1 || stage >= 2 * SGRL_SET_LAYERS) return sfail(SGRL_ERR_ARG, "sgrl_set_debug_stop_after: bad argument");
+  s->stop_after = stage;
   return SGRL_OK;
 }
 

@@ -37,6 +37,7 @@ def _bind(L):
     L.sgrl_set_workspace_bytes.argtypes = [vp]
     L.sgrl_set_workspace_bytes.restype = ctypes.c_int64
     L.sgrl_set_peek.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int64]
+    L.sgrl_set_debug_stop_after.argtypes = [vp, ctypes.c_int]
     L.sgrl_set_last_error.restype = ctypes.c_char_p
     L._set_bound = True
 
@@ -348,6 +349,10 @@ class HipSetActor(object):
         B = state.shape[0]
         self.configure([graph], [B])
         return self.forward_batch(state.contiguous().float(), act_ld=3 * len(graph["parents"]))
+
+    def debug_stop_after(self, stage):
+        """Parity probes: the following forwards return after stage 2l (attention of layer l) / 2l+1 (layer l); -1 = full."""
+        _check(self.L, self.L.sgrl_set_debug_stop_after(self.h, int(stage)), "sgrl_set_debug_stop_after")
 
     def peek(self, which, per_node):
         out = np.zeros((self.num_nodes, per_node), dtype=np.float32)

@@ -285,3 +285,42 @@ def test_too_narrow_rows_are_rejected(ctx):
     rc = act.L.sgrl_set_forward(act.h, ctypes.c_void_p(obs.data_ptr()), 200, ctypes.c_void_p(out.data_ptr()), 21,
                                 ctypes.c_float(1.0), act._stream())
     assert rc != 0 and b"Lmax" in act.L.sgrl_set_last_error()
+
+
+def test_layer_probes_on_the_gpu(ctx, golden_dir):
+    """Walk the HIP forward stage by stage against the reference's own forward hooks on `layers.i.self_attn`, `layers.i`
+    and `transformer_encoder` (tests/golden/set_probes_walker7.npz, captured by tools/capture_golden.py): a compensating
+    error pair inside a layer cannot hide behind a correct final action."""
+    torch, pol, graphs, keys, z = ctx
+    from sgrl_amd.set_hip import HipSetActor
+    p = np.load(os.path.join(golden_dir, "set_probes_walker7.npz"))
+    g = graphs["3d_walker_7_full"]
+    L, B = 7, 2
+    act = HipSetActor(pol)
+    act.configure([_gd(torch, g)], [B])
+    obs = torch.from_numpy(p["obs"].astype(np.float32)).cuda()
+
+    def nodes(a):           # fixture [L, B, ...] -> node-major [B * L, ...] (limbs of one env contiguous)
+        return np.swapaxes(a, 0, 1).reshape((B * L,) + a.shape[2:])
+
+    def close(got, ref, what):
+        ref = nodes(ref)
+        err = np.abs(got.reshape(ref.shape) - ref).max()
+        assert err < 2e-5 * (1 + np.abs(ref).max()), (what, err, np.abs(ref).max())
+
+    try:
+        for l in range(3):
+            act.debug_stop_after(2 * l)
+            act.forward_batch(obs)
+            close(act.peek(8, 384), p["layer%d/attn/out0" % l], "layer%d attention vector output" % l)
+            close(act.peek(9, 128), p["layer%d/attn/out1" % l], "layer%d attention scalar output" % l)
+            act.debug_stop_after(2 * l + 1)
+            act.forward_batch(obs)
+            close(act.peek(0, 384), p["layer%d/out0" % l], "layer%d g" % l)
+            close(act.peek(1, 256)[:, 128:], p["layer%d/out1" % l], "layer%d ng" % l)
+    finally:
+        act.debug_stop_after(-1)
+    out = act.forward_batch(obs).cpu().numpy()
+    close(act.peek(0, 384), p["encoder/out0"], "encoder g")
+    close(act.peek(10, 160)[:, 17:145], p["encoder/out1"], "encoder ng (final norm)")
+    assert np.abs(out - p["act_f64"]).max() < TOL
