@@ -531,8 +531,8 @@ static void make_constraints(const SgrlModelView* m, const double* qpos, const d
  * warm start, solve A_FF x = -b_F, exchange all indices violating x_F >= 0 / (A x + b)_G >= -thresh (one index after
  * the violation count stopped shrinking three times), repeat.  Returns 1 when a complementary solution was found. */
 static int lcp_block_pivot(int n, int nv, Work* w, const double* diag, double thresh) {
-  static double A[64][64];
-  static double C[64][64];
+  double A[64][64];   /* automatic storage: the oracle is re-entrant (tests step several oracle envs from a thread pool) */
+  double C[64][64];
   double x[64], rhs[64];
   int F[64], list[64];
   for (int i = 0; i < n; i++) for (int j = 0; j <= i; j++) {

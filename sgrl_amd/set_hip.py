@@ -300,6 +300,11 @@ class HipSetActor(object):
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    @staticmethod
+    def _ld(t):
+        """Row stride in floats; a one-row tensor may report any stride (NumPy's [None, :] gives 0): use its width."""
+        return int(t.stride(0)) if t.shape[0] > 1 else int(t.shape[1])
+
     def forward_batch(self, obs, out=None, act_ld=None):
         """obs: float32 CUDA [n_env, obs_ld] (rows zero padded beyond 41*L) -> actions float32 [n_env, act_ld]."""
         assert obs.is_cuda and obs.dtype == torch.float32 and obs.dim() == 2 and obs.stride(1) == 1
@@ -311,7 +316,7 @@ class HipSetActor(object):
         if out is None:
             out = torch.empty((self.n_env, act_ld), dtype=torch.float32, device=self.device)
         assert out.is_contiguous() and out.shape == (self.n_env, act_ld)
-        _check(self.L, self.L.sgrl_set_forward(self.h, ctypes.c_void_p(obs.data_ptr()), int(obs.stride(0)),
+        _check(self.L, self.L.sgrl_set_forward(self.h, ctypes.c_void_p(obs.data_ptr()), self._ld(obs),
                                                ctypes.c_void_p(out.data_ptr()), int(act_ld),
                                                ctypes.c_float(float(self.policy.max_action)), self._stream()),
                "sgrl_set_forward")
@@ -329,8 +334,8 @@ class HipSetActor(object):
         if out is None:
             out = torch.empty((self.n_env, q_ld), dtype=torch.float32, device=self.device)
         assert out.is_contiguous() and out.shape == (self.n_env, q_ld)
-        _check(self.L, self.L.sgrl_set_forward_q(self.h, ctypes.c_void_p(obs.data_ptr()), int(obs.stride(0)),
-                                                 ctypes.c_void_p(action.data_ptr()), int(action.stride(0)),
+        _check(self.L, self.L.sgrl_set_forward_q(self.h, ctypes.c_void_p(obs.data_ptr()), self._ld(obs),
+                                                 ctypes.c_void_p(action.data_ptr()), self._ld(action),
                                                  ctypes.c_void_p(out.data_ptr()), int(q_ld), self._stream()),
                "sgrl_set_forward_q")
         return out
@@ -338,8 +343,8 @@ class HipSetActor(object):
     def time_forward(self, obs, out, reps):
         self.sync_weights()
         ms = ctypes.c_float(0)
-        _check(self.L, self.L.sgrl_set_time_forward(self.h, ctypes.c_void_p(obs.data_ptr()), int(obs.stride(0)),
-                                                    ctypes.c_void_p(out.data_ptr()), int(out.stride(0)),
+        _check(self.L, self.L.sgrl_set_time_forward(self.h, ctypes.c_void_p(obs.data_ptr()), self._ld(obs),
+                                                    ctypes.c_void_p(out.data_ptr()), self._ld(out),
                                                     ctypes.c_float(float(self.policy.max_action)), int(reps),
                                                     self._stream(), ctypes.byref(ms)), "sgrl_set_time_forward")
         return float(ms.value)

@@ -130,6 +130,10 @@ def install():
     gym_spaces = types.ModuleType("gym.spaces")
     gym_spaces.Box = _Box
     gym_spaces.Discrete = type("Discrete", (), {})
+    gym_spaces.MultiBinary = type("MultiBinary", (), {})     # imported by common/networks.py:10, unused by the SET path
+    gym_space = types.ModuleType("gym.spaces.space")
+    gym_space.Space = object
+    gym_spaces.space = gym_space
     gym_box = types.ModuleType("gym.spaces.box")
     gym_box.Box = _Box
     gym_disc = types.ModuleType("gym.spaces.discrete")
@@ -157,6 +161,7 @@ def install():
         "gym.spaces": gym_spaces,
         "gym.spaces.box": gym_box,
         "gym.spaces.discrete": gym_disc,
+        "gym.spaces.space": gym_space,
         "gym.utils": gym_utils,
         "gym.envs": gym_envs,
         "gym.envs.registration": gym_reg,
