@@ -734,7 +734,7 @@ static void mj_step_once(const SgrlModelView* m, double* qpos, double* qvel, con
     for (int d = 0; d < nv; d++) if (m->dof_damping[d] > 0) any = 1;
     if (any) {
       for (int i = 0; i < nv; i++) { double s = 0; for (int j = 0; j < nv; j++) s += w->M[i][j] * w->qacc[j]; rhs[i] = s; }
-      static double MH[NVM][NVM], LH[NVM][NVM];
+      double MH[NVM][NVM], LH[NVM][NVM];   /* automatic: re-entrant */
       for (int i = 0; i < nv; i++) for (int j = 0; j < nv; j++) MH[i][j] = w->M[i][j] + (i == j ? h * m->dof_damping[i] : 0);
       cholesky(nv, MH, LH);
       solve_lower(nv, LH, rhs); solve_upper(nv, LH, rhs);

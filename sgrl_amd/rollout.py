@@ -63,10 +63,15 @@ class Rollout(object):
 
 
 class ReplayGather(object):
-    """The replay-buffer push as ONE collective: every rank contributes a fixed-size block of transitions
-    (obs, action, next_obs, reward, done) -- the arguments of ReplayBuffer.add_transition (reference
-    common/buffer.py:75-84) for each of its environments -- and the learner rank receives them all with a single
-    gather (RCCL over xGMI when the backend is 'nccl'; 'gloo' on CPU for tests)."""
+    """The replay-buffer push as ONE collective: every rank contributes a fixed-size block of transition rows
+        obs[obs_max_len] | action[action_max_len] | next_obs[obs_max_len] | reward | done | store | morph_id
+    -- the arguments of ReplayBuffer.add_transition (reference common/buffer.py:75-84) for each of its environments, the
+    flag saying whether the reference's loop would store the row at all (first episode of the round only, reference
+    trainer.py:218) and the morphology the row belongs to (the reference keeps one buffer per morphology, main.py:141-155)
+    -- and the learner rank receives them all with a single gather (RCCL over xGMI when the backend is 'nccl'; 'gloo'
+    on CPU for tests).  Rows are padded to the widest morphology so that every rank sends the same number of bytes."""
+
+    EXTRA = 4     # reward, done, store, morph_id
 
     def __init__(self, n_env_local, obs_max_len, action_max_len, device, dst=0):
         import torch.distributed as dist
@@ -74,14 +79,15 @@ class ReplayGather(object):
         self.dst = dst
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.row = 2 * obs_max_len + action_max_len + 2
+        self.row = 2 * obs_max_len + action_max_len + self.EXTRA
         self.o, self.a = obs_max_len, action_max_len
         self.block = torch.zeros((n_env_local, self.row), dtype=torch.float32, device=device)
+        self.block[:, 2 * obs_max_len + action_max_len + 2] = 1.0      # store flag defaults to "keep"
         self.recv = None
         if self.rank == dst:
             self.recv = [torch.zeros_like(self.block) for _ in range(self.world)]
 
-    def pack(self, obs, action, next_obs, reward, done):
+    def pack(self, obs, action, next_obs, reward, done, store=None, morph_id=None):
         o, a = self.o, self.a
         b = self.block
         b[:, :o] = obs
@@ -89,6 +95,10 @@ class ReplayGather(object):
         b[:, o + a:2 * o + a] = next_obs
         b[:, 2 * o + a] = reward
         b[:, 2 * o + a + 1] = done.to(torch.float32)
+        if store is not None:
+            b[:, 2 * o + a + 2] = store.to(torch.float32)
+        if morph_id is not None:
+            b[:, 2 * o + a + 3] = morph_id.to(torch.float32)     # small integers: exact in float32
         return b
 
     def push(self):
@@ -99,8 +109,10 @@ class ReplayGather(object):
         return self.recv
 
     def unpack(self, block):
+        """(obs, action, next_obs, reward, done, store bool, morph_id long) views / columns of a block."""
         o, a = self.o, self.a
-        return (block[:, :o], block[:, o:o + a], block[:, o + a:2 * o + a], block[:, 2 * o + a], block[:, 2 * o + a + 1])
+        return (block[:, :o], block[:, o:o + a], block[:, o + a:2 * o + a], block[:, 2 * o + a], block[:, 2 * o + a + 1],
+                block[:, 2 * o + a + 2] > 0.5, block[:, 2 * o + a + 3].to(torch.long))
 
     def bytes_per_step(self):
         return self.block.numel() * 4
@@ -149,3 +161,66 @@ class RoundCollector(object):
     def per_morph_iter(self):
         """Number of TD3 updates per morphology after the round (reference trainer.py:244)."""
         return int(self.episode_timesteps.sum().item()) // self.n
+
+
+class TransitionSink(object):
+    """Everything that happens to a batch of transitions after `VecEnv.step` (SURVEY 8 a15 + a16), for one rank:
+
+        RoundCollector.record          which rows the reference's loop would store, with which `done` (trainer.py:205-232)
+        ReplayGather.pack / push       ONE gather of the rows (+ store flag + morphology id) to the learner rank
+        learner: ingest                rank by rank, env by env -- the order of the reference's `for i in range(num_envs)`
+                                       loop -- every kept row goes to the replay buffer of ITS morphology, cut to that
+                                       morphology's 41 L / 3 L columns (`add_transition`, common/buffer.py:75-84)
+        all ranks: round_finished      `all(done_list)` over the environments of every rank (one 4-byte all-reduce)
+
+    `buffers`: list indexed by morphology id of objects with `add_transitions(obs, action, next_obs, reward, done, mask)`
+    (sgrl_amd.replay.DeviceReplayBuffer) on the learner rank, None elsewhere."""
+
+    def __init__(self, env_morph, num_limbs, obs_max_len, action_max_len, max_episode_steps=1000, device="cpu", buffers=None,
+                 dst=0):
+        import torch.distributed as dist
+        self.dist = dist
+        self.device = torch.device(device)
+        self.env_morph = torch.as_tensor(env_morph, dtype=torch.long, device=self.device)
+        self.num_limbs = [int(l) for l in num_limbs]
+        n = int(self.env_morph.numel())
+        self.collector = RoundCollector(n, max_episode_steps, device=self.device)
+        self.gather = ReplayGather(n, obs_max_len, action_max_len, self.device, dst=dst)
+        self.is_learner = self.gather.rank == dst
+        self.buffers = buffers
+        if self.is_learner and buffers is None:
+            raise ValueError("the learner rank needs the per-morphology replay buffers")
+        self.stored = 0           # transitions written on the learner (tot_env_steps bookkeeping, trainer.py:229)
+
+    def begin_round(self):
+        self.collector.begin_round()
+
+    def push(self, prev_obs, action, next_obs, reward, done):
+        """Returns True when every environment of every rank has finished its first episode of this round."""
+        store, done_bool, finished = self.collector.record(reward, done)
+        self.gather.pack(prev_obs, action, next_obs, reward, done_bool, store, self.env_morph)
+        blocks = self.gather.push()
+        if self.is_learner:
+            self.ingest(blocks)
+        if self.gather.world > 1:
+            flag = torch.tensor([1 if finished else 0], dtype=torch.int32, device=self.device)
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+            finished = bool(flag.item())
+        return finished
+
+    def ingest(self, blocks):
+        for blk in blocks:                                   # rank order = global environment order
+            obs, act, nxt, rew, done, store, morph = self.gather.unpack(blk)
+            for k, buf in enumerate(self.buffers):
+                m = store & (morph == k)
+                L = self.num_limbs[k]
+                buf.add_transitions(obs[:, :41 * L], act[:, :3 * L], nxt[:, :41 * L], rew, done, mask=m)
+                self.stored += int(m.sum())
+
+    def total_episode_timesteps(self):
+        """sum(episode_timesteps_list) over all ranks (the numerator of per_morph_iter, trainer.py:244)."""
+        t = self.collector.episode_timesteps.sum().reshape(1)
+        if self.gather.world > 1:
+            t = t.clone()
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return int(t.item())

@@ -6,7 +6,7 @@ laws, resting-contact force balance against the closed-form soft-constraint law,
 import numpy as np
 import pytest
 
-from helpers import oracle_model, WALKERS
+from helpers import oracle_model, packed, WALKERS
 from oracle import physics_ref
 from sgrl_amd import mjcf, model_pack
 from sgrl_amd.env_spec import env_spec_for
@@ -342,3 +342,29 @@ def test_time_limit_truncation():
     flags = [env.step(z)[2:] for _ in range(3)]
     assert [f[0] for f in flags] == [False, False, True]
     assert flags[2][1]["TimeLimit.truncated"]
+
+
+def test_oracle_is_reentrant():
+    """The GPU parity tests step many oracle environments from a thread pool (ctypes releases the GIL): the C oracle must
+    not keep any state outside its arguments.  Pooled and serial runs of the same environments agree bit for bit."""
+    from concurrent.futures import ThreadPoolExecutor
+    names = ["3d_cheetah_14_full", "3d_cheetah_10_tail_leftbleg", "3d_humanoid_9_full", "3d_walker_7_full", "3d_hopper_5_full"] * 3
+
+    def make():
+        out = []
+        for i, n in enumerate(names):
+            m, ib, fb = packed(n, max_rows=64)
+            e = physics_ref.OracleEnv(physics_ref.OracleModel(ib, fb), seed=5, env_id=i)
+            e.reset()
+            out.append(e)
+        return out
+    pooled, serial = make(), make()
+    rng = np.random.RandomState(0)
+    with ThreadPoolExecutor(8) as pool:
+        for t in range(40):
+            a = rng.uniform(-1, 1, size=(len(names), 42))
+            list(pool.map(lambda ia: ia[1].step(a[ia[0]]), enumerate(pooled)))
+            for i, e in enumerate(serial):
+                e.step(a[i])
+    for p, s in zip(pooled, serial):
+        assert np.array_equal(p.qpos, s.qpos) and np.array_equal(p.qvel, s.qvel) and p.counters[1] == s.counters[1]

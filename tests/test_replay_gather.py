@@ -42,7 +42,7 @@ def _worker(rank, world, port, n_env, obs_len, act_len, out_dir):
             else:
                 assert blocks is None
             np.save(os.path.join(out_dir, "sent_%d_%d.npy" % (rank, step)), g.block.numpy().copy())
-        assert g.bytes_per_step() == n_env * (2 * obs_len + act_len + 2) * 4
+        assert g.bytes_per_step() == n_env * (2 * obs_len + act_len + 4) * 4
     finally:
         dist.destroy_process_group()
 
@@ -63,9 +63,13 @@ def test_pack_unpack_round_trip_single_rank():
     rew, done = torch.rand(4), torch.tensor([0, 1, 0, 1], dtype=torch.uint8)
     blk = g.pack(obs, act, nxt, rew, done)
     assert g.push()[0] is blk
-    o, a, n, r, d = g.unpack(blk)
+    o, a, n, r, d, st, mid = g.unpack(blk)
     assert torch.equal(o, obs) and torch.equal(a, act) and torch.equal(n, nxt) and torch.equal(r, rew)
     assert torch.equal(d, done.float())
+    assert st.all() and (mid == 0).all()                 # defaults: keep every row, morphology 0
+    g.pack(obs, act, nxt, rew, done, store=torch.tensor([True, False, True, False]), morph_id=torch.tensor([3, 1, 0, 22]))
+    o, a, n, r, d, st, mid = g.unpack(g.block)
+    assert st.tolist() == [True, False, True, False] and mid.tolist() == [3, 1, 0, 22]
 
 
 def test_env_id_sharding_is_disjoint():
