@@ -1,0 +1,133 @@
+"""Device-side TD3 training loop: BASELINE.json config 5 assembled end to end (e, f1, f2).
+
+The batched counterpart of the reference's `Trainer.warmup` / `Trainer.train` (reference src/trainer.py:90-286): every
+time step is ONE engine launch + ONE batched SET forward for all environments of this rank (rollout.py `Rollout`), the
+per-environment bookkeeping of the reference loop runs as tensor ops (`RoundCollector`), transitions travel to the
+learner rank in one gather and land in device-resident per-morphology ring buffers (`TransitionSink`,
+`DeviceReplayBuffer`), and when every environment of every rank has finished its first episode of the round the learner
+runs the reference's update schedule -- `per_morph_iter = sum(episode_timesteps) // num_envs` TD3 updates for each
+morphology in turn (trainer.py:244-251) -- through `td3.Agent`, then all ranks reset and start the next round.
+
+Multi-GPU: environments are sharded by rank (no collective in the step); the learner (rank `dst`) owns buffers and
+optimizers; after its updates the actor's parameters are broadcast (one flat 18.9 MB `broadcast`) so that every
+rank's rollout uses the new policy.  Single rank: no process group needed.
+"""
+import numpy as np
+import torch
+
+from . import graph as G
+from .replay import DeviceReplayBuffer
+from .rollout import TRAV, Rollout, TransitionSink
+from .td3 import Agent, default_train_args
+
+
+class DeviceTrainer(object):
+    def __init__(self, env_names, envs_per_morph, args=None, seed=0, device="cuda:0", max_buffer_size=1000000,
+                 batch_size=None, dst=0, **env_kw):
+        import torch.distributed as dist
+        self.dist = dist
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.dst = dst
+        self.args = args if args is not None else default_train_args()
+        self.env_names = list(env_names)
+        torch.manual_seed(seed)               # same initial weights on every rank
+        self.agent = Agent(self.args, device=device)
+        self.ro = Rollout(self.env_names, envs_per_morph, policy=self.agent.actor, seed=seed, device=device, rank=self.rank,
+                          max_episode_steps=self.args.max_episode_steps, **env_kw)
+        env = self.ro.env
+        self.device = env.device
+        self.graph_dicts = self.ro.graph_dicts
+        self.is_learner = self.rank == dst
+        self.batch_size = int(batch_size if batch_size is not None else self.args.batch_size)
+        self.buffers = None
+        if self.is_learner:     # one ring buffer per morphology (reference main.py:141-155), rows cut to 41 L / 3 L
+            self.buffers = [DeviceReplayBuffer(41 * L, 3 * L, max_buffer_size, device=self.device) for L in env.num_limbs]
+        self.sink = TransitionSink(env.env_morph, env.num_limbs, env.obs_max_len, env.action_max_len,
+                                   max_episode_steps=self.args.max_episode_steps, device=self.device, buffers=self.buffers,
+                                   dst=dst)
+        self.prev_obs = torch.zeros_like(env.obs)
+        self.num_envs_global = env.num_envs * self.world
+        self.tot_env_steps = 0
+        self.rounds = 0
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(int(seed) * 7919 + 13)
+        self.last_losses = {}
+        self.begin_round()
+
+    # ---- collection ----------------------------------------------------------------------------------
+    def begin_round(self):
+        """`obs_list = envs.reset()` + fresh done / timestep lists (trainer.py:155-160, 268-275)."""
+        self.ro.reset()
+        self.sink.begin_round()
+
+    def collect_step(self, random_actions=False):
+        """One time step of every environment + replay push.  Returns True when the collection round is complete."""
+        env = self.ro.env
+        self.prev_obs.copy_(env.obs)
+        if random_actions:                       # Trainer.warmup: uniform actions (trainer.py:95-102)
+            a = self.ro.random_actions()
+        else:                                    # select_action + exploration noise (trainer.py:173-196)
+            a = self.ro.policy_forward(self.prev_obs)
+            if self.args.expl_noise != 0:
+                a = self.ro.add_exploration_noise(a, self.args.expl_noise)
+            self.ro.actions.copy_(a)
+            a = self.ro.actions
+        obs, rew, done, _ = self.ro.step(a)
+        before = self.sink.stored
+        finished = self.sink.push(self.prev_obs, a, obs, rew, done)
+        self.tot_env_steps += self.sink.stored - before       # learner-side count (trainer.py:229)
+        return finished
+
+    def warmup(self, timesteps):
+        """reference Trainer.warmup (trainer.py:90-138): `timesteps` batched steps of uniform random actions; finished
+        rounds only reset the environments (no updates)."""
+        for _ in range(int(timesteps)):
+            if self.collect_step(random_actions=True):
+                self.begin_round()
+
+    # ---- learning --------------------------------------------------------------------------------------
+    def update_after_round(self, max_iters=None):
+        """The update schedule of trainer.py:240-251 on the learner, then the weight broadcast.  Returns per_morph_iter."""
+        per_morph_iter = self.sink.total_episode_timesteps() // self.num_envs_global
+        if max_iters is not None:
+            per_morph_iter = min(per_morph_iter, int(max_iters))
+        if self.is_learner:
+            self.agent.models2train()
+            for k, name in enumerate(self.env_names):
+                self.agent.change_morphology(self.graph_dicts[k])
+                for it in range(per_morph_iter):
+                    batch = self.buffers[k].sample(self.batch_size, generator=self.gen)
+                    self.last_losses[name] = self.agent.update(batch, it)
+                    self.tot_env_steps += 1                    # the reference counts updates too (trainer.py:250)
+            self.agent.models2eval()
+        self.broadcast_actor()
+        self.rounds += 1
+        return per_morph_iter
+
+    def broadcast_actor(self):
+        if self.world == 1:
+            return
+        params = list(self.agent.actor.parameters())
+        flat = torch.cat([p.data.reshape(-1) for p in params])
+        self.dist.broadcast(flat, src=self.dst)
+        if not self.is_learner:
+            off = 0
+            for p in params:
+                n = p.numel()
+                p.data.copy_(flat[off:off + n].view_as(p))     # in place: the HIP actor reads the live storage
+                off += n
+
+    def train_round(self, max_steps=None, max_iters=None):
+        """Collect until every environment has finished one episode (or max_steps), update, reset.  Returns a summary."""
+        steps = 0
+        while True:
+            steps += 1
+            if self.collect_step() or (max_steps is not None and steps >= max_steps):
+                break
+        returns = self.sink.collector.episode_reward.mean().item()
+        lengths = self.sink.collector.episode_timesteps.float().mean().item()
+        iters = self.update_after_round(max_iters=max_iters)
+        self.begin_round()
+        return {"steps": steps, "per_morph_iter": iters, "performance/train_return": returns,
+                "performance/train_length": lengths, "tot_env_steps": self.tot_env_steps}

@@ -1,0 +1,133 @@
+"""Config 5 assembled on the device (sgrl_amd/train_loop.py): Rollout -> RoundCollector -> ReplayGather -> per-morphology
+DeviceReplayBuffer -> TD3 update -> next round.  a15 / a16 are checked ON THE GPU against a per-environment Python replay
+of the reference's loop (reference src/trainer.py:173-236) fed with the step outputs the engine actually produced -- the
+same technique as the evaluator test in test_dropin_loop_gpu.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["3d_cheetah_10_tail_leftbleg", "3d_hopper_3_shin", "3d_humanoid_7_left_arm", "3d_walker_4_right_knee_left_foot"]
+PER = [2, 3, 2, 3]
+
+
+def _trainer(max_episode_steps=40, seed=3):
+    import torch
+    from sgrl_amd.td3 import default_train_args
+    from sgrl_amd.train_loop import DeviceTrainer
+    assert torch.cuda.is_available()
+    args = default_train_args(max_episode_steps=max_episode_steps, batch_size=16)
+    return torch, DeviceTrainer(NAMES, PER, args=args, seed=seed, device="cuda:0", max_buffer_size=256)
+
+
+class _Tape(object):
+    """Records what went into TransitionSink.push (host copies), step by step."""
+
+    def __init__(self, trainer):
+        self.rows = []
+        sink = trainer.sink
+        orig = sink.push
+
+        def push(prev_obs, action, next_obs, reward, done):
+            self.rows.append(tuple(t.detach().cpu().numpy().copy() for t in (prev_obs, action, next_obs, reward, done)))
+            return orig(prev_obs, action, next_obs, reward, done)
+        sink.push = push
+
+
+def _reenact(tape_rows, env_morph, limbs, max_steps, round_starts):
+    """reference trainer.py:205-236 per env, scalar code; `round_starts` = step indices at which a new round began."""
+    n = len(env_morph)
+    rows = [[] for _ in limbs]
+    done_list, steps = [False] * n, [0] * n
+    finished_at = []
+    for t, (obs, act, nxt, rew, done) in enumerate(tape_rows):
+        if t in round_starts:
+            done_list, steps = [False] * n, [0] * n
+        for i in range(n):
+            curr = bool(done[i])
+            done_bool = float(curr)
+            if steps[i] + 1 == max_steps:
+                done_bool, curr = 0.0, True
+            if not done_list[i]:
+                steps[i] += 1
+                L = limbs[env_morph[i]]
+                rows[env_morph[i]].append((obs[i, :41 * L], act[i, :3 * L], nxt[i, :41 * L], rew[i], done_bool))
+                done_list[i] = done_list[i] or curr
+        if all(done_list):
+            finished_at.append(t)
+    return rows, finished_at
+
+
+def test_collection_rounds_fill_the_per_morphology_buffers_like_the_reference_loop():
+    torch, tr = _trainer()
+    tape = _Tape(tr)
+    env = tr.ro.env
+    round_starts, finished = {0}, []
+    # warm-up with uniform actions (trainer.py:90-138), then policy rounds with exploration noise (:173-196)
+    for t in range(60):
+        if tr.collect_step(random_actions=True):
+            finished.append(len(tape.rows) - 1)
+            tr.begin_round()
+            round_starts.add(len(tape.rows))
+    for t in range(60):
+        if tr.collect_step():
+            finished.append(len(tape.rows) - 1)
+            tr.begin_round()
+            round_starts.add(len(tape.rows))
+    rows, fin_ref = _reenact(tape.rows, list(env.env_morph), env.num_limbs, 40, round_starts)
+    assert finished == fin_ref and len(finished) >= 2
+    assert tr.tot_env_steps == sum(len(r) for r in rows) == tr.sink.stored
+    for k, L in enumerate(env.num_limbs):
+        st = tr.buffers[k].state_arrays()
+        total, cap = len(rows[k]), 256
+        assert st["curr"] == total % cap and st["max_sample_size"] == min(total, cap) and total > 20
+        for j in range(max(0, total - cap), total):
+            o, a, nx, rw, d = rows[k][j]
+            p = j % cap
+            assert np.array_equal(st["obs_buffer"][p], o) and np.array_equal(st["action_buffer"][p], a), (k, j)
+            assert np.array_equal(st["next_obs_buffer"][p], nx) and st["reward_buffer"][p] == rw and st["done_buffer"][p] == d
+        # padding slots and the first three (torso) action slots: the reference stores what the driver produced
+        assert st["obs_buffer"].shape[1] == 41 * L and st["action_buffer"].shape[1] == 3 * L
+    # time-limit rows were stored with done = 0 (trainer.py:209-212) and terminal ones with done = 1
+    alld = np.concatenate([tr.buffers[k].state_arrays()["done_buffer"][:tr.buffers[k].max_sample_size] for k in range(4)])
+    assert (alld == 1).any() and (alld == 0).any()
+    # policy rounds: the stored actions are clipped exploration-noised policy outputs, zero beyond 3 L in the padded tensor
+    a_last = tape.rows[-1][1]
+    assert np.abs(a_last).max() <= 1.0
+    for i, k in enumerate(env.env_morph):
+        assert (a_last[i, 3 * env.num_limbs[k]:] == 0).all()
+
+
+def test_training_round_updates_the_policy_and_the_rollout_follows():
+    torch, tr = _trainer(max_episode_steps=30, seed=5)
+    tr.warmup(80)
+    assert all(b.max_sample_size >= 16 for b in tr.buffers)
+    obs = tr.ro.env.obs.clone()
+    before = [p.detach().clone() for p in tr.agent.actor.parameters()]
+    a0 = tr.ro.policy_forward(obs).clone()
+    out = tr.train_round(max_steps=200, max_iters=3)
+    assert out["per_morph_iter"] >= 1 and out["steps"] >= 1
+    assert tr.rounds == 1
+    for name in NAMES:
+        loss = tr.last_losses[name]
+        assert np.isfinite(float(loss["loss/critic_loss"]))
+    moved = max(float((p - q).abs().max()) for p, q in zip(tr.agent.actor.parameters(), before))
+    assert moved > 0                                           # policy_freq = 2: it = 0 (and 2) updated the actor
+    # the batched HIP actor of the rollout reads the optimizer's in-place updates: same numbers as the PyTorch path now
+    a1 = tr.ro.policy_forward(obs).clone()
+    assert float((a1 - a0).abs().max()) > 0
+    env = tr.ro.env
+    pol = tr.agent.actor
+    pol.use_hip = False
+    with torch.no_grad():
+        for k, sl in enumerate(env.morph_slices):
+            L = env.num_limbs[k]
+            pol.change_morphology(tr.graph_dicts[k])
+            ref = pol(obs[sl, :41 * L])
+            assert float((ref - a1[sl, :3 * L]).abs().max()) < 2e-5, NAMES[k]
+    pol.use_hip = True
+    # targets track the online networks by tau (agent.py:185-187)
+    d_on = sum(float((p - q).abs().sum()) for p, q in zip(tr.agent.actor.parameters(), before))
+    d_tg = sum(float((p - q).abs().sum()) for p, q in zip(tr.agent.actor_target.parameters(), before))
+    assert 0 < d_tg < d_on
+    assert tr.ro.env.row_overflow_envs() == 0
