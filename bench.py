@@ -39,27 +39,17 @@ def algorithmic_bytes_per_env_step(env):
     return total / float(sum(env.counts))
 
 
-def cpu_baseline(names, seed, budget_s=12.0):
-    """The CPU oracle (oracle/physics.c, FP64, same algorithm) + PyTorch-CPU SEPolicy stepped on the host cores over a
-    bounded sample of the same workload.  kind = "port": the reference's own stack (MuJoCo 2.1 + gym) is not installable."""
-    import multiprocessing as mp
-    import numpy as np
-    cores = os.cpu_count() or 1
-    per_morph = 16
-    steps = 400
-    jobs = [(n, i, seed, steps) for n in names for i in range(per_morph)]
-    from concurrent.futures import ProcessPoolExecutor
-    from oracle import physics_ref
-    physics_ref.lib()   # build/load the checker ONCE in the parent; the forked workers inherit it
-    t0 = time.time()
-    with ProcessPoolExecutor(max_workers=min(cores, len(jobs)), mp_context=mp.get_context("fork")) as pool:
-        done = list(pool.map(_cpu_worker, jobs, timeout=120))
-    t_env = time.time() - t0
-    n_steps = sum(done)
-    # SET forward on PyTorch-CPU, batched per morphology (B = per_morph), same number of env-steps
+def _cpu_sample(names, seed, per_morph, steps, cores, pool_cls, mp_ctx):
+    """One bounded sample: `per_morph` oracle envs per walker variant stepped `steps` times on the host cores, then the
+    PyTorch-CPU SEPolicy forward batched per morphology (B = per_morph) for the same number of env-steps."""
     import torch
     from sgrl_amd.set_policy import make_policy
     from sgrl_amd import graph as G, mjcf
+    jobs = [(n, i, seed, steps) for n in names for i in range(per_morph)]
+    t0 = time.time()
+    with pool_cls(max_workers=min(cores, len(jobs)), mp_context=mp_ctx) as pool:
+        done = list(pool.map(_cpu_worker, jobs, timeout=120))
+    t_env = time.time() - t0
     torch.set_num_threads(min(cores, 16))
     pol = make_policy(use_hip=False).eval()
     t1 = time.time()
@@ -71,12 +61,62 @@ def cpu_baseline(names, seed, budget_s=12.0):
             for _ in range(steps):
                 pol(x)
     t_set = time.time() - t1
-    return {"value": round(n_steps / (t_env + t_set), 1), "unit": "env-steps/s", "cores": min(cores, len(jobs)),
-            "kind": "port",
-            "sample": "%d envs (%d per walker variant) x %d steps: oracle/physics.c FP64 step on %d processes (%.1f s) + "
-                      "PyTorch-CPU SEPolicy forward B=%d per morphology (%.1f s)" % (
-                          len(jobs), per_morph, steps, min(cores, len(jobs)), t_env, per_morph, t_set),
-            "env_only_steps_per_s": round(n_steps / t_env, 1)}
+    return sum(done), t_env, t_set
+
+
+def _reference_shaped(names, seed, steps, pool_cls, mp_ctx):
+    """The reference's own shape (reference src/trainer.py:173-200): n = #morphologies environments, one worker process
+    each (SubprocVecEnv), and per time step one B = 1 `select_action` forward per environment on the main process."""
+    import torch
+    from sgrl_amd.set_policy import make_policy
+    from sgrl_amd import graph as G, mjcf
+    jobs = [(n, 0, seed, steps) for n in names]
+    t0 = time.time()
+    with pool_cls(max_workers=len(jobs), mp_context=mp_ctx) as pool:
+        done = list(pool.map(_cpu_worker, jobs, timeout=120))
+    t_env = time.time() - t0
+    pol = make_policy(use_hip=False).eval()
+    gds = [(G.getGraphDict(mjcf.load_asset(n).parents, ["pre", "inlcrs", "postlcrs"], [], device=torch.device("cpu")),
+            mjcf.load_asset(n).num_limbs) for n in names]
+    t1 = time.time()
+    with torch.no_grad():
+        for _ in range(steps):
+            for gd, L in gds:
+                pol.change_morphology(gd)
+                pol(torch.randn(1, 41 * L))
+    t_set = time.time() - t1
+    return sum(done) / (t_env + t_set), t_env, t_set
+
+
+def cpu_baseline(names, seed):
+    """the CPU oracle (oracle/physics.c, FP64, same algorithm) + PyTorch-CPU SEPolicy on the host
+    cores over a bounded sample of the same workload, median of 3 samples, plus the "reference-shaped" figure (8 envs,
+    B = 1 forwards).  kind = "port": the reference's own stack (MuJoCo 2.1 + gym) is not installable on the box."""
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    from oracle import physics_ref
+    cores = os.cpu_count() or 1
+    per_morph, steps = 16, 80
+    physics_ref.lib()   # build/load the checker ONCE in the parent; the forked workers inherit it
+    ctx = mp.get_context("fork")
+    samples = []
+    for rep in range(3):
+        n_steps, t_env, t_set = _cpu_sample(names, seed + rep, per_morph, steps, cores, ProcessPoolExecutor, ctx)
+        samples.append((n_steps / (t_env + t_set), n_steps / t_env, t_env, t_set))
+    samples.sort()
+    med = samples[1]
+    ref_rate, ref_env, ref_set = _reference_shaped(names, seed, 100, ProcessPoolExecutor, ctx)
+    nproc = min(cores, per_morph * len(names))
+    return {"value": round(med[0], 1), "unit": "env-steps/s", "cores": nproc, "kind": "port",
+            "sample": "median of 3 samples of %d envs (%d per walker variant) x %d steps: oracle/physics.c FP64 step on %d "
+                      "processes (%.1f s) + PyTorch-CPU SEPolicy forward B=%d per morphology (%.1f s)" % (
+                          per_morph * len(names), per_morph, steps, nproc, med[2], per_morph, med[3]),
+            "samples": [round(x[0], 1) for x in samples],
+            "env_only_steps_per_s": round(med[1], 1),
+            "reference_shaped": {"value": round(ref_rate, 1), "unit": "env-steps/s", "cores": len(names) + 1,
+                                 "sample": "%d envs (one per walker variant, one process each) x 100 steps (%.2f s) + one B=1 "
+                                           "SEPolicy forward per env per step on the main process (%.1f s): the shape of "
+                                           "reference trainer.py:173-200" % (len(names), ref_env, ref_set)}}
 
 
 def _cpu_worker(job):
@@ -93,6 +133,15 @@ def _cpu_worker(job):
     for _ in range(steps):
         env.step(rng.uniform(-1, 1, size=3 * m.num_limbs))
     return steps
+
+
+# multiply-accumulates the SET forward EXECUTES per limb node (after the Gram-triangle folding: K = 544 instead of 1024 on
+# the seven Gram-fed layers; projections as the zero-padded stacked GEMM operands the kernels really run)
+def set_executed_flops_per_node():
+    layer = (3 * 128 * 32) + 544 * 256 + 256 * 128 + 256 * 768 + 3 * 128 * 256 + 256 * 128 + 3 * 256 * 128      # attention
+    layer += (3 * 128 * 64) + 544 * 256 + 256 * 128 + 2 * (256 * 256) + 256 * 128 + 256 * 1024 + 3 * 32 * 32 + 3 * 32 * 128
+    head = (3 * 144 * 64) + 544 * 128 + 128 * 128 + 160 * 128 + 128 * 128 + 256 * 256 + 256 * 1024 + 3 * 32 * 32
+    return 2 * (3 * layer + head)
 
 
 def main():
@@ -181,15 +230,17 @@ def main():
         ms_set = ro.actor.time_forward(env.obs, ro.policy_actions, 5)
         bytes_step = algorithmic_bytes_per_env_step(env)
         achieved = bytes_step * n_local / (ms_step * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_src = None, None
         pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):   # FETCH_SIZE/WRITE_SIZE of k_env_step from separate rocprofv3 --pmc passes of this command
             with open(pmc) as f:
                 pj = json.load(f)
             if pj.get("envs_per_gpu") == n_local:
                 traffic = pj.get("k_env_step_bytes_per_launch")
+                traffic_src = "profiles/pmc_traffic.json: FETCH_SIZE + WRITE_SIZE per launch from two rocprofv3 --pmc passes " \
+                              "of this command (%s); not re-measured in this run" % pj.get("build", "see profiles/README.md")
         extra["roofline"] = {"bound": "hbm", "kernel": "k_env_step", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                              "algorithmic_bytes_per_launch": int(bytes_step * n_local),
                              "ms_per_launch": round(ms_step, 4),
                              "dispatches_per_launch": env.launch_groups,
@@ -197,11 +248,25 @@ def main():
                                      "against ~1e6 FP64 operations; see DESIGN.md (roofline).  One launch = one "
                                      "sgrl_step = dispatches_per_launch concurrent k_env_step dispatches (one per LDS "
                                      "occupancy class); ms_per_launch is the HIP-event time of the whole launch"}
+        # the VALU view of the same kernel (it is issue / latency bound, not HBM bound): SQ counters of a separate
+        # rocprofv3 --pmc pass of this command, committed under profiles/
+        sq = os.path.join(REPO, "profiles", "sq_pmc.json")
+        if os.path.exists(sq):
+            with open(sq) as f:
+                sj = json.load(f)
+            if sj.get("envs_per_gpu") == n_local:
+                extra["roofline_valu"] = sj.get("k_env_step")
         nodes = ro.actor.num_nodes
+        ex = set_executed_flops_per_node()
         extra["set_actor"] = {"ms_per_forward": round(ms_set, 4), "us_per_env_step": round(ms_set * 1e3 / n_local, 4),
-                              "nodes": nodes, "tflops": round(nodes * 10.07e6 / (ms_set * 1e-3) / 1e12, 2),
+                              "nodes": nodes, "nominal_flops_per_node": 10.07e6, "executed_flops_per_node": ex,
+                              "tflops_nominal": round(nodes * 10.07e6 / (ms_set * 1e-3) / 1e12, 2),
+                              "tflops_executed": round(nodes * ex / (ms_set * 1e-3) / 1e12, 2),
                               "mfma_f32_peak_tflops": 157.3,
-                              "frac_of_f32_mfma_peak": round(nodes * 10.07e6 / (ms_set * 1e-3) / 157.3e12, 4)}
+                              "frac_of_f32_mfma_peak_nominal": round(nodes * 10.07e6 / (ms_set * 1e-3) / 157.3e12, 4),
+                              "frac_of_f32_mfma_peak_executed": round(nodes * ex / (ms_set * 1e-3) / 157.3e12, 4),
+                              "note": "nominal = the reference's dense layer sizes (1024-wide Gram inputs); executed = what "
+                                      "the kernels run after folding the symmetric Gram matrix onto its packed triangle"}
         rec, cnt = env.get_records()
         extra["row_overflow_envs"] = int((cnt[:, 2] > 0).sum())
         if cpu_base is not None:
