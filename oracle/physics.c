@@ -385,28 +385,49 @@ static void collide(const SgrlModelView* m, Work* w) {
         plane_sphere(w, p, 2 * p, margin, p1, n, ca, r, ax); /* frames aligned with the capsule axis [3P-knowledge] */
         plane_sphere(w, p, 2 * p + 1, margin, p1, n, cb, r, ax);
       }
-    } else { /* capsule - capsule */
+    } else { /* capsule - capsule: restates mjc_CapsuleCapsule of MuJoCo 2.1 [3P-knowledge] -- one contact between the
+              * closest points of the two segments; for PARALLEL axes the closest "point" is a whole stretch, and up to
+              * two contacts are made by testing the end spheres of each capsule against the other's axis */
       double a1[3] = {m1[2], m1[5], m1[8]}, a2[3] = {m2[2], m2[5], m2[8]};
       double h1 = m->geom_size[3 * g1 + 1], h2 = m->geom_size[3 * g2 + 1];
       double r1 = m->geom_size[3 * g1], r2 = m->geom_size[3 * g2];
-      /* closest points of segments p1 + s*a1 (|s|<=h1), p2 + t*a2 (|t|<=h2) */
+      /* points p1 + s*a1 (|s|<=h1), p2 + t*a2 (|t|<=h2) */
       double d[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
       double b = dot3(a1, a2), c = dot3(a1, d), f = dot3(a2, d);
-      double den = 1.0 - b * b, s, t;
-      if (den > 1e-12) s = (b * f - c) / den; else s = 0;
-      if (s > h1) s = h1; if (s < -h1) s = -h1;
-      t = b * s + f;
-      if (t > h2) { t = h2; s = b * t - c; if (s > h1) s = h1; if (s < -h1) s = -h1; }
-      else if (t < -h2) { t = -h2; s = b * t - c; if (s > h1) s = h1; if (s < -h1) s = -h1; }
-      double c1[3], c2[3], nn[3];
-      for (int k = 0; k < 3; k++) { c1[k] = p1[k] + s * a1[k]; c2[k] = p2[k] + t * a2[k]; nn[k] = c2[k] - c1[k]; }
-      double len = sqrt(dot3(nn, nn));
-      double dist = len - r1 - r2;
-      if (dist >= margin) continue;
-      if (len < MINVAL) { nn[0] = 1; nn[1] = 0; nn[2] = 0; } else for (int k = 0; k < 3; k++) nn[k] /= len;
-      double pos[3];
-      for (int k = 0; k < 3; k++) pos[k] = c1[k] + nn[k] * (r1 + 0.5 * dist);
-      add_contact(w, p, 2 * p, dist, pos, nn, 0);
+      double den = 1.0 - b * b;
+      double ss[4], tt[4];
+      int ncand = 0, made = 0;
+      if (fabs(den) >= MINVAL) {
+        double s = (b * f - c) / den, t;
+        if (s > h1) s = h1; if (s < -h1) s = -h1;
+        t = b * s + f;
+        if (t > h2) { t = h2; s = b * t - c; if (s > h1) s = h1; if (s < -h1) s = -h1; }
+        else if (t < -h2) { t = -h2; s = b * t - c; if (s > h1) s = h1; if (s < -h1) s = -h1; }
+        ss[0] = s; tt[0] = t; ncand = 1;
+      } else {
+        for (int e = 0; e < 2; e++) {            /* ends of capsule 1 against axis 2 */
+          double s = e ? -h1 : h1, t = b * s + f;
+          if (t > h2) t = h2; if (t < -h2) t = -h2;
+          ss[ncand] = s; tt[ncand] = t; ncand++;
+        }
+        for (int e = 0; e < 2; e++) {            /* ends of capsule 2 against axis 1 */
+          double t = e ? -h2 : h2, s = b * t - c;
+          if (s > h1) s = h1; if (s < -h1) s = -h1;
+          ss[ncand] = s; tt[ncand] = t; ncand++;
+        }
+      }
+      for (int q = 0; q < ncand && made < 2; q++) {
+        double c1[3], c2[3], nn[3];
+        for (int k = 0; k < 3; k++) { c1[k] = p1[k] + ss[q] * a1[k]; c2[k] = p2[k] + tt[q] * a2[k]; nn[k] = c2[k] - c1[k]; }
+        double len = sqrt(dot3(nn, nn));
+        double dist = len - r1 - r2;
+        if (dist >= margin) continue;
+        if (len < MINVAL) { nn[0] = 1; nn[1] = 0; nn[2] = 0; } else for (int k = 0; k < 3; k++) nn[k] /= len;
+        double pos[3];
+        for (int k = 0; k < 3; k++) pos[k] = c1[k] + nn[k] * (r1 + 0.5 * dist);
+        add_contact(w, p, 2 * p + made, dist, pos, nn, 0);
+        made++;
+      }
     }
   }
 }

@@ -582,28 +582,47 @@ struct Engine {
           plane_sphere(2 * p + 1, margin, p1, n, cb, r, ax);
         }
       } else {
+        // capsule - capsule (oracle/physics.c collide()): closest points of the two segments; parallel axes: the end
+        // spheres of each capsule against the other's axis, at most two contacts
         const double a1[3] = {m1[2], m1[5], m1[8]}, a2[3] = {m2[2], m2[5], m2[8]};
         const double h1 = m.geom_size[3 * g1 + 1], h2 = m.geom_size[3 * g2 + 1];
         const double r1 = m.geom_size[3 * g1], r2 = m.geom_size[3 * g2];
         const double d[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
         const double bb = dot3(a1, a2), c = dot3(a1, d), f = dot3(a2, d);
         const double den = 1.0 - bb * bb;
-        double s, t;
-        if (den > 1e-12) s = (bb * f - c) / den; else s = 0;
-        if (s > h1) s = h1;
-        if (s < -h1) s = -h1;
-        t = bb * s + f;
-        if (t > h2) { t = h2; s = bb * t - c; if (s > h1) s = h1; if (s < -h1) s = -h1; }
-        else if (t < -h2) { t = -h2; s = bb * t - c; if (s > h1) s = h1; if (s < -h1) s = -h1; }
-        double c1[3], nn[3];
-        for (int k = 0; k < 3; k++) { c1[k] = p1[k] + s * a1[k]; nn[k] = (p2[k] + t * a2[k]) - c1[k]; }
-        const double len = sqrt(dot3(nn, nn));
-        const double dist = len - r1 - r2;
-        if (len < kMinVal) { nn[0] = 1; nn[1] = 0; nn[2] = 0; } else for (int k = 0; k < 3; k++) nn[k] /= len;
-        double pos[3];
-        for (int k = 0; k < 3; k++) pos[k] = c1[k] + nn[k] * (r1 + 0.5 * dist);
-        put_contact(2 * p, dist < margin, dist, pos, nn, nullptr);
+        const bool general = fabs(den) >= kMinVal;
+        int made = 0;
+        I[o.con_valid + 2 * p] = 0;
         I[o.con_valid + 2 * p + 1] = 0;
+        for (int q = 0; q < (general ? 1 : 4) && made < 2; q++) {
+          double s, t;
+          if (general) {
+            s = (bb * f - c) / den;
+            if (s > h1) s = h1;
+            if (s < -h1) s = -h1;
+            t = bb * s + f;
+            if (t > h2) { t = h2; s = bb * t - c; if (s > h1) s = h1; if (s < -h1) s = -h1; }
+            else if (t < -h2) { t = -h2; s = bb * t - c; if (s > h1) s = h1; if (s < -h1) s = -h1; }
+          } else if (q < 2) {
+            s = q ? -h1 : h1; t = bb * s + f;
+            if (t > h2) t = h2;
+            if (t < -h2) t = -h2;
+          } else {
+            t = (q & 1) ? -h2 : h2; s = bb * t - c;
+            if (s > h1) s = h1;
+            if (s < -h1) s = -h1;
+          }
+          double c1[3], nn[3];
+          for (int k = 0; k < 3; k++) { c1[k] = p1[k] + s * a1[k]; nn[k] = (p2[k] + t * a2[k]) - c1[k]; }
+          const double len = sqrt(dot3(nn, nn));
+          const double dist = len - r1 - r2;
+          if (dist >= margin) continue;
+          if (len < kMinVal) { nn[0] = 1; nn[1] = 0; nn[2] = 0; } else for (int k = 0; k < 3; k++) nn[k] /= len;
+          double pos[3];
+          for (int k = 0; k < 3; k++) pos[k] = c1[k] + nn[k] * (r1 + 0.5 * dist);
+          put_contact(2 * p + made, true, dist, pos, nn, nullptr);
+          made++;
+        }
       }
     });
   }

@@ -246,7 +246,76 @@ def capsule_volume(r, h, mode="mujoco210"):
     return math.pi * (r * r * 2 * h + r ** 3)
 
 
-def compile_mjcf(xml_path, name=None, capsule_volume_mode="mujoco210"):
+# What compile_mjcf reads, per element (context "default/<tag>" = inside <default>).  Anything else in a model file is
+# either on the no-dynamics list below or an error: an attribute this compiler does not understand must not be dropped
+# silently (it could be a `ref`, a `springref`, a `frictionloss`, an <inertial> ... that MuJoCo would honour).
+_JOINT_ATTRS = {"type", "pos", "axis", "limited", "range", "armature", "damping", "stiffness", "margin", "solreflimit",
+                "solimplimit", "name"}
+_GEOM_ATTRS = {"type", "size", "contype", "conaffinity", "condim", "friction", "density", "margin", "gap", "solmix",
+               "solref", "solimp", "fromto", "pos", "quat", "axisangle", "name"}
+_MOTOR_ATTRS = {"ctrllimited", "ctrlrange", "gear", "joint", "name"}
+_CONSUMED = {
+    "mujoco": {"model"},
+    "compiler": {"angle", "coordinate", "inertiafromgeom"},
+    "option": {"timestep", "integrator", "gravity"},
+    "default": set(), "worldbody": set(), "actuator": set(),
+    "default/joint": _JOINT_ATTRS - {"name"}, "default/geom": _GEOM_ATTRS - {"name", "fromto", "pos", "quat", "axisangle"},
+    "default/motor": {"ctrllimited", "ctrlrange", "gear"},
+    "body": {"name", "pos", "quat", "axisangle"},
+    "joint": _JOINT_ATTRS, "geom": _GEOM_ATTRS, "motor": _MOTOR_ATTRS,
+}
+# rendering / memory settings with no effect on the dynamics
+_NO_DYNAMICS_ATTRS = {"geom": {"material", "rgba"}, "default/geom": {"material", "rgba"}}
+_NO_DYNAMICS_ELEMENTS = {"light", "camera", "map", "visual", "asset", "texture", "material", "skybox", "quality", "headlight",
+                         "global", "rgba"}
+_NO_DYNAMICS_SIZE = {"nstack", "nuser_geom", "nconmax", "njmax"}
+_VISUAL_INCLUDES = {"skybox.xml", "visual.xml", "materials.xml"}
+
+
+def audit_mjcf(xml_path):
+    """Every element / attribute of the file that compile_mjcf neither consumes nor knows to be irrelevant to the
+    dynamics, as 'element@attribute' (or 'element' for a whole unknown element).  Empty list = fully understood."""
+    root = ET.parse(xml_path).getroot()
+    unknown = []
+
+    def walk(e, in_default):
+        tag = e.tag
+        if not isinstance(tag, str):
+            return
+        if tag in _NO_DYNAMICS_ELEMENTS:
+            return
+        if tag == "include":
+            if os.path.basename(e.get("file", "")) not in _VISUAL_INCLUDES:
+                unknown.append("include@file=%s" % e.get("file"))
+            return
+        if tag == "size":
+            unknown.extend("size@" + k for k in e.attrib if k not in _NO_DYNAMICS_SIZE)
+            return
+        ctx = "default/" + tag if in_default and tag != "default" else tag
+        if ctx not in _CONSUMED:
+            unknown.append(ctx)
+            return
+        ok = _CONSUMED[ctx] | _NO_DYNAMICS_ATTRS.get(ctx, set())
+        unknown.extend("%s@%s" % (ctx, k) for k in e.attrib if k not in ok)
+        if tag == "compiler" and e.get("inertiafromgeom", "true") != "true":
+            unknown.append("compiler@inertiafromgeom=%s" % e.get("inertiafromgeom"))
+        if tag in ("joint",) and e.get("type", "hinge") not in ("hinge", "free"):
+            unknown.append("joint@type=%s" % e.get("type"))
+        if tag == "geom" and not in_default and e.get("type", "sphere") not in ("plane", "sphere", "capsule"):
+            unknown.append("geom@type=%s" % e.get("type"))
+        for c in e:
+            walk(c, in_default or tag == "default")
+    walk(root, False)
+    return sorted(set(unknown))
+
+
+def compile_mjcf(xml_path, name=None, capsule_volume_mode="mujoco210", strict=True):
+    """strict: refuse a file that contains anything this compiler would silently drop (see audit_mjcf)."""
+    if strict:
+        unknown = audit_mjcf(xml_path)
+        if unknown:
+            raise ValueError("%s: MJCF elements / attributes not understood by sgrl_amd.mjcf (would be ignored): %s"
+                             % (os.path.basename(xml_path), ", ".join(unknown)))
     root = ET.parse(xml_path).getroot()
     comp = root.find("compiler")
     angle_deg = (comp.get("angle", "degree") == "degree") if comp is not None else True
