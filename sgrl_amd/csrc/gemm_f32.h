@@ -1,0 +1,354 @@
+// gemm_f32.h -- the SET actor's f32 MFMA GEMM for gfx950:  C[M,N] = epi(A[M,K] . W[N,K]^T)
+//
+// v_mfma_f32_32x32x2_f32 (exact f32 arithmetic: results track the reference's f32 PyTorch path).  Row-major LDS tiles
+// [rows][BK + 4] so that both the global->LDS staging (one ds_write_b128 per float4) and the operand fetch (one
+// ds_read_b128 = FOUR k-steps of a lane's operand) move 16 bytes per instruction: lane (row, half) of the MFMA owns the
+// contiguous k range [8 * half, 8 * half + 8) of its row -- the matrix instruction sums over k, so which pair of k values
+// an MFMA step covers is free as long as A and W use the same assignment.  Row stride 20 dwords: the 16 lanes of every
+// ds_read_b128 lane group fall on distinct 4-bank groups (20 r mod 64 is injective on 16 consecutive rows).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sgrl_gemm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { EPI_RELU = 1, EPI_ROWDIV = 2, EPI_ACC2 = 4 };
+
+struct GemmArgs {
+  const float* A; int lda;
+  const float* W; int ldw;
+  const float* bias;
+  float* C; int ldc;
+  int M, N, K;
+  int flags;
+  const float* rowdiv;  // [M]: C = (A.W^T + b) / rowdiv[m]
+  float* C2; int ldc2;  // EPI_ACC2: C2[m][n] += value
+};
+
+// BKT = k extent of an LDS tile (16 or 32); row stride BKT + 4 floats (conflict-free ds_read_b128, see above).
+// PF = register prefetch depth: global loads run PF k-tiles ahead of the LDS stage they are written to (PF = 2 doubles the
+// latency budget of a load at the price of one more set of staging registers).
+template <int WM, int WN, int TM, int TN, int BKT>
+struct TileCfg {
+  static constexpr int kThreads = 64 * WM * WN;
+  static constexpr int kBM = 32 * TM * WM, kBN = 32 * TN * WN;
+  static constexpr int kSK = BKT + 4;
+  static constexpr int kLdsBytes = 2 * (kBM + kBN) * kSK * (int)sizeof(float);
+};
+
+// WM x WN waves, each computing a (32 TM) x (32 TN) patch of the block tile.
+template <int FLAGS, int WM, int WN, int TM, int TN, int BKT = 16, int PF = 1>
+__global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
+  using Cfg = TileCfg<WM, WN, TM, TN, BKT>;
+  constexpr int T = Cfg::kThreads, BMT = Cfg::kBM, BNT = Cfg::kBN, SK = Cfg::kSK;
+  constexpr int QPR = BKT / 4;                // float4 per tile row
+  constexpr int RPP = T / QPR;                // tile rows covered per staging pass
+  static_assert(BMT % RPP == 0 && BNT % RPP == 0, "tile rows must be a multiple of the staging pass");
+  static_assert(PF == 1 || PF == 2, "prefetch depth 1 or 2");
+  constexpr int NPA = BMT / RPP, NPW = BNT / RPP;
+  constexpr int KH = BKT / 2;                 // k values per MFMA half (lanes 0..31 | 32..63)
+  constexpr int NQ = KH / 4;                  // float4 per lane per operand row per tile
+  extern __shared__ float gemm_lds[];
+  float* As = gemm_lds;                        // [2][BMT][SK]
+  float* Ws = gemm_lds + 2 * BMT * SK;         // [2][BNT][SK]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = (a.N + BNT - 1) / BNT;
+  // blocks b and b+8 share an XCD (round-robin dispatch): renumber so that each XCD works on a contiguous run of tiles
+  // (the column tiles of one row tile re-read the same A rows out of ONE L2); speed only, never correctness
+  int bid;
+  {
+    const int nt = gridDim.x, per = nt >> 3, rem = nt & 7, x = blockIdx.x & 7, i = blockIdx.x >> 3;
+    bid = (x < rem) ? x * (per + 1) + i : rem * (per + 1) + (x - rem) * per + i;
+  }
+  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  const int m0 = tile_m * BMT, n0 = tile_n * BNT;
+  const int kq = t % QPR, r0 = t / QPR;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+  float4 ra[PF][NPA], rw[PF][NPW];
+  auto gload = [&](int slot, int k0) {
+#pragma unroll
+    for (int i = 0; i < NPA; i++) {
+      const int m = m0 + r0 + RPP * i;
+      ra[slot][i] = (m < a.M) ? *reinterpret_cast<const float4*>(a.A + (size_t)m * a.lda + k0 + 4 * kq) : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NPW; i++) {
+      const int n = n0 + r0 + RPP * i;
+      rw[slot][i] = (n < a.N) ? *reinterpret_cast<const float4*>(a.W + (size_t)n * a.ldw + k0 + 4 * kq) : make_float4(0, 0, 0, 0);
+    }
+  };
+  auto sstore = [&](int slot, int st) {
+#pragma unroll
+    for (int i = 0; i < NPA; i++) *reinterpret_cast<float4*>(As + (st * BMT + r0 + RPP * i) * SK + 4 * kq) = ra[slot][i];
+#pragma unroll
+    for (int i = 0; i < NPW; i++) *reinterpret_cast<float4*>(Ws + (st * BNT + r0 + RPP * i) * SK + 4 * kq) = rw[slot][i];
+  };
+  const int nk = a.K / BKT;
+  gload(0, 0);
+  sstore(0, 0);
+  __syncthreads();
+  // registers hold tiles 1 .. PF (slot of tile k = (k - 1) % PF)
+  if (nk > 1) gload(0, BKT);
+  if (PF == 2 && nk > 2) gload(1, 2 * BKT);
+  const int li = lane & 31, lh = lane >> 5;
+  const float* arow = As + (wm * 32 * TM + li) * SK + KH * lh;
+  const float* brow = Ws + (wn * 32 * TN + li) * SK + KH * lh;
+  auto body = [&](int kt, int slot) {      // slot = register slot holding tile kt + 1 (compile-time constant per call site)
+    const int st = kt & 1;
+    // push tile kt+1 into the idle LDS stage FIRST so the writes drain underneath this tile's MFMAs, then start fetching
+    // tile kt+1+PF into the register slot just freed
+    if (kt + 1 < nk) sstore(slot, st ^ 1);
+    if (kt + 1 + PF < nk) gload(slot, (kt + 1 + PF) * BKT);
+    float4 av[TM][NQ], bv[TN][NQ];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int q = 0; q < NQ; q++) av[i][q] = *reinterpret_cast<const float4*>(arow + (st * BMT + 32 * i) * SK + 4 * q);
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int q = 0; q < NQ; q++) bv[j][q] = *reinterpret_cast<const float4*>(brow + (st * BNT + 32 * j) * SK + 4 * q);
+#pragma unroll
+    for (int h = 0; h < NQ; h++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+          const float x = q == 0 ? av[i][h].x : (q == 1 ? av[i][h].y : (q == 2 ? av[i][h].z : av[i][h].w));
+#pragma unroll
+          for (int j = 0; j < TN; j++) {
+            const float y = q == 0 ? bv[j][h].x : (q == 1 ? bv[j][h].y : (q == 2 ? bv[j][h].z : bv[j][h].w));
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  };
+  if (PF == 1) {
+    for (int kt = 0; kt < nk; kt++) body(kt, 0);
+  } else {
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) { body(kt, 0); body(kt + 1, 1); }
+    if (kt < nk) body(kt, 0);
+  }
+  // epilogue: C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+  // FLAGS is a compile-time constant: no per-element branches, the 16 row divisors of a tile are fetched together.
+#pragma unroll
+  for (int ti = 0; ti < TM; ti++) {
+    const int mb = m0 + wm * 32 * TM + ti * 32 + 4 * lh;
+    float rdiv[16];
+    if (FLAGS & EPI_ROWDIV) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int m = mb + (e & 3) + 8 * (e >> 2);
+        rdiv[e] = 1.0f / ((m < a.M) ? a.rowdiv[m] : 1.f);     // one reciprocal per row, applied by multiplication below
+      }
+    }
+#pragma unroll
+    for (int tj = 0; tj < TN; tj++) {
+      const int n = n0 + wn * 32 * TN + tj * 32 + li;
+      if (n >= a.N) continue;
+      const float bvv = a.bias ? a.bias[n] : 0.f;
+      float old2[16];
+      if (FLAGS & EPI_ACC2) {   // all sixteen second-destination reads in flight before the first store
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int m = mb + (e & 3) + 8 * (e >> 2);
+          old2[e] = (m < a.M) ? a.C2[(size_t)m * a.ldc2 + n] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int m = mb + (e & 3) + 8 * (e >> 2);
+        if (m >= a.M) continue;
+        float v = acc[ti][tj][e] + bvv;
+        if (FLAGS & EPI_RELU) v = fmaxf(v, 0.f);
+        if (FLAGS & EPI_ROWDIV) v = v * rdiv[e];
+        a.C[(size_t)m * a.ldc + n] = v;
+        if (FLAGS & EPI_ACC2) a.C2[(size_t)m * a.ldc2 + n] = old2[e] + v;
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Split-precision variant: the same f32 GEMM carried by the bf16 matrix cores (16x the f32 MFMA rate on gfx950).
+//
+// Every f32 operand x is split EXACTLY into three bf16 pieces x = h + m + l (8 + 8 + 8 significand bits, by truncation:
+// h = top 16 bits of x, m = top 16 bits of x - h, l = x - h - m, each difference exact in f32), and the product a.b is
+// rebuilt from the six partial products whose weight reaches 2^-16 relative: hh | hm mh | hl lh mm.  A bf16 x bf16 product
+// is exact in f32 and the matrix core accumulates in f32, so what is dropped is ml + lm + ll <= 2^-23 |a||b| per term --
+// the size of the rounding error an f32 FMA chain commits per term anyway.  The leading hh products and the five
+// correction products accumulate in separate registers and are added once in the epilogue, so the small terms are not
+// rounded against the large running sum.  Six v_mfma_f32_32x32x16_bf16 (32 cycles, k = 16) replace eight
+// v_mfma_f32_32x32x2_f32 (64 cycles, k = 2) per 16 k-steps: 2.67x fewer matrix-pipe cycles.
+// tools/gemm_lab.hip measures the result against float64: same error as the exact-f32 kernel.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+  h = __float_as_uint(x) & 0xFFFF0000u;
+  const float r1 = x - __uint_as_float(h);
+  m = __float_as_uint(r1) & 0xFFFF0000u;
+  const float r2 = r1 - __uint_as_float(m);
+  l = __float_as_uint(r2);                 // at most 8 significant bits are left: its low 16 bits are zero
+}
+// two f32 bit patterns -> one dword holding their top halves (bf16 of the first in the low half)
+__device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+template <int WM, int WN, int TM, int TN>
+struct TileCfg3 {
+  static constexpr int kThreads = 64 * WM * WN;
+  static constexpr int kBM = 32 * TM * WM, kBN = 32 * TN * WN;
+  static constexpr int kBK = 32;
+  static constexpr int kRowBytes = 2 * kBK + 16;          // 32 bf16 + 16 B pad = 20 dwords: conflict-free ds_read_b128
+  static constexpr int kPlaneA = kBM * kRowBytes, kPlaneW = kBN * kRowBytes;
+  static constexpr int kStageBytes = 3 * (kPlaneA + kPlaneW);
+  static constexpr int kLdsBytes = 2 * kStageBytes;
+};
+
+template <int FLAGS, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(64 * WM * WN) void k_gemm3(GemmArgs a) {
+  using Cfg = TileCfg3<WM, WN, TM, TN>;
+  constexpr int T = Cfg::kThreads, BMT = Cfg::kBM, BNT = Cfg::kBN, BKT = Cfg::kBK, RB = Cfg::kRowBytes;
+  constexpr int QPR = BKT / 4;                // float4 per tile row
+  constexpr int RPP = T / QPR;                // tile rows covered per staging pass
+  static_assert(BMT % RPP == 0 && BNT % RPP == 0, "tile rows must be a multiple of the staging pass");
+  constexpr int NPA = BMT / RPP, NPW = BNT / RPP;
+  extern __shared__ float gemm_lds[];
+  char* lds = reinterpret_cast<char*>(gemm_lds);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = (a.N + BNT - 1) / BNT;
+  int bid;
+  {
+    const int nt = gridDim.x, per = nt >> 3, rem = nt & 7, x = blockIdx.x & 7, i = blockIdx.x >> 3;
+    bid = (x < rem) ? x * (per + 1) + i : rem * (per + 1) + (x - rem) * per + i;
+  }
+  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  const int m0 = tile_m * BMT, n0 = tile_n * BNT;
+  const int kq = t % QPR, r0 = t / QPR;
+  f32x16 acc[TM][TN], cor[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) { acc[i][j][e] = 0.f; cor[i][j][e] = 0.f; }
+  float4 ra[NPA], rw[NPW];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NPA; i++) {
+      const int m = m0 + r0 + RPP * i;
+      ra[i] = (m < a.M) ? *reinterpret_cast<const float4*>(a.A + (size_t)m * a.lda + k0 + 4 * kq) : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NPW; i++) {
+      const int n = n0 + r0 + RPP * i;
+      rw[i] = (n < a.N) ? *reinterpret_cast<const float4*>(a.W + (size_t)n * a.ldw + k0 + 4 * kq) : make_float4(0, 0, 0, 0);
+    }
+  };
+  // split a float4 into its three bf16 planes and store 8 bytes into each
+  auto put = [&](char* plane0, int plane_stride, int row, const float4& v) {
+    unsigned h[4], m[4], l[4];
+    split3(v.x, h[0], m[0], l[0]); split3(v.y, h[1], m[1], l[1]); split3(v.z, h[2], m[2], l[2]); split3(v.w, h[3], m[3], l[3]);
+    char* p = plane0 + row * RB + 8 * kq;
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
+    *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
+    *reinterpret_cast<uint2*>(p + 2 * plane_stride) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
+  };
+  auto sstore = [&](int st) {
+    char* base = lds + st * Cfg::kStageBytes;
+#pragma unroll
+    for (int i = 0; i < NPA; i++) put(base, Cfg::kPlaneA, r0 + RPP * i, ra[i]);
+#pragma unroll
+    for (int i = 0; i < NPW; i++) put(base + 3 * Cfg::kPlaneA, Cfg::kPlaneW, r0 + RPP * i, rw[i]);
+  };
+  const int nk = a.K / BKT;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  if (nk > 1) gload(BKT);
+  const int li = lane & 31, lh = lane >> 5;
+  const int aoff = (wm * 32 * TM + li) * RB + 16 * lh;        // this lane's 8 bf16 of k-step 0; k-step 1 is 32 bytes on
+  const int boff = 3 * Cfg::kPlaneA + (wn * 32 * TN + li) * RB + 16 * lh;
+  for (int kt = 0; kt < nk; kt++) {
+    const int st = kt & 1;
+    if (kt + 1 < nk) sstore(st ^ 1);
+    if (kt + 2 < nk) gload((kt + 2) * BKT);
+    const char* base = lds + st * Cfg::kStageBytes;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      bf16x8 av[TM][3], bv[TN][3];
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++)
+          av[i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(base + pl * Cfg::kPlaneA + aoff + 32 * i * RB + 32 * ks));
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++)
+          bv[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(base + pl * Cfg::kPlaneW + boff + 32 * j * RB + 32 * ks));
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[j][0], acc[i][j], 0, 0, 0);   // hh
+          cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][2], bv[j][0], cor[i][j], 0, 0, 0);   // lh
+          cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[j][2], cor[i][j], 0, 0, 0);   // hl
+          cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][1], bv[j][1], cor[i][j], 0, 0, 0);   // mm
+          cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][1], bv[j][0], cor[i][j], 0, 0, 0);   // mh
+          cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[j][1], cor[i][j], 0, 0, 0);   // hm
+        }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int ti = 0; ti < TM; ti++) {
+    const int mb = m0 + wm * 32 * TM + ti * 32 + 4 * lh;
+    float rdiv[16];
+    if (FLAGS & EPI_ROWDIV) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int m = mb + (e & 3) + 8 * (e >> 2);
+        rdiv[e] = 1.0f / ((m < a.M) ? a.rowdiv[m] : 1.f);
+      }
+    }
+#pragma unroll
+    for (int tj = 0; tj < TN; tj++) {
+      const int n = n0 + wn * 32 * TN + tj * 32 + li;
+      if (n >= a.N) continue;
+      const float bvv = a.bias ? a.bias[n] : 0.f;
+      float old2[16];
+      if (FLAGS & EPI_ACC2) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int m = mb + (e & 3) + 8 * (e >> 2);
+          old2[e] = (m < a.M) ? a.C2[(size_t)m * a.ldc2 + n] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int m = mb + (e & 3) + 8 * (e >> 2);
+        if (m >= a.M) continue;
+        float v = (acc[ti][tj][e] + cor[ti][tj][e]) + bvv;
+        if (FLAGS & EPI_RELU) v = fmaxf(v, 0.f);
+        if (FLAGS & EPI_ROWDIV) v = v * rdiv[e];
+        a.C[(size_t)m * a.ldc + n] = v;
+        if (FLAGS & EPI_ACC2) a.C2[(size_t)m * a.ldc2 + n] = old2[e] + v;
+      }
+    }
+  }
+}
+
+}  // namespace sgrl_gemm

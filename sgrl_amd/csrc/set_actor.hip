@@ -13,12 +13,14 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "../../include/sgrl.h"
 #include "../../include/sgrl_set.h"
+#include "gemm_f32.h"
 
 namespace {
 
@@ -30,8 +32,6 @@ int sfail(int code, const std::string& msg) { g_set_err = msg; return code; }
     if (_e != hipSuccess) return sfail(SGRL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
   } while (0)
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 constexpr int D = 128;
 constexpr int ZD = 32;
 // The 32x32 Gram matrix Z'Z is symmetric: only its lower triangle (528 values, padded to GK) is materialised and the
@@ -41,162 +41,12 @@ constexpr int GK = 544;                    // GTRI padded to a multiple of the G
 constexpr int ZLD = 64;                    // row stride of the stacked projection output [Z (30) .. | Z2 (30) ..]
 constexpr int OGLD = 144;                  // row stride of outg: 136 channels padded to the GEMM K tile
 
-// ------------------------------------------------------------------------------------------------
-// f32 MFMA GEMM:  C[M,N] = epi(A[M,K] . W[N,K]^T)      block tile 128x128x32, 4 waves of 64x64
-enum { EPI_RELU = 1, EPI_ROWDIV = 2, EPI_ACC2 = 4 };
-constexpr int BM = 128, BN = 128, BK = 16, LDT = 130;
-constexpr int TPR = BK / 4;          // threads per tile row (one float4 each)
-constexpr int RPP = 256 / TPR;       // rows covered per pass
-
-constexpr int GEMM_LDS_BYTES = 4 * BK * LDT * (int)sizeof(float);
-
-struct GemmArgs {
-  const float* A; int lda;
-  const float* W; int ldw;
-  const float* bias;
-  float* C; int ldc;
-  int M, N, K;
-  int flags;
-  const float* rowdiv;  // [M]: C = (A.W^T + b) / rowdiv[m]
-  float* C2; int ldc2;  // EPI_ACC2: C2[m][n] += value
-};
-
-// TM = 32-row MFMA tiles per wave in the M direction, WN = waves side by side in the N direction (each 64 columns):
-// block tile (32*TM*4/WN) x (64*WN).  <TM 2, WN 2> = 128 x 128; <1, 2> = 64 x 128 halves the tile for the N = 128 GEMMs,
-// whose 280 full tiles would otherwise quantise badly onto 256 CUs; <1, 1> = 128 x 64 for the narrow projections
-// (N <= 64), which would waste half or more of a 128-column tile.
-template <int FLAGS, int TM, int WN = 2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_gemm(GemmArgs a) {
-  constexpr int BNT = 64 * WN;
-  constexpr int BMT = 32 * TM * (4 / WN);
-  static_assert(BMT <= 128 && BNT <= 128, "LDS tiles hold at most 128 rows");
-  constexpr int NPA = BMT / RPP;       // A-tile load passes
-  constexpr int NPW = BNT / RPP;       // W-tile load passes
-  extern __shared__ float gemm_lds[];   // 2 stages x (A tile + W tile), k-major [BK][LDT]
-  float (*As)[BK][LDT] = reinterpret_cast<float (*)[BK][LDT]>(gemm_lds);
-  float (*Ws)[BK][LDT] = reinterpret_cast<float (*)[BK][LDT]>(gemm_lds + 2 * BK * LDT);
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int tiles_n = (a.N + BNT - 1) / BNT;
-  // blocks b and b+8 share an XCD (round-robin dispatch): renumber so that each XCD works on a contiguous run of
-  // tiles, i.e. the column tiles of one row tile re-read the same A rows out of ONE L2 (speed only, never correctness)
-  int bid;
-  {
-    const int nt = gridDim.x, per = nt >> 3, rem = nt & 7, x = blockIdx.x & 7, i = blockIdx.x >> 3;
-    bid = (x < rem) ? x * (per + 1) + i : rem * (per + 1) + (x - rem) * per + i;
-  }
-  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
-  const int m0 = tile_m * BMT, n0 = tile_n * BNT;
-  const int kq = t % TPR, r0 = t / TPR;
-  f32x16 acc[TM][2];
-  for (int i = 0; i < TM; i++) for (int j = 0; j < 2; j++) for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
-  float4 ra[NPA], rw[NPW];
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < NPA; i++) {
-      const int m = m0 + r0 + RPP * i;
-      ra[i] = (m < a.M) ? *reinterpret_cast<const float4*>(a.A + (size_t)m * a.lda + k0 + 4 * kq) : make_float4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < NPW; i++) {
-      const int n = n0 + r0 + RPP * i;
-      rw[i] = (n < a.N) ? *reinterpret_cast<const float4*>(a.W + (size_t)n * a.ldw + k0 + 4 * kq) : make_float4(0, 0, 0, 0);
-    }
-  };
-  auto sstore = [&](int st) {
-#pragma unroll
-    for (int i = 0; i < NPA; i++) {
-      const int row = r0 + RPP * i;
-      As[st][4 * kq + 0][row] = ra[i].x; As[st][4 * kq + 1][row] = ra[i].y;
-      As[st][4 * kq + 2][row] = ra[i].z; As[st][4 * kq + 3][row] = ra[i].w;
-    }
-#pragma unroll
-    for (int i = 0; i < NPW; i++) {
-      const int row = r0 + RPP * i;
-      Ws[st][4 * kq + 0][row] = rw[i].x; Ws[st][4 * kq + 1][row] = rw[i].y;
-      Ws[st][4 * kq + 2][row] = rw[i].z; Ws[st][4 * kq + 3][row] = rw[i].w;
-    }
-  };
-  const int nk = a.K / BK;
-  gload(0);
-  sstore(0);
-  __syncthreads();
-  if (nk > 1) gload(BK);
-  const int li = lane & 31, lh = lane >> 5;
-  const int arow = wm * 32 * TM + li, bcol = wn * 64 + li;
-  for (int kt = 0; kt < nk; kt++) {
-    const int st = kt & 1;
-    // the registers hold tile kt+1: push it into the idle LDS stage FIRST so the writes drain underneath this tile's
-    // MFMAs, then start fetching tile kt+2
-    if (kt + 1 < nk) sstore(st ^ 1);
-    if (kt + 2 < nk) gload((kt + 2) * BK);
-    // operand fetch for k-pair kk+1 is issued before the MFMAs of k-pair kk (LDS latency under the matrix pipe)
-    float av[TM], bv[2];
-#pragma unroll
-    for (int i = 0; i < TM; i++) av[i] = As[st][lh][arow + 32 * i];
-    bv[0] = Ws[st][lh][bcol]; bv[1] = Ws[st][lh][bcol + 32];
-#pragma unroll
-    for (int kk = 0; kk < BK / 2; kk++) {
-      float na[TM], nb[2];
-#pragma unroll
-      for (int i = 0; i < TM; i++) na[i] = 0.f;
-      nb[0] = 0.f; nb[1] = 0.f;
-      if (kk + 1 < BK / 2) {
-        const int ka = 2 * (kk + 1) + lh;
-#pragma unroll
-        for (int i = 0; i < TM; i++) na[i] = As[st][ka][arow + 32 * i];
-        nb[0] = Ws[st][ka][bcol]; nb[1] = Ws[st][ka][bcol + 32];
-      }
-#pragma unroll
-      for (int i = 0; i < TM; i++) {
-        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[0], acc[i][0], 0, 0, 0);
-        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[1], acc[i][1], 0, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; i++) av[i] = na[i];
-      bv[0] = nb[0]; bv[1] = nb[1];
-    }
-    __syncthreads();
-  }
-  // epilogue: C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-  // FLAGS is a compile-time constant: no per-element branches, the 16 row divisors of a tile are fetched together.
-#pragma unroll
-  for (int ti = 0; ti < TM; ti++) {
-    const int mb = m0 + wm * 32 * TM + ti * 32 + 4 * lh;
-    float rdiv[16];
-    if (FLAGS & EPI_ROWDIV) {
-#pragma unroll
-      for (int e = 0; e < 16; e++) {
-        const int m = mb + (e & 3) + 8 * (e >> 2);
-        rdiv[e] = 1.0f / ((m < a.M) ? a.rowdiv[m] : 1.f);     // one reciprocal per row, applied by multiplication below
-      }
-    }
-#pragma unroll
-    for (int tj = 0; tj < 2; tj++) {
-      const int n = n0 + wn * 64 + tj * 32 + li;
-      if (n >= a.N) continue;
-      const float bvv = a.bias ? a.bias[n] : 0.f;
-      float old2[16];
-      if (FLAGS & EPI_ACC2) {   // all sixteen second-destination reads in flight before the first store
-#pragma unroll
-        for (int e = 0; e < 16; e++) {
-          const int m = mb + (e & 3) + 8 * (e >> 2);
-          old2[e] = (m < a.M) ? a.C2[(size_t)m * a.ldc2 + n] : 0.f;
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < 16; e++) {
-        const int m = mb + (e & 3) + 8 * (e >> 2);
-        if (m >= a.M) continue;
-        float v = acc[ti][tj][e] + bvv;
-        if (FLAGS & EPI_RELU) v = fmaxf(v, 0.f);
-        if (FLAGS & EPI_ROWDIV) v = v * rdiv[e];
-        a.C[(size_t)m * a.ldc + n] = v;
-        if (FLAGS & EPI_ACC2) a.C2[(size_t)m * a.ldc2 + n] = old2[e] + v;
-      }
-    }
-  }
-}
+// The f32 MFMA GEMM (C[M,N] = epi(A[M,K] . W[N,K]^T)) lives in gemm_f32.h.
+using sgrl_gemm::EPI_ACC2;
+using sgrl_gemm::EPI_RELU;
+using sgrl_gemm::EPI_ROWDIV;
+using sgrl_gemm::GemmArgs;
+using sgrl_gemm::k_gemm2;
 
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum_f32(float v) {
@@ -642,29 +492,60 @@ int use_cfg(sgrl_set* s, GraphCfg* c) {
   return SGRL_OK;
 }
 
+// Tile configurations (measured on the shapes of one forward, tools/gemm_lab.hip).  Default: the split-precision kernel
+// k_gemm3 (six bf16 MFMAs per product block, float32-equivalent result -- its error against float64 is BELOW that of the
+// exact-f32 MFMA chain, gemm_f32.h) on 128 x 128 tiles with 16 waves; the exact-f32 kernel k_gemm2 serves the narrow
+// GEMMs (N <= 64, K not a multiple of 32) and, with SGRL_SET_GEMM=f32 in the environment, everything (A/B comparisons).
+//   kNarrow  f32  128 x  64 tile,  4 waves (32 x 64 each), BK 16
+//   kWide    f32  128 x 128 tile,  8 waves (32 x 64 each), BK 32, loads two k-tiles ahead (N >= 512)
+//   kSquare  f32  128 x 128 tile, 16 waves (32 x 32 each), BK 32, loads two k-tiles ahead
+//   kSplit   x6   128 x 128 tile, 16 waves (32 x 32 each), BK 32
+bool gemm_use_split() {
+  static const bool v = [] { const char* e = getenv("SGRL_SET_GEMM"); return !(e && e[0] == 'f'); }();
+  return v;
+}
+template <int F> struct GemmKernels {
+  static constexpr auto kNarrow = k_gemm2<F, 4, 1, 1, 2, 16, 1>;
+  static constexpr auto kWide = k_gemm2<F, 4, 2, 1, 2, 32, 2>;
+  static constexpr auto kSquare = k_gemm2<F, 4, 4, 1, 1, 32, 2>;
+  static constexpr auto kSplit = sgrl_gemm::k_gemm3<F, 4, 4, 1, 1>;
+  static constexpr int kNarrowLds = sgrl_gemm::TileCfg<4, 1, 1, 2, 16>::kLdsBytes;
+  static constexpr int kWideLds = sgrl_gemm::TileCfg<4, 2, 1, 2, 32>::kLdsBytes;
+  static constexpr int kSquareLds = sgrl_gemm::TileCfg<4, 4, 1, 1, 32>::kLdsBytes;
+  static constexpr int kSplitLds = sgrl_gemm::TileCfg3<4, 4, 1, 1>::kLdsBytes;
+  static bool raise_lds_limits() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kNarrow), hipFuncAttributeMaxDynamicSharedMemorySize, kNarrowLds) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(kWide), hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(kSquare), hipFuncAttributeMaxDynamicSharedMemorySize, kSquareLds) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(kSplit), hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLds) == hipSuccess;
+  }
+  static void launch(hipStream_t st, const GemmArgs& a) {
+    const int tiles128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (a.N <= 64 || (a.K % 32) != 0) {
+      hipLaunchKernelGGL(kNarrow, dim3(((a.M + 127) / 128) * ((a.N + 63) / 64)), dim3(256), kNarrowLds, st, a);
+    } else if (gemm_use_split()) {
+      hipLaunchKernelGGL(kSplit, dim3(tiles128), dim3(1024), kSplitLds, st, a);
+    } else if (tiles128 < 512) {
+      hipLaunchKernelGGL(kNarrow, dim3(((a.M + 127) / 128) * ((a.N + 63) / 64)), dim3(256), kNarrowLds, st, a);
+    } else if (a.N >= 512) {
+      hipLaunchKernelGGL(kWide, dim3(tiles128), dim3(512), kWideLds, st, a);
+    } else {
+      hipLaunchKernelGGL(kSquare, dim3(tiles128), dim3(1024), kSquareLds, st, a);
+    }
+  }
+};
+
 int launch_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc,
                 int M, int N, int K, int flags = 0, const float* rowdiv = nullptr, float* C2 = nullptr, int ldc2 = 0) {
-  if (K % BK != 0 || (lda & 3) || (ldw & 3)) return sfail(SGRL_ERR_ARG, "gemm: K must be a multiple of 16 and rows 16-byte aligned");
+  if (K % 16 != 0 || (lda & 3) || (ldw & 3)) return sfail(SGRL_ERR_ARG, "gemm: K must be a multiple of 16 and rows 16-byte aligned");
   GemmArgs a{A, lda, W, ldw, bias, C, ldc, M, N, K, flags, rowdiv, C2, ldc2};
-  if (N <= 64 && flags == 0) {           // narrow projections: 128 x 64 tiles (four waves stacked in M)
-    hipLaunchKernelGGL((k_gemm<0, 1, 1>), dim3((M + 127) / 128), dim3(256), GEMM_LDS_BYTES, st, a);
-    return SGRL_OK;
-  }
-  const int tiles_n = (N + BN - 1) / BN;
-  const int full = ((M + 127) / 128) * tiles_n;
-  const bool half = full < 4 * 256;      // fewer than four full tiles per CU: 64-row tiles quantise better onto 256 CUs
-  const int tiles = half ? ((M + 63) / 64) * tiles_n : full;
-#define SGRL_LAUNCH(F)                                                                                        \
-  if (half) hipLaunchKernelGGL((k_gemm<F, 1>), dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, a);               \
-  else hipLaunchKernelGGL((k_gemm<F, 2>), dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, a)
   switch (flags) {
-    case 0: SGRL_LAUNCH(0); break;
-    case EPI_RELU: SGRL_LAUNCH(EPI_RELU); break;
-    case EPI_ROWDIV: SGRL_LAUNCH(EPI_ROWDIV); break;
-    case EPI_ACC2: SGRL_LAUNCH(EPI_ACC2); break;
+    case 0: GemmKernels<0>::launch(st, a); break;
+    case EPI_RELU: GemmKernels<EPI_RELU>::launch(st, a); break;
+    case EPI_ROWDIV: GemmKernels<EPI_ROWDIV>::launch(st, a); break;
+    case EPI_ACC2: GemmKernels<EPI_ACC2>::launch(st, a); break;
     default: return sfail(SGRL_ERR_ARG, "gemm: unsupported epilogue combination");
   }
-#undef SGRL_LAUNCH
   return SGRL_OK;
 }
 
@@ -793,12 +674,8 @@ int sgrl_set_create(sgrl_set** out) {
     *out = nullptr;
     return sfail(SGRL_ERR_HIP, "no HIP device visible: the SET actor fast path needs an MI355X (there is no CPU fallback)");
   }
-  bool attr_ok = true;
-#define SGRL_ATTR(F, T) attr_ok = attr_ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<F, T>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES) == hipSuccess
-  attr_ok = attr_ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<0, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES) == hipSuccess;
-  SGRL_ATTR(0, 1); SGRL_ATTR(0, 2); SGRL_ATTR(EPI_RELU, 1); SGRL_ATTR(EPI_RELU, 2);
-  SGRL_ATTR(EPI_ROWDIV, 1); SGRL_ATTR(EPI_ROWDIV, 2); SGRL_ATTR(EPI_ACC2, 1); SGRL_ATTR(EPI_ACC2, 2);
-#undef SGRL_ATTR
+  const bool attr_ok = GemmKernels<0>::raise_lds_limits() && GemmKernels<EPI_RELU>::raise_lds_limits() &&
+                       GemmKernels<EPI_ROWDIV>::raise_lds_limits() && GemmKernels<EPI_ACC2>::raise_lds_limits();
   if (!attr_ok) {
     *out = nullptr;
     return sfail(SGRL_ERR_HIP, "cannot raise the dynamic LDS limit of the GEMM kernel");

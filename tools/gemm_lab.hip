@@ -1,0 +1,111 @@
+// tools/gemm_lab.hip -- diagnostic only: the SET actor's GEMM kernels (gemm_f32.h) on the shapes of one forward:
+// exact-f32 MFMA kernel vs the split-precision bf16x6 kernel in several tile configurations, with the error of each against
+// a float64 host reference on sampled outputs.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/gemm_lab tools/gemm_lab.hip && /tmp/gemm_lab
+#include "../sgrl_amd/csrc/gemm_f32.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+using namespace sgrl_gemm;
+
+template <class K>
+static float timeit(K k, int tiles, int threads, int lds, const GemmArgs& a, int reps) {
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipEvent_t t0, t1;
+  hipEventCreate(&t0); hipEventCreate(&t1);
+  for (int w = 0; w < 2; w++) hipLaunchKernelGGL(k, dim3(tiles), dim3(threads), lds, 0, a);
+  hipEventRecord(t0, 0);
+  for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k, dim3(tiles), dim3(threads), lds, 0, a);
+  hipEventRecord(t1, 0);
+  hipEventSynchronize(t1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, t0, t1);
+  if (hipGetLastError() != hipSuccess) printf("  launch error!\n");
+  return ms / reps;
+}
+template <int F, int WM, int WN, int TM, int TN, int BKT, int PF>
+static float run2(const GemmArgs& a, int reps) {
+  using Cfg = TileCfg<WM, WN, TM, TN, BKT>;
+  const int tiles = ((a.M + Cfg::kBM - 1) / Cfg::kBM) * ((a.N + Cfg::kBN - 1) / Cfg::kBN);
+  return timeit(k_gemm2<F, WM, WN, TM, TN, BKT, PF>, tiles, Cfg::kThreads, Cfg::kLdsBytes, a, reps);
+}
+template <int F, int WM, int WN, int TM, int TN>
+static float run3(const GemmArgs& a, int reps) {
+  using Cfg = TileCfg3<WM, WN, TM, TN>;
+  const int tiles = ((a.M + Cfg::kBM - 1) / Cfg::kBM) * ((a.N + Cfg::kBN - 1) / Cfg::kBN);
+  return timeit(k_gemm3<F, WM, WN, TM, TN>, tiles, Cfg::kThreads, Cfg::kLdsBytes, a, reps);
+}
+
+int main(int argc, char** argv) {
+  const int N0 = argc > 1 ? atoi(argv[1]) : 35840;
+  struct Shape { const char* name; int M, N, K, flags; };
+  const Shape shapes[] = {
+      {"qkv    (rowdiv)", N0, 768, 256, EPI_ROWDIV}, {"l4     (rowdiv)", N0, 1024, 256, EPI_ROWDIV},
+      {"lg1    (relu)  ", N0, 256, 544, EPI_RELU},   {"l3     (relu)  ", N0, 256, 256, EPI_RELU},
+      {"vg     (plain) ", 3 * N0, 256, 128, 0},      {"gout   (acc2)  ", 3 * N0, 128, 256, EPI_ACC2},
+      {"lg2    (plain) ", N0, 128, 256, 0},          {"proj64 (plain) ", 3 * N0, 64, 128, 0},
+  };
+  size_t maxA = (size_t)3 * N0 * 544, maxC = (size_t)3 * N0 * 1024;
+  float *A, *W, *C, *C2, *bias, *rd;
+  hipMalloc(&A, maxA * 4); hipMalloc(&W, 1024 * 544 * 4); hipMalloc(&C, maxC * 4); hipMalloc(&C2, maxC * 4);
+  hipMalloc(&bias, 1024 * 4); hipMalloc(&rd, (size_t)3 * N0 * 4);
+  std::vector<float> hA(maxA), hW(1024 * 544), hb(1024), hrd((size_t)3 * N0);
+  {
+    unsigned s = 12345;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
+    // wide dynamic range: magnitudes over ~6 decades, as Gram entries / activations have
+    for (auto& v : hA) { const float m = rnd(); v = m * std::pow(10.0f, 6.0f * rnd()); }
+    for (auto& v : hW) v = rnd() * 0.2f;
+    for (auto& v : hb) v = rnd();
+    for (auto& v : hrd) v = 1.5f + rnd();
+    hipMemcpy(A, hA.data(), maxA * 4, hipMemcpyHostToDevice);
+    hipMemcpy(W, hW.data(), hW.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(bias, hb.data(), 4096, hipMemcpyHostToDevice);
+    hipMemcpy(rd, hrd.data(), hrd.size() * 4, hipMemcpyHostToDevice);
+  }
+  hipMemset(C2, 0, maxC * 4);
+  const int reps = 20;
+  for (const Shape& sh : shapes) {
+    const double gf = 2.0 * sh.M * sh.N * sh.K;
+    printf("%s M %6d N %4d K %3d :", sh.name, sh.M, sh.N, sh.K);
+    GemmArgs a{A, sh.K, W, sh.K, bias, C, sh.N, sh.M, sh.N, sh.K, sh.flags, rd, C2, sh.N};
+    // relative error (max |got - ref| / (sum_k |a_k w_k| + |b|)) against float64 on sampled outputs, plain GEMM value
+    auto err = [&]() {
+      std::vector<float> h((size_t)sh.M * sh.N);
+      hipMemcpy(h.data(), C, h.size() * 4, hipMemcpyDeviceToHost);
+      double worst = 0;
+      unsigned s = 777;
+      for (int q = 0; q < 4000; q++) {
+        s = s * 1664525u + 1013904223u; const int m = (s >> 4) % sh.M;
+        s = s * 1664525u + 1013904223u; const int n = (s >> 4) % sh.N;
+        double ref = hb[n], mag = fabs((double)hb[n]);
+        for (int k = 0; k < sh.K; k++) { const double p = (double)hA[(size_t)m * sh.K + k] * hW[(size_t)n * sh.K + k]; ref += p; mag += fabs(p); }
+        if (sh.flags == EPI_RELU) ref = ref > 0 ? ref : 0;
+        if (sh.flags == EPI_ROWDIV) { ref *= (double)(1.0f / hrd[m]); mag *= (double)(1.0f / hrd[m]); }
+        const double e = fabs((double)h[(size_t)m * sh.N + n] - ref) / mag;
+        if (e > worst) worst = e;
+      }
+      return worst;
+    };
+    float m[8];
+    double e[8];
+#define RUNALL(F)                                                                                            \
+    m[0] = run2<F, 4, 2, 1, 2, 32, 2>(a, reps); e[0] = err(); m[1] = run2<F, 4, 4, 1, 1, 32, 2>(a, reps); e[1] = err();  \
+    m[2] = run3<F, 2, 2, 2, 2>(a, reps); e[2] = err(); m[3] = run3<F, 4, 2, 1, 2>(a, reps); e[3] = err();              \
+    m[4] = run3<F, 4, 2, 2, 2>(a, reps); e[4] = err(); m[5] = run3<F, 4, 1, 1, 2>(a, reps); e[5] = err();              \
+    m[6] = run3<F, 2, 2, 1, 2>(a, reps); e[6] = err(); m[7] = run3<F, 4, 4, 1, 1>(a, reps); e[7] = err()
+    switch (sh.flags) {
+      case 0: RUNALL(0); break;
+      case EPI_RELU: RUNALL(EPI_RELU); break;
+      case EPI_ROWDIV: RUNALL(EPI_ROWDIV); break;
+      case EPI_ACC2: RUNALL(EPI_ACC2); break;
+    }
+    const char* nm[8] = {"f32 128x128/8w", "f32 128x128/16w", "x6 128x128/4w", "x6 128x128/8w", "x6 256x128/8w", "x6 128x64/4w", "x6 64x128/4w", "x6 128x128/16w"};
+    for (int i = 0; i < 8; i++) printf(" | %s %6.1f us %5.1f TF err %.1e", nm[i], m[i] * 1e3, gf / (m[i] * 1e-3) / 1e12, e[i]);
+    printf("\n");
+  }
+  return 0;
+}
