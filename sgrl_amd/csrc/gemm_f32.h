@@ -24,6 +24,9 @@ struct GemmArgs {
   int flags;
   const float* rowdiv;  // [M]: C = (A.W^T + b) / rowdiv[m]
   float* C2; int ldc2;  // EPI_ACC2: C2[m][n] += value
+  // split-precision kernel only: an operand may arrive PRE-SPLIT as three bf16 planes (h | m | l, each [rows][ld] bf16,
+  // `plane` bf16 elements apart) instead of f32 -- A/W then point at plane h and lda/ldw count bf16 elements
+  long long a_plane = 0, w_plane = 0;
 };
 
 // BKT = k extent of an LDS tile (16 or 32); row stride BKT + 4 floats (conflict-free ds_read_b128, see above).
@@ -205,25 +208,29 @@ __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsign
 // two f32 bit patterns -> one dword holding their top halves (bf16 of the first in the low half)
 __device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int BKT = 32>
 struct TileCfg3 {
   static constexpr int kThreads = 64 * WM * WN;
   static constexpr int kBM = 32 * TM * WM, kBN = 32 * TN * WN;
-  static constexpr int kBK = 32;
-  static constexpr int kRowBytes = 2 * kBK + 16;          // 32 bf16 + 16 B pad = 20 dwords: conflict-free ds_read_b128
+  static constexpr int kBK = BKT;
+  static constexpr int kRowBytes = 2 * kBK + 16;          // BK bf16 + 16 B pad (20 / 12 dwords): conflict-free ds_read_b128
   static constexpr int kPlaneA = kBM * kRowBytes, kPlaneW = kBN * kRowBytes;
   static constexpr int kStageBytes = 3 * (kPlaneA + kPlaneW);
   static constexpr int kLdsBytes = 2 * kStageBytes;
 };
 
-template <int FLAGS, int WM, int WN, int TM, int TN>
+// PLA / PLW: operand A / W is given as bf16 planes (GemmArgs::a_plane / w_plane) and is copied to LDS as is
+// LATE: the next tile is split and written to LDS AFTER this tile's MFMAs have been issued (the matrix pipe runs them
+// while the wave does the VALU / LDS-write work) instead of before
+template <int FLAGS, int WM, int WN, int TM, int TN, int BKT = 32, int PF = 1, bool PLA = false, bool PLW = false, bool LATE = false>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm3(GemmArgs a) {
-  using Cfg = TileCfg3<WM, WN, TM, TN>;
-  constexpr int T = Cfg::kThreads, BMT = Cfg::kBM, BNT = Cfg::kBN, BKT = Cfg::kBK, RB = Cfg::kRowBytes;
+  using Cfg = TileCfg3<WM, WN, TM, TN, BKT>;
+  constexpr int T = Cfg::kThreads, BMT = Cfg::kBM, BNT = Cfg::kBN, RB = Cfg::kRowBytes;
   constexpr int QPR = BKT / 4;                // float4 per tile row
   constexpr int RPP = T / QPR;                // tile rows covered per staging pass
-  static_assert(BMT % RPP == 0 && BNT % RPP == 0, "tile rows must be a multiple of the staging pass");
-  constexpr int NPA = BMT / RPP, NPW = BNT / RPP;
+  static_assert(PF == 1 || PF == 2, "prefetch depth 1 or 2");
+  constexpr int NPA = (BMT + RPP - 1) / RPP, NPW = (BNT + RPP - 1) / RPP;    // a pass may be partly idle (more threads than float4s)
+  constexpr int KS = BKT / 16;                // MFMA k-steps per LDS tile
   extern __shared__ float gemm_lds[];
   char* lds = reinterpret_cast<char*>(gemm_lds);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -244,18 +251,52 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm3(GemmArgs a) {
     for (int j = 0; j < TN; j++)
 #pragma unroll
       for (int e = 0; e < 16; e++) { acc[i][j][e] = 0.f; cor[i][j][e] = 0.f; }
-  float4 ra[NPA], rw[NPW];
-  auto gload = [&](int k0) {
+  // staging registers: an f32 operand travels as one float4 (16 B) per slot, a pre-split one as three uint2 (24 B)
+  float4 ra[PF][NPA], rw[PF][NPW];
+  uint2 pa[PF][PLA ? NPA : 1][3], pw[PF][PLW ? NPW : 1][3];
+  const unsigned short* Ap = reinterpret_cast<const unsigned short*>(a.A);
+  const unsigned short* Wp = reinterpret_cast<const unsigned short*>(a.W);
+  // Rows beyond M / N are CLAMPED to the last valid row instead of predicated: the loop body stays free of branches (the
+  // values computed for them are never stored -- the epilogue checks the bounds)
+  const float* arow_g[NPA];
+  const float* wrow_g[NPW];
+#pragma unroll
+  for (int i = 0; i < NPA; i++) {
+    const int m = min(m0 + min(r0 + RPP * i, BMT - 1), a.M - 1);
+    arow_g[i] = PLA ? reinterpret_cast<const float*>(Ap + (size_t)m * a.lda + 4 * kq) : a.A + (size_t)m * a.lda + 4 * kq;
+  }
+#pragma unroll
+  for (int i = 0; i < NPW; i++) {
+    const int n = min(n0 + min(r0 + RPP * i, BNT - 1), a.N - 1);
+    wrow_g[i] = PLW ? reinterpret_cast<const float*>(Wp + (size_t)n * a.ldw + 4 * kq) : a.W + (size_t)n * a.ldw + 4 * kq;
+  }
+  auto gload = [&](int slot, int k0) {
 #pragma unroll
     for (int i = 0; i < NPA; i++) {
-      const int m = m0 + r0 + RPP * i;
-      ra[i] = (m < a.M) ? *reinterpret_cast<const float4*>(a.A + (size_t)m * a.lda + k0 + 4 * kq) : make_float4(0, 0, 0, 0);
+      if (PLA) {
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++)
+          pa[slot][PLA ? i : 0][pl] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(arow_g[i]) + pl * a.a_plane + k0);
+      } else {
+        ra[slot][i] = *reinterpret_cast<const float4*>(arow_g[i] + k0);
+      }
     }
 #pragma unroll
     for (int i = 0; i < NPW; i++) {
-      const int n = n0 + r0 + RPP * i;
-      rw[i] = (n < a.N) ? *reinterpret_cast<const float4*>(a.W + (size_t)n * a.ldw + k0 + 4 * kq) : make_float4(0, 0, 0, 0);
+      if (PLW) {
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++)
+          pw[slot][PLW ? i : 0][pl] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(wrow_g[i]) + pl * a.w_plane + k0);
+      } else {
+        rw[slot][i] = *reinterpret_cast<const float4*>(wrow_g[i] + k0);
+      }
     }
+  };
+  auto put_planes = [&](char* plane0, int plane_stride, int row, const uint2* v) {
+    char* p = plane0 + row * RB + 8 * kq;
+    *reinterpret_cast<uint2*>(p) = v[0];
+    *reinterpret_cast<uint2*>(p + plane_stride) = v[1];
+    *reinterpret_cast<uint2*>(p + 2 * plane_stride) = v[2];
   };
   // split a float4 into its three bf16 planes and store 8 bytes into each
   auto put = [&](char* plane0, int plane_stride, int row, const float4& v) {
@@ -266,28 +307,39 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm3(GemmArgs a) {
     *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
     *reinterpret_cast<uint2*>(p + 2 * plane_stride) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
   };
-  auto sstore = [&](int st) {
+  auto sstore = [&](int slot, int st) {
     char* base = lds + st * Cfg::kStageBytes;
 #pragma unroll
-    for (int i = 0; i < NPA; i++) put(base, Cfg::kPlaneA, r0 + RPP * i, ra[i]);
+    for (int i = 0; i < NPA; i++)
+      if (r0 + RPP * i < BMT) {
+        if (PLA) put_planes(base, Cfg::kPlaneA, r0 + RPP * i, pa[slot][PLA ? i : 0]);
+        else put(base, Cfg::kPlaneA, r0 + RPP * i, ra[slot][i]);
+      }
 #pragma unroll
-    for (int i = 0; i < NPW; i++) put(base + 3 * Cfg::kPlaneA, Cfg::kPlaneW, r0 + RPP * i, rw[i]);
+    for (int i = 0; i < NPW; i++)
+      if (r0 + RPP * i < BNT) {
+        if (PLW) put_planes(base + 3 * Cfg::kPlaneA, Cfg::kPlaneW, r0 + RPP * i, pw[slot][PLW ? i : 0]);
+        else put(base + 3 * Cfg::kPlaneA, Cfg::kPlaneW, r0 + RPP * i, rw[slot][i]);
+      }
   };
   const int nk = a.K / BKT;
-  gload(0);
-  sstore(0);
+  gload(0, 0);
+  sstore(0, 0);
   __syncthreads();
-  if (nk > 1) gload(BKT);
+  if (nk > 1) gload(0, BKT);
+  if (PF == 2 && nk > 2) gload(1, 2 * BKT);
   const int li = lane & 31, lh = lane >> 5;
   const int aoff = (wm * 32 * TM + li) * RB + 16 * lh;        // this lane's 8 bf16 of k-step 0; k-step 1 is 32 bytes on
   const int boff = 3 * Cfg::kPlaneA + (wn * 32 * TN + li) * RB + 16 * lh;
-  for (int kt = 0; kt < nk; kt++) {
+  auto body = [&](int kt, int slot) {
     const int st = kt & 1;
-    if (kt + 1 < nk) sstore(st ^ 1);
-    if (kt + 2 < nk) gload((kt + 2) * BKT);
+    if (!LATE) {
+      if (kt + 1 < nk) sstore(slot, st ^ 1);
+      if (kt + 1 + PF < nk) gload(slot, (kt + 1 + PF) * BKT);
+    }
     const char* base = lds + st * Cfg::kStageBytes;
 #pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
+    for (int ks = 0; ks < KS; ks++) {
       bf16x8 av[TM][3], bv[TN][3];
 #pragma unroll
       for (int i = 0; i < TM; i++)
@@ -311,7 +363,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm3(GemmArgs a) {
           cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[j][1], cor[i][j], 0, 0, 0);   // hm
         }
     }
+    if (LATE) {
+      if (kt + 1 < nk) sstore(slot, st ^ 1);
+      if (kt + 1 + PF < nk) gload(slot, (kt + 1 + PF) * BKT);
+    }
     __syncthreads();
+  };
+  if (PF == 1) {
+    for (int kt = 0; kt < nk; kt++) body(kt, 0);
+  } else {
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) { body(kt, 0); body(kt + 1, 1); }
+    if (kt < nk) body(kt, 0);
   }
 #pragma unroll
   for (int ti = 0; ti < TM; ti++) {
@@ -348,6 +411,20 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm3(GemmArgs a) {
         if (FLAGS & EPI_ACC2) a.C2[(size_t)m * a.ldc2 + n] = old2[e] + v;
       }
     }
+  }
+}
+
+// f32 [rows][ld_src] (cols used: cols) -> three bf16 planes [rows][ld_dst] (`plane` elements apart); columns cols..ld_dst-1 zero
+__global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ src, int ld_src, int rows, int cols,
+                                                      unsigned short* dst, int ld_dst, long long plane) {
+  const size_t n = (size_t)rows * ld_dst;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i / ld_dst), c = (int)(i % ld_dst);
+    unsigned h = 0, m = 0, l = 0;
+    if (c < cols) split3(src[(size_t)r * ld_src + c], h, m, l);
+    dst[i] = (unsigned short)(h >> 16);
+    dst[plane + i] = (unsigned short)(m >> 16);
+    dst[2 * plane + i] = (unsigned short)(l >> 16);
   }
 }
 

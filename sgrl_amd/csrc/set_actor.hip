@@ -494,12 +494,12 @@ int use_cfg(sgrl_set* s, GraphCfg* c) {
 
 // Tile configurations (measured on the shapes of one forward, tools/gemm_lab.hip).  Default: the split-precision kernel
 // k_gemm3 (six bf16 MFMAs per product block, float32-equivalent result -- its error against float64 is BELOW that of the
-// exact-f32 MFMA chain, gemm_f32.h) on 128 x 128 tiles with 16 waves; the exact-f32 kernel k_gemm2 serves the narrow
+// exact-f32 MFMA chain, gemm_f32.h) on 128 x 128 tiles with 8 waves; the exact-f32 kernel k_gemm2 serves the narrow
 // GEMMs (N <= 64, K not a multiple of 32) and, with SGRL_SET_GEMM=f32 in the environment, everything (A/B comparisons).
 //   kNarrow  f32  128 x  64 tile,  4 waves (32 x 64 each), BK 16
 //   kWide    f32  128 x 128 tile,  8 waves (32 x 64 each), BK 32, loads two k-tiles ahead (N >= 512)
 //   kSquare  f32  128 x 128 tile, 16 waves (32 x 32 each), BK 32, loads two k-tiles ahead
-//   kSplit   x6   128 x 128 tile, 16 waves (32 x 32 each), BK 32
+//   kSplit   x6   128 x 128 tile,  8 waves (32 x 64 each), BK 16, loads two k-tiles ahead, two blocks per CU
 bool gemm_use_split() {
   static const bool v = [] { const char* e = getenv("SGRL_SET_GEMM"); return !(e && e[0] == 'f'); }();
   return v;
@@ -508,11 +508,11 @@ template <int F> struct GemmKernels {
   static constexpr auto kNarrow = k_gemm2<F, 4, 1, 1, 2, 16, 1>;
   static constexpr auto kWide = k_gemm2<F, 4, 2, 1, 2, 32, 2>;
   static constexpr auto kSquare = k_gemm2<F, 4, 4, 1, 1, 32, 2>;
-  static constexpr auto kSplit = sgrl_gemm::k_gemm3<F, 4, 4, 1, 1>;
+  static constexpr auto kSplit = sgrl_gemm::k_gemm3<F, 4, 2, 1, 2, 16, 2>;
   static constexpr int kNarrowLds = sgrl_gemm::TileCfg<4, 1, 1, 2, 16>::kLdsBytes;
   static constexpr int kWideLds = sgrl_gemm::TileCfg<4, 2, 1, 2, 32>::kLdsBytes;
   static constexpr int kSquareLds = sgrl_gemm::TileCfg<4, 4, 1, 1, 32>::kLdsBytes;
-  static constexpr int kSplitLds = sgrl_gemm::TileCfg3<4, 4, 1, 1>::kLdsBytes;
+  static constexpr int kSplitLds = sgrl_gemm::TileCfg3<4, 2, 1, 2, 16>::kLdsBytes;
   static bool raise_lds_limits() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kNarrow), hipFuncAttributeMaxDynamicSharedMemorySize, kNarrowLds) == hipSuccess &&
            hipFuncSetAttribute(reinterpret_cast<const void*>(kWide), hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds) == hipSuccess &&
@@ -524,7 +524,7 @@ template <int F> struct GemmKernels {
     if (a.N <= 64 || (a.K % 32) != 0) {
       hipLaunchKernelGGL(kNarrow, dim3(((a.M + 127) / 128) * ((a.N + 63) / 64)), dim3(256), kNarrowLds, st, a);
     } else if (gemm_use_split()) {
-      hipLaunchKernelGGL(kSplit, dim3(tiles128), dim3(1024), kSplitLds, st, a);
+      hipLaunchKernelGGL(kSplit, dim3(tiles128), dim3(512), kSplitLds, st, a);
     } else if (tiles128 < 512) {
       hipLaunchKernelGGL(kNarrow, dim3(((a.M + 127) / 128) * ((a.N + 63) / 64)), dim3(256), kNarrowLds, st, a);
     } else if (a.N >= 512) {

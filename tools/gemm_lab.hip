@@ -32,11 +32,11 @@ static float run2(const GemmArgs& a, int reps) {
   const int tiles = ((a.M + Cfg::kBM - 1) / Cfg::kBM) * ((a.N + Cfg::kBN - 1) / Cfg::kBN);
   return timeit(k_gemm2<F, WM, WN, TM, TN, BKT, PF>, tiles, Cfg::kThreads, Cfg::kLdsBytes, a, reps);
 }
-template <int F, int WM, int WN, int TM, int TN>
+template <int F, int WM, int WN, int TM, int TN, int BKT = 32, int PF = 1, bool PLA = false, bool PLW = false, bool LATE = false>
 static float run3(const GemmArgs& a, int reps) {
-  using Cfg = TileCfg3<WM, WN, TM, TN>;
+  using Cfg = TileCfg3<WM, WN, TM, TN, BKT>;
   const int tiles = ((a.M + Cfg::kBM - 1) / Cfg::kBM) * ((a.N + Cfg::kBN - 1) / Cfg::kBN);
-  return timeit(k_gemm3<F, WM, WN, TM, TN>, tiles, Cfg::kThreads, Cfg::kLdsBytes, a, reps);
+  return timeit(k_gemm3<F, WM, WN, TM, TN, BKT, PF, PLA, PLW, LATE>, tiles, Cfg::kThreads, Cfg::kLdsBytes, a, reps);
 }
 
 int main(int argc, char** argv) {
@@ -67,11 +67,26 @@ int main(int argc, char** argv) {
     hipMemcpy(rd, hrd.data(), hrd.size() * 4, hipMemcpyHostToDevice);
   }
   hipMemset(C2, 0, maxC * 4);
+  unsigned short *Apl, *Wpl;
+  hipMalloc(&Apl, maxA * 2 * 3); hipMalloc(&Wpl, (size_t)1024 * 544 * 2 * 3);
   const int reps = 20;
+  if (argc > 2) {   // profiling mode: one configuration on the linear4 shape, a handful of launches
+    const Shape& sh = shapes[1];
+    GemmArgs a{A, sh.K, W, sh.K, bias, C, sh.N, sh.M, sh.N, sh.K, sh.flags, rd, C2, sh.N};
+    const float ms = run3<EPI_ROWDIV, 4, 2, 1, 2, 16, 2>(a, 5);
+    printf("profile mode: l4 x6 8w(1x2) bk16 pf2: %.1f us\n", ms * 1e3);
+    return 0;
+  }
   for (const Shape& sh : shapes) {
     const double gf = 2.0 * sh.M * sh.N * sh.K;
     printf("%s M %6d N %4d K %3d :", sh.name, sh.M, sh.N, sh.K);
     GemmArgs a{A, sh.K, W, sh.K, bias, C, sh.N, sh.M, sh.N, sh.K, sh.flags, rd, C2, sh.N};
+    // pre-split copies of both operands
+    const long long aplane = (long long)sh.M * sh.K, wplane = (long long)sh.N * sh.K;
+    hipLaunchKernelGGL(k_split_planes, dim3(2048), dim3(256), 0, 0, A, sh.K, sh.M, sh.K, Apl, sh.K, aplane);
+    hipLaunchKernelGGL(k_split_planes, dim3(512), dim3(256), 0, 0, W, sh.K, sh.N, sh.K, Wpl, sh.K, wplane);
+    GemmArgs aw = a; aw.W = reinterpret_cast<const float*>(Wpl); aw.w_plane = wplane;
+    GemmArgs aaw = aw; aaw.A = reinterpret_cast<const float*>(Apl); aaw.a_plane = aplane;
     // relative error (max |got - ref| / (sum_k |a_k w_k| + |b|)) against float64 on sampled outputs, plain GEMM value
     auto err = [&]() {
       std::vector<float> h((size_t)sh.M * sh.N);
@@ -93,17 +108,17 @@ int main(int argc, char** argv) {
     float m[8];
     double e[8];
 #define RUNALL(F)                                                                                            \
-    m[0] = run2<F, 4, 2, 1, 2, 32, 2>(a, reps); e[0] = err(); m[1] = run2<F, 4, 4, 1, 1, 32, 2>(a, reps); e[1] = err();  \
-    m[2] = run3<F, 2, 2, 2, 2>(a, reps); e[2] = err(); m[3] = run3<F, 4, 2, 1, 2>(a, reps); e[3] = err();              \
-    m[4] = run3<F, 4, 2, 2, 2>(a, reps); e[4] = err(); m[5] = run3<F, 4, 1, 1, 2>(a, reps); e[5] = err();              \
-    m[6] = run3<F, 2, 2, 1, 2>(a, reps); e[6] = err(); m[7] = run3<F, 4, 4, 1, 1>(a, reps); e[7] = err()
+    m[0] = run3<F, 4, 2, 1, 2, 16, 2>(a, reps); e[0] = err(); m[1] = run3<F, 4, 2, 1, 2, 16, 2, false, false, true>(a, reps); e[1] = err();  \
+    m[2] = run3<F, 4, 2, 1, 2, 32, 2, false, false, true>(a, reps); e[2] = err(); m[3] = run3<F, 2, 2, 2, 2, 16, 2, false, false, true>(a, reps); e[3] = err();  \
+    m[4] = run3<F, 4, 4, 1, 1, 16, 2, false, false, true>(a, reps); e[4] = err(); m[5] = run3<F, 4, 2, 2, 2, 16, 2, false, false, true>(a, reps); e[5] = err();  \
+    m[6] = run3<F, 4, 2, 1, 2, 16, 1, false, false, true>(a, reps); e[6] = err(); m[7] = run3<F, 2, 4, 2, 1, 16, 2, false, false, true>(a, reps); e[7] = err()
     switch (sh.flags) {
       case 0: RUNALL(0); break;
       case EPI_RELU: RUNALL(EPI_RELU); break;
       case EPI_ROWDIV: RUNALL(EPI_ROWDIV); break;
       case EPI_ACC2: RUNALL(EPI_ACC2); break;
     }
-    const char* nm[8] = {"f32 128x128/8w", "f32 128x128/16w", "x6 128x128/4w", "x6 128x128/8w", "x6 256x128/8w", "x6 128x64/4w", "x6 64x128/4w", "x6 128x128/16w"};
+    const char* nm[8] = {"8w(1x2)bk16pf2", "same LATE", "LATE bk32", "LATE 4w(2x2)", "LATE 16w", "LATE 256x128/8w", "LATE pf1", "LATE 8w(2x1)"};
     for (int i = 0; i < 8; i++) printf(" | %s %6.1f us %5.1f TF err %.1e", nm[i], m[i] * 1e3, gf / (m[i] * 1e-3) / 1e12, e[i]);
     printf("\n");
   }
