@@ -13,8 +13,16 @@
  * Weights: one device float buffer + a host table of SGRL_SET_NW offsets (in floats) in the slot order below.
  * Layout conventions of the packed tensors (sgrl_amd/set_hip.py does the packing from an nn.Module state_dict):
  *   Linear weights are row-major [out, in] exactly as torch stores them, except
- *     QKV_W  = rows of q_proj (pre-multiplied by (2*head_dim)^-0.5), k_proj, v_proj stacked -> [768, 256]; QKV_B alike
- *     VG_W   = vg_proj.weight padded with 4 zero rows -> [256, 128]
+ *     QKV_W  = rows of q_proj (pre-multiplied by (2*head_dim)^-0.5), k_proj and -- folded through ng_out, see below --
+ *              v' stacked -> [768, 256]; QKV_B alike
+ *     VG_W   = the vector-value projection folded through g_out -> [256, 128] (see below)
+ *   Attention output folds (exact algebra, reference subequivariant_attentions.py:138-151): the scalar output is
+ *     ng_out(concat_h(sum_j w_h[i,j] v_h[j])) = sum_h sum_j w_h[i,j] (Wng_h v_h[j]) + b_ng, so the value projection and ng_out
+ *     collapse into ONE 256 -> 128 map per head:  QKV_W rows 512 + 128 h + r = (Wng[:, 128h:128h+128] . Wv[128h:128h+128, :])[r],
+ *     QKV_B likewise with b_v; the vector output g_out(concat_h(sum_j w_h[i,j] [vg_h[j] | gdir[j]])) collapses the same way:
+ *     VG_W rows 128 h + r = (Wgo[:, 128h:128h+126] . Wvg[126h:126h+126, :])[r]  and  A_GD[h][r][0:2] = Wgo[r, 128h+126:128h+128]
+ *     (the gravity / direction columns).  The attention kernel then produces the layer's two outputs directly; the slots
+ *     NGOUT_W and GOUT_W are kept for reference but no longer read by the kernels.
  *     L1NG_W = linear1_ng.weight padded with 15 zero columns -> [128, 160]
  *     A_LG1_W, F_LG1_W, L1G_W (the layers fed by the symmetric 32x32 Gram matrix) are folded onto the packed lower
  *              triangle: W'[n][a(a+1)/2+b] = W[n][32a+b] + W[n][32b+a] (b < a), W[n][33a] (b = a); 528 -> 544 columns
@@ -44,7 +52,7 @@ enum {
   SGRL_SET_QKV_B, SGRL_SET_VG_W, SGRL_SET_NGOUT_W, SGRL_SET_NGOUT_B, SGRL_SET_GOUT_W, SGRL_SET_F_GPROJ2,
   SGRL_SET_F_GPROJ3, SGRL_SET_F_LG1_W, SGRL_SET_F_LG1_B, SGRL_SET_F_LG2_W, SGRL_SET_F_LG2_B, SGRL_SET_L3_W,
   SGRL_SET_L3_B, SGRL_SET_L4_W, SGRL_SET_L4_B, SGRL_SET_L5_W, SGRL_SET_L1_W, SGRL_SET_L1_B, SGRL_SET_L2_W,
-  SGRL_SET_L2_B, SGRL_SET_N1_W, SGRL_SET_N1_B, SGRL_SET_N2_W, SGRL_SET_N2_B,
+  SGRL_SET_L2_B, SGRL_SET_N1_W, SGRL_SET_N1_B, SGRL_SET_N2_W, SGRL_SET_N2_B, SGRL_SET_A_GD,
   SGRL_SET_NLAYER
 };
 #define SGRL_SET_LAYERS 3
@@ -67,11 +75,13 @@ int sgrl_set_weights(sgrl_set* s, const float* w, const int64_t* offsets, int n_
  *   FOLD   src0 [rows, 1024] -> dst [rows, 544] Gram-triangle folding  (A_LG1_W, F_LG1_W, L1G_W; see above)
  *   STACK  dst [64, b]: rows 0..29 = src0 [30, a], rows 32..61 = src1 [30, a] or zero, columns a..b-1 zero
  *          (the two 30-row projections of a proj+Gram site as ONE zero-padded GEMM operand)
+ *   MATMUL dst [n / b, b] = src0 [n / b, a] (row stride lda) . src1 [a, b] (row stride ldb), times scale   (weight folds)
+ *   SUBMAT dst [n / b, b] = src0 [n / b, b] (row stride lda)                                                (column blocks)
  * offsets: HOST int64[SGRL_SET_NW + SGRL_SET_NSITES] -- the slot table followed by the offsets of the seven stacked
  * projection operands (sites 2l = attention g_proj of layer l [64,128]; 2l+1 = g_proj2 | g_proj3 [64,128];
  * 6 = gg_proj | g_proj (actor) [64,144]).  The segments must cover [0, total_floats) entirely.  Parameter storage must
  * stay allocated while the handle is bound; re-bind after anything that moves it (module.to(), new tensors). */
-enum { SGRL_PACK_COPY = 0, SGRL_PACK_PADCOL = 1, SGRL_PACK_FOLD = 2, SGRL_PACK_STACK = 3 };
+enum { SGRL_PACK_COPY = 0, SGRL_PACK_PADCOL = 1, SGRL_PACK_FOLD = 2, SGRL_PACK_STACK = 3, SGRL_PACK_MATMUL = 4, SGRL_PACK_SUBMAT = 5 };
 typedef struct sgrl_pack_seg {
   int64_t dst;        /* first float of the run in the flat buffer */
   const void* src0;   /* DEV float* */
@@ -79,7 +89,8 @@ typedef struct sgrl_pack_seg {
   int32_t n;          /* floats in the run */
   int32_t kind;
   int32_t a, b;
-  float scale;        /* COPY */
+  float scale;        /* COPY, MATMUL */
+  int32_t lda, ldb;   /* MATMUL, SUBMAT: row strides of src0 / src1 in floats */
   int32_t reserved;
 } sgrl_pack_seg;
 #define SGRL_SET_NSITES 7
@@ -117,7 +128,7 @@ int64_t sgrl_set_workspace_bytes(const sgrl_set* s);
 int sgrl_set_time_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_ld, float max_action,
                           int reps, void* stream, float* ms_out);
 /* Debug/parity: copy an intermediate buffer of the LAST forward to the host.  which: 0 g[N,3,128], 1 cat[N,256]
- * (inv | ng), 2 gram[N,544] (packed lower triangle), 3 fn[N], 4 qkv[N,768], 5 attng[N,256], 6 attg[N,3,256], 7 mat[N,1024],
+ * (inv | ng), 2 gram[N,544] (packed lower triangle), 3 fn[N], 4 qkv[N,768] (q | k | v' folded), 5 / 6 unused, 7 mat[N,1024],
  * 8 g1[N,3,128] (attention's vector output), 9 delta[N,128] (attention's / FFN's scalar output before the residual norm),
  * 10 outng[N,160] (input features | final-norm ng | zero padding). */
 int sgrl_set_peek(sgrl_set* s, int which, float* host, int64_t n_floats);

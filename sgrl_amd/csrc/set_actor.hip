@@ -112,13 +112,14 @@ __global__ void k_stack_proj(const float* __restrict__ Wp, const float* __restri
 // are seen by the very next forward -- there is no host-side change detection to go stale.  ~46 MB of traffic (27 MB
 // read, 19 MB written): a few tens of microseconds per forward.  One block handles one PACK_CHUNK-element run of one segment.
 constexpr int PACK_CHUNK = 4096;
+constexpr int PACK_CHUNK_MM = 256;      // matrix-product segments: one output (a dot product) per thread
 __global__ __launch_bounds__(256) void k_pack(const sgrl_pack_seg* __restrict__ segs, const int2* __restrict__ chunks,
                                               const unsigned short* __restrict__ tri, float* w) {
   const int2 ch = chunks[blockIdx.x];
   const sgrl_pack_seg sg = segs[ch.x];
   const float* s0 = static_cast<const float*>(sg.src0);
   const float* s1 = static_cast<const float*>(sg.src1);
-  const int end = min(ch.y + PACK_CHUNK, sg.n);
+  const int end = min(ch.y + (sg.kind == SGRL_PACK_MATMUL ? PACK_CHUNK_MM : PACK_CHUNK), sg.n);
   for (int i = ch.y + (int)threadIdx.x; i < end; i += 256) {
     float v = 0.f;
     switch (sg.kind) {
@@ -146,6 +147,19 @@ __global__ __launch_bounds__(256) void k_pack(const sgrl_pack_seg* __restrict__ 
           if (r < 30) v = s0[r * sg.a + c];
           else if (s1 && r >= 32 && r < 62) v = s1[(r - 32) * sg.a + c];
         }
+        break;
+      }
+      case SGRL_PACK_MATMUL: {  // dst [rows, b] = src0 [rows, a] (stride lda) . src1 [a, b] (stride ldb): weight folds
+        const int r = i / sg.b, c = i % sg.b;
+        const float* ar = s0 + (size_t)r * sg.lda;
+        float acc = 0.f;
+        for (int k = 0; k < sg.a; k++) acc += ar[k] * s1[(size_t)k * sg.ldb + c];
+        v = acc * sg.scale;
+        break;
+      }
+      case SGRL_PACK_SUBMAT: {  // dst [rows, b] = src0 [rows, b] (stride lda)
+        const int r = i / sg.b, c = i % sg.b;
+        v = s0[(size_t)r * sg.lda + c];
         break;
       }
       default: break;
@@ -217,16 +231,23 @@ __global__ void k_relbias(const float* rel, const float* Wr, const float* br, fl
   }
 }
 
-// attention: one 256-thread block per environment
+// attention: one 256-thread block per environment.  With the output projections folded into the value projections
+// (include/sgrl_set.h) the kernel produces the attention block's two outputs directly:
+//   delta[i][c]   = b_ng[c] + sum_h sum_j w_h[i,j] v'[j][128 h + c]                               (scalar stream, 128 wide)
+//   g1[i][s][c]   = sum_h ( sum_j w_h[i,j] U[j][s][128 h + c]  +  GD[h][c][:] . sum_j w_h[i,j] gdir[j][s][:] )
+// (the residual g += g1 of reference SEActor.py:89 is applied by k_equiv together with the feed-forward update of g)
 struct EnvTab {
   const int32_t* env_off;   // [n_env] first node
   const int32_t* env_L;     // [n_env]
   const int32_t* env_relb;  // [n_env] offset into relb
 };
-__global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv, const float* __restrict__ vg,
+__global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv, const float* __restrict__ U,
                                                    const float* __restrict__ gdir, const float* relb, EnvTab et,
-                                                   int use_bias, float* attng, float* attg) {
-  __shared__ float sc[2 * 14 * 14];
+                                                   int use_bias, const float* __restrict__ b_ng, const float* __restrict__ GD,
+                                                   float* delta, float* g1) {
+  constexpr int LMAX = 14;
+  __shared__ float sc[2 * LMAX * LMAX];
+  __shared__ float gd[2 * LMAX * 3 * 2];        // [h][i][s][e] = sum_j w_h[i,j] gdir[j][s][e]
   const int e = blockIdx.x, t = threadIdx.x;
   const int n0 = et.env_off[e], L = et.env_L[e];
   // scores: eight lanes per (head, i, j) dot product -- each group reads its q / k rows as four coalesced 128-byte
@@ -257,38 +278,58 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
     for (int j = 0; j < L; j++) row[j] = row[j] / sum;
   }
   __syncthreads();
-  // A.V with the value column in registers: a thread owns one output column (256 of the invariant values, then 3 x 256
-  // of the geometric ones), reads its L value entries ONCE and produces the L outputs of that column -- the attention
-  // weights come from LDS (broadcast within a head)
-  constexpr int LMAX = 14;
-  {
-    const int col = t, h = col >> 7;
-    float v[LMAX];
-#pragma unroll
-    for (int j = 0; j < LMAX; j++) v[j] = j < L ? qkv[(size_t)(n0 + j) * 768 + 512 + col] : 0.f;
-    for (int i = 0; i < L; i++) {
-      const float* w = sc + (h * L + i) * L;
-      float s = 0.f;
-#pragma unroll
-      for (int j = 0; j < LMAX; j++) if (j < L) s += w[j] * v[j];
-      attng[(size_t)(n0 + i) * 256 + col] = s;
-    }
+  // attention-weighted gravity / direction columns: 2 heads x L x 3 x 2 <= 168 values
+  for (int idx = t; idx < 2 * L * 6; idx += 256) {
+    const int h = idx / (L * 6), i = (idx / 6) % L, se = idx % 6;
+    const float* w = sc + (h * L + i) * L;
+    float s = 0.f;
+    for (int j = 0; j < L; j++) s += w[j] * gdir[(size_t)(n0 + j) * 6 + se];
+    gd[idx] = s;
   }
-  for (int s3 = 0; s3 < 3; s3++) {
-    const int col = t, h = col >> 7, d = col & 127;
-    float v[LMAX];
+  __syncthreads();                               // gd[] complete
+  // thread = (pair of output quantities, output column): threads 0..127 produce the scalar stream and spatial row 0 of
+  // column c, threads 128..255 spatial rows 1 and 2; each sums over BOTH heads itself (no cross-thread reduction, no
+  // barrier), reading the L value entries of a (quantity, head) once into registers
+  const int half = t >> 7, c = t & 127;
 #pragma unroll
-    for (int j = 0; j < LMAX; j++) {
-      float x = 0.f;
-      if (j < L) x = d < 126 ? vg[((size_t)(n0 + j) * 3 + s3) * 256 + h * 126 + d] : gdir[((size_t)(n0 + j) * 3 + s3) * 2 + (d - 126)];
-      v[j] = x;
+  for (int qq = 0; qq < 2; qq++) {
+    const int quantity = 2 * half + qq;          // 0: scalar stream, 1..3: spatial row quantity - 1
+    float out[LMAX];
+#pragma unroll
+    for (int i = 0; i < LMAX; i++) out[i] = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      float v[LMAX];
+#pragma unroll
+      for (int j = 0; j < LMAX; j++) {
+        const int n = n0 + (j < L ? j : 0);
+        const float x = quantity == 0 ? qkv[(size_t)n * 768 + 512 + h * 128 + c]
+                                      : U[((size_t)n * 3 + (quantity - 1)) * 256 + h * 128 + c];
+        v[j] = j < L ? x : 0.f;
+      }
+      float gd0 = 0.f, gd1 = 0.f;
+      if (quantity != 0) { gd0 = GD[(h * 128 + c) * 2]; gd1 = GD[(h * 128 + c) * 2 + 1]; }
+#pragma unroll
+      for (int i = 0; i < LMAX; i++)
+        if (i < L) {
+          const float* w = sc + (h * L + i) * L;
+          float s = 0.f;
+#pragma unroll
+          for (int j = 0; j < LMAX; j++) if (j < L) s += w[j] * v[j];
+          if (quantity != 0) {
+            const float* gg = gd + (h * L + i) * 6 + 2 * (quantity - 1);
+            s += gd0 * gg[0] + gd1 * gg[1];
+          }
+          out[i] += s;
+        }
     }
-    for (int i = 0; i < L; i++) {
-      const float* w = sc + (h * L + i) * L;
-      float s = 0.f;
+    if (quantity == 0) {
+      const float bb = b_ng[c];
 #pragma unroll
-      for (int j = 0; j < LMAX; j++) if (j < L) s += w[j] * v[j];
-      attg[((size_t)(n0 + i) * 3 + s3) * 256 + col] = s;
+      for (int i = 0; i < LMAX; i++) if (i < L) delta[(size_t)(n0 + i) * 128 + c] = out[i] + bb;
+    } else {
+#pragma unroll
+      for (int i = 0; i < LMAX; i++) if (i < L) g1[((size_t)(n0 + i) * 3 + (quantity - 1)) * 128 + c] = out[i];
     }
   }
 }
@@ -309,9 +350,11 @@ __global__ __launch_bounds__(256) void k_add_ln(const float* x, int ldx, const f
   if (out2) { out2[(size_t)row * ld2 + lane] = y0; out2[(size_t)row * ld2 + 64 + lane] = y1; }
 }
 
-// g[n][s][:] += ((Z[n][s][:] . mat[n]) . W5^T)     4 nodes per 128-thread block
+// g[n][s][:] += g1[n][s][:] + ((Z[n][s][:] . mat[n]) . W5^T)     4 nodes per 128-thread block
+// (both residual updates of the vector stream in one pass: the attention output g1, reference SEActor.py:89, and the
+// equivariant feed-forward term, SEActor.py:108-114)
 __global__ __launch_bounds__(128) void k_equiv(const float* __restrict__ Z, const float* __restrict__ mat,
-                                               const float* __restrict__ W5, float* g, int N) {
+                                               const float* __restrict__ W5, const float* __restrict__ g1, float* g, int N) {
   __shared__ float T[4 * 96];
   const int t = threadIdx.x, n0 = blockIdx.x * 4;
   for (int q = 0; q < 3; q++) {
@@ -333,7 +376,8 @@ __global__ __launch_bounds__(128) void k_equiv(const float* __restrict__ Z, cons
       const float* tt = T + node * 96 + s * 32;
       float v = 0.f;
       for (int c = 0; c < 32; c++) v += tt[c] * w[c];
-      g[((size_t)(n0 + node) * 3 + s) * D + t] += v;
+      const size_t o = ((size_t)(n0 + node) * 3 + s) * D + t;
+      g[o] += g1[o] + v;
     }
   }
 }
@@ -414,7 +458,7 @@ struct sgrl_set {
   int64_t ws_floats = 0;
   int carved_N = 0;
   bool ws_dirty = false;        // the carve-up changed: padding columns must be re-zeroed (next forward, on its stream)
-  float *g, *cat, *cat2, *gram, *fn, *h256, *qkv, *vg, *attng, *attg, *g1, *z2, *mat, *t256, *t256b, *t128a, *t128b, *delta,
+  float *g, *cat, *cat2, *gram, *fn, *h256, *qkv, *vg, *g1, *z2, *mat, *t256, *t256b, *t128a, *t128b, *delta,
       *outg, *outng, *gdir, *zall;
   // stacked projection weights of the 7 proj+gram sites: static weights -> own buffer rebuilt on the forward stream after
   // sgrl_set_weights; live weights -> part of the flat buffer, rebuilt by k_pack with everything else
@@ -441,9 +485,9 @@ struct sgrl_set {
 namespace {
 
 constexpr int64_t kPerNodeFloats = 384 /*g*/ + 256 + 256 /*cat, cat2*/ + 1024 /*gram*/ + 1 /*fn*/ + 256 /*h256*/ + 768 /*qkv*/ +
-                                   768 /*vg*/ + 256 /*attng*/ + 768 /*attg*/ + 384 /*g1*/ + 96 /*z2*/ + 1024 /*mat*/ + 256 + 256 /*t256, t256b*/ +
+                                   768 /*vg*/ + 384 /*g1*/ + 96 /*z2*/ + 1024 /*mat*/ + 256 + 256 /*t256, t256b*/ +
                                    128 + 128 + 128 /*t128a,b,delta*/ + 3 * OGLD /*outg*/ + 160 /*outng*/ + 6 /*gdir*/ + 3 * ZLD /*zall*/;
-constexpr int kWsArrays = 22;
+constexpr int kWsArrays = 20;
 
 int64_t ws_floats_for(int64_t N) { return kPerNodeFloats * N + 32 * kWsArrays; }
 
@@ -476,7 +520,7 @@ int use_cfg(sgrl_set* s, GraphCfg* c) {
     float* p = s->ws;
     auto take = [&](int64_t n) { float* r = p; p += (n + 31) & ~int64_t(31); return r; };
     s->g = take(384 * N); s->cat = take(256 * N); s->cat2 = take(256 * N); s->gram = take(1024 * N); s->fn = take(N);
-    s->h256 = take(256 * N); s->qkv = take(768 * N); s->vg = take(768 * N); s->attng = take(256 * N); s->attg = take(768 * N);
+    s->h256 = take(256 * N); s->qkv = take(768 * N); s->vg = take(768 * N);
     s->g1 = take(384 * N); s->z2 = take(96 * N); s->mat = take(1024 * N); s->t256 = take(256 * N); s->t256b = take(256 * N); s->t128a = take(128 * N);
     s->t128b = take(128 * N); s->delta = take(128 * N); s->outg = take(3 * OGLD * N); s->outng = take(160 * N); s->gdir = take(6 * N); s->zall = take(3 * ZLD * N);
     if (p - s->ws > s->ws_floats) return sfail(SGRL_ERR_LIMIT, "workspace carve-up overflow");
@@ -605,18 +649,14 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   for (int l = 0; l < SGRL_SET_LAYERS; l++) {
     // --- attention ---
     fork();
-    GS(s->g, D, s->WL(l, SGRL_SET_VG_W), D, nullptr, s->vg, 256, N3, 256, D);
+    GS(s->g, D, s->WL(l, SGRL_SET_VG_W), D, nullptr, s->vg, 256, N3, 256, D);          // U = g . (Wgo_h Wvg_h)^T, both heads
     PG(s->g, D, D, 2 * l, nullptr);
     G(s->gram, GK, s->WL(l, SGRL_SET_A_LG1_W), GK, s->WL(l, SGRL_SET_A_LG1_B), s->h256, 256, N, 256, GK, EPI_RELU);
     G(s->h256, 256, s->WL(l, SGRL_SET_A_LG2_W), 256, s->WL(l, SGRL_SET_A_LG2_B), s->cat, 256, N, 128, 256);
     G(s->cat, 256, s->WL(l, SGRL_SET_QKV_W), 256, s->WL(l, SGRL_SET_QKV_B), s->qkv, 768, N, 768, 256, EPI_ROWDIV, s->fn);
     join();
     hipLaunchKernelGGL(k_attention, dim3(s->n_env), dim3(256), 0, st, s->qkv, s->vg, s->gdir, s->d_relb, et, l == 0 ? 1 : 0,
-                       s->attng, s->attg);
-    fork();
-    GS(s->attng, 256, s->WL(l, SGRL_SET_NGOUT_W), 256, s->WL(l, SGRL_SET_NGOUT_B), s->delta, D, N, D, 256);
-    G(s->attg, 256, s->WL(l, SGRL_SET_GOUT_W), 256, nullptr, s->g1, D, N3, D, 256, EPI_ACC2, nullptr, s->g, D);
-    join();
+                       s->WL(l, SGRL_SET_NGOUT_B), s->WL(l, SGRL_SET_A_GD), s->delta, s->g1);
     if (s->stop_after == 2 * l) return SGRL_OK;      // probe: g1 = attention's vector output, delta = its scalar output
     hipLaunchKernelGGL(k_add_ln, dim3(lnb), dim3(256), 0, st, ng, 256, s->delta, D, s->WL(l, SGRL_SET_N1_W),
                        s->WL(l, SGRL_SET_N1_B), ng, 256, (float*)nullptr, 0, N);
@@ -629,7 +669,7 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
     GS(s->t256b, 256, s->WL(l, SGRL_SET_L2_W), 256, s->WL(l, SGRL_SET_L2_B), s->delta, D, N, D, 256, EPI_ROWDIV, s->fn);
     G(s->cat, 256, s->WL(l, SGRL_SET_L3_W), 256, s->WL(l, SGRL_SET_L3_B), s->t256, 256, N, 256, 256, EPI_RELU);
     G(s->t256, 256, s->WL(l, SGRL_SET_L4_W), 256, s->WL(l, SGRL_SET_L4_B), s->mat, 1024, N, 1024, 256, EPI_ROWDIV, s->fn);
-    hipLaunchKernelGGL(k_equiv, dim3((N + 3) / 4), dim3(128), 0, st, s->z2, s->mat, s->WL(l, SGRL_SET_L5_W), s->g, N);
+    hipLaunchKernelGGL(k_equiv, dim3((N + 3) / 4), dim3(128), 0, st, s->z2, s->mat, s->WL(l, SGRL_SET_L5_W), s->g1, s->g, N);
     join();
     hipLaunchKernelGGL(k_add_ln, dim3(lnb), dim3(256), 0, st, ng, 256, s->delta, D, s->WL(l, SGRL_SET_N2_W),
                        s->WL(l, SGRL_SET_N2_B), ng, 256, (float*)nullptr, 0, N);
@@ -748,10 +788,12 @@ int sgrl_set_bind_params(sgrl_set* s, const sgrl_pack_seg* segs, int n_segs, con
       case SGRL_PACK_PADCOL: ok = g.a > 0 && g.b >= g.a && g.n % g.b == 0; break;
       case SGRL_PACK_FOLD: ok = g.n % GK == 0; break;
       case SGRL_PACK_STACK: ok = g.a > 0 && g.b >= g.a && g.n == 64 * g.b; break;
+      case SGRL_PACK_MATMUL: ok = g.src1 && g.a > 0 && g.b > 0 && g.n % g.b == 0 && g.lda >= g.a && g.ldb >= g.b; break;
+      case SGRL_PACK_SUBMAT: ok = g.b > 0 && g.n % g.b == 0 && g.lda >= g.b; break;
       default: break;
     }
     if (!ok) return sfail(SGRL_ERR_ARG, "sgrl_set_bind_params: inconsistent segment " + std::to_string(order[oi]));
-    for (int st = 0; st < g.n; st += PACK_CHUNK) chunks.push_back(make_int2(order[oi], st));
+    for (int st = 0; st < g.n; st += (g.kind == SGRL_PACK_MATMUL ? PACK_CHUNK_MM : PACK_CHUNK)) chunks.push_back(make_int2(order[oi], st));
     pos += g.n;
   }
   if (pos != total_floats) return sfail(SGRL_ERR_ARG, "sgrl_set_bind_params: segments do not add up to total_floats");
@@ -904,9 +946,9 @@ int64_t sgrl_set_workspace_bytes(const sgrl_set* s) { return s ? s->ws_floats * 
 
 int sgrl_set_peek(sgrl_set* s, int which, float* host, int64_t n_floats) {
   if (!s || !host || !s->have_graph) return sfail(SGRL_ERR_ARG, "sgrl_set_peek: bad argument");
-  const float* src[] = {s->g, s->cat, s->gram, s->fn, s->qkv, s->attng, s->attg, s->mat, s->g1, s->delta, s->outng};
-  const int64_t per[] = {384, 256, GK, 1, 768, 256, 768, 1024, 384, 128, 160};
-  if (which < 0 || which > 10 || n_floats > per[which] * s->N) return sfail(SGRL_ERR_ARG, "sgrl_set_peek: bad buffer or size");
+  const float* src[] = {s->g, s->cat, s->gram, s->fn, s->qkv, nullptr, nullptr, s->mat, s->g1, s->delta, s->outng};
+  const int64_t per[] = {384, 256, GK, 1, 768, 0, 0, 1024, 384, 128, 160};
+  if (which < 0 || which > 10 || !src[which] || n_floats > per[which] * s->N) return sfail(SGRL_ERR_ARG, "sgrl_set_peek: bad buffer or size");
   SHIP_TRY(hipDeviceSynchronize());
   SHIP_TRY(hipMemcpy(host, src[which], sizeof(float) * n_floats, hipMemcpyDeviceToHost));
   return SGRL_OK;

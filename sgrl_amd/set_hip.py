@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 
-NGLOBAL, NLAYER, LAYERS = 25, 30, 3
+NGLOBAL, NLAYER, LAYERS = 25, 31, 3
 NW = NGLOBAL + LAYERS * NLAYER
 
 
@@ -86,28 +86,34 @@ def pack_tensors(sd, prefix="actor.", critic=False):
         p = "transformer_encoder.layers.%d." % l
         a = p + "self_attn."
         b = NGLOBAL + l * NLAYER
-        vg = g(a + "vg_proj.weight")
+        vg, wgo, wng = g(a + "vg_proj.weight"), g(a + "g_out.weight"), g(a + "ng_out.weight")
+        wv, bv = g(a + "v_proj.weight"), g(a + "v_proj.bias")
+        # attention output folds (include/sgrl_set.h): value projection . output projection, per head
+        vfold = torch.cat([wng[:, 128 * h:128 * h + 128] @ wv[128 * h:128 * h + 128] for h in range(2)], 0)          # [256, 256]
+        bfold = torch.cat([wng[:, 128 * h:128 * h + 128] @ bv[128 * h:128 * h + 128] for h in range(2)], 0)          # [256]
+        ufold = torch.cat([wgo[:, 128 * h:128 * h + 126] @ vg[126 * h:126 * h + 126] for h in range(2)], 0)          # [256, 128]
+        gdcol = torch.stack([wgo[:, 128 * h + 126:128 * h + 128] for h in range(2)], 0).contiguous()                 # [2, 128, 2]
         out[b:b + NLAYER] = [
             g(a + "g_proj.weight"), fold_gram_weight(g(a + "linear_g1.weight")), g(a + "linear_g1.bias"), g(a + "linear_g2.weight"),
             g(a + "linear_g2.bias"),
-            torch.cat([g(a + "q_proj.weight") * scaling, g(a + "k_proj.weight"), g(a + "v_proj.weight")], 0),
-            torch.cat([g(a + "q_proj.bias") * scaling, g(a + "k_proj.bias"), g(a + "v_proj.bias")], 0),
-            torch.cat([vg, vg.new_zeros(256 - vg.shape[0], vg.shape[1])], 0),
-            g(a + "ng_out.weight"), g(a + "ng_out.bias"), g(a + "g_out.weight"),
+            torch.cat([g(a + "q_proj.weight") * scaling, g(a + "k_proj.weight"), vfold], 0),
+            torch.cat([g(a + "q_proj.bias") * scaling, g(a + "k_proj.bias"), bfold], 0),
+            ufold,
+            wng, g(a + "ng_out.bias"), wgo,
             g(p + "g_proj2.weight"), g(p + "g_proj3.weight"), fold_gram_weight(g(p + "linear_g1.weight")), g(p + "linear_g1.bias"),
             g(p + "linear_g2.weight"), g(p + "linear_g2.bias"), g(p + "linear3.weight"), g(p + "linear3.bias"),
             g(p + "linear4.weight"), g(p + "linear4.bias"), g(p + "linear5.weight"), g(p + "linear1.weight"),
             g(p + "linear1.bias"), g(p + "linear2.weight"), g(p + "linear2.bias"), g(p + "norm1.weight"),
-            g(p + "norm1.bias"), g(p + "norm2.weight"), g(p + "norm2.bias")]
+            g(p + "norm1.bias"), g(p + "norm2.weight"), g(p + "norm2.bias"), gdcol]
     return out
 
 
 NSITES = 7
-PACK_COPY, PACK_PADCOL, PACK_FOLD, PACK_STACK = 0, 1, 2, 3
+PACK_COPY, PACK_PADCOL, PACK_FOLD, PACK_STACK, PACK_MATMUL, PACK_SUBMAT = 0, 1, 2, 3, 4, 5
 # struct sgrl_pack_seg (include/sgrl_set.h)
 SEG_DTYPE = np.dtype([("dst", "<i8"), ("src0", "<u8"), ("src1", "<u8"), ("n", "<i4"), ("kind", "<i4"), ("a", "<i4"),
-                      ("b", "<i4"), ("scale", "<f4"), ("reserved", "<i4")])
-assert SEG_DTYPE.itemsize == 48
+                      ("b", "<i4"), ("scale", "<f4"), ("lda", "<i4"), ("ldb", "<i4"), ("reserved", "<i4")])
+assert SEG_DTYPE.itemsize == 56
 
 
 def plan_segments(net, critic=False):
@@ -124,9 +130,11 @@ def plan_segments(net, critic=False):
         assert t.dtype == torch.float32 and t.is_contiguous(), "SET parameters must be contiguous float32: " + name
         return t
 
-    def emit(kind, t0, n, a=0, b=0, scale=1.0, t1=None):
-        segs.append((pos[0], t0.data_ptr(), 0 if t1 is None else t1.data_ptr(), n, kind, a, b, scale, 0))
-        srcs.append((t0, t1))
+    def emit(kind, t0, n, a=0, b=0, scale=1.0, t1=None, off0=0, off1=0, lda=0, ldb=0):
+        """off0 / off1: element offsets into the source tensors (column / row blocks of a weight)."""
+        segs.append((pos[0], t0.data_ptr() + 4 * off0, 0 if t1 is None else t1.data_ptr() + 4 * off1, n, kind, a, b, scale,
+                     lda, ldb, 0))
+        srcs.append((t0, t1, off0, off1))
         pos[0] += n
 
     anchor = p("g_encoder.weight")
@@ -181,13 +189,33 @@ def plan_segments(net, critic=False):
         at = lp + "self_attn."
         b0 = NGLOBAL + l * NLAYER
 
+        wng, wgo = p(at + "ng_out.weight"), p(at + "g_out.weight")
+
         def qkv(kind):
-            copy(at + "q_proj." + kind, scale=scaling); copy(at + "k_proj." + kind); copy(at + "v_proj." + kind)
+            """q (scaled) | k | v folded through ng_out, head by head (include/sgrl_set.h)"""
+            copy(at + "q_proj." + kind, scale=scaling); copy(at + "k_proj." + kind)
+            v = p(at + "v_proj." + kind)
+            for h in range(2):
+                if kind == "weight":      # [128, 256] = Wng[:, 128h:128h+128] . Wv[128h:128h+128, :]
+                    emit(PACK_MATMUL, wng, 128 * 256, a=128, b=256, t1=v, off0=128 * h, off1=128 * h * 256, lda=256, ldb=256)
+                else:                     # [128] = Wng[:, 128h:128h+128] . bv[128h:128h+128]
+                    emit(PACK_MATMUL, wng, 128, a=128, b=1, t1=v, off0=128 * h, off1=128 * h, lda=256, ldb=1)
+
+        def ufold():
+            """[256, 128]: rows 128 h + r = Wgo[r, 128h:128h+126] . Wvg[126h:126h+126, :]"""
+            vgw = p(at + "vg_proj.weight")
+            for h in range(2):
+                emit(PACK_MATMUL, wgo, 128 * 128, a=126, b=128, t1=vgw, off0=128 * h, off1=126 * h * 128, lda=256, ldb=128)
+
+        def gdcols():
+            """[2, 128, 2]: the gravity / direction columns of g_out, per head"""
+            for h in range(2):
+                emit(PACK_SUBMAT, wgo, 128 * 2, b=2, off0=128 * h + 126, lda=256)
         slot(b0 + 0, copy, at + "g_proj.weight")
         slot(b0 + 1, fold, at + "linear_g1.weight"); slot(b0 + 2, copy, at + "linear_g1.bias")
         slot(b0 + 3, copy, at + "linear_g2.weight"); slot(b0 + 4, copy, at + "linear_g2.bias")
         slot(b0 + 5, qkv, "weight"); slot(b0 + 6, qkv, "bias")
-        slot(b0 + 7, copy, at + "vg_proj.weight", n=256 * 128)
+        slot(b0 + 7, ufold)
         slot(b0 + 8, copy, at + "ng_out.weight"); slot(b0 + 9, copy, at + "ng_out.bias")
         slot(b0 + 10, copy, at + "g_out.weight")
         slot(b0 + 11, copy, lp + "g_proj2.weight"); slot(b0 + 12, copy, lp + "g_proj3.weight")
@@ -200,6 +228,7 @@ def plan_segments(net, critic=False):
         slot(b0 + 24, copy, lp + "linear2.weight"); slot(b0 + 25, copy, lp + "linear2.bias")
         slot(b0 + 26, copy, lp + "norm1.weight"); slot(b0 + 27, copy, lp + "norm1.bias")
         slot(b0 + 28, copy, lp + "norm2.weight"); slot(b0 + 29, copy, lp + "norm2.bias")
+        slot(b0 + 30, gdcols)
 
     def stack(w0, w1, cols, cpad):
         t0 = p(w0)
@@ -260,7 +289,7 @@ class HipSetActor(object):
         if not force and ptrs == self._bound:
             return
         segs, offs, total, srcs = plan_segments(self.net, critic=self.critic)
-        if not all(t.is_cuda for t, _ in srcs):
+        if not all(src[0].is_cuda for src in srcs):
             raise _lib.SgrlError("the SET network must live on the GPU for the HIP path")
         _check(self.L, self.L.sgrl_set_bind_params(self.h, ctypes.c_void_p(segs.ctypes.data), len(segs),
                                                    ctypes.c_void_p(offs.ctypes.data), len(offs), ctypes.c_int64(total)),

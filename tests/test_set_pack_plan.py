@@ -12,9 +12,11 @@ from sgrl_amd.set_policy import make_critic, make_policy
 def _run_plan(segs, srcs, total):
     out = np.full(total, np.nan, dtype=np.float32)
     tril_a, tril_b = np.tril_indices(32)      # row-major lower triangle: k = a(a+1)/2 + b
-    for sg, (t0, t1) in zip(segs, srcs):
+    for sg, (t0, t1, off0, off1) in zip(segs, srcs):
         n, kind, a, b = int(sg["n"]), int(sg["kind"]), int(sg["a"]), int(sg["b"])
-        s0 = t0.detach().numpy().reshape(-1)
+        lda, ldb = int(sg["lda"]), int(sg["ldb"])
+        s0 = t0.detach().numpy().reshape(-1)[off0:]
+        s1 = None if t1 is None else t1.detach().numpy().reshape(-1)[off1:]
         v = np.zeros(n, dtype=np.float32)
         if kind == set_hip.PACK_COPY:
             v[:a] = s0[:a] * np.float32(sg["scale"])
@@ -32,7 +34,15 @@ def _run_plan(segs, srcs, total):
             v = v.reshape(64, b)
             v[:30, :a] = s0.reshape(30, a)
             if t1 is not None:
-                v[32:62, :a] = t1.detach().numpy().reshape(30, a)
+                v[32:62, :a] = s1.reshape(30, a)
+        elif kind == set_hip.PACK_MATMUL:      # dst [rows, b] = A [rows, a] (stride lda) . B [a, b] (stride ldb)
+            rows = n // b
+            A = np.stack([s0[r * lda:r * lda + a] for r in range(rows)])
+            Bm = np.stack([s1[k * ldb:k * ldb + b] for k in range(a)])
+            v = (A.astype(np.float64) @ Bm.astype(np.float64) * float(sg["scale"])).astype(np.float32)
+        elif kind == set_hip.PACK_SUBMAT:
+            rows = n // b
+            v = np.stack([s0[r * lda:r * lda + b] for r in range(rows)])
         else:
             raise AssertionError(kind)
         d = int(sg["dst"])
@@ -50,7 +60,7 @@ def test_plan_reproduces_the_host_pack(critic):
     else:
         net = make_policy(use_hip=False).actor
     segs, offs, total, srcs = set_hip.plan_segments(net, critic=critic)
-    assert segs.dtype.itemsize == 48 and total % 64 == 0
+    assert segs.dtype.itemsize == 56 and total % 64 == 0
     flat = _run_plan(segs, srcs, total)
     sd = {"actor." + k: v for k, v in net.state_dict().items()}
     tens = set_hip.pack_tensors(sd, critic=critic)
@@ -58,7 +68,10 @@ def test_plan_reproduces_the_host_pack(critic):
     for i, t in enumerate(tens):
         assert offs[i] == pos, i
         ref = t.reshape(-1).numpy()
-        np.testing.assert_array_equal(flat[pos:pos + ref.size], ref, err_msg="slot %d" % i)
+        if np.array_equal(flat[pos:pos + ref.size], ref):
+            pass
+        else:       # folded slots (matrix products): float32 torch.matmul vs the float64 restatement above
+            np.testing.assert_allclose(flat[pos:pos + ref.size], ref, rtol=1e-5, atol=1e-6, err_msg="slot %d" % i)
         pad = (-ref.size) % 64
         assert (flat[pos + ref.size:pos + ref.size + pad] == 0).all()
         pos += ref.size + pad
@@ -87,8 +100,10 @@ def test_plan_reproduces_the_host_pack(critic):
 def test_plan_sources_are_the_live_parameter_storage():
     net = make_policy(use_hip=False).actor
     segs, offs, total, srcs = set_hip.plan_segments(net)
-    ptrs = {p.data_ptr() for p in net.parameters()}
-    assert {int(s) for s in segs["src0"]} <= ptrs
+    ranges = [(p.data_ptr(), p.data_ptr() + 4 * p.numel()) for p in net.parameters()]
+    for col in ("src0", "src1"):
+        for ptr in segs[col]:
+            assert int(ptr) == 0 or any(lo <= int(ptr) < hi for lo, hi in ranges)      # inside some parameter's own storage
     # a reference-style soft update writes through .data: storage (and therefore the plan) is unchanged
     before = [p.data_ptr() for p in net.parameters()]
     for p in net.parameters():
