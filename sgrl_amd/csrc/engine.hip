@@ -340,6 +340,9 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
       // SGRL_GROUP_POLICY=0: never merge, =2: always merge adjacent classes (8 % faster on a cheetah-only batch)
       if (const char* pol = getenv("SGRL_GROUP_POLICY")) top = pol[0] == '0' ? c : (pol[0] == '2' ? c + 1 : top);
       while (i < e->n_env && cls[env_morph[order[i]]] <= top) { g.lds = std::max(g.lds, e->morph_lds[env_morph[order[i]]]); i++; }
+      // diagnostics only (tools/occupancy_sweep.py): SGRL_LDS_PAD=<bytes> inflates the dynamic LDS request to force fewer
+      // resident workgroups per CU
+      if (const char* pad = getenv("SGRL_LDS_PAD")) { g.lds += atoi(pad); e->lds_bytes = std::max(e->lds_bytes, g.lds); }
       g.count = i - g.first;
       e->groups.push_back(g);
     }

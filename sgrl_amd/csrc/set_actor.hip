@@ -382,10 +382,15 @@ __global__ __launch_bounds__(128) void k_equiv(const float* __restrict__ Z, cons
   }
 }
 
-__global__ void k_copy_g(const float* g, float* outg, int rows) {  // outg[row][8 + c] = g[row][c]
+// outg[row][8 + c] = g[row][c]; the K-padding columns 136 .. OGLD-1 of the row are zeroed here (no reliance on a cleared
+// workspace: the carve-up of the shared workspace changes with the batch structure)
+__global__ void k_copy_g(const float* g, float* outg, int rows) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)rows * D) return;
-  outg[(size_t)(i >> 7) * OGLD + 8 + (i & 127)] = g[i];
+  const int c = (int)(i & 127);
+  float* row = outg + (size_t)(i >> 7) * OGLD;
+  row[8 + c] = g[i];
+  if (c < OGLD - 136) row[136 + c] = 0.f;
 }
 
 // head: vec[s] = ((Zh[s] . mat) . wdec); action_k = max_action * tanh(sum_s axis_k[s] * vec[s]); 32 lanes per node
@@ -457,7 +462,6 @@ struct sgrl_set {
   float* ws = nullptr;
   int64_t ws_floats = 0;
   int carved_N = 0;
-  bool ws_dirty = false;        // the carve-up changed: padding columns must be re-zeroed (next forward, on its stream)
   float *g, *cat, *cat2, *gram, *fn, *h256, *qkv, *vg, *g1, *z2, *mat, *t256, *t256b, *t128a, *t128b, *delta,
       *outg, *outng, *gdir, *zall;
   // stacked projection weights of the 7 proj+gram sites: static weights -> own buffer rebuilt on the forward stream after
@@ -525,7 +529,6 @@ int use_cfg(sgrl_set* s, GraphCfg* c) {
     s->t128b = take(128 * N); s->delta = take(128 * N); s->outg = take(3 * OGLD * N); s->outng = take(160 * N); s->gdir = take(6 * N); s->zall = take(3 * ZLD * N);
     if (p - s->ws > s->ws_floats) return sfail(SGRL_ERR_LIMIT, "workspace carve-up overflow");
     s->carved_N = c->N;
-    s->ws_dirty = true;
   }
   s->n_env = c->n_env; s->N = c->N; s->n_morph = c->n_morph; s->TM = c->TM; s->Lmax = c->Lmax;
   s->d_node_env = c->d_node_env; s->d_node_limb = c->d_node_limb; s->d_node_mnode = c->d_node_mnode; s->d_trav = c->d_trav;
@@ -602,10 +605,6 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   NodeTab nt{s->d_node_env, s->d_node_limb, s->d_node_mnode, s->d_trav, s->TM};
   EnvTab et{s->d_env_off, s->d_env_L, s->d_env_relb};
   (void)hipMemsetAsync(act, 0, sizeof(float) * (size_t)s->n_env * act_ld, st);
-  if (s->ws_dirty) {     // new carve-up of the shared workspace: the K-padding columns of its arrays must read zero
-    (void)hipMemsetAsync(s->ws, 0, sizeof(float) * s->ws_floats, st);
-    s->ws_dirty = false;
-  }
   if (s->live)           // live weights: flat buffer (and the stacked projection operands in it) rebuilt from the parameters
     hipLaunchKernelGGL(k_pack, dim3(s->n_chunks), dim3(256), 0, st, s->d_segs, s->d_chunks, s->d_tri, s->wflat);
   hipLaunchKernelGGL(k_relbias, dim3(s->n_morph), dim3(256), 0, st, s->d_rel, s->W(SGRL_SET_REL_W), s->W(SGRL_SET_REL_B),

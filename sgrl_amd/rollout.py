@@ -190,7 +190,12 @@ class TransitionSink(object):
         self.buffers = buffers
         if self.is_learner and buffers is None:
             raise ValueError("the learner rank needs the per-morphology replay buffers")
-        self.stored = 0           # transitions written on the learner (tot_env_steps bookkeeping, trainer.py:229)
+        self._stored = torch.zeros((), dtype=torch.long, device=self.device)   # device-side count: no host sync per step
+
+    @property
+    def stored(self):
+        """Transitions written on the learner so far (tot_env_steps bookkeeping, trainer.py:229); reading it synchronises."""
+        return int(self._stored.item())
 
     def begin_round(self):
         self.collector.begin_round()
@@ -211,11 +216,21 @@ class TransitionSink(object):
     def ingest(self, blocks):
         for blk in blocks:                                   # rank order = global environment order
             obs, act, nxt, rew, done, store, morph = self.gather.unpack(blk)
-            for k, buf in enumerate(self.buffers):
-                m = store & (morph == k)
+            rows = torch.nonzero(store, as_tuple=False).flatten()          # host sync 1 of 2 per block (row count)
+            if rows.numel() == 0:
+                continue
+            m = morph[rows]
+            rows = rows[torch.argsort(m, stable=True)]                     # grouped by morphology, env order kept inside
+            counts = torch.bincount(m, minlength=len(self.buffers)).tolist()   # host sync 2 (the ring pointers live on the host)
+            self._stored += int(rows.numel())
+            off = 0
+            for k, cnt in enumerate(counts):
+                if cnt == 0:
+                    continue
+                r = rows[off:off + cnt]
+                off += cnt
                 L = self.num_limbs[k]
-                buf.add_transitions(obs[:, :41 * L], act[:, :3 * L], nxt[:, :41 * L], rew, done, mask=m)
-                self.stored += int(m.sum())
+                self.buffers[k].add_transitions(obs[r, :41 * L], act[r, :3 * L], nxt[r, :41 * L], rew[r], done[r])
 
     def total_episode_timesteps(self):
         """sum(episode_timesteps_list) over all ranks (the numerator of per_morph_iter, trainer.py:244)."""

@@ -70,6 +70,17 @@ int main(int argc, char** argv) {
   unsigned short *Apl, *Wpl;
   hipMalloc(&Apl, maxA * 2 * 3); hipMalloc(&Wpl, (size_t)1024 * 544 * 2 * 3);
   const int reps = 20;
+  if (argc > 2 && argv[2][0] == 'p') {   // pitch test: linear4 / l3 / qkv shapes with the A rows 1024 B apart vs padded pitches
+    for (int si : {1, 3, 0}) {
+      const Shape& sh = shapes[si];
+      for (int lda : {256, 264, 272, 288, 320}) {
+        GemmArgs a{A, lda, W, sh.K, bias, C, sh.N, sh.M, sh.N, sh.K, sh.flags, rd, C2, sh.N};
+        const float ms = si == 3 ? run3<EPI_RELU, 4, 2, 1, 2, 16, 2>(a, 20) : run3<EPI_ROWDIV, 4, 2, 1, 2, 16, 2>(a, 20);
+        printf("%s lda %3d (pitch %4d B): %.1f us\n", sh.name, lda, lda * 4, ms * 1e3);
+      }
+    }
+    return 0;
+  }
   if (argc > 2) {   // profiling mode: one configuration on the linear4 shape, a handful of launches
     const Shape& sh = shapes[1];
     GemmArgs a{A, sh.K, W, sh.K, bias, C, sh.N, sh.M, sh.N, sh.K, sh.flags, rd, C2, sh.N};

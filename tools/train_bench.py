@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""BASELINE.json config 5 on one GPU: the 23 cwhh training morphologies x 356 envs, DeviceTrainer (collection rounds +
+TD3 update schedule).  Reports collection env-steps/s (policy forward + exploration noise + engine step + replay ingest)
+and TD3 updates/s (batch 100, one morphology per update, PyTorch-ROCm autograd with HIP no-grad targets).
+Writes gpurun_out/train_bench.json."""
+import json, os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import torch
+from sgrl_amd import mjcf
+from sgrl_amd.td3 import default_train_args
+from sgrl_amd.train_loop import DeviceTrainer
+HELD_OUT = {"3d_walker_3_left_knee_right_knee", "3d_walker_6_right_foot", "3d_humanoid_7_left_leg", "3d_humanoid_8_right_knee",
+            "3d_cheetah_11_leftbkneen_rightffoot", "3d_cheetah_12_tail_leftffoot"}
+names = sorted(n for n in mjcf.list_assets() if n not in HELD_OUT)
+per = int(sys.argv[1]) if len(sys.argv) > 1 else 8192 // len(names)
+args = default_train_args()
+tr = DeviceTrainer(names, per, args=args, seed=1, device="cuda:0", max_buffer_size=200000)
+n = tr.ro.env.num_envs
+tr.warmup(60)                      # fills the buffers (random actions), several rounds
+torch.cuda.synchronize()
+t0 = time.time(); K = 40
+for _ in range(K):
+    if tr.collect_step():
+        tr.begin_round()
+torch.cuda.synchronize()
+t_collect = (time.time() - t0) / K
+# updates: 10 per morphology, as update_after_round would schedule them
+tr.agent.models2train()
+torch.cuda.synchronize()
+t0 = time.time(); U = 0
+for k, name in enumerate(names):
+    tr.agent.change_morphology(tr.graph_dicts[k])
+    for it in range(10):
+        tr.agent.update(tr.buffers[k].sample(args.batch_size, generator=tr.gen), it)
+        U += 1
+torch.cuda.synchronize()
+t_update = (time.time() - t0) / U
+tr.agent.models2eval()
+out = {"morphologies": len(names), "envs": n, "ms_per_collection_step": round(t_collect * 1e3, 3),
+       "collection_env_steps_per_s": round(n / t_collect, 1), "ms_per_td3_update": round(t_update * 1e3, 3),
+       "td3_updates_per_s": round(1.0 / t_update, 2), "batch_size": args.batch_size,
+       "row_overflow_envs": tr.ro.env.row_overflow_envs(), "buffer_rows": [b.max_sample_size for b in tr.buffers]}
+print(json.dumps(out))
+os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+json.dump(out, open(os.path.join(REPO, "gpurun_out", "train_bench.json"), "w"), indent=1)
