@@ -352,9 +352,11 @@ __global__ __launch_bounds__(256) void k_add_ln(const float* x, int ldx, const f
 
 // g[n][s][:] += g1[n][s][:] + ((Z[n][s][:] . mat[n]) . W5^T)     4 nodes per 128-thread block
 // (both residual updates of the vector stream in one pass: the attention output g1, reference SEActor.py:89, and the
-// equivariant feed-forward term, SEActor.py:108-114)
+// equivariant feed-forward term, SEActor.py:108-114).  With outg != null (last layer) the new g is also written into the
+// read-out operand outg[row][8 + c] (reference SEActor.py:254) together with its zero K-padding columns.
 __global__ __launch_bounds__(128) void k_equiv(const float* __restrict__ Z, const float* __restrict__ mat,
-                                               const float* __restrict__ W5, const float* __restrict__ g1, float* g, int N) {
+                                               const float* __restrict__ W5, const float* __restrict__ g1, float* g,
+                                               float* outg, int N) {
   __shared__ float T[4 * 96];
   const int t = threadIdx.x, n0 = blockIdx.x * 4;
   for (int q = 0; q < 3; q++) {
@@ -376,21 +378,15 @@ __global__ __launch_bounds__(128) void k_equiv(const float* __restrict__ Z, cons
       const float* tt = T + node * 96 + s * 32;
       float v = 0.f;
       for (int c = 0; c < 32; c++) v += tt[c] * w[c];
-      const size_t o = ((size_t)(n0 + node) * 3 + s) * D + t;
-      g[o] += g1[o] + v;
+      const size_t row = (size_t)(n0 + node) * 3 + s;
+      const float gn = g[row * D + t] + (g1[row * D + t] + v);
+      g[row * D + t] = gn;
+      if (outg) {
+        outg[row * OGLD + 8 + t] = gn;
+        if (t < OGLD - 136) outg[row * OGLD + 136 + t] = 0.f;
+      }
     }
   }
-}
-
-// outg[row][8 + c] = g[row][c]; the K-padding columns 136 .. OGLD-1 of the row are zeroed here (no reliance on a cleared
-// workspace: the carve-up of the shared workspace changes with the batch structure)
-__global__ void k_copy_g(const float* g, float* outg, int rows) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)rows * D) return;
-  const int c = (int)(i & 127);
-  float* row = outg + (size_t)(i >> 7) * OGLD;
-  row[8 + c] = g[i];
-  if (c < OGLD - 136) row[136 + c] = 0.f;
 }
 
 // head: vec[s] = ((Zh[s] . mat) . wdec); action_k = max_action * tanh(sum_s axis_k[s] * vec[s]); 32 lanes per node
@@ -668,7 +664,8 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
     GS(s->t256b, 256, s->WL(l, SGRL_SET_L2_W), 256, s->WL(l, SGRL_SET_L2_B), s->delta, D, N, D, 256, EPI_ROWDIV, s->fn);
     G(s->cat, 256, s->WL(l, SGRL_SET_L3_W), 256, s->WL(l, SGRL_SET_L3_B), s->t256, 256, N, 256, 256, EPI_RELU);
     G(s->t256, 256, s->WL(l, SGRL_SET_L4_W), 256, s->WL(l, SGRL_SET_L4_B), s->mat, 1024, N, 1024, 256, EPI_ROWDIV, s->fn);
-    hipLaunchKernelGGL(k_equiv, dim3((N + 3) / 4), dim3(128), 0, st, s->z2, s->mat, s->WL(l, SGRL_SET_L5_W), s->g1, s->g, N);
+    hipLaunchKernelGGL(k_equiv, dim3((N + 3) / 4), dim3(128), 0, st, s->z2, s->mat, s->WL(l, SGRL_SET_L5_W), s->g1, s->g,
+                       l == SGRL_SET_LAYERS - 1 ? s->outg : (float*)nullptr, N);
     join();
     hipLaunchKernelGGL(k_add_ln, dim3(lnb), dim3(256), 0, st, ng, 256, s->delta, D, s->WL(l, SGRL_SET_N2_W),
                        s->WL(l, SGRL_SET_N2_B), ng, 256, (float*)nullptr, 0, N);
@@ -680,7 +677,6 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   fork();
   GS(s->outng, 160, s->W(SGRL_SET_L1NG_W), 160, s->W(SGRL_SET_L1NG_B), s->t128b, D, N, D, 160, EPI_RELU);
   GS(s->t128b, D, s->W(SGRL_SET_L2NG_W), D, s->W(SGRL_SET_L2NG_B), s->cat2 + 128, 256, N, D, D);
-  hipLaunchKernelGGL(k_copy_g, dim3((N3 * D + 255) / 256), dim3(256), 0, st, s->g, s->outg, N3);
   PG(s->outg, OGLD, OGLD, 6, critic ? (float*)nullptr : s->z2);
   G(s->gram, GK, s->W(SGRL_SET_L1G_W), GK, s->W(SGRL_SET_L1G_B), s->t128a, D, N, D, GK, EPI_RELU);
   G(s->t128a, D, s->W(SGRL_SET_L2G_W), D, s->W(SGRL_SET_L2G_B), s->cat2, 256, N, D, D);
