@@ -46,15 +46,24 @@ class Agent(nn.Module):
     def __init__(self, args, device=None, use_hip=True):
         super().__init__()
         self.args = args
-        if getattr(args, "actor_type", "set") != "set" or getattr(args, "critic_type", "set") != "set":
-            raise NotImplementedError("only the SET actor / critic are built (SURVEY 8 f4: SWAT / SMP / MLP not started)")
+        atype, ctype = getattr(args, "actor_type", "set"), getattr(args, "critic_type", "set")
+        if atype not in ("set", "swat") or ctype not in ("set", "swat"):
+            raise NotImplementedError("actor / critic types 'set' (HIP fast path) and 'swat' (PyTorch) are built; "
+                                      "'smp' and 'mlp' are not (SURVEY 8 f4)")
         self.networks = {}
+        from .swat_policy import CriticStructurePolicy, StructurePolicy
 
         def actor():
+            if atype == "swat":
+                return StructurePolicy(args.limb_obs_size, args.limb_action_size, args.msg_dim, args.batch_size, args.max_action,
+                                       args.max_children, args.disable_fold, args.td, args.bu, args, device=device)
             return SEPolicy(args.limb_obs_size, args.limb_action_size, args.msg_dim, args.batch_size, args.max_action,
                             args.max_children, args.disable_fold, args.td, args.bu, args, device=device, use_hip=use_hip)
 
         def critic():
+            if ctype == "swat":
+                return CriticStructurePolicy(args.limb_obs_size, args.limb_action_size, args.msg_dim, args.batch_size,
+                                             args.max_children, args.disable_fold, args.td, args.bu, args, device=device)
             return SECritic(args.limb_obs_size, args.limb_action_size, args.msg_dim, args.batch_size, args.max_children,
                             args.disable_fold, args.td, args.bu, args, device=device, use_hip=use_hip)
         self.actor, self.actor_target = actor(), actor()

@@ -130,7 +130,7 @@ def test_agent_surface_and_state_dict_keys():
     agent.models2train()
     assert agent.critic_target.training
     with pytest.raises(NotImplementedError):
-        Agent(default_train_args(actor_type="swat"))
+        Agent(default_train_args(actor_type="smp"))
     soft_update_network(agent.actor, agent.actor_target, 0.5)
 
 
@@ -141,3 +141,21 @@ def test_update_matches_the_reference_on_the_gpu_with_hip_targets(golden):
     agent, hyper, out = run_script(golden, "cuda:0", use_hip=True)
     assert agent.actor_target._hip is not None and agent.critic_target._hip is not None and agent.actor._hip is not None
     check_against_golden(golden, agent, hyper, out, loss_rtol=3e-4, step_tol=2e-2)
+
+
+def test_swat_agent_updates():
+    """actor_type = critic_type = 'swat' (reference agent.py:28-29,66-67): the same TD3 update over the SWAT modules."""
+    from oracle.formula import synth_obs
+    torch.manual_seed(1)
+    agent = Agent(default_train_args(actor_type="swat", critic_type="swat"))
+    m = mjcf.load_asset("3d_walker_5_foot")
+    agent.change_morphology(G.getGraphDict(m.parents, TRAV, [], device=torch.device("cpu")))
+    B, L = 6, m.num_limbs
+    batch = {"obs": torch.from_numpy(synth_obs(L, B, 1).astype(np.float32)), "next_obs": torch.from_numpy(synth_obs(L, B, 2).astype(np.float32)),
+             "action": torch.rand(B, 3 * L) * 2 - 1, "reward": torch.randn(B, 1), "done": torch.zeros(B, 1)}
+    before = [p.detach().clone() for p in agent.actor.parameters()]
+    agent.models2train()
+    out = agent.update(batch, 0)
+    assert np.isfinite(float(out["loss/critic_loss"])) and "loss/actor_loss" in out
+    assert any(float((p - q).abs().max()) > 0 for p, q in zip(agent.actor.parameters(), before))
+    assert agent.select_action(batch["obs"][0].numpy()).shape == (1, 3 * L)
