@@ -77,11 +77,15 @@ int sgrl_set_weights(sgrl_set* s, const float* w, const int64_t* offsets, int n_
  *          (the two 30-row projections of a proj+Gram site as ONE zero-padded GEMM operand)
  *   MATMUL dst [n / b, b] = src0 [n / b, a] (row stride lda) . src1 [a, b] (row stride ldb), times scale   (weight folds)
  *   SUBMAT dst [n / b, b] = src0 [n / b, b] (row stride lda)                                                (column blocks)
+ *   PERM32 dst [1024, a]: row c * 32 + q = src0 row q * 32 + c   (L4_W / L4_B / L2M_W / L2M_B: the 1024 outputs are a 32 x 32
+ *          matrix mat[q][c] per node, reference SEActor.py:105-107; stored c-major so that one 32-column GEMM tile holds all q of
+ *          one c and the epilogue can contract it with z[s][q] without ever writing the matrix: the GEMM emits z . mat [3, 32])
  * offsets: HOST int64[SGRL_SET_NW + SGRL_SET_NSITES] -- the slot table followed by the offsets of the seven stacked
  * projection operands (sites 2l = attention g_proj of layer l [64,128]; 2l+1 = g_proj2 | g_proj3 [64,128];
  * 6 = gg_proj | g_proj (actor) [64,144]).  The segments must cover [0, total_floats) entirely.  Parameter storage must
  * stay allocated while the handle is bound; re-bind after anything that moves it (module.to(), new tensors). */
-enum { SGRL_PACK_COPY = 0, SGRL_PACK_PADCOL = 1, SGRL_PACK_FOLD = 2, SGRL_PACK_STACK = 3, SGRL_PACK_MATMUL = 4, SGRL_PACK_SUBMAT = 5 };
+enum { SGRL_PACK_COPY = 0, SGRL_PACK_PADCOL = 1, SGRL_PACK_FOLD = 2, SGRL_PACK_STACK = 3, SGRL_PACK_MATMUL = 4, SGRL_PACK_SUBMAT = 5,
+       SGRL_PACK_PERM32 = 6 };
 typedef struct sgrl_pack_seg {
   int64_t dst;        /* first float of the run in the flat buffer */
   const void* src0;   /* DEV float* */
@@ -128,7 +132,7 @@ int64_t sgrl_set_workspace_bytes(const sgrl_set* s);
 int sgrl_set_time_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_ld, float max_action,
                           int reps, void* stream, float* ms_out);
 /* Debug/parity: copy an intermediate buffer of the LAST forward to the host.  which: 0 g[N,3,128], 1 cat[N,256]
- * (inv | ng), 2 gram[N,544] (packed lower triangle), 3 fn[N], 4 qkv[N,768] (q | k | v' folded), 5 / 6 unused, 7 mat[N,1024],
+ * (inv | ng), 2 gram[N,544] (packed lower triangle), 3 fn[N], 4 qkv[N,768] (q | k | v' folded), 5 / 6 unused, 7 T[N,3,32] (z . mat),
  * 8 g1[N,3,128] (attention's vector output), 9 delta[N,128] (attention's / FFN's scalar output before the residual norm),
  * 10 outng[N,160] (input features | final-norm ng | zero padding). */
 int sgrl_set_peek(sgrl_set* s, int which, float* host, int64_t n_floats);

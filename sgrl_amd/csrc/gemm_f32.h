@@ -13,7 +13,7 @@ namespace sgrl_gemm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { EPI_RELU = 1, EPI_ROWDIV = 2, EPI_ACC2 = 4 };
+enum { EPI_RELU = 1, EPI_ROWDIV = 2, EPI_ACC2 = 4, EPI_EQUIV = 8 };
 
 struct GemmArgs {
   const float* A; int lda;
@@ -27,6 +27,11 @@ struct GemmArgs {
   // split-precision kernel only: an operand may arrive PRE-SPLIT as three bf16 planes (h | m | l, each [rows][ld] bf16,
   // `plane` bf16 elements apart) instead of f32 -- A/W then point at plane h and lda/ldw count bf16 elements
   long long a_plane = 0, w_plane = 0;
+  // EPI_EQUIV (split-precision kernel, N = 1024 with the output columns ordered c * 32 + a): the [M, 1024] result -- one
+  // 32 x 32 matrix mat[m][a][c] per row m -- is NOT stored; the epilogue contracts it on the fly with zq[m][s][a] (three
+  // 32-vectors per row) and stores only tout[m][s][c] = sum_a zq[m][s][a] * mat[m][a][c]  ([M, 3, 32] floats)
+  const float* zq = nullptr;
+  float* tout = nullptr;
 };
 
 // BKT = k extent of an LDS tile (16 or 32); row stride BKT + 4 floats (conflict-free ds_read_b128, see above).
@@ -222,8 +227,10 @@ struct TileCfg3 {
 // PLA / PLW: operand A / W is given as bf16 planes (GemmArgs::a_plane / w_plane) and is copied to LDS as is
 // LATE: the next tile is split and written to LDS AFTER this tile's MFMAs have been issued (the matrix pipe runs them
 // while the wave does the VALU / LDS-write work) instead of before
-template <int FLAGS, int WM, int WN, int TM, int TN, int BKT = 32, int PF = 1, bool PLA = false, bool PLW = false, bool LATE = false>
-__global__ __launch_bounds__(64 * WM * WN) void k_gemm3(GemmArgs a) {
+// ABL (diagnostics, tools/gemm_lab.hip): 1 = no staging in the loop (LDS keeps tile 0: MFMA + operand reads + barrier only),
+// 2 = staging only (no operand reads / MFMA), 3 = staging without the split arithmetic (raw bit copies)
+template <int FLAGS, int WM, int WN, int TM, int TN, int BKT = 32, int PF = 1, bool PLA = false, bool PLW = false, bool LATE = false, int ABL = 0>
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4))) void k_gemm3(GemmArgs a) {
   using Cfg = TileCfg3<WM, WN, TM, TN, BKT>;
   constexpr int T = Cfg::kThreads, BMT = Cfg::kBM, BNT = Cfg::kBN, RB = Cfg::kRowBytes;
   constexpr int QPR = BKT / 4;                // float4 per tile row
@@ -301,7 +308,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm3(GemmArgs a) {
   // split a float4 into its three bf16 planes and store 8 bytes into each
   auto put = [&](char* plane0, int plane_stride, int row, const float4& v) {
     unsigned h[4], m[4], l[4];
-    split3(v.x, h[0], m[0], l[0]); split3(v.y, h[1], m[1], l[1]); split3(v.z, h[2], m[2], l[2]); split3(v.w, h[3], m[3], l[3]);
+    if (ABL == 3) {
+      h[0] = __float_as_uint(v.x); h[1] = __float_as_uint(v.y); h[2] = __float_as_uint(v.z); h[3] = __float_as_uint(v.w);
+      for (int q = 0; q < 4; q++) { m[q] = h[q] << 3; l[q] = h[q] << 7; }
+    } else {
+      split3(v.x, h[0], m[0], l[0]); split3(v.y, h[1], m[1], l[1]); split3(v.z, h[2], m[2], l[2]); split3(v.w, h[3], m[3], l[3]);
+    }
     char* p = plane0 + row * RB + 8 * kq;
     *reinterpret_cast<uint2*>(p) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
     *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
@@ -333,11 +345,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm3(GemmArgs a) {
   const int boff = 3 * Cfg::kPlaneA + (wn * 32 * TN + li) * RB + 16 * lh;
   auto body = [&](int kt, int slot) {
     const int st = kt & 1;
-    if (!LATE) {
+    if (!LATE && ABL != 1) {
       if (kt + 1 < nk) sstore(slot, st ^ 1);
       if (kt + 1 + PF < nk) gload(slot, (kt + 1 + PF) * BKT);
     }
-    const char* base = lds + st * Cfg::kStageBytes;
+    const char* base = lds + (ABL == 1 ? 0 : st) * Cfg::kStageBytes;
+    if (ABL != 2)
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
       bf16x8 av[TM][3], bv[TN][3];
@@ -355,12 +368,23 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm3(GemmArgs a) {
       for (int i = 0; i < TM; i++)
 #pragma unroll
         for (int j = 0; j < TN; j++) {
+          if (FLAGS & EPI_EQUIV) {
+            // transposed tile (W rows on the accumulator rows = registers, nodes on the lanes): the epilogue's contraction over
+            // the W-row index then runs over REGISTERS of a lane instead of across lanes
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j][0], av[i][0], acc[i][j], 0, 0, 0);
+            cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j][0], av[i][2], cor[i][j], 0, 0, 0);
+            cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j][2], av[i][0], cor[i][j], 0, 0, 0);
+            cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j][1], av[i][1], cor[i][j], 0, 0, 0);
+            cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j][0], av[i][1], cor[i][j], 0, 0, 0);
+            cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j][1], av[i][0], cor[i][j], 0, 0, 0);
+          } else {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[j][0], acc[i][j], 0, 0, 0);   // hh
           cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][2], bv[j][0], cor[i][j], 0, 0, 0);   // lh
           cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[j][2], cor[i][j], 0, 0, 0);   // hl
           cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][1], bv[j][1], cor[i][j], 0, 0, 0);   // mm
           cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][1], bv[j][0], cor[i][j], 0, 0, 0);   // mh
           cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[j][1], cor[i][j], 0, 0, 0);   // hm
+          }
         }
     }
     if (LATE) {
@@ -375,6 +399,51 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm3(GemmArgs a) {
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) { body(kt, 0); body(kt + 1, 1); }
     if (kt < nk) body(kt, 0);
+  }
+  if (FLAGS & EPI_EQUIV) {
+    // Equivariant epilogue.  The accumulators hold TRANSPOSED 32 x 32 tiles: lane = node (column li of the tile), registers
+    // = W rows q (row (e & 3) + 8 (e >> 2) + 4 lh); one tile = mat[node][q][c] for ONE c (output columns ordered c * 32 + q).
+    // tout[node][s][c] = rdiv[node] * sum_q z[node][s][q] * (acc + bias)[q]: 16 register FMAs per lane and s, one exchange
+    // between the two half-waves.  The z rows of the block's 128 nodes are staged in the (now idle) LDS, row stride 100
+    // floats: 16-byte aligned and conflict-free for ds_read_b128 across nodes.
+    static_assert(!(FLAGS & EPI_EQUIV) || TM == 1, "the equivariant epilogue assumes one 32-node row tile per wave");
+    float* zs = gemm_lds;
+    constexpr int ZS = 100;
+    for (int idx = t; idx < BMT * 24; idx += T) {
+      const int r = idx / 24, q4 = idx % 24;
+      const int m = min(m0 + r, a.M - 1);
+      *reinterpret_cast<float4*>(zs + r * ZS + 4 * q4) = *reinterpret_cast<const float4*>(a.zq + (size_t)m * 96 + 4 * q4);
+    }
+    __syncthreads();
+    const int mloc = wm * 32 + li, m = m0 + mloc;
+    const bool ok = m < a.M;
+    const float rd = (FLAGS & EPI_ROWDIV) ? 1.0f / (ok ? a.rowdiv[m] : 1.f) : 1.f;
+#pragma unroll
+    for (int tj = 0; tj < TN; tj++) {
+      const int cidx = (n0 + wn * 32 * TN + tj * 32) >> 5;
+      float ts[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++) {
+        const int q0 = 8 * g4 + 4 * lh;
+        const float4 b4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + cidx * 32 + q0) : make_float4(0, 0, 0, 0);
+        const float v0 = (acc[0][tj][4 * g4 + 0] + cor[0][tj][4 * g4 + 0]) + b4.x;
+        const float v1 = (acc[0][tj][4 * g4 + 1] + cor[0][tj][4 * g4 + 1]) + b4.y;
+        const float v2 = (acc[0][tj][4 * g4 + 2] + cor[0][tj][4 * g4 + 2]) + b4.z;
+        const float v3 = (acc[0][tj][4 * g4 + 3] + cor[0][tj][4 * g4 + 3]) + b4.w;
+#pragma unroll
+        for (int sx = 0; sx < 3; sx++) {
+          const float4 z4 = *reinterpret_cast<const float4*>(zs + mloc * ZS + sx * 32 + q0);
+          ts[sx] += z4.x * v0 + z4.y * v1 + z4.z * v2 + z4.w * v3;
+        }
+      }
+#pragma unroll
+      for (int sx = 0; sx < 3; sx++) {
+        float tv = ts[sx] * rd;
+        tv += __shfl_xor(tv, 32, 64);
+        if (ok && lh == 0) a.tout[(size_t)m * 96 + sx * 32 + cidx] = tv;
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int ti = 0; ti < TM; ti++) {
@@ -410,6 +479,148 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm3(GemmArgs a) {
         a.C[(size_t)m * a.ldc + n] = v;
         if (FLAGS & EPI_ACC2) a.C2[(size_t)m * a.ldc2 + n] = old2[e] + v;
       }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Wave-specialised form of the split-precision GEMM: 16 waves per block, 8 CONSUMERS (4 x 2, a 32 x 64 patch each: LDS
+// operand reads + the six bf16 MFMAs per product block) and 8 PRODUCERS (global loads PF k-tiles ahead, the exact 3-way bf16
+// split, LDS stores).  One barrier per k-tile: while the consumers run tile kt out of LDS stage kt & 1, the producers fill
+// stage (kt + 1) & 1 -- the matrix pipe of a SIMD (two consumer waves) never waits on a global load or on split arithmetic,
+// which sit in the two producer waves sharing that SIMD (VALU and MFMA issue from different waves overlap).
+template <int FLAGS, int BKT = 16, int PF = 3>
+__global__ __launch_bounds__(1024) void k_gemm4(GemmArgs a) {
+  using Cfg = TileCfg3<4, 2, 1, 2, BKT>;        // same 128 x 128 tile / LDS image as the 8-wave k_gemm3
+  constexpr int BMT = 128, BNT = 128, RB = Cfg::kRowBytes, TN = 2;
+  constexpr int QPR = BKT / 4, RPP = 512 / QPR, NP = 128 / RPP;   // producer staging: NP float4 of A and of W per thread
+  constexpr int KS = BKT / 16;
+  extern __shared__ float gemm_lds[];
+  char* lds = reinterpret_cast<char*>(gemm_lds);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const bool producer = wave >= 8;              // wave-uniform
+  const int tiles_n = (a.N + BNT - 1) / BNT;
+  int bid;
+  {
+    const int nt = gridDim.x, per = nt >> 3, rem = nt & 7, x = blockIdx.x & 7, i = blockIdx.x >> 3;
+    bid = (x < rem) ? x * (per + 1) + i : rem * (per + 1) + (x - rem) * per + i;
+  }
+  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  const int m0 = tile_m * BMT, n0 = tile_n * BNT;
+  const int nk = a.K / BKT;
+  // ---- producer state
+  const int pt = t & 511, kq = pt % QPR, r0 = pt / QPR;
+  const float* arow_g[NP];
+  const float* wrow_g[NP];
+  float4 ra[PF][NP], rw[PF][NP];
+#pragma unroll
+  for (int i = 0; i < NP; i++) {
+    arow_g[i] = a.A + (size_t)min(m0 + r0 + RPP * i, a.M - 1) * a.lda + 4 * kq;      // clamped rows: never stored
+    wrow_g[i] = a.W + (size_t)min(n0 + r0 + RPP * i, a.N - 1) * a.ldw + 4 * kq;
+  }
+  auto gload = [&](int slot, int k0) {
+#pragma unroll
+    for (int i = 0; i < NP; i++) { ra[slot][i] = *reinterpret_cast<const float4*>(arow_g[i] + k0); rw[slot][i] = *reinterpret_cast<const float4*>(wrow_g[i] + k0); }
+  };
+  auto put = [&](char* plane0, int plane_stride, int row, const float4& v) {
+    unsigned h[4], m[4], l[4];
+    split3(v.x, h[0], m[0], l[0]); split3(v.y, h[1], m[1], l[1]); split3(v.z, h[2], m[2], l[2]); split3(v.w, h[3], m[3], l[3]);
+    char* p = plane0 + row * RB + 8 * kq;
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
+    *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
+    *reinterpret_cast<uint2*>(p + 2 * plane_stride) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
+  };
+  auto sstore = [&](int slot, int st) {
+    char* base = lds + st * Cfg::kStageBytes;
+#pragma unroll
+    for (int i = 0; i < NP; i++) { put(base, Cfg::kPlaneA, r0 + RPP * i, ra[slot][i]); put(base + 3 * Cfg::kPlaneA, Cfg::kPlaneW, r0 + RPP * i, rw[slot][i]); }
+  };
+  // ---- consumer state
+  const int cw = wave & 7, wm = cw >> 1, wn = cw & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int aoff = (wm * 32 + li) * RB + 16 * lh;
+  const int boff = 3 * Cfg::kPlaneA + (wn * 64 + li) * RB + 16 * lh;
+  f32x16 acc[TN], cor[TN];
+#pragma unroll
+  for (int j = 0; j < TN; j++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) { acc[j][e] = 0.f; cor[j][e] = 0.f; }
+
+  if (producer) {
+    gload(0, 0);
+    sstore(0, 0);
+#pragma unroll
+    for (int q = 0; q < PF; q++) if (1 + q < nk) gload(q, (1 + q) * BKT);      // slot of tile k = (k - 1) % PF
+  }
+  __syncthreads();
+  for (int kt0 = 0; kt0 < nk; kt0 += PF) {
+#pragma unroll
+    for (int q = 0; q < PF; q++) {
+      const int kt = kt0 + q;
+      if (kt < nk) {                         // uniform over the block
+        const int st = kt & 1;
+        if (producer) {
+          if (kt + 1 < nk) sstore(q, st ^ 1);                        // tile kt + 1 sits in slot q
+          if (kt + 1 + PF < nk) gload(q, (kt + 1 + PF) * BKT);
+        } else {
+          const char* base = lds + st * Cfg::kStageBytes;
+#pragma unroll
+          for (int ks = 0; ks < KS; ks++) {
+            bf16x8 av[3], bv[TN][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) av[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(base + pl * Cfg::kPlaneA + aoff + 32 * ks));
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+              for (int pl = 0; pl < 3; pl++)
+                bv[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(base + pl * Cfg::kPlaneW + boff + 32 * j * RB + 32 * ks));
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[j][0], acc[j], 0, 0, 0);   // hh
+              cor[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2], bv[j][0], cor[j], 0, 0, 0);   // lh
+              cor[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[j][2], cor[j], 0, 0, 0);   // hl
+              cor[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[j][1], cor[j], 0, 0, 0);   // mm
+              cor[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[j][0], cor[j], 0, 0, 0);   // mh
+              cor[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[j][1], cor[j], 0, 0, 0);   // hm
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+  if (producer) return;
+  const int mb = m0 + wm * 32 + 4 * lh;
+  float rdiv[16];
+  if (FLAGS & EPI_ROWDIV) {
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const int m = mb + (e & 3) + 8 * (e >> 2);
+      rdiv[e] = 1.0f / ((m < a.M) ? a.rowdiv[m] : 1.f);
+    }
+  }
+#pragma unroll
+  for (int tj = 0; tj < TN; tj++) {
+    const int n = n0 + wn * 64 + tj * 32 + li;
+    if (n >= a.N) continue;
+    const float bvv = a.bias ? a.bias[n] : 0.f;
+    float old2[16];
+    if (FLAGS & EPI_ACC2) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int m = mb + (e & 3) + 8 * (e >> 2);
+        old2[e] = (m < a.M) ? a.C2[(size_t)m * a.ldc2 + n] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const int m = mb + (e & 3) + 8 * (e >> 2);
+      if (m >= a.M) continue;
+      float v = (acc[tj][e] + cor[tj][e]) + bvv;
+      if (FLAGS & EPI_RELU) v = fmaxf(v, 0.f);
+      if (FLAGS & EPI_ROWDIV) v = v * rdiv[e];
+      a.C[(size_t)m * a.ldc + n] = v;
+      if (FLAGS & EPI_ACC2) a.C2[(size_t)m * a.ldc2 + n] = old2[e] + v;
     }
   }
 }

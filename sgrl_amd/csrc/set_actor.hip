@@ -43,6 +43,7 @@ constexpr int OGLD = 144;                  // row stride of outg: 136 channels p
 
 // The f32 MFMA GEMM (C[M,N] = epi(A[M,K] . W[N,K]^T)) lives in gemm_f32.h.
 using sgrl_gemm::EPI_ACC2;
+using sgrl_gemm::EPI_EQUIV;
 using sgrl_gemm::EPI_RELU;
 using sgrl_gemm::EPI_ROWDIV;
 using sgrl_gemm::GemmArgs;
@@ -155,6 +156,11 @@ __global__ __launch_bounds__(256) void k_pack(const sgrl_pack_seg* __restrict__ 
         float acc = 0.f;
         for (int k = 0; k < sg.a; k++) acc += ar[k] * s1[(size_t)k * sg.ldb + c];
         v = acc * sg.scale;
+        break;
+      }
+      case SGRL_PACK_PERM32: {  // [1024, a] rows regrouped: dst row c * 32 + q = src0 row q * 32 + c  (32 x 32 matrix per row block)
+        const int r = i / sg.a, k = i % sg.a;
+        v = s0[(size_t)((r & 31) * 32 + (r >> 5)) * sg.a + k];
         break;
       }
       case SGRL_PACK_SUBMAT: {  // dst [rows, b] = src0 [rows, b] (stride lda)
@@ -350,33 +356,27 @@ __global__ __launch_bounds__(256) void k_add_ln(const float* x, int ldx, const f
   if (out2) { out2[(size_t)row * ld2 + lane] = y0; out2[(size_t)row * ld2 + 64 + lane] = y1; }
 }
 
-// g[n][s][:] += g1[n][s][:] + ((Z[n][s][:] . mat[n]) . W5^T)     4 nodes per 128-thread block
+// g[n][s][:] += g1[n][s][:] + T[n][s][:] . W5^T     8 nodes per 128-thread block, thread = output channel
 // (both residual updates of the vector stream in one pass: the attention output g1, reference SEActor.py:89, and the
-// equivariant feed-forward term, SEActor.py:108-114).  With outg != null (last layer) the new g is also written into the
-// read-out operand outg[row][8 + c] (reference SEActor.py:254) together with its zero K-padding columns.
-__global__ __launch_bounds__(128) void k_equiv(const float* __restrict__ Z, const float* __restrict__ mat,
-                                               const float* __restrict__ W5, const float* __restrict__ g1, float* g,
-                                               float* outg, int N) {
-  __shared__ float T[4 * 96];
-  const int t = threadIdx.x, n0 = blockIdx.x * 4;
-  for (int q = 0; q < 3; q++) {
-    const int o = t + 128 * q, node = o / 96, s = (o % 96) / 32, c = o % 32;
-    float v = 0.f;
-    if (n0 + node < N) {
-      const float* z = Z + ((size_t)(n0 + node) * 3 + s) * ZD;
-      const float* m = mat + (size_t)(n0 + node) * 1024 + c;
-      for (int a = 0; a < 32; a++) v += z[a] * m[a * 32];
-    }
-    T[o] = v;
-  }
-  __syncthreads();
+// equivariant feed-forward term, SEActor.py:108-114, whose 3 x 32 factor T = z3 . mat comes out of the linear4 GEMM's
+// epilogue -- the 32 x 32 matrix per node never reaches memory).  With outg != null (last layer) the new g is also written
+// into the read-out operand outg[row][8 + c] (reference SEActor.py:254) together with its zero K-padding columns.
+__global__ __launch_bounds__(128) void k_equiv(const float* __restrict__ T, const float* __restrict__ W5,
+                                               const float* __restrict__ g1, float* g, float* outg, int N) {
+  __shared__ float Ts[8 * 96];
+  const int t = threadIdx.x, n0 = blockIdx.x * 8;
+  for (int o = t; o < 8 * 96; o += 128) Ts[o] = (n0 + o / 96 < N) ? T[(size_t)n0 * 96 + o] : 0.f;
   float w[32];
+#pragma unroll
   for (int c = 0; c < 32; c++) w[c] = W5[t * 32 + c];
-  for (int node = 0; node < 4; node++) {
+  __syncthreads();
+  for (int node = 0; node < 8; node++) {
     if (n0 + node >= N) break;
+#pragma unroll
     for (int s = 0; s < 3; s++) {
-      const float* tt = T + node * 96 + s * 32;
+      const float* tt = Ts + node * 96 + s * 32;
       float v = 0.f;
+#pragma unroll
       for (int c = 0; c < 32; c++) v += tt[c] * w[c];
       const size_t row = (size_t)(n0 + node) * 3 + s;
       const float gn = g[row * D + t] + (g1[row * D + t] + v);
@@ -389,19 +389,17 @@ __global__ __launch_bounds__(128) void k_equiv(const float* __restrict__ Z, cons
   }
 }
 
-// head: vec[s] = ((Zh[s] . mat) . wdec); action_k = max_action * tanh(sum_s axis_k[s] * vec[s]); 32 lanes per node
-__global__ __launch_bounds__(128) void k_head_out(const float* __restrict__ Zh, const float* __restrict__ mat,
-                                                  const float* __restrict__ wdec, const float* __restrict__ obs,
-                                                  int obs_ld, NodeTab nt, float* act, int act_ld, float max_action, int N) {
+// head: vec[s] = T[n][s][:] . wdec (T = Zh . mat from the linear2_m GEMM's epilogue); action_k = max_action * tanh(sum_s
+// axis_k[s] * vec[s]); 32 lanes per node
+__global__ __launch_bounds__(128) void k_head_out(const float* __restrict__ T, const float* __restrict__ wdec,
+                                                  const float* __restrict__ obs, int obs_ld, NodeTab nt, float* act, int act_ld,
+                                                  float max_action, int N) {
   const int n = blockIdx.x * 4 + (threadIdx.x >> 5), c = threadIdx.x & 31;
   if (n >= N) return;
   float vec[3];
+  const float wd = wdec[c];
   for (int s = 0; s < 3; s++) {
-    const float* z = Zh + ((size_t)n * 3 + s) * ZD;
-    const float* m = mat + (size_t)n * 1024 + c;
-    float v = 0.f;
-    for (int a = 0; a < 32; a++) v += z[a] * m[a * 32];
-    v *= wdec[c];
+    float v = T[(size_t)n * 96 + s * 32 + c] * wd;
     for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
     vec[s] = v;
   }
@@ -485,7 +483,7 @@ struct sgrl_set {
 namespace {
 
 constexpr int64_t kPerNodeFloats = 384 /*g*/ + 256 + 256 /*cat, cat2*/ + 1024 /*gram*/ + 1 /*fn*/ + 256 /*h256*/ + 768 /*qkv*/ +
-                                   768 /*vg*/ + 384 /*g1*/ + 96 /*z2*/ + 1024 /*mat*/ + 256 + 256 /*t256, t256b*/ +
+                                   768 /*vg*/ + 384 /*g1*/ + 96 /*z2*/ + 96 /*T (was mat: 1024)*/ + 256 + 256 /*t256, t256b*/ +
                                    128 + 128 + 128 /*t128a,b,delta*/ + 3 * OGLD /*outg*/ + 160 /*outng*/ + 6 /*gdir*/ + 3 * ZLD /*zall*/;
 constexpr int kWsArrays = 20;
 
@@ -521,7 +519,7 @@ int use_cfg(sgrl_set* s, GraphCfg* c) {
     auto take = [&](int64_t n) { float* r = p; p += (n + 31) & ~int64_t(31); return r; };
     s->g = take(384 * N); s->cat = take(256 * N); s->cat2 = take(256 * N); s->gram = take(1024 * N); s->fn = take(N);
     s->h256 = take(256 * N); s->qkv = take(768 * N); s->vg = take(768 * N);
-    s->g1 = take(384 * N); s->z2 = take(96 * N); s->mat = take(1024 * N); s->t256 = take(256 * N); s->t256b = take(256 * N); s->t128a = take(128 * N);
+    s->g1 = take(384 * N); s->z2 = take(96 * N); s->mat = take(96 * N); s->t256 = take(256 * N); s->t256b = take(256 * N); s->t128a = take(128 * N);
     s->t128b = take(128 * N); s->delta = take(128 * N); s->outg = take(3 * OGLD * N); s->outng = take(160 * N); s->gdir = take(6 * N); s->zall = take(3 * ZLD * N);
     if (p - s->ws > s->ws_floats) return sfail(SGRL_ERR_LIMIT, "workspace carve-up overflow");
     s->carved_N = c->N;
@@ -577,6 +575,18 @@ template <int F> struct GemmKernels {
     }
   }
 };
+
+// linear4 / linear2_m (N = 1024, columns ordered c * 32 + a) with the equivariant contraction in the epilogue:
+// tout[m][s][c] = sum_a zq[m][s][a] * ((A . W^T + b)[m][c * 32 + a] / rowdiv[m]); always the split-precision kernel
+constexpr auto kGemmEquiv = sgrl_gemm::k_gemm3<EPI_ROWDIV | EPI_EQUIV, 4, 2, 1, 2, 16, 2>;
+int launch_gemm_equiv(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, int M, int K,
+                      const float* rowdiv, const float* zq, float* tout) {
+  if (K % 32 != 0 || (lda & 3) || (ldw & 3)) return sfail(SGRL_ERR_ARG, "gemm_equiv: K must be a multiple of 32 and rows 16-byte aligned");
+  GemmArgs a{A, lda, W, ldw, bias, nullptr, 0, M, 1024, K, EPI_ROWDIV | EPI_EQUIV, rowdiv, nullptr, 0};
+  a.zq = zq; a.tout = tout;
+  hipLaunchKernelGGL(kGemmEquiv, dim3(((M + 127) / 128) * 8), dim3(512), GemmKernels<0>::kSplitLds, st, a);
+  return SGRL_OK;
+}
 
 int launch_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc,
                 int M, int N, int K, int flags = 0, const float* rowdiv = nullptr, float* C2 = nullptr, int ldc2 = 0) {
@@ -663,8 +673,9 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
     GS(s->cat, 256, s->WL(l, SGRL_SET_L1_W), 256, s->WL(l, SGRL_SET_L1_B), s->t256b, 256, N, 256, 256, EPI_RELU);
     GS(s->t256b, 256, s->WL(l, SGRL_SET_L2_W), 256, s->WL(l, SGRL_SET_L2_B), s->delta, D, N, D, 256, EPI_ROWDIV, s->fn);
     G(s->cat, 256, s->WL(l, SGRL_SET_L3_W), 256, s->WL(l, SGRL_SET_L3_B), s->t256, 256, N, 256, 256, EPI_RELU);
-    G(s->t256, 256, s->WL(l, SGRL_SET_L4_W), 256, s->WL(l, SGRL_SET_L4_B), s->mat, 1024, N, 1024, 256, EPI_ROWDIV, s->fn);
-    hipLaunchKernelGGL(k_equiv, dim3((N + 3) / 4), dim3(128), 0, st, s->z2, s->mat, s->WL(l, SGRL_SET_L5_W), s->g1, s->g,
+    rc = launch_gemm_equiv(st, s->t256, 256, s->WL(l, SGRL_SET_L4_W), 256, s->WL(l, SGRL_SET_L4_B), N, 256, s->fn, s->z2, s->mat);
+    if (rc != SGRL_OK) return rc;
+    hipLaunchKernelGGL(k_equiv, dim3((N + 7) / 8), dim3(128), 0, st, s->mat, s->WL(l, SGRL_SET_L5_W), s->g1, s->g,
                        l == SGRL_SET_LAYERS - 1 ? s->outg : (float*)nullptr, N);
     join();
     hipLaunchKernelGGL(k_add_ln, dim3(lnb), dim3(256), 0, st, ng, 256, s->delta, D, s->WL(l, SGRL_SET_N2_W),
@@ -687,8 +698,9 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
                        nt, act, act_ld, N);
   } else {
     G(s->cat2, 256, s->W(SGRL_SET_L1M_W), 256, s->W(SGRL_SET_L1M_B), s->t256, 256, N, 256, 256, EPI_RELU);
-    G(s->t256, 256, s->W(SGRL_SET_L2M_W), 256, s->W(SGRL_SET_L2M_B), s->mat, 1024, N, 1024, 256, EPI_ROWDIV, s->fn);
-    hipLaunchKernelGGL(k_head_out, dim3((N + 3) / 4), dim3(128), 0, st, s->z2, s->mat, s->W(SGRL_SET_DECG), obs, obs_ld, nt,
+    rc = launch_gemm_equiv(st, s->t256, 256, s->W(SGRL_SET_L2M_W), 256, s->W(SGRL_SET_L2M_B), N, 256, s->fn, s->z2, s->mat);
+    if (rc != SGRL_OK) return rc;
+    hipLaunchKernelGGL(k_head_out, dim3((N + 3) / 4), dim3(128), 0, st, s->mat, s->W(SGRL_SET_DECG), obs, obs_ld, nt,
                        act, act_ld, max_action, N);
   }
 #undef GS
@@ -709,7 +721,8 @@ int sgrl_set_create(sgrl_set** out) {
     *out = nullptr;
     return sfail(SGRL_ERR_HIP, "no HIP device visible: the SET actor fast path needs an MI355X (there is no CPU fallback)");
   }
-  const bool attr_ok = GemmKernels<0>::raise_lds_limits() && GemmKernels<EPI_RELU>::raise_lds_limits() &&
+  const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kGemmEquiv), hipFuncAttributeMaxDynamicSharedMemorySize, GemmKernels<0>::kSplitLds) == hipSuccess &&
+                       GemmKernels<0>::raise_lds_limits() && GemmKernels<EPI_RELU>::raise_lds_limits() &&
                        GemmKernels<EPI_ROWDIV>::raise_lds_limits() && GemmKernels<EPI_ACC2>::raise_lds_limits();
   if (!attr_ok) {
     *out = nullptr;
@@ -785,6 +798,7 @@ int sgrl_set_bind_params(sgrl_set* s, const sgrl_pack_seg* segs, int n_segs, con
       case SGRL_PACK_STACK: ok = g.a > 0 && g.b >= g.a && g.n == 64 * g.b; break;
       case SGRL_PACK_MATMUL: ok = g.src1 && g.a > 0 && g.b > 0 && g.n % g.b == 0 && g.lda >= g.a && g.ldb >= g.b; break;
       case SGRL_PACK_SUBMAT: ok = g.b > 0 && g.n % g.b == 0 && g.lda >= g.b; break;
+      case SGRL_PACK_PERM32: ok = g.a > 0 && g.n == 1024 * g.a; break;
       default: break;
     }
     if (!ok) return sfail(SGRL_ERR_ARG, "sgrl_set_bind_params: inconsistent segment " + std::to_string(order[oi]));
@@ -942,7 +956,7 @@ int64_t sgrl_set_workspace_bytes(const sgrl_set* s) { return s ? s->ws_floats * 
 int sgrl_set_peek(sgrl_set* s, int which, float* host, int64_t n_floats) {
   if (!s || !host || !s->have_graph) return sfail(SGRL_ERR_ARG, "sgrl_set_peek: bad argument");
   const float* src[] = {s->g, s->cat, s->gram, s->fn, s->qkv, nullptr, nullptr, s->mat, s->g1, s->delta, s->outng};
-  const int64_t per[] = {384, 256, GK, 1, 768, 0, 0, 1024, 384, 128, 160};
+  const int64_t per[] = {384, 256, GK, 1, 768, 0, 0, 96, 384, 128, 160};
   if (which < 0 || which > 10 || !src[which] || n_floats > per[which] * s->N) return sfail(SGRL_ERR_ARG, "sgrl_set_peek: bad buffer or size");
   SHIP_TRY(hipDeviceSynchronize());
   SHIP_TRY(hipMemcpy(host, src[which], sizeof(float) * n_floats, hipMemcpyDeviceToHost));

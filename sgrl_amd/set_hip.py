@@ -59,6 +59,11 @@ def fold_gram_weight(w):
     return torch.cat([f, f.new_zeros(out_f, 544 - f.shape[1])], dim=1).contiguous()
 
 
+def perm32(t):
+    """rows q * 32 + c -> c * 32 + q of a [1024, ...] tensor (include/sgrl_set.h PERM32)"""
+    return t.reshape(32, 32, *t.shape[1:]).transpose(0, 1).reshape(t.shape).contiguous()
+
+
 def pack_tensors(sd, prefix="actor.", critic=False):
     """[(tensor float32, ...)] in slot order (include/sgrl_set.h) from a state_dict-like mapping of torch tensors.
     critic=True packs a critic TransformerModel (scalar head: decoder_ng in the DECG / L1M_B slots, see sgrl_set.h)."""
@@ -79,7 +84,7 @@ def pack_tensors(sd, prefix="actor.", critic=False):
         out[20], out[22], out[23], out[24] = z, z, z, z
     else:
         out[19] = g("decoder_g.weight").reshape(-1)
-        out[20], out[21], out[22], out[23] = g("linear1_m.weight"), g("linear1_m.bias"), g("linear2_m.weight"), g("linear2_m.bias")
+        out[20], out[21], out[22], out[23] = g("linear1_m.weight"), g("linear1_m.bias"), perm32(g("linear2_m.weight")), perm32(g("linear2_m.bias"))
         out[24] = g("g_proj.weight")
     scaling = float(128) ** -0.5   # (2 * head_dim)^-0.5, reference subequivariant_attentions.py:88
     for l in range(LAYERS):
@@ -102,14 +107,14 @@ def pack_tensors(sd, prefix="actor.", critic=False):
             wng, g(a + "ng_out.bias"), wgo,
             g(p + "g_proj2.weight"), g(p + "g_proj3.weight"), fold_gram_weight(g(p + "linear_g1.weight")), g(p + "linear_g1.bias"),
             g(p + "linear_g2.weight"), g(p + "linear_g2.bias"), g(p + "linear3.weight"), g(p + "linear3.bias"),
-            g(p + "linear4.weight"), g(p + "linear4.bias"), g(p + "linear5.weight"), g(p + "linear1.weight"),
+            perm32(g(p + "linear4.weight")), perm32(g(p + "linear4.bias")), g(p + "linear5.weight"), g(p + "linear1.weight"),
             g(p + "linear1.bias"), g(p + "linear2.weight"), g(p + "linear2.bias"), g(p + "norm1.weight"),
             g(p + "norm1.bias"), g(p + "norm2.weight"), g(p + "norm2.bias"), gdcol]
     return out
 
 
 NSITES = 7
-PACK_COPY, PACK_PADCOL, PACK_FOLD, PACK_STACK, PACK_MATMUL, PACK_SUBMAT = 0, 1, 2, 3, 4, 5
+PACK_COPY, PACK_PADCOL, PACK_FOLD, PACK_STACK, PACK_MATMUL, PACK_SUBMAT, PACK_PERM32 = 0, 1, 2, 3, 4, 5, 6
 # struct sgrl_pack_seg (include/sgrl_set.h)
 SEG_DTYPE = np.dtype([("dst", "<i8"), ("src0", "<u8"), ("src1", "<u8"), ("n", "<i4"), ("kind", "<i4"), ("a", "<i4"),
                       ("b", "<i4"), ("scale", "<f4"), ("lda", "<i4"), ("ldb", "<i4"), ("reserved", "<i4")])
@@ -160,6 +165,12 @@ def plan_segments(net, critic=False):
     def zero():
         emit(PACK_COPY, anchor, 64, a=0)
 
+    def perm32(name):
+        """[1024, K] (or [1024]) with the rows regrouped c * 32 + q <- q * 32 + c (include/sgrl_set.h PERM32)"""
+        t = p(name)
+        assert t.shape[0] == 1024
+        emit(PACK_PERM32, t, t.numel(), a=t.numel() // 1024)
+
     def slot(i, fn, *args, **kw):
         align()
         offs[i] = pos[0]
@@ -181,7 +192,7 @@ def plan_segments(net, critic=False):
     else:
         slot(19, copy, "decoder_g.weight")
         slot(20, copy, "linear1_m.weight"); slot(21, copy, "linear1_m.bias")
-        slot(22, copy, "linear2_m.weight"); slot(23, copy, "linear2_m.bias")
+        slot(22, perm32, "linear2_m.weight"); slot(23, perm32, "linear2_m.bias")
         slot(24, copy, "g_proj.weight")
     scaling = float(128) ** -0.5   # (2 * head_dim)^-0.5, reference subequivariant_attentions.py:88
     for l in range(LAYERS):
@@ -222,7 +233,7 @@ def plan_segments(net, critic=False):
         slot(b0 + 13, fold, lp + "linear_g1.weight"); slot(b0 + 14, copy, lp + "linear_g1.bias")
         slot(b0 + 15, copy, lp + "linear_g2.weight"); slot(b0 + 16, copy, lp + "linear_g2.bias")
         slot(b0 + 17, copy, lp + "linear3.weight"); slot(b0 + 18, copy, lp + "linear3.bias")
-        slot(b0 + 19, copy, lp + "linear4.weight"); slot(b0 + 20, copy, lp + "linear4.bias")
+        slot(b0 + 19, perm32, lp + "linear4.weight"); slot(b0 + 20, perm32, lp + "linear4.bias")
         slot(b0 + 21, copy, lp + "linear5.weight")
         slot(b0 + 22, copy, lp + "linear1.weight"); slot(b0 + 23, copy, lp + "linear1.bias")
         slot(b0 + 24, copy, lp + "linear2.weight"); slot(b0 + 25, copy, lp + "linear2.bias")

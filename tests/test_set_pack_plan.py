@@ -40,6 +40,9 @@ def _run_plan(segs, srcs, total):
             A = np.stack([s0[r * lda:r * lda + a] for r in range(rows)])
             Bm = np.stack([s1[k * ldb:k * ldb + b] for k in range(a)])
             v = (A.astype(np.float64) @ Bm.astype(np.float64) * float(sg["scale"])).astype(np.float32)
+        elif kind == set_hip.PACK_PERM32:
+            k = n // 1024
+            v = s0[:n].reshape(32, 32, k).transpose(1, 0, 2).reshape(-1)
         elif kind == set_hip.PACK_SUBMAT:
             rows = n // b
             v = np.stack([s0[r * lda:r * lda + b] for r in range(rows)])

@@ -32,11 +32,18 @@ static float run2(const GemmArgs& a, int reps) {
   const int tiles = ((a.M + Cfg::kBM - 1) / Cfg::kBM) * ((a.N + Cfg::kBN - 1) / Cfg::kBN);
   return timeit(k_gemm2<F, WM, WN, TM, TN, BKT, PF>, tiles, Cfg::kThreads, Cfg::kLdsBytes, a, reps);
 }
-template <int F, int WM, int WN, int TM, int TN, int BKT = 32, int PF = 1, bool PLA = false, bool PLW = false, bool LATE = false>
+template <int F, int WM, int WN, int TM, int TN, int BKT = 32, int PF = 1, bool PLA = false, bool PLW = false, bool LATE = false, int ABL = 0>
 static float run3(const GemmArgs& a, int reps) {
   using Cfg = TileCfg3<WM, WN, TM, TN, BKT>;
   const int tiles = ((a.M + Cfg::kBM - 1) / Cfg::kBM) * ((a.N + Cfg::kBN - 1) / Cfg::kBN);
-  return timeit(k_gemm3<F, WM, WN, TM, TN, BKT, PF, PLA, PLW, LATE>, tiles, Cfg::kThreads, Cfg::kLdsBytes, a, reps);
+  return timeit(k_gemm3<F, WM, WN, TM, TN, BKT, PF, PLA, PLW, LATE, ABL>, tiles, Cfg::kThreads, Cfg::kLdsBytes, a, reps);
+}
+
+template <int F, int BKT, int PF>
+static float run4(const GemmArgs& a, int reps) {
+  using Cfg = TileCfg3<4, 2, 1, 2, BKT>;
+  const int tiles = ((a.M + 127) / 128) * ((a.N + 127) / 128);
+  return timeit(k_gemm4<F, BKT, PF>, tiles, 1024, Cfg::kLdsBytes, a, reps);
 }
 
 int main(int argc, char** argv) {
@@ -81,6 +88,32 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (argc > 2 && argv[2][0] == 'e') {   // linear4 with the equivariant epilogue vs the plain store
+    const Shape& sh = shapes[1];
+    float *zq, *tout;
+    hipMalloc(&zq, (size_t)sh.M * 96 * 4); hipMalloc(&tout, (size_t)sh.M * 96 * 4);
+    hipMemcpy(zq, A, (size_t)sh.M * 96 * 4, hipMemcpyDeviceToDevice);
+    GemmArgs a{A, sh.K, W, sh.K, bias, C, sh.N, sh.M, sh.N, sh.K, sh.flags, rd, C2, sh.N};
+    a.zq = zq; a.tout = tout;
+    const float t0 = run3<EPI_ROWDIV, 4, 2, 1, 2, 16, 2>(a, 20);
+    const float t1 = run3<EPI_ROWDIV | EPI_EQUIV, 4, 2, 1, 2, 16, 2>(a, 20);
+    const float t2 = run3<EPI_ROWDIV | EPI_EQUIV, 4, 2, 1, 2, 16, 2, false, false, false, 1>(a, 20);
+    printf("l4 plain store %.1f us | equivariant epilogue %.1f us | same without staging in the loop %.1f us\n", t0 * 1e3, t1 * 1e3, t2 * 1e3);
+    return 0;
+  }
+  if (argc > 2 && argv[2][0] == 'a') {   // ablations of the 8-wave split kernel on the linear4 / lg1 shapes
+    for (int si : {1, 2}) {
+      const Shape& sh = shapes[si];
+      GemmArgs a{A, sh.K, W, sh.K, bias, C, sh.N, sh.M, sh.N, sh.K, sh.flags, rd, C2, sh.N};
+      const float t0 = run3<0, 4, 2, 1, 2, 16, 2>(a, 20);
+      const float t1 = run3<0, 4, 2, 1, 2, 16, 2, false, false, false, 1>(a, 20);
+      const float t2 = run3<0, 4, 2, 1, 2, 16, 2, false, false, false, 2>(a, 20);
+      const float t3 = run3<0, 4, 2, 1, 2, 16, 2, false, false, false, 3>(a, 20);
+      printf("%s full %.1f us | MFMA + operand reads + barrier only %.1f | staging only (load, split, LDS store, barrier) %.1f | full without split arithmetic %.1f\n",
+             sh.name, t0 * 1e3, t1 * 1e3, t2 * 1e3, t3 * 1e3);
+    }
+    return 0;
+  }
   if (argc > 2) {   // profiling mode: one configuration on the linear4 shape, a handful of launches
     const Shape& sh = shapes[1];
     GemmArgs a{A, sh.K, W, sh.K, bias, C, sh.N, sh.M, sh.N, sh.K, sh.flags, rd, C2, sh.N};
@@ -119,17 +152,17 @@ int main(int argc, char** argv) {
     float m[8];
     double e[8];
 #define RUNALL(F)                                                                                            \
-    m[0] = run3<F, 4, 2, 1, 2, 16, 2>(a, reps); e[0] = err(); m[1] = run3<F, 4, 2, 1, 2, 16, 2, false, false, true>(a, reps); e[1] = err();  \
-    m[2] = run3<F, 4, 2, 1, 2, 32, 2, false, false, true>(a, reps); e[2] = err(); m[3] = run3<F, 2, 2, 2, 2, 16, 2, false, false, true>(a, reps); e[3] = err();  \
-    m[4] = run3<F, 4, 4, 1, 1, 16, 2, false, false, true>(a, reps); e[4] = err(); m[5] = run3<F, 4, 2, 2, 2, 16, 2, false, false, true>(a, reps); e[5] = err();  \
-    m[6] = run3<F, 4, 2, 1, 2, 16, 1, false, false, true>(a, reps); e[6] = err(); m[7] = run3<F, 2, 4, 2, 1, 16, 2, false, false, true>(a, reps); e[7] = err()
+    m[0] = run3<F, 4, 2, 1, 2, 16, 2>(a, reps); e[0] = err(); m[1] = run4<F, 16, 3>(a, reps); e[1] = err();  \
+    m[2] = run4<F, 16, 2>(a, reps); e[2] = err(); m[3] = run4<F, 16, 4>(a, reps); e[3] = err();  \
+    m[4] = run4<F, 32, 2>(a, reps); e[4] = err(); m[5] = run4<F, 32, 3>(a, reps); e[5] = err();  \
+    m[6] = run4<F, 16, 1>(a, reps); e[6] = err(); m[7] = run4<F, 32, 1>(a, reps); e[7] = err()
     switch (sh.flags) {
       case 0: RUNALL(0); break;
       case EPI_RELU: RUNALL(EPI_RELU); break;
       case EPI_ROWDIV: RUNALL(EPI_ROWDIV); break;
       case EPI_ACC2: RUNALL(EPI_ACC2); break;
     }
-    const char* nm[8] = {"8w(1x2)bk16pf2", "same LATE", "LATE bk32", "LATE 4w(2x2)", "LATE 16w", "LATE 256x128/8w", "LATE pf1", "LATE 8w(2x1)"};
+    const char* nm[8] = {"x6 8w bk16pf2", "ws bk16pf3", "ws bk16pf2", "ws bk16pf4", "ws bk32pf2", "ws bk32pf3", "ws bk16pf1", "ws bk32pf1"};
     for (int i = 0; i < 8; i++) printf(" | %s %6.1f us %5.1f TF err %.1e", nm[i], m[i] * 1e3, gf / (m[i] * 1e-3) / 1e12, e[i]);
     printf("\n");
   }
