@@ -81,9 +81,11 @@ class Agent(nn.Module):
     def device(self):
         return next(self.actor.parameters()).device
 
-    def update(self, data_batch, it, noise=None):
-        """One TD3 step on a batch of ONE morphology (reference agent.py:117-183).  `noise` (tests only) replaces the
-        N(0, policy_noise) draw of agent.py:128 so that a run can be compared with the reference number for number."""
+    def update(self, data_batch, it, noise=None, lazy_stats=False):
+        """One TD3 step on a batch of ONE morphology (reference agent.py:117-183).  `noise` replaces the N(0, policy_noise)
+        draw of agent.py:128 (tests: so that a run can be compared with the reference number for number; graph capture: a
+        static buffer refilled before every replay).  lazy_stats: keep the two reward statistics as device tensors instead
+        of `.item()` floats (no host sync -- required inside a hipGraph capture)."""
         args = self.args
         obs_batch, action_batch = data_batch["obs"], data_batch["action"]
         next_obs_batch, reward_batch, done_batch = data_batch["next_obs"], data_batch["reward"], data_batch["done"]
@@ -103,8 +105,9 @@ class Agent(nn.Module):
         if args.grad_clipping_value > 0:
             torch.nn.utils.clip_grad_norm_(self.critic.parameters(), args.grad_clipping_value)
         self.critic_optimizer.step()
-        loss_dict = {"loss/critic_loss": critic_loss, "misc/train_reward_mean": torch.mean(reward_batch).item(),
-                     "misc/train_reward_var": torch.var(reward_batch).item()}
+        rmean, rvar = torch.mean(reward_batch), torch.var(reward_batch)
+        loss_dict = {"loss/critic_loss": critic_loss, "misc/train_reward_mean": rmean if lazy_stats else rmean.item(),
+                     "misc/train_reward_var": rvar if lazy_stats else rvar.item()}
         if it % args.policy_freq == 0:       # delayed policy update
             actor_loss = -self.critic.Q1(obs_batch, self.actor(obs_batch)).mean()
             self.actor_optimizer.zero_grad()
@@ -141,3 +144,76 @@ class Agent(nn.Module):
     def models2train(self):
         for m in (self.actor, self.actor_target, self.critic, self.critic_target):
             m.train()
+
+
+class GraphedUpdates(object):
+    """`Agent.update` captured into hipGraphs (MI355X: the update is ~3 400 small launches -- PyTorch autograd through three
+    SET networks at batch 100 plus the HIP target kernels -- and launch-bound when issued eagerly: 50 ms; a replay is
+    GPU-bound: 32 ms).  One graph per (morphology, with / without the delayed actor step); the batch is copied into static
+    tensors and the target-policy noise redrawn into a static tensor before each replay, so the replayed arithmetic is
+    the eager update's.  Everything reachable from `Agent.update` is capturable: the SET kernels are launched on the
+    capturing stream (their side-stream fork / join becomes part of the graph), parameters are read live, Adam runs with
+    `capturable=True`, the reward statistics stay on the device.
+
+    Capture rules honoured here: every (morphology, batch size) is run eagerly first (so the SET handles have cached the
+    batch structure and grown their workspace to its final size before any pointer is baked into a graph)."""
+
+    def __init__(self, agent, batch_size):
+        self.agent, self.B = agent, int(batch_size)
+        dev = agent.device
+        if dev.type != "cuda":
+            raise RuntimeError("GraphedUpdates needs the agent on the GPU")
+        for opt in (agent.actor_optimizer, agent.critic_optimizer):
+            if opt.state:
+                raise RuntimeError("switch to graphed updates before the first optimizer step (Adam's step counters must be device tensors)")
+            for g in opt.param_groups:
+                g["capturable"] = True
+        self.slots = {}            # key -> dict(static tensors, graphs)
+        self.warmed = set()
+
+    def _slot(self, key, graph, L):
+        sl = self.slots.get(key)
+        if sl is None:
+            dev, B = self.agent.device, self.B
+            z = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)
+            sl = {"graph": graph, "batch": {"obs": z(B, 41 * L), "action": z(B, 3 * L), "next_obs": z(B, 41 * L), "reward": z(B, 1),
+                                            "done": z(B, 1)}, "noise": z(B, 3 * L), "graphs": {}, "out": {}}
+            self.slots[key] = sl
+        return sl
+
+    def _load(self, sl, data_batch):
+        for k, t in sl["batch"].items():
+            t.copy_(data_batch[k].reshape(t.shape))
+        sl["noise"].normal_(0, self.agent.args.policy_noise)
+
+    def warm(self, key, graph, L, data_batch, iters=3):
+        """Eager updates on a side stream (PyTorch's capture protocol); counts as real updates."""
+        sl = self._slot(key, graph, L)
+        self.agent.change_morphology(graph)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for it in range(iters):
+                self._load(sl, data_batch)
+                self.agent.update(sl["batch"], it, noise=sl["noise"], lazy_stats=True)
+        torch.cuda.current_stream().wait_stream(s)
+        self.warmed.add(key)
+
+    def update(self, key, graph, L, data_batch, it):
+        """Same contract as Agent.update(data_batch, it) for the morphology `graph` (dict) identified by `key`."""
+        if data_batch["obs"].shape[0] != self.B:
+            self.agent.change_morphology(graph)         # short batch (buffer not yet filled): eager
+            return self.agent.update(data_batch, it)
+        sl = self._slot(key, graph, L)
+        if key not in self.warmed:
+            raise RuntimeError("warm(%r, ...) every morphology before the first graphed update" % (key,))
+        flag = 0 if it % self.agent.args.policy_freq == 0 else 1
+        self._load(sl, data_batch)
+        if flag not in sl["graphs"]:
+            self.agent.change_morphology(graph)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                sl["out"][flag] = self.agent.update(sl["batch"], flag, noise=sl["noise"], lazy_stats=True)
+            sl["graphs"][flag] = g           # capturing records the work without running it
+        sl["graphs"][flag].replay()
+        return sl["out"][flag]

@@ -23,7 +23,10 @@ from .td3 import Agent, default_train_args
 
 class DeviceTrainer(object):
     def __init__(self, env_names, envs_per_morph, args=None, seed=0, device="cuda:0", max_buffer_size=1000000,
-                 batch_size=None, dst=0, **env_kw):
+                 batch_size=None, dst=0, graph_updates=False, tune_gemms=False, **env_kw):
+        """graph_updates: replay the TD3 update from hipGraphs (td3.GraphedUpdates); tune_gemms: let PyTorch's TunableOp pick
+        the rocBLAS / hipBLASLt algorithm per GEMM shape on first use (the defaults choose 256 x 256 tiles for the 700-row
+        weight-gradient GEMMs of a batch-100 update: 50 -> 38 ms per update)."""
         import torch.distributed as dist
         self.dist = dist
         self.rank = dist.get_rank() if dist.is_initialized() else 0
@@ -33,6 +36,8 @@ class DeviceTrainer(object):
         self.env_names = list(env_names)
         torch.manual_seed(seed)               # same initial weights on every rank
         self.agent = Agent(self.args, device=device)
+        if tune_gemms:
+            torch.cuda.tunable.enable(True)
         self.ro = Rollout(self.env_names, envs_per_morph, policy=self.agent.actor, seed=seed, device=device, rank=self.rank,
                           max_episode_steps=self.args.max_episode_steps, **env_kw)
         env = self.ro.env
@@ -53,6 +58,10 @@ class DeviceTrainer(object):
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(int(seed) * 7919 + 13)
         self.last_losses = {}
+        self.graphed = None
+        if graph_updates and self.is_learner:
+            from .td3 import GraphedUpdates
+            self.graphed = GraphedUpdates(self.agent, self.batch_size)
         self.begin_round()
 
     # ---- collection ----------------------------------------------------------------------------------
@@ -94,11 +103,19 @@ class DeviceTrainer(object):
             per_morph_iter = min(per_morph_iter, int(max_iters))
         if self.is_learner:
             self.agent.models2train()
+            if self.graphed is not None:     # every morphology runs eagerly once before any graph bakes a pointer
+                for k in range(len(self.env_names)):
+                    if k not in self.graphed.warmed and self.buffers[k].max_sample_size >= self.batch_size:
+                        self.graphed.warm(k, self.graph_dicts[k], self.ro.env.num_limbs[k],
+                                          self.buffers[k].sample(self.batch_size, generator=self.gen), iters=2)
             for k, name in enumerate(self.env_names):
                 self.agent.change_morphology(self.graph_dicts[k])
                 for it in range(per_morph_iter):
                     batch = self.buffers[k].sample(self.batch_size, generator=self.gen)
-                    self.last_losses[name] = self.agent.update(batch, it)
+                    if self.graphed is not None and k in self.graphed.warmed:
+                        self.last_losses[name] = self.graphed.update(k, self.graph_dicts[k], self.ro.env.num_limbs[k], batch, it)
+                    else:
+                        self.last_losses[name] = self.agent.update(batch, it)
                     self.tot_env_steps += 1                    # the reference counts updates too (trainer.py:250)
             self.agent.models2eval()
         self.broadcast_actor()

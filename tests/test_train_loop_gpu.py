@@ -131,3 +131,57 @@ def test_training_round_updates_the_policy_and_the_rollout_follows():
     d_tg = sum(float((p - q).abs().sum()) for p, q in zip(tr.agent.actor_target.parameters(), before))
     assert 0 < d_tg < d_on
     assert tr.ro.env.row_overflow_envs() == 0
+
+
+def test_graphed_updates_equal_eager_updates():
+    """td3.GraphedUpdates: the update replayed from hipGraphs (HIP target kernels + autograd + Adam captured together) moves
+    the parameters like the eager update from the same start, on two morphologies, with and without the actor step."""
+    import copy
+    import torch
+    from oracle.formula import synth_obs
+    from sgrl_amd import graph as G, mjcf
+    from sgrl_amd.td3 import Agent, GraphedUpdates, default_train_args
+    args = default_train_args(batch_size=12)
+    torch.manual_seed(2)
+    eager = Agent(args, device="cuda:0")
+    graphed = Agent(args, device="cuda:0")
+    graphed.load_state_dict(copy.deepcopy(eager.state_dict()))
+    gu = GraphedUpdates(graphed, 12)
+    for opt in (eager.actor_optimizer, eager.critic_optimizer):
+        for g in opt.param_groups:
+            g["capturable"] = True            # same Adam arithmetic on both sides
+    eager.models2train(); graphed.models2train()
+    morphs = []
+    for name in ("3d_walker_5_foot", "3d_hopper_3_shin"):
+        m = mjcf.load_asset(name)
+        gd = G.getGraphDict(m.parents, ["pre", "inlcrs", "postlcrs"], [], device=torch.device("cuda:0"))
+        L = m.num_limbs
+        rng = np.random.RandomState(L)
+        batch = {"obs": torch.from_numpy(synth_obs(L, 12, 5).astype(np.float32)).cuda(),
+                 "next_obs": torch.from_numpy(synth_obs(L, 12, 6).astype(np.float32)).cuda(),
+                 "action": torch.from_numpy(rng.uniform(-1, 1, size=(12, 3 * L)).astype(np.float32)).cuda(),
+                 "reward": torch.from_numpy(rng.normal(1, 0.5, size=(12, 1)).astype(np.float32)).cuda(),
+                 "done": torch.zeros(12, 1).cuda()}
+        morphs.append((name, gd, L, batch))
+    start = [p.detach().clone() for p in eager.critic.parameters()]
+    # identical noise on both sides: policy_noise = 0 makes the draw irrelevant
+    args.policy_noise = 0.0
+    for key, (name, gd, L, batch) in enumerate(morphs):          # warm-up = 2 real updates per morphology, mirrored eagerly
+        gu.warm(key, gd, L, batch, iters=2)
+        eager.change_morphology(gd)
+        for it in range(2):
+            eager.update(batch, it, noise=torch.zeros(12, 3 * L, device="cuda"))
+    for it in range(4):                                            # capture at first use, then replays
+        for key, (name, gd, L, batch) in enumerate(morphs):
+            out = gu.update(key, gd, L, batch, it)
+            eager.change_morphology(gd)
+            ref = eager.update(batch, it, noise=torch.zeros(12, 3 * L, device="cuda"))
+            assert abs(float(out["loss/critic_loss"]) - float(ref["loss/critic_loss"])) < 2e-3 * abs(float(ref["loss/critic_loss"])) + 1e-5, (it, name)
+            assert ("loss/actor_loss" in out) == ("loss/actor_loss" in ref)
+    assert set(gu.slots[0]["graphs"]) == {0, 1}
+    for nm in ("actor", "critic", "actor_target", "critic_target"):
+        for p, q, s0 in zip(getattr(graphed, nm).parameters(), getattr(eager, nm).parameters(),
+                            start if nm == "critic" else getattr(eager, nm).parameters()):
+            assert float((p - q).abs().max()) < 2e-4 * (1 + float(q.abs().max())), nm
+    moved = max(float((p - s0).abs().max()) for p, s0 in zip(graphed.critic.parameters(), start))
+    assert moved > 1e-4

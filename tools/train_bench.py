@@ -15,7 +15,9 @@ HELD_OUT = {"3d_walker_3_left_knee_right_knee", "3d_walker_6_right_foot", "3d_hu
 names = sorted(n for n in mjcf.list_assets() if n not in HELD_OUT)
 per = int(sys.argv[1]) if len(sys.argv) > 1 else 8192 // len(names)
 args = default_train_args()
-tr = DeviceTrainer(names, per, args=args, seed=1, device="cuda:0", max_buffer_size=200000)
+GRAPH = os.environ.get("SGRL_GRAPH_UPDATES", "1") != "0"
+TUNE = os.environ.get("SGRL_TUNE_GEMMS", "1") != "0"
+tr = DeviceTrainer(names, per, args=args, seed=1, device="cuda:0", max_buffer_size=200000, graph_updates=GRAPH, tune_gemms=TUNE)
 n = tr.ro.env.num_envs
 tr.warmup(60)                      # fills the buffers (random actions), several rounds
 torch.cuda.synchronize()
@@ -25,21 +27,17 @@ for _ in range(K):
         tr.begin_round()
 torch.cuda.synchronize()
 t_collect = (time.time() - t0) / K
-# updates: 10 per morphology, as update_after_round would schedule them
-tr.agent.models2train()
+# updates through the trainer's own schedule: a first pass warms / tunes / captures, the second is timed
+tr.update_after_round(max_iters=4)
 torch.cuda.synchronize()
-t0 = time.time(); U = 0
-for k, name in enumerate(names):
-    tr.agent.change_morphology(tr.graph_dicts[k])
-    for it in range(10):
-        tr.agent.update(tr.buffers[k].sample(args.batch_size, generator=tr.gen), it)
-        U += 1
+t0 = time.time()
+iters = tr.update_after_round(max_iters=10)
 torch.cuda.synchronize()
+U = 10 * len(names)
 t_update = (time.time() - t0) / U
-tr.agent.models2eval()
 out = {"morphologies": len(names), "envs": n, "ms_per_collection_step": round(t_collect * 1e3, 3),
        "collection_env_steps_per_s": round(n / t_collect, 1), "ms_per_td3_update": round(t_update * 1e3, 3),
-       "td3_updates_per_s": round(1.0 / t_update, 2), "batch_size": args.batch_size,
+       "td3_updates_per_s": round(1.0 / t_update, 2), "batch_size": args.batch_size, "hipgraph_updates": GRAPH, "tunableop": TUNE,
        "row_overflow_envs": tr.ro.env.row_overflow_envs(), "buffer_rows": [b.max_sample_size for b in tr.buffers]}
 print(json.dumps(out))
 os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
