@@ -135,13 +135,13 @@ def _cpu_worker(job):
     return steps
 
 
-# multiply-accumulates the SET forward EXECUTES per limb node: after the Gram-triangle folding (K = 544 instead of 1024 on the
+# multiply-accumulates the SET forward EXECUTES per limb node: after the Gram-triangle folding (K = 576 instead of 1024 on the
 # seven Gram-fed layers), with the projections as the zero-padded stacked GEMM operands the kernels really run, and after
 # folding ng_out / g_out into the value projections (those two GEMMs per layer no longer exist)
 def set_executed_flops_per_node():
-    layer = (3 * 128 * 32) + 544 * 256 + 256 * 128 + 256 * 768 + 3 * 128 * 256                                     # attention
-    layer += (3 * 128 * 64) + 544 * 256 + 256 * 128 + 2 * (256 * 256) + 256 * 128 + 256 * 1024 + 3 * 32 * 32 + 3 * 32 * 128
-    head = (3 * 144 * 64) + 544 * 128 + 128 * 128 + 160 * 128 + 128 * 128 + 256 * 256 + 256 * 1024 + 3 * 32 * 32
+    layer = (3 * 128 * 32) + 576 * 256 + 256 * 128 + 256 * 768 + 3 * 128 * 256                                     # attention
+    layer += (3 * 128 * 64) + 576 * 256 + 256 * 128 + 2 * (256 * 256) + 256 * 128 + 256 * 1024 + 3 * 32 * 32 + 3 * 32 * 128
+    head = (3 * 144 * 64) + 576 * 128 + 128 * 128 + 160 * 128 + 128 * 128 + 256 * 256 + 256 * 1024 + 3 * 32 * 32
     return 2 * (3 * layer + head)
 
 

@@ -24,8 +24,10 @@
  *     (the gravity / direction columns).  The attention kernel then produces the layer's two outputs directly; the slots
  *     NGOUT_W and GOUT_W are kept for reference but no longer read by the kernels.
  *     L1NG_W = linear1_ng.weight padded with 15 zero columns -> [128, 160]
- *     A_LG1_W, F_LG1_W, L1G_W (the layers fed by the symmetric 32x32 Gram matrix) are folded onto the packed lower
- *              triangle: W'[n][a(a+1)/2+b] = W[n][32a+b] + W[n][32b+a] (b < a), W[n][33a] (b = a); 528 -> 544 columns
+ *     A_LG1_W, F_LG1_W, L1G_W (the layers fed by the symmetric 32x32 Gram matrix G = Z'Z) are folded onto the BLOCKED lower
+ *              triangle the GEMM generates its operand in (the Gram matrix itself is never stored): the 36 4x4 blocks (A, B),
+ *              B <= A, one per 16-wide k-tile: column k = 16 (A (A + 1) / 2 + B) + 4 i + j <-> a = 4 A + i, b = 4 B + j;
+ *              W'[n][k] = W[n][32a+b] + W[n][32b+a] (b < a), W[n][33a] (b = a), 0 (b > a, diagonal blocks only); 576 columns
  */
 #ifndef SGRL_SET_H
 #define SGRL_SET_H
@@ -72,7 +74,7 @@ int sgrl_set_weights(sgrl_set* s, const float* w, const int64_t* offsets, int n_
  * traffic).  A segment describes one run of the flat buffer:
  *   COPY   dst[i] = i < a ? src0[i] * scale : 0                        (plain tensors, QKV stacking, zero row padding)
  *   PADCOL src0 [rows, a] -> dst [rows, b], zero columns appended      (L1NG_W)
- *   FOLD   src0 [rows, 1024] -> dst [rows, 544] Gram-triangle folding  (A_LG1_W, F_LG1_W, L1G_W; see above)
+ *   FOLD   src0 [rows, 1024] -> dst [rows, 576] Gram-triangle folding  (A_LG1_W, F_LG1_W, L1G_W; see above)
  *   STACK  dst [64, b]: rows 0..29 = src0 [30, a], rows 32..61 = src1 [30, a] or zero, columns a..b-1 zero
  *          (the two 30-row projections of a proj+Gram site as ONE zero-padded GEMM operand)
  *   MATMUL dst [n / b, b] = src0 [n / b, a] (row stride lda) . src1 [a, b] (row stride ldb), times scale   (weight folds)
@@ -132,7 +134,7 @@ int64_t sgrl_set_workspace_bytes(const sgrl_set* s);
 int sgrl_set_time_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_ld, float max_action,
                           int reps, void* stream, float* ms_out);
 /* Debug/parity: copy an intermediate buffer of the LAST forward to the host.  which: 0 g[N,3,128], 1 cat[N,256]
- * (inv | ng), 2 gram[N,544] (packed lower triangle), 3 fn[N], 4 qkv[N,768] (q | k | v' folded), 5 / 6 unused, 7 T[N,3,32] (z . mat),
+ * (inv | ng), 2 zc[N,3,32] (the projected vectors Z whose Gram matrix Z'Z the lg1 GEMMs consume), 3 fn[N], 4 qkv[N,768] (q | k | v' folded), 5 / 6 unused, 7 T[N,3,32] (z . mat),
  * 8 g1[N,3,128] (attention's vector output), 9 delta[N,128] (attention's / FFN's scalar output before the residual norm),
  * 10 outng[N,160] (input features | final-norm ng | zero padding). */
 int sgrl_set_peek(sgrl_set* s, int which, float* host, int64_t n_floats);

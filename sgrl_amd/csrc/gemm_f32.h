@@ -13,7 +13,10 @@ namespace sgrl_gemm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { EPI_RELU = 1, EPI_ROWDIV = 2, EPI_ACC2 = 4, EPI_EQUIV = 8 };
+// EPI_ZSPLIT (k_gemm2, the stacked 3-vector projections): output column n < 30 goes to C[m][n], column 32 <= n < 62 to
+// C2[m][n - 32], both with row stride 32 (columns 30 / 31 of those rows hold the gravity / direction pair, written once per
+// forward by k_embed); the zero-padding columns 30, 31, 62, 63 of the stacked operand are not stored
+enum { EPI_RELU = 1, EPI_ROWDIV = 2, EPI_ACC2 = 4, EPI_EQUIV = 8, EPI_ZSPLIT = 16 };
 
 struct GemmArgs {
   const float* A; int lda;
@@ -32,6 +35,7 @@ struct GemmArgs {
   // 32-vectors per row) and stores only tout[m][s][c] = sum_a zq[m][s][a] * mat[m][a][c]  ([M, 3, 32] floats)
   const float* zq = nullptr;
   float* tout = nullptr;
+  float* rowdiv_out = nullptr;   // GRAM: receives ||Z'Z||_F + 1 per row (from the blocks of the first column tile)
 };
 
 // BKT = k extent of an LDS tile (16 or 32); row stride BKT + 4 floats (conflict-free ds_read_b128, see above).
@@ -181,6 +185,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
         float v = acc[ti][tj][e] + bvv;
         if (FLAGS & EPI_RELU) v = fmaxf(v, 0.f);
         if (FLAGS & EPI_ROWDIV) v = v * rdiv[e];
+        if (FLAGS & EPI_ZSPLIT) {
+          if (n < 30) a.C[(size_t)m * 32 + n] = v;
+          else if (n >= 32 && n < 62) a.C2[(size_t)m * 32 + (n - 32)] = v;
+          continue;
+        }
         a.C[(size_t)m * a.ldc + n] = v;
         if (FLAGS & EPI_ACC2) a.C2[(size_t)m * a.ldc2 + n] = old2[e] + v;
       }
@@ -229,7 +238,14 @@ struct TileCfg3 {
 // while the wave does the VALU / LDS-write work) instead of before
 // ABL (diagnostics, tools/gemm_lab.hip): 1 = no staging in the loop (LDS keeps tile 0: MFMA + operand reads + barrier only),
 // 2 = staging only (no operand reads / MFMA), 3 = staging without the split arithmetic (raw bit copies)
-template <int FLAGS, int WM, int WN, int TM, int TN, int BKT = 32, int PF = 1, bool PLA = false, bool PLW = false, bool LATE = false, int ABL = 0>
+// GRAM: the A operand is GENERATED, not loaded: a.A points at Z [M][3][32] (three 32-vectors per row) and A[m][k] is the
+// entry G[a][b] = sum_s Z[m][s][a] Z[m][s][b] of the row's 32 x 32 Gram matrix Z'Z, with k running over the 36 blocks
+// (4 a-values x 4 b-values, block row >= block column) of its lower triangle -- one block per 16-wide k-tile, K = 576
+// (kGramK; the weight rows are folded onto the same order at pack time, entries above the diagonal inside the eight
+// diagonal blocks carry zero weight).  The [M, 576] Gram operand (and its [M, 1024] dense form) never exists in memory:
+// a staging thread reads 3 + 12 floats of its row's Z (L2-resident: 384 bytes per row) per k-tile and forms 4 entries.
+constexpr int kGramK = 576;
+template <int FLAGS, int WM, int WN, int TM, int TN, int BKT = 32, int PF = 1, bool PLA = false, bool PLW = false, bool LATE = false, int ABL = 0, bool GRAM = false>
 __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4))) void k_gemm3(GemmArgs a) {
   using Cfg = TileCfg3<WM, WN, TM, TN, BKT>;
   constexpr int T = Cfg::kThreads, BMT = Cfg::kBM, BNT = Cfg::kBN, RB = Cfg::kRowBytes;
@@ -238,6 +254,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
   static_assert(PF == 1 || PF == 2, "prefetch depth 1 or 2");
   constexpr int NPA = (BMT + RPP - 1) / RPP, NPW = (BNT + RPP - 1) / RPP;    // a pass may be partly idle (more threads than float4s)
   constexpr int KS = BKT / 16;                // MFMA k-steps per LDS tile
+  static_assert(!GRAM || (BKT == 16 && RPP == BMT && !PLA && !LATE), "the Gram operand needs one 16-wide k-tile per block pair and one staging pass");
   extern __shared__ float gemm_lds[];
   char* lds = reinterpret_cast<char*>(gemm_lds);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -261,6 +278,11 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
   // staging registers: an f32 operand travels as one float4 (16 B) per slot, a pre-split one as three uint2 (24 B)
   float4 ra[PF][NPA], rw[PF][NPW];
   uint2 pa[PF][PLA ? NPA : 1][3], pw[PF][PLW ? NPW : 1][3];
+  // GRAM: ONE staging slot for A (its Z values come from L2 and are fetched one k-tile ahead), independent of PF
+  float gza[3];                               // Z[m][s][4 A + kq]
+  float4 gzb[3];                              // Z[m][s][4 B .. 4 B + 3]
+  int ga = 0, gb = 0;                         // block pair (A, B) of the next k-tile to be loaded (tiles are loaded in order)
+
   const unsigned short* Ap = reinterpret_cast<const unsigned short*>(a.A);
   const unsigned short* Wp = reinterpret_cast<const unsigned short*>(a.W);
   // Rows beyond M / N are CLAMPED to the last valid row instead of predicated: the loop body stays free of branches (the
@@ -270,17 +292,28 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
 #pragma unroll
   for (int i = 0; i < NPA; i++) {
     const int m = min(m0 + min(r0 + RPP * i, BMT - 1), a.M - 1);
-    arow_g[i] = PLA ? reinterpret_cast<const float*>(Ap + (size_t)m * a.lda + 4 * kq) : a.A + (size_t)m * a.lda + 4 * kq;
+    arow_g[i] = GRAM ? a.A + (size_t)m * 96
+                     : (PLA ? reinterpret_cast<const float*>(Ap + (size_t)m * a.lda + 4 * kq) : a.A + (size_t)m * a.lda + 4 * kq);
   }
 #pragma unroll
   for (int i = 0; i < NPW; i++) {
     const int n = min(n0 + min(r0 + RPP * i, BNT - 1), a.N - 1);
     wrow_g[i] = PLW ? reinterpret_cast<const float*>(Wp + (size_t)n * a.ldw + 4 * kq) : a.W + (size_t)n * a.ldw + 4 * kq;
   }
+  auto gload_gram = [&]() {
+#pragma unroll
+    for (int sx = 0; sx < 3; sx++) gzb[sx] = *reinterpret_cast<const float4*>(arow_g[0] + 32 * sx + 4 * gb);
+    if (gb == 0) {                            // a new block row: this thread's a = 4 A + kq changes (uniform branch)
+#pragma unroll
+      for (int sx = 0; sx < 3; sx++) gza[sx] = arow_g[0][32 * sx + 4 * ga + kq];
+    }
+    if (++gb > ga) { ga++; gb = 0; }
+  };
   auto gload = [&](int slot, int k0) {
 #pragma unroll
     for (int i = 0; i < NPA; i++) {
-      if (PLA) {
+      if (GRAM) {
+      } else if (PLA) {
 #pragma unroll
         for (int pl = 0; pl < 3; pl++)
           pa[slot][PLA ? i : 0][pl] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(arow_g[i]) + pl * a.a_plane + k0);
@@ -324,7 +357,13 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
 #pragma unroll
     for (int i = 0; i < NPA; i++)
       if (r0 + RPP * i < BMT) {
-        if (PLA) put_planes(base, Cfg::kPlaneA, r0 + RPP * i, pa[slot][PLA ? i : 0]);
+        if (GRAM) {
+          const float za0 = gza[0], za1 = gza[1], za2 = gza[2];
+          const float4 b0 = gzb[0], b1 = gzb[1], b2 = gzb[2];
+          const float4 gv = make_float4(za0 * b0.x + za1 * b1.x + za2 * b2.x, za0 * b0.y + za1 * b1.y + za2 * b2.y,
+                                        za0 * b0.z + za1 * b1.z + za2 * b2.z, za0 * b0.w + za1 * b1.w + za2 * b2.w);
+          put(base, Cfg::kPlaneA, r0, gv);
+        } else if (PLA) put_planes(base, Cfg::kPlaneA, r0 + RPP * i, pa[slot][PLA ? i : 0]);
         else put(base, Cfg::kPlaneA, r0 + RPP * i, ra[slot][i]);
       }
 #pragma unroll
@@ -335,9 +374,35 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
       }
   };
   const int nk = a.K / BKT;
+  if (GRAM && a.rowdiv_out && tile_n == 0) {
+    // fn[m] = ||Z'Z||_F + 1 = ||Z Z'||_F + 1: six 32-term dot products of the row's three vectors, a quarter (eight columns)
+    // per staging thread of the row, folded over the four adjacent lanes; written by the first column tile only
+    float c[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const float4 x = *reinterpret_cast<const float4*>(arow_g[0] + 8 * kq + 4 * h);
+      const float4 y = *reinterpret_cast<const float4*>(arow_g[0] + 32 + 8 * kq + 4 * h);
+      const float4 z = *reinterpret_cast<const float4*>(arow_g[0] + 64 + 8 * kq + 4 * h);
+      c[0] += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+      c[1] += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+      c[2] += z.x * z.x + z.y * z.y + z.z * z.z + z.w * z.w;
+      c[3] += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+      c[4] += x.x * z.x + x.y * z.y + x.z * z.z + x.w * z.w;
+      c[5] += y.x * z.x + y.y * z.y + y.z * z.z + y.w * z.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {             // sum over the quad of lanes: DPP quad_perm [1,0,3,2] then [2,3,0,1]
+      c[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c[k]), 0xB1, 0xF, 0xF, true));
+      c[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c[k]), 0x4E, 0xF, 0xF, true));
+    }
+    if (kq == 0 && m0 + r0 < a.M)
+      a.rowdiv_out[m0 + r0] = sqrtf((c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + 2.f * (c[3] * c[3] + c[4] * c[4] + c[5] * c[5])) + 1.0f;
+  }
+  if (GRAM) gload_gram();
   gload(0, 0);
   sstore(0, 0);
   __syncthreads();
+  if (GRAM && nk > 1) gload_gram();
   if (nk > 1) gload(0, BKT);
   if (PF == 2 && nk > 2) gload(1, 2 * BKT);
   const int li = lane & 31, lh = lane >> 5;
@@ -347,6 +412,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
     const int st = kt & 1;
     if (!LATE && ABL != 1) {
       if (kt + 1 < nk) sstore(slot, st ^ 1);
+      if (GRAM && kt + 2 < nk) gload_gram();
       if (kt + 1 + PF < nk) gload(slot, (kt + 1 + PF) * BKT);
     }
     const char* base = lds + (ABL == 1 ? 0 : st) * Cfg::kStageBytes;

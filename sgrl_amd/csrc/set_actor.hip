@@ -7,7 +7,7 @@
 //
 // Node order: environments in batch order, limbs of one environment contiguous.  Buffers (float32, N = nodes):
 //   g    [N,3,128]  equivariant stream           cat  [N,256] = [invariants | ng]  (ng lives in cat[:,128:])
-//   gram [N,1024]   Z'Z                          fn   [N]      ||Z'Z||_F + 1
+//   zc   [N,3,32]   Z (Gram operand Z'Z is generated inside the GEMMs)   fn   [N]   ||Z'Z||_F + 1
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -34,11 +34,11 @@ int sfail(int code, const std::string& msg) { g_set_err = msg; return code; }
 
 constexpr int D = 128;
 constexpr int ZD = 32;
-// The 32x32 Gram matrix Z'Z is symmetric: only its lower triangle (528 values, padded to GK) is materialised and the
-// 1024-wide weight rows of the layers that consume it are folded accordingly at pack time (sgrl_amd/set_hip.py).
-constexpr int GTRI = ZD * (ZD + 1) / 2;   // 528
-constexpr int GK = 544;                    // GTRI padded to a multiple of the GEMM K tile
-constexpr int ZLD = 64;                    // row stride of the stacked projection output [Z (30) .. | Z2 (30) ..]
+// The 32x32 Gram matrix Z'Z is symmetric and is never materialised: the GEMMs that consume it generate their A operand
+// from Z on the fly (gemm_f32.h, GRAM), running over the 36 4x4 blocks of the lower triangle (GK = 576 k values, block
+// (A, B), B <= A, at k = 16 (A (A + 1) / 2 + B) + 4 (a - 4 A) + (b - 4 B)); the 1024-wide weight rows of those layers are
+// folded onto the same order at pack time (k_pack FOLD / sgrl_amd/set_hip.py fold_gram_weight).
+constexpr int GK = sgrl_gemm::kGramK;     // 576
 constexpr int OGLD = 144;                  // row stride of outg: 136 channels padded to the GEMM K tile
 
 // The f32 MFMA GEMM (C[M,N] = epi(A[M,K] . W[N,K]^T)) lives in gemm_f32.h.
@@ -46,6 +46,7 @@ using sgrl_gemm::EPI_ACC2;
 using sgrl_gemm::EPI_EQUIV;
 using sgrl_gemm::EPI_RELU;
 using sgrl_gemm::EPI_ROWDIV;
+using sgrl_gemm::EPI_ZSPLIT;
 using sgrl_gemm::GemmArgs;
 using sgrl_gemm::k_gemm2;
 
@@ -66,7 +67,7 @@ struct NodeTab {
 __global__ __launch_bounds__(128) void k_embed(const float* __restrict__ obs, int obs_ld, const float* __restrict__ action,
                                                int act_ld, int ngf, NodeTab nt, const float* Wge, const float* We,
                                                const float* be, const float* e0, const float* e1, const float* e2, float* g,
-                                               float* cat, float* outg, float* outng, float* gdir) {
+                                               float* cat, float* outg, float* outng, float* gdir, float* zc, float* z2) {
   // per-limb input row: 24 geometric values (8 three-vectors) | ngf non-geometric ones -- 17 from the observation and,
   // for the critic (ngf = 20), the limb's 3 action slots appended (reference SECritic.py:80-83)
   __shared__ float o[44];
@@ -91,7 +92,15 @@ __global__ __launch_bounds__(128) void k_embed(const float* __restrict__ obs, in
   if (c < 24) { const int s = c / 8, j = c % 8; outg[((size_t)n * 3 + s) * OGLD + j] = o[3 * j + s]; }
   if (c < ngf) outng[(size_t)n * 160 + c] = o[24 + c];
   if (c >= ngf && c < 32) outng[(size_t)n * 160 + 128 + c] = 0.f;  // cols 128 + ngf .. 159
-  if (c < 6) { const int s = c / 2, e = c % 2; gdir[((size_t)n * 3 + s) * 2 + e] = o[3 * (1 + e) + s]; }
+  // the gravity / direction pair of the node: for the attention kernel (gdir) and as columns 30 / 31 of the projected
+  // vectors zc / z2 (written here once per forward; the projection GEMMs fill columns 0..29 of those rows, EPI_ZSPLIT)
+  if (c < 6) {
+    const int s = c / 2, e = c % 2;
+    const float v = o[3 * (1 + e) + s];
+    gdir[((size_t)n * 3 + s) * 2 + e] = v;
+    zc[((size_t)n * 3 + s) * ZD + 30 + e] = v;
+    z2[((size_t)n * 3 + s) * ZD + 30 + e] = v;
+  }
 }
 
 // The two 30-row projections of a site stacked into one zero-padded GEMM operand out[64][Cpad]:
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(256) void k_pack(const sgrl_pack_seg* __restrict__ 
         if (c < sg.a) v = s0[(size_t)r * sg.a + c];
         break;
       }
-      case SGRL_PACK_FOLD: {    // [rows, 1024] acting on vec(G), G symmetric 32x32 -> [rows, 544] on its packed lower triangle
+      case SGRL_PACK_FOLD: {    // [rows, 1024] acting on vec(G), G symmetric 32x32 -> [rows, 576] on the blocked lower triangle
         const int r = i / GK, k = i % GK;
         const unsigned short t = tri[k];
         if (t != 0xFFFF) {
@@ -172,56 +181,6 @@ __global__ __launch_bounds__(256) void k_pack(const sgrl_pack_seg* __restrict__ 
     }
     w[sg.dst + i] = v;
   }
-}
-
-// gram: 8 nodes per 256-thread block.  Z = [X.Wp^T (from the MFMA GEMM, row stride ZLD) | gdir] (3x32); packed lower
-// triangle of Z'Z -> gram; fn = ||Z'Z||_F + 1.  With Z2 != null the second projection [X.Wq^T | gdir] is written out
-// compactly (kept for the equivariant update).  tri[o] = (a << 8 | b) of packed entry o, 0xFFFF for the K padding.
-constexpr int GR_NODES = 8;
-__global__ __launch_bounds__(256) void k_gram(const float* __restrict__ Zall, const float* __restrict__ gdir,
-                                              const unsigned short* __restrict__ tri, float* gram, float* fn, float* Z2,
-                                              int N) {
-  __shared__ float Zs[GR_NODES * 96];
-  __shared__ float red[GR_NODES * 4];
-  const int t = threadIdx.x, n0 = blockIdx.x * GR_NODES;
-  const int nn = min(GR_NODES, N - n0);
-  for (int i = t; i < GR_NODES * 96; i += 256) {
-    const int node = i / 96, s = (i % 96) / 32, a = i % 32;
-    float v = 0.f;
-    if (node < nn) {
-      const size_t row = (size_t)(n0 + node) * 3 + s;
-      float v2;
-      if (a < 30) { v = Zall[row * ZLD + a]; v2 = Z2 ? Zall[row * ZLD + 32 + a] : 0.f; }
-      else { v = gdir[row * 2 + (a - 30)]; v2 = v; }
-      if (Z2) Z2[row * ZD + a] = v2;
-    }
-    Zs[i] = v;
-  }
-  unsigned short tb[3];
-#pragma unroll
-  for (int k = 0; k < 3; k++) { const int o = t + 256 * k; tb[k] = o < GK ? tri[o] : (unsigned short)0xFFFF; }
-  __syncthreads();
-  const int wave = t >> 6;
-  for (int node = 0; node < GR_NODES; node++) {
-    float sq = 0.f;
-    const float* z = Zs + node * 96;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const int o = t + 256 * k;
-      if (o >= GK) continue;
-      float v = 0.f;
-      if (tb[k] != 0xFFFF) {
-        const int aa = tb[k] >> 8, bb = tb[k] & 255;
-        v = z[aa] * z[bb] + z[32 + aa] * z[32 + bb] + z[64 + aa] * z[64 + bb];
-        sq += (aa == bb ? 1.f : 2.f) * v * v;
-      }
-      if (node < nn) gram[(size_t)(n0 + node) * GK + o] = v;
-    }
-    sq = wave_sum_f32(sq);
-    if ((t & 63) == 0) red[node * 4 + wave] = sq;
-  }
-  __syncthreads();
-  if (t < nn) fn[n0 + t] = sqrtf((red[t * 4] + red[t * 4 + 1]) + (red[t * 4 + 2] + red[t * 4 + 3])) + 1.0f;
 }
 
 // relation bias per morphology: relb[off + (h*L + i)*L + j] = rel_encoder(relation[i,j])[h]
@@ -456,8 +415,8 @@ struct sgrl_set {
   float* ws = nullptr;
   int64_t ws_floats = 0;
   int carved_N = 0;
-  float *g, *cat, *cat2, *gram, *fn, *h256, *qkv, *vg, *g1, *z2, *mat, *t256, *t256b, *t128a, *t128b, *delta,
-      *outg, *outng, *gdir, *zall;
+  float *g, *cat, *cat2, *zc, *fn, *h256, *qkv, *vg, *g1, *z2, *mat, *t256, *t256b, *t128a, *t128b, *delta,
+      *outg, *outng, *gdir;
   // stacked projection weights of the 7 proj+gram sites: static weights -> own buffer rebuilt on the forward stream after
   // sgrl_set_weights; live weights -> part of the flat buffer, rebuilt by k_pack with everything else
   float* wstack = nullptr;
@@ -482,10 +441,10 @@ struct sgrl_set {
 
 namespace {
 
-constexpr int64_t kPerNodeFloats = 384 /*g*/ + 256 + 256 /*cat, cat2*/ + 1024 /*gram*/ + 1 /*fn*/ + 256 /*h256*/ + 768 /*qkv*/ +
+constexpr int64_t kPerNodeFloats = 384 /*g*/ + 256 + 256 /*cat, cat2*/ + 96 /*zc*/ + 1 /*fn*/ + 256 /*h256*/ + 768 /*qkv*/ +
                                    768 /*vg*/ + 384 /*g1*/ + 96 /*z2*/ + 96 /*T (was mat: 1024)*/ + 256 + 256 /*t256, t256b*/ +
-                                   128 + 128 + 128 /*t128a,b,delta*/ + 3 * OGLD /*outg*/ + 160 /*outng*/ + 6 /*gdir*/ + 3 * ZLD /*zall*/;
-constexpr int kWsArrays = 20;
+                                   128 + 128 + 128 /*t128a,b,delta*/ + 3 * OGLD /*outg*/ + 160 /*outng*/ + 6 /*gdir*/;
+constexpr int kWsArrays = 19;
 
 int64_t ws_floats_for(int64_t N) { return kPerNodeFloats * N + 32 * kWsArrays; }
 
@@ -517,10 +476,10 @@ int use_cfg(sgrl_set* s, GraphCfg* c) {
   if (s->carved_N != c->N) {
     float* p = s->ws;
     auto take = [&](int64_t n) { float* r = p; p += (n + 31) & ~int64_t(31); return r; };
-    s->g = take(384 * N); s->cat = take(256 * N); s->cat2 = take(256 * N); s->gram = take(1024 * N); s->fn = take(N);
+    s->g = take(384 * N); s->cat = take(256 * N); s->cat2 = take(256 * N); s->zc = take(96 * N); s->fn = take(N);
     s->h256 = take(256 * N); s->qkv = take(768 * N); s->vg = take(768 * N);
     s->g1 = take(384 * N); s->z2 = take(96 * N); s->mat = take(96 * N); s->t256 = take(256 * N); s->t256b = take(256 * N); s->t128a = take(128 * N);
-    s->t128b = take(128 * N); s->delta = take(128 * N); s->outg = take(3 * OGLD * N); s->outng = take(160 * N); s->gdir = take(6 * N); s->zall = take(3 * ZLD * N);
+    s->t128b = take(128 * N); s->delta = take(128 * N); s->outg = take(3 * OGLD * N); s->outng = take(160 * N); s->gdir = take(6 * N);
     if (p - s->ws > s->ws_floats) return sfail(SGRL_ERR_LIMIT, "workspace carve-up overflow");
     s->carved_N = c->N;
   }
@@ -588,6 +547,16 @@ int launch_gemm_equiv(hipStream_t st, const float* A, int lda, const float* W, i
   return SGRL_OK;
 }
 
+// C[M,N] = relu(G(Z) . W^T + b): the Gram-operand GEMM (A generated from zc [M, 3, 32]; W [N, 576] folded); N = 128 or 256
+constexpr auto kGemmGram = sgrl_gemm::k_gemm3<EPI_RELU, 4, 2, 1, 2, 16, 2, false, false, false, 0, true>;
+int launch_gemm_gram(hipStream_t st, const float* zc, const float* W, const float* bias, float* C, int ldc, int M, int N, float* fn) {
+  if (N % 128 != 0) return sfail(SGRL_ERR_ARG, "gemm_gram: N must be a multiple of 128");
+  GemmArgs a{zc, 96, W, GK, bias, C, ldc, M, N, GK, EPI_RELU, nullptr, nullptr, 0};
+  a.rowdiv_out = fn;
+  hipLaunchKernelGGL(kGemmGram, dim3(((M + 127) / 128) * (N / 128)), dim3(512), GemmKernels<0>::kSplitLds, st, a);
+  return SGRL_OK;
+}
+
 int launch_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc,
                 int M, int N, int K, int flags = 0, const float* rowdiv = nullptr, float* C2 = nullptr, int ldc2 = 0) {
   if (K % 16 != 0 || (lda & 3) || (ldw & 3)) return sfail(SGRL_ERR_ARG, "gemm: K must be a multiple of 16 and rows 16-byte aligned");
@@ -617,10 +586,11 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
                      s->d_relb, s->d_m_off, s->d_m_L, s->n_morph);
   hipLaunchKernelGGL(k_embed, dim3(N), dim3(128), 0, st, obs, obs_ld, action, action_ld, ngf, nt, s->W(SGRL_SET_GENC), s->W(SGRL_SET_ENC_W),
                      s->W(SGRL_SET_ENC_B), s->W(SGRL_SET_EMB0), s->W(SGRL_SET_EMB1), s->W(SGRL_SET_EMB2), s->g, s->cat,
-                     s->outg, s->outng, s->gdir);
+                     s->outg, s->outng, s->gdir, s->zc, s->z2);
   float* ng = s->cat + 128;
   int rc = SGRL_OK;
 #define G(...) do { rc = launch_gemm(st, __VA_ARGS__); if (rc != SGRL_OK) return rc; } while (0)
+#define GG(W_, b_, C_, ldc_, N_) do { rc = launch_gemm_gram(st, s->zc, W_, b_, C_, ldc_, N, N_, s->fn); if (rc != SGRL_OK) return rc; } while (0)
   // proj + gram site: Z (and Z2) = X . [Wp; Wq]^T on the matrix cores (stacked, zero-padded weights), then the packed
   // Gram triangle per node
   auto site_w = [&](int site) -> const float* {   // site 6 (the head, Cpad 144) is last
@@ -636,11 +606,12 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
     hipLaunchKernelGGL(k_stack_proj, dim3(36), dim3(256), 0, st, s->W(SGRL_SET_GGPROJ), critic ? (const float*)nullptr : s->W(SGRL_SET_GPROJ), 136, OGLD, sw(6));
     s->stack_dirty = false;
   }
+  // projection site: Z (and Z2) = X . [Wp; Wq]^T on the matrix cores (stacked, zero-padded weights), written straight into
+  // the compact rows zc / z2 the Gram GEMM and the equivariant epilogues read
   auto pg = [&](const float* X, int ldx, int K, int site, float* z2) -> int {
-    int r = launch_gemm(st, X, ldx, site_w(site), K, nullptr, s->zall, ZLD, N3, z2 ? 64 : 32, K);
-    if (r != SGRL_OK) return r;
-    hipLaunchKernelGGL(k_gram, dim3((N + GR_NODES - 1) / GR_NODES), dim3(256), 0, st, s->zall, s->gdir, s->d_tri, s->gram,
-                       s->fn, z2, N);
+    if (K % 16 != 0 || (ldx & 3)) return sfail(SGRL_ERR_ARG, "projection: K must be a multiple of 16 and rows 16-byte aligned");
+    GemmArgs a{X, ldx, site_w(site), K, nullptr, s->zc, ZD, N3, z2 ? 64 : 32, K, EPI_ZSPLIT, nullptr, z2, ZD};
+    GemmKernels<EPI_ZSPLIT>::launch(st, a);
     return SGRL_OK;
   };
 #define PG(...) do { rc = pg(__VA_ARGS__); if (rc != SGRL_OK) return rc; } while (0)
@@ -656,7 +627,7 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
     fork();
     GS(s->g, D, s->WL(l, SGRL_SET_VG_W), D, nullptr, s->vg, 256, N3, 256, D);          // U = g . (Wgo_h Wvg_h)^T, both heads
     PG(s->g, D, D, 2 * l, nullptr);
-    G(s->gram, GK, s->WL(l, SGRL_SET_A_LG1_W), GK, s->WL(l, SGRL_SET_A_LG1_B), s->h256, 256, N, 256, GK, EPI_RELU);
+    GG(s->WL(l, SGRL_SET_A_LG1_W), s->WL(l, SGRL_SET_A_LG1_B), s->h256, 256, 256);
     G(s->h256, 256, s->WL(l, SGRL_SET_A_LG2_W), 256, s->WL(l, SGRL_SET_A_LG2_B), s->cat, 256, N, 128, 256);
     G(s->cat, 256, s->WL(l, SGRL_SET_QKV_W), 256, s->WL(l, SGRL_SET_QKV_B), s->qkv, 768, N, 768, 256, EPI_ROWDIV, s->fn);
     join();
@@ -667,7 +638,7 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
                        s->WL(l, SGRL_SET_N1_B), ng, 256, (float*)nullptr, 0, N);
     // --- equivariant feed-forward ---
     PG(s->g1, D, D, 2 * l + 1, s->z2);
-    G(s->gram, GK, s->WL(l, SGRL_SET_F_LG1_W), GK, s->WL(l, SGRL_SET_F_LG1_B), s->h256, 256, N, 256, GK, EPI_RELU);
+    GG(s->WL(l, SGRL_SET_F_LG1_W), s->WL(l, SGRL_SET_F_LG1_B), s->h256, 256, 256);
     G(s->h256, 256, s->WL(l, SGRL_SET_F_LG2_W), 256, s->WL(l, SGRL_SET_F_LG2_B), s->cat, 256, N, 128, 256);
     fork();
     GS(s->cat, 256, s->WL(l, SGRL_SET_L1_W), 256, s->WL(l, SGRL_SET_L1_B), s->t256b, 256, N, 256, 256, EPI_RELU);
@@ -689,7 +660,7 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   GS(s->outng, 160, s->W(SGRL_SET_L1NG_W), 160, s->W(SGRL_SET_L1NG_B), s->t128b, D, N, D, 160, EPI_RELU);
   GS(s->t128b, D, s->W(SGRL_SET_L2NG_W), D, s->W(SGRL_SET_L2NG_B), s->cat2 + 128, 256, N, D, D);
   PG(s->outg, OGLD, OGLD, 6, critic ? (float*)nullptr : s->z2);
-  G(s->gram, GK, s->W(SGRL_SET_L1G_W), GK, s->W(SGRL_SET_L1G_B), s->t128a, D, N, D, GK, EPI_RELU);
+  GG(s->W(SGRL_SET_L1G_W), s->W(SGRL_SET_L1G_B), s->t128a, D, D);
   G(s->t128a, D, s->W(SGRL_SET_L2G_W), D, s->W(SGRL_SET_L2G_B), s->cat2, 256, N, D, D);
   join();
   if (critic) {
@@ -704,6 +675,7 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
                        act, act_ld, max_action, N);
   }
 #undef GS
+#undef GG
 #undef G
 #undef PG
   if (hipGetLastError() != hipSuccess) return sfail(SGRL_ERR_HIP, "kernel launch failed in sgrl_set_forward");
@@ -722,16 +694,23 @@ int sgrl_set_create(sgrl_set** out) {
     return sfail(SGRL_ERR_HIP, "no HIP device visible: the SET actor fast path needs an MI355X (there is no CPU fallback)");
   }
   const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kGemmEquiv), hipFuncAttributeMaxDynamicSharedMemorySize, GemmKernels<0>::kSplitLds) == hipSuccess &&
+                       hipFuncSetAttribute(reinterpret_cast<const void*>(kGemmGram), hipFuncAttributeMaxDynamicSharedMemorySize, GemmKernels<0>::kSplitLds) == hipSuccess &&
                        GemmKernels<0>::raise_lds_limits() && GemmKernels<EPI_RELU>::raise_lds_limits() &&
-                       GemmKernels<EPI_ROWDIV>::raise_lds_limits() && GemmKernels<EPI_ACC2>::raise_lds_limits();
+                       GemmKernels<EPI_ROWDIV>::raise_lds_limits() && GemmKernels<EPI_ACC2>::raise_lds_limits() &&
+                       GemmKernels<EPI_ZSPLIT>::raise_lds_limits();
   if (!attr_ok) {
     *out = nullptr;
     return sfail(SGRL_ERR_HIP, "cannot raise the dynamic LDS limit of the GEMM kernel");
   }
   sgrl_set* s = new sgrl_set();
-  // index table of the packed Gram triangle: entry o = a(a+1)/2 + b  ->  (a << 8 | b); the K padding is marked 0xFFFF
+  // index table of the blocked Gram triangle (gemm_f32.h GRAM): k = 16 (A (A + 1) / 2 + B) + 4 i + j  ->  (a << 8 | b) with
+  // a = 4 A + i, b = 4 B + j; the entries above the diagonal inside a diagonal block carry no weight: marked 0xFFFF
   std::vector<unsigned short> tri(GK, (unsigned short)0xFFFF);
-  for (int a = 0, o = 0; a < ZD; a++) for (int b = 0; b <= a; b++, o++) tri[o] = (unsigned short)((a << 8) | b);
+  for (int A = 0, o = 0; A < ZD / 4; A++)
+    for (int B = 0; B <= A; B++)
+      for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++, o++)
+          if (4 * A + i >= 4 * B + j) tri[o] = (unsigned short)(((4 * A + i) << 8) | (4 * B + j));
   const size_t wstack_floats = 6 * 64 * 128 + 64 * OGLD;
   if (hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -955,8 +934,8 @@ int64_t sgrl_set_workspace_bytes(const sgrl_set* s) { return s ? s->ws_floats * 
 
 int sgrl_set_peek(sgrl_set* s, int which, float* host, int64_t n_floats) {
   if (!s || !host || !s->have_graph) return sfail(SGRL_ERR_ARG, "sgrl_set_peek: bad argument");
-  const float* src[] = {s->g, s->cat, s->gram, s->fn, s->qkv, nullptr, nullptr, s->mat, s->g1, s->delta, s->outng};
-  const int64_t per[] = {384, 256, GK, 1, 768, 0, 0, 96, 384, 128, 160};
+  const float* src[] = {s->g, s->cat, s->zc, s->fn, s->qkv, nullptr, nullptr, s->mat, s->g1, s->delta, s->outng};
+  const int64_t per[] = {384, 256, 96, 1, 768, 0, 0, 96, 384, 128, 160};
   if (which < 0 || which > 10 || !src[which] || n_floats > per[which] * s->N) return sfail(SGRL_ERR_ARG, "sgrl_set_peek: bad buffer or size");
   SHIP_TRY(hipDeviceSynchronize());
   SHIP_TRY(hipMemcpy(host, src[which], sizeof(float) * n_floats, hipMemcpyDeviceToHost));

@@ -47,16 +47,33 @@ def _check(L, rc, what):
         raise _lib.SgrlError("%s failed (%d): %s" % (what, rc, L.sgrl_set_last_error().decode()))
 
 
+GRAM_K = 576
+
+
+def gram_order():
+    """(a, b, valid) of the blocked lower triangle the Gram GEMMs run over (csrc/gemm_f32.h GRAM): the 36 4x4 blocks
+    (A, B), B <= A, one per 16-wide k-tile: k = 16 (A (A + 1) / 2 + B) + 4 i + j <-> a = 4 A + i, b = 4 B + j; the
+    entries above the diagonal inside the diagonal blocks are not used (zero weight)."""
+    a, b, ok = [], [], []
+    for A in range(8):
+        for B in range(A + 1):
+            for i in range(4):
+                for j in range(4):
+                    a.append(4 * A + i); b.append(4 * B + j); ok.append(4 * A + i >= 4 * B + j)
+    return torch.tensor(a), torch.tensor(b), torch.tensor(ok)
+
+
 def fold_gram_weight(w):
-    """[out, 1024] weight acting on vec(G) of a symmetric 32x32 G -> [out, 544] acting on its packed lower triangle."""
+    """[out, 1024] weight acting on vec(G) of a symmetric 32x32 G -> [out, 576] acting on its blocked lower triangle."""
     out_f = w.shape[0]
     w3 = w.reshape(out_f, 32, 32)
     sym = w3 + w3.transpose(1, 2)
-    idx_a, idx_b = torch.tril_indices(32, 32)          # row-major lower triangle: k = a(a+1)/2 + b
+    idx_a, idx_b, ok = gram_order()
     f = sym[:, idx_a, idx_b].clone()
     diag = idx_a == idx_b
     f[:, diag] = w3[:, idx_a[diag], idx_b[diag]]
-    return torch.cat([f, f.new_zeros(out_f, 544 - f.shape[1])], dim=1).contiguous()
+    f[:, ~ok] = 0
+    return f.contiguous()
 
 
 def perm32(t):
@@ -156,7 +173,7 @@ def plan_segments(net, critic=False):
     def fold(name):
         t = p(name)
         assert t.shape[1] == 1024
-        emit(PACK_FOLD, t, t.shape[0] * 544)
+        emit(PACK_FOLD, t, t.shape[0] * GRAM_K)
 
     def padcol(name, cols):
         t = p(name)

@@ -11,7 +11,6 @@ from sgrl_amd.set_policy import make_critic, make_policy
 
 def _run_plan(segs, srcs, total):
     out = np.full(total, np.nan, dtype=np.float32)
-    tril_a, tril_b = np.tril_indices(32)      # row-major lower triangle: k = a(a+1)/2 + b
     for sg, (t0, t1, off0, off1) in zip(segs, srcs):
         n, kind, a, b = int(sg["n"]), int(sg["kind"]), int(sg["a"]), int(sg["b"])
         lda, ldb = int(sg["lda"]), int(sg["ldb"])
@@ -24,12 +23,21 @@ def _run_plan(segs, srcs, total):
             v = v.reshape(-1, b)
             v[:, :a] = s0.reshape(-1, a)
         elif kind == set_hip.PACK_FOLD:
+            # blocked lower triangle (csrc/gemm_f32.h GRAM): written out independently of set_hip.gram_order()
             w3 = s0.reshape(-1, 32, 32)
-            v = v.reshape(-1, 544)
-            f = w3[:, tril_a, tril_b] + w3[:, tril_b, tril_a]
-            diag = tril_a == tril_b
-            f[:, diag] = w3[:, tril_a[diag], tril_b[diag]]
-            v[:, :528] = f
+            v = v.reshape(-1, 576)
+            k = 0
+            for A in range(8):
+                for B in range(A + 1):
+                    for i in range(4):
+                        for j in range(4):
+                            aa, bb = 4 * A + i, 4 * B + j
+                            if aa > bb:
+                                v[:, k] = w3[:, aa, bb] + w3[:, bb, aa]
+                            elif aa == bb:
+                                v[:, k] = w3[:, aa, aa]
+                            k += 1
+            assert k == 576
         elif kind == set_hip.PACK_STACK:
             v = v.reshape(64, b)
             v[:30, :a] = s0.reshape(30, a)

@@ -8,7 +8,7 @@ sys.path.insert(0, REPO)
 import numpy as np, torch
 from sgrl_amd import _lib
 prof_so = os.path.join(REPO, "sgrl_amd", "libsgrl_hip_prof.so")
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSGRL_PHASE_PROF",
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize", "-DSGRL_PHASE_PROF",
                        "-o", prof_so, os.path.join(_lib.CSRC, "engine.hip"), os.path.join(_lib.CSRC, "set_actor.hip")])
 _lib.LIB_PATH = prof_so
 from sgrl_amd.vec_env import BatchedModularVecEnv
