@@ -16,7 +16,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // EPI_ZSPLIT (k_gemm2, the stacked 3-vector projections): output column n < 30 goes to C[m][n], column 32 <= n < 62 to
 // C2[m][n - 32], both with row stride 32 (columns 30 / 31 of those rows hold the gravity / direction pair, written once per
 // forward by k_embed); the zero-padding columns 30, 31, 62, 63 of the stacked operand are not stored
-enum { EPI_RELU = 1, EPI_ROWDIV = 2, EPI_ACC2 = 4, EPI_EQUIV = 8, EPI_ZSPLIT = 16 };
+// EPI_LN (k_gemm3, N = 128 = one column tile): the result is not stored; it is the update of a residual stream that is layer-
+// normalised in place: ln_io[m][:] = LayerNorm(ln_io[m][:] + value[m][:]) * ln_w + ln_b over the 128 columns of the row
+enum { EPI_RELU = 1, EPI_ROWDIV = 2, EPI_ACC2 = 4, EPI_EQUIV = 8, EPI_ZSPLIT = 16, EPI_LN = 32 };
 
 struct GemmArgs {
   const float* A; int lda;
@@ -35,6 +37,8 @@ struct GemmArgs {
   // 32-vectors per row) and stores only tout[m][s][c] = sum_a zq[m][s][a] * mat[m][a][c]  ([M, 3, 32] floats)
   const float* zq = nullptr;
   float* tout = nullptr;
+  float* ln_io = nullptr; int ln_ld = 0;          // EPI_LN: residual stream (read and rewritten), row stride
+  const float* ln_w = nullptr; const float* ln_b = nullptr;
   float* rowdiv_out = nullptr;   // GRAM: receives ||Z'Z||_F + 1 per row (from the blocks of the first column tile)
 };
 
@@ -507,6 +511,74 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
         float tv = ts[sx] * rd;
         tv += __shfl_xor(tv, 32, 64);
         if (ok && lh == 0) a.tout[(size_t)m * 96 + sx * 32 + cidx] = tv;
+      }
+    }
+    return;
+  }
+  if (FLAGS & EPI_LN) {
+    // Residual + LayerNorm epilogue (N = 128: the block holds whole rows).  A row's 128 values sit in two waves (wn) x two
+    // 32-column tiles x 32 lanes: sums run over the lanes of a half-wave (xor shuffles), the two tiles (registers) and the
+    // two waves (through the now idle LDS); mean first, then the centred second moment, as k_add_ln does.
+    static_assert(!(FLAGS & EPI_LN) || (TM == 1 && TN == 2 && WN == 2 && BNT == 128), "EPI_LN assumes the 128 x 128 tile of 4 x 2 waves");
+    float* red = gemm_lds;                       // [128 rows][2 waves]
+    const int mb = m0 + wm * 32 + 4 * lh;
+    float part[16];                              // the accumulators are reused for the row values (acc[0][tj][e])
+#pragma unroll
+    for (int tj = 0; tj < 2; tj++) {
+      const float bvv = a.bias ? a.bias[wn * 64 + tj * 32 + li] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        float v = (acc[0][tj][e] + cor[0][tj][e]) + bvv;
+        if (FLAGS & EPI_RELU) v = fmaxf(v, 0.f);
+        acc[0][tj][e] = v;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const int m = min(mb + (e & 3) + 8 * (e >> 2), a.M - 1);
+      const float rd = (FLAGS & EPI_ROWDIV) ? 1.0f / a.rowdiv[m] : 1.f;
+      const float* rrow = a.ln_io + (size_t)m * a.ln_ld + wn * 64 + li;
+      acc[0][0][e] = rrow[0] + acc[0][0][e] * rd;
+      acc[0][1][e] = rrow[32] + acc[0][1][e] * rd;
+      part[e] = acc[0][0][e] + acc[0][1][e];
+    }
+    auto row_sums = [&]() {                      // part[e] -> sum over the row's 128 columns, in every lane
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) part[e] += __shfl_xor(part[e], off, 32);
+      }
+      __syncthreads();                           // LDS free (first use: the k-loop's last reads; second: the previous sums)
+      if (li == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) red[(wm * 32 + 4 * lh + (e & 3) + 8 * (e >> 2)) * 2 + wn] = part[e];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int r = wm * 32 + 4 * lh + (e & 3) + 8 * (e >> 2);
+        part[e] = red[2 * r] + red[2 * r + 1];
+      }
+    };
+    row_sums();
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const float mu = part[e] * (1.f / 128.f);
+      const float d0 = acc[0][0][e] - mu, d1 = acc[0][1][e] - mu;
+      acc[0][0][e] = d0; acc[0][1][e] = d1;
+      part[e] = d0 * d0 + d1 * d1;
+    }
+    row_sums();
+#pragma unroll
+    for (int e = 0; e < 16; e++) part[e] = 1.0f / sqrtf(part[e] * (1.f / 128.f) + 1e-5f);
+#pragma unroll
+    for (int tj = 0; tj < 2; tj++) {
+      const int n = wn * 64 + tj * 32 + li;
+      const float lw = a.ln_w[n], lb = a.ln_b[n];
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int m = mb + (e & 3) + 8 * (e >> 2);
+        if (m < a.M) a.ln_io[(size_t)m * a.ln_ld + n] = acc[0][tj][e] * part[e] * lw + lb;
       }
     }
     return;

@@ -44,6 +44,7 @@ constexpr int OGLD = 144;                  // row stride of outg: 136 channels p
 // The f32 MFMA GEMM (C[M,N] = epi(A[M,K] . W[N,K]^T)) lives in gemm_f32.h.
 using sgrl_gemm::EPI_ACC2;
 using sgrl_gemm::EPI_EQUIV;
+using sgrl_gemm::EPI_LN;
 using sgrl_gemm::EPI_RELU;
 using sgrl_gemm::EPI_ROWDIV;
 using sgrl_gemm::EPI_ZSPLIT;
@@ -200,7 +201,9 @@ __global__ void k_relbias(const float* rel, const float* Wr, const float* br, fl
 // (include/sgrl_set.h) the kernel produces the attention block's two outputs directly:
 //   delta[i][c]   = b_ng[c] + sum_h sum_j w_h[i,j] v'[j][128 h + c]                               (scalar stream, 128 wide)
 //   g1[i][s][c]   = sum_h ( sum_j w_h[i,j] U[j][s][128 h + c]  +  GD[h][c][:] . sum_j w_h[i,j] gdir[j][s][:] )
-// (the residual g += g1 of reference SEActor.py:89 is applied by k_equiv together with the feed-forward update of g)
+// (the residual g += g1 of reference SEActor.py:89 is applied by k_equiv together with the feed-forward update of g).
+// The scalar stream's residual + norm1 (SEActor.py:90-91) happens here too: ng[i][:] = LayerNorm(ng[i][:] + delta[i][:]),
+// in place (row stride ng_ld); delta itself is only written out for the parity probes (delta_dbg != null).
 struct EnvTab {
   const int32_t* env_off;   // [n_env] first node
   const int32_t* env_L;     // [n_env]
@@ -209,10 +212,12 @@ struct EnvTab {
 __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv, const float* __restrict__ U,
                                                    const float* __restrict__ gdir, const float* relb, EnvTab et,
                                                    int use_bias, const float* __restrict__ b_ng, const float* __restrict__ GD,
-                                                   float* delta, float* g1) {
+                                                   float* delta_dbg, float* g1, float* ng, int ng_ld,
+                                                   const float* __restrict__ ln_w, const float* __restrict__ ln_b) {
   constexpr int LMAX = 14;
   __shared__ float sc[2 * LMAX * LMAX];
   __shared__ float gd[2 * LMAX * 3 * 2];        // [h][i][s][e] = sum_j w_h[i,j] gdir[j][s][e]
+  __shared__ float dl[LMAX][128];               // delta rows, handed from the column threads to the LayerNorm waves
   const int e = blockIdx.x, t = threadIdx.x;
   const int n0 = et.env_off[e], L = et.env_L[e];
   // scores: eight lanes per (head, i, j) dot product -- each group reads its q / k rows as four coalesced 128-byte
@@ -256,10 +261,10 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   // column c, threads 128..255 spatial rows 1 and 2; each sums over BOTH heads itself (no cross-thread reduction, no
   // barrier), reading the L value entries of a (quantity, head) once into registers
   const int half = t >> 7, c = t & 127;
+  float out[LMAX];                               // after the loop: the values of the LAST quantity (half 0: the scalar stream)
 #pragma unroll
-  for (int qq = 0; qq < 2; qq++) {
+  for (int qq = 1; qq >= 0; qq--) {
     const int quantity = 2 * half + qq;          // 0: scalar stream, 1..3: spatial row quantity - 1
-    float out[LMAX];
 #pragma unroll
     for (int i = 0; i < LMAX; i++) out[i] = 0.f;
 #pragma unroll
@@ -288,14 +293,34 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
           out[i] += s;
         }
     }
-    if (quantity == 0) {
-      const float bb = b_ng[c];
-#pragma unroll
-      for (int i = 0; i < LMAX; i++) if (i < L) delta[(size_t)(n0 + i) * 128 + c] = out[i] + bb;
-    } else {
+    if (quantity != 0) {
 #pragma unroll
       for (int i = 0; i < LMAX; i++) if (i < L) g1[((size_t)(n0 + i) * 3 + (quantity - 1)) * 128 + c] = out[i];
     }
+  }
+  // scalar stream (threads 0..127 hold delta[i][c] - b_ng[c] in out[]): the rows go through LDS to the LayerNorm, one wave
+  // per limb row, two channels per lane, exactly k_add_ln's arithmetic
+  if (half == 0) {
+    const float bb = b_ng[c];
+#pragma unroll
+    for (int i = 0; i < LMAX; i++)
+      if (i < L) {
+        dl[i][c] = out[i] + bb;
+        if (delta_dbg) delta_dbg[(size_t)(n0 + i) * 128 + c] = out[i] + bb;
+      }
+  }
+  __syncthreads();
+  const int lane = t & 63;
+  const float w0 = ln_w[lane], w1 = ln_w[64 + lane], b0 = ln_b[lane], b1 = ln_b[64 + lane];
+  for (int i = t >> 6; i < L; i += 4) {
+    float* row = ng + (size_t)(n0 + i) * ng_ld;
+    const float v0 = row[lane] + dl[i][lane], v1 = row[64 + lane] + dl[i][64 + lane];
+    const float mu = wave_sum_f32(v0 + v1) * (1.f / 128.f);
+    const float d0 = v0 - mu, d1 = v1 - mu;
+    const float var = wave_sum_f32(d0 * d0 + d1 * d1) * (1.f / 128.f);
+    const float inv = 1.0f / sqrtf(var + 1e-5f);
+    row[lane] = d0 * inv * w0 + b0;
+    row[64 + lane] = d1 * inv * w1 + b1;
   }
 }
 
@@ -434,7 +459,7 @@ struct sgrl_set {
   int n_chunks = 0;
   // side stream for the GEMM chains that do not depend on each other (their epilogues / tile tails overlap)
   hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_l3 = nullptr;
   const float* W(int slot) const { return w + off[slot]; }
   const float* WL(int layer, int k) const { return w + off[SGRL_SET_NGLOBAL + layer * SGRL_SET_NLAYER + k]; }
 };
@@ -557,6 +582,17 @@ int launch_gemm_gram(hipStream_t st, const float* zc, const float* W, const floa
   return SGRL_OK;
 }
 
+// ln_io[m][:] = LayerNorm(ln_io[m][:] + (A . W^T + b)[m][:] / rowdiv[m]) * ln_w + ln_b   (N = 128, residual stream in place)
+constexpr auto kGemmLn = sgrl_gemm::k_gemm3<EPI_ROWDIV | EPI_LN, 4, 2, 1, 2, 16, 2>;
+int launch_gemm_ln(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, int M, int K,
+                   const float* rowdiv, float* ln_io, int ln_ld, const float* ln_w, const float* ln_b) {
+  if (K % 32 != 0 || (lda & 3) || (ldw & 3)) return sfail(SGRL_ERR_ARG, "gemm_ln: K must be a multiple of 32 and rows 16-byte aligned");
+  GemmArgs a{A, lda, W, ldw, bias, nullptr, 0, M, 128, K, EPI_ROWDIV | EPI_LN, rowdiv, nullptr, 0};
+  a.ln_io = ln_io; a.ln_ld = ln_ld; a.ln_w = ln_w; a.ln_b = ln_b;
+  hipLaunchKernelGGL(kGemmLn, dim3((M + 127) / 128), dim3(512), GemmKernels<0>::kSplitLds, st, a);
+  return SGRL_OK;
+}
+
 int launch_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc,
                 int M, int N, int K, int flags = 0, const float* rowdiv = nullptr, float* C2 = nullptr, int ldc2 = 0) {
   if (K % 16 != 0 || (lda & 3) || (ldw & 3)) return sfail(SGRL_ERR_ARG, "gemm: K must be a multiple of 16 and rows 16-byte aligned");
@@ -632,25 +668,28 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
     G(s->cat, 256, s->WL(l, SGRL_SET_QKV_W), 256, s->WL(l, SGRL_SET_QKV_B), s->qkv, 768, N, 768, 256, EPI_ROWDIV, s->fn);
     join();
     hipLaunchKernelGGL(k_attention, dim3(s->n_env), dim3(256), 0, st, s->qkv, s->vg, s->gdir, s->d_relb, et, l == 0 ? 1 : 0,
-                       s->WL(l, SGRL_SET_NGOUT_B), s->WL(l, SGRL_SET_A_GD), s->delta, s->g1);
+                       s->WL(l, SGRL_SET_NGOUT_B), s->WL(l, SGRL_SET_A_GD), s->stop_after == 2 * l ? s->delta : (float*)nullptr,
+                       s->g1, ng, 256, s->WL(l, SGRL_SET_N1_W), s->WL(l, SGRL_SET_N1_B));
     if (s->stop_after == 2 * l) return SGRL_OK;      // probe: g1 = attention's vector output, delta = its scalar output
-    hipLaunchKernelGGL(k_add_ln, dim3(lnb), dim3(256), 0, st, ng, 256, s->delta, D, s->WL(l, SGRL_SET_N1_W),
-                       s->WL(l, SGRL_SET_N1_B), ng, 256, (float*)nullptr, 0, N);
     // --- equivariant feed-forward ---
     PG(s->g1, D, D, 2 * l + 1, s->z2);
     GG(s->WL(l, SGRL_SET_F_LG1_W), s->WL(l, SGRL_SET_F_LG1_B), s->h256, 256, 256);
     G(s->h256, 256, s->WL(l, SGRL_SET_F_LG2_W), 256, s->WL(l, SGRL_SET_F_LG2_B), s->cat, 256, N, 128, 256);
     fork();
     GS(s->cat, 256, s->WL(l, SGRL_SET_L1_W), 256, s->WL(l, SGRL_SET_L1_B), s->t256b, 256, N, 256, 256, EPI_RELU);
-    GS(s->t256b, 256, s->WL(l, SGRL_SET_L2_W), 256, s->WL(l, SGRL_SET_L2_B), s->delta, D, N, D, 256, EPI_ROWDIV, s->fn);
     G(s->cat, 256, s->WL(l, SGRL_SET_L3_W), 256, s->WL(l, SGRL_SET_L3_B), s->t256, 256, N, 256, 256, EPI_RELU);
+    // linear2 carries the scalar stream's second residual + norm2 in its epilogue (ng rewritten in place): it must not start
+    // before linear3 -- the other reader of cat = [inv | ng] -- is done
+    (void)hipEventRecord(s->ev_l3, st);
+    (void)hipStreamWaitEvent(sd, s->ev_l3, 0);
+    rc = launch_gemm_ln(sd, s->t256b, 256, s->WL(l, SGRL_SET_L2_W), 256, s->WL(l, SGRL_SET_L2_B), N, 256, s->fn, ng, 256,
+                        s->WL(l, SGRL_SET_N2_W), s->WL(l, SGRL_SET_N2_B));
+    if (rc != SGRL_OK) return rc;
     rc = launch_gemm_equiv(st, s->t256, 256, s->WL(l, SGRL_SET_L4_W), 256, s->WL(l, SGRL_SET_L4_B), N, 256, s->fn, s->z2, s->mat);
     if (rc != SGRL_OK) return rc;
     hipLaunchKernelGGL(k_equiv, dim3((N + 7) / 8), dim3(128), 0, st, s->mat, s->WL(l, SGRL_SET_L5_W), s->g1, s->g,
                        l == SGRL_SET_LAYERS - 1 ? s->outg : (float*)nullptr, N);
     join();
-    hipLaunchKernelGGL(k_add_ln, dim3(lnb), dim3(256), 0, st, ng, 256, s->delta, D, s->WL(l, SGRL_SET_N2_W),
-                       s->WL(l, SGRL_SET_N2_B), ng, 256, (float*)nullptr, 0, N);
     if (s->stop_after == 2 * l + 1) return SGRL_OK;  // probe: g / ng (= cat[:, 128:]) are this layer's outputs
   }
   // final norm -> outng[:, 17:145]; head
@@ -695,6 +734,7 @@ int sgrl_set_create(sgrl_set** out) {
   }
   const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kGemmEquiv), hipFuncAttributeMaxDynamicSharedMemorySize, GemmKernels<0>::kSplitLds) == hipSuccess &&
                        hipFuncSetAttribute(reinterpret_cast<const void*>(kGemmGram), hipFuncAttributeMaxDynamicSharedMemorySize, GemmKernels<0>::kSplitLds) == hipSuccess &&
+                       hipFuncSetAttribute(reinterpret_cast<const void*>(kGemmLn), hipFuncAttributeMaxDynamicSharedMemorySize, GemmKernels<0>::kSplitLds) == hipSuccess &&
                        GemmKernels<0>::raise_lds_limits() && GemmKernels<EPI_RELU>::raise_lds_limits() &&
                        GemmKernels<EPI_ROWDIV>::raise_lds_limits() && GemmKernels<EPI_ACC2>::raise_lds_limits() &&
                        GemmKernels<EPI_ZSPLIT>::raise_lds_limits();
@@ -714,7 +754,8 @@ int sgrl_set_create(sgrl_set** out) {
   const size_t wstack_floats = 6 * 64 * 128 + 64 * OGLD;
   if (hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&s->ev_l3, hipEventDisableTiming) != hipSuccess) {
     delete s;
     *out = nullptr;
     return sfail(SGRL_ERR_HIP, "cannot create the side stream of the SET actor");
@@ -743,6 +784,7 @@ void sgrl_set_destroy(sgrl_set* s) {
   if (s->side) (void)hipStreamDestroy(s->side);
   if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+  if (s->ev_l3) (void)hipEventDestroy(s->ev_l3);
   delete s;
 }
 
