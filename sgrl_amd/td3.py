@@ -47,16 +47,20 @@ class Agent(nn.Module):
         super().__init__()
         self.args = args
         atype, ctype = getattr(args, "actor_type", "set"), getattr(args, "critic_type", "set")
-        if atype not in ("set", "swat") or ctype not in ("set", "swat"):
-            raise NotImplementedError("actor / critic types 'set' (HIP fast path) and 'swat' (PyTorch) are built; "
-                                      "'smp' and 'mlp' are not (SURVEY 8 f4)")
+        if atype not in ("set", "swat", "smp") or ctype not in ("set", "swat", "smp"):
+            raise NotImplementedError("actor / critic types 'set' (HIP fast path), 'swat' and 'smp' (PyTorch) are built; "
+                                      "'mlp' is not (SURVEY 8 f4)")
         self.networks = {}
+        from .smp_policy import ActorGraphPolicy, CriticGraphPolicy
         from .swat_policy import CriticStructurePolicy, StructurePolicy
 
         def actor():
             if atype == "swat":
                 return StructurePolicy(args.limb_obs_size, args.limb_action_size, args.msg_dim, args.batch_size, args.max_action,
                                        args.max_children, args.disable_fold, args.td, args.bu, args, device=device)
+            if atype == "smp":
+                return ActorGraphPolicy(args.limb_obs_size, args.limb_action_size, args.msg_dim, args.batch_size, args.max_action,
+                                        args.max_children, args.disable_fold, args.td, args.bu, args, device=device)
             return SEPolicy(args.limb_obs_size, args.limb_action_size, args.msg_dim, args.batch_size, args.max_action,
                             args.max_children, args.disable_fold, args.td, args.bu, args, device=device, use_hip=use_hip)
 
@@ -64,6 +68,9 @@ class Agent(nn.Module):
             if ctype == "swat":
                 return CriticStructurePolicy(args.limb_obs_size, args.limb_action_size, args.msg_dim, args.batch_size,
                                              args.max_children, args.disable_fold, args.td, args.bu, args, device=device)
+            if ctype == "smp":
+                return CriticGraphPolicy(args.limb_obs_size, args.limb_action_size, args.msg_dim, args.batch_size,
+                                         args.max_children, args.disable_fold, args.td, args.bu, args, device=device)
             return SECritic(args.limb_obs_size, args.limb_action_size, args.msg_dim, args.batch_size, args.max_children,
                             args.disable_fold, args.td, args.bu, args, device=device, use_hip=use_hip)
         self.actor, self.actor_target = actor(), actor()

@@ -159,3 +159,24 @@ def test_swat_agent_updates():
     assert np.isfinite(float(out["loss/critic_loss"])) and "loss/actor_loss" in out
     assert any(float((p - q).abs().max()) > 0 for p, q in zip(agent.actor.parameters(), before))
     assert agent.select_action(batch["obs"][0].numpy()).shape == (1, 3 * L)
+
+
+def test_smp_agent_updates():
+    """actor_type = critic_type = 'smp' (reference agent.py:30-31,67-68), both-way message passing: the critic returns the
+    limb-summed twin values [B, 1] and the same TD3 update runs over them."""
+    from oracle.formula import synth_obs
+    torch.manual_seed(2)
+    agent = Agent(default_train_args(actor_type="smp", critic_type="smp", td=True, bu=True, max_children=5))
+    m = mjcf.load_asset("3d_humanoid_9_full")
+    agent.change_morphology(G.getGraphDict(m.parents, TRAV, [], device=torch.device("cpu")))
+    B, L = 6, m.num_limbs
+    batch = {"obs": torch.from_numpy(synth_obs(L, B, 1).astype(np.float32)), "next_obs": torch.from_numpy(synth_obs(L, B, 2).astype(np.float32)),
+             "action": torch.rand(B, 3 * L) * 2 - 1, "reward": torch.randn(B, 1), "done": torch.zeros(B, 1)}
+    before = [p.detach().clone() for p in agent.actor.parameters()]
+    n_params = len(list(agent.actor.parameters()))
+    agent.models2train()
+    out = agent.update(batch, 0)
+    assert np.isfinite(float(out["loss/critic_loss"])) and "loss/actor_loss" in out
+    assert len(list(agent.actor.parameters())) == n_params          # the per-limb module list shares ONE module's parameters
+    assert any(float((p - q).abs().max()) > 0 for p, q in zip(agent.actor.parameters(), before))
+    assert agent.select_action(batch["obs"][0].numpy()).shape == (1, 3 * L)
