@@ -1,0 +1,47 @@
+/* sgrl_train.h -- C ABI of the dense products the TD3 update back-propagates through (gfx950).
+ *
+ * What it replaces: the `torch.nn.Linear` forward / backward calls inside the SET actor and critic when `Agent.update`
+ * (reference src/agent.py:117-183) differentiates through them (reference src/SEActor.py:34-287, src/SECritic.py:8-124;
+ * this repository's differentiable module is sgrl_amd/set_policy.py).  At the update's size -- batch 100 x 7..14 limbs = 700..1400
+ * rows (x 3 for the vector channels) -- the vendor libraries spend most of the update inside a handful of single-workgroup
+ * launches (a 256 x 256 macro tile looping over a 2 100-long contraction for a 30 x 128 weight gradient: 165 us); the kernels
+ * behind this header are built for the latency of small products instead (32 x 32 output tiles, 128-deep k-tiles).
+ *
+ * Arithmetic: the float32 matrix instruction (exact float32 products, float32 accumulation); partial sums (the four waves of a
+ * workgroup, the splits of a long weight-gradient contraction) are added in a fixed order: results are bit-reproducible.
+ *
+ * All pointers are DEVICE pointers owned by the caller; rows are `ld*` floats apart; no alignment is required (16-byte aligned
+ * rows take the vector path).  `ws` (backward only; may be null: no split then) is scratch for split weight-gradient contractions:
+ * sgrl_train_ws_floats() floats, ZERO filled before the first call; every call leaves its counter region zero again, so one
+ * buffer serves any number of consecutive calls ON ONE STREAM.  Calls on different streams need different buffers.
+ * Error codes as in sgrl.h; message via sgrl_train_last_error().  No CPU fallback.
+ */
+#ifndef SGRL_TRAIN_H
+#define SGRL_TRAIN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int64_t sgrl_train_ws_floats(void);
+
+/* y[M, N] = act(x[M, K] . w[N, K]^T + bias[N]); bias may be null; relu != 0 applies max(., 0)   (torch.nn.functional.linear) */
+int sgrl_linear_forward(const float* x, int ldx, const float* w, int ldw, const float* bias, float* y, int ldy, int M, int N,
+                        int K, int relu, void* stream);
+
+/* Backward of the call above.  g = dy, or dy masked by (y_relu > 0) when y_relu != null (the forward's OUTPUT: ReLU backward).
+ *   dx[M, K] = g . w           (skipped when dx == null)
+ *   dw[N, K] = g^T . x         (skipped when dw == null)
+ *   db[N]    = column sums of g (skipped when db == null) */
+int sgrl_linear_backward(const float* dy, int lddy, const float* y_relu, int ldyr, const float* x, int ldx, const float* w,
+                         int ldw, float* dx, int lddx, float* dw, int lddw, float* db, int M, int N, int K, float* ws,
+                         void* stream);
+
+const char* sgrl_train_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

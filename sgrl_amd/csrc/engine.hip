@@ -348,18 +348,24 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
     }
     if (e->groups.size() > 1) {
       bool sok = hipEventCreateWithFlags(&e->fork, hipEventDisableTiming) == hipSuccess;
-      // Stream priorities: the groups are ordered costliest first (largest slabs, longest-running workgroups).  With
-      // equal priorities the many small workgroups of the light groups fragment the LDS and the heavy group trickles in
-      // and finishes last with the chip half empty; with the heavy group preferred its workgroups all start at once
-      // and the light ones fill the gaps.
+      // The group streams are PLAIN non-blocking streams.  Round 1 gave the heavy groups higher stream priorities (their
+      // workgroups then all start at once and the light ones fill the gaps: k_env_step alone 5..10 % faster on mixed
+      // batches), but on this ROCm (7.2) the mere existence of hipStreamCreateWithPriority streams in a process corrupts
+      // LATER hipGraph captures -- work enqueued shortly before a capture is recorded into the graph a second time (the TD3
+      // update graphs of train_loop.py replayed at 45..60 ms instead of 13..24 ms; tools/diag/train_time_probe3.py) -- and
+      // the priorities also slowed the SET forward that follows the step (humanoid mix: step + forward 7.4 ms with, 6.1 ms
+      // without).  SGRL_GROUP_PRIO=1 restores them for engine-only experiments.
       int prio_least = 0, prio_greatest = 0;
       (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);   // numerically lower = higher priority
+      const char* want_prio = getenv("SGRL_GROUP_PRIO");
+      const bool use_prio = want_prio && want_prio[0] == '1';
       int gi = 0;
       for (auto& g : e->groups) {
         int prio = prio_greatest + gi++;
         if (prio > prio_least) prio = prio_least;
-        sok = sok && hipStreamCreateWithPriority(&g.stream, hipStreamNonBlocking, prio) == hipSuccess &&
-              hipEventCreateWithFlags(&g.done, hipEventDisableTiming) == hipSuccess;
+        const hipError_t se = use_prio ? hipStreamCreateWithPriority(&g.stream, hipStreamNonBlocking, prio)
+                                       : hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking);
+        sok = sok && se == hipSuccess && hipEventCreateWithFlags(&g.done, hipEventDisableTiming) == hipSuccess;
       }
       if (!sok) { sgrl_engine_destroy(e); return fail(SGRL_ERR_HIP, "cannot create launch-group streams"); }
     }

@@ -1,0 +1,287 @@
+// train_gemm.hip -- the dense products of the TD3 update's linear layers for gfx950 (C ABI: include/sgrl_train.h).
+//
+// One kernel, three operand layouts:   C[m][n] = sum_k a(m, k) * b(n, k)
+//   forward   y  = x . w^T      a = x  [M][K]  (contraction contiguous)   b = w [N][K]  (contraction contiguous)
+//   dgrad     dx = g . w        a = g  [M][N]  (contraction contiguous)   b = w [N][K]  (contraction = ROW index)
+//   wgrad     dw = g^T . x      a = g  [M][N]  (contraction = ROW index)  b = x [M][K]  (contraction = ROW index)
+// The update's products are SMALL (700..4 200 rows, 30..1 024 columns, contractions up to 4 200) and each is on the critical
+// path of the backward pass, so the kernel is built for LATENCY, not for arithmetic rate: 32 x 32 output tiles (a 700 x 256
+// product is 176 workgroups instead of the vendor libraries' 3..12), and k-tiles 128 deep -- every thread has eight
+// independent 16-byte loads in flight per step and a 256-long contraction is two steps, not sixteen.  Tiles are staged
+// k-major in LDS (an operand whose contraction index is contiguous is transposed on its way in); the arithmetic is the
+// float32 matrix instruction v_mfma_f32_32x32x2_f32 (exact float32 products, float32 accumulation): each of the workgroup's
+// four waves multiplies its quarter of every k-tile into a full 32 x 32 accumulator (one LDS dword per operand and MFMA: a
+// VALU 2 x 2 micro-tile version of this kernel was LDS-bandwidth bound at 4x the time), the four partial tiles meet in LDS
+// in wave order, and the next k-tile's global loads are issued before the current tile's arithmetic.  A weight gradient
+// with a long contraction and a small output (30 x 128 over 2 100 rows: four tiles) is split along the contraction over
+// blockIdx.z: partial tiles go to scratch and the LAST workgroup to arrive at a tile adds them in split order and applies
+// the epilogue -- no floating-point atomics, the result is bit-reproducible.  g may be masked on the
+// fly by the forward's output (ReLU backward), and the weight gradient's workgroups of the first column tile also produce
+// the bias gradient (column sums of g).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <string>
+
+#include "../../include/sgrl.h"
+#include "../../include/sgrl_train.h"
+
+namespace {
+
+thread_local std::string g_train_err;
+int tfail(int code, const std::string& msg) { g_train_err = msg; return code; }
+
+constexpr int BT = 32;          // tile edge
+constexpr int BK = 128;         // k-tile depth
+constexpr int LDP = 36;         // LDS row pitch (floats): rows 16-byte aligned, 8-byte aligned pairs
+constexpr int NLD = BT * BK / 4 / 256;   // float4 loads per thread, operand and k-tile (= 4)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+static_assert(2 * BK * LDP >= 4 * 32 * 33, "the partial tiles reuse the operand tiles' LDS");
+
+struct SArgs {
+  const float* A; int lda;
+  const float* Amask; int ldmask;   // null, or: a(m, k) counts only where Amask (same layout as A) is > 0
+  const float* B; int ldb;
+  const float* bias; int relu;
+  float* C; int ldc;
+  float* db;                        // wgrad only: column sums of the (masked) A operand = rows of C
+  int M, N, K;
+  int kper;                         // contraction length per split (multiple of BK); gridDim.z splits
+  float* ws; unsigned* counters;    // split scratch: [split][tile][TILE_WS] floats, one counter per tile (zero between calls)
+};
+constexpr int TILE_WS = BT * BT + BT;
+constexpr int64_t kWsTiles = 4096;      // (split, tile) slots of the scratch buffer
+constexpr int kCounters = 4096;
+
+__device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// four consecutive elements of a row starting at column c (valid columns: c + j < cmax), zero filled
+__device__ __forceinline__ float4 load4(const float* row, int c, int cmax, bool vec_ok) {
+  if (vec_ok && c + 3 < cmax) return *reinterpret_cast<const float4*>(row + c);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < cmax) v.x = row[c];
+  if (c + 1 < cmax) v.y = row[c + 1];
+  if (c + 2 < cmax) v.z = row[c + 2];
+  if (c + 3 < cmax) v.w = row[c + 3];
+  return v;
+}
+__device__ __forceinline__ float4 relu_mask(float4 v, float4 y) {
+  v.x = y.x > 0.f ? v.x : 0.f; v.y = y.y > 0.f ? v.y : 0.f; v.z = y.z > 0.f ? v.z : 0.f; v.w = y.w > 0.f ? v.w : 0.f;
+  return v;
+}
+
+// AT / BTR: the operand's contraction index is its ROW index (tile rows = k, staged as is: thread = (k, four columns));
+// otherwise its row index is the output index and the contraction runs along the row (thread = (output row, four k), rows
+// on adjacent lanes so that the transposing LDS stores fall on distinct banks).
+template <bool AT, bool BTR>
+__global__ __launch_bounds__(256) void k_sgemm(SArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[BK][LDP];
+  __shared__ __attribute__((aligned(16))) float Bs[BK][LDP];
+  __shared__ int s_last;
+  const int t = threadIdx.x;
+  const int m0 = blockIdx.y * BT, n0 = blockIdx.x * BT;
+  const int k_begin = blockIdx.z * a.kper, k_end = min(a.K, k_begin + a.kper);
+  const bool a_vec = (a.lda & 3) == 0 && aligned16(a.A) && (!a.Amask || ((a.ldmask & 3) == 0 && aligned16(a.Amask)));
+  const bool b_vec = (a.ldb & 3) == 0 && aligned16(a.B);
+  const bool want_db = AT && a.db != nullptr && blockIdx.x == 0;
+  float4 dbp = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 ra[NLD], rb[NLD];
+
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NLD; i++) {
+      const int idx = t + 256 * i;
+      if (AT) {                             // A[k][m]: k = idx / 8, columns m0 + 4 (idx % 8)
+        const int k = k0 + (idx >> 3), c = m0 + 4 * (idx & 7);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < k_end) {
+          v = load4(a.A + (size_t)k * a.lda, c, a.M, a_vec);
+          if (a.Amask) v = relu_mask(v, load4(a.Amask + (size_t)k * a.ldmask, c, a.M, a_vec));
+        }
+        ra[i] = v;
+        if (want_db) { dbp.x += v.x; dbp.y += v.y; dbp.z += v.z; dbp.w += v.w; }
+      } else {                              // A[m][k]: m = idx % 32, k = k0 + 4 (idx / 32)
+        const int m = m0 + (idx & 31), c = k0 + 4 * (idx >> 5);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < a.M) {
+          v = load4(a.A + (size_t)m * a.lda, c, k_end, a_vec);
+          if (a.Amask) v = relu_mask(v, load4(a.Amask + (size_t)m * a.ldmask, c, k_end, a_vec));
+        }
+        ra[i] = v;
+      }
+      if (BTR) {
+        const int k = k0 + (idx >> 3), c = n0 + 4 * (idx & 7);
+        rb[i] = k < k_end ? load4(a.B + (size_t)k * a.ldb, c, a.N, b_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        const int n = n0 + (idx & 31), c = k0 + 4 * (idx >> 5);
+        rb[i] = n < a.N ? load4(a.B + (size_t)n * a.ldb, c, k_end, b_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLD; i++) {
+      const int idx = t + 256 * i;
+      if (AT) *reinterpret_cast<float4*>(&As[idx >> 3][4 * (idx & 7)]) = ra[i];
+      else { const int k = 4 * (idx >> 5), m = idx & 31; As[k][m] = ra[i].x; As[k + 1][m] = ra[i].y; As[k + 2][m] = ra[i].z; As[k + 3][m] = ra[i].w; }
+      if (BTR) *reinterpret_cast<float4*>(&Bs[idx >> 3][4 * (idx & 7)]) = rb[i];
+      else { const int k = 4 * (idx >> 5), n = idx & 31; Bs[k][n] = rb[i].x; Bs[k + 1][n] = rb[i].y; Bs[k + 2][n] = rb[i].z; Bs[k + 3][n] = rb[i].w; }
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; e++) acc[e] = 0.f;
+  const int lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, lh = lane >> 5;             // MFMA operand lane: (row / column li, k parity lh)
+  load_tiles(k_begin);
+  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+    store_tiles();
+    __syncthreads();
+    if (k0 + BK < k_end) load_tiles(k0 + BK);        // in flight underneath this tile's arithmetic
+    const int kn = min(BK, k_end - k0);              // rows kn .. BK - 1 of the tiles are zero (load_tiles): harmless
+    const int kw = wave * (BK / 4);
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; kk += 2)
+      if (kw + kk < kn)                              // wave-uniform: skip the all-zero tail of a short contraction
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kw + kk + lh][li], Bs[kw + kk + lh][li], acc, 0, 0, 0);
+    __syncthreads();
+  }
+  float dbv = 0.f;         // bias gradient: this thread summed four columns of the k rows it staged; fold the 32 k-row groups
+  if (want_db) {
+    float* red = &Bs[0][0];                                   // [32 groups][32 columns], the tiles are dead now
+    *reinterpret_cast<float4*>(red + (t >> 3) * BT + 4 * (t & 7)) = dbp;
+    __syncthreads();
+    if (t < BT) {
+#pragma unroll
+      for (int r = 0; r < 32; r++) dbv += red[r * BT + t];
+    }
+  }
+  // the four waves' partial tiles meet in LDS (C layout of the instruction: column = lane & 31, row = (e & 3) + 8 (e >> 2)
+  // + 4 (lane >> 5)); thread (row = t / 8, four columns) then sums them in wave order and applies the epilogue
+  float* part = &As[0][0];                                    // [4][32][33] floats <= the two operand tiles (want_db is done with As)
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 16; e++) part[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * 33 + li] = acc[e];
+  __syncthreads();
+  const int r = t >> 3, c0 = 4 * (t & 7);
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    v[j] = (part[(0 * 32 + r) * 33 + c0 + j] + part[(1 * 32 + r) * 33 + c0 + j]) +
+           (part[(2 * 32 + r) * 33 + c0 + j] + part[(3 * 32 + r) * 33 + c0 + j]);
+  const int splits = gridDim.z;
+  if (splits > 1) {
+    const int ntiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
+    float* mine = a.ws + ((size_t)blockIdx.z * ntiles + tile) * TILE_WS;
+    *reinterpret_cast<float4*>(mine + r * BT + c0) = make_float4(v[0], v[1], v[2], v[3]);
+    if (want_db && t < BT) mine[BT * BT + t] = dbv;
+    __threadfence();
+    __syncthreads();
+    if (t == 0) s_last = atomicAdd(&a.counters[tile], 1u) == (unsigned)(splits - 1);
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    dbv = 0.f;
+    for (int sp = 0; sp < splits; sp++) {                      // fixed order: the sum does not depend on who arrived when
+      const float* p = a.ws + ((size_t)sp * ntiles + tile) * TILE_WS;
+      const float4 q = *reinterpret_cast<const float4*>(p + r * BT + c0);
+      v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+      if (want_db && t < BT) dbv += p[BT * BT + t];
+    }
+    if (t == 0) a.counters[tile] = 0;                         // left zero for the next call on this stream
+  }
+  if (want_db && t < BT && m0 + t < a.M) a.db[m0 + t] = dbv;
+  const int m = m0 + r;
+  if (m >= a.M) return;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int n = n0 + c0 + j;
+    if (n >= a.N) continue;
+    float o = v[j] + (a.bias ? a.bias[n] : 0.f);
+    if (a.relu) o = fmaxf(o, 0.f);
+    a.C[(size_t)m * a.ldc + n] = o;
+  }
+}
+
+// db alone (no weight gradient requested): column sums of the masked g, 64 columns per workgroup
+__global__ __launch_bounds__(256) void k_colsum(const float* g, int ldg, const float* mask, int ldm, float* db, int M, int N) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), r0 = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < N)
+    for (int m = r0; m < M; m += 4) {
+      const float v = g[(size_t)m * ldg + c];
+      s += (!mask || mask[(size_t)m * ldm + c] > 0.f) ? v : 0.f;
+    }
+  red[r0][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (threadIdx.x < 64 && c < N) db[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// Only the weight gradient (AT) splits its contraction, and only where that pays: the release / acquire fences of the last-
+// workgroup reduction cost ~10-15 us on the eight-XCD chip, more than a few extra k-steps (measured: a 256 x 256 gradient over
+// 700 rows is 20 us unsplit, 27 us in three splits; a 30 x 128 gradient over 2 100 rows 51 us unsplit, 17 us in six).  So: a
+// handful of tiles, or a contraction of a dozen k-tiles and more.  At least two k-tiles per split, never more (split, tile)
+// slots than the scratch holds.
+template <bool AT, bool BTR>
+int launch(SArgs a, float* ws, hipStream_t st) {
+  const int tm = (a.M + BT - 1) / BT, tn = (a.N + BT - 1) / BT, ntiles = tm * tn;
+  if (tm > 65535) return tfail(SGRL_ERR_LIMIT, "train gemm: too many row tiles");
+  const int ktiles = (a.K + BK - 1) / BK;
+  int splits = 1;
+  if (AT && ws && ktiles >= 4 && (ntiles <= 8 || (ktiles >= 12 && ntiles <= 128)))
+    splits = std::max(1, std::min({(256 + ntiles - 1) / ntiles, ktiles / 2, (int)(kWsTiles / ntiles)}));
+  a.kper = ((ktiles + splits - 1) / splits) * BK;
+  splits = (a.K + a.kper - 1) / a.kper;                       // no empty splits
+  a.ws = ws;
+  a.counters = ws ? reinterpret_cast<unsigned*>(ws + kWsTiles * TILE_WS) : nullptr;
+  hipLaunchKernelGGL((k_sgemm<AT, BTR>), dim3(tn, tm, splits), dim3(256), 0, st, a);
+  if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "train gemm: kernel launch failed");
+  return SGRL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sgrl_train_last_error(void) { return g_train_err.c_str(); }
+
+int64_t sgrl_train_ws_floats(void) { return kWsTiles * TILE_WS + kCounters; }
+
+int sgrl_linear_forward(const float* x, int ldx, const float* w, int ldw, const float* bias, float* y, int ldy, int M, int N,
+                        int K, int relu, void* stream) {
+  if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldw < K || ldy < N)
+    return tfail(SGRL_ERR_ARG, "sgrl_linear_forward: bad argument");
+  SArgs a{x, ldx, nullptr, 0, w, ldw, bias, relu ? 1 : 0, y, ldy, nullptr, M, N, K, 0, nullptr, nullptr};
+  return launch<false, false>(a, nullptr, (hipStream_t)stream);
+}
+
+int sgrl_linear_backward(const float* dy, int lddy, const float* y_relu, int ldyr, const float* x, int ldx, const float* w,
+                         int ldw, float* dx, int lddx, float* dw, int lddw, float* db, int M, int N, int K, float* ws,
+                         void* stream) {
+  if (!dy || M <= 0 || N <= 0 || K <= 0 || lddy < N || (y_relu && ldyr < N))
+    return tfail(SGRL_ERR_ARG, "sgrl_linear_backward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (dx) {                 // dx[M][K] = g[M][N] . w[N][K]: contraction N, contiguous in g, the row index of w
+    if (!w || ldw < K || lddx < K) return tfail(SGRL_ERR_ARG, "sgrl_linear_backward: bad weight / dx argument");
+    SArgs a{dy, lddy, y_relu, ldyr, w, ldw, nullptr, 0, dx, lddx, nullptr, M, K, N, 0, nullptr, nullptr};
+    const int rc = launch<false, true>(a, nullptr, st);
+    if (rc != SGRL_OK) return rc;
+  }
+  if (dw) {                 // dw[N][K] = g^T . x: contraction M, the row index of both operands; db rides along
+    if (!x || ldx < K || lddw < K) return tfail(SGRL_ERR_ARG, "sgrl_linear_backward: bad input / dw argument");
+    SArgs a{dy, lddy, y_relu, ldyr, x, ldx, nullptr, 0, dw, lddw, db, N, K, M, 0, nullptr, nullptr};
+    const int rc = launch<true, true>(a, ws, st);
+    if (rc != SGRL_OK) return rc;
+  } else if (db) {
+    hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64), dim3(256), 0, st, dy, lddy, y_relu, ldyr, db, M, N);
+    if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_colsum launch failed");
+  }
+  return SGRL_OK;
+}
+
+}  // extern "C"

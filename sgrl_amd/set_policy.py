@@ -20,8 +20,19 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import train_ops
+
 G_NUM = 8          # 3-vectors per limb observation (reference SEActor.py:205)
 Z_DIM = 32         # invariant channel count (30 projected + gravity + direction)
+
+
+class Linear(nn.Linear):
+    """torch.nn.Linear (same parameters, same state_dict keys) whose differentiable GPU path -- forward, input gradient,
+    weight / bias gradient -- runs on this library's small-product kernels (train_ops.linear, csrc/train_gemm.hip); `relu`
+    folds the activation that follows the layer into the product's epilogue and its mask into the backward products."""
+
+    def forward(self, x, relu=False):
+        return train_ops.linear(x, self.weight, self.bias, relu)
 
 
 class ConcatPositionalEmbedding(nn.Module):
@@ -42,7 +53,7 @@ def _invariants(x, gdir, proj, lin1, lin2):
     z = torch.cat([proj(x), gdir], dim=-1)
     gram = torch.einsum("blsa,blsc->blac", z, z)
     fn = gram.flatten(-2).norm(dim=-1, keepdim=True) + 1.0
-    return lin2(F.relu(lin1(gram.flatten(-2)))), fn
+    return lin2(lin1(gram.flatten(-2), relu=True)), fn
 
 
 class SubequivariantAttention(nn.Module):
@@ -54,19 +65,19 @@ class SubequivariantAttention(nn.Module):
         self.embed_dim, self.num_heads = embed_dim, num_heads
         self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
         self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
-        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        self.out_proj = Linear(embed_dim, embed_dim)
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.zeros_(self.out_proj.bias)
         e2 = 2 * embed_dim
-        self.q_proj = nn.Linear(e2, e2)
-        self.k_proj = nn.Linear(e2, e2)
-        self.v_proj = nn.Linear(e2, e2)
-        self.vg_proj = nn.Linear(embed_dim, e2 - 2 * num_heads, bias=False)
-        self.ng_out = nn.Linear(e2, embed_dim)
-        self.g_out = nn.Linear(e2, embed_dim, bias=False)
-        self.g_proj = nn.Linear(embed_dim, Z_DIM - 2, bias=False)
-        self.linear_g1 = nn.Linear(Z_DIM * Z_DIM, e2)
-        self.linear_g2 = nn.Linear(e2, embed_dim)
+        self.q_proj = Linear(e2, e2)
+        self.k_proj = Linear(e2, e2)
+        self.v_proj = Linear(e2, e2)
+        self.vg_proj = Linear(embed_dim, e2 - 2 * num_heads, bias=False)
+        self.ng_out = Linear(e2, embed_dim)
+        self.g_out = Linear(e2, embed_dim, bias=False)
+        self.g_proj = Linear(embed_dim, Z_DIM - 2, bias=False)
+        self.linear_g1 = Linear(Z_DIM * Z_DIM, e2)
+        self.linear_g2 = Linear(e2, embed_dim)
 
     def forward(self, g, ng, gdir, bias=None):
         B, L = ng.shape[:2]
@@ -94,17 +105,17 @@ class SubequivariantEncoderLayer(nn.Module):
     def __init__(self, d_model, nhead, dim_feedforward):
         super().__init__()
         self.self_attn = SubequivariantAttention(d_model, nhead)
-        self.linear1 = nn.Linear(2 * d_model, dim_feedforward)
-        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.linear1 = Linear(2 * d_model, dim_feedforward)
+        self.linear2 = Linear(dim_feedforward, d_model)
         self.norm1 = nn.LayerNorm(d_model)
         self.norm2 = nn.LayerNorm(d_model)
-        self.g_proj2 = nn.Linear(d_model, Z_DIM - 2, bias=False)
-        self.g_proj3 = nn.Linear(d_model, Z_DIM - 2, bias=False)
-        self.linear_g1 = nn.Linear(Z_DIM * Z_DIM, dim_feedforward)
-        self.linear_g2 = nn.Linear(dim_feedforward, d_model)
-        self.linear3 = nn.Linear(2 * d_model, dim_feedforward)
-        self.linear4 = nn.Linear(dim_feedforward, Z_DIM * Z_DIM)
-        self.linear5 = nn.Linear(Z_DIM, d_model, bias=False)
+        self.g_proj2 = Linear(d_model, Z_DIM - 2, bias=False)
+        self.g_proj3 = Linear(d_model, Z_DIM - 2, bias=False)
+        self.linear_g1 = Linear(Z_DIM * Z_DIM, dim_feedforward)
+        self.linear_g2 = Linear(dim_feedforward, d_model)
+        self.linear3 = Linear(2 * d_model, dim_feedforward)
+        self.linear4 = Linear(dim_feedforward, Z_DIM * Z_DIM)
+        self.linear5 = Linear(Z_DIM, d_model, bias=False)
 
     def forward(self, g, ng, gdir, bias=None):
         g1, ng1 = self.self_attn(g, ng, gdir, bias)
@@ -112,10 +123,10 @@ class SubequivariantEncoderLayer(nn.Module):
         ng = self.norm1(ng + ng1)
         inv, fn = _invariants(g1, gdir, self.g_proj2, self.linear_g1, self.linear_g2)
         c = torch.cat([inv, ng], dim=-1)
-        mat = (self.linear4(F.relu(self.linear3(c))) / fn).view(*ng.shape[:2], Z_DIM, Z_DIM)
+        mat = (self.linear4(self.linear3(c, relu=True)) / fn).view(*ng.shape[:2], Z_DIM, Z_DIM)
         z3 = torch.cat([self.g_proj3(g1), gdir], dim=-1)
         g = g + self.linear5(torch.einsum("blsa,blac->blsc", z3, mat))
-        ng = self.norm2(ng + self.linear2(F.relu(self.linear1(c))) / fn)
+        ng = self.norm2(ng + self.linear2(self.linear1(c, relu=True)) / fn)
         return g, ng
 
 
@@ -128,7 +139,7 @@ class RepeatTransformerEncoder(nn.Module):
         self.num_layers = num_layers
         self.norm = norm
         self.nhead = nhead
-        self.rel_encoder = nn.Linear(d_rel, nhead)
+        self.rel_encoder = Linear(d_rel, nhead)
 
     def forward(self, g, ng, gdir, pos, rel):
         ng = ng + pos.unsqueeze(0)
@@ -153,24 +164,24 @@ class TransformerModel(nn.Module):
             layer, nlayers, nhead, norm=nn.LayerNorm(ninp) if transformer_norm else None, d_rel=rel_size)
         self.g_num = G_NUM
         ng_feature_size = feature_size - 3 * G_NUM
-        self.g_encoder = nn.Linear(G_NUM, ninp, bias=False)
-        self.encoder = nn.Linear(ng_feature_size, ninp)
+        self.g_encoder = Linear(G_NUM, ninp, bias=False)
+        self.encoder = Linear(ng_feature_size, ninp)
         self.ninp = ninp
         self.ninp_att = ninp
         self.condition_decoder = condition_decoder
-        self.gg_proj = nn.Linear(ninp + G_NUM, Z_DIM - 2, bias=False)
-        self.linear1_g = nn.Linear(Z_DIM * Z_DIM, ninp)
-        self.linear2_g = nn.Linear(ninp, ninp)
-        self.linear1_ng = nn.Linear(ninp + ng_feature_size, ninp)
-        self.linear2_ng = nn.Linear(ninp, ninp)
+        self.gg_proj = Linear(ninp + G_NUM, Z_DIM - 2, bias=False)
+        self.linear1_g = Linear(Z_DIM * Z_DIM, ninp)
+        self.linear2_g = Linear(ninp, ninp)
+        self.linear1_ng = Linear(ninp + ng_feature_size, ninp)
+        self.linear2_ng = Linear(ninp, ninp)
         self.output_size = output_size
         if output_size == 1:
-            self.decoder_ng = nn.Linear(2 * ninp, output_size)
+            self.decoder_ng = Linear(2 * ninp, output_size)
         else:
-            self.decoder_g = nn.Linear(Z_DIM, 1, bias=False)
-            self.linear1_m = nn.Linear(2 * ninp, 2 * ninp)
-            self.linear2_m = nn.Linear(2 * ninp, Z_DIM * Z_DIM)
-            self.g_proj = nn.Linear(ninp + G_NUM, Z_DIM - 2, bias=False)
+            self.decoder_g = Linear(Z_DIM, 1, bias=False)
+            self.linear1_m = Linear(2 * ninp, 2 * ninp)
+            self.linear2_m = Linear(2 * ninp, Z_DIM * Z_DIM)
+            self.g_proj = Linear(ninp + G_NUM, Z_DIM - 2, bias=False)
         with torch.no_grad():
             self.encoder.weight.uniform_(-0.1, 0.1)
             self.g_encoder.weight.uniform_(-0.1, 0.1)
@@ -189,11 +200,11 @@ class TransformerModel(nn.Module):
         out_ng = torch.cat([n0, ng], dim=-1)
         out_g = torch.cat([g0, g], dim=-1)
         inv, fn = _invariants(out_g, gdir, self.gg_proj, self.linear1_g, self.linear2_g)
-        hng = self.linear2_ng(F.relu(self.linear1_ng(out_ng)))
+        hng = self.linear2_ng(self.linear1_ng(out_ng, relu=True))
         c = torch.cat([inv, hng], dim=-1)
         if self.output_size == 1:
             return self.decoder_ng(c) / fn
-        mat = (self.linear2_m(F.relu(self.linear1_m(c))) / fn).view(B, L, Z_DIM, Z_DIM)
+        mat = (self.linear2_m(self.linear1_m(c, relu=True)) / fn).view(B, L, Z_DIM, Z_DIM)
         zh = torch.cat([self.g_proj(out_g), gdir], dim=-1)
         vec = self.decoder_g(torch.einsum("blsa,blac->blsc", zh, mat)).squeeze(-1)   # [B,L,3]
         return torch.einsum("blsk,bls->blk", g0[..., 5:8], vec)

@@ -11,6 +11,7 @@ updates (`target_param.data.copy_`, common/functional.py:7-10).
 
 Pinned by tests/golden/td3_update.npz, produced by executing the reference's own `Agent.update`
 (tools/capture_golden_update.py)."""
+import os
 import types
 
 import torch
@@ -21,10 +22,70 @@ from .set_policy import SECritic, SEPolicy, default_args
 
 
 def soft_update_network(source_network, target_network, tau):
-    """target <- tau * source + (1 - tau) * target, parameter by parameter (reference common/functional.py:7-10)."""
+    """target <- tau * source + (1 - tau) * target for every parameter (reference common/functional.py:7-10), written through
+    `.data` like the reference does.  On the GPU the ~300 tensors of a network pair are updated by two multi-tensor launches
+    instead of four small kernels per tensor (the per-tensor loop was 40 % of all launches of a TD3 update); per element the
+    same two products and one sum."""
     with torch.no_grad():
-        for target_param, local_param in zip(target_network.parameters(), source_network.parameters()):
-            target_param.data.copy_(tau * local_param.data + (1 - tau) * target_param.data)
+        targets = [p.data for p in target_network.parameters()]
+        sources = [p.data for p in source_network.parameters()]
+        if targets and targets[0].is_cuda:
+            torch._foreach_mul_(targets, 1 - tau)
+            torch._foreach_add_(targets, torch._foreach_mul(sources, tau))
+        else:
+            for t, l in zip(targets, sources):
+                t.copy_(tau * l + (1 - tau) * t)
+
+
+def adam_step(opt):
+    """`opt.step()` for a torch.optim.Adam whose groups are `capturable` (step counters on the device: GraphedUpdates), on the
+    optimizer's OWN state tensors (state_dict unchanged).  torch's capturable multi-tensor path divides every parameter's
+    tensors by per-parameter 0-dim bias-correction tensors, which its foreach kernels cannot batch: ~3 small launches per
+    parameter, ~900 per TD3 update, a third of the update's launches.  Parameters that have always been stepped together share
+    one step count, so here the two bias corrections are computed ONCE per such class (from its first counter; the classes
+    are kept on the host: a parameter that skipped a step -- no gradient -- forms its own) and applied as single scalar
+    tensors: a dozen multi-tensor launches per optimizer.  Same formula, term for term, as torch.optim.Adam (no weight decay,
+    no amsgrad, not maximising -- the reference's optimizers, agent.py:96-115)."""
+    for group in opt.param_groups:
+        if not group.get("capturable", False) or group.get("weight_decay", 0) != 0 or group.get("amsgrad", False) or \
+                group.get("maximize", False):
+            return opt.step()
+    host = opt.__dict__.setdefault("_sgrl_step_class", {})       # id(param) -> number of steps taken, as far as the host knows
+    for group in opt.param_groups:
+        params = [p for p in group["params"] if p.grad is not None]
+        if not params:
+            continue
+        beta1, beta2 = group["betas"]
+        classes = {}
+        for p in params:
+            st = opt.state[p]
+            if len(st) == 0:        # torch.optim.Adam's lazy state initialisation (capturable: the counter lives on the device)
+                st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                host[id(p)] = 0
+            elif id(p) not in host:  # state loaded from a checkpoint: read the counter once (never during a capture)
+                host[id(p)] = int(st["step"].item())
+            classes.setdefault(host[id(p)], []).append(p)
+            host[id(p)] += 1
+        with torch.no_grad():
+            for members in classes.values():
+                grads = [p.grad for p in members]
+                steps = [opt.state[p]["step"] for p in members]
+                exp_avgs = [opt.state[p]["exp_avg"] for p in members]
+                exp_avg_sqs = [opt.state[p]["exp_avg_sq"] for p in members]
+                torch._foreach_add_(steps, 1)
+                torch._foreach_lerp_(exp_avgs, grads, 1 - beta1)
+                torch._foreach_mul_(exp_avg_sqs, beta2)
+                torch._foreach_addcmul_(exp_avg_sqs, grads, grads, 1 - beta2)
+                step = steps[0]
+                neg_step_size = (group["lr"] / (1 - beta1 ** step)).neg()
+                bias_correction2_sqrt = (1 - beta2 ** step).sqrt()
+                denom = torch._foreach_sqrt(exp_avg_sqs)
+                torch._foreach_div_(denom, bias_correction2_sqrt)
+                torch._foreach_add_(denom, group["eps"])
+                torch._foreach_div_(denom, neg_step_size)
+                torch._foreach_addcdiv_([p.data for p in members], exp_avgs, denom)
 
 
 def default_train_args(**over):
@@ -111,9 +172,12 @@ class Agent(nn.Module):
         critic_loss.backward()
         if args.grad_clipping_value > 0:
             torch.nn.utils.clip_grad_norm_(self.critic.parameters(), args.grad_clipping_value)
-        self.critic_optimizer.step()
+        adam_step(self.critic_optimizer)
         rmean, rvar = torch.mean(reward_batch), torch.var(reward_batch)
-        loss_dict = {"loss/critic_loss": critic_loss, "misc/train_reward_mean": rmean if lazy_stats else rmean.item(),
+        # the losses are returned DETACHED: a loss that keeps its autograd graph alive also keeps the parameters' AccumulateGrad
+        # nodes -- and the stream they were created on -- alive into the next update; a hipGraph captured on another stream then
+        # records a cross-stream hand-over per parameter (a 2 500-node update graph cost 39 ms to launch instead of 19)
+        loss_dict = {"loss/critic_loss": critic_loss.detach(), "misc/train_reward_mean": rmean if lazy_stats else rmean.item(),
                      "misc/train_reward_var": rvar if lazy_stats else rvar.item()}
         if it % args.policy_freq == 0:       # delayed policy update
             actor_loss = -self.critic.Q1(obs_batch, self.actor(obs_batch)).mean()
@@ -121,9 +185,9 @@ class Agent(nn.Module):
             actor_loss.backward()
             if args.grad_clipping_value > 0:
                 torch.nn.utils.clip_grad_norm_(self.actor.parameters(), args.grad_clipping_value)
-            self.actor_optimizer.step()
+            adam_step(self.actor_optimizer)
             self.try_update_target_network()
-            loss_dict.update({"loss/actor_loss": actor_loss})
+            loss_dict.update({"loss/actor_loss": actor_loss.detach()})
         return loss_dict
 
     def try_update_target_network(self):
@@ -219,8 +283,13 @@ class GraphedUpdates(object):
         if flag not in sl["graphs"]:
             self.agent.change_morphology(graph)
             g = torch.cuda.CUDAGraph()
+            dump = os.environ.get("SGRL_GRAPH_DUMP")      # diagnostics: <dir> receives one .dot file per captured graph
+            if dump:
+                g.enable_debug_mode()
             with torch.cuda.graph(g):
                 sl["out"][flag] = self.agent.update(sl["batch"], flag, noise=sl["noise"], lazy_stats=True)
+            if dump:
+                g.debug_dump(os.path.join(dump, "update_%s_flag%d.dot" % (key, flag)))
             sl["graphs"][flag] = g           # capturing records the work without running it
         sl["graphs"][flag].replay()
         return sl["out"][flag]

@@ -25,8 +25,9 @@ def so():
 
 def test_exports_every_declared_symbol(so):
     names = _declared("sgrl.h")
-    if os.path.exists(os.path.join(REPO, "include", "sgrl_set.h")):
-        names += _declared("sgrl_set.h")
+    for extra in ("sgrl_set.h", "sgrl_train.h"):
+        if os.path.exists(os.path.join(REPO, "include", extra)):
+            names += _declared(extra)
     assert len(names) >= 13
     for n in names:
         assert hasattr(so, n), n

@@ -180,3 +180,30 @@ def test_smp_agent_updates():
     assert len(list(agent.actor.parameters())) == n_params          # the per-limb module list shares ONE module's parameters
     assert any(float((p - q).abs().max()) > 0 for p, q in zip(agent.actor.parameters(), before))
     assert agent.select_action(batch["obs"][0].numpy()).shape == (1, 3 * L)
+
+
+def test_adam_step_follows_torch_adam():
+    """td3.adam_step (shared bias corrections, a dozen multi-tensor launches) against torch.optim.Adam, on the optimizer's own
+    state: same parameters to rounding, same step counters, state_dict layout untouched."""
+    from sgrl_amd.td3 import adam_step
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2, 2, 2))]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    o1, o2 = torch.optim.Adam(ps, lr=1e-3), torch.optim.Adam(qs, lr=1e-3)
+    for g in o2.param_groups:
+        g["capturable"] = True
+    for it in range(6):
+        for p, q in zip(ps, qs):
+            g = torch.randn_like(p)
+            p.grad, q.grad = g.clone(), (g.clone() if not (it == 0 and q is qs[2]) else None)     # a parameter without a gradient is skipped
+            if q.grad is None:
+                p.grad = None
+        o1.step()
+        adam_step(o2)
+    assert max(float((p.detach() - q.detach()).abs().max()) for p, q in zip(ps, qs)) < 5e-7
+    assert [float(o2.state[q]["step"]) for q in qs] == [6.0, 6.0, 5.0]
+    assert set(o2.state_dict()["state"][0].keys()) == set(o1.state_dict()["state"][0].keys())
+    o3 = torch.optim.Adam([torch.nn.Parameter(torch.randn(3))], lr=1e-3)     # not capturable: plain opt.step()
+    o3.param_groups[0]["params"][0].grad = torch.ones(3)
+    adam_step(o3)
+    assert float(o3.state[o3.param_groups[0]["params"][0]]["step"]) == 1.0

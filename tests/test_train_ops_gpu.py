@@ -1,0 +1,93 @@
+"""csrc/train_gemm.hip through sgrl_amd/train_ops.linear: forward, input / weight / bias gradients against float64 PyTorch on
+the shapes of a batch-100 TD3 update (ragged sizes, unaligned rows, split contractions, ReLU masks), bit-reproducible."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # (M rows, K in, N out, bias, relu)
+    (700, 256, 256, True, True), (700, 1024, 256, True, True), (700, 256, 1024, True, False), (2100, 128, 30, False, False),
+    (2100, 128, 252, False, False), (2100, 136, 30, False, False), (700, 17, 128, True, False), (700, 145, 128, True, True),
+    (1400, 256, 768, True, False), (49, 3, 2, True, False), (4200, 32, 128, False, False), (1, 256, 128, True, True),
+    (65, 20, 128, True, False), (300, 256, 1, True, False),
+]
+
+
+@pytest.mark.parametrize("M,K,N,has_bias,relu", SHAPES)
+def test_linear_matches_float64(M, K, N, has_bias, relu):
+    from sgrl_amd import train_ops
+    g = torch.Generator().manual_seed(M * 7 + K * 3 + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / np.sqrt(K)
+    b = torch.randn(N, generator=g) if has_bias else None
+    dy = torch.randn(M, N, generator=g)
+    # float64 reference on the CPU
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    br = b.double().requires_grad_() if has_bias else None
+    yr = torch.nn.functional.linear(xr, wr, br)
+    yr = torch.relu(yr) if relu else yr
+    yr.backward(dy.double())
+    xd, wd = x.cuda().requires_grad_(), w.cuda().requires_grad_()
+    bd = b.cuda().requires_grad_() if has_bias else None
+    y = train_ops.linear(xd, wd, bd, relu)
+    assert y.grad_fn is not None and type(y.grad_fn).__name__.startswith("_LinearFn")
+    y.backward(dy.cuda())
+    scale = float(yr.abs().max()) + 1.0
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) < 3e-6 * scale
+    assert float((xd.grad.cpu().double() - xr.grad).abs().max()) < 3e-6 * (float(xr.grad.abs().max()) + 1.0)
+    assert float((wd.grad.cpu().double() - wr.grad).abs().max()) < 3e-6 * (float(wr.grad.abs().max()) + 1.0) * np.sqrt(M / 64 + 1)
+    if has_bias:
+        assert float((bd.grad.cpu().double() - br.grad).abs().max()) < 3e-6 * (float(br.grad.abs().max()) + 1.0) * np.sqrt(M / 64 + 1)
+    # reproducible to the bit (split contractions are reduced in a fixed order)
+    xd2, wd2 = x.cuda().requires_grad_(), w.cuda().requires_grad_()
+    bd2 = b.cuda().requires_grad_() if has_bias else None
+    y2 = train_ops.linear(xd2, wd2, bd2, relu)
+    y2.backward(dy.cuda())
+    assert torch.equal(y, y2) and torch.equal(xd.grad, xd2.grad) and torch.equal(wd.grad, wd2.grad)
+
+
+def test_strided_inputs_frozen_inputs_and_no_grad_fallback():
+    from sgrl_amd import train_ops
+    torch.manual_seed(3)
+    base = torch.randn(50, 7, 8, 3, device="cuda")
+    x = base.transpose(-1, -2)                      # [50, 7, 3, 8], non-contiguous (the g_encoder input of the SET model)
+    w = torch.randn(128, 8, device="cuda", requires_grad=True)
+    y = train_ops.linear(x, w)                      # x does not require grad: no input gradient is computed
+    assert y.shape == (50, 7, 3, 128)
+    y.sum().backward()
+    ref = torch.nn.functional.linear(x.double().cpu(), w.detach().double().cpu())
+    assert float((y.detach().cpu().double() - ref).abs().max()) < 1e-5
+    assert float((w.grad.cpu().double() - x.double().cpu().reshape(-1, 8).sum(0)[None].expand(128, 8)).abs().max()) < 1e-3
+    with torch.no_grad():
+        y0 = train_ops.linear(x, w)
+    assert y0.grad_fn is None and float((y0 - y.detach()).abs().max()) < 1e-4
+
+
+def test_set_policy_gradients_agree_with_the_vendor_gemm_path():
+    """The whole differentiable SET actor + critic: gradients through train_ops.linear vs through F.linear."""
+    from oracle.formula import synth_obs
+    from sgrl_amd import graph as G, mjcf, train_ops
+    from sgrl_amd.rollout import TRAV
+    from sgrl_amd.td3 import Agent, default_train_args
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    agent = Agent(default_train_args(), device=dev, use_hip=False)
+    m = mjcf.load_asset("3d_humanoid_9_full")
+    agent.change_morphology(G.getGraphDict(m.parents, TRAV, [], device=dev))
+    L = m.num_limbs
+    obs = torch.from_numpy(synth_obs(L, 20, 4).astype(np.float32)).to(dev)
+    grads = []
+    for enabled in (True, False):
+        train_ops.ENABLED = enabled
+        try:
+            agent.actor.zero_grad(); agent.critic.zero_grad()
+            q1 = agent.critic.Q1(obs, agent.actor(obs))
+            (-q1.mean()).backward()
+            grads.append([p.grad.detach().clone() for p in list(agent.actor.parameters()) + list(agent.critic.parameters())
+                          if p.grad is not None])
+        finally:
+            train_ops.ENABLED = True
+    assert len(grads[0]) == len(grads[1]) and len(grads[0]) > 100
+    for a, b in zip(grads[0], grads[1]):
+        assert float((a - b).abs().max()) <= 2e-4 * (float(b.abs().max()) + 1e-6) + 1e-7

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""One morphology's TD3 update in isolation (batch 100, synthetic batch): eager timing and, under rocprofv3, the per-kernel
+decomposition of the update's GPU time.  Usage: update_profile.py [morphology] [iters]; SGRL_GRAPH_UPDATES=1 replays hipGraphs."""
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from oracle.formula import synth_obs
+from sgrl_amd import graph as G, mjcf
+from sgrl_amd.rollout import TRAV
+from sgrl_amd.td3 import Agent, GraphedUpdates, default_train_args
+name = sys.argv[1] if len(sys.argv) > 1 else "3d_walker_7_full"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+agent = Agent(default_train_args(), device=dev)
+m = mjcf.load_asset(name)
+gd = G.getGraphDict(m.parents, TRAV, [], device=dev)
+agent.change_morphology(gd)
+agent.models2train()
+B, L = 100, m.num_limbs
+batch = {"obs": torch.from_numpy(synth_obs(L, B, 1).astype(np.float32)).to(dev), "next_obs": torch.from_numpy(synth_obs(L, B, 2).astype(np.float32)).to(dev),
+         "action": (torch.rand(B, 3 * L, device=dev) * 2 - 1), "reward": torch.randn(B, 1, device=dev), "done": torch.zeros(B, 1, device=dev)}
+graphed = GraphedUpdates(agent, B) if os.environ.get("SGRL_GRAPH_UPDATES", "0") == "1" else None
+if graphed is not None:
+    graphed.warm(0, gd, L, batch, iters=3)
+    for it in range(4):
+        graphed.update(0, gd, L, batch, it)
+else:
+    for it in range(4):
+        agent.update(batch, it, lazy_stats=True)
+torch.cuda.synchronize()
+t0 = time.time()
+for it in range(iters):
+    if graphed is not None:
+        graphed.update(0, gd, L, batch, it)
+    else:
+        agent.update(batch, it, lazy_stats=True)
+torch.cuda.synchronize()
+print(json.dumps({"morphology": name, "limbs": L, "batch": B, "graphed": graphed is not None, "iters": iters,
+                  "ms_per_update": round((time.time() - t0) / iters * 1e3, 3)}))
