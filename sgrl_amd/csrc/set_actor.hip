@@ -654,9 +654,15 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   const int lnb = (N + 3) / 4;
   // Independent GEMM chains go to the side stream: fork() makes it wait for everything issued so far on `st`, join()
   // makes `st` wait for it.  The chains' store-heavy epilogues and partial last tile waves overlap each other.
-  hipStream_t sd = s->side;
-  auto fork = [&]() { (void)hipEventRecord(s->ev_fork, st); (void)hipStreamWaitEvent(sd, s->ev_fork, 0); };
-  auto join = [&]() { (void)hipEventRecord(s->ev_join, sd); (void)hipStreamWaitEvent(st, s->ev_join, 0); };
+  // While `st` is being captured into a hipGraph (the TD3 update graphs, td3.GraphedUpdates: batches of 100 environments,
+  // where every kernel is far too small to gain from overlap) everything stays on ONE stream: a graph with cross-stream
+  // forks costs ~7 us of hipGraphLaunch CPU time per node on this ROCm, a single-stream graph ~0.4 us.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cap);
+  const bool one_stream = cap != hipStreamCaptureStatusNone;
+  hipStream_t sd = one_stream ? st : s->side;
+  auto fork = [&]() { if (!one_stream) { (void)hipEventRecord(s->ev_fork, st); (void)hipStreamWaitEvent(sd, s->ev_fork, 0); } };
+  auto join = [&]() { if (!one_stream) { (void)hipEventRecord(s->ev_join, sd); (void)hipStreamWaitEvent(st, s->ev_join, 0); } };
 #define GS(...) do { rc = launch_gemm(sd, __VA_ARGS__); if (rc != SGRL_OK) return rc; } while (0)
   for (int l = 0; l < SGRL_SET_LAYERS; l++) {
     // --- attention ---
@@ -680,8 +686,10 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
     G(s->cat, 256, s->WL(l, SGRL_SET_L3_W), 256, s->WL(l, SGRL_SET_L3_B), s->t256, 256, N, 256, 256, EPI_RELU);
     // linear2 carries the scalar stream's second residual + norm2 in its epilogue (ng rewritten in place): it must not start
     // before linear3 -- the other reader of cat = [inv | ng] -- is done
-    (void)hipEventRecord(s->ev_l3, st);
-    (void)hipStreamWaitEvent(sd, s->ev_l3, 0);
+    if (!one_stream) {
+      (void)hipEventRecord(s->ev_l3, st);
+      (void)hipStreamWaitEvent(sd, s->ev_l3, 0);
+    }
     rc = launch_gemm_ln(sd, s->t256b, 256, s->WL(l, SGRL_SET_L2_W), 256, s->WL(l, SGRL_SET_L2_B), N, 256, s->fn, ng, 256,
                         s->WL(l, SGRL_SET_N2_W), s->WL(l, SGRL_SET_N2_B));
     if (rc != SGRL_OK) return rc;

@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <string>
+#include <type_traits>
 
 #include "../../include/sgrl.h"
 #include "../../include/sgrl_train.h"
@@ -87,9 +88,10 @@ __global__ __launch_bounds__(256) void k_sgemm(SArgs a) {
   const bool b_vec = (a.ldb & 3) == 0 && aligned16(a.B);
   const bool want_db = AT && a.db != nullptr && blockIdx.x == 0;
   float4 dbp = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 ra[NLD], rb[NLD];
+  float4 ra[2][NLD], rb[2][NLD];               // global loads run TWO k-tiles ahead of the arithmetic
 
-  auto load_tiles = [&](int k0) {
+  auto load_tiles = [&](auto slot_c, int k0) __attribute__((always_inline)) {     // slot as a compile-time constant: the staging arrays stay in registers
+    constexpr int slot = decltype(slot_c)::value;
 #pragma unroll
     for (int i = 0; i < NLD; i++) {
       const int idx = t + 256 * i;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void k_sgemm(SArgs a) {
           v = load4(a.A + (size_t)k * a.lda, c, a.M, a_vec);
           if (a.Amask) v = relu_mask(v, load4(a.Amask + (size_t)k * a.ldmask, c, a.M, a_vec));
         }
-        ra[i] = v;
+        ra[slot][i] = v;
         if (want_db) { dbp.x += v.x; dbp.y += v.y; dbp.z += v.z; dbp.w += v.w; }
       } else {                              // A[m][k]: m = idx % 32, k = k0 + 4 (idx / 32)
         const int m = m0 + (idx & 31), c = k0 + 4 * (idx >> 5);
@@ -109,25 +111,27 @@ __global__ __launch_bounds__(256) void k_sgemm(SArgs a) {
           v = load4(a.A + (size_t)m * a.lda, c, k_end, a_vec);
           if (a.Amask) v = relu_mask(v, load4(a.Amask + (size_t)m * a.ldmask, c, k_end, a_vec));
         }
-        ra[i] = v;
+        ra[slot][i] = v;
       }
       if (BTR) {
         const int k = k0 + (idx >> 3), c = n0 + 4 * (idx & 7);
-        rb[i] = k < k_end ? load4(a.B + (size_t)k * a.ldb, c, a.N, b_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rb[slot][i] = k < k_end ? load4(a.B + (size_t)k * a.ldb, c, a.N, b_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
         const int n = n0 + (idx & 31), c = k0 + 4 * (idx >> 5);
-        rb[i] = n < a.N ? load4(a.B + (size_t)n * a.ldb, c, k_end, b_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rb[slot][i] = n < a.N ? load4(a.B + (size_t)n * a.ldb, c, k_end, b_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
   };
-  auto store_tiles = [&]() {
+  auto store_tiles = [&](auto slot_c) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slot_c)::value;
 #pragma unroll
     for (int i = 0; i < NLD; i++) {
       const int idx = t + 256 * i;
-      if (AT) *reinterpret_cast<float4*>(&As[idx >> 3][4 * (idx & 7)]) = ra[i];
-      else { const int k = 4 * (idx >> 5), m = idx & 31; As[k][m] = ra[i].x; As[k + 1][m] = ra[i].y; As[k + 2][m] = ra[i].z; As[k + 3][m] = ra[i].w; }
-      if (BTR) *reinterpret_cast<float4*>(&Bs[idx >> 3][4 * (idx & 7)]) = rb[i];
-      else { const int k = 4 * (idx >> 5), n = idx & 31; Bs[k][n] = rb[i].x; Bs[k + 1][n] = rb[i].y; Bs[k + 2][n] = rb[i].z; Bs[k + 3][n] = rb[i].w; }
+      const float4 va = ra[slot][i], vb = rb[slot][i];
+      if (AT) *reinterpret_cast<float4*>(&As[idx >> 3][4 * (idx & 7)]) = va;
+      else { const int k = 4 * (idx >> 5), m = idx & 31; As[k][m] = va.x; As[k + 1][m] = va.y; As[k + 2][m] = va.z; As[k + 3][m] = va.w; }
+      if (BTR) *reinterpret_cast<float4*>(&Bs[idx >> 3][4 * (idx & 7)]) = vb;
+      else { const int k = 4 * (idx >> 5), n = idx & 31; Bs[k][n] = vb.x; Bs[k + 1][n] = vb.y; Bs[k + 2][n] = vb.z; Bs[k + 3][n] = vb.w; }
     }
   };
 
@@ -136,11 +140,10 @@ __global__ __launch_bounds__(256) void k_sgemm(SArgs a) {
   for (int e = 0; e < 16; e++) acc[e] = 0.f;
   const int lane = t & 63, wave = t >> 6;
   const int li = lane & 31, lh = lane >> 5;             // MFMA operand lane: (row / column li, k parity lh)
-  load_tiles(k_begin);
-  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-    store_tiles();
+  auto body = [&](int k0, auto slot_c) __attribute__((always_inline)) {
+    store_tiles(slot_c);
     __syncthreads();
-    if (k0 + BK < k_end) load_tiles(k0 + BK);        // in flight underneath this tile's arithmetic
+    if (k0 + 2 * BK < k_end) load_tiles(slot_c, k0 + 2 * BK);   // in flight underneath this tile's and the next tile's arithmetic
     const int kn = min(BK, k_end - k0);              // rows kn .. BK - 1 of the tiles are zero (load_tiles): harmless
     const int kw = wave * (BK / 4);
 #pragma unroll
@@ -148,6 +151,15 @@ __global__ __launch_bounds__(256) void k_sgemm(SArgs a) {
       if (kw + kk < kn)                              // wave-uniform: skip the all-zero tail of a short contraction
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kw + kk + lh][li], Bs[kw + kk + lh][li], acc, 0, 0, 0);
     __syncthreads();
+  };
+  constexpr std::integral_constant<int, 0> S0{};
+  constexpr std::integral_constant<int, 1> S1{};
+  load_tiles(S0, k_begin);
+  if (k_begin + BK < k_end) load_tiles(S1, k_begin + BK);
+  {
+    int k0 = k_begin;
+    for (; k0 + BK < k_end; k0 += 2 * BK) { body(k0, S0); body(k0 + BK, S1); }
+    if (k0 < k_end) body(k0, S0);
   }
   float dbv = 0.f;         // bias gradient: this thread summed four columns of the k rows it staged; fold the 32 k-row groups
   if (want_db) {
