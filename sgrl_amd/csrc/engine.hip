@@ -157,6 +157,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #endif
 }
 
+// The step kernel for the LIGHT morphologies (nv <= kLightNv: walker_2/3/4, hopper_3/4): the same source with the register
+// solvers of the larger dof counts compiled out and a 168-register budget, i.e. three waves per SIMD = 12 workgroups per CU
+// instead of 8.  Their slabs (7..13 KB) leave the LDS half empty at 8 per CU, and the kernel is bound by the latency of its
+// dependent chains: throughput follows the number of resident environments.
+constexpr int kLightNv = 15;
+constexpr int kLightPerCu = 12;
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_env_step_light(BatchArgs a, StepOut out) {
+  const int env = __builtin_amdgcn_readfirstlane(a.block_env[blockIdx.x]);
+  SgrlModelView m; sgrl::Layout o; double* S; int32_t* I;
+  setup(a, env, &m, &o, &S, &I);
+  sgrl::HipWaveT<kLightNv> w;
+  const sgrl::StepIO io = make_io(a, out, env);
+  sgrl::env_step(w, m, o, S, I, io);
+}
+
 __global__ __launch_bounds__(64) void k_env_reset(BatchArgs a, StepOut out) {
   const int env = __builtin_amdgcn_readfirstlane(a.block_env[blockIdx.x]);
   SgrlModelView m; sgrl::Layout o; double* S; int32_t* I;
@@ -192,7 +207,7 @@ struct sgrl_engine {
   // Launch groups: morphologies whose LDS slab admits the same number of workgroups per CU share one launch (its
   // dynamic LDS = the group's largest slab), so a 23-morphology mix is not dragged to the occupancy of its biggest
   // member.  Groups run concurrently on their own streams, forked from / joined to the caller's stream by events.
-  struct Group { int first = 0, count = 0, lds = 0; hipStream_t stream = nullptr; hipEvent_t done = nullptr; };
+  struct Group { int first = 0, count = 0, lds = 0; bool light = false; hipStream_t stream = nullptr; hipEvent_t done = nullptr; };
   std::vector<Group> groups;
   hipEvent_t fork = nullptr;
   std::vector<int> morph_lds;
@@ -200,16 +215,17 @@ struct sgrl_engine {
 
 namespace {
 template <class K>
-int launch_groups(sgrl_engine* e, K kernel, const StepOut& out, hipStream_t user) {
+int launch_groups(sgrl_engine* e, K kernel_in, const StepOut& out, hipStream_t user, bool is_step = false) {
+  auto pick = [&](const sgrl_engine::Group& g) { return (is_step && g.light) ? k_env_step_light : kernel_in; };
   if (e->groups.size() == 1) {
-    hipLaunchKernelGGL(kernel, dim3(e->n_env), dim3(64), e->groups[0].lds, user, e->args, out);
+    hipLaunchKernelGGL(pick(e->groups[0]), dim3(e->n_env), dim3(64), e->groups[0].lds, user, e->args, out);
   } else {
     if (hipEventRecord(e->fork, user) != hipSuccess) return fail(SGRL_ERR_HIP, "hipEventRecord(fork) failed");
     for (auto& g : e->groups) {
       BatchArgs a = e->args;
       a.block_env = e->args.block_env + g.first;
       if (hipStreamWaitEvent(g.stream, e->fork, 0) != hipSuccess) return fail(SGRL_ERR_HIP, "hipStreamWaitEvent(fork) failed");
-      hipLaunchKernelGGL(kernel, dim3(g.count), dim3(64), g.lds, g.stream, a, out);
+      hipLaunchKernelGGL(pick(g), dim3(g.count), dim3(64), g.lds, g.stream, a, out);
       if (hipEventRecord(g.done, g.stream) != hipSuccess || hipStreamWaitEvent(user, g.done, 0) != hipSuccess)
         return fail(SGRL_ERR_HIP, "cannot join a launch group back to the caller's stream");
     }
@@ -313,6 +329,12 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
     std::vector<int32_t> order(e->n_env);
     for (int i = 0; i < e->n_env; i++) order[i] = i;
     std::vector<int> cost(n_morph), cls(n_morph);
+    // A batch made of light morphologies ONLY (few dofs, small slabs: walker_2/3/4, hopper_3/4) runs on k_env_step_light, three
+    // waves per SIMD: measured -20 % (8192 x walker_2: 1.96 -> 1.57 ms, walker_4: 2.74 -> 2.20 ms).  In a MIXED batch the light
+    // class as a second concurrent dispatch LOSES (walker mix 2.84 -> 3.18 ms, hopper++ 1.59 -> 1.78 ms): 168- and 235-register
+    // waves fragment the register file of a SIMD (1 heavy + 1 light instead of 3 light), so the light waves pay for their 31
+    // spilled registers without getting the occupancy -- mixed batches therefore stay on the one kernel.  SGRL_LIGHT=0: never.
+    bool light_batch = [] { const char* v = getenv("SGRL_LIGHT"); return !(v && v[0] == '0'); }();
     for (int k = 0; k < n_morph; k++) {
       cost[k] = ib[k][SGRL_H_NV];
       // LDS is handed out in 1280-byte granules (measured with tools/occupancy_probe.py: a 27 064-byte slab fits five
@@ -320,7 +342,9 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
       const int granule = 1280;
       int per_cu = (160 * 1024) / (((e->morph_lds[k] + granule - 1) / granule) * granule);
       cls[k] = per_cu > 8 ? 8 : per_cu;   // register budget (<= 256 VGPRs): two waves per SIMD = 8 workgroups per CU at most
+      light_batch = light_batch && ib[k][SGRL_H_NV] <= kLightNv && per_cu >= kLightPerCu;
     }
+    if (light_batch) for (int k = 0; k < n_morph; k++) cls[k] = kLightPerCu;
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
       const int mx = env_morph[x], my = env_morph[y];
       if (cls[mx] != cls[my]) return cls[mx] < cls[my];
@@ -339,6 +363,9 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
       int top = (c == c_min && c >= 6) ? c + 1 : c;
       // SGRL_GROUP_POLICY=0: never merge, =2: always merge adjacent classes (8 % faster on a cheetah-only batch)
       if (const char* pol = getenv("SGRL_GROUP_POLICY")) top = pol[0] == '0' ? c : (pol[0] == '2' ? c + 1 : top);
+      if (top >= kLightPerCu) top = kLightPerCu;            // the light class never merges with a heavier one ...
+      else if (top > 8) top = 8;                            // ... nor a heavier one with it
+      g.light = c == kLightPerCu;
       while (i < e->n_env && cls[env_morph[order[i]]] <= top) { g.lds = std::max(g.lds, e->morph_lds[env_morph[order[i]]]); i++; }
       // diagnostics only (tools/occupancy_sweep.py): SGRL_LDS_PAD=<bytes> inflates the dynamic LDS request to force fewer
       // resident workgroups per CU
@@ -383,7 +410,8 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
       hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_env_step), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
       hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_env_reset), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
       hipError_t a3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_env_refresh), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
-      if (a1 != hipSuccess || a2 != hipSuccess || a3 != hipSuccess) { sgrl_engine_destroy(e); return fail(SGRL_ERR_HIP, "cannot raise the dynamic LDS limit"); }
+      hipError_t a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_env_step_light), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
+      if (a1 != hipSuccess || a2 != hipSuccess || a3 != hipSuccess || a4 != hipSuccess) { sgrl_engine_destroy(e); return fail(SGRL_ERR_HIP, "cannot raise the dynamic LDS limit"); }
       g_lds_limit = e->lds_bytes;
     }
   }
@@ -414,7 +442,7 @@ int sgrl_step(sgrl_engine* e, const float* actions, float* obs, float* reward, u
   StepOut out{};
   out.actions = actions; out.obs32 = obs; out.obs64 = obs64; out.reward = reward; out.reward64 = reward64;
   out.done = done; out.dist = dist; out.truncated = truncated; out.auto_reset = auto_reset;
-  return launch_groups(e, k_env_step, out, (hipStream_t)stream);
+  return launch_groups(e, k_env_step, out, (hipStream_t)stream, true);
 }
 
 int sgrl_refresh(sgrl_engine* e, float* obs, double* obs64, void* stream) {
@@ -450,7 +478,7 @@ int sgrl_time_steps(sgrl_engine* e, const float* actions, float* obs, float* rew
   out.actions = actions; out.obs32 = obs; out.reward = reward; out.done = done; out.auto_reset = 1;
   HIP_TRY(hipEventRecord(t0, (hipStream_t)stream));
   for (int r = 0; r < reps; r++) {
-    const int rc = launch_groups(e, k_env_step, out, (hipStream_t)stream);
+    const int rc = launch_groups(e, k_env_step, out, (hipStream_t)stream, true);
     if (rc != SGRL_OK) return rc;
   }
   HIP_TRY(hipEventRecord(t1, (hipStream_t)stream));

@@ -34,7 +34,10 @@ __device__ __forceinline__ double wave_max(double x) {
   return fmax(fmax(read_lane(x, 0), read_lane(x, 16)), fmax(read_lane(x, 32), read_lane(x, 48)));
 }
 
-struct HipWave {
+// NVCAP: the largest dof count whose register solver instances are compiled in (24 = all; a kernel variant built for the
+// small morphologies only carries the instances it can meet: fewer registers)
+template <int NVCAP>
+struct HipWaveT {
   int lane;
 #ifdef SGRL_PHASE_PROF
   // diagnostic build only (tools/phase_prof.py): s_memtime deltas per phase of Engine::forward, lane 0 accumulates
@@ -46,7 +49,7 @@ struct HipWave {
     t_last = __builtin_readcyclecounter();
   }
 #endif
-  __device__ __forceinline__ HipWave() : lane(threadIdx.x & 63) {}
+  __device__ __forceinline__ HipWaveT() : lane(threadIdx.x & 63) {}
   // Called at the top of every dynamics evaluation: makes the lane id opaque again so that lane-dependent address
   // arithmetic is not hoisted out of the stage / frame-skip loops (it would stay live across them and spill).
   __device__ __forceinline__ void fence_lane() { asm volatile("" : "+v"(lane)); }
@@ -156,12 +159,12 @@ struct HipWave {
   // true when a register version covers n (the caller falls back to its LDS factorisation otherwise)
   __device__ __forceinline__ bool chol_inv_packed(int n_in, double* P, double minval) {
     const int n = __builtin_amdgcn_readfirstlane(n_in);
-    if (n <= 9) chol_inv_reg<9>(n, P, minval);            // one instance per dof count of the shipped nv <= 24 morphologies
-    else if (n <= 12) chol_inv_reg<12>(n, P, minval);
-    else if (n <= 15) chol_inv_reg<15>(n, P, minval);
-    else if (n <= 18) chol_inv_reg<18>(n, P, minval);
-    else if (n <= 21) chol_inv_reg<21>(n, P, minval);
-    else if (n <= 24) chol_inv_reg<24>(n, P, minval);
+    if (NVCAP >= 9 && n <= 9) chol_inv_reg<9>(n, P, minval);            // one instance per dof count of the shipped nv <= 24 morphologies
+    else if (NVCAP >= 12 && n <= 12) chol_inv_reg<12>(n, P, minval);
+    else if (NVCAP >= 15 && n <= 15) chol_inv_reg<15>(n, P, minval);
+    else if (NVCAP >= 18 && n <= 18) chol_inv_reg<18>(n, P, minval);
+    else if (NVCAP >= 21 && n <= 21) chol_inv_reg<21>(n, P, minval);
+    else if (NVCAP >= 24 && n <= 24) chol_inv_reg<24>(n, P, minval);
     else return false;
     return true;
   }
@@ -216,12 +219,12 @@ struct HipWave {
     return false;
 #endif
     const int n = __builtin_amdgcn_readfirstlane(n_in), nrhs = __builtin_amdgcn_readfirstlane(nrhs_in);
-    if (n <= 9) trmm_rows_reg<9>(nrhs, n, T, Y, ldy);
-    else if (n <= 12) trmm_rows_reg<12>(nrhs, n, T, Y, ldy);
-    else if (n <= 15) trmm_rows_reg<15>(nrhs, n, T, Y, ldy);
-    else if (n <= 18) trmm_rows_reg<18>(nrhs, n, T, Y, ldy);
-    else if (n <= 21) trmm_rows_reg<21>(nrhs, n, T, Y, ldy);
-    else if (n <= 24) trmm_rows_reg<24>(nrhs, n, T, Y, ldy);
+    if (NVCAP >= 9 && n <= 9) trmm_rows_reg<9>(nrhs, n, T, Y, ldy);
+    else if (NVCAP >= 12 && n <= 12) trmm_rows_reg<12>(nrhs, n, T, Y, ldy);
+    else if (NVCAP >= 15 && n <= 15) trmm_rows_reg<15>(nrhs, n, T, Y, ldy);
+    else if (NVCAP >= 18 && n <= 18) trmm_rows_reg<18>(nrhs, n, T, Y, ldy);
+    else if (NVCAP >= 21 && n <= 21) trmm_rows_reg<21>(nrhs, n, T, Y, ldy);
+    else if (NVCAP >= 24 && n <= 24) trmm_rows_reg<24>(nrhs, n, T, Y, ldy);
     else return false;
     return true;
   }
@@ -313,5 +316,6 @@ struct HipWave {
     return wave_max(p);
   }
 };
+using HipWave = HipWaveT<24>;
 
 }  // namespace sgrl
