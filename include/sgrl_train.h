@@ -27,17 +27,25 @@ extern "C" {
 
 int64_t sgrl_train_ws_floats(void);
 
-/* y[M, N] = act(x[M, K] . w[N, K]^T + bias[N]); bias may be null; relu != 0 applies max(., 0)   (torch.nn.functional.linear) */
-int sgrl_linear_forward(const float* x, int ldx, const float* w, int ldw, const float* bias, float* y, int ldy, int M, int N,
-                        int K, int relu, void* stream);
+/* y[M, N] = act(x[M, K] . w[N, K]^T + bias[N]) / rowdiv[M]; bias and rowdiv may be null; relu != 0 applies max(., 0)
+ * (torch.nn.functional.linear, the ReLU that follows it, and the `/ F_norm` of reference SEActor.py:101,117 in one launch) */
+int sgrl_linear_forward(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* rowdiv, float* y,
+                        int ldy, int M, int N, int K, int relu, void* stream);
 
-/* Backward of the call above.  g = dy, or dy masked by (y_relu > 0) when y_relu != null (the forward's OUTPUT: ReLU backward).
- *   dx[M, K] = g . w           (skipped when dx == null)
- *   dw[N, K] = g^T . x         (skipped when dw == null)
- *   db[N]    = column sums of g (skipped when db == null) */
-int sgrl_linear_backward(const float* dy, int lddy, const float* y_relu, int ldyr, const float* x, int ldx, const float* w,
-                         int ldw, float* dx, int lddx, float* dw, int lddw, float* db, int M, int N, int K, float* ws,
-                         void* stream);
+/* Backward of the call above (`y` = its output, needed when relu != 0 or drowdiv != null; relu and rowdiv exclude each other).
+ * g = dy masked by (y > 0) if relu, divided row-wise by rowdiv if given.
+ *   dx[M, K]    = g . w                                  (skipped when dx == null)
+ *   dw[N, K]    = g^T . x                                (skipped when dw == null)
+ *   db[N]       = column sums of g                       (skipped when db == null)
+ *   drowdiv[M]  = -(sum_n dy[m][n] y[m][n]) / rowdiv[m]  (skipped when drowdiv == null) */
+int sgrl_linear_backward(const float* dy, int lddy, const float* y, int ldyo, int relu, const float* rowdiv, const float* x,
+                         int ldx, const float* w, int ldw, float* dx, int lddx, float* dw, int lddw, float* db,
+                         float* drowdiv, int M, int N, int K, float* ws, void* stream);
+
+/* Gram invariants of M nodes' three 32-vectors z[M, 3, 32] (reference SEActor.py:94-98): gram[M, 1024] = vec(Z'Z),
+ * fn[M] = ||Z'Z||_F + 1; and their backward: dz = Z (D + D'), D = dgram + (dfn / ||Z'Z||_F) Z'Z (dgram or dfn may be null). */
+int sgrl_gram_forward(const float* z, float* gram, float* fn, int M, void* stream);
+int sgrl_gram_backward(const float* z, const float* dgram, const float* dfn, const float* fn, float* dz, int M, void* stream);
 
 const char* sgrl_train_last_error(void);
 

@@ -46,6 +46,7 @@ struct SArgs {
   const float* Amask; int ldmask;   // null, or: a(m, k) counts only where Amask (same layout as A) is > 0
   const float* B; int ldb;
   const float* bias; int relu;
+  const float* rowdiv;              // forward: C[m][:] /= rowdiv[m]; backward: the A operand's row of index m is divided by rowdiv[m]
   float* C; int ldc;
   float* db;                        // wgrad only: column sums of the (masked) A operand = rows of C
   int M, N, K;
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(256) void k_sgemm(SArgs a) {
         if (k < k_end) {
           v = load4(a.A + (size_t)k * a.lda, c, a.M, a_vec);
           if (a.Amask) v = relu_mask(v, load4(a.Amask + (size_t)k * a.ldmask, c, a.M, a_vec));
+          if (a.rowdiv) { const float f = a.rowdiv[k]; v.x /= f; v.y /= f; v.z /= f; v.w /= f; }   // wgrad: g = dy / fn, row k
         }
         ra[slot][i] = v;
         if (want_db) { dbp.x += v.x; dbp.y += v.y; dbp.z += v.z; dbp.w += v.w; }
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(256) void k_sgemm(SArgs a) {
         if (m < a.M) {
           v = load4(a.A + (size_t)m * a.lda, c, k_end, a_vec);
           if (a.Amask) v = relu_mask(v, load4(a.Amask + (size_t)m * a.ldmask, c, k_end, a_vec));
+          if (a.rowdiv && BTR) { const float f = a.rowdiv[m]; v.x /= f; v.y /= f; v.z /= f; v.w /= f; }   // dgrad: g = dy / fn, row m
         }
         ra[slot][i] = v;
       }
@@ -215,6 +218,7 @@ __global__ __launch_bounds__(256) void k_sgemm(SArgs a) {
     if (n >= a.N) continue;
     float o = v[j] + (a.bias ? a.bias[n] : 0.f);
     if (a.relu) o = fmaxf(o, 0.f);
+    if (!AT && !BTR && a.rowdiv) o = o / a.rowdiv[m];
     a.C[(size_t)m * a.ldc + n] = o;
   }
 }
@@ -232,6 +236,64 @@ __global__ __launch_bounds__(256) void k_colsum(const float* g, int ldg, const f
   red[r0][threadIdx.x & 63] = s;
   __syncthreads();
   if (threadIdx.x < 64 && c < N) db[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// drowdiv[m] = -(sum_n dy[m][n] y[m][n]) / rowdiv[m]   (y = (x w^T + b) / rowdiv: d/d rowdiv of the forward); one wave per row
+__global__ __launch_bounds__(256) void k_rowdot(const float* dy, int lddy, const float* y, int ldy, const float* rowdiv, float* out,
+                                                int M, int N) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (m >= M) return;
+  float s = 0.f;
+  for (int n = lane; n < N; n += 64) s += dy[(size_t)m * lddy + n] * y[(size_t)m * ldy + n];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) out[m] = -s / rowdiv[m];
+}
+
+// Gram invariants of a node's three 32-vectors (reference SEActor.py:94-98 / subequivariant_attentions.py:38-44):
+//   G = Z' Z  (32 x 32, stored flat, 1024 values)   and   fn = ||G||_F + 1.     One 256-thread workgroup per node.
+__global__ __launch_bounds__(256) void k_gram_fwd(const float* __restrict__ z, float* gram, float* fn, int M) {
+  __shared__ float zs[96];
+  __shared__ float red[4];
+  const int m = blockIdx.x, t = threadIdx.x;
+  if (t < 96) zs[t] = z[(size_t)m * 96 + t];
+  __syncthreads();
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int o = t + 256 * i, a = o >> 5, c = o & 31;
+    const float g = zs[a] * zs[c] + zs[32 + a] * zs[32 + c] + zs[64 + a] * zs[64 + c];
+    gram[(size_t)m * 1024 + o] = g;
+    sq += g * g;
+  }
+  for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+  if ((t & 63) == 0) red[t >> 6] = sq;
+  __syncthreads();
+  if (t == 0) fn[m] = sqrtf((red[0] + red[1]) + (red[2] + red[3])) + 1.0f;
+}
+// dz = Z (D + D'),  D = dG + (dfn / ||G||) G   (||G|| = fn - 1; no norm term where it is zero)
+__global__ __launch_bounds__(256) void k_gram_bwd(const float* __restrict__ z, const float* __restrict__ dgram,
+                                                  const float* __restrict__ dfn, const float* __restrict__ fn, float* dz, int M) {
+  __shared__ float zs[96];
+  __shared__ float D[32][33];
+  const int m = blockIdx.x, t = threadIdx.x;
+  if (t < 96) zs[t] = z[(size_t)m * 96 + t];
+  __syncthreads();
+  const float nrm = fn[m] - 1.0f;
+  const float coef = (dfn && nrm > 0.f) ? dfn[m] / nrm : 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int o = t + 256 * i, a = o >> 5, c = o & 31;
+    const float g = zs[a] * zs[c] + zs[32 + a] * zs[32 + c] + zs[64 + a] * zs[64 + c];
+    D[a][c] = (dgram ? dgram[(size_t)m * 1024 + o] : 0.f) + coef * g;
+  }
+  __syncthreads();
+  if (t < 96) {
+    const int sx = t >> 5, a = t & 31;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; c++) acc += (D[a][c] + D[c][a]) * zs[32 * sx + c];
+    dz[(size_t)m * 96 + t] = acc;
+  }
 }
 
 // Only the weight gradient (AT) splits its contraction, and only where that pays: the release / acquire fences of the last-
@@ -264,35 +326,56 @@ const char* sgrl_train_last_error(void) { return g_train_err.c_str(); }
 
 int64_t sgrl_train_ws_floats(void) { return kWsTiles * TILE_WS + kCounters; }
 
-int sgrl_linear_forward(const float* x, int ldx, const float* w, int ldw, const float* bias, float* y, int ldy, int M, int N,
-                        int K, int relu, void* stream) {
+int sgrl_linear_forward(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* rowdiv, float* y,
+                        int ldy, int M, int N, int K, int relu, void* stream) {
   if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldw < K || ldy < N)
     return tfail(SGRL_ERR_ARG, "sgrl_linear_forward: bad argument");
-  SArgs a{x, ldx, nullptr, 0, w, ldw, bias, relu ? 1 : 0, y, ldy, nullptr, M, N, K, 0, nullptr, nullptr};
+  SArgs a{x, ldx, nullptr, 0, w, ldw, bias, relu ? 1 : 0, rowdiv, y, ldy, nullptr, M, N, K, 0, nullptr, nullptr};
   return launch<false, false>(a, nullptr, (hipStream_t)stream);
 }
 
-int sgrl_linear_backward(const float* dy, int lddy, const float* y_relu, int ldyr, const float* x, int ldx, const float* w,
-                         int ldw, float* dx, int lddx, float* dw, int lddw, float* db, int M, int N, int K, float* ws,
-                         void* stream) {
-  if (!dy || M <= 0 || N <= 0 || K <= 0 || lddy < N || (y_relu && ldyr < N))
+int sgrl_linear_backward(const float* dy, int lddy, const float* y, int ldyo, int relu, const float* rowdiv, const float* x,
+                         int ldx, const float* w, int ldw, float* dx, int lddx, float* dw, int lddw, float* db,
+                         float* drowdiv, int M, int N, int K, float* ws, void* stream) {
+  if (!dy || M <= 0 || N <= 0 || K <= 0 || lddy < N || ((relu || drowdiv) && (!y || ldyo < N)) || (drowdiv && !rowdiv) ||
+      (relu && rowdiv))
     return tfail(SGRL_ERR_ARG, "sgrl_linear_backward: bad argument");
   hipStream_t st = (hipStream_t)stream;
+  const float* mask = relu ? y : nullptr;
+  if (drowdiv) {
+    hipLaunchKernelGGL(k_rowdot, dim3((M + 3) / 4), dim3(256), 0, st, dy, lddy, y, ldyo, rowdiv, drowdiv, M, N);
+    if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_rowdot launch failed");
+  }
   if (dx) {                 // dx[M][K] = g[M][N] . w[N][K]: contraction N, contiguous in g, the row index of w
     if (!w || ldw < K || lddx < K) return tfail(SGRL_ERR_ARG, "sgrl_linear_backward: bad weight / dx argument");
-    SArgs a{dy, lddy, y_relu, ldyr, w, ldw, nullptr, 0, dx, lddx, nullptr, M, K, N, 0, nullptr, nullptr};
+    SArgs a{dy, lddy, mask, ldyo, w, ldw, nullptr, 0, rowdiv, dx, lddx, nullptr, M, K, N, 0, nullptr, nullptr};
     const int rc = launch<false, true>(a, nullptr, st);
     if (rc != SGRL_OK) return rc;
   }
   if (dw) {                 // dw[N][K] = g^T . x: contraction M, the row index of both operands; db rides along
     if (!x || ldx < K || lddw < K) return tfail(SGRL_ERR_ARG, "sgrl_linear_backward: bad input / dw argument");
-    SArgs a{dy, lddy, y_relu, ldyr, x, ldx, nullptr, 0, dw, lddw, db, N, K, M, 0, nullptr, nullptr};
+    SArgs a{dy, lddy, mask, ldyo, x, ldx, nullptr, 0, rowdiv, dw, lddw, db, N, K, M, 0, nullptr, nullptr};
     const int rc = launch<true, true>(a, ws, st);
     if (rc != SGRL_OK) return rc;
   } else if (db) {
-    hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64), dim3(256), 0, st, dy, lddy, y_relu, ldyr, db, M, N);
+    if (rowdiv) return tfail(SGRL_ERR_ARG, "sgrl_linear_backward: db without dw is not offered together with rowdiv");
+    hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64), dim3(256), 0, st, dy, lddy, mask, ldyo, db, M, N);
     if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_colsum launch failed");
   }
+  return SGRL_OK;
+}
+
+int sgrl_gram_forward(const float* z, float* gram, float* fn, int M, void* stream) {
+  if (!z || !gram || !fn || M <= 0) return tfail(SGRL_ERR_ARG, "sgrl_gram_forward: bad argument");
+  hipLaunchKernelGGL(k_gram_fwd, dim3(M), dim3(256), 0, (hipStream_t)stream, z, gram, fn, M);
+  if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_gram_fwd launch failed");
+  return SGRL_OK;
+}
+
+int sgrl_gram_backward(const float* z, const float* dgram, const float* dfn, const float* fn, float* dz, int M, void* stream) {
+  if (!z || !fn || !dz || M <= 0 || (!dgram && !dfn)) return tfail(SGRL_ERR_ARG, "sgrl_gram_backward: bad argument");
+  hipLaunchKernelGGL(k_gram_bwd, dim3(M), dim3(256), 0, (hipStream_t)stream, z, dgram, dfn, fn, dz, M);
+  if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_gram_bwd launch failed");
   return SGRL_OK;
 }
 

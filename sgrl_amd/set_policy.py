@@ -31,8 +31,8 @@ class Linear(nn.Linear):
     weight / bias gradient -- runs on this library's small-product kernels (train_ops.linear, csrc/train_gemm.hip); `relu`
     folds the activation that follows the layer into the product's epilogue and its mask into the backward products."""
 
-    def forward(self, x, relu=False):
-        return train_ops.linear(x, self.weight, self.bias, relu)
+    def forward(self, x, relu=False, rowdiv=None):
+        return train_ops.linear(x, self.weight, self.bias, relu, rowdiv)
 
 
 class ConcatPositionalEmbedding(nn.Module):
@@ -51,9 +51,8 @@ class ConcatPositionalEmbedding(nn.Module):
 def _invariants(x, gdir, proj, lin1, lin2):
     """x [B,L,3,C] -> (features [B,L,out], F_norm [B,L,1])."""
     z = torch.cat([proj(x), gdir], dim=-1)
-    gram = torch.einsum("blsa,blsc->blac", z, z)
-    fn = gram.flatten(-2).norm(dim=-1, keepdim=True) + 1.0
-    return lin2(lin1(gram.flatten(-2), relu=True)), fn
+    gram, fn = train_ops.gram_fn(z)
+    return lin2(lin1(gram, relu=True)), fn
 
 
 class SubequivariantAttention(nn.Module):
@@ -85,9 +84,13 @@ class SubequivariantAttention(nn.Module):
         hd2 = 2 * (self.embed_dim // H)
         inv, fn = _invariants(g, gdir, self.g_proj, self.linear_g1, self.linear_g2)
         c = torch.cat([inv, ng], dim=-1)
-        q = (self.q_proj(c) / fn * float(hd2) ** -0.5).view(B, L, H, hd2)
-        k = (self.k_proj(c) / fn).view(B, L, H, hd2)
-        v = (self.v_proj(c) / fn).view(B, L, H, hd2)
+        # q, k, v share their input and their row divisor: ONE product over the stacked weights
+        qkv = train_ops.linear(c, torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], dim=0),
+                               torch.cat([self.q_proj.bias, self.k_proj.bias, self.v_proj.bias], dim=0), rowdiv=fn)
+        e2 = 2 * self.embed_dim
+        q = (qkv[..., :e2] * float(hd2) ** -0.5).view(B, L, H, hd2)
+        k = qkv[..., e2:2 * e2].view(B, L, H, hd2)
+        v = qkv[..., 2 * e2:].view(B, L, H, hd2)
         vg = self.vg_proj(g).view(B, L, 3, H, hd2 - 2)
         vg = torch.cat([vg, gdir.unsqueeze(3).expand(B, L, 3, H, 2)], dim=-1)
         s = torch.einsum("bihd,bjhd->bhij", q, k)
@@ -123,10 +126,10 @@ class SubequivariantEncoderLayer(nn.Module):
         ng = self.norm1(ng + ng1)
         inv, fn = _invariants(g1, gdir, self.g_proj2, self.linear_g1, self.linear_g2)
         c = torch.cat([inv, ng], dim=-1)
-        mat = (self.linear4(self.linear3(c, relu=True)) / fn).view(*ng.shape[:2], Z_DIM, Z_DIM)
+        mat = self.linear4(self.linear3(c, relu=True), rowdiv=fn).view(*ng.shape[:2], Z_DIM, Z_DIM)
         z3 = torch.cat([self.g_proj3(g1), gdir], dim=-1)
         g = g + self.linear5(torch.einsum("blsa,blac->blsc", z3, mat))
-        ng = self.norm2(ng + self.linear2(self.linear1(c, relu=True)) / fn)
+        ng = self.norm2(ng + self.linear2(self.linear1(c, relu=True), rowdiv=fn))
         return g, ng
 
 
@@ -203,8 +206,8 @@ class TransformerModel(nn.Module):
         hng = self.linear2_ng(self.linear1_ng(out_ng, relu=True))
         c = torch.cat([inv, hng], dim=-1)
         if self.output_size == 1:
-            return self.decoder_ng(c) / fn
-        mat = (self.linear2_m(self.linear1_m(c, relu=True)) / fn).view(B, L, Z_DIM, Z_DIM)
+            return self.decoder_ng(c, rowdiv=fn)
+        mat = self.linear2_m(self.linear1_m(c, relu=True), rowdiv=fn).view(B, L, Z_DIM, Z_DIM)
         zh = torch.cat([self.g_proj(out_g), gdir], dim=-1)
         vec = self.decoder_g(torch.einsum("blsa,blac->blsc", zh, mat)).squeeze(-1)   # [B,L,3]
         return torch.einsum("blsk,bls->blk", g0[..., 5:8], vec)

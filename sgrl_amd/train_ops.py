@@ -25,8 +25,10 @@ def _L():
     L = _lib.lib()
     if not _bound:
         vp, ci = ctypes.c_void_p, ctypes.c_int
-        L.sgrl_linear_forward.argtypes = [vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, vp]
-        L.sgrl_linear_backward.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, vp, vp]
+        L.sgrl_linear_forward.argtypes = [vp, ci, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]
+        L.sgrl_linear_backward.argtypes = [vp, ci, vp, ci, ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, vp, vp]
+        L.sgrl_gram_forward.argtypes = [vp, vp, vp, ci, vp]
+        L.sgrl_gram_backward.argtypes = [vp, vp, vp, vp, vp, ci, vp]
         L.sgrl_train_ws_floats.restype = ctypes.c_int64
         L.sgrl_train_last_error.restype = ctypes.c_char_p
         _bound = True
@@ -55,7 +57,7 @@ def _p(t):
 
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, relu):
+    def forward(ctx, x, weight, bias, relu, rowdiv):
         L = _L()
         N, K = weight.shape
         x2 = x.reshape(-1, K)
@@ -63,37 +65,99 @@ class _LinearFn(torch.autograd.Function):
             x2 = x2.contiguous()
         w = weight if weight.is_contiguous() else weight.contiguous()
         M = x2.shape[0]
+        rd = None
+        if rowdiv is not None:
+            rd = rowdiv.reshape(-1)
+            rd = rd if rd.is_contiguous() else rd.contiguous()
+            assert rd.shape[0] == M and not relu
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
         st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        _check(L, L.sgrl_linear_forward(_p(x2), x2.stride(0), _p(w), K, _p(bias), _p(y), N, M, N, K, 1 if relu else 0, st), "sgrl_linear_forward")
-        ctx.save_for_backward(x2, w, y if relu else None)
-        ctx.has_bias = bias is not None
+        _check(L, L.sgrl_linear_forward(_p(x2), x2.stride(0), _p(w), K, _p(bias), _p(rd), _p(y), N, M, N, K, 1 if relu else 0, st),
+               "sgrl_linear_forward")
+        ctx.save_for_backward(x2, w, y if (relu or rd is not None) else None, rd)
+        ctx.has_bias, ctx.relu = bias is not None, bool(relu)
         ctx.x_shape = x.shape
+        ctx.rd_shape = None if rowdiv is None else rowdiv.shape
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
         L = _L()
-        x2, w, yr = ctx.saved_tensors
+        x2, w, yo, rd = ctx.saved_tensors
         N, K = w.shape
         M = x2.shape[0]
         dy2 = dy.reshape(M, N)
         if dy2.stride(1) != 1 or dy2.stride(0) < N:
             dy2 = dy2.contiguous()
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        need_rd = rd is not None and ctx.needs_input_grad[4]
+        if need_b and not need_w:
+            need_w = True                       # the bias gradient rides on the weight-gradient kernel
         dx = torch.empty((M, K), dtype=torch.float32, device=dy.device) if need_x else None
         dw = torch.empty((N, K), dtype=torch.float32, device=dy.device) if need_w else None
         db = torch.empty((N,), dtype=torch.float32, device=dy.device) if need_b else None
+        drd = torch.empty((M,), dtype=torch.float32, device=dy.device) if need_rd else None
         st = ctypes.c_void_p(torch.cuda.current_stream(dy.device).cuda_stream)
-        _check(L, L.sgrl_linear_backward(_p(dy2), dy2.stride(0), _p(yr), N, _p(x2), x2.stride(0), _p(w), K, _p(dx), K, _p(dw), K,
-                                         _p(db), M, N, K, _p(_scratch(dy.device)), st), "sgrl_linear_backward")
-        return (dx.view(ctx.x_shape) if need_x else None), dw, db, None
+        _check(L, L.sgrl_linear_backward(_p(dy2), dy2.stride(0), _p(yo), N, 1 if ctx.relu else 0, _p(rd), _p(x2), x2.stride(0), _p(w), K,
+                                         _p(dx), K, _p(dw), K, _p(db), _p(drd), M, N, K, _p(_scratch(dy.device)), st),
+               "sgrl_linear_backward")
+        return (dx.view(ctx.x_shape) if need_x else None), (dw if ctx.needs_input_grad[1] else None), db, None, \
+               (drd.view(ctx.rd_shape) if need_rd else None)
 
 
-def linear(x, weight, bias=None, relu=False):
-    """relu(x @ weight.T + bias) if relu else x @ weight.T + bias, differentiable."""
-    if ENABLED and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and \
-            (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
-        return _LinearFn.apply(x, weight, bias, bool(relu))
+class _GramFn(torch.autograd.Function):
+    """z [..., 3, 32] -> (vec(Z'Z) [..., 1024], ||Z'Z||_F + 1 [..., 1])."""
+
+    @staticmethod
+    def forward(ctx, z):
+        L = _L()
+        z2 = z.reshape(-1, 96)
+        z2 = z2 if z2.is_contiguous() else z2.contiguous()
+        M = z2.shape[0]
+        gram = torch.empty((M, 1024), dtype=torch.float32, device=z.device)
+        fn = torch.empty((M,), dtype=torch.float32, device=z.device)
+        st = ctypes.c_void_p(torch.cuda.current_stream(z.device).cuda_stream)
+        _check(L, L.sgrl_gram_forward(_p(z2), _p(gram), _p(fn), M, st), "sgrl_gram_forward")
+        ctx.save_for_backward(z2, fn)
+        ctx.z_shape = z.shape
+        lead = z.shape[:-2]
+        return gram.view(*lead, 1024), fn.view(*lead, 1)
+
+    @staticmethod
+    def backward(ctx, dgram, dfn):
+        L = _L()
+        z2, fn = ctx.saved_tensors
+        M = z2.shape[0]
+        dg = None if dgram is None else dgram.reshape(M, 1024)
+        if dg is not None and not dg.is_contiguous():
+            dg = dg.contiguous()
+        df = None if dfn is None else dfn.reshape(M)
+        if df is not None and not df.is_contiguous():
+            df = df.contiguous()
+        dz = torch.empty((M, 96), dtype=torch.float32, device=z2.device)
+        st = ctypes.c_void_p(torch.cuda.current_stream(z2.device).cuda_stream)
+        _check(L, L.sgrl_gram_backward(_p(z2), _p(dg), _p(df), _p(fn), _p(dz), M, st), "sgrl_gram_backward")
+        return dz.view(ctx.z_shape)
+
+
+def _on_device_with_grad(*ts):
+    return ENABLED and ts[0].is_cuda and ts[0].dtype == torch.float32 and torch.is_grad_enabled() and \
+        any(t is not None and t.requires_grad for t in ts)
+
+
+def linear(x, weight, bias=None, relu=False, rowdiv=None):
+    """act(x @ weight.T + bias) / rowdiv, differentiable in x, weight, bias and rowdiv (act = ReLU if relu; rowdiv: one value
+    per row, broadcast over the output features -- the `/ F_norm` of the reference's SET layers)."""
+    if _on_device_with_grad(x, weight, bias, rowdiv):
+        return _LinearFn.apply(x, weight, bias, bool(relu), rowdiv)
     y = F.linear(x, weight, bias)
-    return F.relu(y) if relu else y
+    y = F.relu(y) if relu else y
+    return y if rowdiv is None else y / rowdiv
+
+
+def gram_fn(z):
+    """z [..., 3, 32] -> (vec(Z'Z) [..., 1024], ||Z'Z||_F + 1 [..., 1])  (reference SEActor.py:94-98)."""
+    if _on_device_with_grad(z):
+        return _GramFn.apply(z)
+    gram = torch.einsum("...sa,...sc->...ac", z, z).flatten(-2)
+    return gram, gram.norm(dim=-1, keepdim=True) + 1.0

@@ -91,3 +91,49 @@ def test_set_policy_gradients_agree_with_the_vendor_gemm_path():
     assert len(grads[0]) == len(grads[1]) and len(grads[0]) > 100
     for a, b in zip(grads[0], grads[1]):
         assert float((a - b).abs().max()) <= 2e-4 * (float(b.abs().max()) + 1e-6) + 1e-7
+
+
+@pytest.mark.parametrize("M,K,N", [(700, 256, 768), (700, 256, 1024), (900, 256, 128), (700, 256, 1), (33, 20, 7)])
+def test_linear_with_row_divisor_matches_float64(M, K, N):
+    """y = (x w^T + b) / fn: forward, and the gradients wrt x, w, b AND fn."""
+    from sgrl_amd import train_ops
+    g = torch.Generator().manual_seed(M + K + N)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / np.sqrt(K), torch.randn(N, generator=g)
+    fn = torch.rand(M, 1, generator=g) * 3 + 1
+    dy = torch.randn(M, N, generator=g)
+    ref = [t.double().requires_grad_() for t in (x, w, b, fn)]
+    yr = torch.nn.functional.linear(ref[0], ref[1], ref[2]) / ref[3]
+    yr.backward(dy.double())
+    dev = [t.cuda().requires_grad_() for t in (x, w, b, fn)]
+    y = train_ops.linear(dev[0], dev[1], dev[2], rowdiv=dev[3])
+    assert type(y.grad_fn).__name__.startswith("_LinearFn")
+    y.backward(dy.cuda())
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) < 3e-6 * (float(yr.abs().max()) + 1)
+    for d, r, name in zip(dev, ref, "x w b fn".split()):
+        scale = (float(r.grad.abs().max()) + 1.0) * (np.sqrt(M / 64 + 1) if name in ("w", "b") else 1.0)
+        assert d.grad.shape == r.grad.shape
+        assert float((d.grad.cpu().double() - r.grad).abs().max()) < 4e-6 * scale, name
+
+
+def test_gram_fn_matches_float64():
+    from sgrl_amd import train_ops
+    torch.manual_seed(11)
+    z = torch.randn(50, 9, 3, 32) * 0.7
+    z[3, 2] = 0.0                                        # a node whose Gram matrix vanishes: no norm term, no NaN
+    dgram, dfn = torch.randn(50, 9, 1024), torch.randn(50, 9, 1)
+    zr = z.double().requires_grad_()
+    gr = torch.einsum("blsa,blsc->blac", zr, zr).flatten(-2)
+    eps_safe = gr.detach().norm(dim=-1, keepdim=True) > 0
+    fr = gr.norm(dim=-1, keepdim=True) + 1.0
+    (gr * dgram.double()).sum().backward(retain_graph=True)
+    g1 = zr.grad.clone(); zr.grad = None
+    (torch.where(eps_safe, fr, fr.detach()) * dfn.double()).sum().backward()
+    ref_grad = g1 + torch.nan_to_num(zr.grad)
+    zd = z.cuda().requires_grad_()
+    gram, fn = train_ops.gram_fn(zd)
+    assert gram.shape == (50, 9, 1024) and fn.shape == (50, 9, 1)
+    assert float((gram.detach().cpu().double() - gr.detach()).abs().max()) < 1e-5
+    assert float((fn.detach().cpu().double() - fr.detach()).abs().max()) < 1e-5 * float(fr.max())
+    ((gram * dgram.cuda()).sum() + (fn * dfn.cuda()).sum()).backward()
+    assert torch.isfinite(zd.grad).all()
+    assert float((zd.grad.cpu().double() - ref_grad).abs().max()) < 2e-5 * (float(ref_grad.abs().max()) + 1)
