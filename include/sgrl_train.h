@@ -47,6 +47,17 @@ int sgrl_linear_backward(const float* dy, int lddy, const float* y, int ldyo, in
 int sgrl_gram_forward(const float* z, float* gram, float* fn, int M, void* stream);
 int sgrl_gram_backward(const float* z, const float* dgram, const float* dfn, const float* fn, float* dz, int M, void* stream);
 
+/* Limb attention of B environments with L <= 14 limbs, 2 heads x 128 channels (reference subequivariant_attentions.py:90-151
+ * between the projections): q, k, v [B, L, 256] (q already scaled), vg [B, L, 3, 256] (vector values), bias [2, L, L] or null.
+ *   w[b][h][i][:] = softmax_j(q_i . k_j + bias),  o[b][i][c] = sum_j w[h(c)] v[j][c],  og[b][i][s][c] = sum_j w[h(c)] vg[j][s][c]
+ * w [B, 2, L, L] is returned for the backward, which yields dq, dk, dv, dvg and ds [B, 2, L, L] (the score gradient: its sum over
+ * the environments is the gradient of `bias`). */
+int sgrl_attention_forward(const float* q, const float* k, const float* v, const float* vg, const float* bias, float* w,
+                           float* o, float* og, int B, int L, void* stream);
+int sgrl_attention_backward(const float* q, const float* k, const float* v, const float* vg, const float* w, const float* d_o,
+                            const float* d_og, float* dq, float* dk, float* dv, float* dvg, float* ds, int B, int L,
+                            void* stream);
+
 const char* sgrl_train_last_error(void);
 
 #ifdef __cplusplus

@@ -297,6 +297,158 @@ __global__ __launch_bounds__(256) void k_gram_bwd(const float* __restrict__ z, c
   }
 }
 
+// Limb attention of one environment (reference subequivariant_attentions.py:90-151 between the projections): H = 2 heads of
+// 128 channels, L <= 14 limbs.  q, k, v [B, L, 256]; vg [B, L, 3, 256] (vector values); bias [2, L, L] or null.
+//   w = softmax_j(q_i . k_j + bias);   o[i][c] = sum_j w[h(c)][i][j] v[j][c];   og[i][s][c] = sum_j w[h(c)][i][j] vg[j][s][c]
+// One 256-thread workgroup per environment; scores by a thread per (head, i, j) from LDS-resident q / k rows (pitch 257: the
+// rows of different limbs fall on different banks), outputs by a thread per channel.  w is kept for the backward.
+constexpr int AL = 14, AP = 257;
+__global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ q, const float* __restrict__ k,
+                                                  const float* __restrict__ v, const float* __restrict__ vg,
+                                                  const float* __restrict__ bias, float* wout, float* o, float* og, int L) {
+  __shared__ float qs[AL * AP], ks[AL * AP];
+  __shared__ float sc[2 * AL * AL];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const size_t base = (size_t)b * L * 256;
+  for (int i = 0; i < L; i++) { qs[i * AP + t] = q[base + i * 256 + t]; ks[i * AP + t] = k[base + i * 256 + t]; }
+  __syncthreads();
+  for (int idx = t; idx < 2 * L * L; idx += 256) {
+    const int h = idx / (L * L), i = (idx / L) % L, j = idx % L;
+    const float* a = qs + i * AP + 128 * h;
+    const float* c = ks + j * AP + 128 * h;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < 128; d++) acc += a[d] * c[d];
+    sc[idx] = bias ? acc + bias[idx] : acc;
+  }
+  __syncthreads();
+  if (t < 2 * L) {
+    float* row = sc + t * L;
+    float mx = row[0];
+    for (int j = 1; j < L; j++) mx = fmaxf(mx, row[j]);
+    float sum = 0.f;
+    for (int j = 0; j < L; j++) { row[j] = expf(row[j] - mx); sum += row[j]; }
+    for (int j = 0; j < L; j++) row[j] = row[j] / sum;
+  }
+  __syncthreads();
+  for (int idx = t; idx < 2 * L * L; idx += 256) wout[(size_t)b * 2 * L * L + idx] = sc[idx];
+  const int h = t >> 7;
+  const float* w = sc + h * L * L;
+  float vv[AL];
+#pragma unroll
+  for (int j = 0; j < AL; j++) vv[j] = j < L ? v[base + j * 256 + t] : 0.f;
+#pragma unroll
+  for (int i = 0; i < AL; i++)
+    if (i < L) {
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < AL; j++) if (j < L) acc += w[i * L + j] * vv[j];
+      o[base + i * 256 + t] = acc;
+    }
+  for (int sx = 0; sx < 3; sx++) {
+#pragma unroll
+    for (int j = 0; j < AL; j++) vv[j] = j < L ? vg[(base + j * 256) * 3 + sx * 256 + t] : 0.f;
+#pragma unroll
+    for (int i = 0; i < AL; i++)
+      if (i < L) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < AL; j++) if (j < L) acc += w[i * L + j] * vv[j];
+        og[(base + i * 256) * 3 + sx * 256 + t] = acc;
+      }
+  }
+}
+// Backward: dw = do v' + sum_s dog_s vg_s' (per head), ds = w (dw - sum_j w dw), dq = ds k, dk = ds' q, dv = w' do, dvg = w' dog.
+// ds [B, 2, L, L] is written out as well (its sum over the environments is the gradient of the relation bias).
+__global__ __launch_bounds__(256) void k_attn_bwd(const float* __restrict__ q, const float* __restrict__ k,
+                                                  const float* __restrict__ v, const float* __restrict__ vg,
+                                                  const float* __restrict__ win, const float* __restrict__ dout,
+                                                  const float* __restrict__ dog, float* dq, float* dk, float* dv, float* dvg,
+                                                  float* ds_out, int L) {
+  __shared__ float as[AL * AP], bs[AL * AP];
+  __shared__ float w[2 * AL * AL], dw[2 * AL * AL];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const size_t base = (size_t)b * L * 256;
+  for (int idx = t; idx < 2 * L * L; idx += 256) { w[idx] = win[(size_t)b * 2 * L * L + idx]; dw[idx] = 0.f; }
+  // dw, four passes: (do, v), (dog_s, vg_s) for s = 0..2, each staged in LDS
+  for (int pass = 0; pass < 4; pass++) {
+    __syncthreads();
+    for (int i = 0; i < L; i++) {
+      if (pass == 0) { as[i * AP + t] = dout[base + i * 256 + t]; bs[i * AP + t] = v[base + i * 256 + t]; }
+      else { as[i * AP + t] = dog[(base + i * 256) * 3 + (pass - 1) * 256 + t]; bs[i * AP + t] = vg[(base + i * 256) * 3 + (pass - 1) * 256 + t]; }
+    }
+    __syncthreads();
+    for (int idx = t; idx < 2 * L * L; idx += 256) {
+      const int h = idx / (L * L), i = (idx / L) % L, j = idx % L;
+      const float* a = as + i * AP + 128 * h;
+      const float* c = bs + j * AP + 128 * h;
+      float acc = 0.f;
+#pragma unroll 8
+      for (int d = 0; d < 128; d++) acc += a[d] * c[d];
+      dw[idx] += acc;
+    }
+  }
+  __syncthreads();
+  if (t < 2 * L) {                                   // softmax backward, one thread per (head, i) row; dw becomes ds in place
+    float* wr = w + t * L;
+    float* dr = dw + t * L;
+    float dot = 0.f;
+    for (int j = 0; j < L; j++) dot += wr[j] * dr[j];
+    for (int j = 0; j < L; j++) dr[j] = wr[j] * (dr[j] - dot);
+  }
+  __syncthreads();
+  for (int idx = t; idx < 2 * L * L; idx += 256) ds_out[(size_t)b * 2 * L * L + idx] = dw[idx];
+  const int h = t >> 7;
+  const float* wh = w + h * L * L;
+  const float* dsh = dw + h * L * L;
+  float col[AL];
+  // dq[i] = sum_j ds[i][j] k[j]
+#pragma unroll
+  for (int j = 0; j < AL; j++) col[j] = j < L ? k[base + j * 256 + t] : 0.f;
+#pragma unroll
+  for (int i = 0; i < AL; i++)
+    if (i < L) {
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < AL; j++) if (j < L) acc += dsh[i * L + j] * col[j];
+      dq[base + i * 256 + t] = acc;
+    }
+  // dk[j] = sum_i ds[i][j] q[i]
+#pragma unroll
+  for (int i = 0; i < AL; i++) col[i] = i < L ? q[base + i * 256 + t] : 0.f;
+#pragma unroll
+  for (int j = 0; j < AL; j++)
+    if (j < L) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < AL; i++) if (i < L) acc += dsh[i * L + j] * col[i];
+      dk[base + j * 256 + t] = acc;
+    }
+  // dv[j] = sum_i w[i][j] do[i];  dvg[j][s] = sum_i w[i][j] dog[i][s]
+#pragma unroll
+  for (int i = 0; i < AL; i++) col[i] = i < L ? dout[base + i * 256 + t] : 0.f;
+#pragma unroll
+  for (int j = 0; j < AL; j++)
+    if (j < L) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < AL; i++) if (i < L) acc += wh[i * L + j] * col[i];
+      dv[base + j * 256 + t] = acc;
+    }
+  for (int sx = 0; sx < 3; sx++) {
+#pragma unroll
+    for (int i = 0; i < AL; i++) col[i] = i < L ? dog[(base + i * 256) * 3 + sx * 256 + t] : 0.f;
+#pragma unroll
+    for (int j = 0; j < AL; j++)
+      if (j < L) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < AL; i++) if (i < L) acc += wh[i * L + j] * col[i];
+        dvg[(base + j * 256) * 3 + sx * 256 + t] = acc;
+      }
+  }
+}
+
 // Only the weight gradient (AT) splits its contraction, and only where that pays: the release / acquire fences of the last-
 // workgroup reduction cost ~10-15 us on the eight-XCD chip, more than a few extra k-steps (measured: a 256 x 256 gradient over
 // 700 rows is 20 us unsplit, 27 us in three splits; a 30 x 128 gradient over 2 100 rows 51 us unsplit, 17 us in six).  So: a
@@ -378,6 +530,24 @@ int sgrl_gram_backward(const float* z, const float* dgram, const float* dfn, con
   if (!z || !fn || !dz || M <= 0 || (!dgram && !dfn)) return tfail(SGRL_ERR_ARG, "sgrl_gram_backward: bad argument");
   hipLaunchKernelGGL(k_gram_bwd, dim3(M), dim3(256), 0, (hipStream_t)stream, z, dgram, dfn, fn, dz, M);
   if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_gram_bwd launch failed");
+  return SGRL_OK;
+}
+
+int sgrl_attention_forward(const float* q, const float* k, const float* v, const float* vg, const float* bias, float* w,
+                           float* o, float* og, int B, int L, void* stream) {
+  if (!q || !k || !v || !vg || !w || !o || !og || B <= 0 || L < 1 || L > AL) return tfail(SGRL_ERR_ARG, "sgrl_attention_forward: bad argument");
+  hipLaunchKernelGGL(k_attn_fwd, dim3(B), dim3(256), 0, (hipStream_t)stream, q, k, v, vg, bias, w, o, og, L);
+  if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_attn_fwd launch failed");
+  return SGRL_OK;
+}
+
+int sgrl_attention_backward(const float* q, const float* k, const float* v, const float* vg, const float* w, const float* d_o,
+                            const float* d_og, float* dq, float* dk, float* dv, float* dvg, float* ds, int B, int L,
+                            void* stream) {
+  if (!q || !k || !v || !vg || !w || !d_o || !d_og || !dq || !dk || !dv || !dvg || !ds || B <= 0 || L < 1 || L > AL)
+    return tfail(SGRL_ERR_ARG, "sgrl_attention_backward: bad argument");
+  hipLaunchKernelGGL(k_attn_bwd, dim3(B), dim3(256), 0, (hipStream_t)stream, q, k, v, vg, w, d_o, d_og, dq, dk, dv, dvg, ds, L);
+  if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_attn_bwd launch failed");
   return SGRL_OK;
 }
 

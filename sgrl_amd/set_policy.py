@@ -88,17 +88,10 @@ class SubequivariantAttention(nn.Module):
         qkv = train_ops.linear(c, torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], dim=0),
                                torch.cat([self.q_proj.bias, self.k_proj.bias, self.v_proj.bias], dim=0), rowdiv=fn)
         e2 = 2 * self.embed_dim
-        q = (qkv[..., :e2] * float(hd2) ** -0.5).view(B, L, H, hd2)
-        k = qkv[..., e2:2 * e2].view(B, L, H, hd2)
-        v = qkv[..., 2 * e2:].view(B, L, H, hd2)
+        q, k, v = qkv[..., :e2] * float(hd2) ** -0.5, qkv[..., e2:2 * e2], qkv[..., 2 * e2:]
         vg = self.vg_proj(g).view(B, L, 3, H, hd2 - 2)
-        vg = torch.cat([vg, gdir.unsqueeze(3).expand(B, L, 3, H, 2)], dim=-1)
-        s = torch.einsum("bihd,bjhd->bhij", q, k)
-        if bias is not None:
-            s = s + bias.unsqueeze(0)
-        w = F.softmax(s, dim=-1)
-        o = torch.einsum("bhij,bjhd->bihd", w, v).reshape(B, L, H * hd2)
-        og = torch.einsum("bhij,bjshd->bishd", w, vg).reshape(B, L, 3, H * hd2)
+        vg = torch.cat([vg, gdir.unsqueeze(3).expand(B, L, 3, H, 2)], dim=-1).reshape(B, L, 3, H * hd2)
+        o, og = train_ops.set_attention(q, k, v, vg, bias)       # H = 2 heads of hd2 = 128 channels: the SET configuration
         return self.g_out(og), self.ng_out(o)
 
 

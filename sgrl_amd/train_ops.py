@@ -29,6 +29,8 @@ def _L():
         L.sgrl_linear_backward.argtypes = [vp, ci, vp, ci, ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, vp, vp]
         L.sgrl_gram_forward.argtypes = [vp, vp, vp, ci, vp]
         L.sgrl_gram_backward.argtypes = [vp, vp, vp, vp, vp, ci, vp]
+        L.sgrl_attention_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]
+        L.sgrl_attention_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]
         L.sgrl_train_ws_floats.restype = ctypes.c_int64
         L.sgrl_train_last_error.restype = ctypes.c_char_p
         _bound = True
@@ -140,6 +142,40 @@ class _GramFn(torch.autograd.Function):
         return dz.view(ctx.z_shape)
 
 
+class _AttnFn(torch.autograd.Function):
+    """q, k, v [B, L, 256], vg [B, L, 3, 256], bias [2, L, L] or None -> (o [B, L, 256], og [B, L, 3, 256])."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, vg, bias):
+        L = _L()
+        B, Ln = q.shape[0], q.shape[1]
+        q, k, v, vg = (t if t.is_contiguous() else t.contiguous() for t in (q, k, v, vg))
+        bz = None if bias is None else (bias if bias.is_contiguous() else bias.contiguous())
+        w = torch.empty((B, 2, Ln, Ln), dtype=torch.float32, device=q.device)
+        o = torch.empty((B, Ln, 256), dtype=torch.float32, device=q.device)
+        og = torch.empty((B, Ln, 3, 256), dtype=torch.float32, device=q.device)
+        st = ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream)
+        _check(L, L.sgrl_attention_forward(_p(q), _p(k), _p(v), _p(vg), _p(bz), _p(w), _p(o), _p(og), B, Ln, st),
+               "sgrl_attention_forward")
+        ctx.save_for_backward(q, k, v, vg, w)
+        ctx.has_bias = bias is not None
+        return o, og
+
+    @staticmethod
+    def backward(ctx, d_o, d_og):
+        L = _L()
+        q, k, v, vg, w = ctx.saved_tensors
+        B, Ln = q.shape[0], q.shape[1]
+        d_o = torch.zeros_like(q) if d_o is None else (d_o if d_o.is_contiguous() else d_o.contiguous())
+        d_og = torch.zeros_like(vg) if d_og is None else (d_og if d_og.is_contiguous() else d_og.contiguous())
+        dq, dk, dv, dvg, ds = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), torch.empty_like(vg), torch.empty_like(w)
+        st = ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream)
+        _check(L, L.sgrl_attention_backward(_p(q), _p(k), _p(v), _p(vg), _p(w), _p(d_o), _p(d_og), _p(dq), _p(dk), _p(dv), _p(dvg),
+                                            _p(ds), B, Ln, st), "sgrl_attention_backward")
+        dbias = ds.sum(0) if (ctx.has_bias and ctx.needs_input_grad[4]) else None
+        return dq, dk, dv, dvg, dbias
+
+
 def _on_device_with_grad(*ts):
     return ENABLED and ts[0].is_cuda and ts[0].dtype == torch.float32 and torch.is_grad_enabled() and \
         any(t is not None and t.requires_grad for t in ts)
@@ -161,3 +197,20 @@ def gram_fn(z):
         return _GramFn.apply(z)
     gram = torch.einsum("...sa,...sc->...ac", z, z).flatten(-2)
     return gram, gram.norm(dim=-1, keepdim=True) + 1.0
+
+
+def set_attention(q, k, v, vg, bias=None):
+    """Limb attention of the SET layers (reference subequivariant_attentions.py:90-151 between the projections): q (already
+    scaled), k, v [B, L, 256] = 2 heads x 128 channels, vg [B, L, 3, 256], bias [2, L, L] or None ->
+    (o [B, L, 256], og [B, L, 3, 256]) with w = softmax_j(q_i . k_j + bias) per head."""
+    if _on_device_with_grad(q, k, v, vg, bias) and q.shape[-1] == 256 and q.shape[1] <= 14:
+        return _AttnFn.apply(q, k, v, vg, bias)
+    B, Ln = q.shape[:2]
+    qh, kh, vh = q.view(B, Ln, 2, 128), k.view(B, Ln, 2, 128), v.view(B, Ln, 2, 128)
+    s = torch.einsum("bihd,bjhd->bhij", qh, kh)
+    if bias is not None:
+        s = s + bias.unsqueeze(0)
+    w = F.softmax(s, dim=-1)
+    o = torch.einsum("bhij,bjhd->bihd", w, vh).reshape(B, Ln, 256)
+    og = torch.einsum("bhij,bjshd->bishd", w, vg.view(B, Ln, 3, 2, 128)).reshape(B, Ln, 3, 256)
+    return o, og
