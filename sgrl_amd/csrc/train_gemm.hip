@@ -77,18 +77,18 @@ __device__ __forceinline__ float4 relu_mask(float4 v, float4 y) {
 // AT / BTR: the operand's contraction index is its ROW index (tile rows = k, staged as is: thread = (k, four columns));
 // otherwise its row index is the output index and the contraction runs along the row (thread = (output row, four k), rows
 // on adjacent lanes so that the transposing LDS stores fall on distinct banks).
+// One output tile (bx = column tile, by = row tile, bz = contraction split of nz, on a grid of gx x gy tiles).
 template <bool AT, bool BTR, int BK>
-__global__ __launch_bounds__(256) void k_sgemm(SArgs a) {
+__device__ __forceinline__ void sgemm_tile(const SArgs& a, float (*As)[LDP], float (*Bs)[LDP], int* s_last_p, int bx, int by,
+                                           int bz, int gx, int gy, int nz) {
   constexpr int NLD = BT * BK / 4 / 256;   // float4 loads per thread, operand and k-tile
-  __shared__ __attribute__((aligned(16))) float As[BK][LDP];
-  __shared__ __attribute__((aligned(16))) float Bs[BK][LDP];
-  __shared__ int s_last;
+  int& s_last = *s_last_p;
   const int t = threadIdx.x;
-  const int m0 = blockIdx.y * BT, n0 = blockIdx.x * BT;
-  const int k_begin = blockIdx.z * a.kper, k_end = min(a.K, k_begin + a.kper);
+  const int m0 = by * BT, n0 = bx * BT;
+  const int k_begin = bz * a.kper, k_end = min(a.K, k_begin + a.kper);
   const bool a_vec = (a.lda & 3) == 0 && aligned16(a.A) && (!a.Amask || ((a.ldmask & 3) == 0 && aligned16(a.Amask)));
   const bool b_vec = (a.ldb & 3) == 0 && aligned16(a.B);
-  const bool want_db = AT && a.db != nullptr && blockIdx.x == 0;
+  const bool want_db = AT && a.db != nullptr && bx == 0;
   float4 dbp = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 ra[2][NLD], rb[2][NLD];               // global loads run TWO k-tiles ahead of the arithmetic
 
@@ -188,10 +188,10 @@ __global__ __launch_bounds__(256) void k_sgemm(SArgs a) {
   for (int j = 0; j < 4; j++)
     v[j] = (part[(0 * 32 + r) * 33 + c0 + j] + part[(1 * 32 + r) * 33 + c0 + j]) +
            (part[(2 * 32 + r) * 33 + c0 + j] + part[(3 * 32 + r) * 33 + c0 + j]);
-  const int splits = gridDim.z;
+  const int splits = nz;
   if (splits > 1) {
-    const int ntiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
-    float* mine = a.ws + ((size_t)blockIdx.z * ntiles + tile) * TILE_WS;
+    const int ntiles = gx * gy, tile = by * gx + bx;
+    float* mine = a.ws + ((size_t)bz * ntiles + tile) * TILE_WS;
     *reinterpret_cast<float4*>(mine + r * BT + c0) = make_float4(v[0], v[1], v[2], v[3]);
     if (want_db && t < BT) mine[BT * BT + t] = dbv;
     __threadfence();
@@ -221,6 +221,33 @@ __global__ __launch_bounds__(256) void k_sgemm(SArgs a) {
     if (a.relu) o = fmaxf(o, 0.f);
     if (!AT && !BTR && a.rowdiv) o = o / a.rowdiv[m];
     a.C[(size_t)m * a.ldc + n] = o;
+  }
+}
+
+template <bool AT, bool BTR, int BK>
+__global__ __launch_bounds__(256) void k_sgemm(SArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[BK][LDP];
+  __shared__ __attribute__((aligned(16))) float Bs[BK][LDP];
+  __shared__ int s_last;
+  sgemm_tile<AT, BTR, BK>(a, As, Bs, &s_last, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z);
+}
+
+// The two products of a layer's backward pass -- input gradient and weight (+ bias) gradient -- need the same dy and nothing
+// from each other: ONE launch, the first nd workgroups take the tiles of the input gradient, the rest those of the weight
+// gradient (and its contraction splits).  Half the launches of the update's backward GEMMs, and each small product no longer
+// waits for the other to drain.
+struct BwdArgs { SArgs d; SArgs w; int nd, dgx, dgy, wgx, wgy, wnz; };
+__global__ __launch_bounds__(256) void k_sgemm_bwd(BwdArgs p) {
+  __shared__ __attribute__((aligned(16))) float As[BKF][LDP];
+  __shared__ __attribute__((aligned(16))) float Bs[BKF][LDP];
+  __shared__ int s_last;
+  static_assert(BKW == BKF, "the fused backward kernel shares one pair of LDS tiles");
+  const int id = blockIdx.x;
+  if (id < p.nd) {
+    sgemm_tile<false, true, BKF>(p.d, As, Bs, &s_last, id % p.dgx, id / p.dgx, 0, p.dgx, p.dgy, 1);
+  } else {
+    const int r = id - p.nd, per = p.wgx * p.wgy;
+    sgemm_tile<true, true, BKW>(p.w, As, Bs, &s_last, (r % per) % p.wgx, (r % per) / p.wgx, r / per, p.wgx, p.wgy, p.wnz);
   }
 }
 
@@ -454,21 +481,43 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const float* __restrict__ q, c
 // 700 rows is 20 us unsplit, 27 us in three splits; a 30 x 128 gradient over 2 100 rows 51 us unsplit, 17 us in six).  So: a
 // handful of tiles, or a contraction of a dozen k-tiles and more.  At least two k-tiles per split, never more (split, tile)
 // slots than the scratch holds.
-template <bool AT, bool BTR>
-int launch(SArgs a, float* ws, hipStream_t st) {
+// grid of one product: tiles + the contraction split (weight gradient only, see above); fills a.kper / a.ws / a.counters
+template <bool AT>
+int plan(SArgs& a, float* ws, int* tn, int* tm, int* splits_out) {
   constexpr int BK = AT ? BKW : BKF;
-  const int tm = (a.M + BT - 1) / BT, tn = (a.N + BT - 1) / BT, ntiles = tm * tn;
-  if (tm > 65535) return tfail(SGRL_ERR_LIMIT, "train gemm: too many row tiles");
+  *tm = (a.M + BT - 1) / BT; *tn = (a.N + BT - 1) / BT;
+  const int ntiles = *tm * *tn;
+  if (*tm > 65535) return tfail(SGRL_ERR_LIMIT, "train gemm: too many row tiles");
   const int ktiles = (a.K + BK - 1) / BK;
   int splits = 1;
   if (AT && ws && ktiles >= 4 && (ntiles <= 8 || (ktiles >= 12 && ntiles <= 128)))
     splits = std::max(1, std::min({(256 + ntiles - 1) / ntiles, ktiles / 2, (int)(kWsTiles / ntiles)}));
   a.kper = ((ktiles + splits - 1) / splits) * BK;
-  splits = (a.K + a.kper - 1) / a.kper;                       // no empty splits
+  *splits_out = (a.K + a.kper - 1) / a.kper;                  // no empty splits
   a.ws = ws;
   a.counters = ws ? reinterpret_cast<unsigned*>(ws + kWsTiles * TILE_WS) : nullptr;
+  return SGRL_OK;
+}
+template <bool AT, bool BTR>
+int launch(SArgs a, float* ws, hipStream_t st) {
+  constexpr int BK = AT ? BKW : BKF;
+  int tn, tm, splits;
+  const int rc = plan<AT>(a, ws, &tn, &tm, &splits);
+  if (rc != SGRL_OK) return rc;
   hipLaunchKernelGGL((k_sgemm<AT, BTR, BK>), dim3(tn, tm, splits), dim3(256), 0, st, a);
   if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "train gemm: kernel launch failed");
+  return SGRL_OK;
+}
+int launch_bwd(SArgs d, SArgs w, float* ws, hipStream_t st) {
+  BwdArgs p;
+  int dsplits;
+  int rc = plan<false>(d, nullptr, &p.dgx, &p.dgy, &dsplits);
+  if (rc != SGRL_OK) return rc;
+  rc = plan<true>(w, ws, &p.wgx, &p.wgy, &p.wnz);
+  if (rc != SGRL_OK) return rc;
+  p.d = d; p.w = w; p.nd = p.dgx * p.dgy;
+  hipLaunchKernelGGL(k_sgemm_bwd, dim3(p.nd + p.wgx * p.wgy * p.wnz), dim3(256), 0, st, p);
+  if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "train gemm: backward kernel launch failed");
   return SGRL_OK;
 }
 
@@ -500,16 +549,20 @@ int sgrl_linear_backward(const float* dy, int lddy, const float* y, int ldyo, in
     hipLaunchKernelGGL(k_rowdot, dim3((M + 3) / 4), dim3(256), 0, st, dy, lddy, y, ldyo, rowdiv, drowdiv, M, N);
     if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_rowdot launch failed");
   }
-  if (dx) {                 // dx[M][K] = g[M][N] . w[N][K]: contraction N, contiguous in g, the row index of w
-    if (!w || ldw < K || lddx < K) return tfail(SGRL_ERR_ARG, "sgrl_linear_backward: bad weight / dx argument");
-    SArgs a{dy, lddy, mask, ldyo, w, ldw, nullptr, 0, rowdiv, dx, lddx, nullptr, M, K, N, 0, nullptr, nullptr};
-    const int rc = launch<false, true>(a, nullptr, st);
+  if (dx && (!w || ldw < K || lddx < K)) return tfail(SGRL_ERR_ARG, "sgrl_linear_backward: bad weight / dx argument");
+  if (dw && (!x || ldx < K || lddw < K)) return tfail(SGRL_ERR_ARG, "sgrl_linear_backward: bad input / dw argument");
+  // dx[M][K] = g[M][N] . w[N][K]: contraction N, contiguous in g, the row index of w
+  SArgs ad{dy, lddy, mask, ldyo, w, ldw, nullptr, 0, rowdiv, dx, lddx, nullptr, M, K, N, 0, nullptr, nullptr};
+  // dw[N][K] = g^T . x: contraction M, the row index of both operands; db rides along
+  SArgs aw{dy, lddy, mask, ldyo, x, ldx, nullptr, 0, rowdiv, dw, lddw, db, N, K, M, 0, nullptr, nullptr};
+  if (dx && dw) {
+    const int rc = launch_bwd(ad, aw, ws, st);
     if (rc != SGRL_OK) return rc;
-  }
-  if (dw) {                 // dw[N][K] = g^T . x: contraction M, the row index of both operands; db rides along
-    if (!x || ldx < K || lddw < K) return tfail(SGRL_ERR_ARG, "sgrl_linear_backward: bad input / dw argument");
-    SArgs a{dy, lddy, mask, ldyo, x, ldx, nullptr, 0, rowdiv, dw, lddw, db, N, K, M, 0, nullptr, nullptr};
-    const int rc = launch<true, true>(a, ws, st);
+  } else if (dx) {
+    const int rc = launch<false, true>(ad, nullptr, st);
+    if (rc != SGRL_OK) return rc;
+  } else if (dw) {
+    const int rc = launch<true, true>(aw, ws, st);
     if (rc != SGRL_OK) return rc;
   } else if (db) {
     if (rowdiv) return tfail(SGRL_ERR_ARG, "sgrl_linear_backward: db without dw is not offered together with rowdiv");
