@@ -149,7 +149,7 @@ class Agent(nn.Module):
     def device(self):
         return next(self.actor.parameters()).device
 
-    def update(self, data_batch, it, noise=None, lazy_stats=False):
+    def update(self, data_batch, it, noise=None, lazy_stats=False, skip_unused_critic_grads=False):
         """One TD3 step on a batch of ONE morphology (reference agent.py:117-183).  `noise` replaces the N(0, policy_noise)
         draw of agent.py:128 (tests: so that a run can be compared with the reference number for number; graph capture: a
         static buffer refilled before every replay).  lazy_stats: keep the two reward statistics as device tensors instead
@@ -180,9 +180,21 @@ class Agent(nn.Module):
         loss_dict = {"loss/critic_loss": critic_loss.detach(), "misc/train_reward_mean": rmean if lazy_stats else rmean.item(),
                      "misc/train_reward_var": rvar if lazy_stats else rvar.item()}
         if it % args.policy_freq == 0:       # delayed policy update
-            actor_loss = -self.critic.Q1(obs_batch, self.actor(obs_batch)).mean()
-            self.actor_optimizer.zero_grad()
-            actor_loss.backward()
+            # The actor loss back-propagates THROUGH the critic, but the critic's own parameter gradients from this pass are
+            # never used (reference agent.py:167-176: only actor_optimizer steps; critic_optimizer.zero_grad() discards them
+            # at the top of the next update).  skip_unused_critic_grads: do not compute them -- a third of the pass's
+            # weight-gradient products; parameters, losses and actions are unchanged, only the stale `critic.*.grad` left behind
+            # differs from the reference's (default off: the reference's exact state; GraphedUpdates turns it on).
+            critic_params = [p for p in self.critic.parameters() if p.requires_grad] if skip_unused_critic_grads else []
+            for p in critic_params:
+                p.requires_grad_(False)
+            try:
+                actor_loss = -self.critic.Q1(obs_batch, self.actor(obs_batch)).mean()
+                self.actor_optimizer.zero_grad()
+                actor_loss.backward()
+            finally:
+                for p in critic_params:
+                    p.requires_grad_(True)
             if args.grad_clipping_value > 0:
                 torch.nn.utils.clip_grad_norm_(self.actor.parameters(), args.grad_clipping_value)
             adam_step(self.actor_optimizer)
@@ -266,7 +278,7 @@ class GraphedUpdates(object):
         with torch.cuda.stream(s):
             for it in range(iters):
                 self._load(sl, data_batch)
-                self.agent.update(sl["batch"], it, noise=sl["noise"], lazy_stats=True)
+                self.agent.update(sl["batch"], it, noise=sl["noise"], lazy_stats=True, skip_unused_critic_grads=True)
         torch.cuda.current_stream().wait_stream(s)
         self.warmed.add(key)
 
@@ -287,7 +299,8 @@ class GraphedUpdates(object):
             if dump:
                 g.enable_debug_mode()
             with torch.cuda.graph(g):
-                sl["out"][flag] = self.agent.update(sl["batch"], flag, noise=sl["noise"], lazy_stats=True)
+                sl["out"][flag] = self.agent.update(sl["batch"], flag, noise=sl["noise"], lazy_stats=True,
+                                                    skip_unused_critic_grads=True)
             if dump:
                 g.debug_dump(os.path.join(dump, "update_%s_flag%d.dot" % (key, flag)))
             sl["graphs"][flag] = g           # capturing records the work without running it

@@ -207,3 +207,35 @@ def test_adam_step_follows_torch_adam():
     o3.param_groups[0]["params"][0].grad = torch.ones(3)
     adam_step(o3)
     assert float(o3.state[o3.param_groups[0]["params"][0]]["step"]) == 1.0
+
+
+def test_skipping_the_unused_critic_gradients_changes_nothing_that_is_used():
+    """skip_unused_critic_grads: the actor pass does not compute the critic's parameter gradients (nobody steps on them).
+    Parameters of all four networks and the losses are identical to the default path; only the stale critic .grad differs."""
+    import copy
+    from oracle.formula import synth_obs
+    torch.manual_seed(4)
+    a1 = Agent(default_train_args())
+    a2 = copy.deepcopy(a1)
+    a2.actor_optimizer = torch.optim.Adam(a2.actor.parameters(), lr=a2.args.lr)
+    a2.critic_optimizer = torch.optim.Adam(a2.critic.parameters(), lr=a2.args.lr)
+    m = mjcf.load_asset("3d_walker_4_right_knee_left_foot")
+    gd = G.getGraphDict(m.parents, TRAV, [], device=torch.device("cpu"))
+    B, L = 5, m.num_limbs
+    for ag in (a1, a2):
+        ag.change_morphology(gd)
+        ag.models2train()
+    for it in range(3):
+        batch = {"obs": torch.from_numpy(synth_obs(L, B, 10 + it).astype(np.float32)), "next_obs": torch.from_numpy(synth_obs(L, B, 20 + it).astype(np.float32)),
+                 "action": torch.rand(B, 3 * L) * 2 - 1, "reward": torch.randn(B, 1), "done": torch.zeros(B, 1)}
+        noise = torch.randn(B, 3 * L) * 0.2
+        o1 = a1.update(batch, it, noise=noise.clone())
+        o2 = a2.update(batch, it, noise=noise.clone(), skip_unused_critic_grads=True)
+        # (not bit-equal: with frozen weights the linear layers take a different GEMM entry point of the BLAS)
+        assert abs(float(o1["loss/critic_loss"]) - float(o2["loss/critic_loss"])) < 1e-5 * abs(float(o1["loss/critic_loss"]))
+        if "loss/actor_loss" in o1:
+            assert abs(float(o1["loss/actor_loss"]) - float(o2["loss/actor_loss"])) < 1e-5 * max(abs(float(o1["loss/actor_loss"])), 1e-2)
+    for nm in ("actor", "critic", "actor_target", "critic_target"):
+        for p, q in zip(getattr(a1, nm).parameters(), getattr(a2, nm).parameters()):
+            assert float((p - q).abs().max()) < 3e-6, nm          # three Adam steps of 1e-4 each: agreement to a few % of one step
+    assert all(p.requires_grad for p in a2.critic.parameters())
