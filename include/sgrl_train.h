@@ -42,6 +42,16 @@ int sgrl_linear_backward(const float* dy, int lddy, const float* y, int ldyo, in
                          int ldx, const float* w, int ldw, float* dx, int lddx, float* dw, int lddw, float* db,
                          float* drowdiv, int M, int N, int K, float* ws, void* stream);
 
+/* The weight (+ bias) gradients of several layers in one launch per 12 layers: dw = g^T x, db = column sums of g, g as in
+ * sgrl_linear_backward (which then is called with dw = db = null).  They are not on the backward pass's critical path -- only the
+ * optimizer needs them -- so a caller may collect the descriptors during the pass and issue them together at its end. */
+typedef struct sgrl_wgrad_desc {
+  const float* dy; const float* y; const float* rowdiv; const float* x;   /* y: the forward's output, read when relu != 0 */
+  float* dw; float* db;                                                    /* db may be null */
+  int32_t lddy, ldy, ldx, lddw, M, N, K, relu;
+} sgrl_wgrad_desc;
+int sgrl_linear_wgrad_group(int n, const sgrl_wgrad_desc* d, float* ws, void* stream);
+
 /* Gram invariants of M nodes' three 32-vectors z[M, 3, 32] (reference SEActor.py:94-98): gram[M, 1024] = vec(Z'Z),
  * fn[M] = ||Z'Z||_F + 1; and their backward: dz = Z (D + D'), D = dgram + (dfn / ||Z'Z||_F) Z'Z (dgram or dfn may be null). */
 int sgrl_gram_forward(const float* z, float* gram, float* fn, int M, void* stream);

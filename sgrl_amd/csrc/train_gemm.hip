@@ -251,6 +251,23 @@ __global__ __launch_bounds__(256) void k_sgemm_bwd(BwdArgs p) {
   }
 }
 
+// Weight (+ bias) gradients of up to kGroup layers in ONE launch: they are needed only when the optimizer steps, not by the
+// backward pass itself, so the autograd functions can postpone them (train_ops.py) and the serial chain of a backward pass
+// shrinks to its input-gradient products.  first[g] = first workgroup of problem g.
+constexpr int kGroup = 12;
+struct GroupArgs { SArgs w[kGroup]; int first[kGroup + 1]; int gx[kGroup], gy[kGroup], nz[kGroup]; int n; };
+__global__ __launch_bounds__(256) void k_sgemm_wgroup(GroupArgs p) {
+  __shared__ __attribute__((aligned(16))) float As[BKW][LDP];
+  __shared__ __attribute__((aligned(16))) float Bs[BKW][LDP];
+  __shared__ int s_last;
+  int g = 0;
+  while (g + 1 < p.n && (int)blockIdx.x >= p.first[g + 1]) g++;
+  const SArgs a = p.w[g];                       // g is uniform: scalar loads from the kernel-argument segment
+  const int gx = p.gx[g], gy = p.gy[g], nz = p.nz[g];
+  const int r = blockIdx.x - p.first[g], per = gx * gy;
+  sgemm_tile<true, true, BKW>(a, As, Bs, &s_last, (r % per) % gx, (r % per) / gx, r / per, gx, gy, nz);
+}
+
 // db alone (no weight gradient requested): column sums of the masked g, 64 columns per workgroup
 __global__ __launch_bounds__(256) void k_colsum(const float* g, int ldg, const float* mask, int ldm, float* db, int M, int N) {
   __shared__ float red[4][64];
@@ -483,19 +500,19 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const float* __restrict__ q, c
 // slots than the scratch holds.
 // grid of one product: tiles + the contraction split (weight gradient only, see above); fills a.kper / a.ws / a.counters
 template <bool AT>
-int plan(SArgs& a, float* ws, int* tn, int* tm, int* splits_out) {
+int plan(SArgs& a, float* ws, int* tn, int* tm, int* splits_out, int64_t ws_slot0 = 0, int counter0 = 0) {
   constexpr int BK = AT ? BKW : BKF;
   *tm = (a.M + BT - 1) / BT; *tn = (a.N + BT - 1) / BT;
   const int ntiles = *tm * *tn;
   if (*tm > 65535) return tfail(SGRL_ERR_LIMIT, "train gemm: too many row tiles");
   const int ktiles = (a.K + BK - 1) / BK;
   int splits = 1;
-  if (AT && ws && ktiles >= 4 && (ntiles <= 8 || (ktiles >= 12 && ntiles <= 128)))
-    splits = std::max(1, std::min({(256 + ntiles - 1) / ntiles, ktiles / 2, (int)(kWsTiles / ntiles)}));
+  if (AT && ws && ktiles >= 4 && (ntiles <= 8 || (ktiles >= 12 && ntiles <= 128)) && counter0 + ntiles <= kCounters)
+    splits = std::max(1, std::min({(256 + ntiles - 1) / ntiles, ktiles / 2, (int)((kWsTiles - ws_slot0) / ntiles)}));
   a.kper = ((ktiles + splits - 1) / splits) * BK;
   *splits_out = (a.K + a.kper - 1) / a.kper;                  // no empty splits
-  a.ws = ws;
-  a.counters = ws ? reinterpret_cast<unsigned*>(ws + kWsTiles * TILE_WS) : nullptr;
+  a.ws = ws ? ws + ws_slot0 * TILE_WS : nullptr;      // this product's own (split, tile) slots and counters
+  a.counters = ws ? reinterpret_cast<unsigned*>(ws + kWsTiles * TILE_WS) + counter0 : nullptr;
   return SGRL_OK;
 }
 template <bool AT, bool BTR>
@@ -601,6 +618,35 @@ int sgrl_attention_backward(const float* q, const float* k, const float* v, cons
     return tfail(SGRL_ERR_ARG, "sgrl_attention_backward: bad argument");
   hipLaunchKernelGGL(k_attn_bwd, dim3(B), dim3(256), 0, (hipStream_t)stream, q, k, v, vg, w, d_o, d_og, dq, dk, dv, dvg, ds, L);
   if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_attn_bwd launch failed");
+  return SGRL_OK;
+}
+
+int sgrl_linear_wgrad_group(int n, const sgrl_wgrad_desc* d, float* ws, void* stream) {
+  if (n <= 0 || !d) return tfail(SGRL_ERR_ARG, "sgrl_linear_wgrad_group: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  for (int i0 = 0; i0 < n; i0 += kGroup) {
+    GroupArgs p;
+    p.n = std::min(kGroup, n - i0);
+    int64_t slot = 0;
+    int counter = 0, blocks = 0;
+    for (int g = 0; g < p.n; g++) {
+      const sgrl_wgrad_desc& q = d[i0 + g];
+      if (!q.dy || !q.x || !q.dw || q.M <= 0 || q.N <= 0 || q.K <= 0 || q.lddy < q.N || q.ldx < q.K || q.lddw < q.K ||
+          (q.relu && (!q.y || q.ldy < q.N)) || (q.relu && q.rowdiv))
+        return tfail(SGRL_ERR_ARG, "sgrl_linear_wgrad_group: bad descriptor " + std::to_string(i0 + g));
+      SArgs a{q.dy, q.lddy, q.relu ? q.y : nullptr, q.ldy, q.x, q.ldx, nullptr, 0, q.rowdiv, q.dw, q.lddw, q.db, q.N, q.K, q.M,
+              0, nullptr, nullptr};
+      const int rc = plan<true>(a, ws, &p.gx[g], &p.gy[g], &p.nz[g], slot, counter);
+      if (rc != SGRL_OK) return rc;
+      if (p.nz[g] > 1) { slot += (int64_t)p.gx[g] * p.gy[g] * p.nz[g]; counter += p.gx[g] * p.gy[g]; }
+      p.w[g] = a;
+      p.first[g] = blocks;
+      blocks += p.gx[g] * p.gy[g] * p.nz[g];
+    }
+    p.first[p.n] = blocks;
+    hipLaunchKernelGGL(k_sgemm_wgroup, dim3(blocks), dim3(256), 0, st, p);
+    if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_sgemm_wgroup launch failed");
+  }
   return SGRL_OK;
 }
 

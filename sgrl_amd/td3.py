@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import train_ops
 from .set_policy import SECritic, SEPolicy, default_args
 
 
@@ -169,7 +170,9 @@ class Agent(nn.Module):
         current_Q1, current_Q2 = self.critic(obs_batch, action_batch)
         critic_loss = F.mse_loss(current_Q1, target_Q) + F.mse_loss(current_Q2, target_Q)
         self.critic_optimizer.zero_grad()
-        critic_loss.backward()
+        # (graphed path) the weight gradients are not on the backward pass's critical path: collected, issued together at the end
+        with train_ops.deferred_wgrads(enabled=skip_unused_critic_grads):
+            critic_loss.backward()
         if args.grad_clipping_value > 0:
             torch.nn.utils.clip_grad_norm_(self.critic.parameters(), args.grad_clipping_value)
         adam_step(self.critic_optimizer)
@@ -191,7 +194,8 @@ class Agent(nn.Module):
             try:
                 actor_loss = -self.critic.Q1(obs_batch, self.actor(obs_batch)).mean()
                 self.actor_optimizer.zero_grad()
-                actor_loss.backward()
+                with train_ops.deferred_wgrads(enabled=skip_unused_critic_grads):
+                    actor_loss.backward()
             finally:
                 for p in critic_params:
                     p.requires_grad_(True)

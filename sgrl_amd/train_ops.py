@@ -7,8 +7,11 @@ modules (set_policy.py) whenever autograd is recording on the GPU -- i.e. inside
 the no-grad rollout path is the fused forward of csrc/set_actor.hip.  No CPU fallback: on the CPU the modules use
 `F.linear`; on the GPU a missing extension raises.
 """
+import contextlib
 import ctypes
 import os
+
+import numpy as np
 
 import torch
 import torch.nn.functional as F
@@ -29,6 +32,7 @@ def _L():
         L.sgrl_linear_backward.argtypes = [vp, ci, vp, ci, ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, vp, vp]
         L.sgrl_gram_forward.argtypes = [vp, vp, vp, ci, vp]
         L.sgrl_gram_backward.argtypes = [vp, vp, vp, vp, vp, ci, vp]
+        L.sgrl_linear_wgrad_group.argtypes = [ci, vp, vp, vp]
         L.sgrl_attention_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]
         L.sgrl_attention_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]
         L.sgrl_train_ws_floats.restype = ctypes.c_int64
@@ -51,6 +55,58 @@ def _scratch(device):
         ws = torch.zeros(int(_L().sgrl_train_ws_floats()), dtype=torch.float32, device=device)
         _ws[key] = ws
     return ws
+
+
+# struct sgrl_wgrad_desc (include/sgrl_train.h)
+_DESC = np.dtype([("dy", "<u8"), ("y", "<u8"), ("rowdiv", "<u8"), ("x", "<u8"), ("dw", "<u8"), ("db", "<u8"), ("lddy", "<i4"),
+                  ("ldy", "<i4"), ("ldx", "<i4"), ("lddw", "<i4"), ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("relu", "<i4")])
+assert _DESC.itemsize == 80
+_pending = None        # None: weight gradients are computed inside backward(); a list: they are postponed (deferred_wgrads)
+
+
+@contextlib.contextmanager
+def deferred_wgrads(enabled=True):
+    """Inside this context the backward() of a linear layer whose weight (and bias) are leaf parameters launches only the
+    INPUT-gradient product; its weight / bias gradients -- which nothing needs before the optimizer steps -- are collected and
+    issued together (12 layers per launch) when the context exits, and only then stored into (or added to) the parameters'
+    `.grad`: autograd itself never sees a gradient tensor that has not been computed yet."""
+    global _pending
+    if not enabled or _pending is not None:
+        yield
+        return
+    _pending = []
+    try:
+        yield
+    finally:
+        todo, _pending = _pending, None
+        flush_wgrads(todo)
+
+
+def flush_wgrads(todo):
+    if not todo:
+        return
+    L = _L()
+    by_stream = {}
+    for rec in todo:
+        by_stream.setdefault((rec["dev"], rec["stream"]), []).append(rec)
+    for (dev, stream), recs in by_stream.items():
+        d = np.zeros(len(recs), dtype=_DESC)
+        for i, r in enumerate(recs):
+            d[i] = (r["dy"].data_ptr(), 0 if r["y"] is None else r["y"].data_ptr(), 0 if r["rowdiv"] is None else r["rowdiv"].data_ptr(),
+                    r["x"].data_ptr(), r["dw"].data_ptr(), 0 if r["db"] is None else r["db"].data_ptr(), r["dy"].stride(0),
+                    r["N"], r["x"].stride(0), r["K"], r["M"], r["N"], r["K"], 1 if r["relu"] else 0)
+        _check(L, L.sgrl_linear_wgrad_group(len(recs), ctypes.c_void_p(d.ctypes.data), _p(_scratch(dev)), ctypes.c_void_p(stream)),
+               "sgrl_linear_wgrad_group")
+        with torch.no_grad():
+            for r in recs:
+                for prm, g in ((r["w_param"], r["dw"]), (r["b_param"], r["db"])):
+                    if prm is None:
+                        continue
+                    g = g.view_as(prm)
+                    if prm.grad is None:
+                        prm.grad = g
+                    else:
+                        prm.grad.add_(g)
 
 
 def _p(t):
@@ -78,6 +134,8 @@ class _LinearFn(torch.autograd.Function):
                "sgrl_linear_forward")
         ctx.save_for_backward(x2, w, y if (relu or rd is not None) else None, rd)
         ctx.has_bias, ctx.relu = bias is not None, bool(relu)
+        # leaf parameters (what deferred_wgrads may postpone): kept by reference so that their .grad can be set at the flush
+        ctx.leaf = (weight, bias) if (weight.is_leaf and (bias is None or bias.is_leaf)) else None
         ctx.x_shape = x.shape
         ctx.rd_shape = None if rowdiv is None else rowdiv.shape
         return y.view(*x.shape[:-1], N)
@@ -99,12 +157,22 @@ class _LinearFn(torch.autograd.Function):
         dw = torch.empty((N, K), dtype=torch.float32, device=dy.device) if need_w else None
         db = torch.empty((N,), dtype=torch.float32, device=dy.device) if need_b else None
         drd = torch.empty((M,), dtype=torch.float32, device=dy.device) if need_rd else None
-        st = ctypes.c_void_p(torch.cuda.current_stream(dy.device).cuda_stream)
-        _check(L, L.sgrl_linear_backward(_p(dy2), dy2.stride(0), _p(yo), N, 1 if ctx.relu else 0, _p(rd), _p(x2), x2.stride(0), _p(w), K,
-                                         _p(dx), K, _p(dw), K, _p(db), _p(drd), M, N, K, _p(_scratch(dy.device)), st),
-               "sgrl_linear_backward")
-        return (dx.view(ctx.x_shape) if need_x else None), (dw if ctx.needs_input_grad[1] else None), db, None, \
-               (drd.view(ctx.rd_shape) if need_rd else None)
+        stream = torch.cuda.current_stream(dy.device).cuda_stream
+        st = ctypes.c_void_p(stream)
+        now_w, now_b = dw, db
+        deferred = _pending is not None and need_w and ctx.leaf is not None
+        if deferred:                              # postponed: computed and stored into .grad when the deferred_wgrads context exits
+            _pending.append({"dy": dy2, "y": yo if ctx.relu else None, "rowdiv": rd, "x": x2, "dw": dw, "db": db, "M": M, "N": N,
+                             "K": K, "relu": ctx.relu, "dev": dy.device, "stream": stream,
+                             "w_param": ctx.leaf[0] if ctx.needs_input_grad[1] else None,
+                             "b_param": ctx.leaf[1] if need_b else None})
+            now_w = now_b = None
+        if dx is not None or now_w is not None or now_b is not None or drd is not None:
+            _check(L, L.sgrl_linear_backward(_p(dy2), dy2.stride(0), _p(yo), N, 1 if ctx.relu else 0, _p(rd), _p(x2), x2.stride(0),
+                                             _p(w), K, _p(dx), K, _p(now_w), K, _p(now_b), _p(drd), M, N, K, _p(_scratch(dy.device)), st),
+                   "sgrl_linear_backward")
+        return (dx.view(ctx.x_shape) if need_x else None), (None if deferred else (dw if ctx.needs_input_grad[1] else None)), \
+               (None if deferred else db), None, (drd.view(ctx.rd_shape) if need_rd else None)
 
 
 class _GramFn(torch.autograd.Function):

@@ -165,3 +165,32 @@ def test_set_attention_matches_float64(L, with_bias):
         if r is None:
             continue
         assert float((d.grad.cpu().double() - r.grad).abs().max()) < 2e-5 * (float(r.grad.abs().max()) + 1), name
+
+
+def test_deferred_weight_gradients_equal_the_immediate_ones():
+    """train_ops.deferred_wgrads: the weight / bias gradients of a whole backward pass issued together at the end (grouped
+    launches) are bit-identical to those computed layer by layer inside backward()."""
+    from oracle.formula import synth_obs
+    from sgrl_amd import graph as G, mjcf, train_ops
+    from sgrl_amd.rollout import TRAV
+    from sgrl_amd.td3 import Agent, default_train_args
+    dev = torch.device("cuda:0")
+    torch.manual_seed(6)
+    agent = Agent(default_train_args(), device=dev, use_hip=False)
+    m = mjcf.load_asset("3d_cheetah_12_rightbknee")
+    agent.change_morphology(G.getGraphDict(m.parents, TRAV, [], device=dev))
+    L = m.num_limbs
+    obs = torch.from_numpy(synth_obs(L, 100, 4).astype(np.float32)).to(dev)
+    act = torch.rand(100, 3 * L, device=dev) * 2 - 1
+    grads = []
+    for deferred in (False, True):
+        agent.critic.zero_grad()
+        q1, q2 = agent.critic(obs, act)
+        loss = (q1 ** 2).mean() + (q2 ** 2).mean()
+        with train_ops.deferred_wgrads(enabled=deferred):
+            loss.backward()
+        torch.cuda.synchronize()
+        grads.append([p.grad.detach().clone() for p in agent.critic.parameters() if p.grad is not None])
+    assert len(grads[0]) == len(grads[1]) > 100
+    for a, b in zip(grads[0], grads[1]):
+        assert torch.equal(a, b)
