@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SGRL_HIP_LIB", os.path.join(_HERE, "libsgrl_hip.so"))   # override: A/B benchmarking of builds
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["engine.hip", "set_actor.hip", "train_gemm.hip"]
+SOURCES = ["engine.hip", "set_actor.hip", "train_gemm.hip", "render.hip"]
 
 _lib = None
 
@@ -27,7 +27,7 @@ def build(verbose=False):
     """Compile every HIP source for gfx950 into sgrl_amd/libsgrl_hip.so (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    deps += [os.path.join(_HERE, "..", "include", f) for f in ("sgrl.h", "sgrl_model.h", "sgrl_set.h", "sgrl_train.h")
+    deps += [os.path.join(_HERE, "..", "include", f) for f in ("sgrl.h", "sgrl_model.h", "sgrl_set.h", "sgrl_train.h", "sgrl_render.h")
              if os.path.exists(os.path.join(_HERE, "..", "include", f))]
     if os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
         return LIB_PATH

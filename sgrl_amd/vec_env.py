@@ -238,8 +238,19 @@ class BatchedModularVecEnv(VecEnv):
     def reset_task(self):
         raise NotImplementedError("reset_task is not defined by the reference ModularEnv either (would raise in the worker)")
 
-    def get_images(self):
-        raise NotImplementedError("off-screen rendering is out of scope (SURVEY.md 8f.4)")
+    def get_images(self, env_ids=None, width=256, height=256):
+        """`SubprocVecEnv.get_images()` (reference src/subproc_vec_env.py:70-73): one RGB frame per environment, uint8
+        [n, height, width, 3] (NumPy), through this repository's own ray caster (sgrl_amd/render.py: MuJoCo's renderer is a
+        third-party dependency; pixel parity is not claimed).  env_ids: which environments (default: all -- at thousands of
+        environments pass a subset); the reference's frames are 500 x 500, here the size is an argument."""
+        from . import render
+        ids = list(range(self.num_envs)) if env_ids is None else [int(i) for i in env_ids]
+        rec, _ = self.get_records()
+        scenes = []
+        for i in ids:
+            m = self.models[self.env_morph[i]]
+            scenes.append(render.scene_of(m, rec[i, :m.nq]))
+        return render.render(scenes, width=width, height=height, device=self.device).cpu().numpy()
 
     def close(self):
         if self.closed:

@@ -25,7 +25,7 @@ def so():
 
 def test_exports_every_declared_symbol(so):
     names = _declared("sgrl.h")
-    for extra in ("sgrl_set.h", "sgrl_train.h"):
+    for extra in ("sgrl_set.h", "sgrl_train.h", "sgrl_render.h"):
         if os.path.exists(os.path.join(REPO, "include", extra)):
             names += _declared(extra)
     assert len(names) >= 13
