@@ -135,7 +135,7 @@ def _cpu_worker(job):
     return steps
 
 
-# multiply-accumulates the SET forward EXECUTES per limb node: after the Gram-triangle folding (K = 576 instead of 1024 on the
+# multiply-accumulates the SET forward EXECUTES per limb node: with the Gram matrix taken over its blocked lower triangle (K = 576 instead of 1024 on the
 # seven Gram-fed layers), with the projections as the zero-padded stacked GEMM operands the kernels really run, and after
 # folding ng_out / g_out into the value projections (those two GEMMs per layer no longer exist)
 def set_executed_flops_per_node():
@@ -266,9 +266,10 @@ def main():
                               "mfma_f32_peak_tflops": 157.3,
                               "frac_of_f32_mfma_peak_nominal": round(nodes * 10.07e6 / (ms_set * 1e-3) / 157.3e12, 4),
                               "frac_of_f32_mfma_peak_executed": round(nodes * ex / (ms_set * 1e-3) / 157.3e12, 4),
-                              "note": "nominal = the reference's dense layer sizes; executed = what the kernels run after "
-                                      "folding the symmetric Gram matrix onto its packed triangle and the attention output "
-                                      "projections into the value projections.  The GEMMs are float32-equivalent but run on the "
+                              "note": "nominal = the reference's dense layer sizes; executed = what the kernels run with the symmetric Gram "
+                                      "matrix taken over the 36 4x4 blocks of its lower triangle (K = 576 instead of 1024; the "
+                                      "operand is generated inside the GEMM, never stored) and the attention output "
+                                      "projections folded into the value projections.  The GEMMs are float32-equivalent but run on the "
                                       "bf16 matrix cores (six bf16 products per f32 product, gemm_f32.h): the f32-MFMA peak is the "
                                       "yardstick the reference arithmetic would be priced against, not a bound of this kernel"}
         rec, cnt = env.get_records()
