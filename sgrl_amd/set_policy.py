@@ -182,10 +182,15 @@ class TransformerModel(nn.Module):
             self.encoder.weight.uniform_(-0.1, 0.1)
             self.g_encoder.weight.uniform_(-0.1, 0.1)
 
-    def forward(self, x, graph):
-        """x: [B, L, feature] (node-major).  Returns [B, L, output_size]."""
+    def forward(self, x, graph, geo_grad=True):
+        """x: [B, L, feature] (node-major).  Returns [B, L, output_size].  geo_grad=False: the caller does not need gradients
+        with respect to the geometric part of x (the critic inside the actor loss: x = [state | action] requires grad because
+        of the action, its 24 geometric values per limb come from the state) -- the gravity / direction columns that are
+        concatenated into every invariant then stay out of the autograd graph."""
         B, L, _ = x.shape
         g0 = x[..., :3 * G_NUM].reshape(B, L, G_NUM, 3).transpose(-1, -2)   # [B,L,3,8]
+        if not geo_grad:
+            g0 = g0.detach()
         n0 = x[..., 3 * G_NUM:]
         gdir = g0[..., 1:3]
         scale = math.sqrt(self.ninp)
@@ -251,7 +256,7 @@ class SEPolicy(nn.Module):
                 self._hip = HipSetActor(self)
             return self._hip.forward_single(state, self.graph)
         x = state.reshape(B, self.num_limbs, -1)
-        act = self.max_action * torch.tanh(self.actor(x, self.graph))
+        act = self.max_action * torch.tanh(self.actor(x, self.graph, state.requires_grad))
         self.action = act.reshape(B, -1)
         return self.action
 
@@ -322,14 +327,14 @@ class SECritic(nn.Module):
         if self._hip_path(state):           # target values under no_grad (reference agent.py:136-148): HIP kernels
             return self._hip_handles().forward_single(state, action, self.graph)
         x = self._input(state, action)
-        B = x.shape[0]
-        return self.critic1(x, self.graph).reshape(B, -1), self.critic2(x, self.graph).reshape(B, -1)
+        B, gg = x.shape[0], state.requires_grad
+        return self.critic1(x, self.graph, gg).reshape(B, -1), self.critic2(x, self.graph, gg).reshape(B, -1)
 
     def Q1(self, state, action):
         if self._hip_path(state):
             return self._hip_handles().forward_single(state, action, self.graph, which=(1,))[0]
         x = self._input(state, action)
-        return self.critic1(x, self.graph).reshape(x.shape[0], -1)
+        return self.critic1(x, self.graph, state.requires_grad).reshape(x.shape[0], -1)
 
     def clear_buffer(self):
         pass

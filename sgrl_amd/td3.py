@@ -264,9 +264,18 @@ class GraphedUpdates(object):
             dev, B = self.agent.device, self.B
             z = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)
             sl = {"graph": graph, "batch": {"obs": z(B, 41 * L), "action": z(B, 3 * L), "next_obs": z(B, 41 * L), "reward": z(B, 1),
-                                            "done": z(B, 1)}, "noise": z(B, 3 * L), "graphs": {}, "out": {}}
+                                            "done": z(B, 1)}, "noise": z(B, 3 * L), "graphs": {}, "out": {}, "stamp": {}}
             self.slots[key] = sl
         return sl
+
+    def _workspace_stamp(self):
+        """Sizes of the device workspaces the captured HIP target kernels point into (include/sgrl_set.h)."""
+        out = []
+        for mod in (self.agent.actor_target, self.agent.critic_target):
+            h = getattr(mod, "_hip", None)
+            for hh in ([h] if hasattr(h, "h") else [getattr(h, "q1", None), getattr(h, "q2", None)]):
+                out.append(-1 if hh is None else int(hh.L.sgrl_set_workspace_bytes(hh.h)))
+        return tuple(out)
 
     def _load(self, sl, data_batch):
         for k, t in sl["batch"].items():
@@ -296,6 +305,12 @@ class GraphedUpdates(object):
             raise RuntimeError("warm(%r, ...) every morphology before the first graphed update" % (key,))
         flag = 0 if it % self.agent.args.policy_freq == 0 else 1
         self._load(sl, data_batch)
+        # A graph bakes the addresses of the SET handles' workspaces.  They only ever grow, and every morphology is run eagerly
+        # before any capture -- but a graph captured before a LATER regrowth would fault on replay (a GPU memory fault, not an
+        # exception): the workspaces' sizes are compared with those at capture time and such a graph is captured again.
+        stamp = self._workspace_stamp()
+        if flag in sl["graphs"] and sl["stamp"].get(flag) != stamp:
+            del sl["graphs"][flag]
         if flag not in sl["graphs"]:
             self.agent.change_morphology(graph)
             g = torch.cuda.CUDAGraph()
@@ -308,5 +323,6 @@ class GraphedUpdates(object):
             if dump:
                 g.debug_dump(os.path.join(dump, "update_%s_flag%d.dot" % (key, flag)))
             sl["graphs"][flag] = g           # capturing records the work without running it
+            sl["stamp"][flag] = self._workspace_stamp()
         sl["graphs"][flag].replay()
         return sl["out"][flag]

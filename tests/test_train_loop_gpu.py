@@ -185,3 +185,36 @@ def test_graphed_updates_equal_eager_updates():
             assert float((p - q).abs().max()) < 2e-4 * (1 + float(q.abs().max())), nm
     moved = max(float((p - s0).abs().max()) for p, s0 in zip(graphed.critic.parameters(), start))
     assert moved > 1e-4
+
+
+def test_graphed_update_survives_a_workspace_regrowth():
+    """A morphology captured BEFORE a larger one makes the SET handles regrow their workspaces must be captured again, not
+    replayed into freed memory (td3.GraphedUpdates workspace stamp)."""
+    from oracle.formula import synth_obs
+    from sgrl_amd import graph as G, mjcf
+    from sgrl_amd.rollout import TRAV
+    from sgrl_amd.td3 import Agent, GraphedUpdates, default_train_args
+    import torch
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    agent = Agent(default_train_args(), device=dev)
+    agent.models2train()
+    gr = GraphedUpdates(agent, 100)
+    data = {}
+    for k, name in enumerate(["3d_hopper_3_shin", "3d_cheetah_14_full"]):
+        m = mjcf.load_asset(name)
+        L = m.num_limbs
+        gd = G.getGraphDict(m.parents, TRAV, [], device=dev)
+        batch = {"obs": torch.from_numpy(synth_obs(L, 100, 1).astype(np.float32)).to(dev), "next_obs": torch.from_numpy(synth_obs(L, 100, 2).astype(np.float32)).to(dev),
+                 "action": torch.rand(100, 3 * L, device=dev) * 2 - 1, "reward": torch.randn(100, 1, device=dev), "done": torch.zeros(100, 1, device=dev)}
+        data[k] = (gd, L, batch)
+        gr.warm(k, gd, L, batch, iters=1)
+        for it in range(2):
+            gr.update(k, gd, L, batch, it)          # captured right after ITS warm-up: the second morphology regrows the workspaces
+    stamp_small = dict(gr.slots[0]["stamp"])
+    gd, L, batch = data[0]
+    for it in range(4):
+        out = gr.update(0, gd, L, batch, it)        # must re-capture, not fault
+    torch.cuda.synchronize()
+    assert gr.slots[0]["stamp"][0] != stamp_small[0]
+    assert np.isfinite(float(out["loss/critic_loss"]))
