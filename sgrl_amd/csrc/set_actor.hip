@@ -261,10 +261,10 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   // column c, threads 128..255 spatial rows 1 and 2; each sums over BOTH heads itself (no cross-thread reduction, no
   // barrier), reading the L value entries of a (quantity, head) once into registers
   const int half = t >> 7, c = t & 127;
-  float out[LMAX];                               // after the loop: the values of the LAST quantity (half 0: the scalar stream)
 #pragma unroll
-  for (int qq = 1; qq >= 0; qq--) {
+  for (int qq = 0; qq < 2; qq++) {
     const int quantity = 2 * half + qq;          // 0: scalar stream, 1..3: spatial row quantity - 1
+    float out[LMAX];
 #pragma unroll
     for (int i = 0; i < LMAX; i++) out[i] = 0.f;
 #pragma unroll
@@ -296,18 +296,16 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
     if (quantity != 0) {
 #pragma unroll
       for (int i = 0; i < LMAX; i++) if (i < L) g1[((size_t)(n0 + i) * 3 + (quantity - 1)) * 128 + c] = out[i];
-    }
-  }
-  // scalar stream (threads 0..127 hold delta[i][c] - b_ng[c] in out[]): the rows go through LDS to the LayerNorm, one wave
-  // per limb row, two channels per lane, exactly k_add_ln's arithmetic
-  if (half == 0) {
-    const float bb = b_ng[c];
+    } else {
+      // scalar stream: the rows go through LDS to the LayerNorm below, one wave per limb row, two channels per lane
+      const float bb = b_ng[c];
 #pragma unroll
-    for (int i = 0; i < LMAX; i++)
-      if (i < L) {
-        dl[i][c] = out[i] + bb;
-        if (delta_dbg) delta_dbg[(size_t)(n0 + i) * 128 + c] = out[i] + bb;
-      }
+      for (int i = 0; i < LMAX; i++)
+        if (i < L) {
+          dl[i][c] = out[i] + bb;
+          if (delta_dbg) delta_dbg[(size_t)(n0 + i) * 128 + c] = out[i] + bb;
+        }
+    }
   }
   __syncthreads();
   const int lane = t & 63;
