@@ -57,6 +57,11 @@ int sgrl_linear_wgrad_group(int n, const sgrl_wgrad_desc* d, float* ws, void* st
 int sgrl_gram_forward(const float* z, float* gram, float* fn, int M, void* stream);
 int sgrl_gram_backward(const float* z, const float* dgram, const float* dfn, const float* fn, float* dz, int M, void* stream);
 
+/* Equivariant contraction of M nodes' three 32-vectors with their 32 x 32 matrices (reference SEActor.py:108-110, 262-264):
+ * t[M, 3, 32] = z[M, 3, 32] . mat[M, 32, 32] per node; backward: dz = dt . mat', dmat = z' . dt. */
+int sgrl_zmat_forward(const float* z, const float* mat, float* t, int M, void* stream);
+int sgrl_zmat_backward(const float* z, const float* mat, const float* dt, float* dz, float* dmat, int M, void* stream);
+
 /* Limb attention of B environments with L <= 14 limbs, 2 heads x 128 channels (reference subequivariant_attentions.py:90-151
  * between the projections): q, k, v [B, L, 256] (q already scaled), vg [B, L, 3, 256] (vector values), bias [2, L, L] or null.
  *   w[b][h][i][:] = softmax_j(q_i . k_j + bias),  o[b][i][c] = sum_j w[h(c)] v[j][c],  og[b][i][s][c] = sum_j w[h(c)] vg[j][s][c]

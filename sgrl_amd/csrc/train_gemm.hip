@@ -493,6 +493,44 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const float* __restrict__ q, c
   }
 }
 
+// Equivariant contraction of a node's three 32-vectors with its 32 x 32 matrix (reference SEActor.py:108-110, 262-264):
+//   t[s][c] = sum_a z[s][a] mat[a][c]       backward:  dz[s][a] = sum_c dt[s][c] mat[a][c],  dmat[a][c] = sum_s z[s][a] dt[s][c]
+// One 128-thread half-workgroup per node (two nodes per workgroup).
+__global__ __launch_bounds__(256) void k_zmat_fwd(const float* __restrict__ z, const float* __restrict__ mat, float* t, int M) {
+  __shared__ float zs[2][96];
+  const int half = threadIdx.x >> 7, u = threadIdx.x & 127, m = blockIdx.x * 2 + half;
+  if (m < M && u < 96) zs[half][u] = z[(size_t)m * 96 + u];
+  __syncthreads();
+  if (m >= M || u >= 96) return;
+  const int sx = u >> 5, c = u & 31;
+  const float* mm = mat + (size_t)m * 1024 + c;
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 32; a++) acc += zs[half][32 * sx + a] * mm[32 * a];
+  t[(size_t)m * 96 + u] = acc;
+}
+__global__ __launch_bounds__(256) void k_zmat_bwd(const float* __restrict__ z, const float* __restrict__ mat,
+                                                  const float* __restrict__ dt, float* dz, float* dmat, int M) {
+  __shared__ float zs[2][96], ds[2][96];
+  const int half = threadIdx.x >> 7, u = threadIdx.x & 127, m = blockIdx.x * 2 + half;
+  if (m < M && u < 96) { zs[half][u] = z[(size_t)m * 96 + u]; ds[half][u] = dt[(size_t)m * 96 + u]; }
+  __syncthreads();
+  if (m >= M) return;
+  const float* mm = mat + (size_t)m * 1024;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {                     // dmat: 1024 entries, eight per thread
+    const int o = u + 128 * i, a = o >> 5, c = o & 31;
+    dmat[(size_t)m * 1024 + o] = zs[half][a] * ds[half][c] + zs[half][32 + a] * ds[half][32 + c] + zs[half][64 + a] * ds[half][64 + c];
+  }
+  if (u < 96) {                                      // dz[s][a] = sum_c dt[s][c] mat[a][c]
+    const int sx = u >> 5, a = u & 31;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; c++) acc += ds[half][32 * sx + c] * mm[32 * a + c];
+    dz[(size_t)m * 96 + u] = acc;
+  }
+}
+
 // Only the weight gradient (AT) splits its contraction, and only where that pays: the release / acquire fences of the last-
 // workgroup reduction cost ~10-15 us on the eight-XCD chip, more than a few extra k-steps (measured: a 256 x 256 gradient over
 // 700 rows is 20 us unsplit, 27 us in three splits; a 30 x 128 gradient over 2 100 rows 51 us unsplit, 17 us in six).  So: a
@@ -647,6 +685,20 @@ int sgrl_linear_wgrad_group(int n, const sgrl_wgrad_desc* d, float* ws, void* st
     hipLaunchKernelGGL(k_sgemm_wgroup, dim3(blocks), dim3(256), 0, st, p);
     if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_sgemm_wgroup launch failed");
   }
+  return SGRL_OK;
+}
+
+int sgrl_zmat_forward(const float* z, const float* mat, float* t, int M, void* stream) {
+  if (!z || !mat || !t || M <= 0) return tfail(SGRL_ERR_ARG, "sgrl_zmat_forward: bad argument");
+  hipLaunchKernelGGL(k_zmat_fwd, dim3((M + 1) / 2), dim3(256), 0, (hipStream_t)stream, z, mat, t, M);
+  if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_zmat_fwd launch failed");
+  return SGRL_OK;
+}
+
+int sgrl_zmat_backward(const float* z, const float* mat, const float* dt, float* dz, float* dmat, int M, void* stream) {
+  if (!z || !mat || !dt || !dz || !dmat || M <= 0) return tfail(SGRL_ERR_ARG, "sgrl_zmat_backward: bad argument");
+  hipLaunchKernelGGL(k_zmat_bwd, dim3((M + 1) / 2), dim3(256), 0, (hipStream_t)stream, z, mat, dt, dz, dmat, M);
+  if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_zmat_bwd launch failed");
   return SGRL_OK;
 }
 

@@ -121,7 +121,7 @@ class SubequivariantEncoderLayer(nn.Module):
         c = torch.cat([inv, ng], dim=-1)
         mat = self.linear4(self.linear3(c, relu=True), rowdiv=fn).view(*ng.shape[:2], Z_DIM, Z_DIM)
         z3 = torch.cat([self.g_proj3(g1), gdir], dim=-1)
-        g = g + self.linear5(torch.einsum("blsa,blac->blsc", z3, mat))
+        g = g + self.linear5(train_ops.zmat(z3, mat))
         ng = self.norm2(ng + self.linear2(self.linear1(c, relu=True), rowdiv=fn))
         return g, ng
 
@@ -207,7 +207,7 @@ class TransformerModel(nn.Module):
             return self.decoder_ng(c, rowdiv=fn)
         mat = self.linear2_m(self.linear1_m(c, relu=True), rowdiv=fn).view(B, L, Z_DIM, Z_DIM)
         zh = torch.cat([self.g_proj(out_g), gdir], dim=-1)
-        vec = self.decoder_g(torch.einsum("blsa,blac->blsc", zh, mat)).squeeze(-1)   # [B,L,3]
+        vec = self.decoder_g(train_ops.zmat(zh, mat)).squeeze(-1)   # [B,L,3]
         return torch.einsum("blsk,bls->blk", g0[..., 5:8], vec)
 
 

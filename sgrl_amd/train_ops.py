@@ -33,6 +33,8 @@ def _L():
         L.sgrl_gram_forward.argtypes = [vp, vp, vp, ci, vp]
         L.sgrl_gram_backward.argtypes = [vp, vp, vp, vp, vp, ci, vp]
         L.sgrl_linear_wgrad_group.argtypes = [ci, vp, vp, vp]
+        L.sgrl_zmat_forward.argtypes = [vp, vp, vp, ci, vp]
+        L.sgrl_zmat_backward.argtypes = [vp, vp, vp, vp, vp, ci, vp]
         L.sgrl_attention_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]
         L.sgrl_attention_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]
         L.sgrl_train_ws_floats.restype = ctypes.c_int64
@@ -210,6 +212,36 @@ class _GramFn(torch.autograd.Function):
         return dz.view(ctx.z_shape)
 
 
+class _ZmatFn(torch.autograd.Function):
+    """z [..., 3, 32], mat [..., 32, 32] -> z . mat [..., 3, 32] per node."""
+
+    @staticmethod
+    def forward(ctx, z, mat):
+        L = _L()
+        z2, m2 = z.reshape(-1, 96), mat.reshape(-1, 1024)
+        z2 = z2 if z2.is_contiguous() else z2.contiguous()
+        m2 = m2 if m2.is_contiguous() else m2.contiguous()
+        M = z2.shape[0]
+        t = torch.empty((M, 96), dtype=torch.float32, device=z.device)
+        st = ctypes.c_void_p(torch.cuda.current_stream(z.device).cuda_stream)
+        _check(L, L.sgrl_zmat_forward(_p(z2), _p(m2), _p(t), M, st), "sgrl_zmat_forward")
+        ctx.save_for_backward(z2, m2)
+        ctx.shapes = (z.shape, mat.shape)
+        return t.view(z.shape)
+
+    @staticmethod
+    def backward(ctx, dt):
+        L = _L()
+        z2, m2 = ctx.saved_tensors
+        M = z2.shape[0]
+        d = dt.reshape(M, 96)
+        d = d if d.is_contiguous() else d.contiguous()
+        dz, dm = torch.empty_like(z2), torch.empty_like(m2)
+        st = ctypes.c_void_p(torch.cuda.current_stream(z2.device).cuda_stream)
+        _check(L, L.sgrl_zmat_backward(_p(z2), _p(m2), _p(d), _p(dz), _p(dm), M, st), "sgrl_zmat_backward")
+        return dz.view(ctx.shapes[0]), dm.view(ctx.shapes[1])
+
+
 class _AttnFn(torch.autograd.Function):
     """q, k, v [B, L, 256], vg [B, L, 3, 256], bias [2, L, L] or None -> (o [B, L, 256], og [B, L, 3, 256])."""
 
@@ -282,3 +314,10 @@ def set_attention(q, k, v, vg, bias=None):
     o = torch.einsum("bhij,bjhd->bihd", w, vh).reshape(B, Ln, 256)
     og = torch.einsum("bhij,bjshd->bishd", w, vg.view(B, Ln, 3, 2, 128)).reshape(B, Ln, 3, 256)
     return o, og
+
+
+def zmat(z, mat):
+    """Per node: z [..., 3, 32] . mat [..., 32, 32] -> [..., 3, 32]  (reference SEActor.py:108-110: torch.bmm(g_src3, mat3))."""
+    if _on_device_with_grad(z, mat) and z.shape[-2:] == (3, 32) and mat.shape[-2:] == (32, 32):
+        return _ZmatFn.apply(z, mat)
+    return torch.einsum("...sa,...ac->...sc", z, mat)

@@ -194,3 +194,19 @@ def test_deferred_weight_gradients_equal_the_immediate_ones():
     assert len(grads[0]) == len(grads[1]) > 100
     for a, b in zip(grads[0], grads[1]):
         assert torch.equal(a, b)
+
+
+def test_zmat_matches_float64():
+    from sgrl_amd import train_ops
+    torch.manual_seed(21)
+    z, mat, dt = torch.randn(31, 5, 3, 32), torch.randn(31, 5, 32, 32) * 0.2, torch.randn(31, 5, 3, 32)
+    zr, mr = z.double().requires_grad_(), mat.double().requires_grad_()
+    tr = torch.einsum("blsa,blac->blsc", zr, mr)
+    tr.backward(dt.double())
+    zd, md = z.cuda().requires_grad_(), mat.cuda().requires_grad_()
+    t = train_ops.zmat(zd, md)
+    assert type(t.grad_fn).__name__.startswith("_ZmatFn")
+    t.backward(dt.cuda())
+    assert float((t.detach().cpu().double() - tr.detach()).abs().max()) < 1e-5
+    assert float((zd.grad.cpu().double() - zr.grad).abs().max()) < 1e-5
+    assert float((md.grad.cpu().double() - mr.grad).abs().max()) < 1e-5
