@@ -63,15 +63,17 @@ int sgrl_zmat_forward(const float* z, const float* mat, float* t, int M, void* s
 int sgrl_zmat_backward(const float* z, const float* mat, const float* dt, float* dz, float* dmat, int M, void* stream);
 
 /* Limb attention of B environments with L <= 14 limbs, 2 heads x 128 channels (reference subequivariant_attentions.py:90-151
- * between the projections): q, k, v [B, L, 256] (q already scaled), vg [B, L, 3, 256] (vector values), bias [2, L, L] or null.
- *   w[b][h][i][:] = softmax_j(q_i . k_j + bias),  o[b][i][c] = sum_j w[h(c)] v[j][c],  og[b][i][s][c] = sum_j w[h(c)] vg[j][s][c]
- * w [B, 2, L, L] is returned for the backward, which yields dq, dk, dv, dvg and ds [B, 2, L, L] (the score gradient: its sum over
- * the environments is the gradient of `bias`). */
-int sgrl_attention_forward(const float* q, const float* k, const float* v, const float* vg, const float* bias, float* w,
+ * between the projections).  qkv [B, L, 768] = q | k | v as the stacked projection leaves them (q is multiplied by `scale` inside);
+ * the vector values are given in parts and never concatenated: vgp [B, L, 3, 252] (126 projected channels per head) and gdir
+ * [B, L, 3, 2] (channels 126, 127 of both heads); bias [2, L, L] or null.
+ *   w[b][h][i][:] = softmax_j(scale q_i . k_j + bias),  o[b][i][c] = sum_j w[h(c)] v[j][c],  og[b][i][s][c] = sum_j w[h(c)] vg[j][s][c]
+ * w [B, 2, L, L] is returned for the backward, which yields dqkv [B, L, 768], dvgp [B, L, 3, 252], dgdh [B, L, 3, 2 heads, 2] (the
+ * gradient of gdir per head: sum over the heads) and ds [B, 2, L, L] (the score gradient: its sum over the environments is the
+ * gradient of `bias`). */
+int sgrl_attention_forward(const float* qkv, const float* vgp, const float* gdir, const float* bias, float scale, float* w,
                            float* o, float* og, int B, int L, void* stream);
-int sgrl_attention_backward(const float* q, const float* k, const float* v, const float* vg, const float* w, const float* d_o,
-                            const float* d_og, float* dq, float* dk, float* dv, float* dvg, float* ds, int B, int L,
-                            void* stream);
+int sgrl_attention_backward(const float* qkv, const float* vgp, const float* gdir, float scale, const float* w, const float* d_o,
+                            const float* d_og, float* dqkv, float* dvgp, float* dgdh, float* ds, int B, int L, void* stream);
 
 const char* sgrl_train_last_error(void);
 

@@ -342,19 +342,25 @@ __global__ __launch_bounds__(256) void k_gram_bwd(const float* __restrict__ z, c
 }
 
 // Limb attention of one environment (reference subequivariant_attentions.py:90-151 between the projections): H = 2 heads of
-// 128 channels, L <= 14 limbs.  q, k, v [B, L, 256]; vg [B, L, 3, 256] (vector values); bias [2, L, L] or null.
-//   w = softmax_j(q_i . k_j + bias);   o[i][c] = sum_j w[h(c)][i][j] v[j][c];   og[i][s][c] = sum_j w[h(c)][i][j] vg[j][s][c]
+// 128 channels, L <= 14 limbs.  qkv [B, L, 768] = (q | k | v) as the stacked projection leaves them (q is scaled by `scale`
+// here); the vector values vg[j][s][h][d] are vgp [B, L, 3, 252] (d < 126: the projected part, 126 per head) and the node's
+// gravity / direction pair gdir [B, L, 3, 2] (d = 126, 127) -- the concatenation is never built; bias [2, L, L] or null.
+//   w = softmax_j(scale q_i . k_j + bias);   o[i][c] = sum_j w[h(c)][i][j] v[j][c];   og[i][s][c] = sum_j w[h(c)][i][j] vg[j][s][c]
 // One 256-thread workgroup per environment; scores by a thread per (head, i, j) from LDS-resident q / k rows (pitch 257: the
 // rows of different limbs fall on different banks), outputs by a thread per channel.  w is kept for the backward.
 constexpr int AL = 14, AP = 257;
-__global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ q, const float* __restrict__ k,
-                                                  const float* __restrict__ v, const float* __restrict__ vg,
-                                                  const float* __restrict__ bias, float* wout, float* o, float* og, int L) {
+__device__ __forceinline__ float vg_at(const float* vgp, const float* gdir, size_t node, int sx, int t) {
+  const int h = t >> 7, d = t & 127;
+  return d < 126 ? vgp[(node * 3 + sx) * 252 + h * 126 + d] : gdir[(node * 3 + sx) * 2 + (d - 126)];
+}
+__global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ qkv, const float* __restrict__ vgp,
+                                                  const float* __restrict__ gdir, const float* __restrict__ bias, float scale,
+                                                  float* wout, float* o, float* og, int L) {
   __shared__ float qs[AL * AP], ks[AL * AP];
   __shared__ float sc[2 * AL * AL];
   const int b = blockIdx.x, t = threadIdx.x;
-  const size_t base = (size_t)b * L * 256;
-  for (int i = 0; i < L; i++) { qs[i * AP + t] = q[base + i * 256 + t]; ks[i * AP + t] = k[base + i * 256 + t]; }
+  const size_t n0 = (size_t)b * L;
+  for (int i = 0; i < L; i++) { qs[i * AP + t] = qkv[(n0 + i) * 768 + t] * scale; ks[i * AP + t] = qkv[(n0 + i) * 768 + 256 + t]; }
   __syncthreads();
   for (int idx = t; idx < 2 * L * L; idx += 256) {
     const int h = idx / (L * L), i = (idx / L) % L, j = idx % L;
@@ -380,46 +386,46 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ q, c
   const float* w = sc + h * L * L;
   float vv[AL];
 #pragma unroll
-  for (int j = 0; j < AL; j++) vv[j] = j < L ? v[base + j * 256 + t] : 0.f;
+  for (int j = 0; j < AL; j++) vv[j] = j < L ? qkv[(n0 + j) * 768 + 512 + t] : 0.f;
 #pragma unroll
   for (int i = 0; i < AL; i++)
     if (i < L) {
       float acc = 0.f;
 #pragma unroll
       for (int j = 0; j < AL; j++) if (j < L) acc += w[i * L + j] * vv[j];
-      o[base + i * 256 + t] = acc;
+      o[(n0 + i) * 256 + t] = acc;
     }
   for (int sx = 0; sx < 3; sx++) {
 #pragma unroll
-    for (int j = 0; j < AL; j++) vv[j] = j < L ? vg[(base + j * 256) * 3 + sx * 256 + t] : 0.f;
+    for (int j = 0; j < AL; j++) vv[j] = j < L ? vg_at(vgp, gdir, n0 + j, sx, t) : 0.f;
 #pragma unroll
     for (int i = 0; i < AL; i++)
       if (i < L) {
         float acc = 0.f;
 #pragma unroll
         for (int j = 0; j < AL; j++) if (j < L) acc += w[i * L + j] * vv[j];
-        og[(base + i * 256) * 3 + sx * 256 + t] = acc;
+        og[((n0 + i) * 3 + sx) * 256 + t] = acc;
       }
   }
 }
-// Backward: dw = do v' + sum_s dog_s vg_s' (per head), ds = w (dw - sum_j w dw), dq = ds k, dk = ds' q, dv = w' do, dvg = w' dog.
+// Backward: dw = do v' + sum_s dog_s vg_s' (per head), ds = w (dw - sum_j w dw), dq = scale ds k, dk = ds' (scale q), dv = w' do,
+// dvg = w' dog.  dqkv [B, L, 768] is written packed; dvg goes to dvgp [B, L, 3, 252] and, per head, dgdh [B, L, 3, 2 heads, 2];
 // ds [B, 2, L, L] is written out as well (its sum over the environments is the gradient of the relation bias).
-__global__ __launch_bounds__(256) void k_attn_bwd(const float* __restrict__ q, const float* __restrict__ k,
-                                                  const float* __restrict__ v, const float* __restrict__ vg,
-                                                  const float* __restrict__ win, const float* __restrict__ dout,
-                                                  const float* __restrict__ dog, float* dq, float* dk, float* dv, float* dvg,
-                                                  float* ds_out, int L) {
+__global__ __launch_bounds__(256) void k_attn_bwd(const float* __restrict__ qkv, const float* __restrict__ vgp,
+                                                  const float* __restrict__ gdir, float scale, const float* __restrict__ win,
+                                                  const float* __restrict__ dout, const float* __restrict__ dog, float* dqkv,
+                                                  float* dvgp, float* dgdh, float* ds_out, int L) {
   __shared__ float as[AL * AP], bs[AL * AP];
   __shared__ float w[2 * AL * AL], dw[2 * AL * AL];
   const int b = blockIdx.x, t = threadIdx.x;
-  const size_t base = (size_t)b * L * 256;
+  const size_t n0 = (size_t)b * L;
   for (int idx = t; idx < 2 * L * L; idx += 256) { w[idx] = win[(size_t)b * 2 * L * L + idx]; dw[idx] = 0.f; }
   // dw, four passes: (do, v), (dog_s, vg_s) for s = 0..2, each staged in LDS
   for (int pass = 0; pass < 4; pass++) {
     __syncthreads();
     for (int i = 0; i < L; i++) {
-      if (pass == 0) { as[i * AP + t] = dout[base + i * 256 + t]; bs[i * AP + t] = v[base + i * 256 + t]; }
-      else { as[i * AP + t] = dog[(base + i * 256) * 3 + (pass - 1) * 256 + t]; bs[i * AP + t] = vg[(base + i * 256) * 3 + (pass - 1) * 256 + t]; }
+      if (pass == 0) { as[i * AP + t] = dout[(n0 + i) * 256 + t]; bs[i * AP + t] = qkv[(n0 + i) * 768 + 512 + t]; }
+      else { as[i * AP + t] = dog[((n0 + i) * 3 + (pass - 1)) * 256 + t]; bs[i * AP + t] = vg_at(vgp, gdir, n0 + i, pass - 1, t); }
     }
     __syncthreads();
     for (int idx = t; idx < 2 * L * L; idx += 256) {
@@ -442,53 +448,54 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const float* __restrict__ q, c
   }
   __syncthreads();
   for (int idx = t; idx < 2 * L * L; idx += 256) ds_out[(size_t)b * 2 * L * L + idx] = dw[idx];
-  const int h = t >> 7;
+  const int h = t >> 7, d = t & 127;
   const float* wh = w + h * L * L;
   const float* dsh = dw + h * L * L;
   float col[AL];
-  // dq[i] = sum_j ds[i][j] k[j]
+  // dq[i] = scale sum_j ds[i][j] k[j]
 #pragma unroll
-  for (int j = 0; j < AL; j++) col[j] = j < L ? k[base + j * 256 + t] : 0.f;
+  for (int j = 0; j < AL; j++) col[j] = j < L ? qkv[(n0 + j) * 768 + 256 + t] : 0.f;
 #pragma unroll
   for (int i = 0; i < AL; i++)
     if (i < L) {
       float acc = 0.f;
 #pragma unroll
       for (int j = 0; j < AL; j++) if (j < L) acc += dsh[i * L + j] * col[j];
-      dq[base + i * 256 + t] = acc;
+      dqkv[(n0 + i) * 768 + t] = acc * scale;
     }
-  // dk[j] = sum_i ds[i][j] q[i]
+  // dk[j] = sum_i ds[i][j] (scale q[i])
 #pragma unroll
-  for (int i = 0; i < AL; i++) col[i] = i < L ? q[base + i * 256 + t] : 0.f;
+  for (int i = 0; i < AL; i++) col[i] = i < L ? qkv[(n0 + i) * 768 + t] * scale : 0.f;
 #pragma unroll
   for (int j = 0; j < AL; j++)
     if (j < L) {
       float acc = 0.f;
 #pragma unroll
       for (int i = 0; i < AL; i++) if (i < L) acc += dsh[i * L + j] * col[i];
-      dk[base + j * 256 + t] = acc;
+      dqkv[(n0 + j) * 768 + 256 + t] = acc;
     }
   // dv[j] = sum_i w[i][j] do[i];  dvg[j][s] = sum_i w[i][j] dog[i][s]
 #pragma unroll
-  for (int i = 0; i < AL; i++) col[i] = i < L ? dout[base + i * 256 + t] : 0.f;
+  for (int i = 0; i < AL; i++) col[i] = i < L ? dout[(n0 + i) * 256 + t] : 0.f;
 #pragma unroll
   for (int j = 0; j < AL; j++)
     if (j < L) {
       float acc = 0.f;
 #pragma unroll
       for (int i = 0; i < AL; i++) if (i < L) acc += wh[i * L + j] * col[i];
-      dv[base + j * 256 + t] = acc;
+      dqkv[(n0 + j) * 768 + 512 + t] = acc;
     }
   for (int sx = 0; sx < 3; sx++) {
 #pragma unroll
-    for (int i = 0; i < AL; i++) col[i] = i < L ? dog[(base + i * 256) * 3 + sx * 256 + t] : 0.f;
+    for (int i = 0; i < AL; i++) col[i] = i < L ? dog[((n0 + i) * 3 + sx) * 256 + t] : 0.f;
 #pragma unroll
     for (int j = 0; j < AL; j++)
       if (j < L) {
         float acc = 0.f;
 #pragma unroll
         for (int i = 0; i < AL; i++) if (i < L) acc += wh[i * L + j] * col[i];
-        dvg[(base + j * 256) * 3 + sx * 256 + t] = acc;
+        if (d < 126) dvgp[((n0 + j) * 3 + sx) * 252 + h * 126 + d] = acc;
+        else dgdh[(((n0 + j) * 3 + sx) * 2 + h) * 2 + (d - 126)] = acc;
       }
   }
 }
@@ -641,20 +648,19 @@ int sgrl_gram_backward(const float* z, const float* dgram, const float* dfn, con
   return SGRL_OK;
 }
 
-int sgrl_attention_forward(const float* q, const float* k, const float* v, const float* vg, const float* bias, float* w,
+int sgrl_attention_forward(const float* qkv, const float* vgp, const float* gdir, const float* bias, float scale, float* w,
                            float* o, float* og, int B, int L, void* stream) {
-  if (!q || !k || !v || !vg || !w || !o || !og || B <= 0 || L < 1 || L > AL) return tfail(SGRL_ERR_ARG, "sgrl_attention_forward: bad argument");
-  hipLaunchKernelGGL(k_attn_fwd, dim3(B), dim3(256), 0, (hipStream_t)stream, q, k, v, vg, bias, w, o, og, L);
+  if (!qkv || !vgp || !gdir || !w || !o || !og || B <= 0 || L < 1 || L > AL) return tfail(SGRL_ERR_ARG, "sgrl_attention_forward: bad argument");
+  hipLaunchKernelGGL(k_attn_fwd, dim3(B), dim3(256), 0, (hipStream_t)stream, qkv, vgp, gdir, bias, scale, w, o, og, L);
   if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_attn_fwd launch failed");
   return SGRL_OK;
 }
 
-int sgrl_attention_backward(const float* q, const float* k, const float* v, const float* vg, const float* w, const float* d_o,
-                            const float* d_og, float* dq, float* dk, float* dv, float* dvg, float* ds, int B, int L,
-                            void* stream) {
-  if (!q || !k || !v || !vg || !w || !d_o || !d_og || !dq || !dk || !dv || !dvg || !ds || B <= 0 || L < 1 || L > AL)
+int sgrl_attention_backward(const float* qkv, const float* vgp, const float* gdir, float scale, const float* w, const float* d_o,
+                            const float* d_og, float* dqkv, float* dvgp, float* dgdh, float* ds, int B, int L, void* stream) {
+  if (!qkv || !vgp || !gdir || !w || !d_o || !d_og || !dqkv || !dvgp || !dgdh || !ds || B <= 0 || L < 1 || L > AL)
     return tfail(SGRL_ERR_ARG, "sgrl_attention_backward: bad argument");
-  hipLaunchKernelGGL(k_attn_bwd, dim3(B), dim3(256), 0, (hipStream_t)stream, q, k, v, vg, w, d_o, d_og, dq, dk, dv, dvg, ds, L);
+  hipLaunchKernelGGL(k_attn_bwd, dim3(B), dim3(256), 0, (hipStream_t)stream, qkv, vgp, gdir, scale, w, d_o, d_og, dqkv, dvgp, dgdh, ds, L);
   if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_attn_bwd launch failed");
   return SGRL_OK;
 }

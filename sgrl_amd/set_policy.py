@@ -87,11 +87,9 @@ class SubequivariantAttention(nn.Module):
         # q, k, v share their input and their row divisor: ONE product over the stacked weights
         qkv = train_ops.linear(c, torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], dim=0),
                                torch.cat([self.q_proj.bias, self.k_proj.bias, self.v_proj.bias], dim=0), rowdiv=fn)
-        e2 = 2 * self.embed_dim
-        q, k, v = qkv[..., :e2] * float(hd2) ** -0.5, qkv[..., e2:2 * e2], qkv[..., 2 * e2:]
-        vg = self.vg_proj(g).view(B, L, 3, H, hd2 - 2)
-        vg = torch.cat([vg, gdir.unsqueeze(3).expand(B, L, 3, H, 2)], dim=-1).reshape(B, L, 3, H * hd2)
-        o, og = train_ops.set_attention(q, k, v, vg, bias)       # H = 2 heads of hd2 = 128 channels: the SET configuration
+        # H = 2 heads of hd2 = 128 channels (the SET configuration): scores, softmax and both weighted sums in one operation on the
+        # stacked qkv and on the vector values in parts (projected channels | the node's gravity / direction pair)
+        o, og = train_ops.set_attention(qkv, self.vg_proj(g), gdir, bias, float(hd2) ** -0.5)
         return self.g_out(og), self.ng_out(o)
 
 

@@ -35,8 +35,8 @@ def _L():
         L.sgrl_linear_wgrad_group.argtypes = [ci, vp, vp, vp]
         L.sgrl_zmat_forward.argtypes = [vp, vp, vp, ci, vp]
         L.sgrl_zmat_backward.argtypes = [vp, vp, vp, vp, vp, ci, vp]
-        L.sgrl_attention_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]
-        L.sgrl_attention_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]
+        L.sgrl_attention_forward.argtypes = [vp, vp, vp, vp, ctypes.c_float, vp, vp, vp, ci, ci, vp]
+        L.sgrl_attention_backward.argtypes = [vp, vp, vp, ctypes.c_float, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]
         L.sgrl_train_ws_floats.restype = ctypes.c_int64
         L.sgrl_train_last_error.restype = ctypes.c_char_p
         _bound = True
@@ -243,37 +243,39 @@ class _ZmatFn(torch.autograd.Function):
 
 
 class _AttnFn(torch.autograd.Function):
-    """q, k, v [B, L, 256], vg [B, L, 3, 256], bias [2, L, L] or None -> (o [B, L, 256], og [B, L, 3, 256])."""
+    """qkv [B, L, 768], vgp [B, L, 3, 252], gdir [B, L, 3, 2], bias [2, L, L] or None -> (o [B, L, 256], og [B, L, 3, 256])."""
 
     @staticmethod
-    def forward(ctx, q, k, v, vg, bias):
+    def forward(ctx, qkv, vgp, gdir, bias, scale):
         L = _L()
-        B, Ln = q.shape[0], q.shape[1]
-        q, k, v, vg = (t if t.is_contiguous() else t.contiguous() for t in (q, k, v, vg))
+        B, Ln = qkv.shape[0], qkv.shape[1]
+        qkv, vgp, gdir = (t if t.is_contiguous() else t.contiguous() for t in (qkv, vgp, gdir))
         bz = None if bias is None else (bias if bias.is_contiguous() else bias.contiguous())
-        w = torch.empty((B, 2, Ln, Ln), dtype=torch.float32, device=q.device)
-        o = torch.empty((B, Ln, 256), dtype=torch.float32, device=q.device)
-        og = torch.empty((B, Ln, 3, 256), dtype=torch.float32, device=q.device)
-        st = ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream)
-        _check(L, L.sgrl_attention_forward(_p(q), _p(k), _p(v), _p(vg), _p(bz), _p(w), _p(o), _p(og), B, Ln, st),
+        w = torch.empty((B, 2, Ln, Ln), dtype=torch.float32, device=qkv.device)
+        o = torch.empty((B, Ln, 256), dtype=torch.float32, device=qkv.device)
+        og = torch.empty((B, Ln, 3, 256), dtype=torch.float32, device=qkv.device)
+        st = ctypes.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)
+        _check(L, L.sgrl_attention_forward(_p(qkv), _p(vgp), _p(gdir), _p(bz), ctypes.c_float(scale), _p(w), _p(o), _p(og), B, Ln, st),
                "sgrl_attention_forward")
-        ctx.save_for_backward(q, k, v, vg, w)
-        ctx.has_bias = bias is not None
+        ctx.save_for_backward(qkv, vgp, gdir, w)
+        ctx.has_bias, ctx.scale = bias is not None, float(scale)
         return o, og
 
     @staticmethod
     def backward(ctx, d_o, d_og):
         L = _L()
-        q, k, v, vg, w = ctx.saved_tensors
-        B, Ln = q.shape[0], q.shape[1]
-        d_o = torch.zeros_like(q) if d_o is None else (d_o if d_o.is_contiguous() else d_o.contiguous())
-        d_og = torch.zeros_like(vg) if d_og is None else (d_og if d_og.is_contiguous() else d_og.contiguous())
-        dq, dk, dv, dvg, ds = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), torch.empty_like(vg), torch.empty_like(w)
-        st = ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream)
-        _check(L, L.sgrl_attention_backward(_p(q), _p(k), _p(v), _p(vg), _p(w), _p(d_o), _p(d_og), _p(dq), _p(dk), _p(dv), _p(dvg),
-                                            _p(ds), B, Ln, st), "sgrl_attention_backward")
-        dbias = ds.sum(0) if (ctx.has_bias and ctx.needs_input_grad[4]) else None
-        return dq, dk, dv, dvg, dbias
+        qkv, vgp, gdir, w = ctx.saved_tensors
+        B, Ln = qkv.shape[0], qkv.shape[1]
+        d_o = torch.zeros((B, Ln, 256), dtype=torch.float32, device=qkv.device) if d_o is None else (d_o if d_o.is_contiguous() else d_o.contiguous())
+        d_og = torch.zeros((B, Ln, 3, 256), dtype=torch.float32, device=qkv.device) if d_og is None else (d_og if d_og.is_contiguous() else d_og.contiguous())
+        dqkv, dvgp, ds = torch.empty_like(qkv), torch.empty_like(vgp), torch.empty_like(w)
+        dgdh = torch.empty((B, Ln, 3, 2, 2), dtype=torch.float32, device=qkv.device)
+        st = ctypes.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)
+        _check(L, L.sgrl_attention_backward(_p(qkv), _p(vgp), _p(gdir), ctypes.c_float(ctx.scale), _p(w), _p(d_o), _p(d_og), _p(dqkv),
+                                            _p(dvgp), _p(dgdh), _p(ds), B, Ln, st), "sgrl_attention_backward")
+        dgdir = dgdh.sum(3) if ctx.needs_input_grad[2] else None
+        dbias = ds.sum(0) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
+        return dqkv, dvgp, dgdir, dbias, None
 
 
 def _on_device_with_grad(*ts):
@@ -299,20 +301,23 @@ def gram_fn(z):
     return gram, gram.norm(dim=-1, keepdim=True) + 1.0
 
 
-def set_attention(q, k, v, vg, bias=None):
-    """Limb attention of the SET layers (reference subequivariant_attentions.py:90-151 between the projections): q (already
-    scaled), k, v [B, L, 256] = 2 heads x 128 channels, vg [B, L, 3, 256], bias [2, L, L] or None ->
-    (o [B, L, 256], og [B, L, 3, 256]) with w = softmax_j(q_i . k_j + bias) per head."""
-    if _on_device_with_grad(q, k, v, vg, bias) and q.shape[-1] == 256 and q.shape[1] <= 14:
-        return _AttnFn.apply(q, k, v, vg, bias)
-    B, Ln = q.shape[:2]
-    qh, kh, vh = q.view(B, Ln, 2, 128), k.view(B, Ln, 2, 128), v.view(B, Ln, 2, 128)
+def set_attention(qkv, vgp, gdir, bias, scale):
+    """Limb attention of the SET layers (reference subequivariant_attentions.py:90-151 between the projections), 2 heads x 128
+    channels: qkv [B, L, 768] = q | k | v (q is multiplied by `scale` here), vector values given in parts -- vgp [B, L, 3, 252]
+    (126 projected channels per head) and gdir [B, L, 3, 2] (channels 126, 127 of BOTH heads) --, bias [2, L, L] or None ->
+    (o [B, L, 256], og [B, L, 3, 256]) with w = softmax_j(scale q_i . k_j + bias) per head."""
+    B, Ln = qkv.shape[:2]
+    if _on_device_with_grad(qkv, vgp, gdir, bias) and qkv.shape[-1] == 768 and vgp.shape[-1] == 252 and Ln <= 14:
+        return _AttnFn.apply(qkv, vgp, gdir, bias, float(scale))
+    qh = (qkv[..., :256] * scale).view(B, Ln, 2, 128)
+    kh, vh = qkv[..., 256:512].view(B, Ln, 2, 128), qkv[..., 512:].view(B, Ln, 2, 128)
+    vg = torch.cat([vgp.view(B, Ln, 3, 2, 126), gdir.unsqueeze(3).expand(B, Ln, 3, 2, 2)], dim=-1)
     s = torch.einsum("bihd,bjhd->bhij", qh, kh)
     if bias is not None:
         s = s + bias.unsqueeze(0)
     w = F.softmax(s, dim=-1)
     o = torch.einsum("bhij,bjhd->bihd", w, vh).reshape(B, Ln, 256)
-    og = torch.einsum("bhij,bjshd->bishd", w, vg.view(B, Ln, 3, 2, 128)).reshape(B, Ln, 3, 256)
+    og = torch.einsum("bhij,bjshd->bishd", w, vg).reshape(B, Ln, 3, 256)
     return o, og
 
 

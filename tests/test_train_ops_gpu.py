@@ -143,27 +143,28 @@ def test_gram_fn_matches_float64():
 def test_set_attention_matches_float64(L, with_bias):
     from sgrl_amd import train_ops
     torch.manual_seed(L)
-    B = 23
-    q, k, v = (torch.randn(B, L, 256) * 0.3 for _ in range(3))
-    vg, bias = torch.randn(B, L, 3, 256), (torch.randn(2, L, L) if with_bias else None)
+    B, scale = 23, 128 ** -0.5
+    qkv, vgp, gdir = torch.randn(B, L, 768) * 0.6, torch.randn(B, L, 3, 252), torch.randn(B, L, 3, 2)
+    bias = torch.randn(2, L, L) if with_bias else None
     d_o, d_og = torch.randn(B, L, 256), torch.randn(B, L, 3, 256)
-    ref = [t.double().requires_grad_() for t in (q, k, v, vg)] + ([bias.double().requires_grad_()] if with_bias else [None])
+    ref = [t.double().requires_grad_() for t in (qkv, vgp, gdir)] + ([bias.double().requires_grad_()] if with_bias else [None])
     enabled = train_ops.ENABLED
     train_ops.ENABLED = False                                    # the einsum formulation, in float64 on the CPU
     try:
-        o_r, og_r = train_ops.set_attention(*ref)
+        o_r, og_r = train_ops.set_attention(*ref, scale)
     finally:
         train_ops.ENABLED = enabled
     ((o_r * d_o.double()).sum() + (og_r * d_og.double()).sum()).backward()
-    dev = [t.cuda().requires_grad_() for t in (q, k, v, vg)] + ([bias.cuda().requires_grad_()] if with_bias else [None])
-    o, og = train_ops.set_attention(*dev)
+    dev = [t.cuda().requires_grad_() for t in (qkv, vgp, gdir)] + ([bias.cuda().requires_grad_()] if with_bias else [None])
+    o, og = train_ops.set_attention(*dev, scale)
     assert type(o.grad_fn).__name__.startswith("_AttnFn")
     ((o * d_o.cuda()).sum() + (og * d_og.cuda()).sum()).backward()
     assert float((o.detach().cpu().double() - o_r.detach()).abs().max()) < 1e-5
     assert float((og.detach().cpu().double() - og_r.detach()).abs().max()) < 1e-5
-    for d, r, name in zip(dev, ref, "q k v vg bias".split()):
+    for d, r, name in zip(dev, ref, "qkv vgp gdir bias".split()):
         if r is None:
             continue
+        assert d.grad.shape == r.grad.shape
         assert float((d.grad.cpu().double() - r.grad).abs().max()) < 2e-5 * (float(r.grad.abs().max()) + 1), name
 
 
