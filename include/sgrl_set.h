@@ -143,6 +143,11 @@ int sgrl_set_peek(sgrl_set* s, int which, float* host, int64_t n_floats);
  * MyTransformerEncoderLayer's outputs, SEActor.py:82-125); the action / Q output of such a forward is not written.
  * stage = -1 restores the full forward. */
 int sgrl_set_debug_stop_after(sgrl_set* s, int stage);
+/* Batches of at most `nodes` nodes run their dense products through the 32 x 32 tile kernels of sgrl_train.h (latency-bound
+ * sizes: the TD3 update's target networks, single-environment action selection) instead of the 128 x 128 tile kernels; same
+ * results to float32 rounding.  Default 2048 (SGRL_SET_SMALL_NODES in the environment); 0 = never; -1 restores the default.
+ * Tests use it to run one input through both paths. */
+int sgrl_set_debug_small_nodes(sgrl_set* s, int nodes);
 const char* sgrl_set_last_error(void);
 
 #ifdef __cplusplus

@@ -20,6 +20,7 @@
 
 #include "../../include/sgrl.h"
 #include "../../include/sgrl_set.h"
+#include "../../include/sgrl_train.h"
 #include "gemm_f32.h"
 
 namespace {
@@ -448,6 +449,7 @@ struct sgrl_set {
   bool stack_dirty = true;
   bool stack_critic = false;   // mode the stacked operands were built for
   int stop_after = -1;         // parity probes: leave run_forward after this stage (sgrl_set_debug_stop_after)
+  int small_nodes = -1;        // batches of at most this many nodes take the small-batch products; -1: SGRL_SET_SMALL_NODES / default
   // live weights (sgrl_set_bind_params)
   bool live = false;
   float* wflat = nullptr;
@@ -605,6 +607,73 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw
   return SGRL_OK;
 }
 
+// ---- small batches ------------------------------------------------------------------------------------------------------
+// Below kSmallNodes nodes (the TD3 update's no-grad target networks: 100 transitions of one morphology = 700..1400 nodes;
+// single-environment action selection) a 128 x 128 tile kernel has a handful of workgroups that each walk the whole
+// contraction: the forward is a chain of ~50 latency-bound launches.  Those batches take the products through the 32 x 32 tile
+// kernels of the training path instead (train_gemm.hip, include/sgrl_train.h: exact-float32 matrix instruction, four waves
+// splitting every k-tile); the epilogue fusions of the big path become the small kernels below.  Scratch: the attention's
+// qkv | vg block (contiguous, 1536 floats per node), idle whenever these run.
+constexpr int kSmallNodesDefault = 2048;
+int small_nodes() {
+  static const int v = [] { const char* e = getenv("SGRL_SET_SMALL_NODES"); return e ? atoi(e) : kSmallNodesDefault; }();
+  return v;
+}
+
+// A[n][0:576] = blocked lower triangle of Z'Z (order of the folded weights), fn[n] = ||Z'Z||_F + 1; one wave per node
+__global__ __launch_bounds__(256) void k_gram576(const float* __restrict__ zc, const unsigned short* __restrict__ tri,
+                                                 float* __restrict__ A, float* __restrict__ fn, int N) {
+  __shared__ float zs[4][96];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, node = blockIdx.x * 4 + w;
+  const bool live = node < N;
+  if (live) {
+    zs[w][lane] = zc[(size_t)node * 96 + lane];
+    if (lane < 32) zs[w][64 + lane] = zc[(size_t)node * 96 + 64 + lane];
+  }
+  __syncthreads();
+  if (!live) return;
+  float ss = 0.f;
+  for (int k = lane; k < GK; k += 64) {
+    const unsigned t = tri[k];
+    float v = 0.f;
+    if (t != 0xFFFFu) {
+      const int a = t >> 8, b = t & 255;
+      v = zs[w][a] * zs[w][b] + zs[w][32 + a] * zs[w][32 + b] + zs[w][64 + a] * zs[w][64 + b];
+      ss += (a == b ? 1.f : 2.f) * v * v;
+    }
+    A[(size_t)node * GK + k] = v;
+  }
+  ss = wave_sum_f32(ss);
+  if (lane == 0) fn[node] = sqrtf(ss) + 1.f;
+}
+
+// tout[n][s][c] = sum_a zq[n][s][a] * matp[n][c * 32 + a]   (the 32 x 32 matrix in the packed c-major order); block = node
+__global__ __launch_bounds__(128) void k_zmat_perm(const float* __restrict__ zq, const float* __restrict__ matp,
+                                                   float* __restrict__ tout) {
+  __shared__ float ms[32 * 33], zs[96];
+  const int t = threadIdx.x;
+  const size_t n = blockIdx.x;
+  for (int o = t; o < 1024; o += 128) ms[(o >> 5) * 33 + (o & 31)] = matp[n * 1024 + o];
+  if (t < 96) zs[t] = zq[n * 96 + t];
+  __syncthreads();
+  if (t >= 96) return;
+  const int sI = t >> 5, c = t & 31;
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 32; a++) acc += zs[sI * 32 + a] * ms[c * 33 + a];
+  tout[n * 96 + t] = acc;
+}
+
+int small_fail() { return sfail(SGRL_ERR_HIP, std::string("small-batch product: ") + sgrl_train_last_error()); }
+
+int small_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M,
+               int N, int K, int flags = 0, const float* rowdiv = nullptr) {
+  if (flags & ~(EPI_RELU | EPI_ROWDIV)) return sfail(SGRL_ERR_ARG, "small gemm: unsupported epilogue");
+  const int rc = sgrl_linear_forward(A, lda, W, ldw, bias, (flags & EPI_ROWDIV) ? rowdiv : nullptr, C, ldc, M, N, K,
+                                     (flags & EPI_RELU) ? 1 : 0, st);
+  return rc == SGRL_OK ? rc : small_fail();
+}
+
 // critic = false: actions[e, 0:3L] = max_action * tanh(actor(obs)).  critic = true: `action` holds the per-limb action
 // slots that complete the critic's input rows and `act` receives the per-limb Q values (row stride act_ld).
 int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_ld, float max_action, hipStream_t st,
@@ -623,8 +692,23 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
                      s->outg, s->outng, s->gdir, s->zc, s->z2);
   float* ng = s->cat + 128;
   int rc = SGRL_OK;
-#define G(...) do { rc = launch_gemm(st, __VA_ARGS__); if (rc != SGRL_OK) return rc; } while (0)
-#define GG(W_, b_, C_, ldc_, N_) do { rc = launch_gemm_gram(st, s->zc, W_, b_, C_, ldc_, N, N_, s->fn); if (rc != SGRL_OK) return rc; } while (0)
+  const bool small = N <= (s->small_nodes >= 0 ? s->small_nodes : small_nodes());
+  float* const scratch = s->qkv;      // small path: [N, 576] Gram triangle / [N, 1024] per-node matrices (spans qkv | vg)
+#define G(...) do { rc = small ? small_gemm(st, __VA_ARGS__) : launch_gemm(st, __VA_ARGS__); if (rc != SGRL_OK) return rc; } while (0)
+  auto gram_gemm = [&](const float* W_, const float* b_, float* C_, int ldc_, int N_) -> int {
+    if (!small) return launch_gemm_gram(st, s->zc, W_, b_, C_, ldc_, N, N_, s->fn);
+    hipLaunchKernelGGL(k_gram576, dim3((N + 3) / 4), dim3(256), 0, st, s->zc, s->d_tri, scratch, s->fn, N);
+    return small_gemm(st, scratch, GK, W_, GK, b_, C_, ldc_, N, N_, GK, EPI_RELU);
+  };
+  // linear4 / linear2_m + equivariant contraction; linear2 + residual + LayerNorm
+  auto equiv_gemm = [&](const float* A_, const float* W_, const float* b_) -> int {
+    if (!small) return launch_gemm_equiv(st, A_, 256, W_, 256, b_, N, 256, s->fn, s->z2, s->mat);
+    const int r = small_gemm(st, A_, 256, W_, 256, b_, scratch, 1024, N, 1024, 256, EPI_ROWDIV, s->fn);
+    if (r != SGRL_OK) return r;
+    hipLaunchKernelGGL(k_zmat_perm, dim3(N), dim3(128), 0, st, s->z2, scratch, s->mat);
+    return SGRL_OK;
+  };
+#define GG(W_, b_, C_, ldc_, N_) do { rc = gram_gemm(W_, b_, C_, ldc_, N_); if (rc != SGRL_OK) return rc; } while (0)
   // proj + gram site: Z (and Z2) = X . [Wp; Wq]^T on the matrix cores (stacked, zero-padded weights), then the packed
   // Gram triangle per node
   auto site_w = [&](int site) -> const float* {   // site 6 (the head, Cpad 144) is last
@@ -644,6 +728,11 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   // the compact rows zc / z2 the Gram GEMM and the equivariant epilogues read
   auto pg = [&](const float* X, int ldx, int K, int site, float* z2) -> int {
     if (K % 16 != 0 || (ldx & 3)) return sfail(SGRL_ERR_ARG, "projection: K must be a multiple of 16 and rows 16-byte aligned");
+    if (small) {          // rows 0..29 / 32..61 of the stacked operand: two narrow products (columns 30, 31 hold gdir)
+      int r = small_gemm(st, X, ldx, site_w(site), K, nullptr, s->zc, ZD, N3, 30, K);
+      if (r == SGRL_OK && z2) r = small_gemm(st, X, ldx, site_w(site) + (size_t)32 * K, K, nullptr, z2, ZD, N3, 30, K);
+      return r;
+    }
     GemmArgs a{X, ldx, site_w(site), K, nullptr, s->zc, ZD, N3, z2 ? 64 : 32, K, EPI_ZSPLIT, nullptr, z2, ZD};
     GemmKernels<EPI_ZSPLIT>::launch(st, a);
     return SGRL_OK;
@@ -657,11 +746,11 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   // forks costs ~7 us of hipGraphLaunch CPU time per node on this ROCm, a single-stream graph ~0.4 us.
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(st, &cap);
-  const bool one_stream = cap != hipStreamCaptureStatusNone;
+  const bool one_stream = small || cap != hipStreamCaptureStatusNone;
   hipStream_t sd = one_stream ? st : s->side;
   auto fork = [&]() { if (!one_stream) { (void)hipEventRecord(s->ev_fork, st); (void)hipStreamWaitEvent(sd, s->ev_fork, 0); } };
   auto join = [&]() { if (!one_stream) { (void)hipEventRecord(s->ev_join, sd); (void)hipStreamWaitEvent(st, s->ev_join, 0); } };
-#define GS(...) do { rc = launch_gemm(sd, __VA_ARGS__); if (rc != SGRL_OK) return rc; } while (0)
+#define GS(...) do { rc = small ? small_gemm(sd, __VA_ARGS__) : launch_gemm(sd, __VA_ARGS__); if (rc != SGRL_OK) return rc; } while (0)
   for (int l = 0; l < SGRL_SET_LAYERS; l++) {
     // --- attention ---
     fork();
@@ -688,10 +777,17 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
       (void)hipEventRecord(s->ev_l3, st);
       (void)hipStreamWaitEvent(sd, s->ev_l3, 0);
     }
-    rc = launch_gemm_ln(sd, s->t256b, 256, s->WL(l, SGRL_SET_L2_W), 256, s->WL(l, SGRL_SET_L2_B), N, 256, s->fn, ng, 256,
-                        s->WL(l, SGRL_SET_N2_W), s->WL(l, SGRL_SET_N2_B));
-    if (rc != SGRL_OK) return rc;
-    rc = launch_gemm_equiv(st, s->t256, 256, s->WL(l, SGRL_SET_L4_W), 256, s->WL(l, SGRL_SET_L4_B), N, 256, s->fn, s->z2, s->mat);
+    if (small) {
+      rc = small_gemm(st, s->t256b, 256, s->WL(l, SGRL_SET_L2_W), 256, s->WL(l, SGRL_SET_L2_B), s->delta, 128, N, 128, 256, EPI_ROWDIV, s->fn);
+      if (rc != SGRL_OK) return rc;
+      hipLaunchKernelGGL(k_add_ln, dim3(lnb), dim3(256), 0, st, ng, 256, s->delta, 128, s->WL(l, SGRL_SET_N2_W),
+                         s->WL(l, SGRL_SET_N2_B), (float*)nullptr, 0, ng, 256, N);
+    } else {
+      rc = launch_gemm_ln(sd, s->t256b, 256, s->WL(l, SGRL_SET_L2_W), 256, s->WL(l, SGRL_SET_L2_B), N, 256, s->fn, ng, 256,
+                          s->WL(l, SGRL_SET_N2_W), s->WL(l, SGRL_SET_N2_B));
+      if (rc != SGRL_OK) return rc;
+    }
+    rc = equiv_gemm(s->t256, s->WL(l, SGRL_SET_L4_W), s->WL(l, SGRL_SET_L4_B));
     if (rc != SGRL_OK) return rc;
     hipLaunchKernelGGL(k_equiv, dim3((N + 7) / 8), dim3(128), 0, st, s->mat, s->WL(l, SGRL_SET_L5_W), s->g1, s->g,
                        l == SGRL_SET_LAYERS - 1 ? s->outg : (float*)nullptr, N);
@@ -714,7 +810,7 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
                        nt, act, act_ld, N);
   } else {
     G(s->cat2, 256, s->W(SGRL_SET_L1M_W), 256, s->W(SGRL_SET_L1M_B), s->t256, 256, N, 256, 256, EPI_RELU);
-    rc = launch_gemm_equiv(st, s->t256, 256, s->W(SGRL_SET_L2M_W), 256, s->W(SGRL_SET_L2M_B), N, 256, s->fn, s->z2, s->mat);
+    rc = equiv_gemm(s->t256, s->W(SGRL_SET_L2M_W), s->W(SGRL_SET_L2M_B));
     if (rc != SGRL_OK) return rc;
     hipLaunchKernelGGL(k_head_out, dim3((N + 3) / 4), dim3(128), 0, st, s->mat, s->W(SGRL_SET_DECG), obs, obs_ld, nt,
                        act, act_ld, max_action, N);
@@ -993,6 +1089,12 @@ int sgrl_set_peek(sgrl_set* s, int which, float* host, int64_t n_floats) {
 int sgrl_set_debug_stop_after(sgrl_set* s, int stage) {
   if (!s || stage < -1 || stage >= 2 * SGRL_SET_LAYERS) return sfail(SGRL_ERR_ARG, "sgrl_set_debug_stop_after: bad argument");
   s->stop_after = stage;
+  return SGRL_OK;
+}
+
+int sgrl_set_debug_small_nodes(sgrl_set* s, int nodes) {
+  if (!s || nodes < -1) return sfail(SGRL_ERR_ARG, "sgrl_set_debug_small_nodes: bad argument");
+  s->small_nodes = nodes;
   return SGRL_OK;
 }
 

@@ -38,6 +38,7 @@ def _bind(L):
     L.sgrl_set_workspace_bytes.restype = ctypes.c_int64
     L.sgrl_set_peek.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int64]
     L.sgrl_set_debug_stop_after.argtypes = [vp, ctypes.c_int]
+    L.sgrl_set_debug_small_nodes.argtypes = [vp, ctypes.c_int]
     L.sgrl_set_last_error.restype = ctypes.c_char_p
     L._set_bound = True
 
@@ -415,6 +416,10 @@ class HipSetActor(object):
     def debug_stop_after(self, stage):
         """Parity probes: the following forwards return after stage 2l (attention of layer l) / 2l+1 (layer l); -1 = full."""
         _check(self.L, self.L.sgrl_set_debug_stop_after(self.h, int(stage)), "sgrl_set_debug_stop_after")
+
+    def debug_small_nodes(self, nodes):
+        """Batches of at most `nodes` nodes take the small-batch products (include/sgrl_set.h); 0 = never, -1 = default."""
+        _check(self.L, self.L.sgrl_set_debug_small_nodes(self.h, int(nodes)), "sgrl_set_debug_small_nodes")
 
     def peek(self, which, per_node):
         out = np.zeros((self.num_nodes, per_node), dtype=np.float32)

@@ -287,7 +287,8 @@ def test_too_narrow_rows_are_rejected(ctx):
     assert rc != 0 and b"Lmax" in act.L.sgrl_set_last_error()
 
 
-def test_layer_probes_on_the_gpu(ctx, golden_dir):
+@pytest.mark.parametrize("small_nodes", [-1, 0], ids=["small_batch_products", "tile128_products"])
+def test_layer_probes_on_the_gpu(ctx, golden_dir, small_nodes):
     """Walk the HIP forward stage by stage against the reference's own forward hooks on `layers.i.self_attn`, `layers.i`
     and `transformer_encoder` (tests/golden/set_probes_walker7.npz, captured by tools/capture_golden.py): a compensating
     error pair inside a layer cannot hide behind a correct final action."""
@@ -297,6 +298,7 @@ def test_layer_probes_on_the_gpu(ctx, golden_dir):
     g = graphs["3d_walker_7_full"]
     L, B = 7, 2
     act = HipSetActor(pol)
+    act.debug_small_nodes(small_nodes)      # 14 nodes: the small-batch products by default; 0 forces the 128 x 128 tile kernels
     act.configure([_gd(torch, g)], [B])
     obs = torch.from_numpy(p["obs"].astype(np.float32)).cuda()
 
@@ -324,3 +326,34 @@ def test_layer_probes_on_the_gpu(ctx, golden_dir):
     close(act.peek(0, 384), p["encoder/out0"], "encoder g")
     close(act.peek(10, 160)[:, 17:145], p["encoder/out1"], "encoder ng (final norm)")
     assert np.abs(out - p["act_f64"]).max() < TOL
+
+
+@pytest.mark.gpu
+def test_small_batch_products_match_the_tile_kernels(ctx):
+    """One input through both product paths of the forward (include/sgrl_set.h sgrl_set_debug_small_nodes): the 32 x 32 tile
+    kernels batches below 2048 nodes take, and the 128 x 128 tile kernels of the collection step -- actor and critic, a
+    mixed-morphology batch of 1 000 nodes."""
+    torch, pol, graphs, keys, z = ctx
+    from sgrl_amd.set_hip import HipSetActor
+    from oracle.formula import synth_obs
+    names = ["3d_walker_7_full", "3d_hopper_3_shin", "3d_cheetah_14_full"]
+    names = [n for n in names if n in graphs] or list(graphs)[:2]
+    counts = [40] * len(names)
+    gds = [_gd(torch, graphs[n]) for n in names]
+    act = HipSetActor(pol)
+    act.configure(gds, counts)
+    amax = 3 * max(len(graphs[n]["parents"]) for n in names)
+    omax = 41 * max(len(graphs[n]["parents"]) for n in names)
+    obs = torch.zeros((sum(counts), omax), device="cuda")
+    r = 0
+    for n, c in zip(names, counts):
+        L = len(graphs[n]["parents"])
+        obs[r:r + c, :41 * L] = torch.from_numpy(synth_obs(L, c, 3).astype(np.float32)).cuda()
+        r += c
+    outs = []
+    for sn in (100000, 0):
+        act.debug_small_nodes(sn)
+        outs.append(act.forward_batch(obs).cpu().numpy().copy())
+    act.debug_small_nodes(-1)
+    assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 1e-3
+    assert np.abs(outs[0] - outs[1]).max() < TOL
