@@ -188,7 +188,7 @@ def main():
     ro = Rollout(WALKERS, args.envs_per_morph, policy=policy, seed=args.seed, device=dev, rank=rank)
     env = ro.env
     n_local = env.num_envs
-    gather = ReplayGather(n_local, env.obs_max_len, env.action_max_len, dev) if world > 1 else None
+    gather = ReplayGather(n_local, env.obs_max_len, env.action_max_len, dev, depth=2) if world > 1 else None
     prev_obs = torch.zeros_like(env.obs)
 
     def one_step():
@@ -199,7 +199,7 @@ def main():
         ro.policy_forward(obs)
         if gather is not None:
             gather.pack(prev_obs, a, obs, rew, done)
-            gather.push()
+            gather.push(wait=False)        # in flight over xGMI while the next step runs; its block is reused two steps on
 
     ro.reset()
     for _ in range(args.preroll):          # synthetic-state preparation: reach the stationary episode mix
@@ -208,6 +208,8 @@ def main():
         one_step()
 
     def barrier():
+        if gather is not None:
+            gather.drain()                 # every replay block of the timed steps has arrived before the clock stops
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -289,7 +291,7 @@ def main():
             "config": {"workload": "3D_Walker++ 8 variants x %d envs per GPU (config 3), random U(-1,1) actions, "
                                    "auto-reset, SET actor forward on every step, random-init weights" % args.envs_per_morph,
                        "envs_per_gpu": n_local, "obs_max_len": env.obs_max_len, "action_max_len": env.action_max_len,
-                       "replay_gather": "torch.distributed.gather (RCCL) of %d B/rank/step" % gather.bytes_per_step()
+                       "replay_gather": "torch.distributed.gather (RCCL) of %d B/rank/step, in flight during the next step (2 blocks in turn)" % gather.bytes_per_step()
                        if gather is not None else "none (single rank)"},
         }
         out.update(extra)

@@ -73,7 +73,9 @@ class ReplayGather(object):
 
     EXTRA = 4     # reward, done, store, morph_id
 
-    def __init__(self, n_env_local, obs_max_len, action_max_len, device, dst=0):
+    def __init__(self, n_env_local, obs_max_len, action_max_len, device, dst=0, depth=1):
+        """depth > 1: that many send blocks (and receive lists on the learner) used in turn, so that `push(wait=False)` can
+        leave a gather in flight while the next steps run; a block is waited for only when its turn comes again."""
         import torch.distributed as dist
         self.dist = dist
         self.dst = dst
@@ -81,15 +83,35 @@ class ReplayGather(object):
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.row = 2 * obs_max_len + action_max_len + self.EXTRA
         self.o, self.a = obs_max_len, action_max_len
-        self.block = torch.zeros((n_env_local, self.row), dtype=torch.float32, device=device)
-        self.block[:, 2 * obs_max_len + action_max_len + 2] = 1.0      # store flag defaults to "keep"
-        self.recv = None
+        self.depth = int(depth)
+        assert self.depth >= 1
+        self.blocks = [torch.zeros((n_env_local, self.row), dtype=torch.float32, device=device) for _ in range(self.depth)]
+        for b in self.blocks:
+            b[:, 2 * obs_max_len + action_max_len + 2] = 1.0      # store flag defaults to "keep"
+        self.block = self.blocks[0]        # the block packed last
+        self.recvs = [None] * self.depth
         if self.rank == dst:
-            self.recv = [torch.zeros_like(self.block) for _ in range(self.world)]
+            self.recvs = [[torch.zeros_like(self.blocks[0]) for _ in range(self.world)] for _ in range(self.depth)]
+        self.recv = self.recvs[0]
+        self._works = [None] * self.depth
+        self._k = 0
+
+    def _wait(self, slot):
+        if self._works[slot] is not None:
+            self._works[slot].wait()       # nccl: the current stream waits for the collective; gloo: the host does
+            self._works[slot] = None
+
+    def drain(self):
+        """Wait for every gather still in flight (call before reading the received blocks / before a timing barrier)."""
+        for slot in range(self.depth):
+            self._wait(slot)
 
     def pack(self, obs, action, next_obs, reward, done, store=None, morph_id=None):
         o, a = self.o, self.a
-        b = self.block
+        slot = self._k % self.depth
+        self._wait(slot)                   # the gather that last used this block (depth pushes ago) must be done
+        b = self.block = self.blocks[slot]
+        self.recv = self.recvs[slot]
         b[:, :o] = obs
         b[:, o:o + a] = action
         b[:, o + a:2 * o + a] = next_obs
@@ -101,11 +123,19 @@ class ReplayGather(object):
             b[:, 2 * o + a + 3] = morph_id.to(torch.float32)     # small integers: exact in float32
         return b
 
-    def push(self):
-        """Returns the list of per-rank blocks on the learner rank, None elsewhere."""
+    def push(self, wait=True):
+        """Gather the block packed last.  Returns the list of per-rank blocks on the learner rank, None elsewhere.  wait=False
+        leaves the gather in flight (the returned blocks are complete after `drain()`, or once `depth` further pushes have been
+        packed): the next step's kernels overlap the transfer."""
+        slot = self._k % self.depth
+        self._k += 1
         if self.world == 1:
             return [self.block]
-        self.dist.gather(self.block, self.recv if self.rank == self.dst else None, dst=self.dst)
+        work = self.dist.gather(self.block, self.recv if self.rank == self.dst else None, dst=self.dst, async_op=True)
+        if wait:
+            work.wait()
+        else:
+            self._works[slot] = work
         return self.recv
 
     def unpack(self, block):

@@ -47,6 +47,51 @@ def _worker(rank, world, port, n_env, obs_len, act_len, out_dir):
         dist.destroy_process_group()
 
 
+def _worker_pipelined(rank, world, port, n_env, obs_len, act_len, out_dir):
+    """depth 2, push(wait=False): the gather of step t is in flight while step t + 1 is packed into the other block."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = ReplayGather(n_env, obs_len, act_len, "cpu", dst=0, depth=2)
+        rng = np.random.RandomState(200 + rank)
+        pending = []
+        for step in range(5):
+            obs = torch.from_numpy(rng.rand(n_env, obs_len).astype(np.float32))
+            act = torch.from_numpy(rng.rand(n_env, act_len).astype(np.float32))
+            nxt = torch.from_numpy(rng.rand(n_env, obs_len).astype(np.float32))
+            rew = torch.from_numpy(rng.rand(n_env).astype(np.float32))
+            done = torch.from_numpy((rng.rand(n_env) > 0.5).astype(np.uint8))
+            blk = g.pack(obs, act, nxt, rew, done)          # waits for the gather that used this block two pushes ago
+            assert blk is g.blocks[step % 2]
+            np.save(os.path.join(out_dir, "sent_%d_%d.npy" % (rank, step)), blk.numpy().copy())
+            recv = g.push(wait=False)
+            pending.append((step, recv))
+            if len(pending) == 2:                            # the older one is complete once its slot comes up again: drain to read it
+                g.drain()
+                for st, rv in pending:
+                    if rank == 0:
+                        np.save(os.path.join(out_dir, "recv_%d.npy" % st), torch.stack(rv).numpy())
+                    else:
+                        assert rv is None
+                pending = []
+        g.drain()
+        for st, rv in pending:
+            if rank == 0:
+                np.save(os.path.join(out_dir, "recv_%d.npy" % st), torch.stack(rv).numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_gather_world_size_2(tmp_path):
+    world, n_env, obs_len, act_len = 2, 6, 41 * 2, 6
+    mp.spawn(_worker_pipelined, args=(world, _free_port(), n_env, obs_len, act_len, str(tmp_path)), nprocs=world, join=True)
+    for step in range(5):
+        recv = np.load(tmp_path / ("recv_%d.npy" % step))
+        for r in range(world):
+            assert np.array_equal(recv[r], np.load(tmp_path / ("sent_%d_%d.npy" % (r, step))))
+
+
 def test_gather_world_size_2(tmp_path):
     world, n_env, obs_len, act_len = 2, 5, 41 * 3, 9
     mp.spawn(_worker, args=(world, _free_port(), n_env, obs_len, act_len, str(tmp_path)), nprocs=world, join=True)
