@@ -153,6 +153,9 @@ def main():
     ap.add_argument("--envs-per-morph", type=int, default=1024)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="diagnostic: run the N > 1 code path (process group, replay gather, barriers, max-over-ranks) with "
+                         "WORLD_SIZE=1 under torch.distributed.run -- what a 1-GPU box can exercise of it")
     ap.add_argument("--preroll", type=int, default=200,
                     help="untimed rollout steps run during set-up so that episodes are desynchronised and the timed "
                          "steps see the stationary mix of flight / stance / fallen states (not warm-up of the code)")
@@ -177,7 +180,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
-    if world > 1:
+    multi = world > 1 or args.force_collectives
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device(dev))
 
@@ -188,7 +192,7 @@ def main():
     ro = Rollout(WALKERS, args.envs_per_morph, policy=policy, seed=args.seed, device=dev, rank=rank)
     env = ro.env
     n_local = env.num_envs
-    gather = ReplayGather(n_local, env.obs_max_len, env.action_max_len, dev, depth=2) if world > 1 else None
+    gather = ReplayGather(n_local, env.obs_max_len, env.action_max_len, dev, depth=2) if multi else None
     prev_obs = torch.zeros_like(env.obs)
 
     def one_step():
@@ -210,7 +214,7 @@ def main():
     def barrier():
         if gather is not None:
             gather.drain()                 # every replay block of the timed steps has arrived before the clock stops
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -220,7 +224,7 @@ def main():
         one_step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -296,7 +300,7 @@ def main():
         }
         out.update(extra)
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.barrier()                     # rank 0's post-run kernel timings are done before any rank tears NCCL down
         dist.destroy_process_group()
 

@@ -129,8 +129,8 @@ class ReplayGather(object):
         packed): the next step's kernels overlap the transfer."""
         slot = self._k % self.depth
         self._k += 1
-        if self.world == 1:
-            return [self.block]
+        if self.world == 1 and not self.dist.is_initialized():
+            return [self.block]            # no process group: the learner's own block is the whole gather
         work = self.dist.gather(self.block, self.recv if self.rank == self.dst else None, dst=self.dst, async_op=True)
         if wait:
             work.wait()

@@ -123,3 +123,33 @@ def test_env_id_sharding_is_disjoint():
     a = physics_ref.lib().sgrl_oracle_rng_uniform01(7, 8191, 0, 0, 0)
     b = physics_ref.lib().sgrl_oracle_rng_uniform01(7, 8192, 0, 0, 0)
     assert a != b and 0 < a < 1 and 0 < b < 1
+
+
+@pytest.mark.gpu
+def test_rccl_gather_in_flight_single_rank():
+    """The pipelined push on the 'nccl' (= RCCL) backend with device tensors: a one-rank process group still runs the real
+    collective (asynchronous gather, stream-side wait), which is all a 1-GPU box can exercise of the N > 1 path."""
+    assert torch.cuda.is_available()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,
+                            device_id=torch.device("cuda:0"))
+    try:
+        g = ReplayGather(64, 287, 21, "cuda:0", dst=0, depth=2)
+        gen = torch.Generator(device="cuda:0").manual_seed(3)
+        sent, got = [], []
+        for step in range(5):
+            obs, nxt = torch.rand(64, 287, device="cuda:0", generator=gen), torch.rand(64, 287, device="cuda:0", generator=gen)
+            act, rew = torch.rand(64, 21, device="cuda:0", generator=gen), torch.rand(64, device="cuda:0", generator=gen)
+            done = torch.rand(64, device="cuda:0", generator=gen) > 0.5
+            sent.append(g.pack(obs, act, nxt, rew, done).clone())
+            recv = g.push(wait=False)
+            assert recv is g.recvs[step % 2]
+            if step % 2 == 1:
+                g.drain()
+                got += [g.recvs[0][0].clone(), g.recvs[1][0].clone()]
+        g.drain()
+        got.append(g.recvs[0][0].clone())
+        torch.cuda.synchronize()
+        for a, b in zip(sent, got):
+            assert torch.equal(a, b)
+    finally:
+        dist.destroy_process_group()
