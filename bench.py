@@ -193,16 +193,15 @@ def main():
     env = ro.env
     n_local = env.num_envs
     gather = ReplayGather(n_local, env.obs_max_len, env.action_max_len, dev, depth=2) if multi else None
-    prev_obs = torch.zeros_like(env.obs)
 
     def one_step():
         a = ro.random_actions()
         if gather is not None:
-            prev_obs.copy_(env.obs)
+            gather.stage_obs(env.obs)      # the row's observation half, before the step overwrites env.obs in place
         obs, rew, done, _ = ro.step(a)
         ro.policy_forward(obs)
         if gather is not None:
-            gather.pack(prev_obs, a, obs, rew, done)
+            gather.pack(None, a, obs, rew, done)
             gather.push(wait=False)        # in flight over xGMI while the next step runs; its block is reused two steps on
 
     ro.reset()

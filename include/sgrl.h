@@ -84,6 +84,16 @@ int sgrl_refresh(sgrl_engine* e, float* obs, double* obs64, void* stream);
 int sgrl_time_steps(sgrl_engine* e, const float* actions, float* obs, float* reward, uint8_t* done, int reps,
                     void* stream, float* ms_out);
 
+/* The replay push's row format (reference common/buffer.py:75-84 `add_transition` arguments + the bookkeeping of
+ * trainer.py:205-232), written for all environments in one launch:
+ *   block[n_env][2 * obs_len + act_len + 4] = obs | action | next_obs | reward | done | store | morph_id   (float32)
+ * Sources are device pointers with row strides ld_*; a NULL source leaves its columns untouched (the observation half can be
+ * written before the step overwrites the observation buffer, the rest after it).  `done` comes as float32 OR as bytes (non-zero =
+ * 1.0), not both; `store` as bytes; `morph_id` as int64 (small integers: exact in float32). */
+int sgrl_pack_transitions(const float* obs, int ld_obs, const float* action, int ld_act, const float* next_obs, int ld_next,
+                          const float* reward, const float* done_f32, const uint8_t* done_u8, const uint8_t* store,
+                          const int64_t* morph_id, float* block, int n_env, int obs_len, int act_len, void* stream);
+
 const char* sgrl_last_error(void);
 const char* sgrl_version(void);
 

@@ -29,6 +29,7 @@
 #endif
 #include "../../include/sgrl.h"
 #include "step_body.h"
+#include "stream_pick.h"
 #include "wave_hip.h"
 
 namespace {
@@ -209,6 +210,7 @@ struct sgrl_engine {
   // member.  Groups run concurrently on their own streams, forked from / joined to the caller's stream by events.
   struct Group { int first = 0, count = 0, lds = 0; bool light = false; hipStream_t stream = nullptr; hipEvent_t done = nullptr; };
   std::vector<Group> groups;
+  bool groups_checked = false;     // group streams measured to sit on distinct hardware queues (stream_pick.h)
   hipEvent_t fork = nullptr;
   std::vector<int> morph_lds;
 };
@@ -220,6 +222,20 @@ int launch_groups(sgrl_engine* e, K kernel_in, const StepOut& out, hipStream_t u
   if (e->groups.size() == 1) {
     hipLaunchKernelGGL(pick(e->groups[0]), dim3(e->n_env), dim3(64), e->groups[0].lds, user, e->args, out);
   } else {
+    if (!e->groups_checked && sgrl_streams::enabled()) {
+      // first multi-group launch: every group's stream on its own hardware queue, as far as the runtime has them
+      // (stream_pick.h; the caller's stream only waits meanwhile, so it may share a queue with a group)
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      (void)hipStreamIsCapturing(user, &cap);
+      if (cap == hipStreamCaptureStatusNone) {
+        std::vector<hipStream_t> taken;
+        for (auto& g : e->groups) {
+          if (!taken.empty()) g.stream = sgrl_streams::pick(taken, g.stream, 6);
+          taken.push_back(g.stream);
+        }
+        e->groups_checked = true;
+      }
+    }
     if (hipEventRecord(e->fork, user) != hipSuccess) return fail(SGRL_ERR_HIP, "hipEventRecord(fork) failed");
     for (auto& g : e->groups) {
       BatchArgs a = e->args;
@@ -234,6 +250,37 @@ int launch_groups(sgrl_engine* e, K kernel_in, const StepOut& out, hipStream_t u
   return SGRL_OK;
 }
 }  // namespace
+
+
+// ---- replay push: the rows of ReplayBuffer.add_transition, one launch -----------------------------------------------------
+// block[e] = obs[o] | action[a] | next_obs[o] | reward | done | store | morph_id (floats; sgrl.h sgrl_pack_transitions).  A null
+// source leaves its columns as they are (the observation half is written before the step overwrites the observation buffer, the
+// rest after it).  HBM-bound copy: one workgroup per environment, consecutive lanes on consecutive floats of the row.
+struct PackArgs {
+  const float* obs; const float* act; const float* nxt; const float* rew; const float* done_f; const uint8_t* done_u8;
+  const uint8_t* store; const int64_t* morph; float* block;
+  int ld_obs, ld_act, ld_nxt, o, a;
+};
+__global__ __launch_bounds__(256) void k_pack_transitions(PackArgs p) {
+  const size_t e = blockIdx.x;
+  const int row = 2 * p.o + p.a + 4;
+  float* b = p.block + e * row;
+  for (int c = threadIdx.x; c < row; c += 256) {
+    if (c < p.o) {
+      if (p.obs) b[c] = p.obs[e * p.ld_obs + c];
+    } else if (c < p.o + p.a) {
+      if (p.act) b[c] = p.act[e * p.ld_act + (c - p.o)];
+    } else if (c < 2 * p.o + p.a) {
+      if (p.nxt) b[c] = p.nxt[e * p.ld_nxt + (c - p.o - p.a)];
+    } else {
+      const int k = c - 2 * p.o - p.a;
+      if (k == 0) { if (p.rew) b[c] = p.rew[e]; }
+      else if (k == 1) { if (p.done_f) b[c] = p.done_f[e]; else if (p.done_u8) b[c] = p.done_u8[e] ? 1.f : 0.f; }
+      else if (k == 2) { if (p.store) b[c] = p.store[e] ? 1.f : 0.f; }
+      else if (p.morph) b[c] = (float)p.morph[e];
+    }
+  }
+}
 
 extern "C" {
 
@@ -489,6 +536,19 @@ int sgrl_time_steps(sgrl_engine* e, const float* actions, float* obs, float* rew
   (void)hipEventDestroy(t1);
   HIP_TRY(hipGetLastError());
   *ms_out = ms / reps;
+  return SGRL_OK;
+}
+
+int sgrl_pack_transitions(const float* obs, int ld_obs, const float* action, int ld_act, const float* next_obs, int ld_next,
+                          const float* reward, const float* done_f32, const uint8_t* done_u8, const uint8_t* store,
+                          const int64_t* morph_id, float* block, int n_env, int obs_len, int act_len, void* stream) {
+  if (!block || n_env < 0 || obs_len <= 0 || act_len <= 0 || (obs && ld_obs < obs_len) || (action && ld_act < act_len) ||
+      (next_obs && ld_next < obs_len) || (done_f32 && done_u8))
+    return fail(SGRL_ERR_ARG, "sgrl_pack_transitions: bad argument");
+  if (n_env == 0) return SGRL_OK;
+  PackArgs p{obs, action, next_obs, reward, done_f32, done_u8, store, morph_id, block, ld_obs, ld_act, ld_next, obs_len, act_len};
+  hipLaunchKernelGGL(k_pack_transitions, dim3(n_env), dim3(256), 0, (hipStream_t)stream, p);
+  HIP_TRY(hipGetLastError());
   return SGRL_OK;
 }
 

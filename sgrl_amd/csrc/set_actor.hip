@@ -22,6 +22,7 @@
 #include "../../include/sgrl_set.h"
 #include "../../include/sgrl_train.h"
 #include "gemm_f32.h"
+#include "stream_pick.h"
 
 namespace {
 
@@ -460,6 +461,8 @@ struct sgrl_set {
   // side stream for the GEMM chains that do not depend on each other (their epilogues / tile tails overlap)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_l3 = nullptr;
+  bool side_checked = false;          // `side` has been measured to overlap `side_checked_for` (stream_pick.h)
+  hipStream_t side_checked_for = nullptr;
   const float* W(int slot) const { return w + off[slot]; }
   const float* WL(int layer, int k) const { return w + off[SGRL_SET_NGLOBAL + layer * SGRL_SET_NLAYER + k]; }
 };
@@ -747,6 +750,12 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(st, &cap);
   const bool one_stream = small || cap != hipStreamCaptureStatusNone;
+  if (!one_stream && sgrl_streams::enabled() && !(s->side_checked && s->side_checked_for == st)) {
+    // first forward on this caller stream: make sure the side stream sits on another hardware queue (stream_pick.h)
+    s->side = sgrl_streams::pick({st}, s->side);
+    s->side_checked = true;
+    s->side_checked_for = st;
+  }
   hipStream_t sd = one_stream ? st : s->side;
   auto fork = [&]() { if (!one_stream) { (void)hipEventRecord(s->ev_fork, st); (void)hipStreamWaitEvent(sd, s->ev_fork, 0); } };
   auto join = [&]() { if (!one_stream) { (void)hipEventRecord(s->ev_join, sd); (void)hipStreamWaitEvent(st, s->ev_join, 0); } };

@@ -106,21 +106,84 @@ class ReplayGather(object):
         for slot in range(self.depth):
             self._wait(slot)
 
-    def pack(self, obs, action, next_obs, reward, done, store=None, morph_id=None):
-        o, a = self.o, self.a
+    def _take_slot(self):
         slot = self._k % self.depth
         self._wait(slot)                   # the gather that last used this block (depth pushes ago) must be done
-        b = self.block = self.blocks[slot]
+        self.block = self.blocks[slot]
         self.recv = self.recvs[slot]
-        b[:, :o] = obs
-        b[:, o:o + a] = action
-        b[:, o + a:2 * o + a] = next_obs
-        b[:, 2 * o + a] = reward
-        b[:, 2 * o + a + 1] = done.to(torch.float32)
+        return self.block
+
+    def _write(self, b, obs, action, next_obs, reward, done, store, morph_id):
+        """Columns of the block from their sources (None = leave as is).  Device blocks: ONE launch of the library's
+        k_pack_transitions (include/sgrl.h sgrl_pack_transitions); host blocks (gloo ranks in the CPU tests): slice copies."""
+        o, a = self.o, self.a
+        if b.is_cuda:
+            import ctypes
+            from . import _lib
+            L = _lib.lib()
+            keep = []
+
+            def rows(t, width):
+                if t is None:
+                    return None, 0
+                if t.dtype != torch.float32 or t.stride(-1) != 1:
+                    t = t.to(torch.float32).contiguous()
+                assert t.shape[0] == b.shape[0] and t.shape[1] >= width and t.device == b.device
+                keep.append(t)
+                return ctypes.c_void_p(t.data_ptr()), int(t.stride(0))
+
+            def col(t, dtype):
+                if t is None:
+                    return None
+                if t.dtype == torch.bool and dtype == torch.uint8:
+                    t = t.contiguous().view(torch.uint8)
+                elif t.dtype != dtype or not t.is_contiguous():
+                    t = t.to(dtype).contiguous()
+                assert t.numel() == b.shape[0] and t.device == b.device
+                keep.append(t)
+                return ctypes.c_void_p(t.data_ptr())
+            po, ldo = rows(obs, o)
+            pa, lda = rows(action, a)
+            pn, ldn = rows(next_obs, o)
+            done_u8 = done is not None and done.dtype in (torch.bool, torch.uint8)
+            _lib.check(L.sgrl_pack_transitions(po, ldo, pa, lda, pn, ldn, col(reward, torch.float32),
+                                               None if done_u8 else col(done, torch.float32),
+                                               col(done, torch.uint8) if done_u8 else None, col(store, torch.uint8),
+                                               col(morph_id, torch.int64), ctypes.c_void_p(b.data_ptr()), int(b.shape[0]), o, a,
+                                               ctypes.c_void_p(torch.cuda.current_stream(b.device).cuda_stream)),
+                       "sgrl_pack_transitions")
+            return
+        if obs is not None:
+            b[:, :o] = obs[:, :o]
+        if action is not None:
+            b[:, o:o + a] = action[:, :a]
+        if next_obs is not None:
+            b[:, o + a:2 * o + a] = next_obs[:, :o]
+        if reward is not None:
+            b[:, 2 * o + a] = reward
+        if done is not None:
+            b[:, 2 * o + a + 1] = done.to(torch.float32)
         if store is not None:
             b[:, 2 * o + a + 2] = store.to(torch.float32)
         if morph_id is not None:
             b[:, 2 * o + a + 3] = morph_id.to(torch.float32)     # small integers: exact in float32
+
+    def stage_obs(self, obs):
+        """First half of a row, written BEFORE the step overwrites the observation buffer in place (saves the copy of the
+        previous observations); the following `pack(None, ...)` completes the same block."""
+        b = self._take_slot()
+        self._write(b, obs, None, None, None, None, None, None)
+        self._staged = True
+        return b
+
+    def pack(self, obs, action, next_obs, reward, done, store=None, morph_id=None):
+        if getattr(self, "_staged", False):
+            assert obs is None, "stage_obs() already wrote this block's observation columns"
+            self._staged = False
+            b = self.block
+        else:
+            b = self._take_slot()
+        self._write(b, obs, action, next_obs, reward, done, store, morph_id)
         return b
 
     def push(self, wait=True):

@@ -153,3 +153,37 @@ def test_rccl_gather_in_flight_single_rank():
             assert torch.equal(a, b)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_device_pack_kernel_equals_the_slice_copies():
+    """sgrl_pack_transitions (one launch per block on the device) against the host form of the same `pack` on the same data:
+    byte-equal rows, for done flags given as bool / uint8 / float32, rows cut out of wider tensors (row stride > width), the
+    staged form (observation half first, the rest after the step), and columns left untouched by None sources."""
+    n, o, a = 37, 41 * 7, 21
+    gen = torch.Generator().manual_seed(11)
+    wide_obs = torch.rand(n, o + 13, generator=gen)
+    act, nxt, rew = torch.rand(n, a, generator=gen) * 2 - 1, torch.rand(n, o, generator=gen), torch.randn(n, generator=gen)
+    done_b = torch.rand(n, generator=gen) > 0.5
+    store = torch.rand(n, generator=gen) > 0.3
+    morph = torch.randint(0, 23, (n,), generator=gen)
+    host = ReplayGather(n, o, a, "cpu")
+    dev = ReplayGather(n, o, a, "cuda:0", depth=2)
+    c = lambda t: None if t is None else t.cuda()
+    for done in (done_b, done_b.to(torch.uint8), done_b.to(torch.float32)):
+        ref = host.pack(wide_obs[:, :o], act, nxt, rew, done, store, morph).clone()
+        got = dev.pack(c(wide_obs)[:, :o], c(act), c(nxt), c(rew), c(done), c(store), c(morph))
+        dev.push()
+        assert torch.equal(got.cpu(), ref)
+    # staged: observation half first; the rest later; store / morph_id left as the previous use of that block wrote them
+    blk = dev.stage_obs(c(nxt))
+    before = blk.clone()
+    assert torch.equal(before[:, :o].cpu(), nxt) and torch.equal(before[:, o:].cpu(), dev.blocks[dev._k % 2][:, o:].cpu())
+    got = dev.pack(None, c(act), c(wide_obs)[:, :o], c(rew), c(done_b))
+    assert got is blk
+    exp = before.cpu()
+    exp[:, o:o + a], exp[:, o + a:2 * o + a], exp[:, 2 * o + a], exp[:, 2 * o + a + 1] = act, wide_obs[:, :o], rew, done_b.float()
+    assert torch.equal(got.cpu(), exp)
+    with pytest.raises(AssertionError):
+        dev.stage_obs(c(nxt))
+        dev.pack(c(nxt), c(act), c(nxt), c(rew), c(done_b))
