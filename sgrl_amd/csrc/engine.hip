@@ -246,7 +246,10 @@ int launch_groups(sgrl_engine* e, K kernel_in, const StepOut& out, hipStream_t u
         return fail(SGRL_ERR_HIP, "cannot join a launch group back to the caller's stream");
     }
   }
-  if (hipGetLastError() != hipSuccess) return fail(SGRL_ERR_HIP, "kernel launch failed");
+  {
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail(SGRL_ERR_HIP, std::string("kernel launch failed (") + hipGetErrorName(le) + ": " + hipGetErrorString(le) + ")");
+  }
   return SGRL_OK;
 }
 }  // namespace

@@ -461,8 +461,8 @@ struct sgrl_set {
   // side stream for the GEMM chains that do not depend on each other (their epilogues / tile tails overlap)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_l3 = nullptr;
-  bool side_checked = false;          // `side` has been measured to overlap `side_checked_for` (stream_pick.h)
-  hipStream_t side_checked_for = nullptr;
+  std::vector<hipStream_t> side_ok_for;   // caller streams `side` has been measured to overlap (stream_pick.h)
+  int side_picks = 0;                     // measurements spent so far (bounded: a caller hopping between streams must not pay forever)
   const float* W(int slot) const { return w + off[slot]; }
   const float* WL(int layer, int k) const { return w + off[SGRL_SET_NGLOBAL + layer * SGRL_SET_NLAYER + k]; }
 };
@@ -750,11 +750,14 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(st, &cap);
   const bool one_stream = small || cap != hipStreamCaptureStatusNone;
-  if (!one_stream && sgrl_streams::enabled() && !(s->side_checked && s->side_checked_for == st)) {
+  if (!one_stream && sgrl_streams::enabled() && s->side_picks < 6 &&
+      std::find(s->side_ok_for.begin(), s->side_ok_for.end(), st) == s->side_ok_for.end()) {
     // first forward on this caller stream: make sure the side stream sits on another hardware queue (stream_pick.h)
-    s->side = sgrl_streams::pick({st}, s->side);
-    s->side_checked = true;
-    s->side_checked_for = st;
+    s->side_picks++;
+    hipStream_t chosen = sgrl_streams::pick({st}, s->side);
+    if (chosen != s->side) s->side_ok_for.clear();     // a new side stream: nothing is known about the other callers
+    s->side = chosen;
+    s->side_ok_for.push_back(st);
   }
   hipStream_t sd = one_stream ? st : s->side;
   auto fork = [&]() { if (!one_stream) { (void)hipEventRecord(s->ev_fork, st); (void)hipStreamWaitEvent(sd, s->ev_fork, 0); } };
@@ -828,7 +831,11 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
 #undef GG
 #undef G
 #undef PG
-  if (hipGetLastError() != hipSuccess) return sfail(SGRL_ERR_HIP, "kernel launch failed in sgrl_set_forward");
+  {
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess)
+      return sfail(SGRL_ERR_HIP, std::string("kernel launch failed in sgrl_set_forward (") + hipGetErrorName(le) + ": " + hipGetErrorString(le) + ")");
+  }
   return SGRL_OK;
 }
 

@@ -32,6 +32,14 @@ namespace {
 
 thread_local std::string g_train_err;
 int tfail(int code, const std::string& msg) { g_train_err = msg; return code; }
+// after a launch: the runtime's last error, named in the message (a stale error of an earlier call reads differently from a
+// refused launch, e.g. into an invalidated stream capture)
+bool launched(const char* what, int* rc) {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return true;
+  *rc = tfail(SGRL_ERR_HIP, std::string(what) + " (" + hipGetErrorName(e) + ": " + hipGetErrorString(e) + ")");
+  return false;
+}
 
 constexpr int BT = 32;          // tile edge
 constexpr int BKF = 128;        // k-tile depth of the forward / input-gradient products (BKW for the weight gradient)
@@ -567,7 +575,7 @@ int launch(SArgs a, float* ws, hipStream_t st) {
   const int rc = plan<AT>(a, ws, &tn, &tm, &splits);
   if (rc != SGRL_OK) return rc;
   hipLaunchKernelGGL((k_sgemm<AT, BTR, BK>), dim3(tn, tm, splits), dim3(256), 0, st, a);
-  if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "train gemm: kernel launch failed");
+  { int lrc = SGRL_OK; if (!launched("train gemm: kernel launch failed", &lrc)) return lrc; }
   return SGRL_OK;
 }
 int launch_bwd(SArgs d, SArgs w, float* ws, hipStream_t st) {
@@ -579,7 +587,7 @@ int launch_bwd(SArgs d, SArgs w, float* ws, hipStream_t st) {
   if (rc != SGRL_OK) return rc;
   p.d = d; p.w = w; p.nd = p.dgx * p.dgy;
   hipLaunchKernelGGL(k_sgemm_bwd, dim3(p.nd + p.wgx * p.wgy * p.wnz), dim3(256), 0, st, p);
-  if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "train gemm: backward kernel launch failed");
+  { int lrc = SGRL_OK; if (!launched("train gemm: backward kernel launch failed", &lrc)) return lrc; }
   return SGRL_OK;
 }
 
@@ -609,7 +617,7 @@ int sgrl_linear_backward(const float* dy, int lddy, const float* y, int ldyo, in
   const float* mask = relu ? y : nullptr;
   if (drowdiv) {
     hipLaunchKernelGGL(k_rowdot, dim3((M + 3) / 4), dim3(256), 0, st, dy, lddy, y, ldyo, rowdiv, drowdiv, M, N);
-    if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_rowdot launch failed");
+    { int lrc = SGRL_OK; if (!launched("k_rowdot launch failed", &lrc)) return lrc; }
   }
   if (dx && (!w || ldw < K || lddx < K)) return tfail(SGRL_ERR_ARG, "sgrl_linear_backward: bad weight / dx argument");
   if (dw && (!x || ldx < K || lddw < K)) return tfail(SGRL_ERR_ARG, "sgrl_linear_backward: bad input / dw argument");
@@ -629,7 +637,7 @@ int sgrl_linear_backward(const float* dy, int lddy, const float* y, int ldyo, in
   } else if (db) {
     if (rowdiv) return tfail(SGRL_ERR_ARG, "sgrl_linear_backward: db without dw is not offered together with rowdiv");
     hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64), dim3(256), 0, st, dy, lddy, mask, ldyo, db, M, N);
-    if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_colsum launch failed");
+    { int lrc = SGRL_OK; if (!launched("k_colsum launch failed", &lrc)) return lrc; }
   }
   return SGRL_OK;
 }
@@ -637,14 +645,14 @@ int sgrl_linear_backward(const float* dy, int lddy, const float* y, int ldyo, in
 int sgrl_gram_forward(const float* z, float* gram, float* fn, int M, void* stream) {
   if (!z || !gram || !fn || M <= 0) return tfail(SGRL_ERR_ARG, "sgrl_gram_forward: bad argument");
   hipLaunchKernelGGL(k_gram_fwd, dim3(M), dim3(256), 0, (hipStream_t)stream, z, gram, fn, M);
-  if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_gram_fwd launch failed");
+  { int lrc = SGRL_OK; if (!launched("k_gram_fwd launch failed", &lrc)) return lrc; }
   return SGRL_OK;
 }
 
 int sgrl_gram_backward(const float* z, const float* dgram, const float* dfn, const float* fn, float* dz, int M, void* stream) {
   if (!z || !fn || !dz || M <= 0 || (!dgram && !dfn)) return tfail(SGRL_ERR_ARG, "sgrl_gram_backward: bad argument");
   hipLaunchKernelGGL(k_gram_bwd, dim3(M), dim3(256), 0, (hipStream_t)stream, z, dgram, dfn, fn, dz, M);
-  if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_gram_bwd launch failed");
+  { int lrc = SGRL_OK; if (!launched("k_gram_bwd launch failed", &lrc)) return lrc; }
   return SGRL_OK;
 }
 
@@ -652,7 +660,7 @@ int sgrl_attention_forward(const float* qkv, const float* vgp, const float* gdir
                            float* o, float* og, int B, int L, void* stream) {
   if (!qkv || !vgp || !gdir || !w || !o || !og || B <= 0 || L < 1 || L > AL) return tfail(SGRL_ERR_ARG, "sgrl_attention_forward: bad argument");
   hipLaunchKernelGGL(k_attn_fwd, dim3(B), dim3(256), 0, (hipStream_t)stream, qkv, vgp, gdir, bias, scale, w, o, og, L);
-  if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_attn_fwd launch failed");
+  { int lrc = SGRL_OK; if (!launched("k_attn_fwd launch failed", &lrc)) return lrc; }
   return SGRL_OK;
 }
 
@@ -661,7 +669,7 @@ int sgrl_attention_backward(const float* qkv, const float* vgp, const float* gdi
   if (!qkv || !vgp || !gdir || !w || !d_o || !d_og || !dqkv || !dvgp || !dgdh || !ds || B <= 0 || L < 1 || L > AL)
     return tfail(SGRL_ERR_ARG, "sgrl_attention_backward: bad argument");
   hipLaunchKernelGGL(k_attn_bwd, dim3(B), dim3(256), 0, (hipStream_t)stream, qkv, vgp, gdir, scale, w, d_o, d_og, dqkv, dvgp, dgdh, ds, L);
-  if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_attn_bwd launch failed");
+  { int lrc = SGRL_OK; if (!launched("k_attn_bwd launch failed", &lrc)) return lrc; }
   return SGRL_OK;
 }
 
@@ -689,7 +697,7 @@ int sgrl_linear_wgrad_group(int n, const sgrl_wgrad_desc* d, float* ws, void* st
     }
     p.first[p.n] = blocks;
     hipLaunchKernelGGL(k_sgemm_wgroup, dim3(blocks), dim3(256), 0, st, p);
-    if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_sgemm_wgroup launch failed");
+    { int lrc = SGRL_OK; if (!launched("k_sgemm_wgroup launch failed", &lrc)) return lrc; }
   }
   return SGRL_OK;
 }
@@ -697,14 +705,14 @@ int sgrl_linear_wgrad_group(int n, const sgrl_wgrad_desc* d, float* ws, void* st
 int sgrl_zmat_forward(const float* z, const float* mat, float* t, int M, void* stream) {
   if (!z || !mat || !t || M <= 0) return tfail(SGRL_ERR_ARG, "sgrl_zmat_forward: bad argument");
   hipLaunchKernelGGL(k_zmat_fwd, dim3((M + 1) / 2), dim3(256), 0, (hipStream_t)stream, z, mat, t, M);
-  if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_zmat_fwd launch failed");
+  { int lrc = SGRL_OK; if (!launched("k_zmat_fwd launch failed", &lrc)) return lrc; }
   return SGRL_OK;
 }
 
 int sgrl_zmat_backward(const float* z, const float* mat, const float* dt, float* dz, float* dmat, int M, void* stream) {
   if (!z || !mat || !dt || !dz || !dmat || M <= 0) return tfail(SGRL_ERR_ARG, "sgrl_zmat_backward: bad argument");
   hipLaunchKernelGGL(k_zmat_bwd, dim3((M + 1) / 2), dim3(256), 0, (hipStream_t)stream, z, mat, dt, dz, dmat, M);
-  if (hipGetLastError() != hipSuccess) return tfail(SGRL_ERR_HIP, "k_zmat_bwd launch failed");
+  { int lrc = SGRL_OK; if (!launched("k_zmat_bwd launch failed", &lrc)) return lrc; }
   return SGRL_OK;
 }
 

@@ -14,6 +14,9 @@ Pinned by tests/golden/td3_update.npz, produced by executing the reference's own
 import os
 import types
 
+import contextlib
+import gc
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -233,6 +236,24 @@ class Agent(nn.Module):
             m.train()
 
 
+@contextlib.contextmanager
+def _no_finalizers_during_capture():
+    """Collect dead Python cycles NOW and keep the cyclic collector off until the capture has ended.  A collector pass in the
+    middle of a capture may finalize an object of an earlier phase that owns device resources (a `HipSetActor`, a vec-env, a
+    `DeviceTrainer`: their destructors call hipFree / hipStreamDestroy), and any such call invalidates a global-mode capture
+    (`hipErrorStreamCaptureInvalidated` at the next launch).  torch.cuda.graph collected unconditionally in older releases; this one
+    only does with torch.compiler.config.force_cudagraph_gc -- found as a test failure that came and went with the number of
+    objects pytest had allocated before the capture."""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
+
 class GraphedUpdates(object):
     """`Agent.update` captured into hipGraphs (MI355X: the update is ~3 400 small launches -- PyTorch autograd through three
     SET networks at batch 100 plus the HIP target kernels -- and launch-bound when issued eagerly: 50 ms; a replay is
@@ -317,7 +338,7 @@ class GraphedUpdates(object):
             dump = os.environ.get("SGRL_GRAPH_DUMP")      # diagnostics: <dir> receives one .dot file per captured graph
             if dump:
                 g.enable_debug_mode()
-            with torch.cuda.graph(g):
+            with _no_finalizers_during_capture(), torch.cuda.graph(g):
                 sl["out"][flag] = self.agent.update(sl["batch"], flag, noise=sl["noise"], lazy_stats=True,
                                                     skip_unused_critic_grads=True)
             if dump:
