@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/sgrl.h"
@@ -259,54 +260,85 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
     gd[idx] = s;
   }
   __syncthreads();                               // gd[] complete
-  // thread = (pair of output quantities, output column): threads 0..127 produce the scalar stream and spatial row 0 of
-  // column c, threads 128..255 spatial rows 1 and 2; each sums over BOTH heads itself (no cross-thread reduction, no
-  // barrier), reading the L value entries of a (quantity, head) once into registers
-  const int half = t >> 7, c = t & 127;
+  // wave = output quantity (0: scalar stream, 1..3: spatial row quantity - 1), half-wave = head, lane = FOUR output columns:
+  // a lane streams its head's value rows as 16-byte loads (one per key limb, the next one in flight while this one is used),
+  // keeps the L output rows of its four columns in registers, and the two heads meet over one cross-half exchange.  The row
+  // count is a compile-time bound per instance (4 or 8 rows at a time) so that the register arrays stay small.
+  {
+    const int quantity = t >> 6, ln = t & 63, h = ln >> 5, c4 = (ln & 31) * 4;
+    const float* vbase = quantity == 0 ? qkv + (size_t)n0 * 768 + 512 + h * 128 + c4
+                                       : U + ((size_t)n0 * 3 + (quantity - 1)) * 256 + h * 128 + c4;     // 768 floats per node either way
+    auto body = [&](auto ltc, const int i0) __attribute__((always_inline)) {      // output rows i0 .. i0 + LT - 1
+      constexpr int LT = decltype(ltc)::value;
+      float4 out[LT];
 #pragma unroll
-  for (int qq = 0; qq < 2; qq++) {
-    const int quantity = 2 * half + qq;          // 0: scalar stream, 1..3: spatial row quantity - 1
-    float out[LMAX];
+      for (int i = 0; i < LT; i++) out[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* wh = sc + h * L * L;
+      if (L <= 8) {          // all value rows in flight at once (one 16-byte load per key limb), then the products
+        float4 v[8];
 #pragma unroll
-    for (int i = 0; i < LMAX; i++) out[i] = 0.f;
+        for (int j = 0; j < 8; j++)
+          v[j] = j < L ? *reinterpret_cast<const float4*>(vbase + (size_t)j * 768) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      float v[LMAX];
+        for (int j = 0; j < 8; j++)
+          if (j < L) {
 #pragma unroll
-      for (int j = 0; j < LMAX; j++) {
-        const int n = n0 + (j < L ? j : 0);
-        const float x = quantity == 0 ? qkv[(size_t)n * 768 + 512 + h * 128 + c]
-                                      : U[((size_t)n * 3 + (quantity - 1)) * 256 + h * 128 + c];
-        v[j] = j < L ? x : 0.f;
-      }
-      float gd0 = 0.f, gd1 = 0.f;
-      if (quantity != 0) { gd0 = GD[(h * 128 + c) * 2]; gd1 = GD[(h * 128 + c) * 2 + 1]; }
-#pragma unroll
-      for (int i = 0; i < LMAX; i++)
-        if (i < L) {
-          const float* w = sc + (h * L + i) * L;
-          float s = 0.f;
-#pragma unroll
-          for (int j = 0; j < LMAX; j++) if (j < L) s += w[j] * v[j];
-          if (quantity != 0) {
-            const float* gg = gd + (h * L + i) * 6 + 2 * (quantity - 1);
-            s += gd0 * gg[0] + gd1 * gg[1];
+            for (int i = 0; i < LT; i++)
+              if (i0 + i < L) {
+                const float w = wh[(i0 + i) * L + j];
+                out[i].x += w * v[j].x; out[i].y += w * v[j].y; out[i].z += w * v[j].z; out[i].w += w * v[j].w;
+              }
           }
-          out[i] += s;
-        }
-    }
-    if (quantity != 0) {
+      } else {               // more than 8 key limbs: stream them, the next row in flight while this one is used
+        float4 v = *reinterpret_cast<const float4*>(vbase);
+        for (int j = 0; j < L; j++) {
+          const float4 vn = *reinterpret_cast<const float4*>(vbase + (size_t)(j + 1 < L ? j + 1 : j) * 768);
 #pragma unroll
-      for (int i = 0; i < LMAX; i++) if (i < L) g1[((size_t)(n0 + i) * 3 + (quantity - 1)) * 128 + c] = out[i];
-    } else {
-      // scalar stream: the rows go through LDS to the LayerNorm below, one wave per limb row, two channels per lane
-      const float bb = b_ng[c];
-#pragma unroll
-      for (int i = 0; i < LMAX; i++)
-        if (i < L) {
-          dl[i][c] = out[i] + bb;
-          if (delta_dbg) delta_dbg[(size_t)(n0 + i) * 128 + c] = out[i] + bb;
+          for (int i = 0; i < LT; i++)
+            if (i0 + i < L) {
+              const float w = wh[(i0 + i) * L + j];
+              out[i].x += w * v.x; out[i].y += w * v.y; out[i].z += w * v.z; out[i].w += w * v.w;
+            }
+          v = vn;
         }
+      }
+      if (quantity != 0) {
+        const float4 ga = *reinterpret_cast<const float4*>(GD + (h * 128 + c4) * 2);        // (gd0, gd1) of columns c4, c4 + 1
+        const float4 gb = *reinterpret_cast<const float4*>(GD + (h * 128 + c4) * 2 + 4);    // ... of columns c4 + 2, c4 + 3
+#pragma unroll
+        for (int i = 0; i < LT; i++)
+          if (i0 + i < L) {
+            const float* gg = gd + (h * L + i0 + i) * 6 + 2 * (quantity - 1);
+            const float g0 = gg[0], g1v = gg[1];
+            out[i].x += ga.x * g0 + ga.y * g1v; out[i].y += ga.z * g0 + ga.w * g1v;
+            out[i].z += gb.x * g0 + gb.y * g1v; out[i].w += gb.z * g0 + gb.w * g1v;
+          }
+      }
+      // both heads: exchange across the half-waves; afterwards both halves hold the sums, each stores every other row
+      float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (quantity == 0) bb = *reinterpret_cast<const float4*>(b_ng + c4);
+#pragma unroll
+      for (int i = 0; i < LT; i++)
+        if (i0 + i < L) {
+          float4 o = out[i];
+          const float px = __shfl_xor(o.x, 32, 64), py = __shfl_xor(o.y, 32, 64), pz = __shfl_xor(o.z, 32, 64), pw = __shfl_xor(o.w, 32, 64);
+          // head 0's term first, as the sequential sum over the heads had it
+          o = h == 0 ? make_float4(o.x + px, o.y + py, o.z + pz, o.w + pw) : make_float4(px + o.x, py + o.y, pz + o.z, pw + o.w);
+          if ((i & 1) == h) {
+            if (quantity != 0) {
+              *reinterpret_cast<float4*>(g1 + ((size_t)(n0 + i0 + i) * 3 + (quantity - 1)) * 128 + c4) = o;
+            } else {
+              o.x += bb.x; o.y += bb.y; o.z += bb.z; o.w += bb.w;
+              *reinterpret_cast<float4*>(&dl[i0 + i][c4]) = o;       // to the LayerNorm below, one wave per limb row
+              if (delta_dbg) *reinterpret_cast<float4*>(delta_dbg + (size_t)(n0 + i0 + i) * 128 + c4) = o;
+            }
+          }
+        }
+    };
+    if (L <= 4) {
+      body(std::integral_constant<int, 4>{}, 0);
+    } else {                                       // more than 8 limbs: two passes over the value rows (they come from L1 / L2)
+      for (int i0 = 0; i0 < L; i0 += 8) body(std::integral_constant<int, 8>{}, i0);
     }
   }
   __syncthreads();
