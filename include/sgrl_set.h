@@ -148,6 +148,20 @@ int sgrl_set_debug_stop_after(sgrl_set* s, int stage);
  * results to float32 rounding.  Default 2048 (SGRL_SET_SMALL_NODES in the environment); 0 = never; -1 restores the default.
  * Tests use it to run one input through both paths. */
 int sgrl_set_debug_small_nodes(sgrl_set* s, int nodes);
+/* Form of the 128 x 128 tile products (reference: plain f32 `F.linear`, subequivariant_attentions.py:90-151 / SEActor.py:82-125).
+ * Both forms carry the f32 product on the 16-bit matrix cores and measure the same error against float64 as an f32 FMA chain
+ * (tools/gemm_lab.hip):
+ *   SGRL_SET_FORM_F16X3  (default) every operand = two f16 pieces, three matrix instructions per product block.  Operands of
+ *                        magnitude above 65 000 (f16's finite range) are clamped to +-65 000 and COUNTED;
+ *   SGRL_SET_FORM_BF16X6 three bf16 pieces, six instructions: f32's whole exponent range, ~25 % slower products.
+ * form 0 restores the default (SGRL_SET_GEMM=bf16x6 in the environment selects the second form). */
+#define SGRL_SET_FORM_F16X3 2
+#define SGRL_SET_FORM_BF16X6 3
+int sgrl_set_gemm_form(sgrl_set* s, int form);
+/* Number of kernel threads that clamped an operand since the last reset (0 in any sane policy state: activations of 6.5e4
+ * mean a diverged network in the reference too).  Synchronise the forward's stream first.  A caller that sees a non-zero count
+ * repeats the forward after sgrl_set_gemm_form(s, SGRL_SET_FORM_BF16X6). */
+int sgrl_set_range_events(sgrl_set* s, unsigned* count, int reset);
 const char* sgrl_set_last_error(void);
 
 #ifdef __cplusplus

@@ -40,6 +40,7 @@ struct GemmArgs {
   float* ln_io = nullptr; int ln_ld = 0;          // EPI_LN: residual stream (read and rewritten), row stride
   const float* ln_w = nullptr; const float* ln_b = nullptr;
   float* rowdiv_out = nullptr;   // GRAM: receives ||Z'Z||_F + 1 per row (from the blocks of the first column tile)
+  unsigned* range_events = nullptr;   // two-piece f16 kernel: incremented by every thread that had to clamp an operand (see split2h)
 };
 
 // BKT = k extent of an LDS tile (16 or 32); row stride BKT + 4 floats (conflict-free ds_read_b128, see above).
@@ -226,14 +227,34 @@ __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsign
 // two f32 bit patterns -> one dword holding their top halves (bf16 of the first in the low half)
 __device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
-template <int WM, int WN, int TM, int TN, int BKT = 32>
+// Two-piece form (NPL = 2): x = h + l' / 2^11 with h = f16(x) and l' = f16((x - h) * 2^11), both rounded to nearest.  h carries
+// 11 significant bits, the remainder x - h is exact in f32 and at most 2^-11 |x|, l' carries 11 bits of it: |x - h - l'/2^11|
+// <= 2^-22 |x|.  a.b is rebuilt from hh + (h l' + l' h) / 2^11 -- THREE v_mfma_f32_32x32x16_f16 instead of six bf16 ones, two
+// LDS planes per operand instead of three; dropped: l'l' / 2^22 <= 2^-22 |a||b|.  An f16 x f16 product is exact in f32 and the
+// matrix core accumulates in f32.  The scaling of l' keeps the small piece in f16's NORMAL range wherever h is normal: full
+// accuracy for 6.1e-5 <= |x| <= 65 000; below, the absolute error stays under 2^-36 (h and l' turn subnormal, x - h is still
+// exact); above, the operand is CLAMPED to +-65 000 (f16 has no larger finite values worth having) and the event is counted
+// in GemmArgs::range_events -- the host surfaces the counter and can switch the handle to the bf16 x 6 form, which has
+// f32's full exponent range.  tools/gemm_lab.hip measures both forms against float64.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr float kF16Lim = 65000.f;
+constexpr float kF16LowScale = 2048.f;
+__device__ __forceinline__ void split2h(float x0, float x1, unsigned& h, unsigned& l) {
+  const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+  const _Float16 l0 = (_Float16)((x0 - (float)h0) * kF16LowScale), l1 = (_Float16)((x1 - (float)h1) * kF16LowScale);
+  h = __builtin_bit_cast(unsigned, f16x2{h0, h1});
+  l = __builtin_bit_cast(unsigned, f16x2{l0, l1});
+}
+
+template <int WM, int WN, int TM, int TN, int BKT = 32, int NPL = 3>
 struct TileCfg3 {
   static constexpr int kThreads = 64 * WM * WN;
   static constexpr int kBM = 32 * TM * WM, kBN = 32 * TN * WN;
   static constexpr int kBK = BKT;
   static constexpr int kRowBytes = 2 * kBK + 16;          // BK bf16 + 16 B pad (20 / 12 dwords): conflict-free ds_read_b128
   static constexpr int kPlaneA = kBM * kRowBytes, kPlaneW = kBN * kRowBytes;
-  static constexpr int kStageBytes = 3 * (kPlaneA + kPlaneW);
+  static constexpr int kStageBytes = NPL * (kPlaneA + kPlaneW);
   static constexpr int kLdsBytes = 2 * kStageBytes;
 };
 
@@ -249,9 +270,21 @@ struct TileCfg3 {
 // diagonal blocks carry zero weight).  The [M, 576] Gram operand (and its [M, 1024] dense form) never exists in memory:
 // a staging thread reads 3 + 12 floats of its row's Z (L2-resident: 384 bytes per row) per k-tile and forms 4 entries.
 constexpr int kGramK = 576;
-template <int FLAGS, int WM, int WN, int TM, int TN, int BKT = 32, int PF = 1, bool PLA = false, bool PLW = false, bool LATE = false, int ABL = 0, bool GRAM = false>
+// NPL = 3: bf16 x 6 (exact three-way split, f32's exponent range); NPL = 2: f16 x 3 (two-piece split above)
+template <int FLAGS, int WM, int WN, int TM, int TN, int BKT = 32, int PF = 1, bool PLA = false, bool PLW = false, bool LATE = false, int ABL = 0, bool GRAM = false, int NPL = 3>
 __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4))) void k_gemm3(GemmArgs a) {
-  using Cfg = TileCfg3<WM, WN, TM, TN, BKT>;
+  using Cfg = TileCfg3<WM, WN, TM, TN, BKT, NPL>;
+  static_assert(NPL == 3 || (NPL == 2 && !PLA && !PLW && ABL != 3), "two-piece form: f32 operands only");
+  // two-piece form: the correction accumulator holds 2^11 x its sum; the Gram operand is generated 2^-8 x its value (entries
+  // are SQUARES of the projections' size: the clamp moves out to 1.6e7) and the result scaled back -- both exact
+  constexpr float kCorW = NPL == 2 ? 1.f / kF16LowScale : 1.f;
+  constexpr float kPre = (NPL == 2 && GRAM) ? 1.f / 256.f : 1.f;
+  constexpr float kPost = (NPL == 2 && GRAM) ? 256.f : 1.f;
+  auto fin = [&](float hi, float co) -> float {
+    if (NPL == 2) { const float v = hi + co * kCorW; return GRAM ? v * kPost : v; }
+    return hi + co;
+  };
+  int clamped = 0;
   constexpr int T = Cfg::kThreads, BMT = Cfg::kBM, BNT = Cfg::kBN, RB = Cfg::kRowBytes;
   constexpr int QPR = BKT / 4;                // float4 per tile row
   constexpr int RPP = T / QPR;                // tile rows covered per staging pass
@@ -309,7 +342,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
     for (int sx = 0; sx < 3; sx++) gzb[sx] = *reinterpret_cast<const float4*>(arow_g[0] + 32 * sx + 4 * gb);
     if (gb == 0) {                            // a new block row: this thread's a = 4 A + kq changes (uniform branch)
 #pragma unroll
-      for (int sx = 0; sx < 3; sx++) gza[sx] = arow_g[0][32 * sx + 4 * ga + kq];
+      for (int sx = 0; sx < 3; sx++) gza[sx] = arow_g[0][32 * sx + 4 * ga + kq] * kPre;
     }
     if (++gb > ga) { ga++; gb = 0; }
   };
@@ -343,7 +376,22 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
     *reinterpret_cast<uint2*>(p + 2 * plane_stride) = v[2];
   };
   // split a float4 into its three bf16 planes and store 8 bytes into each
-  auto put = [&](char* plane0, int plane_stride, int row, const float4& v) {
+  auto put = [&](char* plane0, int plane_stride, int row, const float4& vin) {
+    if (NPL == 2) {
+      float4 v = vin;
+      if (fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) > kF16Lim) {      // rare: see split2h
+        v.x = __builtin_amdgcn_fmed3f(v.x, -kF16Lim, kF16Lim); v.y = __builtin_amdgcn_fmed3f(v.y, -kF16Lim, kF16Lim);
+        v.z = __builtin_amdgcn_fmed3f(v.z, -kF16Lim, kF16Lim); v.w = __builtin_amdgcn_fmed3f(v.w, -kF16Lim, kF16Lim);
+        clamped = 1;
+      }
+      unsigned h0, l0, h1, l1;
+      split2h(v.x, v.y, h0, l0); split2h(v.z, v.w, h1, l1);
+      char* p = plane0 + row * RB + 8 * kq;
+      *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(l0, l1);
+      return;
+    }
+    const float4& v = vin;
     unsigned h[4], m[4], l[4];
     if (ABL == 3) {
       h[0] = __float_as_uint(v.x); h[1] = __float_as_uint(v.y); h[2] = __float_as_uint(v.z); h[3] = __float_as_uint(v.w);
@@ -373,8 +421,8 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
 #pragma unroll
     for (int i = 0; i < NPW; i++)
       if (r0 + RPP * i < BNT) {
-        if (PLW) put_planes(base + 3 * Cfg::kPlaneA, Cfg::kPlaneW, r0 + RPP * i, pw[slot][PLW ? i : 0]);
-        else put(base + 3 * Cfg::kPlaneA, Cfg::kPlaneW, r0 + RPP * i, rw[slot][i]);
+        if (PLW) put_planes(base + NPL * Cfg::kPlaneA, Cfg::kPlaneW, r0 + RPP * i, pw[slot][PLW ? i : 0]);
+        else put(base + NPL * Cfg::kPlaneA, Cfg::kPlaneW, r0 + RPP * i, rw[slot][i]);
       }
   };
   const int nk = a.K / BKT;
@@ -411,7 +459,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
   if (PF == 2 && nk > 2) gload(1, 2 * BKT);
   const int li = lane & 31, lh = lane >> 5;
   const int aoff = (wm * 32 * TM + li) * RB + 16 * lh;        // this lane's 8 bf16 of k-step 0; k-step 1 is 32 bytes on
-  const int boff = 3 * Cfg::kPlaneA + (wn * 32 * TN + li) * RB + 16 * lh;
+  const int boff = NPL * Cfg::kPlaneA + (wn * 32 * TN + li) * RB + 16 * lh;
   auto body = [&](int kt, int slot) {
     const int st = kt & 1;
     if (!LATE && ABL != 1) {
@@ -427,18 +475,30 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
 #pragma unroll
       for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++)
+        for (int pl = 0; pl < NPL; pl++)
           av[i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(base + pl * Cfg::kPlaneA + aoff + 32 * i * RB + 32 * ks));
 #pragma unroll
       for (int j = 0; j < TN; j++)
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++)
+        for (int pl = 0; pl < NPL; pl++)
           bv[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(base + pl * Cfg::kPlaneW + boff + 32 * j * RB + 32 * ks));
 #pragma unroll
       for (int i = 0; i < TM; i++)
 #pragma unroll
         for (int j = 0; j < TN; j++) {
-          if (FLAGS & EPI_EQUIV) {
+          if (NPL == 2) {
+            const f16x8 ah = __builtin_bit_cast(f16x8, av[i][0]), al = __builtin_bit_cast(f16x8, av[i][1]);
+            const f16x8 bh = __builtin_bit_cast(f16x8, bv[j][0]), bl = __builtin_bit_cast(f16x8, bv[j][1]);
+            if (FLAGS & EPI_EQUIV) {          // transposed tile, as below
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[i][j], 0, 0, 0);
+              cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, cor[i][j], 0, 0, 0);
+              cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, cor[i][j], 0, 0, 0);
+            } else {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i][j], 0, 0, 0);   // hh
+              cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, cor[i][j], 0, 0, 0);   // l'h
+              cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, cor[i][j], 0, 0, 0);   // hl'
+            }
+          } else if (FLAGS & EPI_EQUIV) {
             // transposed tile (W rows on the accumulator rows = registers, nodes on the lanes): the epilogue's contraction over
             // the W-row index then runs over REGISTERS of a lane instead of across lanes
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j][0], av[i][0], acc[i][j], 0, 0, 0);
@@ -470,6 +530,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
     for (; kt + 1 < nk; kt += 2) { body(kt, 0); body(kt + 1, 1); }
     if (kt < nk) body(kt, 0);
   }
+  if (NPL == 2 && clamped && a.range_events) atomicAdd(a.range_events, 1u);
   if (FLAGS & EPI_EQUIV) {
     // Equivariant epilogue.  The accumulators hold TRANSPOSED 32 x 32 tiles: lane = node (column li of the tile), registers
     // = W rows q (row (e & 3) + 8 (e >> 2) + 4 lh); one tile = mat[node][q][c] for ONE c (output columns ordered c * 32 + q).
@@ -496,10 +557,10 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
       for (int g4 = 0; g4 < 4; g4++) {
         const int q0 = 8 * g4 + 4 * lh;
         const float4 b4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + cidx * 32 + q0) : make_float4(0, 0, 0, 0);
-        const float v0 = (acc[0][tj][4 * g4 + 0] + cor[0][tj][4 * g4 + 0]) + b4.x;
-        const float v1 = (acc[0][tj][4 * g4 + 1] + cor[0][tj][4 * g4 + 1]) + b4.y;
-        const float v2 = (acc[0][tj][4 * g4 + 2] + cor[0][tj][4 * g4 + 2]) + b4.z;
-        const float v3 = (acc[0][tj][4 * g4 + 3] + cor[0][tj][4 * g4 + 3]) + b4.w;
+        const float v0 = fin(acc[0][tj][4 * g4 + 0], cor[0][tj][4 * g4 + 0]) + b4.x;
+        const float v1 = fin(acc[0][tj][4 * g4 + 1], cor[0][tj][4 * g4 + 1]) + b4.y;
+        const float v2 = fin(acc[0][tj][4 * g4 + 2], cor[0][tj][4 * g4 + 2]) + b4.z;
+        const float v3 = fin(acc[0][tj][4 * g4 + 3], cor[0][tj][4 * g4 + 3]) + b4.w;
 #pragma unroll
         for (int sx = 0; sx < 3; sx++) {
           const float4 z4 = *reinterpret_cast<const float4*>(zs + mloc * ZS + sx * 32 + q0);
@@ -528,7 +589,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
       const float bvv = a.bias ? a.bias[wn * 64 + tj * 32 + li] : 0.f;
 #pragma unroll
       for (int e = 0; e < 16; e++) {
-        float v = (acc[0][tj][e] + cor[0][tj][e]) + bvv;
+        float v = fin(acc[0][tj][e], cor[0][tj][e]) + bvv;
         if (FLAGS & EPI_RELU) v = fmaxf(v, 0.f);
         acc[0][tj][e] = v;
       }
@@ -611,7 +672,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
       for (int e = 0; e < 16; e++) {
         const int m = mb + (e & 3) + 8 * (e >> 2);
         if (m >= a.M) continue;
-        float v = (acc[ti][tj][e] + cor[ti][tj][e]) + bvv;
+        float v = fin(acc[ti][tj][e], cor[ti][tj][e]) + bvv;
         if (FLAGS & EPI_RELU) v = fmaxf(v, 0.f);
         if (FLAGS & EPI_ROWDIV) v = v * rdiv[e];
         a.C[(size_t)m * a.ldc + n] = v;

@@ -483,6 +483,8 @@ struct sgrl_set {
   bool stack_critic = false;   // mode the stacked operands were built for
   int stop_after = -1;         // parity probes: leave run_forward after this stage (sgrl_set_debug_stop_after)
   int small_nodes = -1;        // batches of at most this many nodes take the small-batch products; -1: SGRL_SET_SMALL_NODES / default
+  int gemm_form = 0;           // SGRL_SET_FORM_* of the tile products; 0: SGRL_SET_GEMM / default (sgrl_set_gemm_form)
+  unsigned* d_range_events = nullptr;   // operands the two-piece f16 form had to clamp (sgrl_set_range_events)
   // live weights (sgrl_set_bind_params)
   bool live = false;
   float* wflat = nullptr;
@@ -564,11 +566,23 @@ bool gemm_use_split() {
   static const bool v = [] { const char* e = getenv("SGRL_SET_GEMM"); return !(e && e[0] == 'f'); }();
   return v;
 }
+// Split form of the forward in flight (set by run_forward from its handle): SGRL_SET_FORM_F16X3 = two f16 pieces, three matrix
+// instructions per product block (default; operands beyond +-65 000 are clamped and counted in `events`), SGRL_SET_FORM_BF16X6 =
+// three bf16 pieces, six instructions, f32's exponent range (gemm_f32.h).  SGRL_SET_GEMM=bf16x6 makes the latter the default.
+struct GemmCtx { int form = SGRL_SET_FORM_F16X3; unsigned* events = nullptr; };
+thread_local GemmCtx g_gemm;
+int gemm_default_form() {
+  static const int v = [] { const char* e = getenv("SGRL_SET_GEMM"); return (e && e[0] == 'b') ? SGRL_SET_FORM_BF16X6 : SGRL_SET_FORM_F16X3; }();
+  return v;
+}
+GemmArgs with_events(const GemmArgs& a) { GemmArgs b = a; b.range_events = g_gemm.events; return b; }
 template <int F> struct GemmKernels {
   static constexpr auto kNarrow = k_gemm2<F, 4, 1, 1, 2, 16, 1>;
   static constexpr auto kWide = k_gemm2<F, 4, 2, 1, 2, 32, 2>;
   static constexpr auto kSquare = k_gemm2<F, 4, 4, 1, 1, 32, 2>;
   static constexpr auto kSplit = sgrl_gemm::k_gemm3<F, 4, 2, 1, 2, 16, 2>;
+  static constexpr auto kSplitH = sgrl_gemm::k_gemm3<F, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2>;
+  static constexpr int kSplitHLds = sgrl_gemm::TileCfg3<4, 2, 1, 2, 16, 2>::kLdsBytes;
   static constexpr int kNarrowLds = sgrl_gemm::TileCfg<4, 1, 1, 2, 16>::kLdsBytes;
   static constexpr int kWideLds = sgrl_gemm::TileCfg<4, 2, 1, 2, 32>::kLdsBytes;
   static constexpr int kSquareLds = sgrl_gemm::TileCfg<4, 4, 1, 1, 32>::kLdsBytes;
@@ -577,14 +591,16 @@ template <int F> struct GemmKernels {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kNarrow), hipFuncAttributeMaxDynamicSharedMemorySize, kNarrowLds) == hipSuccess &&
            hipFuncSetAttribute(reinterpret_cast<const void*>(kWide), hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds) == hipSuccess &&
            hipFuncSetAttribute(reinterpret_cast<const void*>(kSquare), hipFuncAttributeMaxDynamicSharedMemorySize, kSquareLds) == hipSuccess &&
-           hipFuncSetAttribute(reinterpret_cast<const void*>(kSplit), hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLds) == hipSuccess;
+           hipFuncSetAttribute(reinterpret_cast<const void*>(kSplit), hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLds) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(kSplitH), hipFuncAttributeMaxDynamicSharedMemorySize, kSplitHLds) == hipSuccess;
   }
   static void launch(hipStream_t st, const GemmArgs& a) {
     const int tiles128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
     if (a.N <= 64 || (a.K % 32) != 0) {
       hipLaunchKernelGGL(kNarrow, dim3(((a.M + 127) / 128) * ((a.N + 63) / 64)), dim3(256), kNarrowLds, st, a);
     } else if (gemm_use_split()) {
-      hipLaunchKernelGGL(kSplit, dim3(tiles128), dim3(512), kSplitLds, st, a);
+      if (g_gemm.form == SGRL_SET_FORM_F16X3) hipLaunchKernelGGL(kSplitH, dim3(tiles128), dim3(512), kSplitHLds, st, with_events(a));
+      else hipLaunchKernelGGL(kSplit, dim3(tiles128), dim3(512), kSplitLds, st, a);
     } else if (tiles128 < 512) {
       hipLaunchKernelGGL(kNarrow, dim3(((a.M + 127) / 128) * ((a.N + 63) / 64)), dim3(256), kNarrowLds, st, a);
     } else if (a.N >= 512) {
@@ -598,33 +614,39 @@ template <int F> struct GemmKernels {
 // linear4 / linear2_m (N = 1024, columns ordered c * 32 + a) with the equivariant contraction in the epilogue:
 // tout[m][s][c] = sum_a zq[m][s][a] * ((A . W^T + b)[m][c * 32 + a] / rowdiv[m]); always the split-precision kernel
 constexpr auto kGemmEquiv = sgrl_gemm::k_gemm3<EPI_ROWDIV | EPI_EQUIV, 4, 2, 1, 2, 16, 2>;
+constexpr auto kGemmEquivH = sgrl_gemm::k_gemm3<EPI_ROWDIV | EPI_EQUIV, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2>;
 int launch_gemm_equiv(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, int M, int K,
                       const float* rowdiv, const float* zq, float* tout) {
   if (K % 32 != 0 || (lda & 3) || (ldw & 3)) return sfail(SGRL_ERR_ARG, "gemm_equiv: K must be a multiple of 32 and rows 16-byte aligned");
   GemmArgs a{A, lda, W, ldw, bias, nullptr, 0, M, 1024, K, EPI_ROWDIV | EPI_EQUIV, rowdiv, nullptr, 0};
   a.zq = zq; a.tout = tout;
-  hipLaunchKernelGGL(kGemmEquiv, dim3(((M + 127) / 128) * 8), dim3(512), GemmKernels<0>::kSplitLds, st, a);
+  if (g_gemm.form == SGRL_SET_FORM_F16X3) hipLaunchKernelGGL(kGemmEquivH, dim3(((M + 127) / 128) * 8), dim3(512), GemmKernels<0>::kSplitLds, st, with_events(a));
+  else hipLaunchKernelGGL(kGemmEquiv, dim3(((M + 127) / 128) * 8), dim3(512), GemmKernels<0>::kSplitLds, st, a);
   return SGRL_OK;
 }
 
 // C[M,N] = relu(G(Z) . W^T + b): the Gram-operand GEMM (A generated from zc [M, 3, 32]; W [N, 576] folded); N = 128 or 256
 constexpr auto kGemmGram = sgrl_gemm::k_gemm3<EPI_RELU, 4, 2, 1, 2, 16, 2, false, false, false, 0, true>;
+constexpr auto kGemmGramH = sgrl_gemm::k_gemm3<EPI_RELU, 4, 2, 1, 2, 16, 2, false, false, false, 0, true, 2>;
 int launch_gemm_gram(hipStream_t st, const float* zc, const float* W, const float* bias, float* C, int ldc, int M, int N, float* fn) {
   if (N % 128 != 0) return sfail(SGRL_ERR_ARG, "gemm_gram: N must be a multiple of 128");
   GemmArgs a{zc, 96, W, GK, bias, C, ldc, M, N, GK, EPI_RELU, nullptr, nullptr, 0};
   a.rowdiv_out = fn;
-  hipLaunchKernelGGL(kGemmGram, dim3(((M + 127) / 128) * (N / 128)), dim3(512), GemmKernels<0>::kSplitLds, st, a);
+  if (g_gemm.form == SGRL_SET_FORM_F16X3) hipLaunchKernelGGL(kGemmGramH, dim3(((M + 127) / 128) * (N / 128)), dim3(512), GemmKernels<0>::kSplitHLds, st, with_events(a));
+  else hipLaunchKernelGGL(kGemmGram, dim3(((M + 127) / 128) * (N / 128)), dim3(512), GemmKernels<0>::kSplitLds, st, a);
   return SGRL_OK;
 }
 
 // ln_io[m][:] = LayerNorm(ln_io[m][:] + (A . W^T + b)[m][:] / rowdiv[m]) * ln_w + ln_b   (N = 128, residual stream in place)
 constexpr auto kGemmLn = sgrl_gemm::k_gemm3<EPI_ROWDIV | EPI_LN, 4, 2, 1, 2, 16, 2>;
+constexpr auto kGemmLnH = sgrl_gemm::k_gemm3<EPI_ROWDIV | EPI_LN, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2>;
 int launch_gemm_ln(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, int M, int K,
                    const float* rowdiv, float* ln_io, int ln_ld, const float* ln_w, const float* ln_b) {
   if (K % 32 != 0 || (lda & 3) || (ldw & 3)) return sfail(SGRL_ERR_ARG, "gemm_ln: K must be a multiple of 32 and rows 16-byte aligned");
   GemmArgs a{A, lda, W, ldw, bias, nullptr, 0, M, 128, K, EPI_ROWDIV | EPI_LN, rowdiv, nullptr, 0};
   a.ln_io = ln_io; a.ln_ld = ln_ld; a.ln_w = ln_w; a.ln_b = ln_b;
-  hipLaunchKernelGGL(kGemmLn, dim3((M + 127) / 128), dim3(512), GemmKernels<0>::kSplitLds, st, a);
+  if (g_gemm.form == SGRL_SET_FORM_F16X3) hipLaunchKernelGGL(kGemmLnH, dim3((M + 127) / 128), dim3(512), GemmKernels<0>::kSplitHLds, st, with_events(a));
+  else hipLaunchKernelGGL(kGemmLn, dim3((M + 127) / 128), dim3(512), GemmKernels<0>::kSplitLds, st, a);
   return SGRL_OK;
 }
 
@@ -715,6 +737,8 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
                 bool critic = false, const float* action = nullptr, int action_ld = 0) {
   const int N = s->N, N3 = 3 * s->N;
   const int ngf = critic ? 20 : 17;
+  g_gemm.form = s->gemm_form ? s->gemm_form : gemm_default_form();
+  g_gemm.events = s->d_range_events;
   NodeTab nt{s->d_node_env, s->d_node_limb, s->d_node_mnode, s->d_trav, s->TM};
   EnvTab et{s->d_env_off, s->d_env_L, s->d_env_relb};
   (void)hipMemsetAsync(act, 0, sizeof(float) * (size_t)s->n_env * act_ld, st);
@@ -885,6 +909,10 @@ int sgrl_set_create(sgrl_set** out) {
   const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kGemmEquiv), hipFuncAttributeMaxDynamicSharedMemorySize, GemmKernels<0>::kSplitLds) == hipSuccess &&
                        hipFuncSetAttribute(reinterpret_cast<const void*>(kGemmGram), hipFuncAttributeMaxDynamicSharedMemorySize, GemmKernels<0>::kSplitLds) == hipSuccess &&
                        hipFuncSetAttribute(reinterpret_cast<const void*>(kGemmLn), hipFuncAttributeMaxDynamicSharedMemorySize, GemmKernels<0>::kSplitLds) == hipSuccess &&
+                       // the equivariant epilogue stages 128 z rows of 100 floats in the tile's LDS: that kernel keeps the larger request
+                       hipFuncSetAttribute(reinterpret_cast<const void*>(kGemmEquivH), hipFuncAttributeMaxDynamicSharedMemorySize, GemmKernels<0>::kSplitLds) == hipSuccess &&
+                       hipFuncSetAttribute(reinterpret_cast<const void*>(kGemmGramH), hipFuncAttributeMaxDynamicSharedMemorySize, GemmKernels<0>::kSplitHLds) == hipSuccess &&
+                       hipFuncSetAttribute(reinterpret_cast<const void*>(kGemmLnH), hipFuncAttributeMaxDynamicSharedMemorySize, GemmKernels<0>::kSplitHLds) == hipSuccess &&
                        GemmKernels<0>::raise_lds_limits() && GemmKernels<EPI_RELU>::raise_lds_limits() &&
                        GemmKernels<EPI_ROWDIV>::raise_lds_limits() && GemmKernels<EPI_ACC2>::raise_lds_limits() &&
                        GemmKernels<EPI_ZSPLIT>::raise_lds_limits();
@@ -911,7 +939,9 @@ int sgrl_set_create(sgrl_set** out) {
     return sfail(SGRL_ERR_HIP, "cannot create the side stream of the SET actor");
   }
   if (hipMalloc(&s->wstack, sizeof(float) * wstack_floats) != hipSuccess || hipMalloc(&s->d_tri, sizeof(unsigned short) * GK) != hipSuccess ||
+      hipMalloc(&s->d_range_events, sizeof(unsigned)) != hipSuccess || hipMemset(s->d_range_events, 0, sizeof(unsigned)) != hipSuccess ||
       hipMemcpy(s->d_tri, tri.data(), sizeof(unsigned short) * GK, hipMemcpyHostToDevice) != hipSuccess) {
+    if (s->d_range_events) (void)hipFree(s->d_range_events);
     if (s->wstack) (void)hipFree(s->wstack);
     if (s->d_tri) (void)hipFree(s->d_tri);
     delete s;
@@ -928,6 +958,7 @@ void sgrl_set_destroy(sgrl_set* s) {
   free_graphs(s);
   if (s->wstack) (void)hipFree(s->wstack);
   if (s->d_tri) (void)hipFree(s->d_tri);
+  if (s->d_range_events) (void)hipFree(s->d_range_events);
   if (s->wflat) (void)hipFree(s->wflat);
   if (s->d_segs) (void)hipFree(s->d_segs);
   if (s->d_chunks) (void)hipFree(s->d_chunks);
@@ -1143,6 +1174,20 @@ int sgrl_set_debug_stop_after(sgrl_set* s, int stage) {
 int sgrl_set_debug_small_nodes(sgrl_set* s, int nodes) {
   if (!s || nodes < -1) return sfail(SGRL_ERR_ARG, "sgrl_set_debug_small_nodes: bad argument");
   s->small_nodes = nodes;
+  return SGRL_OK;
+}
+
+int sgrl_set_gemm_form(sgrl_set* s, int form) {
+  if (!s || (form != 0 && form != SGRL_SET_FORM_F16X3 && form != SGRL_SET_FORM_BF16X6)) return sfail(SGRL_ERR_ARG, "sgrl_set_gemm_form: bad argument");
+  s->gemm_form = form;
+  return SGRL_OK;
+}
+
+int sgrl_set_range_events(sgrl_set* s, unsigned* count, int reset) {
+  if (!s || !count) return sfail(SGRL_ERR_ARG, "sgrl_set_range_events: bad argument");
+  // the null stream orders this copy behind the forwards of blocking streams only: callers synchronise their stream first
+  if (hipMemcpy(count, s->d_range_events, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return sfail(SGRL_ERR_HIP, "sgrl_set_range_events: copy failed");
+  if (reset && *count && hipMemset(s->d_range_events, 0, sizeof(unsigned)) != hipSuccess) return sfail(SGRL_ERR_HIP, "sgrl_set_range_events: reset failed");
   return SGRL_OK;
 }
 

@@ -39,6 +39,8 @@ def _bind(L):
     L.sgrl_set_peek.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int64]
     L.sgrl_set_debug_stop_after.argtypes = [vp, ctypes.c_int]
     L.sgrl_set_debug_small_nodes.argtypes = [vp, ctypes.c_int]
+    L.sgrl_set_gemm_form.argtypes = [vp, ctypes.c_int]
+    L.sgrl_set_range_events.argtypes = [vp, ctypes.POINTER(ctypes.c_uint), ctypes.c_int]
     L.sgrl_set_last_error.restype = ctypes.c_char_p
     L._set_bound = True
 
@@ -420,6 +422,32 @@ class HipSetActor(object):
     def debug_small_nodes(self, nodes):
         """Batches of at most `nodes` nodes take the small-batch products (include/sgrl_set.h); 0 = never, -1 = default."""
         _check(self.L, self.L.sgrl_set_debug_small_nodes(self.h, int(nodes)), "sgrl_set_debug_small_nodes")
+
+    FORM_F16X3, FORM_BF16X6 = 2, 3
+
+    def gemm_form(self, form):
+        """Form of the tile products (include/sgrl_set.h): FORM_F16X3 (default: operands beyond +-65 000 are clamped and
+        counted), FORM_BF16X6 (f32's exponent range, slower), 0 = default."""
+        _check(self.L, self.L.sgrl_set_gemm_form(self.h, int(form)), "sgrl_set_gemm_form")
+
+    def range_events(self, reset=True):
+        """Kernel threads that clamped an operand since the last reset (synchronises the device)."""
+        torch.cuda.synchronize(self.device)
+        n = ctypes.c_uint(0)
+        _check(self.L, self.L.sgrl_set_range_events(self.h, ctypes.byref(n), 1 if reset else 0), "sgrl_set_range_events")
+        return int(n.value)
+
+    def check_range(self):
+        """Call at a point where a device synchronisation is affordable (end of a collection round, of an evaluation):
+        if the two-piece products met an operand outside f16's range since the last check, warn and move this handle to
+        the full-range form for good.  Returns the number of events seen."""
+        n = self.range_events(reset=True)
+        if n:
+            import warnings
+            warnings.warn("SET forward: %d kernel threads clamped an operand beyond +-65 000 (two-piece f16 products); "
+                          "this handle now uses the bf16 x 6 form (f32 exponent range)" % n, RuntimeWarning)
+            self.gemm_form(self.FORM_BF16X6)
+        return n
 
     def peek(self, which, per_node):
         out = np.zeros((self.num_nodes, per_node), dtype=np.float32)

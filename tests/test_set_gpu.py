@@ -357,3 +357,35 @@ def test_small_batch_products_match_the_tile_kernels(ctx):
     act.debug_small_nodes(-1)
     assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 1e-3
     assert np.abs(outs[0] - outs[1]).max() < TOL
+
+
+def test_tile_product_forms_agree_and_out_of_range_operands_are_counted(ctx):
+    """The two split forms of the 128 x 128 tile products (include/sgrl_set.h sgrl_set_gemm_form): f16 x 3 (default) and
+    bf16 x 6 both reproduce the reference fixture at the suite's tolerance and agree far below it; no operand of a sane
+    input is clamped.  An absurd input (observations x 1e8) is clamped, COUNTED and stays finite; check_range() then moves
+    the handle to the full-range form."""
+    torch, pol, graphs, keys, z = ctx
+    from sgrl_amd.set_hip import HipSetActor
+    name = "3d_walker_7_full"
+    g = graphs[name]
+    act = HipSetActor(pol)
+    act.configure([_gd(torch, g)], [5])
+    act.debug_small_nodes(0)                      # the tile kernels, whatever the batch size
+    obs = torch.from_numpy(z["%s/B5/obs" % name]).cuda()
+    ref = z["%s/B5/act_f64" % name]
+    outs = {}
+    for form in (HipSetActor.FORM_F16X3, HipSetActor.FORM_BF16X6):
+        act.gemm_form(form)
+        outs[form] = act.forward_batch(obs).cpu().numpy().copy()
+        assert np.abs(outs[form] - ref).max() < TOL, form
+    assert np.abs(outs[HipSetActor.FORM_F16X3] - outs[HipSetActor.FORM_BF16X6]).max() < 5e-6
+    assert act.range_events() == 0
+    act.gemm_form(0)                              # default = f16 x 3
+    big = act.forward_batch(obs * 1e8).cpu().numpy()
+    assert np.isfinite(big).all()
+    with pytest.warns(RuntimeWarning):
+        assert act.check_range() > 0
+    act.forward_batch(obs * 1e8)                  # now on the bf16 x 6 form: nothing left to clamp
+    assert act.range_events() == 0
+    out = act.forward_batch(obs).cpu().numpy()
+    assert np.abs(out - outs[HipSetActor.FORM_BF16X6]).max() == 0.0

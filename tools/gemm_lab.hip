@@ -32,11 +32,11 @@ static float run2(const GemmArgs& a, int reps) {
   const int tiles = ((a.M + Cfg::kBM - 1) / Cfg::kBM) * ((a.N + Cfg::kBN - 1) / Cfg::kBN);
   return timeit(k_gemm2<F, WM, WN, TM, TN, BKT, PF>, tiles, Cfg::kThreads, Cfg::kLdsBytes, a, reps);
 }
-template <int F, int WM, int WN, int TM, int TN, int BKT = 32, int PF = 1, bool PLA = false, bool PLW = false, bool LATE = false, int ABL = 0>
+template <int F, int WM, int WN, int TM, int TN, int BKT = 32, int PF = 1, bool PLA = false, bool PLW = false, bool LATE = false, int ABL = 0, int NPL = 3>
 static float run3(const GemmArgs& a, int reps) {
-  using Cfg = TileCfg3<WM, WN, TM, TN, BKT>;
+  using Cfg = TileCfg3<WM, WN, TM, TN, BKT, NPL>;
   const int tiles = ((a.M + Cfg::kBM - 1) / Cfg::kBM) * ((a.N + Cfg::kBN - 1) / Cfg::kBN);
-  return timeit(k_gemm3<F, WM, WN, TM, TN, BKT, PF, PLA, PLW, LATE, ABL>, tiles, Cfg::kThreads, Cfg::kLdsBytes, a, reps);
+  return timeit(k_gemm3<F, WM, WN, TM, TN, BKT, PF, PLA, PLW, LATE, ABL, false, NPL>, tiles, Cfg::kThreads, Cfg::kLdsBytes, a, reps);
 }
 
 template <int F, int BKT, int PF>
@@ -111,7 +111,61 @@ int main(int argc, char** argv) {
       const float t3 = run3<0, 4, 2, 1, 2, 16, 2, false, false, false, 3>(a, 20);
       printf("%s full %.1f us | MFMA + operand reads + barrier only %.1f | staging only (load, split, LDS store, barrier) %.1f | full without split arithmetic %.1f\n",
              sh.name, t0 * 1e3, t1 * 1e3, t2 * 1e3, t3 * 1e3);
+      const float h0 = run3<0, 4, 2, 1, 2, 16, 2, false, false, false, 0, 2>(a, 20);
+      const float h1 = run3<0, 4, 2, 1, 2, 16, 2, false, false, false, 1, 2>(a, 20);
+      const float h2 = run3<0, 4, 2, 1, 2, 16, 2, false, false, false, 2, 2>(a, 20);
+      printf("%s f16x3: full %.1f us | MFMA + operand reads + barrier only %.1f | staging only %.1f\n", sh.name, h0 * 1e3, h1 * 1e3, h2 * 1e3);
+      const float g0 = run3<0, 4, 2, 1, 2, 32, 1, false, false, false, 0, 2>(a, 20);
+      const float g1 = run3<0, 4, 2, 1, 2, 32, 1, false, false, false, 1, 2>(a, 20);
+      const float g2 = run3<0, 4, 2, 1, 2, 32, 1, false, false, false, 2, 2>(a, 20);
+      printf("%s f16x3 bk32 pf1: full %.1f us | MFMA + operand reads + barrier only %.1f | staging only %.1f\n", sh.name, g0 * 1e3, g1 * 1e3, g2 * 1e3);
     }
+    return 0;
+  }
+  if (argc > 2 && argv[2][0] == 'h') {   // two-piece f16 x 3 form against the bf16 x 6 form and the exact-f32 kernel: time and error vs float64
+    unsigned* ev; hipMalloc(&ev, 4); hipMemset(ev, 0, 4);
+    for (const Shape& sh : shapes) {
+      const double gf = 2.0 * sh.M * sh.N * sh.K;
+      GemmArgs a{A, sh.K, W, sh.K, bias, C, sh.N, sh.M, sh.N, sh.K, sh.flags, rd, C2, sh.N};
+      a.range_events = ev;
+      auto err = [&]() {
+        std::vector<float> h((size_t)sh.M * sh.N);
+        hipMemcpy(h.data(), C, h.size() * 4, hipMemcpyDeviceToHost);
+        double worst = 0, sum = 0;
+        unsigned s = 777;
+        for (int q = 0; q < 4000; q++) {
+          s = s * 1664525u + 1013904223u; const int m = (s >> 4) % sh.M;
+          s = s * 1664525u + 1013904223u; const int n = (s >> 4) % sh.N;
+          double ref = hb[n], mag = fabs((double)hb[n]);
+          for (int k = 0; k < sh.K; k++) { const double p = (double)hA[(size_t)m * sh.K + k] * hW[(size_t)n * sh.K + k]; ref += p; mag += fabs(p); }
+          if (sh.flags == EPI_RELU) ref = ref > 0 ? ref : 0;
+          if (sh.flags == EPI_ROWDIV) { ref *= (double)(1.0f / hrd[m]); mag *= (double)(1.0f / hrd[m]); }
+          const double e = fabs((double)h[(size_t)m * sh.N + n] - ref) / mag;
+          if (e > worst) worst = e;
+          sum += e;
+        }
+        printf(" err max %.1e mean %.1e", worst, sum / 4000);
+      };
+      printf("%s M %6d N %4d K %3d\n", sh.name, sh.M, sh.N, sh.K);
+#define RUNH(F)                                                                                                              \
+      { float ms;                                                                                                            \
+        ms = run2<F, 4, 2, 1, 2, 32, 2>(a, reps); printf("   exact f32 mfma    %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
+        ms = run3<F, 4, 2, 1, 2, 16, 2>(a, reps); printf("   bf16x6 bk16 pf2   %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
+        ms = run3<F, 4, 2, 1, 2, 16, 2, false, false, false, 0, 2>(a, reps); printf("   f16x3  bk16 pf2   %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
+        ms = run3<F, 4, 2, 1, 2, 16, 1, false, false, false, 0, 2>(a, reps); printf("   f16x3  bk16 pf1   %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
+        ms = run3<F, 4, 2, 1, 2, 32, 1, false, false, false, 0, 2>(a, reps); printf("   f16x3  bk32 pf1   %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
+        ms = run3<F, 4, 2, 1, 2, 32, 2, false, false, false, 0, 2>(a, reps); printf("   f16x3  bk32 pf2   %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
+        ms = run3<F, 2, 2, 2, 2, 16, 2, false, false, false, 0, 2>(a, reps); printf("   f16x3  4w 64x64 bk16 pf2 %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
+        ms = run3<F, 2, 2, 2, 2, 32, 1, false, false, false, 0, 2>(a, reps); printf("   f16x3  4w 64x64 bk32 pf1 %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); }
+      switch (sh.flags) {
+        case 0: RUNH(0); break;
+        case EPI_RELU: RUNH(EPI_RELU); break;
+        case EPI_ROWDIV: RUNH(EPI_ROWDIV); break;
+        case EPI_ACC2: RUNH(EPI_ACC2); break;
+      }
+    }
+    unsigned hev = 0; hipMemcpy(&hev, ev, 4, hipMemcpyDeviceToHost);
+    printf("range events (threads that clamped): %u\n", hev);
     return 0;
   }
   if (argc > 2) {   // profiling mode: one configuration on the linear4 shape, a handful of launches
