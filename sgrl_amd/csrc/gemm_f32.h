@@ -40,6 +40,7 @@ struct GemmArgs {
   float* ln_io = nullptr; int ln_ld = 0;          // EPI_LN: residual stream (read and rewritten), row stride
   const float* ln_w = nullptr; const float* ln_b = nullptr;
   float* rowdiv_out = nullptr;   // GRAM: receives ||Z'Z||_F + 1 per row (from the blocks of the first column tile)
+  int phase_sleep = 0;                // k_gemm3: blocks of odd dispatch rounds start this many x 64 clocks late (see the kernel)
   unsigned* range_events = nullptr;   // two-piece f16 kernel: incremented by every thread that had to clamp an operand (see split2h)
 };
 
@@ -240,11 +241,31 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 constexpr float kF16Lim = 65000.f;
 constexpr float kF16LowScale = 2048.f;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2h(float x0, float x1, unsigned& h, unsigned& l) {
-  const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-  const _Float16 l0 = (_Float16)((x0 - (float)h0) * kF16LowScale), l1 = (_Float16)((x1 - (float)h1) * kF16LowScale);
-  h = __builtin_bit_cast(unsigned, f16x2{h0, h1});
-  l = __builtin_bit_cast(unsigned, f16x2{l0, l1});
+  const f16x2 hv = __builtin_convertvector(f32x2{x0, x1}, f16x2);                        // one v_cvt_pk_f16_f32 (round to nearest)
+  const float r0 = __builtin_fmaf((float)hv[0], -1.0f, x0), r1 = __builtin_fmaf((float)hv[1], -1.0f, x1);   // exact
+  const f16x2 lv = __builtin_convertvector(f32x2{r0 * kF16LowScale, r1 * kF16LowScale}, f16x2);
+  h = __builtin_bit_cast(unsigned, hv);
+  l = __builtin_bit_cast(unsigned, lv);
+}
+
+// An operand of the two-piece form may arrive PRE-SPLIT ("words"): one 32-bit word per element, h in the low half, l' in the
+// high half -- the same four bytes as the f32 it stands for, written ONCE by the kernel that produces the value (a GEMM
+// epilogue, the attention / equivariant kernels, the weight packer) instead of being split again by every column tile of every
+// consumer.  On gfx950 VALU instructions do not issue under matrix instructions (tools/micro/mfma_valu_overlap.hip: the times
+// add), so the ~22 VALU operations per four elements of an in-loop split cost matrix time; a word operand costs four byte
+// permutes per four elements.
+__device__ __forceinline__ unsigned enc_word(float x, float& rmax) {
+  rmax = fmaxf(rmax, fabsf(x));
+  const float c = __builtin_amdgcn_fmed3f(x, -kF16Lim, kF16Lim);
+  const _Float16 h = (_Float16)c;
+  const _Float16 l = (_Float16)((c - (float)h) * kF16LowScale);
+  return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+}
+__device__ __forceinline__ float dec_word(unsigned w) {
+  const _Float16 h = __builtin_bit_cast(_Float16, (unsigned short)(w & 0xFFFFu)), l = __builtin_bit_cast(_Float16, (unsigned short)(w >> 16));
+  return (float)h + (float)l * (1.f / kF16LowScale);
 }
 
 template <int WM, int WN, int TM, int TN, int BKT = 32, int NPL = 3>
@@ -271,7 +292,14 @@ struct TileCfg3 {
 // a staging thread reads 3 + 12 floats of its row's Z (L2-resident: 384 bytes per row) per k-tile and forms 4 entries.
 constexpr int kGramK = 576;
 // NPL = 3: bf16 x 6 (exact three-way split, f32's exponent range); NPL = 2: f16 x 3 (two-piece split above)
-template <int FLAGS, int WM, int WN, int TM, int TN, int BKT = 32, int PF = 1, bool PLA = false, bool PLW = false, bool LATE = false, int ABL = 0, bool GRAM = false, int NPL = 3>
+// SKEW: the upper half of a block's waves runs every k-tile in the LATE order (matrix instructions of tile kt first, then the
+// split + LDS store of tile kt + 1), the lower half in the early order.  Waves w and w + 4 of a block share a SIMD, and the
+// barrier keeps all waves of a block in lockstep: without the skew both waves of a SIMD (and, started together, those of the
+// co-resident block) sit in their VALU phase at the same time and in their matrix phase at the same time -- the phases ADD
+// (tools/gemm_lab.hip a: full = matrix part + staging part).  With it one wave's split arithmetic runs under the other's matrix
+// instructions by construction.  Both orders keep the same invariant at the barrier (LDS stage kt & 1 = tile kt, register
+// slots = tiles kt + 1, kt + 2).
+template <int FLAGS, int WM, int WN, int TM, int TN, int BKT = 32, int PF = 1, bool PLA = false, bool PLW = false, bool LATE = false, int ABL = 0, bool GRAM = false, int NPL = 3, bool SKEW = false, int WORDS = 0>
 __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4))) void k_gemm3(GemmArgs a) {
   using Cfg = TileCfg3<WM, WN, TM, TN, BKT, NPL>;
   static_assert(NPL == 3 || (NPL == 2 && !PLA && !PLW && ABL != 3), "two-piece form: f32 operands only");
@@ -284,14 +312,20 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
     if (NPL == 2) { const float v = hi + co * kCorW; return GRAM ? v * kPost : v; }
     return hi + co;
   };
-  int clamped = 0;
+  static_assert(!SKEW || (!LATE && ABL == 0 && WM * WN == 8), "the skew assumes eight waves (w and w + 4 on one SIMD)");
+  // WORDS: bit 0 = A arrives as words (enc_word), bit 1 = W arrives as words, bit 2 = the plain epilogue (and EPI_LN's copy of
+  // its output for the following products) WRITES words
+  static_assert(WORDS == 0 || NPL == 2, "pre-split words belong to the two-piece form");
+  static_assert(!(WORDS & 1) || !GRAM, "the Gram operand is generated, not loaded");
+  constexpr bool AWD = (WORDS & 1) != 0, WWD = (WORDS & 2) != 0, CWD = (WORDS & 4) != 0;
+  float rmax = 0.f;                           // largest operand magnitude this thread has staged (two-piece form)
   constexpr int T = Cfg::kThreads, BMT = Cfg::kBM, BNT = Cfg::kBN, RB = Cfg::kRowBytes;
   constexpr int QPR = BKT / 4;                // float4 per tile row
   constexpr int RPP = T / QPR;                // tile rows covered per staging pass
   static_assert(PF == 1 || PF == 2, "prefetch depth 1 or 2");
   constexpr int NPA = (BMT + RPP - 1) / RPP, NPW = (BNT + RPP - 1) / RPP;    // a pass may be partly idle (more threads than float4s)
   constexpr int KS = BKT / 16;                // MFMA k-steps per LDS tile
-  static_assert(!GRAM || (BKT == 16 && RPP == BMT && !PLA && !LATE), "the Gram operand needs one 16-wide k-tile per block pair and one staging pass");
+  static_assert(!GRAM || (BKT == 16 && RPP == BMT && !PLA), "the Gram operand needs one 16-wide k-tile per block pair and one staging pass");
   extern __shared__ float gemm_lds[];
   char* lds = reinterpret_cast<char*>(gemm_lds);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -375,15 +409,21 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
     *reinterpret_cast<uint2*>(p + plane_stride) = v[1];
     *reinterpret_cast<uint2*>(p + 2 * plane_stride) = v[2];
   };
+  // four pre-split words -> 8 bytes of h and 8 bytes of l' (two byte permutes each)
+  auto put_words = [&](char* plane0, int plane_stride, int row, const float4& v) {
+    const unsigned w0 = __float_as_uint(v.x), w1 = __float_as_uint(v.y), w2 = __float_as_uint(v.z), w3 = __float_as_uint(v.w);
+    char* p = plane0 + row * RB + 8 * kq;
+    *reinterpret_cast<uint2*>(p) = make_uint2(__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u));
+    *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u));
+  };
   // split a float4 into its three bf16 planes and store 8 bytes into each
   auto put = [&](char* plane0, int plane_stride, int row, const float4& vin) {
     if (NPL == 2) {
-      float4 v = vin;
-      if (fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) > kF16Lim) {      // rare: see split2h
-        v.x = __builtin_amdgcn_fmed3f(v.x, -kF16Lim, kF16Lim); v.y = __builtin_amdgcn_fmed3f(v.y, -kF16Lim, kF16Lim);
-        v.z = __builtin_amdgcn_fmed3f(v.z, -kF16Lim, kF16Lim); v.w = __builtin_amdgcn_fmed3f(v.w, -kF16Lim, kF16Lim);
-        clamped = 1;
-      }
+      float4 v;                               // branch-free: always clamped, the running maximum tells at the end whether it bit
+      rmax = fmaxf(fmaxf(rmax, fabsf(vin.x)), fabsf(vin.y));
+      rmax = fmaxf(fmaxf(rmax, fabsf(vin.z)), fabsf(vin.w));
+      v.x = __builtin_amdgcn_fmed3f(vin.x, -kF16Lim, kF16Lim); v.y = __builtin_amdgcn_fmed3f(vin.y, -kF16Lim, kF16Lim);
+      v.z = __builtin_amdgcn_fmed3f(vin.z, -kF16Lim, kF16Lim); v.w = __builtin_amdgcn_fmed3f(vin.w, -kF16Lim, kF16Lim);
       unsigned h0, l0, h1, l1;
       split2h(v.x, v.y, h0, l0); split2h(v.z, v.w, h1, l1);
       char* p = plane0 + row * RB + 8 * kq;
@@ -408,7 +448,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
     char* base = lds + st * Cfg::kStageBytes;
 #pragma unroll
     for (int i = 0; i < NPA; i++)
-      if (r0 + RPP * i < BMT) {
+      if (BMT % RPP == 0 || r0 + RPP * i < BMT) {
         if (GRAM) {
           const float za0 = gza[0], za1 = gza[1], za2 = gza[2];
           const float4 b0 = gzb[0], b1 = gzb[1], b2 = gzb[2];
@@ -416,16 +456,23 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
                                         za0 * b0.z + za1 * b1.z + za2 * b2.z, za0 * b0.w + za1 * b1.w + za2 * b2.w);
           put(base, Cfg::kPlaneA, r0, gv);
         } else if (PLA) put_planes(base, Cfg::kPlaneA, r0 + RPP * i, pa[slot][PLA ? i : 0]);
+        else if (AWD) put_words(base, Cfg::kPlaneA, r0 + RPP * i, ra[slot][i]);
         else put(base, Cfg::kPlaneA, r0 + RPP * i, ra[slot][i]);
       }
 #pragma unroll
     for (int i = 0; i < NPW; i++)
-      if (r0 + RPP * i < BNT) {
+      if (BNT % RPP == 0 || r0 + RPP * i < BNT) {
         if (PLW) put_planes(base + NPL * Cfg::kPlaneA, Cfg::kPlaneW, r0 + RPP * i, pw[slot][PLW ? i : 0]);
+        else if (WWD) put_words(base + NPL * Cfg::kPlaneA, Cfg::kPlaneW, r0 + RPP * i, rw[slot][i]);
         else put(base + NPL * Cfg::kPlaneA, Cfg::kPlaneW, r0 + RPP * i, rw[slot][i]);
       }
   };
   const int nk = a.K / BKT;
+  // The two blocks a CU holds start together and run the same instruction sequence at the same pace: their load, LDS and
+  // matrix phases coincide and each unit idles while the others work.  Blocks of the second half of a dispatch round (the
+  // second block of each CU: 8 XCDs x 32 CUs = 256 blocks per half) start a fraction of a k-tile later.
+  if (a.phase_sleep > 0 && ((blockIdx.x >> 8) & 1))
+    for (int q = 0; q < a.phase_sleep; q++) __builtin_amdgcn_s_sleep(1);
   if (GRAM && a.rowdiv_out && tile_n == 0) {
     // fn[m] = ||Z'Z||_F + 1 = ||Z Z'||_F + 1: six 32-term dot products of the row's three vectors, a quarter (eight columns)
     // per staging thread of the row, folded over the four adjacent lanes; written by the first column tile only
@@ -460,9 +507,10 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
   const int li = lane & 31, lh = lane >> 5;
   const int aoff = (wm * 32 * TM + li) * RB + 16 * lh;        // this lane's 8 bf16 of k-step 0; k-step 1 is 32 bytes on
   const int boff = NPL * Cfg::kPlaneA + (wn * 32 * TN + li) * RB + 16 * lh;
+  const bool late = SKEW ? (wave >= 4) : LATE;                   // wave-uniform
   auto body = [&](int kt, int slot) {
     const int st = kt & 1;
-    if (!LATE && ABL != 1) {
+    if (!late && ABL != 1) {
       if (kt + 1 < nk) sstore(slot, st ^ 1);
       if (GRAM && kt + 2 < nk) gload_gram();
       if (kt + 1 + PF < nk) gload(slot, (kt + 1 + PF) * BKT);
@@ -517,8 +565,9 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
           }
         }
     }
-    if (LATE) {
+    if (late) {
       if (kt + 1 < nk) sstore(slot, st ^ 1);
+      if (GRAM && kt + 2 < nk) gload_gram();
       if (kt + 1 + PF < nk) gload(slot, (kt + 1 + PF) * BKT);
     }
     __syncthreads();
@@ -530,7 +579,8 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
     for (; kt + 1 < nk; kt += 2) { body(kt, 0); body(kt + 1, 1); }
     if (kt < nk) body(kt, 0);
   }
-  if (NPL == 2 && clamped && a.range_events) atomicAdd(a.range_events, 1u);
+  if (NPL == 2 && rmax > kF16Lim && a.range_events) atomicAdd(a.range_events, 1u);
+  float rmax2 = 0.f;                          // largest value this thread encodes in its epilogue (CWD)
   if (FLAGS & EPI_EQUIV) {
     // Equivariant epilogue.  The accumulators hold TRANSPOSED 32 x 32 tiles: lane = node (column li of the tile), registers
     // = W rows q (row (e & 3) + 8 (e >> 2) + 4 lh); one tile = mat[node][q][c] for ONE c (output columns ordered c * 32 + q).
@@ -639,9 +689,14 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
 #pragma unroll
       for (int e = 0; e < 16; e++) {
         const int m = mb + (e & 3) + 8 * (e >> 2);
-        if (m < a.M) a.ln_io[(size_t)m * a.ln_ld + n] = acc[0][tj][e] * part[e] * lw + lb;
+        if (m < a.M) {
+          const float y = acc[0][tj][e] * part[e] * lw + lb;
+          a.ln_io[(size_t)m * a.ln_ld + n] = y;
+          if (CWD) reinterpret_cast<unsigned*>(a.C)[(size_t)m * a.ldc + n] = enc_word(y, rmax2);
+        }
       }
     }
+    if (CWD && rmax2 > kF16Lim && a.range_events) atomicAdd(a.range_events, 1u);
     return;
   }
 #pragma unroll
@@ -675,11 +730,27 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
         float v = fin(acc[ti][tj][e], cor[ti][tj][e]) + bvv;
         if (FLAGS & EPI_RELU) v = fmaxf(v, 0.f);
         if (FLAGS & EPI_ROWDIV) v = v * rdiv[e];
-        a.C[(size_t)m * a.ldc + n] = v;
+        if (CWD) reinterpret_cast<unsigned*>(a.C)[(size_t)m * a.ldc + n] = enc_word(v, rmax2);
+        else a.C[(size_t)m * a.ldc + n] = v;
         if (FLAGS & EPI_ACC2) a.C2[(size_t)m * a.ldc2 + n] = old2[e] + v;
       }
     }
   }
+  if (CWD && rmax2 > kF16Lim && a.range_events) atomicAdd(a.range_events, 1u);
+}
+
+// f32 [n] -> words [n] (weights of the two-piece form: once per forward behind the packer, or once per weight upload)
+__global__ __launch_bounds__(256) void k_encode_words(const float* __restrict__ src, unsigned* __restrict__ dst, long long n, unsigned* events) {
+  float rmax = 0.f;
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      const float4 v = *reinterpret_cast<const float4*>(src + i);
+      *reinterpret_cast<uint4*>(dst + i) = make_uint4(enc_word(v.x, rmax), enc_word(v.y, rmax), enc_word(v.z, rmax), enc_word(v.w, rmax));
+    } else {
+      for (long long j = i; j < n; j++) dst[j] = enc_word(src[j], rmax);
+    }
+  }
+  if (rmax > kF16Lim && events) atomicAdd(events, 1u);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

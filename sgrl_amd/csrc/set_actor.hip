@@ -581,7 +581,7 @@ template <int F> struct GemmKernels {
   static constexpr auto kWide = k_gemm2<F, 4, 2, 1, 2, 32, 2>;
   static constexpr auto kSquare = k_gemm2<F, 4, 4, 1, 1, 32, 2>;
   static constexpr auto kSplit = sgrl_gemm::k_gemm3<F, 4, 2, 1, 2, 16, 2>;
-  static constexpr auto kSplitH = sgrl_gemm::k_gemm3<F, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2>;
+  static constexpr auto kSplitH = sgrl_gemm::k_gemm3<F, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2, true>;
   static constexpr int kSplitHLds = sgrl_gemm::TileCfg3<4, 2, 1, 2, 16, 2>::kLdsBytes;
   static constexpr int kNarrowLds = sgrl_gemm::TileCfg<4, 1, 1, 2, 16>::kLdsBytes;
   static constexpr int kWideLds = sgrl_gemm::TileCfg<4, 2, 1, 2, 32>::kLdsBytes;
@@ -614,7 +614,7 @@ template <int F> struct GemmKernels {
 // linear4 / linear2_m (N = 1024, columns ordered c * 32 + a) with the equivariant contraction in the epilogue:
 // tout[m][s][c] = sum_a zq[m][s][a] * ((A . W^T + b)[m][c * 32 + a] / rowdiv[m]); always the split-precision kernel
 constexpr auto kGemmEquiv = sgrl_gemm::k_gemm3<EPI_ROWDIV | EPI_EQUIV, 4, 2, 1, 2, 16, 2>;
-constexpr auto kGemmEquivH = sgrl_gemm::k_gemm3<EPI_ROWDIV | EPI_EQUIV, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2>;
+constexpr auto kGemmEquivH = sgrl_gemm::k_gemm3<EPI_ROWDIV | EPI_EQUIV, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2, true>;
 int launch_gemm_equiv(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, int M, int K,
                       const float* rowdiv, const float* zq, float* tout) {
   if (K % 32 != 0 || (lda & 3) || (ldw & 3)) return sfail(SGRL_ERR_ARG, "gemm_equiv: K must be a multiple of 32 and rows 16-byte aligned");
@@ -627,7 +627,7 @@ int launch_gemm_equiv(hipStream_t st, const float* A, int lda, const float* W, i
 
 // C[M,N] = relu(G(Z) . W^T + b): the Gram-operand GEMM (A generated from zc [M, 3, 32]; W [N, 576] folded); N = 128 or 256
 constexpr auto kGemmGram = sgrl_gemm::k_gemm3<EPI_RELU, 4, 2, 1, 2, 16, 2, false, false, false, 0, true>;
-constexpr auto kGemmGramH = sgrl_gemm::k_gemm3<EPI_RELU, 4, 2, 1, 2, 16, 2, false, false, false, 0, true, 2>;
+constexpr auto kGemmGramH = sgrl_gemm::k_gemm3<EPI_RELU, 4, 2, 1, 2, 16, 2, false, false, false, 0, true, 2, true>;
 int launch_gemm_gram(hipStream_t st, const float* zc, const float* W, const float* bias, float* C, int ldc, int M, int N, float* fn) {
   if (N % 128 != 0) return sfail(SGRL_ERR_ARG, "gemm_gram: N must be a multiple of 128");
   GemmArgs a{zc, 96, W, GK, bias, C, ldc, M, N, GK, EPI_RELU, nullptr, nullptr, 0};
@@ -639,7 +639,7 @@ int launch_gemm_gram(hipStream_t st, const float* zc, const float* W, const floa
 
 // ln_io[m][:] = LayerNorm(ln_io[m][:] + (A . W^T + b)[m][:] / rowdiv[m]) * ln_w + ln_b   (N = 128, residual stream in place)
 constexpr auto kGemmLn = sgrl_gemm::k_gemm3<EPI_ROWDIV | EPI_LN, 4, 2, 1, 2, 16, 2>;
-constexpr auto kGemmLnH = sgrl_gemm::k_gemm3<EPI_ROWDIV | EPI_LN, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2>;
+constexpr auto kGemmLnH = sgrl_gemm::k_gemm3<EPI_ROWDIV | EPI_LN, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2, true>;
 int launch_gemm_ln(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, int M, int K,
                    const float* rowdiv, float* ln_io, int ln_ld, const float* ln_w, const float* ln_b) {
   if (K % 32 != 0 || (lda & 3) || (ldw & 3)) return sfail(SGRL_ERR_ARG, "gemm_ln: K must be a multiple of 32 and rows 16-byte aligned");

@@ -32,11 +32,11 @@ static float run2(const GemmArgs& a, int reps) {
   const int tiles = ((a.M + Cfg::kBM - 1) / Cfg::kBM) * ((a.N + Cfg::kBN - 1) / Cfg::kBN);
   return timeit(k_gemm2<F, WM, WN, TM, TN, BKT, PF>, tiles, Cfg::kThreads, Cfg::kLdsBytes, a, reps);
 }
-template <int F, int WM, int WN, int TM, int TN, int BKT = 32, int PF = 1, bool PLA = false, bool PLW = false, bool LATE = false, int ABL = 0, int NPL = 3>
+template <int F, int WM, int WN, int TM, int TN, int BKT = 32, int PF = 1, bool PLA = false, bool PLW = false, bool LATE = false, int ABL = 0, int NPL = 3, bool SKEW = false, int WORDS = 0>
 static float run3(const GemmArgs& a, int reps) {
   using Cfg = TileCfg3<WM, WN, TM, TN, BKT, NPL>;
   const int tiles = ((a.M + Cfg::kBM - 1) / Cfg::kBM) * ((a.N + Cfg::kBN - 1) / Cfg::kBN);
-  return timeit(k_gemm3<F, WM, WN, TM, TN, BKT, PF, PLA, PLW, LATE, ABL, false, NPL>, tiles, Cfg::kThreads, Cfg::kLdsBytes, a, reps);
+  return timeit(k_gemm3<F, WM, WN, TM, TN, BKT, PF, PLA, PLW, LATE, ABL, false, NPL, SKEW, WORDS>, tiles, Cfg::kThreads, Cfg::kLdsBytes, a, reps);
 }
 
 template <int F, int BKT, int PF>
@@ -122,6 +122,20 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (argc > 2 && argv[2][0] == 's') {   // phase offset between the two blocks of a CU
+    for (int si : {0, 1, 3}) {
+      const Shape& sh = shapes[si];
+      GemmArgs a{A, sh.K, W, sh.K, bias, C, sh.N, sh.M, sh.N, sh.K, sh.flags, rd, C2, sh.N};
+      printf("%s f16x3 bk16 pf2, phase sleep (x64 clocks):", sh.name);
+      for (int ps : {0, 2, 4, 6, 8, 10, 12, 16, 20, 24, 32, 48}) {
+        a.phase_sleep = ps;
+        const float ms = si == 3 ? run3<EPI_RELU, 4, 2, 1, 2, 16, 2, false, false, false, 0, 2>(a, 20) : run3<EPI_ROWDIV, 4, 2, 1, 2, 16, 2, false, false, false, 0, 2>(a, 20);
+        printf(" %d:%.1f", ps, ms * 1e3);
+      }
+      printf(" us\n");
+    }
+    return 0;
+  }
   if (argc > 2 && argv[2][0] == 'h') {   // two-piece f16 x 3 form against the bf16 x 6 form and the exact-f32 kernel: time and error vs float64
     unsigned* ev; hipMalloc(&ev, 4); hipMemset(ev, 0, 4);
     for (const Shape& sh : shapes) {
@@ -147,6 +161,10 @@ int main(int argc, char** argv) {
         printf(" err max %.1e mean %.1e", worst, sum / 4000);
       };
       printf("%s M %6d N %4d K %3d\n", sh.name, sh.M, sh.N, sh.K);
+      hipLaunchKernelGGL(k_encode_words, dim3(2048), dim3(256), 0, 0, A, reinterpret_cast<unsigned*>(Apl), (long long)sh.M * sh.K, ev);
+      hipLaunchKernelGGL(k_encode_words, dim3(512), dim3(256), 0, 0, W, reinterpret_cast<unsigned*>(Wpl), (long long)sh.N * sh.K, ev);
+      GemmArgs aww = a; aww.W = reinterpret_cast<const float*>(Wpl);
+      GemmArgs aaw = aww; aaw.A = reinterpret_cast<const float*>(Apl);
 #define RUNH(F)                                                                                                              \
       { float ms;                                                                                                            \
         ms = run2<F, 4, 2, 1, 2, 32, 2>(a, reps); printf("   exact f32 mfma    %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
@@ -155,8 +173,12 @@ int main(int argc, char** argv) {
         ms = run3<F, 4, 2, 1, 2, 16, 1, false, false, false, 0, 2>(a, reps); printf("   f16x3  bk16 pf1   %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
         ms = run3<F, 4, 2, 1, 2, 32, 1, false, false, false, 0, 2>(a, reps); printf("   f16x3  bk32 pf1   %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
         ms = run3<F, 4, 2, 1, 2, 32, 2, false, false, false, 0, 2>(a, reps); printf("   f16x3  bk32 pf2   %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
-        ms = run3<F, 2, 2, 2, 2, 16, 2, false, false, false, 0, 2>(a, reps); printf("   f16x3  4w 64x64 bk16 pf2 %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
-        ms = run3<F, 2, 2, 2, 2, 32, 1, false, false, false, 0, 2>(a, reps); printf("   f16x3  4w 64x64 bk32 pf1 %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); }
+        ms = run3<F, 4, 2, 1, 2, 16, 2, false, false, false, 0, 2, false, 2>(aww, reps); printf("   f16x3  W words          %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
+        ms = run3<F, 4, 2, 1, 2, 16, 2, false, false, false, 0, 2, false, 3>(aaw, reps); printf("   f16x3  A+W words        %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
+        ms = run3<F, 4, 2, 1, 2, 16, 1, false, false, false, 0, 2, false, 3>(aaw, reps); printf("   f16x3  A+W words pf1    %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
+        ms = run3<F, 4, 2, 1, 2, 32, 1, false, false, false, 0, 2, false, 3>(aaw, reps); printf("   f16x3  A+W words bk32pf1 %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
+        ms = run3<F, 4, 2, 1, 2, 16, 2, false, false, false, 0, 2, true, 3>(aaw, reps); printf("   f16x3  A+W words SKEW   %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
+        ms = run3<F, 4, 2, 1, 2, 16, 2, false, false, false, 0, 2, false, 7>(aaw, reps); printf("   f16x3  A+W words, C words %6.1f us %5.1f TF (output not checked)\n", ms * 1e3, gf / (ms * 1e-3) / 1e12); }
       switch (sh.flags) {
         case 0: RUNH(0); break;
         case EPI_RELU: RUNH(EPI_RELU); break;
