@@ -128,7 +128,9 @@ __global__ void k_stack_proj(const float* __restrict__ Wp, const float* __restri
 constexpr int PACK_CHUNK = 4096;
 constexpr int PACK_CHUNK_MM = 256;      // matrix-product segments: one output (a dot product) per thread
 __global__ __launch_bounds__(256) void k_pack(const sgrl_pack_seg* __restrict__ segs, const int2* __restrict__ chunks,
-                                              const unsigned short* __restrict__ tri, float* w) {
+                                              const unsigned short* __restrict__ tri, float* w, unsigned* ww, unsigned* events) {
+  // ww: the same buffer as pre-split words (gemm_f32.h enc_word) -- the W operand of the two-piece tile products
+  float rmax = 0.f;
   const int2 ch = chunks[blockIdx.x];
   const sgrl_pack_seg sg = segs[ch.x];
   const float* s0 = static_cast<const float*>(sg.src0);
@@ -184,7 +186,9 @@ __global__ __launch_bounds__(256) void k_pack(const sgrl_pack_seg* __restrict__ 
       default: break;
     }
     w[sg.dst + i] = v;
+    if (ww) ww[sg.dst + i] = sgrl_gemm::enc_word(v, rmax);
   }
+  if (ww && rmax > sgrl_gemm::kF16Lim && events) atomicAdd(events, 1u);
 }
 
 // relation bias per morphology: relb[off + (h*L + i)*L + j] = rel_encoder(relation[i,j])[h]
@@ -488,6 +492,7 @@ struct sgrl_set {
   // live weights (sgrl_set_bind_params)
   bool live = false;
   float* wflat = nullptr;
+  unsigned* wwords = nullptr;  // wflat as pre-split words (two-piece products)
   int64_t wflat_floats = 0;
   sgrl_pack_seg* d_segs = nullptr;
   int2* d_chunks = nullptr;
@@ -569,19 +574,28 @@ bool gemm_use_split() {
 // Split form of the forward in flight (set by run_forward from its handle): SGRL_SET_FORM_F16X3 = two f16 pieces, three matrix
 // instructions per product block (default; operands beyond +-65 000 are clamped and counted in `events`), SGRL_SET_FORM_BF16X6 =
 // three bf16 pieces, six instructions, f32's exponent range (gemm_f32.h).  SGRL_SET_GEMM=bf16x6 makes the latter the default.
-struct GemmCtx { int form = SGRL_SET_FORM_F16X3; unsigned* events = nullptr; };
+struct GemmCtx {
+  int form = SGRL_SET_FORM_F16X3; unsigned* events = nullptr;
+  const float* w_base = nullptr; const unsigned* w_words = nullptr;   // flat weight buffer and its pre-split twin (k_pack)
+};
 thread_local GemmCtx g_gemm;
 int gemm_default_form() {
   static const int v = [] { const char* e = getenv("SGRL_SET_GEMM"); return (e && e[0] == 'b') ? SGRL_SET_FORM_BF16X6 : SGRL_SET_FORM_F16X3; }();
   return v;
 }
-GemmArgs with_events(const GemmArgs& a) { GemmArgs b = a; b.range_events = g_gemm.events; return b; }
+// arguments of a two-piece launch: the event counter, and W taken from the pre-split twin of the weight buffer
+GemmArgs with_events(const GemmArgs& a) {
+  GemmArgs b = a;
+  b.range_events = g_gemm.events;
+  b.W = reinterpret_cast<const float*>(g_gemm.w_words + (a.W - g_gemm.w_base));
+  return b;
+}
 template <int F> struct GemmKernels {
   static constexpr auto kNarrow = k_gemm2<F, 4, 1, 1, 2, 16, 1>;
   static constexpr auto kWide = k_gemm2<F, 4, 2, 1, 2, 32, 2>;
   static constexpr auto kSquare = k_gemm2<F, 4, 4, 1, 1, 32, 2>;
   static constexpr auto kSplit = sgrl_gemm::k_gemm3<F, 4, 2, 1, 2, 16, 2>;
-  static constexpr auto kSplitH = sgrl_gemm::k_gemm3<F, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2, true>;
+  static constexpr auto kSplitH = sgrl_gemm::k_gemm3<F, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2, true, 2>;
   static constexpr int kSplitHLds = sgrl_gemm::TileCfg3<4, 2, 1, 2, 16, 2>::kLdsBytes;
   static constexpr int kNarrowLds = sgrl_gemm::TileCfg<4, 1, 1, 2, 16>::kLdsBytes;
   static constexpr int kWideLds = sgrl_gemm::TileCfg<4, 2, 1, 2, 32>::kLdsBytes;
@@ -614,7 +628,7 @@ template <int F> struct GemmKernels {
 // linear4 / linear2_m (N = 1024, columns ordered c * 32 + a) with the equivariant contraction in the epilogue:
 // tout[m][s][c] = sum_a zq[m][s][a] * ((A . W^T + b)[m][c * 32 + a] / rowdiv[m]); always the split-precision kernel
 constexpr auto kGemmEquiv = sgrl_gemm::k_gemm3<EPI_ROWDIV | EPI_EQUIV, 4, 2, 1, 2, 16, 2>;
-constexpr auto kGemmEquivH = sgrl_gemm::k_gemm3<EPI_ROWDIV | EPI_EQUIV, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2, true>;
+constexpr auto kGemmEquivH = sgrl_gemm::k_gemm3<EPI_ROWDIV | EPI_EQUIV, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2, true, 2>;
 int launch_gemm_equiv(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, int M, int K,
                       const float* rowdiv, const float* zq, float* tout) {
   if (K % 32 != 0 || (lda & 3) || (ldw & 3)) return sfail(SGRL_ERR_ARG, "gemm_equiv: K must be a multiple of 32 and rows 16-byte aligned");
@@ -627,7 +641,7 @@ int launch_gemm_equiv(hipStream_t st, const float* A, int lda, const float* W, i
 
 // C[M,N] = relu(G(Z) . W^T + b): the Gram-operand GEMM (A generated from zc [M, 3, 32]; W [N, 576] folded); N = 128 or 256
 constexpr auto kGemmGram = sgrl_gemm::k_gemm3<EPI_RELU, 4, 2, 1, 2, 16, 2, false, false, false, 0, true>;
-constexpr auto kGemmGramH = sgrl_gemm::k_gemm3<EPI_RELU, 4, 2, 1, 2, 16, 2, false, false, false, 0, true, 2, true>;
+constexpr auto kGemmGramH = sgrl_gemm::k_gemm3<EPI_RELU, 4, 2, 1, 2, 16, 2, false, false, false, 0, true, 2, true, 2>;
 int launch_gemm_gram(hipStream_t st, const float* zc, const float* W, const float* bias, float* C, int ldc, int M, int N, float* fn) {
   if (N % 128 != 0) return sfail(SGRL_ERR_ARG, "gemm_gram: N must be a multiple of 128");
   GemmArgs a{zc, 96, W, GK, bias, C, ldc, M, N, GK, EPI_RELU, nullptr, nullptr, 0};
@@ -639,7 +653,7 @@ int launch_gemm_gram(hipStream_t st, const float* zc, const float* W, const floa
 
 // ln_io[m][:] = LayerNorm(ln_io[m][:] + (A . W^T + b)[m][:] / rowdiv[m]) * ln_w + ln_b   (N = 128, residual stream in place)
 constexpr auto kGemmLn = sgrl_gemm::k_gemm3<EPI_ROWDIV | EPI_LN, 4, 2, 1, 2, 16, 2>;
-constexpr auto kGemmLnH = sgrl_gemm::k_gemm3<EPI_ROWDIV | EPI_LN, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2, true>;
+constexpr auto kGemmLnH = sgrl_gemm::k_gemm3<EPI_ROWDIV | EPI_LN, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2, true, 2>;
 int launch_gemm_ln(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, int M, int K,
                    const float* rowdiv, float* ln_io, int ln_ld, const float* ln_w, const float* ln_b) {
   if (K % 32 != 0 || (lda & 3) || (ldw & 3)) return sfail(SGRL_ERR_ARG, "gemm_ln: K must be a multiple of 32 and rows 16-byte aligned");
@@ -738,12 +752,16 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   const int N = s->N, N3 = 3 * s->N;
   const int ngf = critic ? 20 : 17;
   g_gemm.form = s->gemm_form ? s->gemm_form : gemm_default_form();
+  if (!s->live || !s->wwords) g_gemm.form = SGRL_SET_FORM_BF16X6;   // the two-piece form takes W pre-split by k_pack (bound parameters)
   g_gemm.events = s->d_range_events;
+  g_gemm.w_base = s->w;
+  g_gemm.w_words = s->wwords;
   NodeTab nt{s->d_node_env, s->d_node_limb, s->d_node_mnode, s->d_trav, s->TM};
   EnvTab et{s->d_env_off, s->d_env_L, s->d_env_relb};
   (void)hipMemsetAsync(act, 0, sizeof(float) * (size_t)s->n_env * act_ld, st);
   if (s->live)           // live weights: flat buffer (and the stacked projection operands in it) rebuilt from the parameters
-    hipLaunchKernelGGL(k_pack, dim3(s->n_chunks), dim3(256), 0, st, s->d_segs, s->d_chunks, s->d_tri, s->wflat);
+    hipLaunchKernelGGL(k_pack, dim3(s->n_chunks), dim3(256), 0, st, s->d_segs, s->d_chunks, s->d_tri, s->wflat,
+                       g_gemm.form == SGRL_SET_FORM_F16X3 ? s->wwords : (unsigned*)nullptr, s->d_range_events);
   hipLaunchKernelGGL(k_relbias, dim3(s->n_morph), dim3(256), 0, st, s->d_rel, s->W(SGRL_SET_REL_W), s->W(SGRL_SET_REL_B),
                      s->d_relb, s->d_m_off, s->d_m_L, s->n_morph);
   hipLaunchKernelGGL(k_embed, dim3(N), dim3(128), 0, st, obs, obs_ld, action, action_ld, ngf, nt, s->W(SGRL_SET_GENC), s->W(SGRL_SET_ENC_W),
@@ -960,6 +978,7 @@ void sgrl_set_destroy(sgrl_set* s) {
   if (s->d_tri) (void)hipFree(s->d_tri);
   if (s->d_range_events) (void)hipFree(s->d_range_events);
   if (s->wflat) (void)hipFree(s->wflat);
+  if (s->wwords) (void)hipFree(s->wwords);
   if (s->d_segs) (void)hipFree(s->d_segs);
   if (s->d_chunks) (void)hipFree(s->d_chunks);
   if (s->side) (void)hipStreamDestroy(s->side);
@@ -1012,10 +1031,13 @@ int sgrl_set_bind_params(sgrl_set* s, const sgrl_pack_seg* segs, int n_segs, con
     if (offsets[k] < 0 || offsets[k] >= total_floats || (offsets[k] & 3)) return sfail(SGRL_ERR_ARG, "sgrl_set_bind_params: bad offset");
   // replace the previous binding (a forward may still be reading it: hipFree waits for the device)
   if (s->wflat) (void)hipFree(s->wflat);
+  if (s->wwords) (void)hipFree(s->wwords);
   if (s->d_segs) (void)hipFree(s->d_segs);
   if (s->d_chunks) (void)hipFree(s->d_chunks);
+  s->wwords = nullptr;
   s->wflat = nullptr; s->d_segs = nullptr; s->d_chunks = nullptr; s->live = false; s->have_w = false;
   if (hipMalloc(&s->wflat, sizeof(float) * total_floats) != hipSuccess ||
+      hipMalloc(&s->wwords, sizeof(unsigned) * total_floats) != hipSuccess ||
       hipMalloc(&s->d_segs, sizeof(sgrl_pack_seg) * n_segs) != hipSuccess ||
       hipMalloc(&s->d_chunks, sizeof(int2) * chunks.size()) != hipSuccess ||
       hipMemcpy(s->d_segs, segs, sizeof(sgrl_pack_seg) * n_segs, hipMemcpyHostToDevice) != hipSuccess ||
