@@ -13,7 +13,7 @@ namespace sgrl_gemm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// EPI_ZSPLIT (k_gemm2, the stacked 3-vector projections): output column n < 30 goes to C[m][n], column 32 <= n < 62 to
+// EPI_ZSPLIT (the stacked 3-vector projections): output column n < 30 goes to C[m][n], column 32 <= n < 62 to
 // C2[m][n - 32], both with row stride 32 (columns 30 / 31 of those rows hold the gravity / direction pair, written once per
 // forward by k_embed); the zero-padding columns 30, 31, 62, 63 of the stacked operand are not stored
 // EPI_LN (k_gemm3, N = 128 = one column tile): the result is not stored; it is the update of a residual stream that is layer-
@@ -730,6 +730,11 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4)
         float v = fin(acc[ti][tj][e], cor[ti][tj][e]) + bvv;
         if (FLAGS & EPI_RELU) v = fmaxf(v, 0.f);
         if (FLAGS & EPI_ROWDIV) v = v * rdiv[e];
+        if (FLAGS & EPI_ZSPLIT) {               // stacked projections: see the enum's comment
+          if (n < 30) a.C[(size_t)m * 32 + n] = v;
+          else if (n >= 32 && n < 62) a.C2[(size_t)m * 32 + (n - 32)] = v;
+          continue;
+        }
         if (CWD) reinterpret_cast<unsigned*>(a.C)[(size_t)m * a.ldc + n] = enc_word(v, rmax2);
         else a.C[(size_t)m * a.ldc + n] = v;
         if (FLAGS & EPI_ACC2) a.C2[(size_t)m * a.ldc2 + n] = old2[e] + v;

@@ -625,6 +625,10 @@ template <int F> struct GemmKernels {
   }
 };
 
+// the stacked projections (N = 32 / 64) in the two-piece form
+constexpr auto kProjH = sgrl_gemm::k_gemm3<EPI_ZSPLIT, 4, 1, 1, 2, 16, 2, false, false, false, 0, false, 2, false, 2>;
+constexpr int kProjHLds = sgrl_gemm::TileCfg3<4, 1, 1, 2, 16, 2>::kLdsBytes;
+
 // linear4 / linear2_m (N = 1024, columns ordered c * 32 + a) with the equivariant contraction in the epilogue:
 // tout[m][s][c] = sum_a zq[m][s][a] * ((A . W^T + b)[m][c * 32 + a] / rowdiv[m]); always the split-precision kernel
 constexpr auto kGemmEquiv = sgrl_gemm::k_gemm3<EPI_ROWDIV | EPI_EQUIV, 4, 2, 1, 2, 16, 2>;
@@ -811,7 +815,10 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
       return r;
     }
     GemmArgs a{X, ldx, site_w(site), K, nullptr, s->zc, ZD, N3, z2 ? 64 : 32, K, EPI_ZSPLIT, nullptr, z2, ZD};
-    GemmKernels<EPI_ZSPLIT>::launch(st, a);
+    if (g_gemm.form == SGRL_SET_FORM_F16X3 && gemm_use_split())      // 128 x 64 tiles, four waves, W pre-split
+      hipLaunchKernelGGL(kProjH, dim3(((a.M + 127) / 128) * ((a.N + 63) / 64)), dim3(256), kProjHLds, st, with_events(a));
+    else
+      GemmKernels<EPI_ZSPLIT>::launch(st, a);
     return SGRL_OK;
   };
 #define PG(...) do { rc = pg(__VA_ARGS__); if (rc != SGRL_OK) return rc; } while (0)

@@ -173,12 +173,12 @@ int main(int argc, char** argv) {
         ms = run3<F, 4, 2, 1, 2, 16, 1, false, false, false, 0, 2>(a, reps); printf("   f16x3  bk16 pf1   %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
         ms = run3<F, 4, 2, 1, 2, 32, 1, false, false, false, 0, 2>(a, reps); printf("   f16x3  bk32 pf1   %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
         ms = run3<F, 4, 2, 1, 2, 32, 2, false, false, false, 0, 2>(a, reps); printf("   f16x3  bk32 pf2   %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
-        ms = run3<F, 4, 2, 1, 2, 16, 2, false, false, false, 0, 2, false, 2>(aww, reps); printf("   f16x3  W words          %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
-        ms = run3<F, 4, 2, 1, 2, 16, 2, false, false, false, 0, 2, false, 3>(aaw, reps); printf("   f16x3  A+W words        %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
-        ms = run3<F, 4, 2, 1, 2, 16, 1, false, false, false, 0, 2, false, 3>(aaw, reps); printf("   f16x3  A+W words pf1    %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
-        ms = run3<F, 4, 2, 1, 2, 32, 1, false, false, false, 0, 2, false, 3>(aaw, reps); printf("   f16x3  A+W words bk32pf1 %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
-        ms = run3<F, 4, 2, 1, 2, 16, 2, false, false, false, 0, 2, true, 3>(aaw, reps); printf("   f16x3  A+W words SKEW   %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
-        ms = run3<F, 4, 2, 1, 2, 16, 2, false, false, false, 0, 2, false, 7>(aaw, reps); printf("   f16x3  A+W words, C words %6.1f us %5.1f TF (output not checked)\n", ms * 1e3, gf / (ms * 1e-3) / 1e12); }
+        ms = run3<F, 4, 2, 1, 2, 16, 2, false, false, false, 0, 2, true, 2>(aww, reps); printf("   f16x3  W words SKEW 128x128/8w   %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
+        ms = run3<F, 2, 2, 1, 2, 16, 2, false, false, false, 0, 2, false, 2>(aww, reps); printf("   f16x3  W words  64x128/4w        %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
+        ms = run3<F, 2, 2, 1, 2, 32, 1, false, false, false, 0, 2, false, 2>(aww, reps); printf("   f16x3  W words  64x128/4w bk32pf1 %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
+        ms = run3<F, 2, 2, 1, 2, 32, 2, false, false, false, 0, 2, false, 2>(aww, reps); printf("   f16x3  W words  64x128/4w bk32pf2 %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
+        ms = run3<F, 4, 1, 1, 2, 16, 2, false, false, false, 0, 2, false, 2>(aww, reps); printf("   f16x3  W words 128x64/4w         %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
+        ms = run3<F, 2, 4, 1, 1, 16, 2, false, false, false, 0, 2, false, 2>(aww, reps); printf("   f16x3  W words  64x128/8w(32x32) %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); }
       switch (sh.flags) {
         case 0: RUNH(0); break;
         case EPI_RELU: RUNH(EPI_RELU); break;
