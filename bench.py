@@ -271,12 +271,18 @@ def main():
                               "mfma_f32_peak_tflops": 157.3,
                               "frac_of_f32_mfma_peak_nominal": round(nodes * 10.07e6 / (ms_set * 1e-3) / 157.3e12, 4),
                               "frac_of_f32_mfma_peak_executed": round(nodes * ex / (ms_set * 1e-3) / 157.3e12, 4),
+                              "product_form": os.environ.get("SGRL_SET_GEMM", "f16x3"),
+                              "range_events": ro.actor.range_events(reset=False),
                               "note": "nominal = the reference's dense layer sizes; executed = what the kernels run with the symmetric Gram "
                                       "matrix taken over the 36 4x4 blocks of its lower triangle (K = 576 instead of 1024; the "
                                       "operand is generated inside the GEMM, never stored) and the attention output "
-                                      "projections folded into the value projections.  The GEMMs are float32-equivalent but run on the "
-                                      "bf16 matrix cores (six bf16 products per f32 product, gemm_f32.h): the f32-MFMA peak is the "
-                                      "yardstick the reference arithmetic would be priced against, not a bound of this kernel"}
+                                      "projections folded into the value projections.  The GEMMs are float32 products (f32 in, f32 out, error "
+                                      "against float64 at or below an f32 FMA chain's: tools/gemm_lab.hip h) carried by the 16-bit matrix "
+                                      "cores: every operand is cut into two f16 pieces, three matrix instructions per product block "
+                                      "(gemm_f32.h; SGRL_SET_GEMM=bf16x6 selects the three-piece bf16 form with f32's exponent range); "
+                                      "range_events = kernel threads that had to clamp an operand beyond +-65 000 during this run (0 = the "
+                                      "two-piece form was exact to its stated bound everywhere).  The f32-MFMA peak is the yardstick the "
+                                      "reference arithmetic would be priced against, not a bound of this kernel"}
         rec, cnt = env.get_records()
         extra["row_overflow_envs"] = int((cnt[:, 2] > 0).sum())
         if cpu_base is not None:

@@ -55,6 +55,7 @@ class DeviceTrainer(object):
         self.num_envs_global = env.num_envs * self.world
         self.tot_env_steps = 0
         self.rounds = 0
+        self.range_events = 0        # operands the rollout actor clamped so far (HipSetActor.check_range)
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(int(seed) * 7919 + 13)
         self.last_losses = {}
@@ -118,6 +119,10 @@ class DeviceTrainer(object):
                         self.last_losses[name] = self.agent.update(batch, it)
                     self.tot_env_steps += 1                    # the reference counts updates too (trainer.py:250)
             self.agent.models2eval()
+        # once per round (a synchronisation is affordable here): did the rollout actor's two-piece products meet an operand
+        # outside f16's range?  If so warn and use the full-range form from now on (include/sgrl_set.h)
+        if getattr(self.ro, "actor", None) is not None:
+            self.range_events += self.ro.actor.check_range()
         self.broadcast_actor()
         self.rounds += 1
         return per_morph_iter
