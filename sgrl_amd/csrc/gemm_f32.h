@@ -300,7 +300,10 @@ constexpr int kGramK = 576;
 // instructions by construction.  Both orders keep the same invariant at the barrier (LDS stage kt & 1 = tile kt, register
 // slots = tiles kt + 1, kt + 2).
 template <int FLAGS, int WM, int WN, int TM, int TN, int BKT = 32, int PF = 1, bool PLA = false, bool PLW = false, bool LATE = false, int ABL = 0, bool GRAM = false, int NPL = 3, bool SKEW = false, int WORDS = 0>
-__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4))) void k_gemm3(GemmArgs a) {
+#ifndef SGRL_GEMM_WPE
+#define SGRL_GEMM_WPE 4        // tools/gemm_lab.hip compiles variants with another register budget (-DSGRL_GEMM_WPE=6 / 8)
+#endif
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SGRL_GEMM_WPE))) void k_gemm3(GemmArgs a) {
   using Cfg = TileCfg3<WM, WN, TM, TN, BKT, NPL>;
   static_assert(NPL == 3 || (NPL == 2 && !PLA && !PLW && ABL != 3), "two-piece form: f32 operands only");
   // two-piece form: the correction accumulator holds 2^11 x its sum; the Gram operand is generated 2^-8 x its value (entries

@@ -193,8 +193,10 @@ int main(int argc, char** argv) {
   if (argc > 2) {   // profiling mode: one configuration on the linear4 shape, a handful of launches
     const Shape& sh = shapes[1];
     GemmArgs a{A, sh.K, W, sh.K, bias, C, sh.N, sh.M, sh.N, sh.K, sh.flags, rd, C2, sh.N};
-    const float ms = run3<EPI_ROWDIV, 4, 2, 1, 2, 16, 2>(a, 5);
-    printf("profile mode: l4 x6 8w(1x2) bk16 pf2: %.1f us\n", ms * 1e3);
+    hipLaunchKernelGGL(k_encode_words, dim3(512), dim3(256), 0, 0, W, reinterpret_cast<unsigned*>(Wpl), (long long)sh.N * sh.K, (unsigned*)nullptr);
+    GemmArgs aww = a; aww.W = reinterpret_cast<const float*>(Wpl);
+    const float ms = run3<EPI_ROWDIV, 4, 2, 1, 2, 16, 2, false, false, false, 0, 2, true, 2>(aww, 5);
+    printf("profile mode: l4 f16x3 W words SKEW bk16 pf2: %.1f us\n", ms * 1e3);
     return 0;
   }
   for (const Shape& sh : shapes) {
