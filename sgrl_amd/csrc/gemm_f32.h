@@ -474,8 +474,9 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
   // The two blocks a CU holds start together and run the same instruction sequence at the same pace: their load, LDS and
   // matrix phases coincide and each unit idles while the others work.  Blocks of the second half of a dispatch round (the
   // second block of each CU: 8 XCDs x 32 CUs = 256 blocks per half) start a fraction of a k-tile later.
-  if (a.phase_sleep > 0 && ((blockIdx.x >> 8) & 1))
-    for (int q = 0; q < a.phase_sleep; q++) __builtin_amdgcn_s_sleep(1);
+  // (phase_sleep bits 16..: which blocks are delayed -- 0: the second half of a 512-block round, 1: every second block of an XCD)
+  if ((a.phase_sleep & 0xFFFF) > 0 && (((a.phase_sleep >> 16) == 0 ? (blockIdx.x >> 8) : (blockIdx.x >> 3)) & 1))
+    for (int q = 0; q < (a.phase_sleep & 0xFFFF); q++) __builtin_amdgcn_s_sleep(1);
   if (GRAM && a.rowdiv_out && tile_n == 0) {
     // fn[m] = ||Z'Z||_F + 1 = ||Z Z'||_F + 1: six 32-term dot products of the row's three vectors, a quarter (eight columns)
     // per staging thread of the row, folded over the four adjacent lanes; written by the first column tile only

@@ -127,7 +127,7 @@ int main(int argc, char** argv) {
       const Shape& sh = shapes[si];
       GemmArgs a{A, sh.K, W, sh.K, bias, C, sh.N, sh.M, sh.N, sh.K, sh.flags, rd, C2, sh.N};
       printf("%s f16x3 bk16 pf2, phase sleep (x64 clocks):", sh.name);
-      for (int ps : {0, 2, 4, 6, 8, 10, 12, 16, 20, 24, 32, 48}) {
+      for (int ps : {0, 4, 8, 12, 16, 24, 32, 65536 + 4, 65536 + 8, 65536 + 12, 65536 + 16, 65536 + 24, 65536 + 32}) {
         a.phase_sleep = ps;
         const float ms = si == 3 ? run3<EPI_RELU, 4, 2, 1, 2, 16, 2, false, false, false, 0, 2>(a, 20) : run3<EPI_ROWDIV, 4, 2, 1, 2, 16, 2, false, false, false, 0, 2>(a, 20);
         printf(" %d:%.1f", ps, ms * 1e3);
