@@ -1,8 +1,10 @@
 // set_actor.hip -- SET actor forward for gfx950 (C ABI: include/sgrl_set.h).
 //
-// All per-node linear layers are batched over the nodes of every morphology (weights are shared) and run on
-// the f32-input matrix cores (v_mfma_f32_32x32x2_f32: exact f32, so results track the reference's f32 PyTorch
-// arithmetic); the per-limb 3x32 Gram invariants, the 3x32 . 32x32 equivariant updates, the per-environment
+// All per-node linear layers are batched over the nodes of every morphology (weights are shared) and run as float32
+// products on the matrix cores: batches above 2 048 nodes through the split kernels of gemm_f32.h (every operand cut into
+// two f16 pieces -- or three bf16 pieces -- whose partial products are exact in f32: float32's error against float64, so
+// results track the reference's f32 PyTorch arithmetic), smaller ones through the exact-f32 32 x 32 tile kernels of
+// train_gemm.hip; the per-limb 3x32 Gram invariants, the 3x32 . 32x32 equivariant updates, the per-environment
 // limb attention (<= 14 keys) and layer norms are wave-reduced VALU kernels.
 //
 // Node order: environments in batch order, limbs of one environment contiguous.  Buffers (float32, N = nodes):
@@ -560,9 +562,11 @@ int use_cfg(sgrl_set* s, GraphCfg* c) {
 }
 
 // Tile configurations (measured on the shapes of one forward, tools/gemm_lab.hip).  Default: the split-precision kernel
-// k_gemm3 (six bf16 MFMAs per product block, float32-equivalent result -- its error against float64 is BELOW that of the
-// exact-f32 MFMA chain, gemm_f32.h) on 128 x 128 tiles with 8 waves; the exact-f32 kernel k_gemm2 serves the narrow
-// GEMMs (N <= 64, K not a multiple of 32) and, with SGRL_SET_GEMM=f32 in the environment, everything (A/B comparisons).
+// k_gemm3 in its two-piece form (three f16 MFMAs per product block, weights pre-split by k_pack; float32 result -- its
+// error against float64 is BELOW that of the exact-f32 MFMA chain, gemm_f32.h) on 128 x 128 tiles with 8 waves, the stacked
+// projections on 128 x 64 tiles (kProjH); SGRL_SET_GEMM=bf16x6 / sgrl_set_gemm_form select the three-piece bf16 form.  The
+// exact-f32 kernel k_gemm2 serves K not a multiple of 32 and, with SGRL_SET_GEMM=f32 in the environment, everything (A/B
+// comparisons).
 //   kNarrow  f32  128 x  64 tile,  4 waves (32 x 64 each), BK 16
 //   kWide    f32  128 x 128 tile,  8 waves (32 x 64 each), BK 32, loads two k-tiles ahead (N >= 512)
 //   kSquare  f32  128 x 128 tile, 16 waves (32 x 32 each), BK 32, loads two k-tiles ahead
