@@ -29,16 +29,20 @@ def soft_update_network(source_network, target_network, tau):
     """target <- tau * source + (1 - tau) * target for every parameter (reference common/functional.py:7-10), written through
     `.data` like the reference does.  On the GPU the ~300 tensors of a network pair are updated by two multi-tensor launches
     instead of four small kernels per tensor (the per-tensor loop was 40 % of all launches of a TD3 update); per element the
-    same two products and one sum."""
+    same two products and one sum (the second product inside the addition)."""
     with torch.no_grad():
         targets = [p.data for p in target_network.parameters()]
         sources = [p.data for p in source_network.parameters()]
         if targets and targets[0].is_cuda:
             torch._foreach_mul_(targets, 1 - tau)
-            torch._foreach_add_(targets, torch._foreach_mul(sources, tau))
+            torch._foreach_add_(targets, sources, alpha=tau)
         else:
             for t, l in zip(targets, sources):
                 t.copy_(tau * l + (1 - tau) * t)
+
+
+# SGRL_FUSED_ADAM=0: the foreach chain (bit-compatible with torch.optim.Adam's multi-tensor path) instead of the fused kernel
+_FUSED_ADAM = os.environ.get("SGRL_FUSED_ADAM", "1") != "0" and hasattr(torch, "_fused_adam_")
 
 
 def adam_step(opt):
@@ -79,6 +83,15 @@ def adam_step(opt):
                 exp_avgs = [opt.state[p]["exp_avg"] for p in members]
                 exp_avg_sqs = [opt.state[p]["exp_avg_sq"] for p in members]
                 torch._foreach_add_(steps, 1)
+                if _FUSED_ADAM and members[0].is_cuda:
+                    # the whole update of the class in one multi-tensor kernel (torch's own `fused=True` Adam kernel: per-
+                    # parameter step counters are read on the device, so nothing here divides by 0-dim tensors): three launches
+                    # instead of a dozen per class.  Same formula; its float32 operation order differs from the foreach chain
+                    # below in the last bit (tests/test_td3_update.py holds both to the reference's Agent.update).
+                    torch._fused_adam_([p.data for p in members], grads, exp_avgs, exp_avg_sqs, [], steps, amsgrad=False,
+                                       lr=group["lr"], beta1=beta1, beta2=beta2, weight_decay=0.0, eps=group["eps"],
+                                       maximize=False, grad_scale=None, found_inf=None)
+                    continue
                 torch._foreach_lerp_(exp_avgs, grads, 1 - beta1)
                 torch._foreach_mul_(exp_avg_sqs, beta2)
                 torch._foreach_addcmul_(exp_avg_sqs, grads, grads, 1 - beta2)
