@@ -389,3 +389,35 @@ def test_tile_product_forms_agree_and_out_of_range_operands_are_counted(ctx):
     assert act.range_events() == 0
     out = act.forward_batch(obs).cpu().numpy()
     assert np.abs(out - outs[HipSetActor.FORM_BF16X6]).max() == 0.0
+
+
+def test_product_forms_agree_on_engine_observations_at_size(ctx):
+    """Realistic operands: 8 walker variants x 256 environments stepped by the engine under random actions (falls, resets,
+    velocity spikes included), the resulting observations through the tile kernels in both product forms -- the two-piece
+    f16 form clamps nothing (range_events == 0: its operands stay far inside +-65 000 on what the physics produces) and
+    agrees with the bf16 x 6 form well below the suite's tolerance; both are deterministic."""
+    torch, pol, graphs, keys, z = ctx
+    from sgrl_amd.rollout import Rollout
+    from sgrl_amd.set_hip import HipSetActor
+    names = sorted(n for n in graphs if "walker" in n)
+    ro = Rollout(names, 256, policy=pol, seed=5, device="cuda:0")
+    ro.reset()
+    worst = 0.0
+    for t in range(60):
+        obs, rew, done, _ = ro.step(ro.random_actions())
+        if t % 20 != 19:
+            continue
+        outs = {}
+        for form in (HipSetActor.FORM_F16X3, HipSetActor.FORM_BF16X6):
+            ro.actor.gemm_form(form)
+            a1 = ro.actor.forward_batch(obs, act_ld=ro.env.action_max_len).clone()
+            a2 = ro.actor.forward_batch(obs, act_ld=ro.env.action_max_len)
+            assert torch.equal(a1, a2), form                       # deterministic
+            assert bool(torch.isfinite(a1).all())
+            outs[form] = a1
+        worst = max(worst, float((outs[HipSetActor.FORM_F16X3] - outs[HipSetActor.FORM_BF16X6]).abs().max()))
+    ro.actor.gemm_form(0)
+    assert ro.actor.num_nodes > 2048                               # the tile kernels, not the small-batch products
+    assert ro.actor.range_events() == 0
+    assert worst < 1e-5, worst
+    print("two-piece vs three-piece products on engine observations: max |action diff| = %.2e" % worst)
