@@ -263,6 +263,7 @@ __global__ __launch_bounds__(256) void k_sgemm_bwd(BwdArgs p) {
 // backward pass itself, so the autograd functions can postpone them (train_ops.py) and the serial chain of a backward pass
 // shrinks to its input-gradient products.  first[g] = first workgroup of problem g.
 constexpr int kGroup = 12;
+constexpr int kGroupNoSplitTiles = 256;       // sgrl_linear_wgrad_group: launches with at least this many output tiles do not split
 struct GroupArgs { SArgs w[kGroup]; int first[kGroup + 1]; int gx[kGroup], gy[kGroup], nz[kGroup]; int n; };
 __global__ __launch_bounds__(256) void k_sgemm_wgroup(GroupArgs p) {
   __shared__ __attribute__((aligned(16))) float As[BKW][LDP];
@@ -681,6 +682,13 @@ int sgrl_linear_wgrad_group(int n, const sgrl_wgrad_desc* d, float* ws, void* st
     p.n = std::min(kGroup, n - i0);
     int64_t slot = 0;
     int counter = 0, blocks = 0;
+    // Contraction splits exist to give a LONE small product enough workgroups; their price is two device-scope fences per
+    // workgroup, and hundreds of workgroups fencing at once serialise (tools/diag/wgroup_probe.py: twelve 64 x 128 gradients over
+    // 2 100 rows take 73 us in one launch, 14.7 us each alone).  A launch whose products already put a workgroup on every CU
+    // without splitting runs them unsplit: its duration is then its longest contraction, not the fences.
+    int unsplit_tiles = 0;
+    for (int g = 0; g < p.n; g++) unsplit_tiles += ((d[i0 + g].N + BT - 1) / BT) * ((d[i0 + g].K + BT - 1) / BT);
+    float* const ws_eff = unsplit_tiles >= kGroupNoSplitTiles ? nullptr : ws;
     for (int g = 0; g < p.n; g++) {
       const sgrl_wgrad_desc& q = d[i0 + g];
       if (!q.dy || !q.x || !q.dw || q.M <= 0 || q.N <= 0 || q.K <= 0 || q.lddy < q.N || q.ldx < q.K || q.lddw < q.K ||
@@ -688,7 +696,7 @@ int sgrl_linear_wgrad_group(int n, const sgrl_wgrad_desc* d, float* ws, void* st
         return tfail(SGRL_ERR_ARG, "sgrl_linear_wgrad_group: bad descriptor " + std::to_string(i0 + g));
       SArgs a{q.dy, q.lddy, q.relu ? q.y : nullptr, q.ldy, q.x, q.ldx, nullptr, 0, q.rowdiv, q.dw, q.lddw, q.db, q.N, q.K, q.M,
               0, nullptr, nullptr};
-      const int rc = plan<true>(a, ws, &p.gx[g], &p.gy[g], &p.nz[g], slot, counter);
+      const int rc = plan<true>(a, ws_eff, &p.gx[g], &p.gy[g], &p.nz[g], slot, counter);
       if (rc != SGRL_OK) return rc;
       if (p.nz[g] > 1) { slot += (int64_t)p.gx[g] * p.gy[g] * p.nz[g]; counter += p.gx[g] * p.gy[g]; }
       p.w[g] = a;
