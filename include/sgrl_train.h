@@ -52,6 +52,18 @@ typedef struct sgrl_wgrad_desc {
 } sgrl_wgrad_desc;
 int sgrl_linear_wgrad_group(int n, const sgrl_wgrad_desc* d, float* ws, void* stream);
 
+/* Twin products: the same layer of the reference's two critics (SECritic.py:8-124: critic1 / critic2, two TransformerModels on one
+ * batch; agent.py:150-160 updates both from one loss) in ONE launch -- two argument sets of identical shape, the workgroup's z index
+ * picks one.  Forward: y_i = act(x_i w_i^T + b_i) / rd_i; input gradient (and the row divisor's): dx_i = g_i w_i with g_i = dy_i
+ * masked by y_i > 0 (relu) or divided by rd_i, drd_i[m] = -(dy_i[m] . y_i[m]) / rd_i[m].  The weight gradients of both go
+ * through sgrl_linear_wgrad_group.  b / rd / drd: both null or both given. */
+int sgrl_linear_forward_twin(const float* x0, const float* x1, int ldx, const float* w0, const float* w1, int ldw, const float* b0,
+                             const float* b1, const float* rd0, const float* rd1, float* y0, float* y1, int ldy, int M, int N, int K,
+                             int relu, void* stream);
+int sgrl_linear_dgrad_twin(const float* dy0, const float* dy1, int lddy, const float* y0, const float* y1, int ldyo, int relu,
+                           const float* rd0, const float* rd1, const float* w0, const float* w1, int ldw, float* dx0, float* dx1,
+                           int lddx, float* drd0, float* drd1, int M, int N, int K, void* stream);
+
 /* Gram invariants of M nodes' three 32-vectors z[M, 3, 32] (reference SEActor.py:94-98): gram[M, 1024] = vec(Z'Z),
  * fn[M] = ||Z'Z||_F + 1; and their backward: dz = Z (D + D'), D = dgram + (dfn / ||Z'Z||_F) Z'Z (dgram or dfn may be null). */
 int sgrl_gram_forward(const float* z, float* gram, float* fn, int M, void* stream);

@@ -240,6 +240,19 @@ __global__ __launch_bounds__(256) void k_sgemm(SArgs a) {
   sgemm_tile<AT, BTR, BK>(a, As, Bs, &s_last, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z);
 }
 
+// Twin launch: TWO independent products of the same shape (the layers of the twin critics, reference SECritic.py: critic1 /
+// critic2 are two TransformerModels applied to the same batch) in one grid -- blockIdx.z picks the argument set.  Half the
+// launches of a critic pass; forward and input-gradient products only (their contractions are never split).
+struct SArgs2 { SArgs a[2]; };
+template <bool BTR>
+__global__ __launch_bounds__(256) void k_sgemm_twin(SArgs2 p) {
+  __shared__ __attribute__((aligned(16))) float As[BKF][LDP];
+  __shared__ __attribute__((aligned(16))) float Bs[BKF][LDP];
+  __shared__ int s_last;
+  const SArgs a = p.a[blockIdx.z];              // uniform: scalar loads from the kernel-argument segment
+  sgemm_tile<false, BTR, BKF>(a, As, Bs, &s_last, blockIdx.x, blockIdx.y, 0, gridDim.x, gridDim.y, 1);
+}
+
 // The two products of a layer's backward pass -- input gradient and weight (+ bias) gradient -- need the same dy and nothing
 // from each other: ONE launch, the first nd workgroups take the tiles of the input gradient, the rest those of the weight
 // gradient (and its contraction splits).  Half the launches of the update's backward GEMMs, and each small product no longer
@@ -640,6 +653,44 @@ int sgrl_linear_backward(const float* dy, int lddy, const float* y, int ldyo, in
     hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64), dim3(256), 0, st, dy, lddy, mask, ldyo, db, M, N);
     { int lrc = SGRL_OK; if (!launched("k_colsum launch failed", &lrc)) return lrc; }
   }
+  return SGRL_OK;
+}
+
+int sgrl_linear_forward_twin(const float* x0, const float* x1, int ldx, const float* w0, const float* w1, int ldw, const float* b0,
+                             const float* b1, const float* rd0, const float* rd1, float* y0, float* y1, int ldy, int M, int N, int K,
+                             int relu, void* stream) {
+  if (!x0 || !x1 || !w0 || !w1 || !y0 || !y1 || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldw < K || ldy < N || (!b0) != (!b1) ||
+      (!rd0) != (!rd1))
+    return tfail(SGRL_ERR_ARG, "sgrl_linear_forward_twin: bad argument");
+  SArgs2 p;
+  p.a[0] = SArgs{x0, ldx, nullptr, 0, w0, ldw, b0, relu ? 1 : 0, rd0, y0, ldy, nullptr, M, N, K, 0, nullptr, nullptr};
+  p.a[1] = SArgs{x1, ldx, nullptr, 0, w1, ldw, b1, relu ? 1 : 0, rd1, y1, ldy, nullptr, M, N, K, 0, nullptr, nullptr};
+  int tn, tm, splits;
+  for (int i = 0; i < 2; i++) { const int rc = plan<false>(p.a[i], nullptr, &tn, &tm, &splits); if (rc != SGRL_OK) return rc; }
+  hipLaunchKernelGGL(k_sgemm_twin<false>, dim3(tn, tm, 2), dim3(256), 0, (hipStream_t)stream, p);
+  { int lrc = SGRL_OK; if (!launched("k_sgemm_twin launch failed", &lrc)) return lrc; }
+  return SGRL_OK;
+}
+
+int sgrl_linear_dgrad_twin(const float* dy0, const float* dy1, int lddy, const float* y0, const float* y1, int ldyo, int relu,
+                           const float* rd0, const float* rd1, const float* w0, const float* w1, int ldw, float* dx0, float* dx1,
+                           int lddx, float* drd0, float* drd1, int M, int N, int K, void* stream) {
+  if (!dy0 || !dy1 || !w0 || !w1 || !dx0 || !dx1 || M <= 0 || N <= 0 || K <= 0 || lddy < N || ldw < K || lddx < K ||
+      ((relu || drd0) && (!y0 || !y1 || ldyo < N)) || (!rd0) != (!rd1) || (!drd0) != (!drd1) || (drd0 && !rd0) || (relu && rd0))
+    return tfail(SGRL_ERR_ARG, "sgrl_linear_dgrad_twin: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (drd0) {
+    hipLaunchKernelGGL(k_rowdot, dim3((M + 3) / 4), dim3(256), 0, st, dy0, lddy, y0, ldyo, rd0, drd0, M, N);
+    hipLaunchKernelGGL(k_rowdot, dim3((M + 3) / 4), dim3(256), 0, st, dy1, lddy, y1, ldyo, rd1, drd1, M, N);
+    { int lrc = SGRL_OK; if (!launched("k_rowdot launch failed", &lrc)) return lrc; }
+  }
+  SArgs2 p;
+  p.a[0] = SArgs{dy0, lddy, relu ? y0 : nullptr, ldyo, w0, ldw, nullptr, 0, rd0, dx0, lddx, nullptr, M, K, N, 0, nullptr, nullptr};
+  p.a[1] = SArgs{dy1, lddy, relu ? y1 : nullptr, ldyo, w1, ldw, nullptr, 0, rd1, dx1, lddx, nullptr, M, K, N, 0, nullptr, nullptr};
+  int tn, tm, splits;
+  for (int i = 0; i < 2; i++) { const int rc = plan<false>(p.a[i], nullptr, &tn, &tm, &splits); if (rc != SGRL_OK) return rc; }
+  hipLaunchKernelGGL(k_sgemm_twin<true>, dim3(tn, tm, 2), dim3(256), 0, st, p);
+  { int lrc = SGRL_OK; if (!launched("k_sgemm_twin (input gradient) launch failed", &lrc)) return lrc; }
   return SGRL_OK;
 }
 

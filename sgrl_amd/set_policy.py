@@ -22,6 +22,10 @@ import torch.nn.functional as F
 
 from . import train_ops
 
+import os
+
+# SGRL_TWIN_CRITICS=0: the two critics one after the other, as the reference runs them (A/B comparisons)
+TWIN_CRITICS = os.environ.get("SGRL_TWIN_CRITICS", "1") != "0"
 G_NUM = 8          # 3-vectors per limb observation (reference SEActor.py:205)
 Z_DIM = 32         # invariant channel count (30 projected + gravity + direction)
 
@@ -209,6 +213,92 @@ class TransformerModel(nn.Module):
         return torch.einsum("blsk,bls->blk", g0[..., 5:8], vec)
 
 
+# ---- the twin critics in one pass ---------------------------------------------------------------------------------------
+# The reference's SECritic (SECritic.py:8-124) applies two TransformerModels of identical shape to the same batch and
+# agent.py:150-160 trains both from one loss.  Run one after the other they are two serial chains of ~250 small launches
+# each way; twin_forward walks BOTH networks at once on activations stacked along a leading axis of two: every linear layer
+# is one launch for the pair (train_ops.linear2), and the weight-free operations (Gram invariants, attention, the equivariant
+# contraction, residual adds, concatenations) simply see twice the nodes.  Same arithmetic per network as
+# TransformerModel.forward, operation by operation (tests/test_set_critic.py, tests/test_train_ops_gpu.py).
+def _lin2(l0, l1, x, relu=False, rowdiv=None, shared=False):
+    return train_ops.linear2(x, l0.weight, l1.weight, l0.bias, l1.bias, relu, rowdiv, shared)
+
+
+def _norm2(n0, n1, x):
+    return torch.stack([n0(x[0]), n1(x[1])])
+
+
+def _invariants2(x, gdir2, proj, lin1, lin2):
+    z = torch.cat([_lin2(proj[0], proj[1], x), gdir2], dim=-1)
+    gram, fn = train_ops.gram_fn(z)
+    return _lin2(lin2[0], lin2[1], _lin2(lin1[0], lin1[1], gram, relu=True)), fn
+
+
+def _attention2(a, g, ng, gdir, gdir2, bias):
+    """a = (SubequivariantAttention of network 0, of network 1); g [2,B,L,3,128], ng [2,B,L,128]; bias: None or a pair."""
+    _, B, L = ng.shape[:3]
+    hd2 = 2 * (a[0].embed_dim // a[0].num_heads)
+    inv, fn = _invariants2(g, gdir2, (a[0].g_proj, a[1].g_proj), (a[0].linear_g1, a[1].linear_g1), (a[0].linear_g2, a[1].linear_g2))
+    c = torch.cat([inv, ng], dim=-1)
+    qw = [torch.cat([m.q_proj.weight, m.k_proj.weight, m.v_proj.weight], dim=0) for m in a]
+    qb = [torch.cat([m.q_proj.bias, m.k_proj.bias, m.v_proj.bias], dim=0) for m in a]
+    qkv = train_ops.linear2(c, qw[0], qw[1], qb[0], qb[1], rowdiv=fn)
+    vg = _lin2(a[0].vg_proj, a[1].vg_proj, g)
+    scale = float(hd2) ** -0.5
+    if bias is None:            # the two networks' environments as one batch of 2 B
+        o, og = train_ops.set_attention(qkv.reshape(2 * B, L, -1), vg.reshape(2 * B, L, 3, -1),
+                                        gdir2.reshape(2 * B, L, 3, 2), None, scale)
+        o, og = o.view(2, B, L, -1), og.view(2, B, L, 3, -1)
+    else:                       # layer 0: each network has its own relation bias
+        parts = [train_ops.set_attention(qkv[i], vg[i], gdir, bias[i], scale) for i in range(2)]
+        o, og = torch.stack([parts[0][0], parts[1][0]]), torch.stack([parts[0][1], parts[1][1]])
+    return _lin2(a[0].g_out, a[1].g_out, og), _lin2(a[0].ng_out, a[1].ng_out, o)
+
+
+def _layer2(l, g, ng, gdir, gdir2, bias):
+    g1, ng1 = _attention2((l[0].self_attn, l[1].self_attn), g, ng, gdir, gdir2, bias)
+    g = g + g1
+    ng = _norm2(l[0].norm1, l[1].norm1, ng + ng1)
+    inv, fn = _invariants2(g1, gdir2, (l[0].g_proj2, l[1].g_proj2), (l[0].linear_g1, l[1].linear_g1), (l[0].linear_g2, l[1].linear_g2))
+    c = torch.cat([inv, ng], dim=-1)
+    mat = _lin2(l[0].linear4, l[1].linear4, _lin2(l[0].linear3, l[1].linear3, c, relu=True), rowdiv=fn)
+    mat = mat.view(*ng.shape[:3], Z_DIM, Z_DIM)
+    z3 = torch.cat([_lin2(l[0].g_proj3, l[1].g_proj3, g1), gdir2], dim=-1)
+    g = g + _lin2(l[0].linear5, l[1].linear5, train_ops.zmat(z3, mat))
+    ng = _norm2(l[0].norm2, l[1].norm2, ng + _lin2(l[0].linear2, l[1].linear2, _lin2(l[0].linear1, l[1].linear1, c, relu=True), rowdiv=fn))
+    return g, ng
+
+
+def twin_forward(m0, m1, x, graph, geo_grad=True):
+    """(m0(x, graph, geo_grad), m1(x, graph, geo_grad)) for two TransformerModels of identical shape with scalar output
+    (the critics), stacked: [2, B, L, 1]."""
+    assert m0.output_size == 1 and m1.output_size == 1 and m0.ninp == m1.ninp
+    B, L, _ = x.shape
+    g0 = x[..., :3 * G_NUM].reshape(B, L, G_NUM, 3).transpose(-1, -2)
+    if not geo_grad:
+        g0 = g0.detach()
+    n0 = x[..., 3 * G_NUM:]
+    gdir = g0[..., 1:3]
+    gdir2 = gdir.unsqueeze(0).expand(2, B, L, 3, 2)
+    scale = math.sqrt(m0.ninp)
+    g = _lin2(m0.g_encoder, m1.g_encoder, g0, shared=True) * scale
+    ng = _lin2(m0.encoder, m1.encoder, n0, shared=True) * scale
+    e0, e1 = m0.transformer_encoder, m1.transformer_encoder
+    pos = torch.stack([m0.pos_encoder(graph["traversals"]), m1.pos_encoder(graph["traversals"])])
+    ng = ng + pos.unsqueeze(1)
+    bias = [e.rel_encoder(graph["relation"]).permute(2, 0, 1) for e in (e0, e1)]
+    for i in range(e0.num_layers):
+        g, ng = _layer2((e0.layers[i], e1.layers[i]), g, ng, gdir, gdir2, bias if i == 0 else None)
+    if e0.norm is not None:
+        ng = _norm2(e0.norm, e1.norm, ng)
+    out_ng = torch.cat([n0.unsqueeze(0).expand(2, *n0.shape), ng], dim=-1)
+    out_g = torch.cat([g0.unsqueeze(0).expand(2, *g0.shape), g], dim=-1)
+    inv, fn = _invariants2(out_g, gdir2, (m0.gg_proj, m1.gg_proj), (m0.linear1_g, m1.linear1_g), (m0.linear2_g, m1.linear2_g))
+    hng = _lin2(m0.linear2_ng, m1.linear2_ng, _lin2(m0.linear1_ng, m1.linear1_ng, out_ng, relu=True))
+    c = torch.cat([inv, hng], dim=-1)
+    return _lin2(m0.decoder_ng, m1.decoder_ng, c, rowdiv=fn)
+
+
 class SEPolicy(nn.Module):
     """Drop-in for reference SEActor.SEPolicy (constructor signature of SEActor.py:293-305)."""
 
@@ -326,6 +416,9 @@ class SECritic(nn.Module):
             return self._hip_handles().forward_single(state, action, self.graph)
         x = self._input(state, action)
         B, gg = x.shape[0], state.requires_grad
+        if TWIN_CRITICS and x.is_cuda and torch.is_grad_enabled() and train_ops.ENABLED:     # both networks in one pass (twin_forward)
+            q = twin_forward(self.critic1, self.critic2, x, self.graph, gg)
+            return q[0].reshape(B, -1), q[1].reshape(B, -1)
         return self.critic1(x, self.graph, gg).reshape(B, -1), self.critic2(x, self.graph, gg).reshape(B, -1)
 
     def Q1(self, state, action):

@@ -30,6 +30,8 @@ def _L():
         vp, ci = ctypes.c_void_p, ctypes.c_int
         L.sgrl_linear_forward.argtypes = [vp, ci, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]
         L.sgrl_linear_backward.argtypes = [vp, ci, vp, ci, ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, vp, vp]
+        L.sgrl_linear_forward_twin.argtypes = [vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
+        L.sgrl_linear_dgrad_twin.argtypes = [vp, vp, ci, vp, vp, ci, ci, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, vp]
         L.sgrl_gram_forward.argtypes = [vp, vp, vp, ci, vp]
         L.sgrl_gram_backward.argtypes = [vp, vp, vp, vp, vp, ci, vp]
         L.sgrl_linear_wgrad_group.argtypes = [ci, vp, vp, vp]
@@ -177,6 +179,94 @@ class _LinearFn(torch.autograd.Function):
                (None if deferred else db), None, (drd.view(ctx.rd_shape) if need_rd else None)
 
 
+class _Linear2Fn(torch.autograd.Function):
+    """The same layer of two networks of identical shape in one launch (csrc/train_gemm.hip k_sgemm_twin; include/sgrl_train.h):
+    x is either ONE input both share, [..., K], or their two inputs stacked, [2, ..., K]; the result is stacked, [2, ..., N]."""
+
+    @staticmethod
+    def forward(ctx, x, w0, w1, b0, b1, relu, rowdiv, shared):
+        L = _L()
+        N, K = w0.shape
+        assert w1.shape == w0.shape and (b0 is None) == (b1 is None)
+        lead = x.shape[:-1] if shared else x.shape[1:-1]
+        xs = x.reshape(-1, K) if shared else x.reshape(2, -1, K)
+        if xs.stride(-1) != 1 or xs.stride(-2) < K or (not shared and xs.stride(0) < 0):
+            xs = xs.contiguous()
+        M = xs.shape[-2]
+        x0, x1 = (xs, xs) if shared else (xs[0], xs[1])
+        params = ((w0, b0), (w1, b1))               # the tensors autograd knows (leaf parameters, or e.g. a concatenation of some)
+        w0 = w0 if w0.is_contiguous() else w0.contiguous()
+        w1 = w1 if w1.is_contiguous() else w1.contiguous()
+        rd = None
+        if rowdiv is not None:
+            rd = rowdiv.reshape(2, -1)
+            rd = rd if rd.is_contiguous() else rd.contiguous()
+            assert rd.shape[1] == M and not relu
+        y = torch.empty((2, M, N), dtype=torch.float32, device=x.device)
+        st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        _check(L, L.sgrl_linear_forward_twin(_p(x0), _p(x1), xs.stride(-2), _p(w0), _p(w1), K, _p(b0), _p(b1),
+                                             _p(None if rd is None else rd[0]), _p(None if rd is None else rd[1]), _p(y[0]), _p(y[1]),
+                                             N, M, N, K, 1 if relu else 0, st), "sgrl_linear_forward_twin")
+        ctx.save_for_backward(xs, w0, w1, y if (relu or rd is not None) else None, rd)
+        ctx.has_bias, ctx.relu, ctx.shared = b0 is not None, bool(relu), bool(shared)
+        ctx.leaf = [((w, b) if (w.is_leaf and (b is None or b.is_leaf)) else None) for w, b in params]
+        ctx.params = params
+        ctx.x_shape = x.shape
+        ctx.rd_shape = None if rowdiv is None else rowdiv.shape
+        return y.view(2, *lead, N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _L()
+        xs, w0, w1, yo, rd = ctx.saved_tensors
+        N, K = w0.shape
+        M = xs.shape[-2]
+        dy2 = dy.reshape(2, M, N)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        need_x = ctx.needs_input_grad[0]
+        need_w = [ctx.needs_input_grad[1], ctx.needs_input_grad[2]]
+        need_b = [ctx.has_bias and ctx.needs_input_grad[3], ctx.has_bias and ctx.needs_input_grad[4]]
+        need_rd = rd is not None and ctx.needs_input_grad[6]
+        dev = dy.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        st = ctypes.c_void_p(stream)
+        dx = torch.empty((2, M, K), dtype=torch.float32, device=dev) if need_x else None
+        drd = torch.empty((2, M), dtype=torch.float32, device=dev) if need_rd else None
+        if need_x:
+            _check(L, L.sgrl_linear_dgrad_twin(_p(dy2[0]), _p(dy2[1]), N, _p(None if yo is None else yo[0]), _p(None if yo is None else yo[1]),
+                                               N, 1 if ctx.relu else 0, _p(None if rd is None else rd[0]), _p(None if rd is None else rd[1]),
+                                               _p(w0), _p(w1), K, _p(dx[0]), _p(dx[1]), K, _p(None if drd is None else drd[0]),
+                                               _p(None if drd is None else drd[1]), M, N, K, st), "sgrl_linear_dgrad_twin")
+        elif need_rd:                               # the row divisor's gradient without an input gradient: the single-network kernel twice
+            for i in range(2):
+                _check(L, L.sgrl_linear_backward(_p(dy2[i]), N, _p(yo[i]), N, 0, _p(rd[i]), _p(None), 0, _p(None), 0, _p(None), 0,
+                                                 _p(None), 0, _p(None), _p(drd[i]), M, N, K, _p(_scratch(dev)), st), "sgrl_linear_backward")
+        # weight / bias gradients: one descriptor per network -- postponed (deferred_wgrads) or issued together now
+        grads_w, grads_b, recs = [None, None], [None, None], []
+        for i, (w, b) in enumerate(ctx.params):
+            if not (need_w[i] or need_b[i]):
+                continue
+            x_i = xs if ctx.shared else xs[i]
+            dw = torch.empty((N, K), dtype=torch.float32, device=dev)
+            db = torch.empty((N,), dtype=torch.float32, device=dev) if need_b[i] else None
+            deferred = _pending is not None and ctx.leaf[i] is not None
+            rec = {"dy": dy2[i], "y": yo[i] if ctx.relu else None, "rowdiv": None if rd is None else rd[i], "x": x_i, "dw": dw, "db": db,
+                   "M": M, "N": N, "K": K, "relu": ctx.relu, "dev": dev, "stream": stream,
+                   "w_param": (w if need_w[i] else None) if deferred else None, "b_param": (b if need_b[i] else None) if deferred else None}
+            if deferred:
+                _pending.append(rec)
+            else:
+                recs.append(rec)
+                grads_w[i], grads_b[i] = (dw if need_w[i] else None), db
+        if recs:
+            flush_wgrads(recs)                      # w_param / b_param are None: nothing is stored, the gradients are returned below
+        dx_out = None
+        if need_x:
+            dx_out = (dx[0] + dx[1]).view(ctx.x_shape) if ctx.shared else dx.view(ctx.x_shape)
+        return dx_out, grads_w[0], grads_w[1], grads_b[0], grads_b[1], None, (drd.view(ctx.rd_shape) if need_rd else None), None
+
+
 class _GramFn(torch.autograd.Function):
     """z [..., 3, 32] -> (vec(Z'Z) [..., 1024], ||Z'Z||_F + 1 [..., 1])."""
 
@@ -291,6 +381,16 @@ def linear(x, weight, bias=None, relu=False, rowdiv=None):
     y = F.linear(x, weight, bias)
     y = F.relu(y) if relu else y
     return y if rowdiv is None else y / rowdiv
+
+
+def linear2(x, w0, w1, b0=None, b1=None, relu=False, rowdiv=None, shared=False):
+    """`linear` for the same layer of two networks at once: returns [2, ..., N]; x = the input both share ([..., K], shared=True) or
+    their inputs stacked ([2, ..., K]); rowdiv stacked [2, ..., 1]."""
+    if _on_device_with_grad(x, w0, w1, b0, b1, rowdiv):
+        return _Linear2Fn.apply(x, w0, w1, b0, b1, bool(relu), rowdiv, bool(shared))
+    xs = (x, x) if shared else (x[0], x[1])
+    return torch.stack([linear(xs[0], w0, b0, relu, None if rowdiv is None else rowdiv[0]),
+                        linear(xs[1], w1, b1, relu, None if rowdiv is None else rowdiv[1])])
 
 
 def gram_fn(z):

@@ -222,3 +222,55 @@ def test_zmat_matches_float64():
     assert float((t.detach().cpu().double() - tr.detach()).abs().max()) < 1e-5
     assert float((zd.grad.cpu().double() - zr.grad).abs().max()) < 1e-5
     assert float((md.grad.cpu().double() - mr.grad).abs().max()) < 1e-5
+
+
+def test_twin_critic_pass_equals_the_two_separate_passes():
+    """set_policy.twin_forward (both critics of SECritic walked at once, every linear layer one launch for the pair:
+    train_ops.linear2 / k_sgemm_twin) against the two TransformerModels run one after the other: Q values bit for bit (the
+    same product kernels on the same operands), parameter gradients to float32 rounding (the attention of layers 1, 2 and
+    the weight-free operations see the pair as one batch, so a few sums run in another order), with and without deferred
+    weight gradients, and through the geo_grad = False path of the actor loss."""
+    from oracle.formula import synth_obs
+    from sgrl_amd import graph as G, mjcf, set_policy, train_ops
+    from sgrl_amd.rollout import TRAV
+    from sgrl_amd.td3 import Agent, default_train_args
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    agent = Agent(default_train_args(), device=dev, use_hip=False)
+    for name in ("3d_walker_7_full", "3d_hopper_3_shin"):
+        m = mjcf.load_asset(name)
+        agent.change_morphology(G.getGraphDict(m.parents, TRAV, [], device=dev))
+        L = m.num_limbs
+        obs = torch.from_numpy(synth_obs(L, 100, 4).astype(np.float32)).to(dev)
+        act = torch.rand(100, 3 * L, device=dev) * 2 - 1
+        out = {}
+        for twin in (False, True):
+            for deferred in (False, True):
+                set_policy.TWIN_CRITICS = twin
+                agent.critic.zero_grad()
+                q1, q2 = agent.critic(obs, act)
+                loss = (q1 ** 2).mean() + 0.5 * (q2 ** 3).mean()
+                with train_ops.deferred_wgrads(enabled=deferred):
+                    loss.backward()
+                torch.cuda.synchronize()
+                out[(twin, deferred)] = (q1.detach().clone(), q2.detach().clone(),
+                                         {k: p.grad.detach().clone() for k, p in agent.critic.named_parameters() if p.grad is not None})
+        set_policy.TWIN_CRITICS = True
+        ref = out[(False, False)]
+        for key in ((True, False), (True, True)):
+            got = out[key]
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (name, key)
+            assert got[2].keys() == ref[2].keys() and len(ref[2]) > 100
+            for k in ref[2]:
+                a, b = ref[2][k], got[2][k]
+                assert float((a - b).abs().max()) <= 3e-6 * (float(a.abs().max()) + 1e-12) + 1e-12, (name, key, k)
+        # the critic inside the actor loss takes gradients w.r.t. the action only (geo_grad = False): twin path, d/d action
+        a_req = act.clone().requires_grad_(True)
+        grads = []
+        for twin in (False, True):
+            set_policy.TWIN_CRITICS = twin
+            q1, q2 = agent.critic(obs, a_req)
+            g, = torch.autograd.grad(q1.mean() + q2.mean(), a_req)
+            grads.append(g)
+        set_policy.TWIN_CRITICS = True
+        assert float((grads[0] - grads[1]).abs().max()) <= 3e-6 * float(grads[0].abs().max()) + 1e-12
