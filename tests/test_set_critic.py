@@ -36,3 +36,32 @@ def test_state_dict_and_forward_match_reference(golden_dir):
     q1, q2 = crit(obs, act.requires_grad_(True))
     (q1.sum() + q2.sum()).backward()
     assert act.grad is not None and float(act.grad.abs().sum()) > 0
+
+
+def test_twin_forward_walks_both_critics_exactly_like_the_two_separate_passes():
+    """set_policy.twin_forward (what SECritic.forward runs on the GPU in grad mode: both TransformerModels at once on stacked
+    activations) through its plain-PyTorch operations on the CPU: the same values as critic1(x) / critic2(x), and the same
+    gradients, for a chain and a branched morphology.  (The device kernels behind it: tests/test_train_ops_gpu.py.)"""
+    import torch
+    from sgrl_amd import graph as G, mjcf, set_policy
+    from sgrl_amd.set_policy import make_critic
+    torch.manual_seed(3)
+    crit = make_critic(device="cpu", use_hip=False)
+    for name in ("3d_hopper_3_shin", "3d_walker_7_full"):
+        m = mjcf.load_asset(name)
+        crit.change_morphology(G.getGraphDict(m.parents, ["pre", "inlcrs", "postlcrs"], [], device=torch.device("cpu")))
+        L = m.num_limbs
+        obs, act = torch.randn(6, 41 * L), torch.rand(6, 3 * L) * 2 - 1
+        crit.zero_grad()
+        q1, q2 = crit(obs, act)                       # CPU: the two networks one after the other
+        ((q1 ** 2).mean() + (q2 ** 3).mean()).backward()
+        ref = {k: p.grad.clone() for k, p in crit.named_parameters() if p.grad is not None}
+        crit.zero_grad()
+        q = set_policy.twin_forward(crit.critic1, crit.critic2, crit._input(obs, act), crit.graph, False)
+        t1, t2 = q[0].reshape(6, -1), q[1].reshape(6, -1)
+        assert torch.allclose(t1, q1, rtol=0, atol=1e-6) and torch.allclose(t2, q2, rtol=0, atol=1e-6)
+        ((t1 ** 2).mean() + (t2 ** 3).mean()).backward()
+        got = {k: p.grad for k, p in crit.named_parameters() if p.grad is not None}
+        assert got.keys() == ref.keys() and len(ref) > 100
+        for k in ref:
+            assert float((got[k] - ref[k]).abs().max()) <= 1e-5 * (float(ref[k].abs().max()) + 1e-9), (name, k)
