@@ -171,7 +171,15 @@ __global__ __launch_bounds__(256) void k_pack(const sgrl_pack_seg* __restrict__ 
         const int r = i / sg.b, c = i % sg.b;
         const float* ar = s0 + (size_t)r * sg.lda;
         float acc = 0.f;
-        for (int k = 0; k < sg.a; k++) acc += ar[k] * s1[(size_t)k * sg.ldb + c];
+        int k = 0;
+        for (; k + 8 <= sg.a; k += 8) {          // eight independent load pairs in flight (the trip count is a run-time value; 16: no faster)
+          float x[8], y[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) { x[u] = ar[k + u]; y[u] = s1[(size_t)(k + u) * sg.ldb + c]; }
+#pragma unroll
+          for (int u = 0; u < 8; u++) acc += x[u] * y[u];
+        }
+        for (; k < sg.a; k++) acc += ar[k] * s1[(size_t)k * sg.ldb + c];
         v = acc * sg.scale;
         break;
       }
