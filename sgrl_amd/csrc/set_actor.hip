@@ -62,7 +62,9 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
   return v;
 }
 
-// embed: one 128-thread block per node (thread = channel)
+// embed: one 128-thread block per kEmbedNodes nodes (thread = channel): a thread keeps its rows of the two encoder weights
+// (8 + ngf <= 28 values, gathered at a stride of ngf floats) in registers and walks the block's nodes, whose input rows are
+// staged in LDS together -- one gather of the weights per eight nodes instead of one per node (52 -> 42 us at 35 840 nodes)
 struct NodeTab {
   const int32_t* node_env;    // [N]
   const int32_t* node_limb;   // [N]
@@ -70,42 +72,64 @@ struct NodeTab {
   const int32_t* trav;        // [3][TM]
   int TM;
 };
+constexpr int kEmbedNodes = 8;
 __global__ __launch_bounds__(128) void k_embed(const float* __restrict__ obs, int obs_ld, const float* __restrict__ action,
                                                int act_ld, int ngf, NodeTab nt, const float* Wge, const float* We,
                                                const float* be, const float* e0, const float* e1, const float* e2, float* g,
-                                               float* cat, float* outg, float* outng, float* gdir, float* zc, float* z2) {
+                                               float* cat, float* outg, float* outng, float* gdir, float* zc, float* z2, int N) {
   // per-limb input row: 24 geometric values (8 three-vectors) | ngf non-geometric ones -- 17 from the observation and,
   // for the critic (ngf = 20), the limb's 3 action slots appended (reference SECritic.py:80-83)
-  __shared__ float o[44];
-  const int n = blockIdx.x, c = threadIdx.x;
-  const int env = nt.node_env[n], limb = nt.node_limb[n], mn = nt.node_mnode[n];
-  if (c < 41) o[c] = obs[(size_t)env * obs_ld + 41 * limb + c];
-  else if (c < 44) o[c] = action ? action[(size_t)env * act_ld + 3 * limb + (c - 41)] : 0.f;
+  __shared__ float os[kEmbedNodes][44];
+  const int n0 = blockIdx.x * kEmbedNodes, c = threadIdx.x;
+  for (int idx = c; idx < kEmbedNodes * 44; idx += 128) {
+    const int q = idx / 44, k = idx % 44, n = n0 + q;
+    float v = 0.f;
+    if (n < N) {
+      const int env = nt.node_env[n], limb = nt.node_limb[n];
+      if (k < 41) v = obs[(size_t)env * obs_ld + 41 * limb + k];
+      else if (action) v = action[(size_t)env * act_ld + 3 * limb + (k - 41)];
+    }
+    os[q][k] = v;
+  }
+  float wg[8], we[20];
+#pragma unroll
+  for (int j = 0; j < 8; j++) wg[j] = Wge[c * 8 + j];
+#pragma unroll
+  for (int j = 0; j < 20; j++) we[j] = j < ngf ? We[c * ngf + j] : 0.f;
+  const float bias = be[c];
   __syncthreads();
   const float sc = sqrtf(128.f);
-  for (int s = 0; s < 3; s++) {
-    float v = 0.f;
-    for (int j = 0; j < 8; j++) v += Wge[c * 8 + j] * o[3 * j + s];
-    g[((size_t)n * 3 + s) * D + c] = v * sc;
-  }
-  float v = be[c];
-  for (int j = 0; j < ngf; j++) v += We[c * ngf + j] * o[24 + j];
-  float pos;
-  if (c < 42) pos = e0[nt.trav[mn] * 42 + c];
-  else if (c < 84) pos = e1[nt.trav[nt.TM + mn] * 42 + (c - 42)];
-  else pos = e2[nt.trav[2 * nt.TM + mn] * 44 + (c - 84)];
-  cat[(size_t)n * 256 + 128 + c] = v * sc + pos;
-  if (c < 24) { const int s = c / 8, j = c % 8; outg[((size_t)n * 3 + s) * OGLD + j] = o[3 * j + s]; }
-  if (c < ngf) outng[(size_t)n * 160 + c] = o[24 + c];
-  if (c >= ngf && c < 32) outng[(size_t)n * 160 + 128 + c] = 0.f;  // cols 128 + ngf .. 159
-  // the gravity / direction pair of the node: for the attention kernel (gdir) and as columns 30 / 31 of the projected
-  // vectors zc / z2 (written here once per forward; the projection GEMMs fill columns 0..29 of those rows, EPI_ZSPLIT)
-  if (c < 6) {
-    const int s = c / 2, e = c % 2;
-    const float v = o[3 * (1 + e) + s];
-    gdir[((size_t)n * 3 + s) * 2 + e] = v;
-    zc[((size_t)n * 3 + s) * ZD + 30 + e] = v;
-    z2[((size_t)n * 3 + s) * ZD + 30 + e] = v;
+  for (int q = 0; q < kEmbedNodes; q++) {
+    const int n = n0 + q;
+    if (n >= N) break;
+    const float* o = os[q];
+    const int mn = nt.node_mnode[n];
+    for (int s = 0; s < 3; s++) {
+      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; j++) v += wg[j] * o[3 * j + s];
+      g[((size_t)n * 3 + s) * D + c] = v * sc;
+    }
+    float v = bias;
+#pragma unroll
+    for (int j = 0; j < 20; j++) if (j < ngf) v += we[j] * o[24 + j];
+    float pos;
+    if (c < 42) pos = e0[nt.trav[mn] * 42 + c];
+    else if (c < 84) pos = e1[nt.trav[nt.TM + mn] * 42 + (c - 42)];
+    else pos = e2[nt.trav[2 * nt.TM + mn] * 44 + (c - 84)];
+    cat[(size_t)n * 256 + 128 + c] = v * sc + pos;
+    if (c < 24) { const int s = c / 8, j = c % 8; outg[((size_t)n * 3 + s) * OGLD + j] = o[3 * j + s]; }
+    if (c < ngf) outng[(size_t)n * 160 + c] = o[24 + c];
+    if (c >= ngf && c < 32) outng[(size_t)n * 160 + 128 + c] = 0.f;  // cols 128 + ngf .. 159
+    // the gravity / direction pair of the node: for the attention kernel (gdir) and as columns 30 / 31 of the projected
+    // vectors zc / z2 (written here once per forward; the projection GEMMs fill columns 0..29 of those rows, EPI_ZSPLIT)
+    if (c < 6) {
+      const int s = c / 2, e = c % 2;
+      const float gv = o[3 * (1 + e) + s];
+      gdir[((size_t)n * 3 + s) * 2 + e] = gv;
+      zc[((size_t)n * 3 + s) * ZD + 30 + e] = gv;
+      z2[((size_t)n * 3 + s) * ZD + 30 + e] = gv;
+    }
   }
 }
 
@@ -780,9 +804,9 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
                        g_gemm.form == SGRL_SET_FORM_F16X3 ? s->wwords : (unsigned*)nullptr, s->d_range_events);
   hipLaunchKernelGGL(k_relbias, dim3(s->n_morph), dim3(256), 0, st, s->d_rel, s->W(SGRL_SET_REL_W), s->W(SGRL_SET_REL_B),
                      s->d_relb, s->d_m_off, s->d_m_L, s->n_morph);
-  hipLaunchKernelGGL(k_embed, dim3(N), dim3(128), 0, st, obs, obs_ld, action, action_ld, ngf, nt, s->W(SGRL_SET_GENC), s->W(SGRL_SET_ENC_W),
-                     s->W(SGRL_SET_ENC_B), s->W(SGRL_SET_EMB0), s->W(SGRL_SET_EMB1), s->W(SGRL_SET_EMB2), s->g, s->cat,
-                     s->outg, s->outng, s->gdir, s->zc, s->z2);
+  hipLaunchKernelGGL(k_embed, dim3((N + kEmbedNodes - 1) / kEmbedNodes), dim3(128), 0, st, obs, obs_ld, action, action_ld, ngf, nt,
+                     s->W(SGRL_SET_GENC), s->W(SGRL_SET_ENC_W), s->W(SGRL_SET_ENC_B), s->W(SGRL_SET_EMB0), s->W(SGRL_SET_EMB1),
+                     s->W(SGRL_SET_EMB2), s->g, s->cat, s->outg, s->outng, s->gdir, s->zc, s->z2, N);
   float* ng = s->cat + 128;
   int rc = SGRL_OK;
   const bool small = N <= (s->small_nodes >= 0 ? s->small_nodes : small_nodes());
