@@ -3,7 +3,7 @@
 # Runs the default bench, the rocprofv3 stats pass and the two --pmc passes of the same command, the GPU test suite, the config
 # sweep and the config-5 trainer bench; summarises into profiles/ ON THE BOX and copies the summaries to gpurun_out/final/ (the raw
 # traces stay on the box: gpurun_out/ is limited to 64 MiB).
-TAG=${1:-r2_v7}
+TAG=${1:-r2_v8}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/final
 RAW=/tmp/sgrl_raw
