@@ -225,7 +225,8 @@ def _lin2(l0, l1, x, relu=False, rowdiv=None, shared=False):
 
 
 def _norm2(n0, n1, x):
-    return torch.stack([n0(x[0]), n1(x[1])])
+    a, b = x.unbind(0)          # (not x[0], x[1]: each index costs a zero-filled gradient, a slice copy and an add going back)
+    return torch.stack([n0(a), n1(b)])
 
 
 def _invariants2(x, gdir2, proj, lin1, lin2):
@@ -250,7 +251,7 @@ def _attention2(a, g, ng, gdir, gdir2, bias):
                                         gdir2.reshape(2 * B, L, 3, 2), None, scale)
         o, og = o.view(2, B, L, -1), og.view(2, B, L, 3, -1)
     else:                       # layer 0: each network has its own relation bias
-        parts = [train_ops.set_attention(qkv[i], vg[i], gdir, bias[i], scale) for i in range(2)]
+        parts = [train_ops.set_attention(q_i, v_i, gdir, bias[i], scale) for i, (q_i, v_i) in enumerate(zip(qkv.unbind(0), vg.unbind(0)))]
         o, og = torch.stack([parts[0][0], parts[1][0]]), torch.stack([parts[0][1], parts[1][1]])
     return _lin2(a[0].g_out, a[1].g_out, og), _lin2(a[0].ng_out, a[1].ng_out, o)
 
@@ -417,8 +418,8 @@ class SECritic(nn.Module):
         x = self._input(state, action)
         B, gg = x.shape[0], state.requires_grad
         if TWIN_CRITICS and x.is_cuda and torch.is_grad_enabled() and train_ops.ENABLED:     # both networks in one pass (twin_forward)
-            q = twin_forward(self.critic1, self.critic2, x, self.graph, gg)
-            return q[0].reshape(B, -1), q[1].reshape(B, -1)
+            q1, q2 = twin_forward(self.critic1, self.critic2, x, self.graph, gg).unbind(0)
+            return q1.reshape(B, -1), q2.reshape(B, -1)
         return self.critic1(x, self.graph, gg).reshape(B, -1), self.critic2(x, self.graph, gg).reshape(B, -1)
 
     def Q1(self, state, action):

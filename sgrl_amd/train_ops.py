@@ -221,9 +221,10 @@ class _Linear2Fn(torch.autograd.Function):
         xs, w0, w1, yo, rd = ctx.saved_tensors
         N, K = w0.shape
         M = xs.shape[-2]
-        dy2 = dy.reshape(2, M, N)
-        if not dy2.is_contiguous():
+        dy2 = dy.reshape(2, M, N)                    # a row-strided view (the gradient of one part of a concatenation) is read as is
+        if dy2.stride(2) != 1 or dy2.stride(1) < N or dy2.stride(0) < 0:
             dy2 = dy2.contiguous()
+        lddy = dy2.stride(1)
         need_x = ctx.needs_input_grad[0]
         need_w = [ctx.needs_input_grad[1], ctx.needs_input_grad[2]]
         need_b = [ctx.has_bias and ctx.needs_input_grad[3], ctx.has_bias and ctx.needs_input_grad[4]]
@@ -234,13 +235,13 @@ class _Linear2Fn(torch.autograd.Function):
         dx = torch.empty((2, M, K), dtype=torch.float32, device=dev) if need_x else None
         drd = torch.empty((2, M), dtype=torch.float32, device=dev) if need_rd else None
         if need_x:
-            _check(L, L.sgrl_linear_dgrad_twin(_p(dy2[0]), _p(dy2[1]), N, _p(None if yo is None else yo[0]), _p(None if yo is None else yo[1]),
+            _check(L, L.sgrl_linear_dgrad_twin(_p(dy2[0]), _p(dy2[1]), lddy, _p(None if yo is None else yo[0]), _p(None if yo is None else yo[1]),
                                                N, 1 if ctx.relu else 0, _p(None if rd is None else rd[0]), _p(None if rd is None else rd[1]),
                                                _p(w0), _p(w1), K, _p(dx[0]), _p(dx[1]), K, _p(None if drd is None else drd[0]),
                                                _p(None if drd is None else drd[1]), M, N, K, st), "sgrl_linear_dgrad_twin")
         elif need_rd:                               # the row divisor's gradient without an input gradient: the single-network kernel twice
             for i in range(2):
-                _check(L, L.sgrl_linear_backward(_p(dy2[i]), N, _p(yo[i]), N, 0, _p(rd[i]), _p(None), 0, _p(None), 0, _p(None), 0,
+                _check(L, L.sgrl_linear_backward(_p(dy2[i]), lddy, _p(yo[i]), N, 0, _p(rd[i]), _p(None), 0, _p(None), 0, _p(None), 0,
                                                  _p(None), 0, _p(None), _p(drd[i]), M, N, K, _p(_scratch(dev)), st), "sgrl_linear_backward")
         # weight / bias gradients: one descriptor per network -- postponed (deferred_wgrads) or issued together now
         grads_w, grads_b, recs = [None, None], [None, None], []
