@@ -274,3 +274,50 @@ def test_twin_critic_pass_equals_the_two_separate_passes():
             grads.append(g)
         set_policy.TWIN_CRITICS = True
         assert float((grads[0] - grads[1]).abs().max()) <= 3e-6 * float(grads[0].abs().max()) + 1e-12
+
+
+@pytest.mark.parametrize("M,K,N,has_bias,relu,rowdiv,shared", [
+    (700, 256, 256, True, True, False, False), (700, 256, 1024, True, False, True, False), (13, 126, 30, False, False, False, False),
+    (2100, 128, 252, False, False, False, False), (700, 20, 128, True, False, False, True), (65, 256, 1, True, False, True, False),
+    (300, 576, 256, True, True, False, False)])
+def test_linear2_matches_float64(M, K, N, has_bias, relu, rowdiv, shared):
+    """train_ops.linear2 (the same layer of two networks in one launch: k_sgemm_twin, include/sgrl_train.h
+    sgrl_linear_forward_twin / sgrl_linear_dgrad_twin): values and every gradient against float64 PyTorch for both networks,
+    stacked and shared inputs, ReLU masks and row divisors, ragged sizes, a row-strided incoming gradient."""
+    from sgrl_amd import train_ops
+    g = torch.Generator().manual_seed(M + 5 * K + 11 * N)
+    x = torch.randn((M, K) if shared else (2, M, K), generator=g)
+    w = [torch.randn(N, K, generator=g) / np.sqrt(K) for _ in range(2)]
+    b = [torch.randn(N, generator=g) for _ in range(2)] if has_bias else [None, None]
+    rd = (torch.rand(2, M, 1, generator=g) + 0.5) if rowdiv else None
+    dy_wide = torch.randn(2, M, N + 8, generator=g)           # the gradient arrives as a slice of a wider tensor
+    xd = x.cuda().requires_grad_()
+    wd = [t.cuda().requires_grad_() for t in w]
+    bd = [t.cuda().requires_grad_() if t is not None else None for t in b]
+    rdd = rd.cuda().requires_grad_() if rowdiv else None
+    y = train_ops.linear2(xd, wd[0], wd[1], bd[0], bd[1], relu, rdd, shared)
+    assert y.shape == (2, M, N) and type(y.grad_fn).__name__.startswith("_Linear2Fn")
+    y.backward(dy_wide.cuda()[..., :N])
+    # float64 reference; the ReLU's mask is the DEVICE's (an output within float32 rounding of zero may fall on the other side
+    # in float64, which would move a gradient by a whole term without either result being wrong)
+    mask = (y.detach().cpu() > 0).double()
+    xr = x.double().requires_grad_()
+    wr = [t.double().requires_grad_() for t in w]
+    br = [t.double().requires_grad_() if t is not None else None for t in b]
+    rdr = rd.double().requires_grad_() if rowdiv else None
+    ys = []
+    for i in range(2):
+        yi = torch.nn.functional.linear(xr if shared else xr[i], wr[i], br[i])
+        yi = yi * mask[i] if relu else yi
+        ys.append(yi / rdr[i] if rowdiv else yi)
+    yr = torch.stack(ys)
+    yr.backward(dy_wide[..., :N].double())
+    tol = lambda ref: 3e-6 * (float(ref.abs().max()) + 1.0)
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) < tol(yr)
+    assert float((xd.grad.cpu().double() - xr.grad).abs().max()) < tol(xr.grad)
+    for i in range(2):
+        assert float((wd[i].grad.cpu().double() - wr[i].grad).abs().max()) < tol(wr[i].grad) * np.sqrt(M / 64 + 1), i
+        if has_bias:
+            assert float((bd[i].grad.cpu().double() - br[i].grad).abs().max()) < tol(br[i].grad) * np.sqrt(M / 64 + 1), i
+    if rowdiv:
+        assert float((rdd.grad.cpu().double() - rdr.grad).abs().max()) < tol(rdr.grad)
