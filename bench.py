@@ -264,6 +264,15 @@ def main():
                 extra["roofline_valu"] = sj.get("k_env_step")
         nodes = ro.actor.num_nodes
         ex = set_executed_flops_per_node()
+        # outside the timed region: the forward on this run's last observations in BOTH product forms (two-piece f16 = what was
+        # timed, three-piece bf16 = f32's full exponent range); the largest difference between the two action tensors
+        forms_diff = None
+        if os.environ.get("SGRL_SET_GEMM", "")[:1] not in ("b", "f"):
+            a_h = ro.actor.forward_batch(env.obs, act_ld=env.action_max_len).clone()
+            ro.actor.gemm_form(ro.actor.FORM_BF16X6)
+            a_b = ro.actor.forward_batch(env.obs, act_ld=env.action_max_len)
+            ro.actor.gemm_form(0)
+            forms_diff = float((a_h - a_b).abs().max())
         extra["set_actor"] = {"ms_per_forward": round(ms_set, 4), "us_per_env_step": round(ms_set * 1e3 / n_local, 4),
                               "nodes": nodes, "nominal_flops_per_node": 10.07e6, "executed_flops_per_node": ex,
                               "tflops_nominal": round(nodes * 10.07e6 / (ms_set * 1e-3) / 1e12, 2),
@@ -273,6 +282,7 @@ def main():
                               "frac_of_f32_mfma_peak_executed": round(nodes * ex / (ms_set * 1e-3) / 157.3e12, 4),
                               "product_form": os.environ.get("SGRL_SET_GEMM", "f16x3"),
                               "range_events": ro.actor.range_events(reset=False),
+                              "max_action_diff_between_product_forms": forms_diff,
                               "note": "nominal = the reference's dense layer sizes; executed = what the kernels run with the symmetric Gram "
                                       "matrix taken over the 36 4x4 blocks of its lower triangle (K = 576 instead of 1024; the "
                                       "operand is generated inside the GEMM, never stored) and the attention output "
