@@ -94,6 +94,19 @@ int sgrl_pack_transitions(const float* obs, int ld_obs, const float* action, int
                           const float* reward, const float* done_f32, const uint8_t* done_u8, const uint8_t* store,
                           const int64_t* morph_id, float* block, int n_env, int obs_len, int act_len, void* stream);
 
+/* The learner's side of the replay push: the kept rows of one gathered block (format above) go into the ring buffers of their
+ * morphologies -- reference common/buffer.py:75-84 `add_transition` once per stored row, one buffer per morphology
+ * (main.py:141-155), the block walked in global environment order (trainer.py:205-236) -- in ONE launch.  Row r is written to
+ * ring slot `slot[r]` of ring `morph_id(r)` (its columns cut to that ring's obs_dim / act_dim); slot[r] < 0 skips the row.  The
+ * caller computes the slots (write pointer + rank of the row among the stored rows of its morphology, modulo the capacity):
+ * sgrl_amd/rollout.py TransitionSink.ingest.  `rings` is a DEVICE array of n_rings descriptors holding device pointers. */
+typedef struct sgrl_ring {
+  float* obs; float* action; float* next_obs; float* reward; float* done;   /* [capacity][obs_dim] | [capacity][act_dim] | ... */
+  int32_t obs_dim, act_dim;
+} sgrl_ring;
+int sgrl_ingest_rows(const float* block, int n_rows, int obs_len, int act_len, const int64_t* slot, const sgrl_ring* rings,
+                     int n_rings, void* stream);
+
 const char* sgrl_last_error(void);
 const char* sgrl_version(void);
 

@@ -78,12 +78,13 @@ def lib():
     L.sgrl_time_steps.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float)]
     ci = ctypes.c_int
     L.sgrl_pack_transitions.argtypes = [vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]
+    L.sgrl_ingest_rows.argtypes = [vp, ci, ci, ci, vp, vp, ci, vp]
     _lib = L
     return L
 
 
 EXPORTS = ["sgrl_engine_create", "sgrl_engine_destroy", "sgrl_num_envs", "sgrl_record_stride", "sgrl_lds_bytes", "sgrl_launch_groups",
-           "sgrl_reset", "sgrl_step", "sgrl_get_records", "sgrl_set_records", "sgrl_refresh", "sgrl_time_steps", "sgrl_pack_transitions",
+           "sgrl_reset", "sgrl_step", "sgrl_get_records", "sgrl_set_records", "sgrl_refresh", "sgrl_time_steps", "sgrl_pack_transitions", "sgrl_ingest_rows",
            "sgrl_last_error", "sgrl_version"]
 
 

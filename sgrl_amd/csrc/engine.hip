@@ -285,6 +285,25 @@ __global__ __launch_bounds__(256) void k_pack_transitions(PackArgs p) {
   }
 }
 
+// replay ingest: one workgroup per row of the gathered block; the row's morphology picks the ring, slot[] the place in it
+__global__ __launch_bounds__(256) void k_ingest_rows(const float* __restrict__ block, int o, int a, const int64_t* __restrict__ slot,
+                                                     const sgrl_ring* __restrict__ rings, int n_rings) {
+  const size_t r = blockIdx.x;
+  const long long sl = slot[r];
+  if (sl < 0) return;
+  const int row = 2 * o + a + 4;
+  const float* b = block + r * row;
+  const int k = (int)b[2 * o + a + 3];
+  if (k < 0 || k >= n_rings) return;
+  const sgrl_ring g = rings[k];
+  for (int c = threadIdx.x; c < g.obs_dim; c += 256) {
+    g.obs[(size_t)sl * g.obs_dim + c] = b[c];
+    g.next_obs[(size_t)sl * g.obs_dim + c] = b[o + a + c];
+  }
+  for (int c = threadIdx.x; c < g.act_dim; c += 256) g.action[(size_t)sl * g.act_dim + c] = b[o + c];
+  if (threadIdx.x == 0) { g.reward[sl] = b[2 * o + a]; g.done[sl] = b[2 * o + a + 1]; }
+}
+
 extern "C" {
 
 const char* sgrl_last_error(void) { return g_err.c_str(); }
@@ -539,6 +558,16 @@ int sgrl_time_steps(sgrl_engine* e, const float* actions, float* obs, float* rew
   (void)hipEventDestroy(t1);
   HIP_TRY(hipGetLastError());
   *ms_out = ms / reps;
+  return SGRL_OK;
+}
+
+int sgrl_ingest_rows(const float* block, int n_rows, int obs_len, int act_len, const int64_t* slot, const sgrl_ring* rings,
+                     int n_rings, void* stream) {
+  if (!block || !slot || !rings || n_rows <= 0 || obs_len <= 0 || act_len <= 0 || n_rings <= 0)
+    return fail(SGRL_ERR_ARG, "sgrl_ingest_rows: bad argument");
+  hipLaunchKernelGGL(k_ingest_rows, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, block, obs_len, act_len, slot, rings, n_rings);
+  const hipError_t le = hipGetLastError();
+  if (le != hipSuccess) return fail(SGRL_ERR_HIP, std::string("k_ingest_rows launch failed (") + hipGetErrorName(le) + ")");
   return SGRL_OK;
 }
 

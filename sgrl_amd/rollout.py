@@ -3,14 +3,20 @@
 and the random-action warm-up loop trainer.py:90-138), with the same per-environment semantics but ONE engine
 launch and ONE batched SET forward per time step, plus the replay push as a single gather to the learner rank.
 """
+import ctypes
+import os
+
 import numpy as np
 import torch
 
 from . import graph as G
+from .replay import DeviceReplayBuffer
 from .set_hip import HipSetActor
 from .vec_env import BatchedModularVecEnv
 
 TRAV = ["pre", "inlcrs", "postlcrs"]
+# SGRL_FUSED_INGEST=0: the learner writes a gathered block morphology by morphology with indexed copies (the CPU path) on the GPU too
+FUSED_INGEST = os.environ.get("SGRL_FUSED_INGEST", "1") != "0"
 
 
 class Rollout(object):
@@ -306,8 +312,66 @@ class TransitionSink(object):
             finished = bool(flag.item())
         return finished
 
+    # ---- learner: one launch per gathered block (CUDA) -----------------------------------------------------------------
+    def _ring_table(self):
+        """Device array of include/sgrl.h sgrl_ring descriptors (one per morphology) + the capacities; rebuilt if a buffer's
+        storage has moved."""
+        key = tuple((b.obs_buffer.data_ptr(), b.action_buffer.data_ptr(), b.next_obs_buffer.data_ptr(), b.reward_buffer.data_ptr(),
+                     b.done_buffer.data_ptr()) for b in self.buffers)
+        if getattr(self, "_ring_key", None) != key:
+            desc = np.zeros(len(self.buffers), dtype=np.dtype([("obs", "<u8"), ("action", "<u8"), ("next_obs", "<u8"), ("reward", "<u8"),
+                                                               ("done", "<u8"), ("obs_dim", "<i4"), ("act_dim", "<i4")]))
+            assert desc.dtype.itemsize == 48
+            for k, b in enumerate(self.buffers):
+                desc[k] = key[k] + (b.obs_dim, b.action_dim)
+            self._ring_dev = torch.from_numpy(desc.view(np.uint8).copy()).to(self.device)
+            self._ring_cap = torch.tensor([b.max_buffer_size for b in self.buffers], dtype=torch.long, device=self.device)
+            self._ring_ids = torch.arange(len(self.buffers), device=self.device)
+            self._ring_key = key
+        return self._ring_dev
+
+    def _ingest_block_hip(self, blk):
+        """The rows of one block into their morphologies' rings with ONE launch (include/sgrl.h sgrl_ingest_rows) and one host
+        synchronisation (the per-morphology row counts, for the rings' host-side write pointers).  Slot of a stored row =
+        write pointer of its ring + its rank among the stored rows of its morphology in this block (row order), modulo the
+        capacity -- what add_transition row by row produces.  Returns False (nothing written) when a ring would wrap onto
+        itself inside this one block: the row-by-row path handles that."""
+        from . import _lib
+        _, _, _, _, _, store, morph = self.gather.unpack(blk)
+        rings = self._ring_table()
+        m = morph.clamp(0, len(self.buffers) - 1)
+        hit = (self._ring_ids.unsqueeze(1) == m.unsqueeze(0)) & store.unsqueeze(0)              # [morphologies, rows]
+        cs = torch.cumsum(hit, dim=1, dtype=torch.int64)                                          # scans along the contiguous axis
+        counts_dev = cs[:, -1]
+        counts = counts_dev.tolist()                                                               # the one host sync
+        if sum(counts) == 0:
+            return True
+        if any(c > b.max_buffer_size for c, b in zip(counts, self.buffers)):
+            return False
+        host_pos = tuple(b.curr for b in self.buffers)
+        if getattr(self, "_pos_host", None) != host_pos:          # first block, or the buffers were written / loaded elsewhere
+            self._pos_dev = torch.tensor(host_pos, dtype=torch.long, device=self.device)
+        rank = cs.gather(0, m.unsqueeze(0)).squeeze(0) - 1
+        slot = torch.where(store, (self._pos_dev[m] + rank) % self._ring_cap[m], rank.new_full((), -1))
+        blk = blk if blk.is_contiguous() else blk.contiguous()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().sgrl_ingest_rows(ctypes.c_void_p(blk.data_ptr()), int(blk.shape[0]), int(self.gather.o), int(self.gather.a),
+                                               ctypes.c_void_p(slot.data_ptr()), ctypes.c_void_p(rings.data_ptr()), len(self.buffers),
+                                               ctypes.c_void_p(stream)), "sgrl_ingest_rows")
+        for c, b in zip(counts, self.buffers):
+            if c:
+                b.curr = (b.curr + c) % b.max_buffer_size
+                b.max_sample_size = min(b.max_sample_size + c, b.max_buffer_size)
+        self._pos_dev = (self._pos_dev + counts_dev) % self._ring_cap      # the device copy follows without another upload
+        self._pos_host = tuple(b.curr for b in self.buffers)
+        self._stored += int(sum(counts))
+        return True
+
     def ingest(self, blocks):
+        fast = FUSED_INGEST and self.device.type == "cuda" and all(isinstance(b, DeviceReplayBuffer) for b in self.buffers)
         for blk in blocks:                                   # rank order = global environment order
+            if fast and self._ingest_block_hip(blk):
+                continue
             obs, act, nxt, rew, done, store, morph = self.gather.unpack(blk)
             rows = torch.nonzero(store, as_tuple=False).flatten()          # host sync 1 of 2 per block (row count)
             if rows.numel() == 0:

@@ -218,3 +218,58 @@ def test_graphed_update_survives_a_workspace_regrowth():
     torch.cuda.synchronize()
     assert gr.slots[0]["stamp"][0] != stamp_small[0]
     assert np.isfinite(float(out["loss/critic_loss"]))
+
+
+def test_fused_ingest_writes_exactly_what_the_row_by_row_path_writes():
+    """TransitionSink.ingest on the GPU: one launch per gathered block (include/sgrl.h sgrl_ingest_rows, slots from a prefix sum of
+    the store flags) against the morphology-by-morphology indexed copies of the CPU path -- every ring buffer bit for bit, the
+    write pointers and fill levels, over several blocks with random store flags, including a ring that wraps and a block that
+    stores nothing; a block that would wrap a ring onto itself falls back to the row-by-row path."""
+    import torch
+    from sgrl_amd import rollout
+    from sgrl_amd.replay import DeviceReplayBuffer
+    dev = torch.device("cuda:0")
+    limbs = [2, 7, 4, 5]
+    per = [40, 30, 50, 20]
+    env_morph = sum(([k] * n for k, n in enumerate(per)), [])
+    n, omax, amax = len(env_morph), 41 * 7, 3 * 7
+    caps = [1000, 64, 1000, 25]                       # ring 1 wraps after a few blocks, ring 3 is smaller than one full block of its rows... almost
+    def make():
+        bufs = [DeviceReplayBuffer(41 * L, 3 * L, max_buffer_size=c, device=dev) for L, c in zip(limbs, caps)]
+        return rollout.TransitionSink(env_morph, limbs, omax, amax, device=dev, buffers=bufs), bufs
+    g = torch.Generator().manual_seed(4)
+    blocks = []
+    for t in range(9):
+        row = torch.randn(n, 2 * omax + amax + 4, generator=g)
+        store = (torch.rand(n, generator=g) < (0.0 if t == 3 else 0.7)).float()
+        if t == 6:
+            store[:] = 1.0                            # 20 rows for ring 3 (capacity 25): fits; ring 1 gets 30 rows of 64
+        row[:, 2 * omax + amax + 2] = store
+        row[:, 2 * omax + amax + 3] = torch.tensor(env_morph, dtype=torch.float32)
+        blocks.append(row.to(dev))
+    out = {}
+    for fused in (False, True):
+        rollout.FUSED_INGEST = fused
+        sink, bufs = make()
+        for b in blocks:
+            sink.ingest([b])
+        torch.cuda.synchronize()
+        out[fused] = ([(x.obs_buffer.clone(), x.action_buffer.clone(), x.next_obs_buffer.clone(), x.reward_buffer.clone(), x.done_buffer.clone(),
+                        x.curr, x.max_sample_size) for x in bufs], sink.stored)
+    rollout.FUSED_INGEST = True
+    assert out[True][1] == out[False][1] > 0
+    for a, b in zip(out[False][0], out[True][0]):
+        assert a[5:] == b[5:]
+        for ta, tb in zip(a[:5], b[:5]):
+            assert torch.equal(ta, tb)
+    # more stored rows of one morphology than its ring holds, in ONE block: the fused path declines, the result is still the reference's
+    tiny = [DeviceReplayBuffer(41 * L, 3 * L, max_buffer_size=8, device=dev) for L in limbs]
+    ref = [DeviceReplayBuffer(41 * L, 3 * L, max_buffer_size=8, device=dev) for L in limbs]
+    s1 = rollout.TransitionSink(env_morph, limbs, omax, amax, device=dev, buffers=tiny)
+    rollout.FUSED_INGEST = False
+    s0 = rollout.TransitionSink(env_morph, limbs, omax, amax, device=dev, buffers=ref)
+    s0.ingest([blocks[6]])
+    rollout.FUSED_INGEST = True
+    s1.ingest([blocks[6]])
+    for x, y in zip(tiny, ref):
+        assert torch.equal(x.obs_buffer, y.obs_buffer) and (x.curr, x.max_sample_size) == (y.curr, y.max_sample_size)
