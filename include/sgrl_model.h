@@ -116,8 +116,18 @@ SGRL_HD int sgrl_model_view_from(sgrl_hdr_t hdr_src, sgrl_fhdr_t fhdr_src, sgrl_
   if (hdr_src[SGRL_H_MAGIC] != SGRL_MAGIC) return -1;
   v->hdr = hdr_src;
   v->fhdr = fhdr_src;
+#if defined(SGRL_FIX_DIMS_W7) && defined(__HIP_DEVICE_COMPILE__)
+  const int nb_ = hdr_src[SGRL_H_NBODY], nj_ = hdr_src[SGRL_H_NJNT], nq_ = hdr_src[SGRL_H_NQ], nv_ = hdr_src[SGRL_H_NV];
+  const int nu_ = hdr_src[SGRL_H_NU], ng_ = hdr_src[SGRL_H_NGEOM], np_ = hdr_src[SGRL_H_NPAIR];
+#else
   const int nb = hdr_src[SGRL_H_NBODY], nj = hdr_src[SGRL_H_NJNT], nq = hdr_src[SGRL_H_NQ], nv = hdr_src[SGRL_H_NV];
   const int nu = hdr_src[SGRL_H_NU], ng = hdr_src[SGRL_H_NGEOM], np = hdr_src[SGRL_H_NPAIR];
+#endif
+#if defined(SGRL_FIX_DIMS_W7) && defined(__HIP_DEVICE_COMPILE__)   /* diagnostic build only (tools/diag/variant_probe.py) */
+  const int nb = 8, nj = 19, nq = 25, nv = 24;
+  const int nu = 18, ng = 8, np = 7;
+  (void)nb_; (void)nj_; (void)nq_; (void)nv_; (void)nu_; (void)ng_; (void)np_;
+#endif
   v->nbody = nb; v->njnt = nj; v->nq = nq; v->nv = nv; v->nu = nu; v->ngeom = ng; v->npair = np;
   sgrl_itab_t p = ib + SGRL_NHDR;
   v->body_parent = p; p += nb;

@@ -130,6 +130,11 @@ int sgrl_set_forward_q(sgrl_set* s, const float* obs, int obs_ld, const float* a
 
 int sgrl_set_num_nodes(const sgrl_set* s);
 int64_t sgrl_set_workspace_bytes(const sgrl_set* s);
+/* Counter bumped whenever the handle FREES device memory that a forward recorded earlier may point into: a batch structure
+ * evicted from the content cache of sgrl_set_graph, the flat weight buffers replaced by sgrl_set_bind_params, a regrown
+ * workspace.  A hipGraph that captured forwards of this handle must be captured again once the value has changed (replaying
+ * it would dereference freed memory: a GPU fault, not an error code).  No reference counterpart (PyTorch owns its tensors). */
+int64_t sgrl_set_generation(const sgrl_set* s);
 /* Time `reps` forwards with HIP events on `stream` (mean ms per forward). */
 int sgrl_set_time_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_ld, float max_action,
                           int reps, void* stream, float* ms_out);
@@ -162,6 +167,12 @@ int sgrl_set_gemm_form(sgrl_set* s, int form);
  * mean a diverged network in the reference too).  Synchronise the forward's stream first.  A caller that sees a non-zero count
  * repeats the forward after sgrl_set_gemm_form(s, SGRL_SET_FORM_BF16X6). */
 int sgrl_set_range_events(sgrl_set* s, unsigned* count, int reset);
+/* The same counter as the forwards that have COMPLETED so far left it: the last kernel of every forward copies it into a word of
+ * pinned host memory, which this call reads -- no device synchronisation, no stream operation, safe during a graph capture.  A
+ * caller polls it after enqueueing a forward and, when it is non-zero, synchronises and handles the event (sgrl_set_range_events
+ * with reset, sgrl_set_gemm_form): how `SEPolicy` / `SECritic` users get the warning and the form switch without asking
+ * (sgrl_amd/set_hip.py HipSetActor._poll_range).  No reference counterpart: PyTorch's f32 products have f32's range. */
+unsigned sgrl_set_range_events_seen(const sgrl_set* s);
 const char* sgrl_set_last_error(void);
 
 #ifdef __cplusplus

@@ -94,6 +94,13 @@ __device__ __forceinline__ void setup(const BatchArgs& a, int env, SgrlModelView
   int32_t hdr[SGRL_NHDR];
 #pragma unroll
   for (int k = 0; k < SGRL_NHDR; k++) hdr[k] = __builtin_amdgcn_readfirstlane(md.ib[k]);
+#ifdef SGRL_FIX_DIMS_W7
+  // diagnostic build only (tools/diag/variant_probe.py): the dimensions of 3d_walker_7_full as compile-time constants, to price
+  // what a per-morphology specialisation of the kernel (layout offsets as immediates, no scalar-register spills) would buy
+  hdr[SGRL_H_NBODY] = 8; hdr[SGRL_H_NJNT] = 19; hdr[SGRL_H_NQ] = 25; hdr[SGRL_H_NV] = 24; hdr[SGRL_H_NU] = 18;
+  hdr[SGRL_H_NGEOM] = 8; hdr[SGRL_H_NPAIR] = 7; hdr[SGRL_H_INTEGRATOR] = 1; hdr[SGRL_H_FRAME_SKIP] = 4; hdr[SGRL_H_MAX_ROWS] = 48;
+  hdr[SGRL_H_SOLVER] = 1;
+#endif
   int n_int, n_f64;
   sgrl_model_blob_sizes(hdr, &n_int, &n_f64);
   // integer tables (paths, masks, parents: walked in inner loops) are staged in LDS; the float tables are read once
@@ -472,16 +479,21 @@ int sgrl_engine_create(int n_morph, const int32_t* const* ib, const int32_t* ib_
     (void)hipMemcpy(e->d_cnt, cnt0.data(), sizeof(int32_t) * cnt0.size(), hipMemcpyHostToDevice);
   }
   {
-    // hipFuncAttributeMaxDynamicSharedMemorySize is process-global per kernel: only ever RAISE it (a second engine with a
-    // smaller slab must not lower the limit under the first one's launches)
-    static int g_lds_limit = 48 * 1024;
-    if (e->lds_bytes > g_lds_limit) {
+    // hipFuncAttributeMaxDynamicSharedMemorySize is kept per kernel AND per device: only ever RAISE it (a second engine with a
+    // smaller slab must not lower the limit under the first one's launches), and remember what was raised on WHICH device
+    static int g_lds_limit[64];
+    static bool g_lds_init = false;
+    if (!g_lds_init) { for (int& v : g_lds_limit) v = 48 * 1024; g_lds_init = true; }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int& limit = g_lds_limit[dev >= 0 && dev < 64 ? dev : 0];
+    if (e->lds_bytes > limit) {
       hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_env_step), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
       hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_env_reset), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
       hipError_t a3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_env_refresh), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
       hipError_t a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_env_step_light), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
       if (a1 != hipSuccess || a2 != hipSuccess || a3 != hipSuccess || a4 != hipSuccess) { sgrl_engine_destroy(e); return fail(SGRL_ERR_HIP, "cannot raise the dynamic LDS limit"); }
-      g_lds_limit = e->lds_bytes;
+      limit = e->lds_bytes;
     }
   }
   BatchArgs& a = e->args;

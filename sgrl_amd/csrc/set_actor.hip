@@ -447,7 +447,9 @@ __global__ __launch_bounds__(128) void k_equiv(const float* __restrict__ T, cons
 // axis_k[s] * vec[s]); 32 lanes per node
 __global__ __launch_bounds__(128) void k_head_out(const float* __restrict__ T, const float* __restrict__ wdec,
                                                   const float* __restrict__ obs, int obs_ld, NodeTab nt, float* act, int act_ld,
-                                                  float max_action, int N) {
+                                                  float max_action, int N, const unsigned* events, unsigned* events_host) {
+  // last kernel of a forward: hand the clamp counter to the pinned host word the handle polls (sgrl_set_range_events_seen)
+  if (blockIdx.x == 0 && threadIdx.x == 0 && events_host) __hip_atomic_store(events_host, *events, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const int n = blockIdx.x * 4 + (threadIdx.x >> 5), c = threadIdx.x & 31;
   if (n >= N) return;
   float vec[3];
@@ -468,7 +470,9 @@ __global__ __launch_bounds__(128) void k_head_out(const float* __restrict__ T, c
 
 // critic head: q[env][limb] = (w . c[n] + b) / fn[n]   (reference SEActor.py:279-281 with output_size = 1); one wave per node
 __global__ __launch_bounds__(256) void k_q_head(const float* __restrict__ c, const float* __restrict__ w, const float* __restrict__ b,
-                                                const float* __restrict__ fn, NodeTab nt, float* q, int q_ld, int N) {
+                                                const float* __restrict__ fn, NodeTab nt, float* q, int q_ld, int N,
+                                                const unsigned* events, unsigned* events_host) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && events_host) __hip_atomic_store(events_host, *events, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (n >= N) return;
   const float* row = c + (size_t)n * 256;
@@ -506,6 +510,9 @@ struct sgrl_set {
   float *d_rel = nullptr, *d_relb = nullptr;
   std::vector<GraphCfg*> cfgs;
   uint64_t use_clock = 0;
+  // bumped whenever device memory a captured hipGraph may have baked a pointer into is FREED: a batch structure evicted from
+  // the cache, the flat weight buffers of a rebinding, a regrown workspace (sgrl_set_generation; td3.GraphedUpdates compares it)
+  int64_t generation = 0;
   // workspace: shared by all batch structures, grows only; carved for the current N
   float* ws = nullptr;
   int64_t ws_floats = 0;
@@ -523,6 +530,10 @@ struct sgrl_set {
   int small_nodes = -1;        // batches of at most this many nodes take the small-batch products; -1: SGRL_SET_SMALL_NODES / default
   int gemm_form = 0;           // SGRL_SET_FORM_* of the tile products; 0: SGRL_SET_GEMM / default (sgrl_set_gemm_form)
   unsigned* d_range_events = nullptr;   // operands the two-piece f16 form had to clamp (sgrl_set_range_events)
+  // the same counter as the LAST kernel of every forward leaves it in pinned host memory: the host reads it without touching the
+  // device (sgrl_set_range_events_seen), so the module surface notices clamped operands by itself
+  unsigned* h_events = nullptr;         // host address
+  unsigned* d_events_host = nullptr;    // device address of the same word
   // live weights (sgrl_set_bind_params)
   bool live = false;
   float* wflat = nullptr;
@@ -569,7 +580,7 @@ int use_cfg(sgrl_set* s, GraphCfg* c) {
   const int64_t N = c->N;
   const int64_t need = ws_floats_for(N);
   if (need > s->ws_floats) {
-    if (s->ws) (void)hipFree(s->ws);       // hipFree waits for the device: no kernel still reads the old block
+    if (s->ws) { (void)hipFree(s->ws); s->generation++; }       // hipFree waits for the device: no kernel still reads the old block
     s->ws = nullptr; s->ws_floats = 0; s->carved_N = 0;
     if (hipMalloc(&s->ws, sizeof(float) * need) != hipSuccess) return sfail(SGRL_ERR_HIP, "device allocation failed (SET workspace)");
     s->ws_floats = need;
@@ -936,13 +947,13 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   if (critic) {
     // slots reused by the critic head: DECG = decoder_ng.weight [256], L1M_B = decoder_ng.bias [1]
     hipLaunchKernelGGL(k_q_head, dim3((N + 3) / 4), dim3(256), 0, st, s->cat2, s->W(SGRL_SET_DECG), s->W(SGRL_SET_L1M_B), s->fn,
-                       nt, act, act_ld, N);
+                       nt, act, act_ld, N, s->d_range_events, s->d_events_host);
   } else {
     G(s->cat2, 256, s->W(SGRL_SET_L1M_W), 256, s->W(SGRL_SET_L1M_B), s->t256, 256, N, 256, 256, EPI_RELU);
     rc = equiv_gemm(s->t256, s->W(SGRL_SET_L2M_W), s->W(SGRL_SET_L2M_B));
     if (rc != SGRL_OK) return rc;
     hipLaunchKernelGGL(k_head_out, dim3((N + 3) / 4), dim3(128), 0, st, s->mat, s->W(SGRL_SET_DECG), obs, obs_ld, nt,
-                       act, act_ld, max_action, N);
+                       act, act_ld, max_action, N, s->d_range_events, s->d_events_host);
   }
 #undef GS
 #undef GG
@@ -1001,20 +1012,25 @@ int sgrl_set_create(sgrl_set** out) {
   }
   if (hipMalloc(&s->wstack, sizeof(float) * wstack_floats) != hipSuccess || hipMalloc(&s->d_tri, sizeof(unsigned short) * GK) != hipSuccess ||
       hipMalloc(&s->d_range_events, sizeof(unsigned)) != hipSuccess || hipMemset(s->d_range_events, 0, sizeof(unsigned)) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&s->h_events), sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+      hipHostGetDevicePointer(reinterpret_cast<void**>(&s->d_events_host), s->h_events, 0) != hipSuccess ||
       hipMemcpy(s->d_tri, tri.data(), sizeof(unsigned short) * GK, hipMemcpyHostToDevice) != hipSuccess) {
     if (s->d_range_events) (void)hipFree(s->d_range_events);
+    if (s->h_events) (void)hipHostFree(s->h_events);
     if (s->wstack) (void)hipFree(s->wstack);
     if (s->d_tri) (void)hipFree(s->d_tri);
     delete s;
     *out = nullptr;
     return sfail(SGRL_ERR_HIP, "device allocation failed in sgrl_set_create");
   }
+  *s->h_events = 0;
   *out = s;
   return SGRL_OK;
 }
 
 void sgrl_set_destroy(sgrl_set* s) {
   if (!s) return;
+  if (s->h_events) { (void)hipDeviceSynchronize(); (void)hipHostFree(s->h_events); s->h_events = nullptr; }
   if (s->side) (void)hipStreamSynchronize(s->side);
   free_graphs(s);
   if (s->wstack) (void)hipFree(s->wstack);
@@ -1073,6 +1089,7 @@ int sgrl_set_bind_params(sgrl_set* s, const sgrl_pack_seg* segs, int n_segs, con
   for (int k = 0; k < n_offsets; k++)
     if (offsets[k] < 0 || offsets[k] >= total_floats || (offsets[k] & 3)) return sfail(SGRL_ERR_ARG, "sgrl_set_bind_params: bad offset");
   // replace the previous binding (a forward may still be reading it: hipFree waits for the device)
+  if (s->wflat) s->generation++;
   if (s->wflat) (void)hipFree(s->wflat);
   if (s->wwords) (void)hipFree(s->wwords);
   if (s->d_segs) (void)hipFree(s->d_segs);
@@ -1160,6 +1177,7 @@ int sgrl_set_graph(sgrl_set* s, int n_morph, const int32_t* morph_L, const int32
     size_t lru = 0;
     for (size_t i = 1; i < s->cfgs.size(); i++) if (s->cfgs[i]->last_use < s->cfgs[lru]->last_use) lru = i;
     s->cfgs[lru]->release();                              // hipFree waits for the device
+    s->generation++;
     delete s->cfgs[lru];
     s->cfgs.erase(s->cfgs.begin() + lru);
   }
@@ -1219,6 +1237,7 @@ int sgrl_set_time_forward(sgrl_set* s, const float* obs, int obs_ld, float* act,
 
 int sgrl_set_num_nodes(const sgrl_set* s) { return s ? s->N : SGRL_ERR_ARG; }
 int64_t sgrl_set_workspace_bytes(const sgrl_set* s) { return s ? s->ws_floats * 4 : -1; }
+int64_t sgrl_set_generation(const sgrl_set* s) { return s ? s->generation : -1; }
 
 int sgrl_set_peek(sgrl_set* s, int which, float* host, int64_t n_floats) {
   if (!s || !host || !s->have_graph) return sfail(SGRL_ERR_ARG, "sgrl_set_peek: bad argument");
@@ -1244,6 +1263,7 @@ int sgrl_set_debug_small_nodes(sgrl_set* s, int nodes) {
 
 int sgrl_set_gemm_form(sgrl_set* s, int form) {
   if (!s || (form != 0 && form != SGRL_SET_FORM_F16X3 && form != SGRL_SET_FORM_BF16X6)) return sfail(SGRL_ERR_ARG, "sgrl_set_gemm_form: bad argument");
+  if (s->gemm_form != form) s->generation++;     // a captured graph holds the kernels of the previous form
   s->gemm_form = form;
   return SGRL_OK;
 }
@@ -1253,7 +1273,12 @@ int sgrl_set_range_events(sgrl_set* s, unsigned* count, int reset) {
   // the null stream orders this copy behind the forwards of blocking streams only: callers synchronise their stream first
   if (hipMemcpy(count, s->d_range_events, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return sfail(SGRL_ERR_HIP, "sgrl_set_range_events: copy failed");
   if (reset && *count && hipMemset(s->d_range_events, 0, sizeof(unsigned)) != hipSuccess) return sfail(SGRL_ERR_HIP, "sgrl_set_range_events: reset failed");
+  if (reset && s->h_events) *s->h_events = 0;
   return SGRL_OK;
+}
+
+unsigned sgrl_set_range_events_seen(const sgrl_set* s) {
+  return (s && s->h_events) ? *reinterpret_cast<volatile const unsigned*>(s->h_events) : 0u;
 }
 
 const char* sgrl_set_last_error(void) { return g_set_err.c_str(); }

@@ -293,6 +293,9 @@ struct Engine {
   // all ~26 bases as VGPRs once and keeps them live across the whole step (then spills them); making the bases opaque
   // at the top of every evaluation confines those copies to where they are used.
   SGRL_DEV void fence_view() {
+#ifdef SGRL_FIX_DIMS_W7
+    return;        // diagnostic build: table addresses are compile-time constants
+#endif
     m.body_parent = w.fenced(m.body_parent); m.body_jntadr = w.fenced(m.body_jntadr);
     m.body_jntnum = w.fenced(m.body_jntnum); m.body_dofadr = w.fenced(m.body_dofadr);
     m.body_dofnum = w.fenced(m.body_dofnum); m.body_limbtype = w.fenced(m.body_limbtype);
@@ -1136,7 +1139,11 @@ struct Engine {
     collide();                  SGRL_TICK(3);
     bias_and_smooth_force();    SGRL_TICK(4);
     const int wanted = count_rows();
+#ifdef SGRL_FORCE_SLAB_ROWS      // diagnostic build only: every evaluation keeps its constraint rows in the HBM slab (prices Y out of LDS)
+    if (big_scratch != nullptr) {
+#else
     if (wanted > o.lrows && big_scratch != nullptr) {
+#endif
       const Rows R = rows_hbm();
       fill_rows(R, wanted, o.maxrows);           SGRL_TICK(5);
       build_rows_and_halfsolve<true>(R);         SGRL_TICK(10);

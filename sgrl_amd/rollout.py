@@ -289,12 +289,34 @@ class TransitionSink(object):
         self.buffers = buffers
         if self.is_learner and buffers is None:
             raise ValueError("the learner rank needs the per-morphology replay buffers")
-        self._stored = torch.zeros((), dtype=torch.long, device=self.device)   # device-side count: no host sync per step
+        self._stored = 0            # host-side count, current after fold_counters()
+        # rows per morphology written by the one-launch ingest since the rings' host-side pointers were last brought up to date
+        # (device tensor: the ingest itself never synchronises; readers of `curr` / `max_sample_size` / `stored` fold it in)
+        self._pend = None
+        if self.is_learner and buffers is not None:
+            for b in buffers:
+                if isinstance(b, DeviceReplayBuffer):
+                    b._sync_hook = self.fold_counters
+
+    def fold_counters(self):
+        """Bring the rings' host-side write pointers / fill levels and `stored` up to date with what the device-side ingest has
+        written (ONE host synchronisation, when somebody looks: round end, sampling, snapshots, tests -- not per step)."""
+        if self._pend is None:
+            return
+        pend, self._pend = self._pend, None
+        counts = pend.tolist()
+        for c, b in zip(counts, self.buffers):
+            if c:
+                b._curr = (b._curr + c) % b.max_buffer_size
+                b._fill = min(b._fill + c, b.max_buffer_size)
+        self._stored += int(sum(counts))
+        self._pos_host = tuple(b._curr for b in self.buffers)
 
     @property
     def stored(self):
         """Transitions written on the learner so far (tot_env_steps bookkeeping, trainer.py:229); reading it synchronises."""
-        return int(self._stored.item())
+        self.fold_counters()
+        return int(self._stored)
 
     def begin_round(self):
         self.collector.begin_round()
@@ -331,26 +353,25 @@ class TransitionSink(object):
         return self._ring_dev
 
     def _ingest_block_hip(self, blk):
-        """The rows of one block into their morphologies' rings with ONE launch (include/sgrl.h sgrl_ingest_rows) and one host
-        synchronisation (the per-morphology row counts, for the rings' host-side write pointers).  Slot of a stored row =
-        write pointer of its ring + its rank among the stored rows of its morphology in this block (row order), modulo the
-        capacity -- what add_transition row by row produces.  Returns False (nothing written) when a ring would wrap onto
-        itself inside this one block: the row-by-row path handles that."""
+        """The rows of one block into their morphologies' rings with ONE launch (include/sgrl.h sgrl_ingest_rows) and NO host
+        synchronisation: the rings' write pointers are mirrored on the device, the per-morphology row counts stay there too
+        (`_pend`) until somebody reads the host-side pointers (fold_counters: once per round).  Slot of a stored row = write
+        pointer of its ring + its rank among the stored rows of its morphology in this block (row order), modulo the capacity
+        -- what add_transition row by row produces.  Returns False (nothing written) when a block has more rows than the
+        smallest ring holds (it could wrap a ring onto itself): the row-by-row path handles that."""
         from . import _lib
+        if int(blk.shape[0]) > min(b.max_buffer_size for b in self.buffers):
+            return False
         _, _, _, _, _, store, morph = self.gather.unpack(blk)
         rings = self._ring_table()
         m = morph.clamp(0, len(self.buffers) - 1)
         hit = (self._ring_ids.unsqueeze(1) == m.unsqueeze(0)) & store.unsqueeze(0)              # [morphologies, rows]
         cs = torch.cumsum(hit, dim=1, dtype=torch.int64)                                          # scans along the contiguous axis
         counts_dev = cs[:, -1]
-        counts = counts_dev.tolist()                                                               # the one host sync
-        if sum(counts) == 0:
-            return True
-        if any(c > b.max_buffer_size for c, b in zip(counts, self.buffers)):
-            return False
-        host_pos = tuple(b.curr for b in self.buffers)
-        if getattr(self, "_pos_host", None) != host_pos:          # first block, or the buffers were written / loaded elsewhere
-            self._pos_dev = torch.tensor(host_pos, dtype=torch.long, device=self.device)
+        if self._pend is None:
+            host_pos = tuple(b._curr for b in self.buffers)
+            if getattr(self, "_pos_host", None) != host_pos:      # first block, or the buffers were written / loaded elsewhere
+                self._pos_dev = torch.tensor(host_pos, dtype=torch.long, device=self.device)
         rank = cs.gather(0, m.unsqueeze(0)).squeeze(0) - 1
         slot = torch.where(store, (self._pos_dev[m] + rank) % self._ring_cap[m], rank.new_full((), -1))
         blk = blk if blk.is_contiguous() else blk.contiguous()
@@ -358,13 +379,8 @@ class TransitionSink(object):
         _lib.check(_lib.lib().sgrl_ingest_rows(ctypes.c_void_p(blk.data_ptr()), int(blk.shape[0]), int(self.gather.o), int(self.gather.a),
                                                ctypes.c_void_p(slot.data_ptr()), ctypes.c_void_p(rings.data_ptr()), len(self.buffers),
                                                ctypes.c_void_p(stream)), "sgrl_ingest_rows")
-        for c, b in zip(counts, self.buffers):
-            if c:
-                b.curr = (b.curr + c) % b.max_buffer_size
-                b.max_sample_size = min(b.max_sample_size + c, b.max_buffer_size)
-        self._pos_dev = (self._pos_dev + counts_dev) % self._ring_cap      # the device copy follows without another upload
-        self._pos_host = tuple(b.curr for b in self.buffers)
-        self._stored += int(sum(counts))
+        self._pos_dev = (self._pos_dev + counts_dev) % self._ring_cap      # the device copy follows without an upload
+        self._pend = counts_dev if self._pend is None else self._pend + counts_dev
         return True
 
     def ingest(self, blocks):
@@ -372,6 +388,7 @@ class TransitionSink(object):
         for blk in blocks:                                   # rank order = global environment order
             if fast and self._ingest_block_hip(blk):
                 continue
+            self.fold_counters()                             # the row-by-row path works on the host-side pointers
             obs, act, nxt, rew, done, store, morph = self.gather.unpack(blk)
             rows = torch.nonzero(store, as_tuple=False).flatten()          # host sync 1 of 2 per block (row count)
             if rows.numel() == 0:

@@ -36,11 +36,15 @@ def _bind(L):
     L.sgrl_set_num_nodes.argtypes = [vp]
     L.sgrl_set_workspace_bytes.argtypes = [vp]
     L.sgrl_set_workspace_bytes.restype = ctypes.c_int64
+    L.sgrl_set_generation.argtypes = [vp]
+    L.sgrl_set_generation.restype = ctypes.c_int64
     L.sgrl_set_peek.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int64]
     L.sgrl_set_debug_stop_after.argtypes = [vp, ctypes.c_int]
     L.sgrl_set_debug_small_nodes.argtypes = [vp, ctypes.c_int]
     L.sgrl_set_gemm_form.argtypes = [vp, ctypes.c_int]
     L.sgrl_set_range_events.argtypes = [vp, ctypes.POINTER(ctypes.c_uint), ctypes.c_int]
+    L.sgrl_set_range_events_seen.argtypes = [vp]
+    L.sgrl_set_range_events_seen.restype = ctypes.c_uint
     L.sgrl_set_last_error.restype = ctypes.c_char_p
     L._set_bound = True
 
@@ -380,6 +384,7 @@ class HipSetActor(object):
                                                ctypes.c_void_p(out.data_ptr()), int(act_ld),
                                                ctypes.c_float(float(self.policy.max_action)), self._stream()),
                "sgrl_set_forward")
+        self._poll_range()
         return out
 
     def forward_q(self, obs, action, out=None, q_ld=None):
@@ -398,6 +403,7 @@ class HipSetActor(object):
                                                  ctypes.c_void_p(action.data_ptr()), self._ld(action),
                                                  ctypes.c_void_p(out.data_ptr()), int(q_ld), self._stream()),
                "sgrl_set_forward_q")
+        self._poll_range()
         return out
 
     def time_forward(self, obs, out, reps):
@@ -436,6 +442,20 @@ class HipSetActor(object):
         n = ctypes.c_uint(0)
         _check(self.L, self.L.sgrl_set_range_events(self.h, ctypes.byref(n), 1 if reset else 0), "sgrl_set_range_events")
         return int(n.value)
+
+    def range_events_seen(self):
+        """Clamped operands as the forwards COMPLETED so far left the counter (a word of pinned host memory the last kernel of
+        every forward writes; include/sgrl_set.h sgrl_set_range_events_seen): no synchronisation, callable during a capture."""
+        return int(self.L.sgrl_set_range_events_seen(self.h))
+
+    def _poll_range(self):
+        """After every forward through the module / driver surface: if an EARLIER forward of this handle clamped an operand,
+        warn and switch to the full-range form now (one synchronisation, only in that case) -- users of `SEPolicy` /
+        `SECritic` / `BatchedEvaluator` get what `DeviceTrainer` does once per round without asking for it.  The forward just
+        enqueued is looked at by the next poll (or by check_range()).  Never synchronises while the stream is being captured
+        (the capturing caller polls after the replay: td3.GraphedUpdates)."""
+        if self.L.sgrl_set_range_events_seen(self.h) and not torch.cuda.is_current_stream_capturing():
+            self.range_events_total = getattr(self, "range_events_total", 0) + self.check_range()
 
     def check_range(self):
         """Call at a point where a device synchronisation is affordable (end of a collection round, of an evaluation):

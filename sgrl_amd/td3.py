@@ -291,6 +291,7 @@ class GraphedUpdates(object):
                 g["capturable"] = True
         self.slots = {}            # key -> dict(static tensors, graphs)
         self.warmed = set()
+        self.range_events = 0      # operands the target networks' two-piece products clamped so far (poll_range)
 
     def _slot(self, key, graph, L):
         sl = self.slots.get(key)
@@ -302,32 +303,52 @@ class GraphedUpdates(object):
             self.slots[key] = sl
         return sl
 
-    def _workspace_stamp(self):
-        """Sizes of the device workspaces the captured HIP target kernels point into (include/sgrl_set.h)."""
+    def _hip_handles(self):
+        """The HIP handles whose forwards the update graphs record: the target actor and the two target critics."""
         out = []
         for mod in (self.agent.actor_target, self.agent.critic_target):
             h = getattr(mod, "_hip", None)
-            for hh in ([h] if hasattr(h, "h") else [getattr(h, "q1", None), getattr(h, "q2", None)]):
-                out.append(-1 if hh is None else int(hh.L.sgrl_set_workspace_bytes(hh.h)))
-        return tuple(out)
+            out.extend([h] if hasattr(h, "h") else [getattr(h, "q1", None), getattr(h, "q2", None)])
+        return [hh for hh in out if hh is not None]
+
+    def _workspace_stamp(self):
+        """What the captured HIP target kernels point into, per handle: the workspace's size and the handle's GENERATION
+        (include/sgrl_set.h sgrl_set_generation: bumped whenever the handle frees device memory a recorded forward may
+        reference -- a batch structure evicted from its cache, the flat weight buffers of a rebinding, a regrown workspace --
+        or changes the form of its tile products)."""
+        return tuple((int(hh.L.sgrl_set_workspace_bytes(hh.h)), int(hh.L.sgrl_set_generation(hh.h))) for hh in self._hip_handles())
+
+    def poll_range(self):
+        """Clamped operands in the target networks' forwards (they run inside replayed graphs, where nothing can poll): warn,
+        move the handle to the full-range form (its generation changes, so the graphs are captured again).  Returns events."""
+        n = 0
+        for hh in self._hip_handles():
+            if hh.range_events_seen():
+                n += hh.check_range()
+        self.range_events += n
+        return n
 
     def _load(self, sl, data_batch):
         for k, t in sl["batch"].items():
             t.copy_(data_batch[k].reshape(t.shape))
         sl["noise"].normal_(0, self.agent.args.policy_noise)
 
-    def warm(self, key, graph, L, data_batch, iters=3):
-        """Eager updates on a side stream (PyTorch's capture protocol); counts as real updates."""
+    def warm(self, key, graph, L, data_batch, iters=3, first_it=0):
+        """Eager updates on a side stream (PyTorch's capture protocol).  They are REAL updates: the caller passes the first
+        `iters` iterations of its schedule (`data_batch` may be a callable returning a fresh batch per iteration, `first_it`
+        the index of the first one) instead of adding updates of its own.  Returns the loss dicts."""
         sl = self._slot(key, graph, L)
         self.agent.change_morphology(graph)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
+        outs = []
         with torch.cuda.stream(s):
-            for it in range(iters):
-                self._load(sl, data_batch)
-                self.agent.update(sl["batch"], it, noise=sl["noise"], lazy_stats=True, skip_unused_critic_grads=True)
+            for it in range(first_it, first_it + iters):
+                self._load(sl, data_batch() if callable(data_batch) else data_batch)
+                outs.append(self.agent.update(sl["batch"], it, noise=sl["noise"], lazy_stats=True, skip_unused_critic_grads=True))
         torch.cuda.current_stream().wait_stream(s)
         self.warmed.add(key)
+        return outs
 
     def update(self, key, graph, L, data_batch, it):
         """Same contract as Agent.update(data_batch, it) for the morphology `graph` (dict) identified by `key`."""
@@ -359,4 +380,5 @@ class GraphedUpdates(object):
             sl["graphs"][flag] = g           # capturing records the work without running it
             sl["stamp"][flag] = self._workspace_stamp()
         sl["graphs"][flag].replay()
-        return sl["out"][flag]
+        # the capture's output tensors are overwritten by the next replay: hand out copies
+        return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in sl["out"][flag].items()}

@@ -53,7 +53,8 @@ class DeviceTrainer(object):
                                    dst=dst)
         self.prev_obs = torch.zeros_like(env.obs)
         self.num_envs_global = env.num_envs * self.world
-        self.tot_env_steps = 0
+        self._updates = 0            # TD3 updates so far (the reference adds them to tot_env_steps: trainer.py:250)
+        self._tot_synced = 0         # non-learner ranks: the learner's count as of the last round end
         self.rounds = 0
         self.range_events = 0        # operands the rollout actor clamped so far (HipSetActor.check_range)
         self.gen = torch.Generator(device=self.device)
@@ -64,6 +65,15 @@ class DeviceTrainer(object):
             from .td3 import GraphedUpdates
             self.graphed = GraphedUpdates(self.agent, self.batch_size)
         self.begin_round()
+
+    @property
+    def tot_env_steps(self):
+        """Stored transitions + updates (trainer.py:229, 250).  The learner's count: reading it there folds the device-side
+        ingest counters in (one synchronisation -- nothing in the per-step path reads it); the other ranks hold the value the
+        learner broadcast at the last round end."""
+        if self.is_learner:
+            return self.sink.stored + self._updates
+        return self._tot_synced
 
     # ---- collection ----------------------------------------------------------------------------------
     def begin_round(self):
@@ -84,10 +94,7 @@ class DeviceTrainer(object):
             self.ro.actions.copy_(a)
             a = self.ro.actions
         obs, rew, done, _ = self.ro.step(a)
-        before = self.sink.stored
-        finished = self.sink.push(self.prev_obs, a, obs, rew, done)
-        self.tot_env_steps += self.sink.stored - before       # learner-side count (trainer.py:229)
-        return finished
+        return self.sink.push(self.prev_obs, a, obs, rew, done)    # one host synchronisation per step: the round-finished flag
 
     def warmup(self, timesteps):
         """reference Trainer.warmup (trainer.py:90-138): `timesteps` batched steps of uniform random actions; finished
@@ -104,25 +111,40 @@ class DeviceTrainer(object):
             per_morph_iter = min(per_morph_iter, int(max_iters))
         if self.is_learner:
             self.agent.models2train()
-            if self.graphed is not None:     # every morphology runs eagerly once before any graph bakes a pointer
+            start = [0] * len(self.env_names)
+            if self.graphed is not None:
+                # every morphology runs eagerly before any graph bakes a pointer (capture protocol of td3.GraphedUpdates): the
+                # FIRST iterations of its schedule serve as those eager runs -- same number of updates as the reference's
+                # schedule, in the first such round the morphologies' first two iterations come before everybody's remaining ones
                 for k in range(len(self.env_names)):
-                    if k not in self.graphed.warmed and self.buffers[k].max_sample_size >= self.batch_size:
-                        self.graphed.warm(k, self.graph_dicts[k], self.ro.env.num_limbs[k],
-                                          self.buffers[k].sample(self.batch_size, generator=self.gen), iters=2)
+                    if k not in self.graphed.warmed and self.buffers[k].max_sample_size >= self.batch_size and per_morph_iter > 0:
+                        n = min(2, per_morph_iter)
+                        outs = self.graphed.warm(k, self.graph_dicts[k], self.ro.env.num_limbs[k],
+                                                 lambda k=k: self.buffers[k].sample(self.batch_size, generator=self.gen), iters=n)
+                        self.last_losses[self.env_names[k]] = outs[-1]
+                        start[k] = n
+                        self._updates += n
             for k, name in enumerate(self.env_names):
                 self.agent.change_morphology(self.graph_dicts[k])
-                for it in range(per_morph_iter):
+                for it in range(start[k], per_morph_iter):
                     batch = self.buffers[k].sample(self.batch_size, generator=self.gen)
                     if self.graphed is not None and k in self.graphed.warmed:
                         self.last_losses[name] = self.graphed.update(k, self.graph_dicts[k], self.ro.env.num_limbs[k], batch, it)
                     else:
                         self.last_losses[name] = self.agent.update(batch, it)
-                    self.tot_env_steps += 1                    # the reference counts updates too (trainer.py:250)
+                    self._updates += 1                         # the reference counts updates too (trainer.py:250)
             self.agent.models2eval()
-        # once per round (a synchronisation is affordable here): did the rollout actor's two-piece products meet an operand
-        # outside f16's range?  If so warn and use the full-range form from now on (include/sgrl_set.h)
+            if self.graphed is not None:     # the target networks' forwards ran inside replayed graphs: look at their counters now
+                self.range_events += self.graphed.poll_range()
+        # the rollout actor polls its clamp counter by itself after every forward (set_hip.HipSetActor._poll_range); once per round
+        # a synchronisation is affordable: also catch the events of the round's LAST forwards
         if getattr(self.ro, "actor", None) is not None:
-            self.range_events += self.ro.actor.check_range()
+            self.range_events += self.ro.actor.check_range() + getattr(self.ro.actor, "range_events_total", 0)
+            self.ro.actor.range_events_total = 0
+        if self.world > 1:                   # every rank reports the learner's step count (checkpoints, stopping rule)
+            t = torch.tensor([self.tot_env_steps if self.is_learner else 0], dtype=torch.long, device=self.device)
+            self.dist.broadcast(t, src=self.dst)
+            self._tot_synced = int(t.item())
         self.broadcast_actor()
         self.rounds += 1
         return per_morph_iter
