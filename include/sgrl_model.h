@@ -111,23 +111,16 @@ typedef struct SgrlModelView {
  * `hdr_src` / `fhdr_src`, which may be different copies of the same blobs: the HIP engine passes the copies in
  * constant memory there (scalar loads -> sizes, offsets and every header constant stay in scalar registers) while ib
  * points at the LDS copy of the int tables.  Returns 0, or -1 on a bad magic. */
-SGRL_HD int sgrl_model_view_from(sgrl_hdr_t hdr_src, sgrl_fhdr_t fhdr_src, sgrl_itab_t ib, sgrl_ftab_t fb,
+/* `dims`: the SGRL_NHDR header VALUES the table sizes are taken from (the HIP engine passes them in registers: copies of the
+ * header made wave-uniform, or compile-time constants in a kernel instance built for one dimension set); hdr_src / fhdr_src:
+ * the header copies the view exposes for later reads of task constants. */
+SGRL_HD int sgrl_model_view_dims(const int32_t* dims, sgrl_hdr_t hdr_src, sgrl_fhdr_t fhdr_src, sgrl_itab_t ib, sgrl_ftab_t fb,
                                  SgrlModelView* v) {
-  if (hdr_src[SGRL_H_MAGIC] != SGRL_MAGIC) return -1;
+  if (dims[SGRL_H_MAGIC] != SGRL_MAGIC) return -1;
   v->hdr = hdr_src;
   v->fhdr = fhdr_src;
-#if defined(SGRL_FIX_DIMS_W7) && defined(__HIP_DEVICE_COMPILE__)
-  const int nb_ = hdr_src[SGRL_H_NBODY], nj_ = hdr_src[SGRL_H_NJNT], nq_ = hdr_src[SGRL_H_NQ], nv_ = hdr_src[SGRL_H_NV];
-  const int nu_ = hdr_src[SGRL_H_NU], ng_ = hdr_src[SGRL_H_NGEOM], np_ = hdr_src[SGRL_H_NPAIR];
-#else
-  const int nb = hdr_src[SGRL_H_NBODY], nj = hdr_src[SGRL_H_NJNT], nq = hdr_src[SGRL_H_NQ], nv = hdr_src[SGRL_H_NV];
-  const int nu = hdr_src[SGRL_H_NU], ng = hdr_src[SGRL_H_NGEOM], np = hdr_src[SGRL_H_NPAIR];
-#endif
-#if defined(SGRL_FIX_DIMS_W7) && defined(__HIP_DEVICE_COMPILE__)   /* diagnostic build only (tools/diag/variant_probe.py) */
-  const int nb = 8, nj = 19, nq = 25, nv = 24;
-  const int nu = 18, ng = 8, np = 7;
-  (void)nb_; (void)nj_; (void)nq_; (void)nv_; (void)nu_; (void)ng_; (void)np_;
-#endif
+  const int nb = dims[SGRL_H_NBODY], nj = dims[SGRL_H_NJNT], nq = dims[SGRL_H_NQ], nv = dims[SGRL_H_NV];
+  const int nu = dims[SGRL_H_NU], ng = dims[SGRL_H_NGEOM], np = dims[SGRL_H_NPAIR];
   v->nbody = nb; v->njnt = nj; v->nq = nq; v->nv = nv; v->nu = nu; v->ngeom = ng; v->npair = np;
   sgrl_itab_t p = ib + SGRL_NHDR;
   v->body_parent = p; p += nb;
@@ -186,6 +179,13 @@ SGRL_HD int sgrl_model_view_from(sgrl_hdr_t hdr_src, sgrl_fhdr_t fhdr_src, sgrl_
   v->act_ctrlrange = f; f += 2 * nu;
   v->n_f64 = (int)(f - fb);
   return 0;
+}
+
+SGRL_HD int sgrl_model_view_from(sgrl_hdr_t hdr_src, sgrl_fhdr_t fhdr_src, sgrl_itab_t ib, sgrl_ftab_t fb,
+                                 SgrlModelView* v) {
+  int32_t dims[SGRL_NHDR];
+  for (int k = 0; k < SGRL_NHDR; k++) dims[k] = hdr_src[k];
+  return sgrl_model_view_dims(dims, hdr_src, fhdr_src, ib, fb, v);
 }
 
 /* Blob lengths implied by a header (the same sums sgrl_model_view_from walks; tests/test_abi.py checks them against

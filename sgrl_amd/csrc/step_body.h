@@ -293,9 +293,7 @@ struct Engine {
   // all ~26 bases as VGPRs once and keeps them live across the whole step (then spills them); making the bases opaque
   // at the top of every evaluation confines those copies to where they are used.
   SGRL_DEV void fence_view() {
-#ifdef SGRL_FIX_DIMS_W7
-    return;        // diagnostic build: table addresses are compile-time constants
-#endif
+    if (W::kFixedDims) return;     // a fixed-dimension kernel instance: the table addresses are compile-time constants
     m.body_parent = w.fenced(m.body_parent); m.body_jntadr = w.fenced(m.body_jntadr);
     m.body_jntnum = w.fenced(m.body_jntnum); m.body_dofadr = w.fenced(m.body_dofadr);
     m.body_dofnum = w.fenced(m.body_dofnum); m.body_limbtype = w.fenced(m.body_limbtype);
@@ -476,7 +474,7 @@ struct Engine {
         S[o.L + tri(i) + j] = dot6(cj, buf);
       }
     });
-    if (m.hdr[SGRL_H_INTEGRATOR] == 0) {  // Euler needs M again for (M + h D)
+    if (W::hdr_const(m, SGRL_H_INTEGRATOR) == 0) {  // Euler needs M again for (M + h D)
       w.lanes(nv, [&](int i) { for (int k = 0; k <= i; k++) S[o.Mfull + tri(i) + k] = S[o.L + tri(i) + k]; });
     }
     SGRL_TICK(2);
@@ -984,7 +982,9 @@ struct Engine {
           xwp[pos] = -R.eb[i];
         }
       });
-      // A_FF = Y_F Y_F' + diag(R_F), compact packed lower triangle
+      // A_FF = Y_F Y_F' + diag(R_F), compact packed lower triangle: on the FP64 matrix cores where the wave policy has them
+      // and the free set is large enough to pay, else one lane per entry
+      if (!w.aff_rows(nf, nv, R.Y, ldy, R.flist, R.eR, C))
       w.lanes(nf * (nf + 1) / 2, [&](int p) {
         int i, j;
         tri_decode(p, &i, &j);
@@ -1085,7 +1085,7 @@ struct Engine {
       const double bmax = w.maxabs(nrow, [&](int r) { return R.eb[r]; });
       const double thresh = m.fhdr[SGRL_F_PGS_TOL] * (1.0 + bmax);
       bool solved = false;
-      if (m.hdr[SGRL_H_SOLVER] == 1) {
+      if (W::hdr_const(m, SGRL_H_SOLVER) == 1) {
         if (!BIG) {
           solved = lcp_block_pivot<true>(R, nrow, thresh, &sweeps);             // rows and factor scratch in LDS
           if (!solved) diag_code |= 1 << 8;                                     // diagnostics: block pivoting gave up
@@ -1182,7 +1182,7 @@ struct Engine {
   SGRL_DEV void mj_step() {
     const int nv = o.nv, nq = o.nq;
     const double h = m.fhdr[SGRL_F_TIMESTEP];
-    const bool rk4 = m.hdr[SGRL_H_INTEGRATOR] == 1;
+    const bool rk4 = W::hdr_const(m, SGRL_H_INTEGRATOR) == 1;
     {
       // RK4 (four stages) or Euler (one); the kinematics left in LDS afterwards are those of the last stage (what
       // _get_obs reads).  One loop with a single inlined copy of forward() keeps the kernel's code near the I-cache.
@@ -1310,7 +1310,7 @@ struct Engine {
       const double dist_before = sqrt((tx - pbx) * (tx - pbx) + (ty - pby) * (ty - pby));
       const double pax = S[o.xpos + 3], pay = S[o.xpos + 4];
       const double dist_after = sqrt((tx - pax) * (tx - pax) + (ty - pay) * (ty - pay));
-      const double dt = m.fhdr[SGRL_F_TIMESTEP] * m.hdr[SGRL_H_FRAME_SKIP];
+      const double dt = m.fhdr[SGRL_F_TIMESTEP] * W::hdr_const(m, SGRL_H_FRAME_SKIP);
       double height = S[o.qpos + 2];
       double r = (dist_before - dist_after) / dt;
       if (m.fhdr[SGRL_F_HEADING_WEIGHT] != 0.0) r += ((pax - pbx) * cos(heading) + (pay - pby) * sin(heading)) / dt;
@@ -1463,7 +1463,7 @@ SGRL_DEV void env_step(W& w, const SgrlModelView& m, const Layout& o, double* S,
     if (u < 4) S[o.misc + MS_PREQUAT + u] = S[o.qpos + 3 + u];
     if (u == 4) { I[o.icnt + IC_OVERFLOW] = 0; I[o.icnt + IC_PREV_N] = 0; I[o.icnt + IC_SWEEPS] = 0; I[o.icnt + IC_ROWSUM] = 0; }
   });
-  const int fs = m.hdr[SGRL_H_FRAME_SKIP];
+  const int fs = W::hdr_const(m, SGRL_H_FRAME_SKIP);
 #pragma unroll 1
   for (int s = 0; s < fs; s++) e.mj_step();
   e.body_velocities();

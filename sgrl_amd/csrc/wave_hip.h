@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "../../include/sgrl_model.h"
+
 namespace sgrl {
 
 template <int CTRL>
@@ -34,10 +36,51 @@ __device__ __forceinline__ double wave_max(double x) {
   return fmax(fmax(read_lane(x, 0), read_lane(x, 16)), fmax(read_lane(x, 32), read_lane(x, 48)));
 }
 
+// Dimension policy of a kernel instance.  DimsAny: everything comes from the morphology's header (one kernel for all
+// morphologies).  DimsFixed<...>: the counts the LDS layout, the model view and every loop bound derive from are compile-time
+// constants -- layout offsets become immediates of the LDS instructions, table bases constants, the scalar registers that held
+// ~120 offsets / pointers (and spilled: 483 spills in the generic kernel) are free; measured on 8192 x 3d_walker_7_full:
+// 4.52-4.78 -> 4.07-4.29 ms per launch (profiles/r3_variant_probe_1.log).  The host only launches an instance on environments
+// whose header matches it field for field (engine.hip spec_for).
+struct DimsAny {
+  static constexpr bool kFixed = false;
+  __device__ static __forceinline__ void apply(int32_t*) {}
+  template <class M> __device__ static __forceinline__ int hdr_const(const M& m, int idx) { return m.hdr[idx]; }
+};
+template <int NB, int NJ, int NQ, int NV, int NU, int NG, int NP, int INTEG, int FSKIP, int MAXROWS, int SOLVER>
+struct DimsFixed {
+  static constexpr bool kFixed = true;
+  static constexpr int kNv = NV;
+  __device__ static __forceinline__ void apply(int32_t* hdr) {
+    hdr[SGRL_H_NBODY] = NB; hdr[SGRL_H_NJNT] = NJ; hdr[SGRL_H_NQ] = NQ; hdr[SGRL_H_NV] = NV; hdr[SGRL_H_NU] = NU;
+    hdr[SGRL_H_NGEOM] = NG; hdr[SGRL_H_NPAIR] = NP; hdr[SGRL_H_INTEGRATOR] = INTEG; hdr[SGRL_H_FRAME_SKIP] = FSKIP;
+    hdr[SGRL_H_MAX_ROWS] = MAXROWS; hdr[SGRL_H_SOLVER] = SOLVER;
+  }
+  // header fields the engine branches on: constants of the instance
+  template <class M> __device__ static __forceinline__ int hdr_const(const M& m, int idx) {
+    return idx == SGRL_H_INTEGRATOR ? INTEG : (idx == SGRL_H_SOLVER ? SOLVER : (idx == SGRL_H_FRAME_SKIP ? FSKIP : m.hdr[idx]));
+  }
+};
+
+typedef double sgrl_v4d __attribute__((ext_vector_type(4)));
+// FP64 matrix cores (v_mfma_f64_16x16x4_f64; tools/micro/mfma_f64_lab.hip, profiles/r3_mfma_f64_lab.log: 145 cycles issue
+// interval, 180 dependent -- 7 FMA/clk/SIMD, under HALF the vector unit's 16, so they pay only where the vector form leaves
+// most lanes idle or waits on LDS: the Gram product A_FF = Y_F Y_F' (11.3 k -> 3.5 k cycles at nf = 24 at the engine's
+// residency) and the triangular product Y <- Y L^-T (7.6 k -> 4.8 k at n = 24)).  Operand maps: A[row = lane & 15][k = lane >> 4],
+// B[k = lane >> 4][col = lane & 15], D register i = row (lane >> 4) + 4 i, column lane & 15.
+#ifndef SGRL_AFF_MFMA_MIN
+#define SGRL_AFF_MFMA_MIN 8       // free sets from this size on form A_FF on the matrix cores
+#endif
+#ifndef SGRL_TRMM_MFMA_MIN
+#define SGRL_TRMM_MFMA_MIN 9      // dof counts from this on run the half-solve product on the matrix cores
+#endif
+
 // NVCAP: the largest dof count whose register solver instances are compiled in (24 = all; a kernel variant built for the
 // small morphologies only carries the instances it can meet: fewer registers)
-template <int NVCAP>
+template <int NVCAP, class D = DimsAny>
 struct HipWaveT {
+  static constexpr bool kFixedDims = D::kFixed;     // the kernel instance knows the morphology's dimensions at compile time
+  template <class M> __device__ static __forceinline__ int hdr_const(const M& m, int idx) { return D::hdr_const(m, idx); }
   int lane;
 #ifdef SGRL_PHASE_PROF
   // diagnostic build only (tools/phase_prof.py): s_memtime deltas per phase of Engine::forward, lane 0 accumulates
@@ -214,11 +257,94 @@ struct HipWaveT {
     }
     __syncthreads();
   }
+  // The same product on the matrix cores: Y[r][d] <- sum_{c <= d} T[d][c] Y[r][c], 16 right-hand sides x 16 outputs per tile,
+  // only the k-steps of the triangle.  n <= 24 (six k-steps kept in registers), in place: a tile's operands are in registers
+  // before its first store, tiles of different right-hand sides do not overlap.
+  __device__ __forceinline__ void trmm_rows_mfma(int nrhs, int n, const double* T, double* Y, int ldy) {
+    const int lo = lane & 15, hi = lane >> 4;
+    const int ksteps = (n + 3) >> 2;
+    for (int r0 = 0; r0 < nrhs; r0 += 16) {
+      const int r = r0 + lo;
+      const bool rv = r < nrhs;
+      const double* yr = Y + (rv ? r : 0) * ldy;
+      double b[6];
+#pragma unroll
+      for (int s = 0; s < 6; s++) {
+        const int c = 4 * s + hi;
+        const double v = yr[c < n ? c : 0];
+        b[s] = (rv && c < n) ? v : 0.0;
+      }
+#pragma unroll
+      for (int dt = 0; dt < 2; dt++) {
+        if (16 * dt < n) {                                   // uniform
+          const int d = 16 * dt + lo;
+          const bool dv = d < n;
+          const double* Td = T + (dv ? d * (d + 1) / 2 : 0);
+          sgrl_v4d acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+          for (int s = 0; s < 6; s++) {
+            if (s < ksteps && s < 4 * dt + 4) {              // uniform: k-steps of the triangle only
+              const int c = 4 * s + hi;
+              const double t = Td[(dv && c <= d) ? c : 0];
+              const double a = (dv && c <= d) ? t : 0.0;
+              if (s & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[s], acc1, 0, 0, 0);
+              else acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[s], acc0, 0, 0, 0);
+            }
+          }
+          if (rv) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              const int dd = 16 * dt + hi + 4 * i;
+              if (dd < n) Y[r * ldy + dd] = acc0[i] + acc1[i];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // A_FF = Y_F Y_F' + diag(R_F) into the packed lower triangle C (free-set order: row i of the block = constraint row fl[i]),
+  // 16 x 16 tiles of the lower triangle, k over the dofs.  false: free set too small to pay (the caller's lane-per-entry form).
+  __device__ __forceinline__ bool aff_rows(int nf_in, int nv_in, const double* Y, int ldy, const int32_t* fl, const double* eR, double* C) {
+    const int nf = __builtin_amdgcn_readfirstlane(nf_in), nv = __builtin_amdgcn_readfirstlane(nv_in);
+    if (nf < SGRL_AFF_MFMA_MIN) return false;
+    const int lo = lane & 15, hi = lane >> 4;
+    const int nt = (nf + 15) >> 4, ksteps = (nv + 3) >> 2;
+    for (int ti = 0; ti < nt; ti++) {
+      const int ri = 16 * ti + lo;
+      const double* yi = Y + fl[ri < nf ? ri : 0] * ldy;
+      for (int tj = 0; tj <= ti; tj++) {
+        const int rj = 16 * tj + lo;
+        const double* yj = Y + fl[rj < nf ? rj : 0] * ldy;
+        sgrl_v4d acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+        for (int s = 0; s < ksteps; s += 2) {
+          const int d0 = 4 * s + hi, d1 = d0 + 4;
+          const double a0 = yi[d0 < nv ? d0 : 0], b0 = yj[d0 < nv ? d0 : 0];
+          const double a1 = yi[d1 < nv ? d1 : 0], b1 = yj[d1 < nv ? d1 : 0];
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64((d0 < nv && ri < nf) ? a0 : 0.0, (d0 < nv && rj < nf) ? b0 : 0.0, acc0, 0, 0, 0);
+          if (s + 1 < ksteps)
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((d1 < nv && ri < nf) ? a1 : 0.0, (d1 < nv && rj < nf) ? b1 : 0.0, acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int r = 16 * ti + hi + 4 * i, c = 16 * tj + lo;
+          if (r < nf && c <= r) {
+            double v = acc0[i] + acc1[i];
+            if (r == c) v += eR[fl[r]];
+            C[r * (r + 1) / 2 + c] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    return true;
+  }
   __device__ __forceinline__ bool trmm_rows(int nrhs_in, int n_in, const double* T, double* Y, int ldy) {
 #ifdef SGRL_NO_TRMM
     return false;
 #endif
     const int n = __builtin_amdgcn_readfirstlane(n_in), nrhs = __builtin_amdgcn_readfirstlane(nrhs_in);
+    if (n >= SGRL_TRMM_MFMA_MIN && n <= 24) { trmm_rows_mfma(nrhs, n, T, Y, ldy); return true; }
     if (NVCAP >= 9 && n <= 9) trmm_rows_reg<9>(nrhs, n, T, Y, ldy);
     else if (NVCAP >= 12 && n <= 12) trmm_rows_reg<12>(nrhs, n, T, Y, ldy);
     else if (NVCAP >= 15 && n <= 15) trmm_rows_reg<15>(nrhs, n, T, Y, ldy);

@@ -96,7 +96,7 @@ class BatchedModularVecEnv(VecEnv):
         self.waiting = False
         self.closed = False
         # constraint-row cap per morphology: multi-geom bodies (humanoid, cheetah) can touch the floor in many places
-        rows_of = lambda m: max_rows if max_rows is not None else (64 if m.ngeom > 10 else model_pack.DEFAULT_MAX_ROWS)
+        rows_of = lambda m: max_rows if max_rows is not None else _lib.default_max_rows(m)
         self._blobs = [model_pack.pack_model(m, spec=env_spec_for(nm), max_rows=rows_of(m), pgs_iters=pgs_iters,
                                              pgs_tol=pgs_tol) for m, nm in zip(self.models, self.env_names)]
         L = _lib.lib()

@@ -17,6 +17,8 @@ bool g_reverse = false;
 bool g_linv = true;   // exercise the explicit-inverse path (what HipWave takes for nv <= 24); 0 = always the L path
 
 struct EmuWave {
+  static constexpr bool kFixedDims = false;
+  template <class M> static int hdr_const(const M& m, int idx) { return m.hdr[idx]; }
   void fence_lane() {}
   template <class T> T fenced(T v) { return v; }
   template <class F> void lanes(int n, F f) {
@@ -55,6 +57,7 @@ struct EmuWave {
   }
   // triangular solves on a packed lower triangle (reference semantics of the HipWave register versions)
   bool trmm_rows(int, int, const double*, double*, int) { return false; }   // the emulator takes the generic lanes() form
+  bool aff_rows(int, int, const double*, int, const int32_t*, const double*, double*) { return false; }
   // reference semantics of HipWave::chol_inv_packed: P <- L^-1 (packed, with diagonal)
   bool chol_inv_packed(int n, double* P, double minval) {
     if (!g_linv || n > 24) return false;
