@@ -58,7 +58,10 @@ void sgrl_engine_destroy(sgrl_engine* e);
 int sgrl_num_envs(const sgrl_engine* e);
 int sgrl_record_stride(const sgrl_engine* e);   /* doubles per env record: max over morphs of nq+nv+4 */
 int sgrl_lds_bytes(const sgrl_engine* e);       /* dynamic LDS per workgroup used by the step kernel */
-int sgrl_launch_groups(const sgrl_engine* e);   /* concurrent k_env_step dispatches one sgrl_step issues (one per LDS occupancy class) */
+int sgrl_launch_groups(const sgrl_engine* e);   /* concurrent k_env_step dispatches one sgrl_step issues (one per LDS occupancy class / kernel family) */
+/* How many of those dispatches run on a FIXED-DIMENSION kernel (sgrl_amd/csrc/step_spec.hip: the dimension sets of a shipped
+ * morphology family as compile-time constants) instead of the generic one; 0 for custom XMLs / row caps, or with SGRL_SPECS=0. */
+int sgrl_fixed_dim_groups(const sgrl_engine* e);
 
 /* VecEnv.reset(): every env starts a new episode.  obs: DEV float[n_env*obs_max_len]; obs64: DEV double[...] or NULL. */
 int sgrl_reset(sgrl_engine* e, float* obs, double* obs64, void* stream);

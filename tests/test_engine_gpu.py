@@ -261,7 +261,8 @@ def test_limits_are_rejected_loudly():
 def test_fixed_dimension_kernels_agree_with_the_generic_kernel(monkeypatch):
     """The family kernels of csrc/step_spec.hip (dimensions as compile-time constants, light families at four waves per SIMD)
     and the generic kernel are the same source: same states after 30 free-running steps to rounding (contraction of
-    multiply-adds may differ between instances), identical flags -- and the batch really ran on two family launch groups."""
+    multiply-adds may differ between instances), identical flags -- and the batch really ran on the walker family's fixed-dimension kernel.  A custom row cap has no instance:
+    generic kernel."""
     import torch
     from sgrl_amd.vec_env import BatchedModularVecEnv
     names = sorted(n for n in __import__("sgrl_amd.mjcf", fromlist=["x"]).list_assets() if "walker" in n)
@@ -269,7 +270,7 @@ def test_fixed_dimension_kernels_agree_with_the_generic_kernel(monkeypatch):
     for specs in ("0", "1"):
         monkeypatch.setenv("SGRL_SPECS", specs)
         env = BatchedModularVecEnv(names, 3, seed=21, device="cuda:0")
-        assert env.launch_groups == (1 if specs == "0" else 2)
+        assert env.launch_groups == 1 and env.fixed_dim_groups == int(specs)
         env.enable_f64_outputs()
         env.reset_device()
         g = torch.Generator(device="cuda").manual_seed(5)
@@ -283,5 +284,8 @@ def test_fixed_dimension_kernels_agree_with_the_generic_kernel(monkeypatch):
         outs.append((rec, cnt, env.obs64.cpu().numpy(), torch.stack(dones).cpu().numpy()))
         env.close()
     (r0, c0, o0, d0), (r1, c1, o1, d1) = outs
+    envc = BatchedModularVecEnv(names[:2], 2, seed=21, device="cuda:0", max_rows=40)
+    assert envc.fixed_dim_groups == 0
+    envc.close()
     assert (d0 == d1).all() and (c0[:, :3] == c1[:, :3]).all()
     assert abs(r0 - r1).max() < 1e-9 * (1 + abs(r0).max()) and abs(o0 - o1).max() < 1e-9 * (1 + abs(o0).max())

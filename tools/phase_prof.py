@@ -8,8 +8,10 @@ sys.path.insert(0, REPO)
 import numpy as np, torch
 from sgrl_amd import _lib
 prof_so = os.path.join(REPO, "sgrl_amd", "libsgrl_hip_prof.so")
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize", "-DSGRL_PHASE_PROF",
-                       "-o", prof_so, os.path.join(_lib.CSRC, "engine.hip"), os.path.join(_lib.CSRC, "set_actor.hip")])
+srcs = [os.path.join(_lib.CSRC, f) for f in ("engine.hip", "set_actor.hip", "train_gemm.hip", "render.hip")]
+if not os.path.exists(prof_so) or os.path.getmtime(prof_so) < max(os.path.getmtime(os.path.join(_lib.CSRC, f)) for f in os.listdir(_lib.CSRC)):
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize", "-DSGRL_PHASE_PROF",
+                           "-DSGRL_NO_SPECS", "-o", prof_so] + srcs)      # generic kernel only (build it before going to the GPU box)
 _lib.LIB_PATH = prof_so
 from sgrl_amd.vec_env import BatchedModularVecEnv
 names = sorted(n for n in __import__("sgrl_amd.mjcf", fromlist=["x"]).list_assets() if "walker" in n)
