@@ -109,8 +109,9 @@ def cpu_baseline(names, seed):
     nproc = min(cores, per_morph * len(names))
     return {"value": round(med[0], 1), "unit": "env-steps/s", "cores": nproc, "kind": "port",
             "sample": "median of 3 samples of %d envs (%d per walker variant) x %d steps: oracle/physics.c FP64 step on %d "
-                      "processes (%.1f s) + PyTorch-CPU SEPolicy forward B=%d per morphology (%.1f s)" % (
-                          per_morph * len(names), per_morph, steps, nproc, med[2], per_morph, med[3]),
+                      "processes (%.1f s) + PyTorch-CPU SEPolicy forward B=%d per morphology (%.1f s); %d steps per sample replace "
+                      "BASELINE.md section 3's T = 1000 so that the default run fits the driver's clock" % (
+                          per_morph * len(names), per_morph, steps, nproc, med[2], per_morph, med[3], steps),
             "samples": [round(x[0], 1) for x in samples],
             "env_only_steps_per_s": round(med[1], 1),
             "reference_shaped": {"value": round(ref_rate, 1), "unit": "env-steps/s", "cores": len(names) + 1,
@@ -156,6 +157,10 @@ def main():
     ap.add_argument("--force-collectives", action="store_true",
                     help="diagnostic: run the N > 1 code path (process group, replay gather, barriers, max-over-ranks) with "
                          "WORLD_SIZE=1 under torch.distributed.run -- what a 1-GPU box can exercise of it")
+    ap.add_argument("--set-forward-only", action="store_true",
+                    help="internal: time the SET forward alone on this process's settings and print {\"ms_per_forward\": x} "
+                         "(the parent bench starts it as a child with SGRL_SET_GEMM=f32 for the exact-f32 comparison)")
+    ap.add_argument("--regions", type=int, default=3, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--preroll", type=int, default=200,
                     help="untimed rollout steps run during set-up so that episodes are desynchronised and the timed "
                          "steps see the stationary mix of flight / stance / fallen states (not warm-up of the code)")
@@ -169,6 +174,8 @@ def main():
     # The CPU baseline forks worker processes: it must run BEFORE this process touches the GPU (a process that
     # has initialised HIP must neither fork-and-use nor exec).  Rank 0 at N=1 only.
     cpu_base = None
+    if args.set_forward_only:
+        args.no_cpu_baseline = True
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_base = cpu_baseline(WALKERS, args.seed)
     import torch
@@ -192,7 +199,36 @@ def main():
     ro = Rollout(WALKERS, args.envs_per_morph, policy=policy, seed=args.seed, device=dev, rank=rank)
     env = ro.env
     n_local = env.num_envs
+    if args.set_forward_only:
+        ro.reset()
+        for _ in range(50):
+            ro.step(ro.random_actions())
+        ms = ro.actor.time_forward(env.obs, ro.policy_actions, 5)
+        ms = min(ms, ro.actor.time_forward(env.obs, ro.policy_actions, 5))
+        print(json.dumps({"ms_per_forward": round(ms, 4), "SGRL_SET_GEMM": os.environ.get("SGRL_SET_GEMM", "")}))
+        return
     gather = ReplayGather(n_local, env.obs_max_len, env.action_max_len, dev, depth=2) if multi else None
+    # N > 1: the learner rank (0) also INGESTS the N gathered blocks of every step into its per-morphology replay rings
+    # (reference common/buffer.py:75-84 x N x envs per rank): one sgrl_ingest_rows launch per block, no host synchronisation
+    # (rollout.TransitionSink).  The blocks of step t are ingested during step t + 1, once their gather has completed.
+    sink = None
+    if multi:
+        from sgrl_amd.replay import DeviceReplayBuffer
+        from sgrl_amd.rollout import TransitionSink
+        buffers = None
+        if rank == 0:
+            cap = max(4 * world * args.envs_per_morph, 65536)
+            buffers = [DeviceReplayBuffer(41 * L, 3 * L, cap, device=dev) for L in env.num_limbs]
+        sink = TransitionSink(env.env_morph, env.num_limbs, env.obs_max_len, env.action_max_len, device=dev, buffers=buffers, dst=0)
+    state = {"pending": None, "ingest": True}
+
+    def ingest_pending():
+        if state["pending"] is not None:
+            slot, blocks = state["pending"]
+            gather._wait(slot)             # the gather that filled these blocks (issued one step ago)
+            if state["ingest"] and rank == 0:
+                sink.ingest(blocks)
+            state["pending"] = None
 
     def one_step():
         a = ro.random_actions()
@@ -201,8 +237,11 @@ def main():
         obs, rew, done, _ = ro.step(a)
         ro.policy_forward(obs)
         if gather is not None:
-            gather.pack(None, a, obs, rew, done)
-            gather.push(wait=False)        # in flight over xGMI while the next step runs; its block is reused two steps on
+            ingest_pending()               # last step's blocks: their transfer ran under this step's kernels
+            gather.pack(None, a, obs, rew, done, morph_id=sink.env_morph)
+            slot = gather._k % gather.depth
+            blocks = gather.push(wait=False)   # in flight over xGMI while the next step runs; its block is reused two steps on
+            state["pending"] = (slot, blocks) if blocks is not None else None
 
     ro.reset()
     for _ in range(args.preroll):          # synthetic-state preparation: reach the stationary episode mix
@@ -212,21 +251,34 @@ def main():
 
     def barrier():
         if gather is not None:
-            gather.drain()                 # every replay block of the timed steps has arrived before the clock stops
+            ingest_pending()
+            gather.drain()                 # every replay block of the timed steps has arrived (and is ingested) before the clock stops
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if multi:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def timed_region():
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if multi:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    # `regions` timed regions of exactly `steps` steps each (barrier + synchronize on both sides, max over ranks); the MEDIAN is
+    # what `value` / `ms_per_step` report, all samples are listed
+    samples = [timed_region() for _ in range(max(1, args.regions))]
+    dt = sorted(samples)[len(samples) // 2]
+    dt_no_ingest = None
+    if multi:                              # the same region with the learner's ingest switched off: what the ingest costs
+        state["ingest"] = False
+        dt_no_ingest = timed_region()
+        state["ingest"] = True
 
     # per-kernel timings with HIP events on the launch stream (rank 0 only; not part of the timed region above)
     extra = {}
@@ -249,11 +301,13 @@ def main():
                              "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                              "algorithmic_bytes_per_launch": int(bytes_step * n_local),
                              "ms_per_launch": round(ms_step, 4),
-                             "dispatches_per_launch": env.launch_groups,
+                             "dispatches_per_launch": env.launch_groups, "fixed_dimension_kernels": env.fixed_dim_groups,
                              "note": "latency/VALU-bound FP64 rigid-body kernel: ~2 KB of HBM traffic per env-step "
                                      "against ~1e6 FP64 operations; see DESIGN.md (roofline).  One launch = one "
-                                     "sgrl_step = dispatches_per_launch concurrent k_env_step dispatches (one per LDS "
-                                     "occupancy class); ms_per_launch is the HIP-event time of the whole launch"}
+                                     "sgrl_step = dispatches_per_launch concurrent step-kernel dispatches (one per kernel "
+                                     "family / LDS occupancy class; this workload: ONE dispatch of the walker family's "
+                                     "fixed-dimension kernel k_env_step_spec, csrc/step_spec.hip); ms_per_launch is the HIP-event "
+                                     "time of the whole launch"}
         # the VALU view of the same kernel (it is issue / latency bound, not HBM bound): SQ counters of a separate
         # rocprofv3 --pmc pass of this command, committed under profiles/
         sq = os.path.join(REPO, "profiles", "sq_pmc.json")
@@ -293,6 +347,52 @@ def main():
                                       "range_events = kernel threads that had to clamp an operand beyond +-65 000 during this run (0 = the "
                                       "two-piece form was exact to its stated bound everywhere).  The f32-MFMA peak is the yardstick the "
                                       "reference arithmetic would be priced against, not a bound of this kernel"}
+        # the exact-f32 forward next to the two-piece one: a child process with SGRL_SET_GEMM=f32 (plain products on
+        # v_mfma_f32_32x32x2_f32, the reference's arithmetic; generated-operand products bf16 x 6) -- outside the timed region
+        exact = None
+        if world == 1 and not args.force_collectives and os.environ.get("SGRL_BENCH_NO_CHILD", "") != "1":
+            import subprocess
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--set-forward-only", "--envs-per-morph", str(args.envs_per_morph)],
+                                   env=dict(os.environ, SGRL_SET_GEMM="f32", SGRL_BENCH_NO_CHILD="1"), capture_output=True, text=True, timeout=300)
+                exact = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["ms_per_forward"]
+            except Exception as e:       # diagnostics only: never fail the bench line over it
+                exact = "unavailable: %r" % (e,)
+        ro.actor.gemm_form(ro.actor.FORM_BF16X6)
+        ms_b6 = ro.actor.time_forward(env.obs, ro.policy_actions, 5)
+        ro.actor.gemm_form(0)
+        extra["set_actor"]["ms_per_forward_bf16x6"] = round(ms_b6, 4)
+        extra["set_actor"]["ms_per_forward_exact_f32"] = exact
+        if isinstance(exact, float):
+            extra["set_actor"]["env_steps_per_s_with_exact_f32_forward"] = round(n_local / ((ms_step + exact) * 1e-3), 1)
+            extra["set_actor"]["exact_f32_note"] = ("child process with SGRL_SET_GEMM=f32: plain products on v_mfma_f32_32x32x2_f32 "
+                                                    "(exact f32), generated-operand products (Gram, equivariant) bf16 x 6; the rate "
+                                                    "is n_envs / (k_env_step ms_per_launch + that forward)")
+        # replay ingest on the learner, priced on this GPU (outside the timed region at N = 1): one block of this rank's rows
+        try:
+            from sgrl_amd.replay import DeviceReplayBuffer
+            from sgrl_amd.rollout import TransitionSink, ReplayGather as _RG
+            bufs = [DeviceReplayBuffer(41 * L, 3 * L, 65536, device=dev) for L in env.num_limbs]
+            sk = sink if (sink is not None and sink.buffers is not None) else TransitionSink(
+                env.env_morph, env.num_limbs, env.obs_max_len, env.action_max_len, device=dev, buffers=bufs, dst=0)
+            g1 = sk.gather if sk is not sink else gather
+            blk = g1.pack(env.obs, ro.actions, env.obs, env.rew, env.done, morph_id=sk.env_morph)
+            for _ in range(3):
+                sk.ingest([blk])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                sk.ingest([blk])
+            e1.record()
+            torch.cuda.synchronize()
+            ms_ing = e0.elapsed_time(e1) / 10
+            extra["replay_ingest"] = {"ms_ingest_per_block": round(ms_ing, 4), "rows_per_block": n_local,
+                                      "projected_learner_ms_per_step_at_8_gpus": round(8 * ms_ing, 3),
+                                      "note": "learner-side ingest of one rank's gathered block (all rows stored): one "
+                                              "sgrl_ingest_rows launch + the slot arithmetic, no host synchronisation; at N ranks the "
+                                              "learner ingests N blocks per step, inside the timed region of an N > 1 run"}
+        except Exception as e:
+            extra["replay_ingest"] = {"error": repr(e)}
         rec, cnt = env.get_records()
         extra["row_overflow_envs"] = int((cnt[:, 2] > 0).sum())
         if cpu_base is not None:
@@ -305,6 +405,7 @@ def main():
             "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "ms_per_step_samples": [round(x / args.steps * 1e3, 4) for x in samples], "timed_regions": len(samples),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64 (dynamics) / f32 (SET actor, obs)", "data": "synthetic",
             "config": {"workload": "3D_Walker++ 8 variants x %d envs per GPU (config 3), random U(-1,1) actions, "
@@ -313,6 +414,10 @@ def main():
                        "replay_gather": "torch.distributed.gather (RCCL) of %d B/rank/step, in flight during the next step (2 blocks in turn)" % gather.bytes_per_step()
                        if gather is not None else "none (single rank)"},
         }
+        if dt_no_ingest is not None:
+            out["learner_ingest"] = {"in_timed_region": True, "blocks_per_step_on_rank0": world,
+                                     "ms_per_step_without_ingest": round(dt_no_ingest / args.steps * 1e3, 4),
+                                     "value_without_ingest": round(total_envs * args.steps / dt_no_ingest, 1)}
         out.update(extra)
         print(json.dumps(out))
     if multi:
