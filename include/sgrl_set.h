@@ -173,6 +173,13 @@ int sgrl_set_range_events(sgrl_set* s, unsigned* count, int reset);
  * with reset, sgrl_set_gemm_form): how `SEPolicy` / `SECritic` users get the warning and the form switch without asking
  * (sgrl_amd/set_hip.py HipSetActor._poll_range).  No reference counterpart: PyTorch's f32 products have f32's range. */
 unsigned sgrl_set_range_events_seen(const sgrl_set* s);
+/* Test hook: ONE product through the production tile kernels of the forward on caller-supplied device operands (kinds: plain,
+ * ReLU, row division, Gram operand, equivariant epilogue, stacked projections, residual + LayerNorm; forms as above, 1 = the
+ * exact-f32 matrix instruction for the first three) -- tests/test_split_products_gpu.py holds every instantiation the forward
+ * launches against float64 with it.  Synchronises `stream`.  Argument conventions: sgrl_amd/csrc/set_actor.hip. */
+int sgrl_set_debug_product(sgrl_set* s, int kind, int form, const float* A, int lda, const float* W, int ldw, const float* bias,
+                           float* C, int ldc, int M, int N, int K, const float* rowdiv, const float* aux_in, float* aux_out,
+                           void* stream);
 const char* sgrl_set_last_error(void);
 
 #ifdef __cplusplus

@@ -1281,6 +1281,74 @@ unsigned sgrl_set_range_events_seen(const sgrl_set* s) {
   return (s && s->h_events) ? *reinterpret_cast<volatile const unsigned*>(s->h_events) : 0u;
 }
 
+// Test hook (tests/test_split_products_gpu.py): ONE product through the production tile kernels on caller-supplied operands, so
+// that every k_gemm3 instantiation the forward launches is held against float64 by `pytest -m gpu`, not only by a lab executable.
+//   kind 0 plain | 1 ReLU | 2 row division (C = (A W' + b) / rowdiv)                 A [M, K], W [N, K], C [M, N]
+//        3 Gram operand, ReLU (A = Z [M, 96]; W [N, 576] in the folded order; fn [M] out in aux_out)
+//        4 equivariant epilogue (N = 1024: W [1024, K], rowdiv, zq [M, 96] in aux_in; tout [M, 96] out in C)
+//        5 stacked projections (N = 64: C [M, 32] <- columns 0..29, aux_out [M, 32] <- columns 32..61)
+//        6 residual + LayerNorm epilogue (N = 128: rowdiv; C [M, 128] is ln_io, read and rewritten; aux_in = ln_w | ln_b [256])
+//   form SGRL_SET_FORM_F16X3 | SGRL_SET_FORM_BF16X6 | 1 = the exact-f32 matrix instruction (k_gemm2; kinds 0..2 only)
+// Weights of the two-piece form are pre-split here exactly as k_pack does for the forward (k_encode_words).
+int sgrl_set_debug_product(sgrl_set* s, int kind, int form, const float* A, int lda, const float* W, int ldw, const float* bias,
+                           float* C, int ldc, int M, int N, int K, const float* rowdiv, const float* aux_in, float* aux_out,
+                           void* stream) {
+  if (!s || !A || !W || !C || M <= 0 || N <= 0 || K <= 0) return sfail(SGRL_ERR_ARG, "sgrl_set_debug_product: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (!GemmKernels<0>::raise_lds_limits() || !GemmKernels<EPI_RELU>::raise_lds_limits() || !GemmKernels<EPI_ROWDIV>::raise_lds_limits())
+    return sfail(SGRL_ERR_HIP, "cannot raise the dynamic LDS limit of the tile kernels");
+  unsigned* words = nullptr;
+  const size_t wn = (size_t)N * ldw;
+  g_gemm.form = form == 1 ? SGRL_SET_FORM_BF16X6 : form;
+  g_gemm.events = s->d_range_events;
+  g_gemm.w_base = W;
+  g_gemm.w_words = nullptr;
+  if (form == SGRL_SET_FORM_F16X3) {
+    if (hipMalloc(&words, sizeof(unsigned) * wn) != hipSuccess) return sfail(SGRL_ERR_HIP, "debug product: allocation failed");
+    hipLaunchKernelGGL(sgrl_gemm::k_encode_words, dim3(256), dim3(256), 0, st, W, words, (long long)wn, s->d_range_events);
+    g_gemm.w_words = words;
+  }
+  int rc = SGRL_OK;
+  if (form == 1) {
+    if (kind > 2 || (K % 16) != 0) rc = sfail(SGRL_ERR_ARG, "debug product: the exact-f32 kernel serves kinds 0..2");
+    else {
+      GemmArgs a{A, lda, W, ldw, bias, C, ldc, M, N, K, kind == 1 ? EPI_RELU : (kind == 2 ? EPI_ROWDIV : 0), rowdiv, nullptr, 0};
+      const dim3 grid(((M + 127) / 128) * ((N + 63) / 64));
+      if (kind == 0) hipLaunchKernelGGL(GemmKernels<0>::kNarrow, grid, dim3(256), GemmKernels<0>::kNarrowLds, st, a);
+      else if (kind == 1) hipLaunchKernelGGL(GemmKernels<EPI_RELU>::kNarrow, grid, dim3(256), GemmKernels<0>::kNarrowLds, st, a);
+      else hipLaunchKernelGGL(GemmKernels<EPI_ROWDIV>::kNarrow, grid, dim3(256), GemmKernels<0>::kNarrowLds, st, a);
+    }
+  } else if (kind <= 2) {
+    if (N <= 64 || (K % 32) != 0) rc = sfail(SGRL_ERR_ARG, "debug product: the split kernels serve N > 64, K % 32 == 0");
+    else rc = launch_gemm(st, A, lda, W, ldw, bias, C, ldc, M, N, K, kind == 1 ? EPI_RELU : (kind == 2 ? EPI_ROWDIV : 0), rowdiv);
+  } else if (kind == 3) {
+    if (K != GK || ldw != GK || !aux_out) rc = sfail(SGRL_ERR_ARG, "debug product: Gram operand needs K = ldw = 576 and aux_out");
+    else rc = launch_gemm_gram(st, A, W, bias, C, ldc, M, N, aux_out);
+  } else if (kind == 4) {
+    if (N != 1024 || !rowdiv || !aux_in) rc = sfail(SGRL_ERR_ARG, "debug product: equivariant epilogue needs N = 1024, rowdiv, zq");
+    else rc = launch_gemm_equiv(st, A, lda, W, ldw, bias, M, K, rowdiv, aux_in, C);
+  } else if (kind == 5) {
+    if (N != 64 || !aux_out || (K % 16) != 0) rc = sfail(SGRL_ERR_ARG, "debug product: stacked projections need N = 64 and aux_out");
+    else {
+      GemmArgs a{A, lda, W, ldw, nullptr, C, ZD, M, 64, K, EPI_ZSPLIT, nullptr, aux_out, ZD};
+      if (form == SGRL_SET_FORM_F16X3) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kProjH), hipFuncAttributeMaxDynamicSharedMemorySize, kProjHLds) != hipSuccess)
+          rc = sfail(SGRL_ERR_HIP, "debug product: LDS limit");
+        else hipLaunchKernelGGL(kProjH, dim3(((M + 127) / 128) * 1), dim3(256), kProjHLds, st, with_events(a));
+      } else if (GemmKernels<EPI_ZSPLIT>::raise_lds_limits()) GemmKernels<EPI_ZSPLIT>::launch(st, a);
+      else rc = sfail(SGRL_ERR_HIP, "debug product: LDS limit");
+    }
+  } else if (kind == 6) {
+    if (N != 128 || !rowdiv || !aux_in) rc = sfail(SGRL_ERR_ARG, "debug product: LayerNorm epilogue needs N = 128, rowdiv, ln_w | ln_b");
+    else rc = launch_gemm_ln(st, A, lda, W, ldw, bias, M, K, rowdiv, C, ldc, aux_in, aux_in + 128);
+  } else rc = sfail(SGRL_ERR_ARG, "debug product: unknown kind");
+  const hipError_t le = hipGetLastError();
+  if (rc == SGRL_OK && le != hipSuccess) rc = sfail(SGRL_ERR_HIP, std::string("debug product: launch failed: ") + hipGetErrorString(le));
+  (void)hipStreamSynchronize(st);
+  if (words) (void)hipFree(words);
+  return rc;
+}
+
 const char* sgrl_set_last_error(void) { return g_set_err.c_str(); }
 
 }  // extern "C"

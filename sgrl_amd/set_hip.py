@@ -46,6 +46,8 @@ def _bind(L):
     L.sgrl_set_range_events_seen.argtypes = [vp]
     L.sgrl_set_range_events_seen.restype = ctypes.c_uint
     L.sgrl_set_last_error.restype = ctypes.c_char_p
+    ci = ctypes.c_int
+    L.sgrl_set_debug_product.argtypes = [vp, ci, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp]
     L._set_bound = True
 
 
