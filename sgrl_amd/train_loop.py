@@ -23,7 +23,7 @@ from .td3 import Agent, default_train_args
 
 class DeviceTrainer(object):
     def __init__(self, env_names, envs_per_morph, args=None, seed=0, device="cuda:0", max_buffer_size=1000000,
-                 batch_size=None, dst=0, graph_updates=False, tune_gemms=False, **env_kw):
+                 batch_size=None, dst=0, graph_updates=False, tune_gemms=False, rollout=None, **env_kw):
         """graph_updates: replay the TD3 update from hipGraphs (td3.GraphedUpdates); tune_gemms: let PyTorch's TunableOp pick
         the rocBLAS / hipBLASLt algorithm per GEMM shape on first use (the defaults choose 256 x 256 tiles for the 700-row
         weight-gradient GEMMs of a batch-100 update: 50 -> 38 ms per update)."""
@@ -38,8 +38,15 @@ class DeviceTrainer(object):
         self.agent = Agent(self.args, device=device)
         if tune_gemms:
             torch.cuda.tunable.enable(True)
-        self.ro = Rollout(self.env_names, envs_per_morph, policy=self.agent.actor, seed=seed, device=device, rank=self.rank,
-                          max_episode_steps=self.args.max_episode_steps, **env_kw)
+        # `rollout`: a ready-made driver with the Rollout surface (env, graph_dicts, reset / step / random_actions / policy_forward /
+        # add_exploration_noise, actions) or a callable (policy, rank) -> driver; the engine-backed Rollout by default.  The
+        # multi-rank control flow of this class (round schedule, counters, actor broadcast) is covered on CPU ranks by
+        # tests/test_trainer_multirank.py with a scripted driver injected here -- the product itself never builds one.
+        if rollout is not None:
+            self.ro = rollout(self.agent.actor, self.rank) if callable(rollout) else rollout
+        else:
+            self.ro = Rollout(self.env_names, envs_per_morph, policy=self.agent.actor, seed=seed, device=device, rank=self.rank,
+                              max_episode_steps=self.args.max_episode_steps, **env_kw)
         env = self.ro.env
         self.device = env.device
         self.graph_dicts = self.ro.graph_dicts
