@@ -4,7 +4,6 @@ decomposition of the update's GPU time.  Usage: update_profile.py [morphology] [
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from oracle.formula import synth_obs
 from sgrl_amd import graph as G, mjcf
 from sgrl_amd.rollout import TRAV
 from sgrl_amd.td3 import Agent, GraphedUpdates, default_train_args
@@ -18,7 +17,12 @@ gd = G.getGraphDict(m.parents, TRAV, [], device=dev)
 agent.change_morphology(gd)
 agent.models2train()
 B, L = 100, m.num_limbs
-batch = {"obs": torch.from_numpy(synth_obs(L, B, 1).astype(np.float32)).to(dev), "next_obs": torch.from_numpy(synth_obs(L, B, 2).astype(np.float32)).to(dev),
+def synth_obs(seed):     # plausible magnitudes: positions / velocities O(1), the constant columns of the 41-float limb row
+    g = torch.Generator(device=dev).manual_seed(seed)
+    o = torch.randn((B, L, 41), device=dev, generator=g) * 0.5
+    o[:, :, 3:5] = 0; o[:, :, 5] = -9.81; o[:, :, 8] = 0
+    return o.reshape(B, 41 * L).contiguous()
+batch = {"obs": synth_obs(1), "next_obs": synth_obs(2),
          "action": (torch.rand(B, 3 * L, device=dev) * 2 - 1), "reward": torch.randn(B, 1, device=dev), "done": torch.zeros(B, 1, device=dev)}
 graphed = GraphedUpdates(agent, B) if os.environ.get("SGRL_GRAPH_UPDATES", "0") == "1" else None
 if graphed is not None:
