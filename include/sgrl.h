@@ -109,6 +109,12 @@ typedef struct sgrl_ring {
 } sgrl_ring;
 int sgrl_ingest_rows(const float* block, int n_rows, int obs_len, int act_len, const int64_t* slot, const sgrl_ring* rings,
                      int n_rings, void* stream);
+/* The same with the slot arithmetic on the device too (two launches, no host involvement): `pos` / `cap` / `pending` are DEVICE
+ * arrays of n_rings (<= 32) int64 -- the rings' write pointers (read and advanced), capacities, and a running count of rows stored
+ * per ring that the host folds into its own pointers when it next looks (rollout.py TransitionSink.fold_counters); `slot_ws`
+ * receives the n_rows slots.  Same result as sgrl_ingest_rows with the caller's slots, bit for bit. */
+int sgrl_ingest_block(const float* block, int n_rows, int obs_len, int act_len, const sgrl_ring* rings, int n_rings, int64_t* pos,
+                      const int64_t* cap, int64_t* pending, int64_t* slot_ws, void* stream);
 
 const char* sgrl_last_error(void);
 const char* sgrl_version(void);

@@ -362,23 +362,40 @@ class TransitionSink(object):
         from . import _lib
         if int(blk.shape[0]) > min(b.max_buffer_size for b in self.buffers):
             return False
-        _, _, _, _, _, store, morph = self.gather.unpack(blk)
         rings = self._ring_table()
-        m = morph.clamp(0, len(self.buffers) - 1)
-        hit = (self._ring_ids.unsqueeze(1) == m.unsqueeze(0)) & store.unsqueeze(0)              # [morphologies, rows]
-        cs = torch.cumsum(hit, dim=1, dtype=torch.int64)                                          # scans along the contiguous axis
-        counts_dev = cs[:, -1]
         if self._pend is None:
             host_pos = tuple(b._curr for b in self.buffers)
             if getattr(self, "_pos_host", None) != host_pos:      # first block, or the buffers were written / loaded elsewhere
                 self._pos_dev = torch.tensor(host_pos, dtype=torch.long, device=self.device)
-        rank = cs.gather(0, m.unsqueeze(0)).squeeze(0) - 1
-        slot = torch.where(store, (self._pos_dev[m] + rank) % self._ring_cap[m], rank.new_full((), -1))
         blk = blk if blk.is_contiguous() else blk.contiguous()
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(_lib.lib().sgrl_ingest_rows(ctypes.c_void_p(blk.data_ptr()), int(blk.shape[0]), int(self.gather.o), int(self.gather.a),
-                                               ctypes.c_void_p(slot.data_ptr()), ctypes.c_void_p(rings.data_ptr()), len(self.buffers),
-                                               ctypes.c_void_p(stream)), "sgrl_ingest_rows")
+        L = _lib.lib()
+        if len(self.buffers) <= 32:
+            # slots, write pointers and the pending counts on the device (include/sgrl.h sgrl_ingest_block): two launches
+            if self._pend is None:
+                self._pend_buf = getattr(self, "_pend_buf", None)
+                if self._pend_buf is None:
+                    self._pend_buf = torch.zeros(len(self.buffers), dtype=torch.long, device=self.device)
+                else:
+                    self._pend_buf.zero_()
+                self._pend = self._pend_buf
+            if getattr(self, "_slot_ws", None) is None or self._slot_ws.numel() < blk.shape[0]:
+                self._slot_ws = torch.empty(int(blk.shape[0]), dtype=torch.long, device=self.device)
+            _lib.check(L.sgrl_ingest_block(ctypes.c_void_p(blk.data_ptr()), int(blk.shape[0]), int(self.gather.o), int(self.gather.a),
+                                           ctypes.c_void_p(rings.data_ptr()), len(self.buffers), ctypes.c_void_p(self._pos_dev.data_ptr()),
+                                           ctypes.c_void_p(self._ring_cap.data_ptr()), ctypes.c_void_p(self._pend.data_ptr()),
+                                           ctypes.c_void_p(self._slot_ws.data_ptr()), ctypes.c_void_p(stream)), "sgrl_ingest_block")
+            return True
+        _, _, _, _, _, store, morph = self.gather.unpack(blk)
+        m = morph.clamp(0, len(self.buffers) - 1)
+        hit = (self._ring_ids.unsqueeze(1) == m.unsqueeze(0)) & store.unsqueeze(0)              # [morphologies, rows]
+        cs = torch.cumsum(hit, dim=1, dtype=torch.int64)                                          # scans along the contiguous axis
+        counts_dev = cs[:, -1]
+        rank = cs.gather(0, m.unsqueeze(0)).squeeze(0) - 1
+        slot = torch.where(store, (self._pos_dev[m] + rank) % self._ring_cap[m], rank.new_full((), -1))
+        _lib.check(L.sgrl_ingest_rows(ctypes.c_void_p(blk.data_ptr()), int(blk.shape[0]), int(self.gather.o), int(self.gather.a),
+                                      ctypes.c_void_p(slot.data_ptr()), ctypes.c_void_p(rings.data_ptr()), len(self.buffers),
+                                      ctypes.c_void_p(stream)), "sgrl_ingest_rows")
         self._pos_dev = (self._pos_dev + counts_dev) % self._ring_cap      # the device copy follows without an upload
         self._pend = counts_dev if self._pend is None else self._pend + counts_dev
         return True
