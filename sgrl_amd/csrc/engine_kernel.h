@@ -42,7 +42,8 @@ struct BatchArgs {
   const int32_t* block_env;   // [n_env] workgroup -> env, most expensive morphologies first (tail balance)
   double* rec;                // [n_env * stride]
   int32_t* cnt;               // [n_env * 4]
-  double* scratch;            // [n_env * kScratchDoubles] HBM slabs for the rare > 32-row constraint solves
+  double* scratch;            // [n_env * scratch_stride] HBM slabs for the constraint solves with more rows than the LDS arrays hold
+  int scratch_stride;         // doubles per environment: max over the batch's morphologies of slab_doubles(max_rows, ldy)
   int stride;
   int n_env;
   int obs_max_len, action_max_len;
@@ -121,7 +122,7 @@ __device__ __forceinline__ sgrl::StepIO make_io(const BatchArgs& a, const StepOu
   io.dist = out.dist ? out.dist + env : nullptr;
   io.truncated = out.truncated ? out.truncated + env : nullptr;
   io.obs_max_len = a.obs_max_len;
-  io.scratch = a.scratch ? a.scratch + (size_t)env * sgrl::kScratchDoubles : nullptr;
+  io.scratch = a.scratch ? a.scratch + (size_t)env * a.scratch_stride : nullptr;
   io.seed = a.seed;
   io.env_id = a.env_id_base + (uint32_t)env;
   io.max_episode_steps = a.max_episode_steps;

@@ -46,9 +46,14 @@ constexpr double kMaxImp = 0.9999;
 constexpr double kPi = 3.14159265358979323846;
 constexpr int kNAMax = 32;                        // most rows whose factor the LDS scratch (dead zone) is asked to hold
 constexpr int kBppMaxIter = 40;                   // block-pivot rounds before giving up (-> Gauss-Seidel)
-constexpr int kSlabRows = 64;                     // most constraint rows an evaluation may have (HBM slab path)
+constexpr int kSlabRows = 256;                    // most constraint rows an evaluation may have (HBM slab path; the row cap of a morphology)
+constexpr int kPivotRows = 64;                    // ... of which the exact block-pivot solve takes up to this many (free set = 64-bit mask);
+                                                  // evaluations with more rows run Gauss-Seidel over the rows in the slab (pgs_big)
+constexpr int kPrevRows = 64;                     // warm-start memory (LDS): the first rows of the previous evaluation
 constexpr int kSlabLdy = 47;                      // largest Y row stride served: nv <= 46
-constexpr int kScratchDoubles = 5632;              // per-env HBM slab (Engine::rows_hbm): factor | Y | row arrays for 64 rows
+// per-env HBM slab (Engine::rows_hbm): factor of a <= 64-row free set | Y | five row arrays | four int row arrays
+SGRL_HD int slab_doubles(int maxrows, int ldy) { return kPivotRows * (kPivotRows + 1) / 2 + (maxrows + 1) * ldy + 5 * maxrows + 2 * maxrows + 8; }
+constexpr int kScratchDoublesMax = 2080 + 257 * 47 + 7 * 256 + 8;     // slab_doubles(kSlabRows, kSlabLdy): what a test harness may allocate
 
 // ------------------------------------------------------------------------------------------------
 // LDS layout (offsets in doubles for S, in ints for I)
@@ -107,7 +112,8 @@ SGRL_HD void make_layout_rows(const int32_t* hdr, Layout* o, int n_int, int n_f6
   o->Y = p; p += (o->lrows + 1) * o->ldy;
   o->eR = p; p += o->lrows; o->earef = p; p += o->lrows; o->eb = p; p += o->lrows;
   o->ef = p; p += o->lrows;
-  o->eidg = p; p += o->lrows; o->prev_f = p; p += o->maxrows;
+  const int prevcap = o->maxrows < kPrevRows ? o->maxrows : kPrevRows;
+  o->eidg = p; p += o->lrows; o->prev_f = p; p += prevcap;
   o->misc = p; p += 16;
   o->Mfull = p;
   if (hdr[SGRL_H_INTEGRATOR] == 0) p += nv * (nv + 1) / 2;
@@ -116,7 +122,7 @@ SGRL_HD void make_layout_rows(const int32_t* hdr, Layout* o, int n_int, int n_f6
   int q = 0;
   o->con_valid = q; q += o->ncon;
   o->row_kind = q; q += o->lrows; o->row_src = q; q += o->lrows; o->row_sub = q; q += o->lrows;
-  o->prev_key = q; q += o->maxrows;
+  o->prev_key = q; q += prevcap;
   o->flist = q; q += o->lrows;
   o->ecnt = q; q += 2 * nj + o->ncon;
   o->icnt = q; q += 8;
@@ -743,17 +749,16 @@ struct Engine {
     return Rows{S + o.Y, S + o.eR, S + o.earef, S + o.eb, S + o.ef, S + o.eidg, S + o.dead,
                 I + o.row_kind, I + o.row_src, I + o.row_sub, I + o.flist};
   }
-  SGRL_DEV Rows rows_hbm() const {   // slab: C[64*65/2] | Y[65][47] | 5 x 64 doubles | 4 x 64 ints
-    static_assert(kSlabRows * (kSlabRows + 1) / 2 + (kSlabRows + 1) * kSlabLdy + 5 * kSlabRows + 4 * kSlabRows / 2 <= kScratchDoubles,
-                  "HBM slab layout exceeds kScratchDoubles");
+  SGRL_DEV Rows rows_hbm() const {   // slab: C[64*65/2] | Y[maxrows + 1][ldy] | 5 x maxrows doubles | 4 x maxrows ints  (slab_doubles)
     double* p = big_scratch;
+    const int mr = o.maxrows;
     Rows r;
-    r.C = p; p += kSlabRows * (kSlabRows + 1) / 2;
-    r.Y = p; p += (kSlabRows + 1) * kSlabLdy;
-    r.eR = p; p += kSlabRows; r.earef = p; p += kSlabRows; r.eb = p; p += kSlabRows; r.ef = p; p += kSlabRows;
-    r.eidg = p; p += kSlabRows;
+    r.C = p; p += kPivotRows * (kPivotRows + 1) / 2;
+    r.Y = p; p += (mr + 1) * o.ldy;
+    r.eR = p; p += mr; r.earef = p; p += mr; r.eb = p; p += mr; r.ef = p; p += mr;
+    r.eidg = p; p += mr;
     int32_t* q = reinterpret_cast<int32_t*>(p);
-    r.kind = q; r.src = q + kSlabRows; r.sub = q + 2 * kSlabRows; r.flist = q + 3 * kSlabRows;
+    r.kind = q; r.src = q + mr; r.sub = q + 2 * mr; r.flist = q + 3 * mr;
     return r;
   }
 
@@ -1089,7 +1094,7 @@ struct Engine {
         if (!BIG) {
           solved = lcp_block_pivot<true>(R, nrow, thresh, &sweeps);             // rows and factor scratch in LDS
           if (!solved) diag_code |= 1 << 8;                                     // diagnostics: block pivoting gave up
-        } else if (nrow <= 64) {
+        } else if (nrow <= kPivotRows) {
           // rare (a few envs per 8192-env launch): more rows than the LDS arrays hold -> the same exact solve with
           // rows and factor in this environment's HBM scratch slab
           solved = lcp_block_pivot<false>(R, nrow, thresh, &sweeps);
@@ -1099,18 +1104,22 @@ struct Engine {
       if (!solved) {
         // matrix-free projected Gauss-Seidel, the policy keeps v = Y'f one entry per lane (also the SOLVER = 0 path)
         diag_code |= 1;
-        sweeps = w.pgs(nrow, nv, R.Y, ldy, R.eb, R.eR, R.eidg, R.ef, S + o.vpgs,
-                       m.hdr[SGRL_H_PGS_ITERS], thresh);
+        if (BIG && nrow > kPivotRows)     // more rows than the register version keeps: rows streamed from the slab
+          sweeps = w.pgs_big(nrow, nv, R.Y, ldy, R.eb, R.eR, R.eidg, R.ef, S + o.vpgs, m.hdr[SGRL_H_PGS_ITERS], thresh);
+        else
+          sweeps = w.pgs(nrow, nv, R.Y, ldy, R.eb, R.eR, R.eidg, R.ef, S + o.vpgs, m.hdr[SGRL_H_PGS_ITERS], thresh);
       }
     }
     SGRL_TICK(7);
     // remember the solution for the next evaluation's warm start
-    w.lanes(nrow > 0 ? nrow : 1, [&](int r) {
-      if (r < nrow) {
+    const int prevcap = o.maxrows < kPrevRows ? o.maxrows : kPrevRows;       // the warm-start memory keeps the first rows
+    const int nkeep = nrow < prevcap ? nrow : prevcap;
+    w.lanes(nkeep > 0 ? nkeep : 1, [&](int r) {
+      if (r < nkeep) {
         I[o.prev_key + r] = (R.kind[r] << 16) | (R.src[r] << 3) | R.sub[r];
         S[o.prev_f + r] = R.ef[r];
       }
-      if (r == 0) { I[o.icnt + IC_PREV_N] = nrow; I[o.icnt + IC_SWEEPS] += sweeps; I[o.icnt + IC_ROWSUM] += diag_code; }
+      if (r == 0) { I[o.icnt + IC_PREV_N] = nkeep; I[o.icnt + IC_SWEEPS] += sweeps; I[o.icnt + IC_ROWSUM] += diag_code; }
     });
     // qacc = L^-T (ys + Y' f)
     if (linv) {
@@ -1400,7 +1409,7 @@ struct StepIO {
   float* reward; uint8_t* done; float* dist; uint8_t* truncated;  // scalars for this env (nullable)
   double* reward64;      // nullable
   int obs_max_len;
-  double* scratch;       // per-env HBM slab (SGRL_SCRATCH_DOUBLES doubles) or null
+  double* scratch;       // per-env HBM slab (slab_doubles(max_rows, ldy) doubles) or null
   uint64_t seed; uint32_t env_id; int max_episode_steps; int auto_reset;
 };
 

@@ -156,6 +156,45 @@ struct HipWaveT {
     __syncthreads();
     return it;
   }
+  // The same iteration for ANY number of rows (evaluations with more than 64: the block-pivot solve does not take them, the
+  // register version above does not hold them): row scalars and Y rows stream from the environment's HBM slab, the operands
+  // of row r + 1 are requested before the arithmetic of row r; lane d keeps v[d].  Slow (a few hundred cycles per row and
+  // sweep) and rare: contact-rich states of the many-geom morphologies (a cheetah lying on the floor).
+  __device__ __forceinline__ int pgs_big(int n_in, int nv_in, const double* Y, int ldy, const double* b, const double* R,
+                                          const double* idg, double* f, double* v, int iters_in, double thresh) {
+    const int n = __builtin_amdgcn_readfirstlane(n_in), nv = __builtin_amdgcn_readfirstlane(nv_in);
+    const int iters = __builtin_amdgcn_readfirstlane(iters_in);
+    const bool dofl = lane < nv;
+    const int dl = dofl ? lane : 0;
+    double vv = 0.0;
+    for (int r = 0; r < n; r++) {
+      const double fr = f[r];
+      const double y = Y[r * ldy + dl];
+      if (dofl) vv += y * fr;
+    }
+    int it = 0;
+    for (; it < iters; it++) {
+      double change = 0.0;
+      double yn = Y[dl], bn = b[0], Rn = R[0], in_ = idg[0], fn_ = f[0];
+      for (int r = 0; r < n; r++) {
+        const double y = dofl ? yn : 0.0, br = bn, Rr = Rn, ir = in_, fr = fn_;
+        if (r + 1 < n) { yn = Y[(r + 1) * ldy + dl]; bn = b[r + 1]; Rn = R[r + 1]; in_ = idg[r + 1]; fn_ = f[r + 1]; }
+        const double dot = wave_sum(y * vv);
+        const double res = br + Rr * fr + dot;
+        double fnew = fr - res * ir;
+        fnew = fnew < 0.0 ? 0.0 : fnew;
+        const double df = fnew - fr;
+        vv += y * df;
+        if (lane == 0) f[r] = fnew;
+        change = fmax(change, fabs(df) / ir);
+      }
+      __syncthreads();                  // this sweep's stores of f before the next sweep's loads
+      if (change < thresh) { it++; break; }
+    }
+    if (dofl) v[lane] = vv;
+    __syncthreads();
+    return it;
+  }
   // ---- triangular solves on a packed lower triangle in LDS (entry (i, j) at i(i+1)/2 + j), n <= 64 ---------------------
   // The serial recurrences run on registers: lane = matrix row (or right-hand side), pivots / solution entries are
   // broadcast with v_readlane, so the dependent chain per step is a few ALU ops instead of an LDS round trip.

@@ -55,6 +55,8 @@ struct EmuWave {
     }
     return iters;
   }
+  int pgs_big(int n, int nv, const double* Y, int ldy, const double* b, const double* R, const double* idg, double* f, double* v,
+              int iters, double thresh) { return pgs(n, nv, Y, ldy, b, R, idg, f, v, iters, thresh); }
   // triangular solves on a packed lower triangle (reference semantics of the HipWave register versions)
   bool trmm_rows(int, int, const double*, double*, int) { return false; }   // the emulator takes the generic lanes() form
   bool aff_rows(int, int, const double*, int, const int32_t*, const double*, double*) { return false; }
@@ -125,7 +127,7 @@ int sgrl_emu_forward(const int32_t* ib, const double* fb, double* qpos, const do
   std::vector<int32_t> I(o.i_total + 2, -12345);
   EmuWave w;
   sgrl::Engine<EmuWave> e(w, m, o, S.data(), I.data());
-  static std::vector<double> fscratch(sgrl::kScratchDoubles);
+  static std::vector<double> fscratch(sgrl::kScratchDoublesMax);
   e.big_scratch = fscratch.data();
   for (int i = 0; i < m.nq; i++) S[o.qpos + i] = qpos[i];
   for (int i = 0; i < m.nv; i++) S[o.qvel + i] = qvel[i];
@@ -156,7 +158,7 @@ int sgrl_emu_env(int op, const int32_t* ib, const double* fb, double* rec, int32
   sgrl::StepIO io;
   io.rec = rec; io.cnt = cnt; io.action = action; io.obs32 = obs32; io.obs64 = obs64; io.reward = nullptr;
   io.done = done; io.dist = dist; io.truncated = truncated; io.reward64 = reward64; io.obs_max_len = obs_max_len;
-  static std::vector<double> scratch(sgrl::kScratchDoubles);
+  static std::vector<double> scratch(sgrl::kScratchDoublesMax);
   io.scratch = scratch.data();
   io.seed = seed; io.env_id = env_id; io.max_episode_steps = max_episode_steps; io.auto_reset = auto_reset;
   if (op == 0) sgrl::env_reset(w, m, o, S.data(), I.data(), io, false);

@@ -10,7 +10,10 @@ for name, d in (("fetch", fetch_dir), ("write", write_dir)):
     acc = collections.defaultdict(list)
     for r in rows:
         m = re.search(r"(k_[a-z_0-9]+)[<(]", r["Kernel_Name"])
-        acc[m.group(1) if m else r["Kernel_Name"][:60]].append(float(r["Counter_Value"]))
+        k = m.group(1) if m else r["Kernel_Name"][:60]
+        if k.startswith("k_env_step"):      # generic kernel and the fixed-dimension family kernels (k_env_step_spec): one row
+            k = "k_env_step"
+        acc[k].append(float(r["Counter_Value"]))
     with open("profiles/%s_pmc_%s_size_summary.csv" % (tag, name), "w") as f:
         f.write("kernel,counter,launches,mean_KB,min_KB,max_KB\n")
         for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
@@ -30,7 +33,7 @@ for i in range(0, len(tr) - groups + 1, groups):
 half = len(spans) // 2   # the second half of the run is the stationary episode mix (after the pre-roll)
 span_ms = float(np.mean(spans[half:])) if spans else None
 out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 5 --warmup 3 --no-cpu-baseline (two separate passes)",
-       "envs_per_gpu": json.loads(line)["config"]["envs_per_gpu"], "kernel": "k_env_step",
+       "envs_per_gpu": json.loads(line)["config"]["envs_per_gpu"], "kernel": "k_env_step (this workload: k_env_step_spec, the walker family's fixed-dimension kernel)",
        "FETCH_SIZE_KB_per_launch_mean": round(means["fetch"][0], 1), "WRITE_SIZE_KB_per_launch_mean": round(means["write"][0], 1),
        "dispatches_per_launch": groups, "dispatches": means["fetch"][1],
        "k_env_step_bytes_per_launch": int((means["fetch"][0] + means["write"][0]) * 1024 * groups),
