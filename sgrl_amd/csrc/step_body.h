@@ -315,6 +315,22 @@ struct Engine {
   }
 
   // ---- position stage -------------------------------------------------------------------------
+  // rotate v by the unit quaternion q (through its matrix, as the oracle does)
+  SGRL_DEV static void quat_rot(double* r, const double* q, const double* v) {
+    double mtx[9];
+    quat2mat(mtx, q);
+    mat_vec(r, mtx, v);
+  }
+
+  // Body poses.  A body's pose is the product of the LOCAL transforms along its chain, and what made the chain walk slow was
+  // not its arithmetic but the look-ups inside it (path -> joints of the body -> per-joint constants: four dependent LDS round
+  // trips per joint, three joints per level).  So the local transform of every body -- body offset, then its hinges: rotation
+  // about the anchor -- is composed FIRST, one lane per body (phase 2), and the walk (phase 3) is one quaternion product and one
+  // rotated offset per level with every operand address known up front.  Joint anchors / axes in the world frame follow from
+  // the parent's pose, one lane per hinge (phase 4).  Same products as oracle/physics.c kinematics() in another association
+  // (and one normalisation per body at the end of its own chain instead of one per level): agreement to rounding.
+  // Scratch: the constraint rows' Y block, dead until build_rows -- per joint 17 doubles (rotation 4 | axis 3 | position 3 |
+  // local quaternion before the joint 4 | local anchor 3), per body 7 (local offset 3 | local quaternion 4).
   SGRL_DEV void kinematics() {
     // root quaternion normalised in place first (mj_kinematics of 2.1.0 [3P-knowledge]; oracle/physics.c kinematics())
     w.lanes(1, [&](int) {
@@ -322,24 +338,44 @@ struct Engine {
       quat_normalize(q);
       S[o.qpos + 3] = q[0]; S[o.qpos + 4] = q[1]; S[o.qpos + 5] = q[2]; S[o.qpos + 6] = q[3];
     });
-    // First, in parallel: one lane per hinge evaluates its rotation (the sincos of a chain would otherwise run serially,
-    // once per descendant), and the model constants the chain walk needs are copied from the float tables (L2) into
-    // LDS.  Parked in arrays that are dead until later phases refill them: 7 doubles per joint (rotation quaternion,
-    // axis) in the contact block, 7 per body (pos, quat) in the composite-inertia array.
-    const int jq = o.con_pos, bq = o.crb, jpq = o.cinert;     // jpq: 3 doubles per joint (position in the body frame)
-    w.lanes(o.nj > o.nb ? o.nj : o.nb, [&](int j) {
-      if (j < o.nb && j >= 1) {
-        for (int k = 0; k < 3; k++) S[bq + 10 * j + k] = m.body_pos[3 * j + k];
-        for (int k = 0; k < 4; k++) S[bq + 10 * j + 3 + k] = m.body_quat[4 * j + k];
-      }
-      if (j >= o.nj || m.jnt_type[j] == SGRL_JNT_FREE) return;
+    const int TJ = o.Y, TB = o.Y + 17 * o.nj;
+    // phase 1: one lane per hinge -- its rotation (sincos once per joint) and its constants from the float tables (L2)
+    w.lanes(o.nj, [&](int j) {
+      if (m.jnt_type[j] == SGRL_JNT_FREE) return;
       double ja[3], ql[4];
       ld3(ja, m.jnt_axis + 3 * j);
       const int qa = m.jnt_qposadr[j];
       axisangle2quat(ql, ja, S[o.qpos + qa] - m.qpos0[qa]);
-      for (int k = 0; k < 4; k++) S[jq + 7 * j + k] = ql[k];
-      for (int k = 0; k < 3; k++) { S[jq + 7 * j + 4 + k] = ja[k]; S[jpq + 3 * j + k] = m.jnt_pos[3 * j + k]; }
+      double* t = S + TJ + 17 * j;
+      for (int k = 0; k < 4; k++) t[k] = ql[k];
+      for (int k = 0; k < 3; k++) { t[4 + k] = ja[k]; t[7 + k] = m.jnt_pos[3 * j + k]; }
     });
+    // phase 2: one lane per body below the torso -- local transform (parent frame -> body frame after its joints)
+    w.lanes(o.nb, [&](int c) {
+      if (c < 2) return;
+      double p[3], q[4];
+      ld3(p, m.body_pos + 3 * c);
+      for (int k = 0; k < 4; k++) q[k] = m.body_quat[4 * c + k];
+      const int j0 = m.body_jntadr[c], jn = m.body_jntnum[c];
+      for (int j = j0; j < j0 + jn; j++) {
+        double* t = S + TJ + 17 * j;
+        double ql[4], jp[3], anchor[3], v[3], qn[4];
+        for (int k = 0; k < 4; k++) ql[k] = t[k];
+        ld3(jp, t + 7);
+        quat_rot(v, q, jp);
+        for (int k = 0; k < 3; k++) anchor[k] = p[k] + v[k];
+        for (int k = 0; k < 4; k++) t[10 + k] = q[k];              // local orientation BEFORE this joint: what turns its axis
+        for (int k = 0; k < 3; k++) t[14 + k] = anchor[k];
+        quat_mul(qn, q, ql);
+        for (int k = 0; k < 4; k++) q[k] = qn[k];
+        quat_rot(v, q, jp);                                        // exactly zero for a joint at the body origin
+        for (int k = 0; k < 3; k++) p[k] = anchor[k] - v[k];
+      }
+      double* u = S + TB + 7 * c;
+      for (int k = 0; k < 3; k++) u[k] = p[k];
+      for (int k = 0; k < 4; k++) u[3 + k] = q[k];
+    });
+    // phase 3: one lane per body -- its own chain of local transforms
     w.lanes(o.nb, [&](int b) {
       if (b == 0) {
         for (int k = 0; k < 3; k++) S[o.xpos + k] = 0;
@@ -352,42 +388,20 @@ struct Engine {
       // level 0 = torso with the free joint
       for (int k = 0; k < 3; k++) pos[k] = S[o.qpos + k];
       for (int k = 0; k < 4; k++) quat[k] = S[o.qpos + 3 + k];
-      if (b == 1) {
-        for (int k = 0; k < 3; k++) { S[o.xanchor + k] = pos[k]; S[o.xaxis + k] = (k == 2) ? 1.0 : 0.0; }
+      quat_normalize(quat);
+      for (int lvl = 1; lvl < depth; lvl++) {
+        const int c = m.body_path[8 * b + lvl];
+        const double* u = S + TB + 7 * c;
+        double pl[3], qloc[4], t[3], qn[4];
+        ld3(pl, u);
+        for (int k = 0; k < 4; k++) qloc[k] = u[3 + k];
+        quat_rot(t, quat, pl);
+        for (int k = 0; k < 3; k++) pos[k] += t[k];
+        quat_mul(qn, quat, qloc);
+        for (int k = 0; k < 4; k++) quat[k] = qn[k];
       }
       quat_normalize(quat);
       quat2mat(mat, quat);
-      for (int lvl = 1; lvl < depth; lvl++) {
-        const int c = m.body_path[8 * b + lvl];
-        double t[3], bp[3], bqv[4], qn[4];
-        ld3(bp, S + bq + 10 * c);
-        mat_vec(t, mat, bp);
-        for (int k = 0; k < 3; k++) pos[k] += t[k];
-        for (int k = 0; k < 4; k++) bqv[k] = S[bq + 10 * c + 3 + k];
-        quat_mul(qn, quat, bqv);
-        for (int k = 0; k < 4; k++) quat[k] = qn[k];
-        const int j0 = m.body_jntadr[c], jn = m.body_jntnum[c];
-        for (int j = j0; j < j0 + jn; j++) {
-          double r[9], jp[3], ja[3], anchor[3], axis[3], ql[4], v[3];
-          quat2mat(r, quat);
-          ld3(jp, S + jpq + 3 * j); ld3(ja, S + jq + 7 * j + 4);
-          const bool at_origin = (jp[0] == 0.0 && jp[1] == 0.0 && jp[2] == 0.0);   // global-coordinate MJCFs
-          if (at_origin) { t[0] = 0; t[1] = 0; t[2] = 0; } else mat_vec(t, r, jp);
-          for (int k = 0; k < 3; k++) anchor[k] = pos[k] + t[k];
-          mat_vec(axis, r, ja);
-          if (c == b) for (int k = 0; k < 3; k++) { S[o.xanchor + 3 * j + k] = anchor[k]; S[o.xaxis + 3 * j + k] = axis[k]; }
-          for (int k = 0; k < 4; k++) ql[k] = S[jq + 7 * j + k];
-          quat_mul(qn, quat, ql);
-          for (int k = 0; k < 4; k++) quat[k] = qn[k];
-          if (!at_origin) {
-            quat2mat(r, quat);
-            mat_vec(v, r, jp);
-            for (int k = 0; k < 3; k++) pos[k] = anchor[k] - v[k];
-          }
-        }
-        quat_normalize(quat);
-        quat2mat(mat, quat);
-      }
       for (int k = 0; k < 3; k++) S[o.xpos + 3 * b + k] = pos[k];
       for (int k = 0; k < 4; k++) S[o.xquat + 4 * b + k] = quat[k];
       for (int k = 0; k < 9; k++) S[o.xmat + 9 * b + k] = mat[k];
@@ -396,17 +410,36 @@ struct Engine {
       mat_vec(t, mat, ip);
       for (int k = 0; k < 3; k++) S[o.xipos + 3 * b + k] = pos[k] + t[k];
     });
+    // phase 4: one lane per joint -- anchor and axis in the world frame from the PARENT body's pose
+    w.lanes(o.nj, [&](int j) {
+      if (m.jnt_type[j] == SGRL_JNT_FREE) {
+        const int b = m.jnt_body[j];
+        for (int k = 0; k < 3; k++) { S[o.xanchor + 3 * j + k] = S[o.xpos + 3 * b + k]; S[o.xaxis + 3 * j + k] = (k == 2) ? 1.0 : 0.0; }
+        return;
+      }
+      const int par = m.body_parent[m.jnt_body[j]];
+      const double* t = S + TJ + 17 * j;
+      double pp[3], qp[4], qb[4], ql[4], al[3], ja[3], v[3], ax[3];
+      ld3(pp, S + o.xpos + 3 * par);
+      for (int k = 0; k < 4; k++) { qp[k] = S[o.xquat + 4 * par + k]; ql[k] = t[10 + k]; }
+      ld3(al, t + 14); ld3(ja, t + 4);
+      quat_rot(v, qp, al);
+      quat_mul(qb, qp, ql);
+      quat_rot(ax, qb, ja);
+      for (int k = 0; k < 3; k++) { S[o.xanchor + 3 * j + k] = pp[k] + v[k]; S[o.xaxis + 3 * j + k] = ax[k]; }
+    });
   }
 
   SGRL_DEV void com_pos() {
     const double mt = m.fhdr[SGRL_F_TOTAL_MASS];
-    for (int k = 0; k < 3; k++) {
-      const double c = w.sum(o.nb, [&](int b) { return b == 0 ? 0.0 : m.body_mass[b] * S[o.xipos + 3 * b + k]; });
-      w.lanes(1, [&](int) { S[o.misc + MS_COM + k] = c / mt; });
-    }
+    // the three wave sums come back in every lane: they are used straight from registers by the phase below (one phase
+    // instead of seven); lane 0 also parks them in LDS for the later stages (constraint rows, body velocities)
+    double comr[3];
+    for (int k = 0; k < 3; k++)
+      comr[k] = w.sum(o.nb, [&](int b) { return b == 0 ? 0.0 : m.body_mass[b] * S[o.xipos + 3 * b + k]; }) / mt;
     w.lanes(o.nb > o.nv ? o.nb : o.nv, [&](int i) {
-      double com[3];
-      ld3(com, S + o.misc + MS_COM);
+      const double com[3] = {comr[0], comr[1], comr[2]};
+      if (i == 0) for (int k = 0; k < 3; k++) S[o.misc + MS_COM + k] = com[k];
       if (i >= 1 && i < o.nb) {
         const int b = i;
         double R[9], Wm[9], RI[9];
@@ -947,14 +980,17 @@ struct Engine {
     w.lanes(nrow > nv ? nrow : nv, [&](int r) {
       if (r < nrow) {
         const double* Yr = R.Y + r * ldy;
-        double s2 = 0;
-        for (int d = 0; d < nv; d++) s2 += Yr[d] * Yr[d];
-        const double Rr = R.eR[r];
-        R.eidg[r] = 1.0 / (s2 + Rr);
-        double s = 0;
         const double* ys = R.Y + nrow * ldy;      // the half-solved smooth force: the extra right-hand side
-        for (int d = 0; d < nv; d++) s += Yr[d] * ys[d];
-        R.eb[r] = s - R.earef[r];
+        double q0 = 0, q1 = 0, t0 = 0, t1 = 0;    // two chains per dot product
+        int d = 0;
+        for (; d + 2 <= nv; d += 2) {
+          const double y0 = Yr[d], y1 = Yr[d + 1];
+          q0 += y0 * y0; q1 += y1 * y1; t0 += y0 * ys[d]; t1 += y1 * ys[d + 1];
+        }
+        for (; d < nv; d++) { q0 += Yr[d] * Yr[d]; t0 += Yr[d] * ys[d]; }
+        const double Rr = R.eR[r];
+        R.eidg[r] = 1.0 / ((q0 + q1) + Rr);
+        R.eb[r] = (t0 + t1) - R.earef[r];
       }
       if (r < nv) S[o.vpgs + r] = 0;
     });
@@ -996,14 +1032,15 @@ struct Engine {
         const int fi = R.flist[i], fj = R.flist[j];
         const double* yi = R.Y + fi * ldy;
         const double* yj = R.Y + fj * ldy;
-        double a = 0;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;      // four independent chains: a dot product over nv is latency, not work
         int d = 0;
         for (; d + 4 <= nv; d += 4) {
           const double a0 = yi[d], a1 = yi[d + 1], a2 = yi[d + 2], a3 = yi[d + 3];
           const double b0 = yj[d], b1 = yj[d + 1], b2 = yj[d + 2], b3 = yj[d + 3];
-          a += a0 * b0; a += a1 * b1; a += a2 * b2; a += a3 * b3;
+          s0 += a0 * b0; s1 += a1 * b1; s2 += a2 * b2; s3 += a3 * b3;
         }
-        for (; d < nv; d++) a += yi[d] * yj[d];
+        for (; d < nv; d++) s0 += yi[d] * yj[d];
+        double a = (s0 + s1) + (s2 + s3);
         if (i == j) a += R.eR[fi];
         C[p] = a;
       });
@@ -1052,16 +1089,23 @@ struct Engine {
       }
       // u = Y_F' x  (= Y' f for the candidate f);  violations: x_i < 0 on F, (Y_i u + b_i) < -thresh on the complement
       w.lanes(nv, [&](int d) {
-        double u = 0;
-        for (int k = 0; k < nf; k++) u += R.Y[R.flist[k] * ldy + d] * xwp[k];
-        S[o.vpgs + d] = u;
+        double u0 = 0, u1 = 0;
+        int k = 0;
+        for (; k + 2 <= nf; k += 2) { u0 += R.Y[R.flist[k] * ldy + d] * xwp[k]; u1 += R.Y[R.flist[k + 1] * ldy + d] * xwp[k + 1]; }
+        if (k < nf) u0 += R.Y[R.flist[k] * ldy + d] * xwp[k];
+        S[o.vpgs + d] = u0 + u1;
       });
       const uint64_t V = w.ballot(n, [&](int i) {
         if ((F >> i) & 1ull) return xwp[popcount64(F & ((1ull << i) - 1ull))] < -thresh * R.eidg[i];
         const double* yi = R.Y + i * ldy;
-        double y = R.eb[i];
-        for (int d = 0; d < nv; d++) y += yi[d] * S[o.vpgs + d];
-        return y < -thresh;
+        double y0 = R.eb[i], y1 = 0, y2 = 0, y3 = 0;
+        int d = 0;
+        for (; d + 4 <= nv; d += 4) {
+          y0 += yi[d] * S[o.vpgs + d]; y1 += yi[d + 1] * S[o.vpgs + d + 1];
+          y2 += yi[d + 2] * S[o.vpgs + d + 2]; y3 += yi[d + 3] * S[o.vpgs + d + 3];
+        }
+        for (; d < nv; d++) y0 += yi[d] * S[o.vpgs + d];
+        return (y0 + y1) + (y2 + y3) < -thresh;
       });
       if (V == 0) {
         w.lanes(n, [&](int i) {
