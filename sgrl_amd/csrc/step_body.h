@@ -49,7 +49,7 @@ constexpr int kBppMaxIter = 40;                   // block-pivot rounds before g
 constexpr int kSlabRows = 256;                    // most constraint rows an evaluation may have (HBM slab path; the row cap of a morphology)
 constexpr int kPivotRows = 64;                    // ... of which the exact block-pivot solve takes up to this many (free set = 64-bit mask);
                                                   // evaluations with more rows run Gauss-Seidel over the rows in the slab (pgs_big)
-constexpr int kPrevRows = 64;                     // warm-start memory (LDS): the first rows of the previous evaluation
+constexpr int kPrevRows = 48;                     // warm-start memory (LDS): the first rows of the previous evaluation
 constexpr int kSlabLdy = 47;                      // largest Y row stride served: nv <= 46
 // per-env HBM slab (Engine::rows_hbm): factor of a <= 64-row free set | Y | five row arrays | four int row arrays
 SGRL_HD int slab_doubles(int maxrows, int ldy) { return kPivotRows * (kPivotRows + 1) / 2 + (maxrows + 1) * ldy + 5 * maxrows + 2 * maxrows + 8; }
@@ -1003,19 +1003,24 @@ struct Engine {
   // scratch C (packed lower triangle), and the complement test uses  (A x)_G = Y_G (Y_F' x).  The free set is
   // warm-started from the previous evaluation.  On success S[vpgs] = Y' f.  The result is the same unique optimum
   // projected Gauss-Seidel converges to; PGS remains the fallback.
-  template <bool SMALL>
+  template <bool SMALL, bool CLDS>
   SGRL_DEV bool lcp_block_pivot(const Rows& R, int n, double thresh, int* iters_out) {
     double* const wvp = R.earef;          // scratch: reciprocal pivots / intermediate vector
-    double* const xwp = S + o.prev_f;     // scratch: right-hand side -> solution (compact, free-set order)
+    // scratch: right-hand side -> solution (compact, free-set order; up to 64 entries).  LDS rows: the warm-start array (n <=
+    // lrows <= its size); slab rows: the LDS Y block, idle while the rows live in the slab
+    double* const xwp = SMALL ? S + o.prev_f : S + o.Y;
     const int nv = o.nv, ldy = o.ldy;
     uint64_t F = w.ballot(n, [&](int i) { return R.ef[i] > 0.0; });
     int patience = 3, best = n + 1;
     for (int iter = 0; iter < kBppMaxIter; iter++) {
       w.fence_lane();            // nothing lane-dependent is carried across pivoting rounds (registers)
       const int nf = popcount64(F);
-      // factor scratch: the slab's own (LDS dead zone for the LDS rows).  Slab-path evaluations borrow the LDS dead zone
-      // too whenever the free set is small enough for it -- the elimination then runs out of LDS, not global memory.
-      double* const C = (!SMALL && nf <= o.na_max) ? S + o.dead : R.C;
+      // factor scratch: the LDS dead zone (LDS rows; slab-path evaluations whose WHOLE row set is small enough for it: the
+      // elimination then runs out of LDS, not global memory) or the slab's own.  The choice is a template parameter, never a
+      // run-time select between an LDS and a global pointer: that select makes the accesses FLAT, and in the fixed-dimension
+      // kernels (LDS address a compile-time constant) such a flat access faulted (memory aperture violation on a humanoid_7
+      // lying on the floor, round 3: tools/diag/contact_stress.py); with a static address space there are no flat accesses.
+      double* const C = CLDS ? S + o.dead : R.C;
       w.lanes(n, [&](int i) {
         if ((F >> i) & 1ull) {
           const int pos = popcount64(F & ((1ull << i) - 1ull));
@@ -1136,12 +1141,13 @@ struct Engine {
       bool solved = false;
       if (W::hdr_const(m, SGRL_H_SOLVER) == 1) {
         if (!BIG) {
-          solved = lcp_block_pivot<true>(R, nrow, thresh, &sweeps);             // rows and factor scratch in LDS
+          solved = lcp_block_pivot<true, true>(R, nrow, thresh, &sweeps);       // rows and factor scratch in LDS
           if (!solved) diag_code |= 1 << 8;                                     // diagnostics: block pivoting gave up
         } else if (nrow <= kPivotRows) {
           // rare (a few envs per 8192-env launch): more rows than the LDS arrays hold -> the same exact solve with
           // rows and factor in this environment's HBM scratch slab
-          solved = lcp_block_pivot<false>(R, nrow, thresh, &sweeps);
+          solved = nrow <= o.na_max ? lcp_block_pivot<false, true>(R, nrow, thresh, &sweeps)
+                                    : lcp_block_pivot<false, false>(R, nrow, thresh, &sweeps);
           diag_code |= (1 << 16) | (solved ? 0 : 1 << 8);
         }
       }

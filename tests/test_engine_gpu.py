@@ -315,6 +315,47 @@ def test_contact_rich_states_keep_every_constraint_row():
     assert pgs_evals > 0, "no evaluation went beyond the 64 rows of the block-pivot solve: the test state is too tame"
 
 
+def test_contact_rich_free_running_on_both_kernel_kinds(monkeypatch):
+    """Regression (round 3): a humanoid_7 lying on the floor took the slab path with 33..64 rows, where the factor scratch was a
+    run-time select between an LDS and a global pointer -- flat accesses that FAULTED in the fixed-dimension kernels (memory
+    aperture violation).  The address space is now static.  64 environments per morphology from lying poses, free-running
+    with auto-reset, on the family kernels and on the generic kernel: finite, no dropped rows, both kinds agree."""
+    import torch
+    from sgrl_amd.vec_env import BatchedModularVecEnv
+    names = ["3d_cheetah_14_full", "3d_humanoid_9_full", "3d_cheetah_10_tail_leftbleg", "3d_humanoid_7_left_arm", "3d_walker_7_full"]
+    quats = [[1, 0, 0, 0], [0.70710678, 0.70710678, 0, 0], [0.70710678, 0, 0.70710678, 0]]
+    for specs in ("1", "0"):
+        monkeypatch.setenv("SGRL_SPECS", specs)
+        env = BatchedModularVecEnv(names, 64, seed=3, device="cuda:0")
+        assert (env.fixed_dim_groups > 0) == (specs == "1")
+        env.enable_f64_outputs()
+        env.reset_device()
+        rec, cnt = env.get_records()
+        for i in range(env.num_envs):
+            m = env.models[env.env_morph[i]]
+            q = np.array(env._blobs[env.env_morph[i]][1][16:16 + m.nq])
+            q[2] = 0.05 + 0.02 * (i % 5)
+            q[3:7] = quats[i % 3]
+            rec[i, :m.nq] = q
+            rec[i, m.nq:m.nq + m.nv] = 0
+        env.set_records(rec, cnt)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        slab = 0
+        for t in range(40):
+            a = (torch.rand((env.num_envs, env.action_max_len), device="cuda", generator=g) * 2 - 1).contiguous()
+            env.step_device(a, auto_reset=True)
+            if t % 10 == 9:
+                torch.cuda.synchronize()
+                c = env.get_counters()
+                slab += int((c[:, 3] >> 16).sum())
+                assert (c[:, 2] == 0).all() and bool(torch.isfinite(env.obs).all())
+        assert slab > 0, "no evaluation took the slab path: the poses are too tame"
+        rec = env.get_records()[0]
+        for i in range(env.num_envs):             # the used part of every record (rows are padded to the widest morphology)
+            assert all(np.isfinite(x).all() for x in env.state_of(rec, i)), (specs, names[env.env_morph[i]])
+        env.close()
+
+
 def test_fixed_dimension_kernels_agree_with_the_generic_kernel(monkeypatch):
     """The family kernels of csrc/step_spec.hip (dimensions as compile-time constants, light families at four waves per SIMD)
     and the generic kernel are the same source: same states after 30 free-running steps to rounding (contraction of
