@@ -1049,6 +1049,7 @@ struct Engine {
         if (i == j) a += R.eR[fi];
         C[p] = a;
       });
+      SGRL_TICK(12);
       // factor A_FF and solve.  Small free sets in LDS: Cholesky + explicit inverse of the factor on registers (wave
       // policy), then x = T'(T rhs) as two recurrence-free products; otherwise the lane-parallel root-free elimination
       if (SMALL && w.chol_inv_packed(nf, C, kMinVal)) {
@@ -1092,6 +1093,7 @@ struct Engine {
           w.lanes(j, [&](int k) { xwp[k] -= C[j * (j + 1) / 2 + k] * wvp[k] * xj; });
         }
       }
+      SGRL_TICK(13);
       // u = Y_F' x  (= Y' f for the candidate f);  violations: x_i < 0 on F, (Y_i u + b_i) < -thresh on the complement
       w.lanes(nv, [&](int d) {
         double u0 = 0, u1 = 0;
@@ -1112,6 +1114,7 @@ struct Engine {
         for (; d < nv; d++) y0 += yi[d] * S[o.vpgs + d];
         return (y0 + y1) + (y2 + y3) < -thresh;
       });
+      SGRL_TICK(14);
       if (V == 0) {
         w.lanes(n, [&](int i) {
           R.ef[i] = ((F >> i) & 1ull) ? xwp[popcount64(F & ((1ull << i) - 1ull))] : 0.0;

@@ -25,8 +25,9 @@ buf = np.zeros((env.num_envs, 16), dtype=np.uint64)
 L.sgrl_phase_prof(None, env.num_envs, 1)
 for _ in range(5): env.step_device(a)
 L.sgrl_phase_prof(ctypes.c_void_p(buf.ctypes.data), env.num_envs, 0)
-names_p = ["kinematics", "com/cinert/cdof", "crba", "collide", "rne bias", "enumerate rows", "build rows", "lcp", "cholesky", "halfsolve", "diag/b", "backsolve"]
+names_p = ["kinematics", "com/cinert/cdof", "crba", "collide", "rne bias", "enumerate rows", "build rows", "lcp rest", "cholesky", "halfsolve", "diag/b", "backsolve",
+           "lcp:flist+A_FF", "lcp:factor+solve", "lcp:u+test"]
 for k, sl in enumerate(env.morph_slices):
     b = buf[sl].astype(np.float64).mean(0) / 5
     tot = b[15]
-    print("%-34s total %8.0f kcyc/env-step | " % (names[k], tot / 1e3) + " ".join("%s %4.1f%%" % (n[:9], 100 * b[i] / tot) for i, n in enumerate(names_p)) + " | other %4.1f%%" % (100 * (tot - b[:12].sum()) / tot))
+    print("%-34s total %8.0f kcyc/env-step | " % (names[k], tot / 1e3) + " ".join("%s %4.1f%%" % (n[:9], 100 * b[i] / tot) for i, n in enumerate(names_p)) + " | other %4.1f%%" % (100 * (tot - b[:15].sum()) / tot))
