@@ -74,6 +74,17 @@ int sgrl_gram_backward(const float* z, const float* dgram, const float* dfn, con
 int sgrl_zmat_forward(const float* z, const float* mat, float* t, int M, void* stream);
 int sgrl_zmat_backward(const float* z, const float* mat, const float* dt, float* dz, float* dmat, int M, void* stream);
 
+/* Residual + LayerNorm over 128 columns (reference SEActor.py:90-91, 113-114: norm1(ng + attention update), norm2(ng + feed-forward
+ * update); SEActor.py:164: the encoder's final norm, res = null):  y = LayerNorm(x + res) * w + b, eps inside the square root.
+ * `nets` (1 or 2) networks stacked along the row axis, `rows` rows each ([nets * rows, 128]); network i uses w_i, b_i [128].
+ * xhat [nets * rows, 128] (the normalised rows) and rstd [nets * rows] are what the backward needs (both null: not saved).
+ * Backward: dx [nets * rows, 128] = the gradient of x AND of res; dw_i = sum_rows dy xhat, db_i = sum_rows dy (written, not
+ * accumulated; null = not wanted; rows summed in a fixed order: bit-reproducible).  One launch each. */
+int sgrl_add_ln_forward(const float* x, const float* res, const float* w0, const float* b0, const float* w1, const float* b1, float* y,
+                        float* xhat, float* rstd, int rows, int nets, float eps, void* stream);
+int sgrl_add_ln_backward(const float* dy, const float* xhat, const float* rstd, const float* w0, const float* w1, float* dx, float* dw0,
+                         float* db0, float* dw1, float* db1, int rows, int nets, void* stream);
+
 /* Limb attention of B environments with L <= 14 limbs, 2 heads x 128 channels (reference subequivariant_attentions.py:90-151
  * between the projections).  qkv [B, L, 768] = q | k | v as the stacked projection leaves them (q is multiplied by `scale` inside);
  * the vector values are given in parts and never concatenated: vgp [B, L, 3, 252] (126 projected channels per head) and gdir

@@ -560,6 +560,80 @@ __global__ __launch_bounds__(256) void k_zmat_bwd(const float* __restrict__ z, c
   }
 }
 
+// Residual + LayerNorm over 128 columns (reference SEActor.py:90-91, 113-114, 164: norm(ng + update)), forward and backward in
+// ONE launch each -- the update's rows are few (700 .. 4 200), so a norm is launch-bound: torch's add + native_layer_norm and its
+// three backward kernels are five launches per site (eleven for the twin critics' unbind / stack form).  `nets` networks are
+// stacked along the row axis, `rows` rows each; network i normalises with w[i], b[i].  One wavefront per row, two columns per lane.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__global__ __launch_bounds__(256) void k_add_ln_fwd(const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ w0,
+                                                    const float* __restrict__ b0, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                    float* __restrict__ y, float* __restrict__ xhat, float* __restrict__ rstd, int rows, int total, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= total) return;
+  const bool second = row >= rows;
+  const float* w = second ? w1 : w0;
+  const float* b = second ? b1 : b0;
+  float2 v = *reinterpret_cast<const float2*>(x + (size_t)row * 128 + 2 * lane);
+  if (res) { const float2 r = *reinterpret_cast<const float2*>(res + (size_t)row * 128 + 2 * lane); v.x += r.x; v.y += r.y; }
+  const float mean = wave_sum(v.x + v.y) * (1.f / 128.f);
+  const float d0 = v.x - mean, d1 = v.y - mean;
+  const float var = wave_sum(d0 * d0 + d1 * d1) * (1.f / 128.f);
+  const float r = 1.0f / sqrtf(var + eps);
+  const float2 xh = make_float2(d0 * r, d1 * r);
+  const float2 wv = *reinterpret_cast<const float2*>(w + 2 * lane), bv = *reinterpret_cast<const float2*>(b + 2 * lane);
+  *reinterpret_cast<float2*>(y + (size_t)row * 128 + 2 * lane) = make_float2(xh.x * wv.x + bv.x, xh.y * wv.y + bv.y);
+  if (xhat) {
+    *reinterpret_cast<float2*>(xhat + (size_t)row * 128 + 2 * lane) = xh;
+    if (lane == 0) rstd[row] = r;
+  }
+}
+// workgroups [0, nrow_blocks): dx of four rows each; the rest: (network, 32 columns) -> dw = sum_rows dy xhat, db = sum_rows dy, the
+// rows summed in a fixed order (eight interleaved row groups, then the groups in order): bit-reproducible, no atomics
+__global__ __launch_bounds__(256) void k_add_ln_bwd(const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ rstd,
+                                                    const float* __restrict__ w0, const float* __restrict__ w1, float* __restrict__ dx,
+                                                    float* dw0, float* db0, float* dw1, float* db1, int rows, int total, int nrow_blocks) {
+  __shared__ float red[2][8][32];
+  if ((int)blockIdx.x < nrow_blocks) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= total) return;
+    const float* w = row >= rows ? w1 : w0;
+    const float2 g0 = *reinterpret_cast<const float2*>(dy + (size_t)row * 128 + 2 * lane);
+    const float2 wv = *reinterpret_cast<const float2*>(w + 2 * lane);
+    const float2 xh = *reinterpret_cast<const float2*>(xhat + (size_t)row * 128 + 2 * lane);
+    const float gx = g0.x * wv.x, gy = g0.y * wv.y;
+    const float c1 = wave_sum(gx + gy) * (1.f / 128.f);
+    const float c2 = wave_sum(gx * xh.x + gy * xh.y) * (1.f / 128.f);
+    const float r = rstd[row];
+    *reinterpret_cast<float2*>(dx + (size_t)row * 128 + 2 * lane) = make_float2(r * (gx - c1 - xh.x * c2), r * (gy - c1 - xh.y * c2));
+    return;
+  }
+  const int q = blockIdx.x - nrow_blocks, net = q >> 2, c = 32 * (q & 3) + (threadIdx.x & 31), grp = threadIdx.x >> 5;
+  float* dw = net ? dw1 : dw0;
+  float* db = net ? db1 : db0;
+  if (!dw && !db) return;
+  float aw = 0.f, ab = 0.f;
+  const size_t base = (size_t)net * rows * 128 + c;
+  for (int r = grp; r < rows; r += 8) {
+    const float g = dy[base + (size_t)r * 128];
+    aw += g * xhat[base + (size_t)r * 128];
+    ab += g;
+  }
+  red[0][grp][threadIdx.x & 31] = aw;
+  red[1][grp][threadIdx.x & 31] = ab;
+  __syncthreads();
+  if (grp == 0) {
+    float sw = 0.f, sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { sw += red[0][k][threadIdx.x]; sb += red[1][k][threadIdx.x]; }
+    if (dw) dw[c] = sw;
+    if (db) db[c] = sb;
+  }
+}
+
 // Only the weight gradient (AT) splits its contraction, and only where that pays: the release / acquire fences of the last-
 // workgroup reduction cost ~10-15 us on the eight-XCD chip, more than a few extra k-steps (measured: a 256 x 256 gradient over
 // 700 rows is 20 us unsplit, 27 us in three splits; a 30 x 128 gradient over 2 100 rows 51 us unsplit, 17 us in six).  So: a
@@ -772,6 +846,28 @@ int sgrl_zmat_backward(const float* z, const float* mat, const float* dt, float*
   if (!z || !mat || !dt || !dz || !dmat || M <= 0) return tfail(SGRL_ERR_ARG, "sgrl_zmat_backward: bad argument");
   hipLaunchKernelGGL(k_zmat_bwd, dim3((M + 1) / 2), dim3(256), 0, (hipStream_t)stream, z, mat, dt, dz, dmat, M);
   { int lrc = SGRL_OK; if (!launched("k_zmat_bwd launch failed", &lrc)) return lrc; }
+  return SGRL_OK;
+}
+
+int sgrl_add_ln_forward(const float* x, const float* res, const float* w0, const float* b0, const float* w1, const float* b1, float* y,
+                        float* xhat, float* rstd, int rows, int nets, float eps, void* stream) {
+  if (!x || !w0 || !b0 || !y || rows <= 0 || (nets != 1 && nets != 2) || (nets == 2 && (!w1 || !b1)) || ((xhat == nullptr) != (rstd == nullptr)))
+    return tfail(SGRL_ERR_ARG, "sgrl_add_ln_forward: bad argument");
+  const int total = rows * nets;
+  hipLaunchKernelGGL(k_add_ln_fwd, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, res, w0, b0, w1, b1, y, xhat, rstd, rows, total, eps);
+  { int lrc = SGRL_OK; if (!launched("k_add_ln_fwd launch failed", &lrc)) return lrc; }
+  return SGRL_OK;
+}
+
+int sgrl_add_ln_backward(const float* dy, const float* xhat, const float* rstd, const float* w0, const float* w1, float* dx, float* dw0,
+                         float* db0, float* dw1, float* db1, int rows, int nets, void* stream) {
+  if (!dy || !xhat || !rstd || !w0 || !dx || rows <= 0 || (nets != 1 && nets != 2) || (nets == 2 && !w1))
+    return tfail(SGRL_ERR_ARG, "sgrl_add_ln_backward: bad argument");
+  const int total = rows * nets, nrow_blocks = (total + 3) / 4;
+  const bool params = dw0 || db0 || dw1 || db1;
+  hipLaunchKernelGGL(k_add_ln_bwd, dim3(nrow_blocks + (params ? 4 * nets : 0)), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, w0, w1, dx,
+                     dw0, db0, dw1, db1, rows, total, nrow_blocks);
+  { int lrc = SGRL_OK; if (!launched("k_add_ln_bwd launch failed", &lrc)) return lrc; }
   return SGRL_OK;
 }
 

@@ -118,13 +118,13 @@ class SubequivariantEncoderLayer(nn.Module):
     def forward(self, g, ng, gdir, bias=None):
         g1, ng1 = self.self_attn(g, ng, gdir, bias)
         g = g + g1
-        ng = self.norm1(ng + ng1)
+        ng = train_ops.add_layer_norm(ng, ng1, self.norm1)
         inv, fn = _invariants(g1, gdir, self.g_proj2, self.linear_g1, self.linear_g2)
         c = torch.cat([inv, ng], dim=-1)
         mat = self.linear4(self.linear3(c, relu=True), rowdiv=fn).view(*ng.shape[:2], Z_DIM, Z_DIM)
         z3 = torch.cat([self.g_proj3(g1), gdir], dim=-1)
         g = g + self.linear5(train_ops.zmat(z3, mat))
-        ng = self.norm2(ng + self.linear2(self.linear1(c, relu=True), rowdiv=fn))
+        ng = train_ops.add_layer_norm(ng, self.linear2(self.linear1(c, relu=True), rowdiv=fn), self.norm2)
         return g, ng
 
 
@@ -145,7 +145,7 @@ class RepeatTransformerEncoder(nn.Module):
         for i, layer in enumerate(self.layers):
             g, ng = layer(g, ng, gdir, bias if i == 0 else None)
         if self.norm is not None:
-            ng = self.norm(ng)
+            ng = train_ops.add_layer_norm(ng, None, self.norm)
         return g, ng
 
 
@@ -224,9 +224,8 @@ def _lin2(l0, l1, x, relu=False, rowdiv=None, shared=False):
     return train_ops.linear2(x, l0.weight, l1.weight, l0.bias, l1.bias, relu, rowdiv, shared)
 
 
-def _norm2(n0, n1, x):
-    a, b = x.unbind(0)          # (not x[0], x[1]: each index costs a zero-filled gradient, a slice copy and an add going back)
-    return torch.stack([n0(a), n1(b)])
+def _norm2(n0, n1, x, res=None):
+    return train_ops.add_layer_norm2(x, res, n0, n1)
 
 
 def _invariants2(x, gdir2, proj, lin1, lin2):
@@ -259,14 +258,14 @@ def _attention2(a, g, ng, gdir, gdir2, bias):
 def _layer2(l, g, ng, gdir, gdir2, bias):
     g1, ng1 = _attention2((l[0].self_attn, l[1].self_attn), g, ng, gdir, gdir2, bias)
     g = g + g1
-    ng = _norm2(l[0].norm1, l[1].norm1, ng + ng1)
+    ng = _norm2(l[0].norm1, l[1].norm1, ng, ng1)
     inv, fn = _invariants2(g1, gdir2, (l[0].g_proj2, l[1].g_proj2), (l[0].linear_g1, l[1].linear_g1), (l[0].linear_g2, l[1].linear_g2))
     c = torch.cat([inv, ng], dim=-1)
     mat = _lin2(l[0].linear4, l[1].linear4, _lin2(l[0].linear3, l[1].linear3, c, relu=True), rowdiv=fn)
     mat = mat.view(*ng.shape[:3], Z_DIM, Z_DIM)
     z3 = torch.cat([_lin2(l[0].g_proj3, l[1].g_proj3, g1), gdir2], dim=-1)
     g = g + _lin2(l[0].linear5, l[1].linear5, train_ops.zmat(z3, mat))
-    ng = _norm2(l[0].norm2, l[1].norm2, ng + _lin2(l[0].linear2, l[1].linear2, _lin2(l[0].linear1, l[1].linear1, c, relu=True), rowdiv=fn))
+    ng = _norm2(l[0].norm2, l[1].norm2, ng, _lin2(l[0].linear2, l[1].linear2, _lin2(l[0].linear1, l[1].linear1, c, relu=True), rowdiv=fn))
     return g, ng
 
 

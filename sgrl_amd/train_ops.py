@@ -39,6 +39,8 @@ def _L():
         L.sgrl_zmat_backward.argtypes = [vp, vp, vp, vp, vp, ci, vp]
         L.sgrl_attention_forward.argtypes = [vp, vp, vp, vp, ctypes.c_float, vp, vp, vp, ci, ci, vp]
         L.sgrl_attention_backward.argtypes = [vp, vp, vp, ctypes.c_float, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]
+        L.sgrl_add_ln_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ctypes.c_float, vp]
+        L.sgrl_add_ln_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]
         L.sgrl_train_ws_floats.restype = ctypes.c_int64
         L.sgrl_train_last_error.restype = ctypes.c_char_p
         _bound = True
@@ -369,6 +371,54 @@ class _AttnFn(torch.autograd.Function):
         return dqkv, dvgp, dgdir, dbias, None
 
 
+class _AddLNFn(torch.autograd.Function):
+    """y = LayerNorm(x + res) * w + b over 128 columns, one launch forward and one backward (csrc/train_gemm.hip k_add_ln_*);
+    w1 / b1 given: x stacks TWO networks along dim 0, each with its own affine pair."""
+
+    @staticmethod
+    def forward(ctx, x, res, w0, b0, w1, b1, eps):
+        L = _L()
+        nets = 2 if w1 is not None else 1
+        x2 = x.reshape(-1, 128)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        r2 = None
+        if res is not None:
+            r2 = res.expand_as(x).reshape(-1, 128)
+            r2 = r2 if r2.is_contiguous() else r2.contiguous()
+        total = x2.shape[0]
+        assert total % nets == 0
+        y = torch.empty_like(x2)
+        xhat = torch.empty_like(x2)
+        rstd = torch.empty((total,), dtype=torch.float32, device=x.device)
+        st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        _check(L, L.sgrl_add_ln_forward(_p(x2), _p(r2), _p(w0), _p(b0), _p(w1), _p(b1), _p(y), _p(xhat), _p(rstd), total // nets, nets,
+                                        ctypes.c_float(eps), st), "sgrl_add_ln_forward")
+        ctx.save_for_backward(xhat, rstd, w0, w1)
+        ctx.nets, ctx.x_shape, ctx.res_shape = nets, x.shape, None if res is None else res.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _L()
+        xhat, rstd, w0, w1 = ctx.saved_tensors
+        total, nets = xhat.shape[0], ctx.nets
+        dy2 = dy.reshape(total, 128)
+        dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        need = ctx.needs_input_grad
+        dx = torch.empty_like(xhat)
+        new = lambda want: torch.empty((128,), dtype=torch.float32, device=dy.device) if want else None
+        dw0, db0 = new(need[2]), new(need[3])
+        dw1, db1 = new(nets == 2 and need[4]), new(nets == 2 and need[5])
+        st = ctypes.c_void_p(torch.cuda.current_stream(dy.device).cuda_stream)
+        _check(L, L.sgrl_add_ln_backward(_p(dy2), _p(xhat), _p(rstd), _p(w0), _p(w1), _p(dx), _p(dw0), _p(db0), _p(dw1), _p(db1),
+                                         total // nets, nets, st), "sgrl_add_ln_backward")
+        dxv = dx.view(ctx.x_shape)
+        dres = None
+        if ctx.res_shape is not None and need[1]:
+            dres = dxv if tuple(ctx.res_shape) == tuple(ctx.x_shape) else dxv.sum_to_size(ctx.res_shape)
+        return (dxv if need[0] else None), dres, dw0, db0, dw1, db1, None
+
+
 def _on_device_with_grad(*ts):
     return ENABLED and ts[0].is_cuda and ts[0].dtype == torch.float32 and torch.is_grad_enabled() and \
         any(t is not None and t.requires_grad for t in ts)
@@ -427,3 +477,21 @@ def zmat(z, mat):
     if _on_device_with_grad(z, mat) and z.shape[-2:] == (3, 32) and mat.shape[-2:] == (32, 32):
         return _ZmatFn.apply(z, mat)
     return torch.einsum("...sa,...ac->...sc", z, mat)
+
+
+def add_layer_norm(x, res, norm):
+    """norm(x + res) for an nn.LayerNorm over the last dimension (res may be None): one launch forward, one backward when autograd is
+    recording on the GPU and the width is 128; the module itself otherwise."""
+    if x.shape[-1] == 128 and norm.elementwise_affine and norm.bias is not None and _on_device_with_grad(x, res, norm.weight, norm.bias):
+        return _AddLNFn.apply(x, res, norm.weight, norm.bias, None, None, float(norm.eps))
+    return norm(x if res is None else x + res)
+
+
+def add_layer_norm2(x, res, n0, n1):
+    """The same for the stacked activations of two networks: x [2, ..., 128] -> stack(n0(x[0] + res[0]), n1(x[1] + res[1]))."""
+    if x.shape[-1] == 128 and x.shape[0] == 2 and n0.elementwise_affine and n1.elementwise_affine and n0.bias is not None and \
+            n1.bias is not None and n0.eps == n1.eps and _on_device_with_grad(x, res, n0.weight, n0.bias, n1.weight, n1.bias):
+        return _AddLNFn.apply(x, res, n0.weight, n0.bias, n1.weight, n1.bias, float(n0.eps))
+    s = x if res is None else x + res
+    a, b = s.unbind(0)          # (not s[0], s[1]: each index costs a zero-filled gradient, a slice copy and an add going back)
+    return torch.stack([n0(a), n1(b)])

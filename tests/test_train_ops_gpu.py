@@ -321,3 +321,63 @@ def test_linear2_matches_float64(M, K, N, has_bias, relu, rowdiv, shared):
             assert float((bd[i].grad.cpu().double() - br[i].grad).abs().max()) < tol(br[i].grad) * np.sqrt(M / 64 + 1), i
     if rowdiv:
         assert float((rdd.grad.cpu().double() - rdr.grad).abs().max()) < tol(rdr.grad)
+
+
+@pytest.mark.parametrize("rows,twin,with_res", [(700, False, True), (700, True, True), (4200, True, False), (13, False, False),
+                                                (1, True, True), (2100, False, True)])
+def test_add_layer_norm_matches_float64(rows, twin, with_res):
+    """train_ops.add_layer_norm / add_layer_norm2 (one launch forward, one backward) against float64 LayerNorm(x + res) on the CPU:
+    value, gradients of x, res and both affine pairs; bit-reproducible; frozen affine parameters (the critic inside the actor loss)."""
+    from sgrl_amd import train_ops
+    g = torch.Generator().manual_seed(rows * 3 + twin + 2 * with_res)
+    shape = (2, rows, 128) if twin else (rows, 128)
+    x = torch.randn(shape, generator=g) * 3 + 0.5
+    res = torch.randn(shape, generator=g) if with_res else None
+    dy = torch.randn(shape, generator=g)
+    norms = [torch.nn.LayerNorm(128) for _ in range(2 if twin else 1)]
+    for n in norms:
+        with torch.no_grad():
+            n.weight.copy_(torch.randn(128, generator=g)); n.bias.copy_(torch.randn(128, generator=g))
+    # float64 reference
+    ref_norms = [torch.nn.LayerNorm(128).double() for _ in norms]
+    for rn, n in zip(ref_norms, norms):
+        rn.load_state_dict({k: v.double() for k, v in n.state_dict().items()})
+    xr = x.double().requires_grad_()
+    rr = res.double().requires_grad_() if with_res else None
+    sr = xr + rr if with_res else xr
+    yr = torch.stack([ref_norms[0](sr[0]), ref_norms[1](sr[1])]) if twin else ref_norms[0](sr)
+    yr.backward(dy.double())
+
+    def run():
+        dn = [torch.nn.LayerNorm(128).cuda() for _ in norms]
+        for d, n in zip(dn, norms):
+            d.load_state_dict(n.state_dict())
+        xd = x.cuda().requires_grad_()
+        rd = res.cuda().requires_grad_() if with_res else None
+        y = train_ops.add_layer_norm2(xd, rd, dn[0], dn[1]) if twin else train_ops.add_layer_norm(xd, rd, dn[0])
+        assert type(y.grad_fn).__name__.startswith("_AddLNFn")
+        y.backward(dy.cuda())
+        return y, xd, rd, dn
+    y, xd, rd, dn = run()
+    tol = lambda ref: 2e-5 * (float(ref.abs().max()) + 1.0)
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) < tol(yr)
+    assert float((xd.grad.cpu().double() - xr.grad).abs().max()) < tol(xr.grad)
+    if with_res:
+        assert float((rd.grad.cpu().double() - rr.grad).abs().max()) < tol(rr.grad)
+    for d, rn in zip(dn, ref_norms):
+        assert float((d.weight.grad.cpu().double() - rn.weight.grad).abs().max()) < tol(rn.weight.grad) * np.sqrt(rows / 64 + 1)
+        assert float((d.bias.grad.cpu().double() - rn.bias.grad).abs().max()) < tol(rn.bias.grad) * np.sqrt(rows / 64 + 1)
+    y2, xd2, _, dn2 = run()
+    assert torch.equal(y, y2) and torch.equal(xd.grad, xd2.grad) and all(torch.equal(a.weight.grad, b.weight.grad) for a, b in zip(dn, dn2))
+    # frozen affine parameters: only the input gradient is produced
+    fz = torch.nn.LayerNorm(128).cuda()
+    fz.load_state_dict(norms[0].state_dict())
+    for p in fz.parameters():
+        p.requires_grad_(False)
+    xs = (x[0] if twin else x).cuda().requires_grad_()
+    train_ops.add_layer_norm(xs, None, fz).backward((dy[0] if twin else dy).cuda())
+    assert fz.weight.grad is None and xs.grad is not None
+    # no autograd: the module itself
+    with torch.no_grad():
+        yn = train_ops.add_layer_norm(xs, None, fz)
+    assert yn.grad_fn is None and float((yn - fz(xs)).abs().max()) == 0.0
