@@ -32,6 +32,21 @@ int64_t sgrl_train_ws_floats(void);
 int sgrl_linear_forward(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* rowdiv, float* y,
                         int ldy, int M, int N, int K, int relu, void* stream);
 
+/* sgrl_linear_forward with two optional fusions of what follows the product in the SET layers (one launch instead of two):
+ *   addend [M, N] (row stride ldadd): y += addend after the epilogue -- the residual of the vector stream, g + linear5(.)
+ *     (reference SEActor.py:110);
+ *   tail [M, ntail]: y[m][N + j] = tail[m][j] -- columns appended to the product's N (y has N + ntail <= ldy columns): the
+ *     gravity / direction pair behind the 30 projected channels, z = [proj(x) | gdir] (reference SEActor.py:93-94); the appended
+ *     columns must fall into the product's last 32-column tile (N % 32 != 0, N % 32 + ntail <= 32).
+ * The twin form does the same for the two critics' layers in one launch. */
+int sgrl_linear_forward_fused(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* rowdiv,
+                              const float* addend, int ldadd, const float* tail, int ntail, float* y, int ldy, int M, int N, int K,
+                              int relu, void* stream);
+int sgrl_linear_forward_twin_fused(const float* x0, const float* x1, int ldx, const float* w0, const float* w1, int ldw, const float* b0,
+                                   const float* b1, const float* rd0, const float* rd1, const float* add0, const float* add1, int ldadd,
+                                   const float* tail0, const float* tail1, int ntail, float* y0, float* y1, int ldy, int M, int N, int K,
+                                   int relu, void* stream);
+
 /* Backward of the call above (`y` = its output, needed when relu != 0 or drowdiv != null; relu and rowdiv exclude each other).
  * g = dy masked by (y > 0) if relu, divided row-wise by rowdiv if given.
  *   dx[M, K]    = g . w                                  (skipped when dx == null)

@@ -60,6 +60,10 @@ struct SArgs {
   int M, N, K;
   int kper;                         // contraction length per split (multiple of BK); gridDim.z splits
   float* ws; unsigned* counters;    // split scratch: [split][tile][TILE_WS] floats, one counter per tile (zero between calls)
+  // forward only (both optional, last so that the other products' initialisers leave them null):
+  const float* addend; int ldadd;   // C[m][n] += addend[m][n] after the epilogue (a residual stream: g + linear5(...))
+  const float* tail; int ntail;     // C[m][N + j] = tail[m][j], j < ntail: columns appended to the product's N (z = [proj(x) | gdir]);
+                                    // they must fall into the last column tile (N % 32 + ntail <= 32)
 };
 constexpr int TILE_WS = BT * BT + BT;
 constexpr int64_t kWsTiles = 4096;      // (split, tile) slots of the scratch buffer
@@ -224,10 +228,14 @@ __device__ __forceinline__ void sgemm_tile(const SArgs& a, float (*As)[LDP], flo
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int n = n0 + c0 + j;
-    if (n >= a.N) continue;
+    if (n >= a.N) {
+      if (!AT && !BTR && a.tail && n < a.N + a.ntail) a.C[(size_t)m * a.ldc + n] = a.tail[(size_t)m * a.ntail + (n - a.N)];
+      continue;
+    }
     float o = v[j] + (a.bias ? a.bias[n] : 0.f);
     if (a.relu) o = fmaxf(o, 0.f);
     if (!AT && !BTR && a.rowdiv) o = o / a.rowdiv[m];
+    if (!AT && !BTR && a.addend) o += a.addend[(size_t)m * a.ldadd + n];
     a.C[(size_t)m * a.ldc + n] = o;
   }
 }
@@ -695,6 +703,16 @@ int sgrl_linear_forward(const float* x, int ldx, const float* w, int ldw, const 
   return launch<false, false>(a, nullptr, (hipStream_t)stream);
 }
 
+int sgrl_linear_forward_fused(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* rowdiv,
+                              const float* addend, int ldadd, const float* tail, int ntail, float* y, int ldy, int M, int N, int K,
+                              int relu, void* stream) {
+  if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldw < K || ldy < N + (tail ? ntail : 0) || (addend && ldadd < N) ||
+      (tail && (ntail <= 0 || (N % 32) == 0 || (N % 32) + ntail > 32)))
+    return tfail(SGRL_ERR_ARG, "sgrl_linear_forward_fused: bad argument");
+  SArgs a{x, ldx, nullptr, 0, w, ldw, bias, relu ? 1 : 0, rowdiv, y, ldy, nullptr, M, N, K, 0, nullptr, nullptr, addend, ldadd, tail, ntail};
+  return launch<false, false>(a, nullptr, (hipStream_t)stream);
+}
+
 int sgrl_linear_backward(const float* dy, int lddy, const float* y, int ldyo, int relu, const float* rowdiv, const float* x,
                          int ldx, const float* w, int ldw, float* dx, int lddx, float* dw, int lddw, float* db,
                          float* drowdiv, int M, int N, int K, float* ws, void* stream) {
@@ -739,6 +757,24 @@ int sgrl_linear_forward_twin(const float* x0, const float* x1, int ldx, const fl
   SArgs2 p;
   p.a[0] = SArgs{x0, ldx, nullptr, 0, w0, ldw, b0, relu ? 1 : 0, rd0, y0, ldy, nullptr, M, N, K, 0, nullptr, nullptr};
   p.a[1] = SArgs{x1, ldx, nullptr, 0, w1, ldw, b1, relu ? 1 : 0, rd1, y1, ldy, nullptr, M, N, K, 0, nullptr, nullptr};
+  int tn, tm, splits;
+  for (int i = 0; i < 2; i++) { const int rc = plan<false>(p.a[i], nullptr, &tn, &tm, &splits); if (rc != SGRL_OK) return rc; }
+  hipLaunchKernelGGL(k_sgemm_twin<false>, dim3(tn, tm, 2), dim3(256), 0, (hipStream_t)stream, p);
+  { int lrc = SGRL_OK; if (!launched("k_sgemm_twin launch failed", &lrc)) return lrc; }
+  return SGRL_OK;
+}
+
+int sgrl_linear_forward_twin_fused(const float* x0, const float* x1, int ldx, const float* w0, const float* w1, int ldw, const float* b0,
+                                   const float* b1, const float* rd0, const float* rd1, const float* add0, const float* add1, int ldadd,
+                                   const float* tail0, const float* tail1, int ntail, float* y0, float* y1, int ldy, int M, int N, int K,
+                                   int relu, void* stream) {
+  if (!x0 || !x1 || !w0 || !w1 || !y0 || !y1 || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldw < K || (!b0) != (!b1) || (!rd0) != (!rd1) ||
+      (!add0) != (!add1) || (!tail0) != (!tail1) || ldy < N + (tail0 ? ntail : 0) || (add0 && ldadd < N) ||
+      (tail0 && (ntail <= 0 || (N % 32) == 0 || (N % 32) + ntail > 32)))
+    return tfail(SGRL_ERR_ARG, "sgrl_linear_forward_twin_fused: bad argument");
+  SArgs2 p;
+  p.a[0] = SArgs{x0, ldx, nullptr, 0, w0, ldw, b0, relu ? 1 : 0, rd0, y0, ldy, nullptr, M, N, K, 0, nullptr, nullptr, add0, ldadd, tail0, ntail};
+  p.a[1] = SArgs{x1, ldx, nullptr, 0, w1, ldw, b1, relu ? 1 : 0, rd1, y1, ldy, nullptr, M, N, K, 0, nullptr, nullptr, add1, ldadd, tail1, ntail};
   int tn, tm, splits;
   for (int i = 0; i < 2; i++) { const int rc = plan<false>(p.a[i], nullptr, &tn, &tm, &splits); if (rc != SGRL_OK) return rc; }
   hipLaunchKernelGGL(k_sgemm_twin<false>, dim3(tn, tm, 2), dim3(256), 0, (hipStream_t)stream, p);

@@ -35,8 +35,8 @@ class Linear(nn.Linear):
     weight / bias gradient -- runs on this library's small-product kernels (train_ops.linear, csrc/train_gemm.hip); `relu`
     folds the activation that follows the layer into the product's epilogue and its mask into the backward products."""
 
-    def forward(self, x, relu=False, rowdiv=None):
-        return train_ops.linear(x, self.weight, self.bias, relu, rowdiv)
+    def forward(self, x, relu=False, rowdiv=None, addend=None, tail=None):
+        return train_ops.linear(x, self.weight, self.bias, relu, rowdiv, addend, tail)
 
 
 class ConcatPositionalEmbedding(nn.Module):
@@ -54,7 +54,7 @@ class ConcatPositionalEmbedding(nn.Module):
 
 def _invariants(x, gdir, proj, lin1, lin2):
     """x [B,L,3,C] -> (features [B,L,out], F_norm [B,L,1])."""
-    z = torch.cat([proj(x), gdir], dim=-1)
+    z = proj(x, tail=gdir)                      # [proj(x) | gdir]: the appended pair rides on the projection's launch
     gram, fn = train_ops.gram_fn(z)
     return lin2(lin1(gram, relu=True)), fn
 
@@ -122,8 +122,8 @@ class SubequivariantEncoderLayer(nn.Module):
         inv, fn = _invariants(g1, gdir, self.g_proj2, self.linear_g1, self.linear_g2)
         c = torch.cat([inv, ng], dim=-1)
         mat = self.linear4(self.linear3(c, relu=True), rowdiv=fn).view(*ng.shape[:2], Z_DIM, Z_DIM)
-        z3 = torch.cat([self.g_proj3(g1), gdir], dim=-1)
-        g = g + self.linear5(train_ops.zmat(z3, mat))
+        z3 = self.g_proj3(g1, tail=gdir)
+        g = self.linear5(train_ops.zmat(z3, mat), addend=g)
         ng = train_ops.add_layer_norm(ng, self.linear2(self.linear1(c, relu=True), rowdiv=fn), self.norm2)
         return g, ng
 
@@ -208,7 +208,7 @@ class TransformerModel(nn.Module):
         if self.output_size == 1:
             return self.decoder_ng(c, rowdiv=fn)
         mat = self.linear2_m(self.linear1_m(c, relu=True), rowdiv=fn).view(B, L, Z_DIM, Z_DIM)
-        zh = torch.cat([self.g_proj(out_g), gdir], dim=-1)
+        zh = self.g_proj(out_g, tail=gdir)
         vec = self.decoder_g(train_ops.zmat(zh, mat)).squeeze(-1)   # [B,L,3]
         return torch.einsum("blsk,bls->blk", g0[..., 5:8], vec)
 
@@ -220,8 +220,8 @@ class TransformerModel(nn.Module):
 # is one launch for the pair (train_ops.linear2), and the weight-free operations (Gram invariants, attention, the equivariant
 # contraction, residual adds, concatenations) simply see twice the nodes.  Same arithmetic per network as
 # TransformerModel.forward, operation by operation (tests/test_set_critic.py, tests/test_train_ops_gpu.py).
-def _lin2(l0, l1, x, relu=False, rowdiv=None, shared=False):
-    return train_ops.linear2(x, l0.weight, l1.weight, l0.bias, l1.bias, relu, rowdiv, shared)
+def _lin2(l0, l1, x, relu=False, rowdiv=None, shared=False, addend=None, tail=None):
+    return train_ops.linear2(x, l0.weight, l1.weight, l0.bias, l1.bias, relu, rowdiv, shared, addend, tail)
 
 
 def _norm2(n0, n1, x, res=None):
@@ -229,7 +229,7 @@ def _norm2(n0, n1, x, res=None):
 
 
 def _invariants2(x, gdir2, proj, lin1, lin2):
-    z = torch.cat([_lin2(proj[0], proj[1], x), gdir2], dim=-1)
+    z = _lin2(proj[0], proj[1], x, tail=gdir2)
     gram, fn = train_ops.gram_fn(z)
     return _lin2(lin2[0], lin2[1], _lin2(lin1[0], lin1[1], gram, relu=True)), fn
 
@@ -263,8 +263,8 @@ def _layer2(l, g, ng, gdir, gdir2, bias):
     c = torch.cat([inv, ng], dim=-1)
     mat = _lin2(l[0].linear4, l[1].linear4, _lin2(l[0].linear3, l[1].linear3, c, relu=True), rowdiv=fn)
     mat = mat.view(*ng.shape[:3], Z_DIM, Z_DIM)
-    z3 = torch.cat([_lin2(l[0].g_proj3, l[1].g_proj3, g1), gdir2], dim=-1)
-    g = g + _lin2(l[0].linear5, l[1].linear5, train_ops.zmat(z3, mat))
+    z3 = _lin2(l[0].g_proj3, l[1].g_proj3, g1, tail=gdir2)
+    g = _lin2(l[0].linear5, l[1].linear5, train_ops.zmat(z3, mat), addend=g)
     ng = _norm2(l[0].norm2, l[1].norm2, ng, _lin2(l[0].linear2, l[1].linear2, _lin2(l[0].linear1, l[1].linear1, c, relu=True), rowdiv=fn))
     return g, ng
 

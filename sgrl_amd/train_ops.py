@@ -39,6 +39,8 @@ def _L():
         L.sgrl_zmat_backward.argtypes = [vp, vp, vp, vp, vp, ci, vp]
         L.sgrl_attention_forward.argtypes = [vp, vp, vp, vp, ctypes.c_float, vp, vp, vp, ci, ci, vp]
         L.sgrl_attention_backward.argtypes = [vp, vp, vp, ctypes.c_float, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]
+        L.sgrl_linear_forward_fused.argtypes = [vp, ci, vp, ci, vp, vp, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp]
+        L.sgrl_linear_forward_twin_fused.argtypes = [vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, ci, ci, vp]
         L.sgrl_add_ln_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ctypes.c_float, vp]
         L.sgrl_add_ln_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]
         L.sgrl_train_ws_floats.restype = ctypes.c_int64
@@ -100,7 +102,7 @@ def flush_wgrads(todo):
         for i, r in enumerate(recs):
             d[i] = (r["dy"].data_ptr(), 0 if r["y"] is None else r["y"].data_ptr(), 0 if r["rowdiv"] is None else r["rowdiv"].data_ptr(),
                     r["x"].data_ptr(), r["dw"].data_ptr(), 0 if r["db"] is None else r["db"].data_ptr(), r["dy"].stride(0),
-                    r["N"], r["x"].stride(0), r["K"], r["M"], r["N"], r["K"], 1 if r["relu"] else 0)
+                    r.get("ldy", r["N"]), r["x"].stride(0), r["K"], r["M"], r["N"], r["K"], 1 if r["relu"] else 0)
         _check(L, L.sgrl_linear_wgrad_group(len(recs), ctypes.c_void_p(d.ctypes.data), _p(_scratch(dev)), ctypes.c_void_p(stream)),
                "sgrl_linear_wgrad_group")
         with torch.no_grad():
@@ -121,7 +123,7 @@ def _p(t):
 
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, relu, rowdiv):
+    def forward(ctx, x, weight, bias, relu, rowdiv, addend=None, tail=None):
         L = _L()
         N, K = weight.shape
         x2 = x.reshape(-1, K)
@@ -134,17 +136,34 @@ class _LinearFn(torch.autograd.Function):
             rd = rowdiv.reshape(-1)
             rd = rd if rd.is_contiguous() else rd.contiguous()
             assert rd.shape[0] == M and not relu
-        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        # fused followers (include/sgrl_train.h sgrl_linear_forward_fused): a residual added to the result, columns appended to it
+        nt = 0 if tail is None else tail.shape[-1]
+        ad2 = tl2 = None
+        if addend is not None:
+            assert not relu and rd is None and tail is None
+            ad2 = addend.reshape(M, N)
+            ad2 = ad2 if (ad2.stride(1) == 1 and ad2.stride(0) >= N) else ad2.contiguous()
+        if tail is not None:
+            tl2 = tail.reshape(M, nt)
+            tl2 = tl2 if tl2.is_contiguous() else tl2.contiguous()
+        y = torch.empty((M, N + nt), dtype=torch.float32, device=x.device)
         st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        _check(L, L.sgrl_linear_forward(_p(x2), x2.stride(0), _p(w), K, _p(bias), _p(rd), _p(y), N, M, N, K, 1 if relu else 0, st),
-               "sgrl_linear_forward")
+        if ad2 is None and tl2 is None:
+            _check(L, L.sgrl_linear_forward(_p(x2), x2.stride(0), _p(w), K, _p(bias), _p(rd), _p(y), N, M, N, K, 1 if relu else 0, st),
+                   "sgrl_linear_forward")
+        else:
+            _check(L, L.sgrl_linear_forward_fused(_p(x2), x2.stride(0), _p(w), K, _p(bias), _p(rd), _p(ad2), 0 if ad2 is None else ad2.stride(0),
+                                                  _p(tl2), nt, _p(y), N + nt, M, N, K, 1 if relu else 0, st), "sgrl_linear_forward_fused")
+        ctx.ntail = nt
+        ctx.ad_shape = None if addend is None else addend.shape
+        ctx.tail_shape = None if tail is None else tail.shape
         ctx.save_for_backward(x2, w, y if (relu or rd is not None) else None, rd)
         ctx.has_bias, ctx.relu = bias is not None, bool(relu)
         # leaf parameters (what deferred_wgrads may postpone): kept by reference so that their .grad can be set at the flush
         ctx.leaf = (weight, bias) if (weight.is_leaf and (bias is None or bias.is_leaf)) else None
         ctx.x_shape = x.shape
         ctx.rd_shape = None if rowdiv is None else rowdiv.shape
-        return y.view(*x.shape[:-1], N)
+        return y.view(*x.shape[:-1], N + nt)
 
     @staticmethod
     def backward(ctx, dy):
@@ -152,9 +171,12 @@ class _LinearFn(torch.autograd.Function):
         x2, w, yo, rd = ctx.saved_tensors
         N, K = w.shape
         M = x2.shape[0]
-        dy2 = dy.reshape(M, N)
-        if dy2.stride(1) != 1 or dy2.stride(0) < N:
-            dy2 = dy2.contiguous()
+        nt = ctx.ntail
+        dyf = dy.reshape(M, N + nt)
+        if dyf.stride(1) != 1 or dyf.stride(0) < N + nt:
+            dyf = dyf.contiguous()
+        dy2 = dyf[:, :N] if nt else dyf             # the product's own columns: a row-strided view, read as is
+        ldyo = N + nt                               # row stride of the saved output (ReLU mask / row-divisor gradient)
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         need_rd = rd is not None and ctx.needs_input_grad[4]
         if need_b and not need_w:
@@ -169,16 +191,18 @@ class _LinearFn(torch.autograd.Function):
         deferred = _pending is not None and need_w and ctx.leaf is not None
         if deferred:                              # postponed: computed and stored into .grad when the deferred_wgrads context exits
             _pending.append({"dy": dy2, "y": yo if ctx.relu else None, "rowdiv": rd, "x": x2, "dw": dw, "db": db, "M": M, "N": N,
-                             "K": K, "relu": ctx.relu, "dev": dy.device, "stream": stream,
+                             "K": K, "relu": ctx.relu, "dev": dy.device, "stream": stream, "ldy": ldyo,
                              "w_param": ctx.leaf[0] if ctx.needs_input_grad[1] else None,
                              "b_param": ctx.leaf[1] if need_b else None})
             now_w = now_b = None
         if dx is not None or now_w is not None or now_b is not None or drd is not None:
-            _check(L, L.sgrl_linear_backward(_p(dy2), dy2.stride(0), _p(yo), N, 1 if ctx.relu else 0, _p(rd), _p(x2), x2.stride(0),
+            _check(L, L.sgrl_linear_backward(_p(dy2), dy2.stride(0), _p(yo), ldyo, 1 if ctx.relu else 0, _p(rd), _p(x2), x2.stride(0),
                                              _p(w), K, _p(dx), K, _p(now_w), K, _p(now_b), _p(drd), M, N, K, _p(_scratch(dy.device)), st),
                    "sgrl_linear_backward")
+        dadd = dy.reshape(ctx.ad_shape) if (ctx.ad_shape is not None and ctx.needs_input_grad[5]) else None
+        dtail = dyf[:, N:].reshape(ctx.tail_shape) if (nt and ctx.needs_input_grad[6]) else None
         return (dx.view(ctx.x_shape) if need_x else None), (None if deferred else (dw if ctx.needs_input_grad[1] else None)), \
-               (None if deferred else db), None, (drd.view(ctx.rd_shape) if need_rd else None)
+               (None if deferred else db), None, (drd.view(ctx.rd_shape) if need_rd else None), dadd, dtail
 
 
 class _Linear2Fn(torch.autograd.Function):
@@ -186,7 +210,7 @@ class _Linear2Fn(torch.autograd.Function):
     x is either ONE input both share, [..., K], or their two inputs stacked, [2, ..., K]; the result is stacked, [2, ..., N]."""
 
     @staticmethod
-    def forward(ctx, x, w0, w1, b0, b1, relu, rowdiv, shared):
+    def forward(ctx, x, w0, w1, b0, b1, relu, rowdiv, shared, addend=None, tail=None):
         L = _L()
         N, K = w0.shape
         assert w1.shape == w0.shape and (b0 is None) == (b1 is None)
@@ -204,18 +228,40 @@ class _Linear2Fn(torch.autograd.Function):
             rd = rowdiv.reshape(2, -1)
             rd = rd if rd.is_contiguous() else rd.contiguous()
             assert rd.shape[1] == M and not relu
-        y = torch.empty((2, M, N), dtype=torch.float32, device=x.device)
+        # fused followers: addend [2, ..., N] (a residual per network), tail [..., nt] or [2, ..., nt] (columns appended to each result)
+        nt = 0 if tail is None else tail.shape[-1]
+        ad2 = tl = None
+        if addend is not None:
+            assert not relu and rd is None and tail is None
+            ad2 = addend.reshape(2, M, N)
+            ad2 = ad2 if ad2.is_contiguous() else ad2.contiguous()
+        if tail is not None:
+            tl = tail.reshape(-1, M, nt)             # one tail both networks share, or one each
+            tl = tl if tl.is_contiguous() else tl.contiguous()
+            tl = (tl[0], tl[0]) if tl.shape[0] == 1 else (tl[0], tl[1])
+        y = torch.empty((2, M, N + nt), dtype=torch.float32, device=x.device)
         st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        _check(L, L.sgrl_linear_forward_twin(_p(x0), _p(x1), xs.stride(-2), _p(w0), _p(w1), K, _p(b0), _p(b1),
-                                             _p(None if rd is None else rd[0]), _p(None if rd is None else rd[1]), _p(y[0]), _p(y[1]),
-                                             N, M, N, K, 1 if relu else 0, st), "sgrl_linear_forward_twin")
+        if ad2 is None and tl is None:
+            _check(L, L.sgrl_linear_forward_twin(_p(x0), _p(x1), xs.stride(-2), _p(w0), _p(w1), K, _p(b0), _p(b1),
+                                                 _p(None if rd is None else rd[0]), _p(None if rd is None else rd[1]), _p(y[0]), _p(y[1]),
+                                                 N, M, N, K, 1 if relu else 0, st), "sgrl_linear_forward_twin")
+        else:
+            _check(L, L.sgrl_linear_forward_twin_fused(_p(x0), _p(x1), xs.stride(-2), _p(w0), _p(w1), K, _p(b0), _p(b1),
+                                                       _p(None if rd is None else rd[0]), _p(None if rd is None else rd[1]),
+                                                       _p(None if ad2 is None else ad2[0]), _p(None if ad2 is None else ad2[1]), N,
+                                                       _p(None if tl is None else tl[0]), _p(None if tl is None else tl[1]), nt,
+                                                       _p(y[0]), _p(y[1]), N + nt, M, N, K, 1 if relu else 0, st),
+                   "sgrl_linear_forward_twin_fused")
+        ctx.ntail = nt
+        ctx.ad_shape = None if addend is None else addend.shape
+        ctx.tail_shape = None if tail is None else tail.shape
         ctx.save_for_backward(xs, w0, w1, y if (relu or rd is not None) else None, rd)
         ctx.has_bias, ctx.relu, ctx.shared = b0 is not None, bool(relu), bool(shared)
         ctx.leaf = [((w, b) if (w.is_leaf and (b is None or b.is_leaf)) else None) for w, b in params]
         ctx.params = params
         ctx.x_shape = x.shape
         ctx.rd_shape = None if rowdiv is None else rowdiv.shape
-        return y.view(2, *lead, N)
+        return y.view(2, *lead, N + nt)
 
     @staticmethod
     def backward(ctx, dy):
@@ -223,10 +269,13 @@ class _Linear2Fn(torch.autograd.Function):
         xs, w0, w1, yo, rd = ctx.saved_tensors
         N, K = w0.shape
         M = xs.shape[-2]
-        dy2 = dy.reshape(2, M, N)                    # a row-strided view (the gradient of one part of a concatenation) is read as is
-        if dy2.stride(2) != 1 or dy2.stride(1) < N or dy2.stride(0) < 0:
-            dy2 = dy2.contiguous()
+        nt = ctx.ntail
+        dyf = dy.reshape(2, M, N + nt)               # a row-strided view (the gradient of one part of a concatenation) is read as is
+        if dyf.stride(2) != 1 or dyf.stride(1) < N + nt or dyf.stride(0) < 0:
+            dyf = dyf.contiguous()
+        dy2 = dyf[:, :, :N] if nt else dyf
         lddy = dy2.stride(1)
+        ldyo = N + nt
         need_x = ctx.needs_input_grad[0]
         need_w = [ctx.needs_input_grad[1], ctx.needs_input_grad[2]]
         need_b = [ctx.has_bias and ctx.needs_input_grad[3], ctx.has_bias and ctx.needs_input_grad[4]]
@@ -238,12 +287,12 @@ class _Linear2Fn(torch.autograd.Function):
         drd = torch.empty((2, M), dtype=torch.float32, device=dev) if need_rd else None
         if need_x:
             _check(L, L.sgrl_linear_dgrad_twin(_p(dy2[0]), _p(dy2[1]), lddy, _p(None if yo is None else yo[0]), _p(None if yo is None else yo[1]),
-                                               N, 1 if ctx.relu else 0, _p(None if rd is None else rd[0]), _p(None if rd is None else rd[1]),
+                                               ldyo, 1 if ctx.relu else 0, _p(None if rd is None else rd[0]), _p(None if rd is None else rd[1]),
                                                _p(w0), _p(w1), K, _p(dx[0]), _p(dx[1]), K, _p(None if drd is None else drd[0]),
                                                _p(None if drd is None else drd[1]), M, N, K, st), "sgrl_linear_dgrad_twin")
         elif need_rd:                               # the row divisor's gradient without an input gradient: the single-network kernel twice
             for i in range(2):
-                _check(L, L.sgrl_linear_backward(_p(dy2[i]), lddy, _p(yo[i]), N, 0, _p(rd[i]), _p(None), 0, _p(None), 0, _p(None), 0,
+                _check(L, L.sgrl_linear_backward(_p(dy2[i]), lddy, _p(yo[i]), ldyo, 0, _p(rd[i]), _p(None), 0, _p(None), 0, _p(None), 0,
                                                  _p(None), 0, _p(None), _p(drd[i]), M, N, K, _p(_scratch(dev)), st), "sgrl_linear_backward")
         # weight / bias gradients: one descriptor per network -- postponed (deferred_wgrads) or issued together now
         grads_w, grads_b, recs = [None, None], [None, None], []
@@ -255,7 +304,7 @@ class _Linear2Fn(torch.autograd.Function):
             db = torch.empty((N,), dtype=torch.float32, device=dev) if need_b[i] else None
             deferred = _pending is not None and ctx.leaf[i] is not None
             rec = {"dy": dy2[i], "y": yo[i] if ctx.relu else None, "rowdiv": None if rd is None else rd[i], "x": x_i, "dw": dw, "db": db,
-                   "M": M, "N": N, "K": K, "relu": ctx.relu, "dev": dev, "stream": stream,
+                   "M": M, "N": N, "K": K, "relu": ctx.relu, "dev": dev, "stream": stream, "ldy": ldyo,
                    "w_param": (w if need_w[i] else None) if deferred else None, "b_param": (b if need_b[i] else None) if deferred else None}
             if deferred:
                 _pending.append(rec)
@@ -267,7 +316,11 @@ class _Linear2Fn(torch.autograd.Function):
         dx_out = None
         if need_x:
             dx_out = (dx[0] + dx[1]).view(ctx.x_shape) if ctx.shared else dx.view(ctx.x_shape)
-        return dx_out, grads_w[0], grads_w[1], grads_b[0], grads_b[1], None, (drd.view(ctx.rd_shape) if need_rd else None), None
+        dadd = dy.reshape(ctx.ad_shape) if (ctx.ad_shape is not None and ctx.needs_input_grad[8]) else None
+        dtail = None
+        if nt and ctx.needs_input_grad[9]:
+            dtail = dyf[:, :, N:].reshape(2, *ctx.x_shape[(0 if ctx.shared else 1):-1], nt).sum_to_size(ctx.tail_shape)
+        return dx_out, grads_w[0], grads_w[1], grads_b[0], grads_b[1], None, (drd.view(ctx.rd_shape) if need_rd else None), None, dadd, dtail
 
 
 class _GramFn(torch.autograd.Function):
@@ -424,24 +477,38 @@ def _on_device_with_grad(*ts):
         any(t is not None and t.requires_grad for t in ts)
 
 
-def linear(x, weight, bias=None, relu=False, rowdiv=None):
+def _tail_fits(N, tail):
+    return tail is None or (N % 32 != 0 and N % 32 + tail.shape[-1] <= 32)
+
+
+def linear(x, weight, bias=None, relu=False, rowdiv=None, addend=None, tail=None):
     """act(x @ weight.T + bias) / rowdiv, differentiable in x, weight, bias and rowdiv (act = ReLU if relu; rowdiv: one value
-    per row, broadcast over the output features -- the `/ F_norm` of the reference's SET layers)."""
-    if _on_device_with_grad(x, weight, bias, rowdiv):
-        return _LinearFn.apply(x, weight, bias, bool(relu), rowdiv)
+    per row, broadcast over the output features -- the `/ F_norm` of the reference's SET layers).  Two followers can ride on
+    the product's launch: `addend` (same shape as the result) is added to it -- a residual --, `tail` [..., t] is appended to it
+    along the last dimension (torch.cat([result, tail], -1))."""
+    if _on_device_with_grad(x, weight, bias, rowdiv, addend, tail) and _tail_fits(weight.shape[0], tail) and \
+            (addend is None or (not relu and rowdiv is None and tail is None)):
+        return _LinearFn.apply(x, weight, bias, bool(relu), rowdiv, addend, tail)
     y = F.linear(x, weight, bias)
     y = F.relu(y) if relu else y
-    return y if rowdiv is None else y / rowdiv
+    y = y if rowdiv is None else y / rowdiv
+    y = y if addend is None else addend + y
+    return y if tail is None else torch.cat([y, tail], dim=-1)
 
 
-def linear2(x, w0, w1, b0=None, b1=None, relu=False, rowdiv=None, shared=False):
+def linear2(x, w0, w1, b0=None, b1=None, relu=False, rowdiv=None, shared=False, addend=None, tail=None):
     """`linear` for the same layer of two networks at once: returns [2, ..., N]; x = the input both share ([..., K], shared=True) or
-    their inputs stacked ([2, ..., K]); rowdiv stacked [2, ..., 1]."""
-    if _on_device_with_grad(x, w0, w1, b0, b1, rowdiv):
-        return _Linear2Fn.apply(x, w0, w1, b0, b1, bool(relu), rowdiv, bool(shared))
+    their inputs stacked ([2, ..., K]); rowdiv stacked [2, ..., 1]; addend stacked [2, ..., N]; tail [2, ..., t] (or one both share,
+    [..., t] / expanded)."""
+    if _on_device_with_grad(x, w0, w1, b0, b1, rowdiv, addend, tail) and _tail_fits(w0.shape[0], tail) and \
+            (addend is None or (not relu and rowdiv is None and tail is None)):
+        if tail is not None and tail.dim() == x.dim() + (1 if shared else 0) and tail.stride(0) == 0:
+            tail = tail[0]                          # an expanded pair: the one tensor both networks share
+        return _Linear2Fn.apply(x, w0, w1, b0, b1, bool(relu), rowdiv, bool(shared), addend, tail)
     xs = (x, x) if shared else (x[0], x[1])
-    return torch.stack([linear(xs[0], w0, b0, relu, None if rowdiv is None else rowdiv[0]),
-                        linear(xs[1], w1, b1, relu, None if rowdiv is None else rowdiv[1])])
+    ts = (None, None) if tail is None else ((tail[0], tail[1]) if tail.dim() == xs[0].dim() + 1 else (tail, tail))
+    return torch.stack([linear(xs[0], w0, b0, relu, None if rowdiv is None else rowdiv[0], None if addend is None else addend[0], ts[0]),
+                        linear(xs[1], w1, b1, relu, None if rowdiv is None else rowdiv[1], None if addend is None else addend[1], ts[1])])
 
 
 def gram_fn(z):

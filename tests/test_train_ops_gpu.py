@@ -381,3 +381,50 @@ def test_add_layer_norm_matches_float64(rows, twin, with_res):
     with torch.no_grad():
         yn = train_ops.add_layer_norm(xs, None, fz)
     assert yn.grad_fn is None and float((yn - fz(xs)).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("twin", [False, True])
+def test_linear_followers_match_float64(twin):
+    """The two followers that ride on a product's launch (sgrl_linear_forward_fused): `tail` appends columns (z = [proj(x) | gdir],
+    30 + 2 of a 32-wide row), `addend` adds a residual (g + linear5(.)); values and every gradient against float64 torch.cat / add."""
+    from sgrl_amd import train_ops
+    g = torch.Generator().manual_seed(11 + twin)
+    lead = (2,) if twin else ()
+    x = torch.randn(*lead, 100, 7, 3, 128, generator=g)
+    gdir = torch.randn(100, 7, 3, 2, generator=g)
+    ws = [torch.randn(30, 128, generator=g) / 11 for _ in range(2)]
+    w5 = [torch.randn(128, 32, generator=g) / 6 for _ in range(2)]
+    res = torch.randn(*lead, 100, 7, 3, 128, generator=g)
+    dz = torch.randn(*lead, 100, 7, 3, 32, generator=g)
+    dg = torch.randn(*lead, 100, 7, 3, 128, generator=g)
+
+    def run(dev, dt):
+        xs, gd, rs = x.to(dev, dt).requires_grad_(), gdir.to(dev, dt).requires_grad_(), res.to(dev, dt).requires_grad_()
+        w = [t.to(dev, dt).requires_grad_() for t in ws]
+        v = [t.to(dev, dt).requires_grad_() for t in w5]
+        if dev == "cpu":
+            if twin:
+                z = torch.stack([torch.cat([xs[i] @ w[i].T, gd], -1) for i in range(2)])
+                out = torch.stack([rs[i] + z[i] @ v[i].T for i in range(2)])
+            else:
+                z = torch.cat([xs @ w[0].T, gd], -1)
+                out = rs + z @ v[0].T
+        elif twin:
+            z = train_ops.linear2(xs, w[0], w[1], tail=gd.unsqueeze(0).expand(2, *gd.shape))
+            out = train_ops.linear2(z, v[0], v[1], addend=rs)
+            assert type(z.grad_fn).__name__.startswith("_Linear2Fn")
+        else:
+            z = train_ops.linear(xs, w[0], tail=gd)
+            out = train_ops.linear(z, v[0], addend=rs)
+            assert type(z.grad_fn).__name__.startswith("_LinearFn")
+        (z * dz.to(dev, dt)).sum().backward(retain_graph=True)
+        (out * dg.to(dev, dt)).sum().backward()
+        grads = [xs.grad, gd.grad, rs.grad] + [t.grad for t in (w if twin else w[:1])] + [t.grad for t in (v if twin else v[:1])]
+        return [z.detach(), out.detach()] + grads
+    ref = run("cpu", torch.float64)
+    got = run("cuda", torch.float32)
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape
+        assert float((a.cpu().double() - b).abs().max()) < 2e-5 * (float(b.abs().max()) + 1.0) * 6
+    got2 = run("cuda", torch.float32)
+    assert all(torch.equal(a, b) for a, b in zip(got, got2))
