@@ -194,7 +194,7 @@ class TransformerModel(nn.Module):
         if not geo_grad:
             g0 = g0.detach()
         n0 = x[..., 3 * G_NUM:]
-        gdir = g0[..., 1:3]
+        gdir = g0[..., 1:3].contiguous()        # one copy per forward: every projection appends it (train_ops.linear tail)
         scale = math.sqrt(self.ninp)
         g = self.g_encoder(g0) * scale
         ng = self.encoder(n0) * scale
@@ -278,7 +278,7 @@ def twin_forward(m0, m1, x, graph, geo_grad=True):
     if not geo_grad:
         g0 = g0.detach()
     n0 = x[..., 3 * G_NUM:]
-    gdir = g0[..., 1:3]
+    gdir = g0[..., 1:3].contiguous()
     gdir2 = gdir.unsqueeze(0).expand(2, B, L, 3, 2)
     scale = math.sqrt(m0.ninp)
     g = _lin2(m0.g_encoder, m1.g_encoder, g0, shared=True) * scale
