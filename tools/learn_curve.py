@@ -11,7 +11,7 @@
     `sgrl_get_records` every 50 steps of environments whose episode has lasted at least 50 steps.  Writes
     gpurun_out/policy_states.npz (copied to tests/golden/ by hand).
 
-usage: learn_curve.py [train_seconds=480] [envs_per_morph=64]
+usage: learn_curve.py [train_seconds=480] [envs_per_morph=64] [seed=3] [hopper|walker]
 """
 import json
 import os
@@ -32,6 +32,8 @@ OUT = os.path.join(REPO, "gpurun_out")
 os.makedirs(OUT, exist_ok=True)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 480.0
 per = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+seed = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+family = sys.argv[4] if len(sys.argv) > 4 else "hopper"      # "walker": BASELINE.json config 3 (the eight 3D_Walker++ variants), training only
 HOPPERS = ["3d_hopper_3_shin", "3d_hopper_4_lower_shin", "3d_hopper_5_full"]
 
 
@@ -42,7 +44,8 @@ def diag(env):
 
 def train():
     args = default_train_args()
-    tr = DeviceTrainer(HOPPERS, per, args=args, seed=3, device="cuda:0", max_buffer_size=400000, graph_updates=True)
+    names = HOPPERS if family == "hopper" else sorted(n for n in mjcf.list_assets() if "walker" in n)
+    tr = DeviceTrainer(names, per, args=args, seed=seed, device="cuda:0", max_buffer_size=400000, graph_updates=True)
     env = tr.ro.env
     curve = []
     t0 = time.time()
@@ -69,7 +72,7 @@ def train():
         if rnd % 5 == 0:
             print("round %d: return %.2f length %.1f iters %d wall %.0f s" % (rnd, s["performance/train_return"],
                   s["performance/train_length"], s["per_morph_iter"], s["wall_s"]), flush=True)
-    out = {"config": "BASELINE.json config 2: 3D_Hopper++ (%s) x %d envs" % (", ".join(HOPPERS), per),
+    out = {"seed": seed, "config": "BASELINE.json config %s (%s) x %d envs" % ("2: 3D_Hopper++" if family == "hopper" else "3: 3D_Walker++", ", ".join(names), per),
            "schedule": "reference trainer.py:143-286 (per_morph_iter updates per morphology per round, batch 100, lr 1e-4, expl_noise 0.126)",
            "random_policy": {"train_return_mean": float(np.mean(rand_returns)) if rand_returns else None,
                              "train_length_mean": float(np.mean(rand_lengths)) if rand_lengths else None, "rounds": len(rand_returns)},
@@ -137,6 +140,8 @@ def capture(names, driver, policy=None, steps=600, per_morph=8, tag=""):
 
 def main():
     tr = train()
+    if family != "hopper":
+        return
     torch.save({k: v.detach().cpu() for k, v in tr.agent.actor.state_dict().items()}, os.path.join(OUT, "hopper_actor.pt"))
     A = mjcf.list_assets()
     fam = {"hopper": sorted(n for n in A if "hopper" in n), "walker": sorted(n for n in A if "walker" in n),
