@@ -314,8 +314,10 @@ __global__ __launch_bounds__(256) void k_colsum(const float* g, int ldg, const f
 }
 
 // drowdiv[m] = -(sum_n dy[m][n] y[m][n]) / rowdiv[m]   (y = (x w^T + b) / rowdiv: d/d rowdiv of the forward); one wave per row
+// (blockIdx.y = 1: the second argument set -- the twin critics' pair of layers in one launch)
 __global__ __launch_bounds__(256) void k_rowdot(const float* dy, int lddy, const float* y, int ldy, const float* rowdiv, float* out,
-                                                int M, int N) {
+                                                int M, int N, const float* dy1, const float* y1, const float* rowdiv1, float* out1) {
+  if (blockIdx.y) { dy = dy1; y = y1; rowdiv = rowdiv1; out = out1; }
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (m >= M) return;
   float s = 0.f;
@@ -722,7 +724,8 @@ int sgrl_linear_backward(const float* dy, int lddy, const float* y, int ldyo, in
   hipStream_t st = (hipStream_t)stream;
   const float* mask = relu ? y : nullptr;
   if (drowdiv) {
-    hipLaunchKernelGGL(k_rowdot, dim3((M + 3) / 4), dim3(256), 0, st, dy, lddy, y, ldyo, rowdiv, drowdiv, M, N);
+    hipLaunchKernelGGL(k_rowdot, dim3((M + 3) / 4), dim3(256), 0, st, dy, lddy, y, ldyo, rowdiv, drowdiv, M, N,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
     { int lrc = SGRL_OK; if (!launched("k_rowdot launch failed", &lrc)) return lrc; }
   }
   if (dx && (!w || ldw < K || lddx < K)) return tfail(SGRL_ERR_ARG, "sgrl_linear_backward: bad weight / dx argument");
@@ -790,8 +793,7 @@ int sgrl_linear_dgrad_twin(const float* dy0, const float* dy1, int lddy, const f
     return tfail(SGRL_ERR_ARG, "sgrl_linear_dgrad_twin: bad argument");
   hipStream_t st = (hipStream_t)stream;
   if (drd0) {
-    hipLaunchKernelGGL(k_rowdot, dim3((M + 3) / 4), dim3(256), 0, st, dy0, lddy, y0, ldyo, rd0, drd0, M, N);
-    hipLaunchKernelGGL(k_rowdot, dim3((M + 3) / 4), dim3(256), 0, st, dy1, lddy, y1, ldyo, rd1, drd1, M, N);
+    hipLaunchKernelGGL(k_rowdot, dim3((M + 3) / 4, 2), dim3(256), 0, st, dy0, lddy, y0, ldyo, rd0, drd0, M, N, dy1, y1, rd1, drd1);
     { int lrc = SGRL_OK; if (!launched("k_rowdot launch failed", &lrc)) return lrc; }
   }
   SArgs2 p;
