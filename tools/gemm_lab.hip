@@ -327,6 +327,9 @@ int main(int argc, char** argv) {
         ms = run3<F, 2, 2, 1, 2, 32, 2, false, false, false, 0, 2, false, 2>(aww, reps); printf("   f16x3  W words  64x128/4w bk32pf2 %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
         ms = run3<F, 4, 1, 1, 2, 16, 2, false, false, false, 0, 2, false, 2>(aww, reps); printf("   f16x3  W words 128x64/4w         %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
         ms = run3<F, 2, 4, 1, 1, 16, 2, false, false, false, 0, 2, false, 2>(aww, reps); printf("   f16x3  W words  64x128/8w(32x32) %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
+        ms = run3<F, 2, 2, 2, 2, 16, 2, false, false, false, 0, 2, false, 2>(aww, reps); printf("   f16x3  W words 128x128/4w (64x64 per wave) %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
+        ms = run3<F, 2, 2, 2, 2, 16, 1, false, false, false, 0, 2, false, 2>(aww, reps); printf("   f16x3  W words 128x128/4w (64x64 per wave) pf1 %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
+        ms = run3<F, 2, 4, 2, 1, 16, 2, false, false, false, 0, 2, true, 2>(aww, reps); printf("   f16x3  W words 128x128/8w SKEW (64x32 per wave) %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
         ms = run6<F, 3>(a6, reps); printf("   gemm6  planes by LDS-DMA, 3 stages  %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
         ms = run6<F, 4>(a6, reps); printf("   gemm6  planes by LDS-DMA, 4 stages  %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
         ms = run6<F, 5>(a6, reps); printf("   gemm6  planes by LDS-DMA, 5 stages  %6.1f us %5.1f TF", ms * 1e3, gf / (ms * 1e-3) / 1e12); err(); printf("\n"); \
