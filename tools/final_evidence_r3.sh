@@ -34,5 +34,5 @@ echo "second bench done"
 timeout 900 python3 -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/r3_gpu_pytest.log
 echo "pytest done"
 timeout 400 python3 tools/config_sweep.py > $RAW/sweep.log 2>&1; cp gpurun_out/config_sweep.json $O/r3_config_sweep.json 2>/dev/null
-tail -3 $RAW/bench_default.err $RAW/stats.err $O/summarize.log > $O/stderr_tails.log 2>&1
+for f in $RAW/bench_default.err $RAW/stats.err $O/summarize.log; do tail -n 3 $f; done > $O/stderr_tails.log 2>&1
 ls -la $O
