@@ -486,12 +486,14 @@ def linear(x, weight, bias=None, relu=False, rowdiv=None, addend=None, tail=None
     per row, broadcast over the output features -- the `/ F_norm` of the reference's SET layers).  Two followers can ride on
     the product's launch: `addend` (same shape as the result) is added to it -- a residual --, `tail` [..., t] is appended to it
     along the last dimension (torch.cat([result, tail], -1))."""
-    if _on_device_with_grad(x, weight, bias, rowdiv, addend, tail) and _tail_fits(weight.shape[0], tail) and \
-            (addend is None or (not relu and rowdiv is None and tail is None)):
-        return _LinearFn.apply(x, weight, bias, bool(relu), rowdiv, addend, tail)
-    y = F.linear(x, weight, bias)
-    y = F.relu(y) if relu else y
-    y = y if rowdiv is None else y / rowdiv
+    if _on_device_with_grad(x, weight, bias, rowdiv, addend, tail):
+        if _tail_fits(weight.shape[0], tail) and (addend is None or (not relu and rowdiv is None and tail is None)):
+            return _LinearFn.apply(x, weight, bias, bool(relu), rowdiv, addend, tail)
+        y = _LinearFn.apply(x, weight, bias, bool(relu), rowdiv, None, None)     # a follower the kernel does not take: own launches
+    else:
+        y = F.linear(x, weight, bias)
+        y = F.relu(y) if relu else y
+        y = y if rowdiv is None else y / rowdiv
     y = y if addend is None else addend + y
     return y if tail is None else torch.cat([y, tail], dim=-1)
 

@@ -89,3 +89,29 @@ def test_differentiable_and_checkpoint_round_trip(gold):
     pol2.change_morphology(pol.graph)
     with torch.no_grad():
         assert torch.equal(pol2(obs), pol(obs))
+
+
+def test_linear_followers_and_fused_norm_fall_back_to_the_plain_operations_on_the_cpu():
+    """train_ops.linear(tail= / addend=), linear2 and add_layer_norm(2) off the GPU are exactly cat / add / the LayerNorm module
+    (the HIP forms are held against float64 by tests/test_train_ops_gpu.py)."""
+    import torch
+    from sgrl_amd import train_ops
+    g = torch.Generator().manual_seed(5)
+    x, gd = torch.randn(4, 5, 3, 16, generator=g), torch.randn(4, 5, 3, 2, generator=g)
+    w0, w1 = torch.randn(30, 16, generator=g), torch.randn(30, 16, generator=g)
+    z = train_ops.linear(x, w0, tail=gd)
+    assert z.shape == (4, 5, 3, 32) and torch.equal(z, torch.cat([x @ w0.T, gd], -1))
+    r = torch.randn(4, 5, 3, 30, generator=g)
+    assert torch.equal(train_ops.linear(x, w0, addend=r), r + x @ w0.T)
+    z2 = train_ops.linear2(x, w0, w1, shared=True, tail=gd.unsqueeze(0).expand(2, *gd.shape))
+    assert torch.equal(z2[1], torch.cat([x @ w1.T, gd], -1)) and z2.shape == (2, 4, 5, 3, 32)
+    r2 = torch.randn(2, 4, 5, 3, 30, generator=g)
+    assert torch.equal(train_ops.linear2(x, w0, w1, shared=True, addend=r2)[0], r2[0] + x @ w0.T)
+    n0, n1 = torch.nn.LayerNorm(128), torch.nn.LayerNorm(128)
+    with torch.no_grad():
+        n1.weight.mul_(0.5); n1.bias.add_(0.25)
+    a, b = torch.randn(2, 6, 128, generator=g), torch.randn(2, 6, 128, generator=g)
+    assert torch.equal(train_ops.add_layer_norm(a[0], b[0], n0), n0(a[0] + b[0]))
+    assert torch.equal(train_ops.add_layer_norm(a[0], None, n0), n0(a[0]))
+    y = train_ops.add_layer_norm2(a, b, n0, n1)
+    assert torch.equal(y[0], n0(a[0] + b[0])) and torch.equal(y[1], n1(a[1] + b[1]))
