@@ -36,8 +36,8 @@ int sgrl_linear_forward(const float* x, int ldx, const float* w, int ldw, const 
  *   addend [M, N] (row stride ldadd): y += addend after the epilogue -- the residual of the vector stream, g + linear5(.)
  *     (reference SEActor.py:110);
  *   tail [M, ntail]: y[m][N + j] = tail[m][j] -- columns appended to the product's N (y has N + ntail <= ldy columns): the
- *     gravity / direction pair behind the 30 projected channels, z = [proj(x) | gdir] (reference SEActor.py:93-94); the appended
- *     columns must fall into the product's last 32-column tile (N % 32 != 0, N % 32 + ntail <= 32).
+ *     gravity / direction pair behind the 30 projected channels, z = [proj(x) | gdir] (reference SEActor.py:93-94), or the scalar
+ *     stream behind the invariant features, c = [inv | ng] (SEActor.py:98, 101); any ntail > 0.
  * The twin form does the same for the two critics' layers in one launch. */
 int sgrl_linear_forward_fused(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* rowdiv,
                               const float* addend, int ldadd, const float* tail, int ntail, float* y, int ldy, int M, int N, int K,

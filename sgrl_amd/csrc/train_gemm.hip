@@ -62,8 +62,8 @@ struct SArgs {
   float* ws; unsigned* counters;    // split scratch: [split][tile][TILE_WS] floats, one counter per tile (zero between calls)
   // forward only (both optional, last so that the other products' initialisers leave them null):
   const float* addend; int ldadd;   // C[m][n] += addend[m][n] after the epilogue (a residual stream: g + linear5(...))
-  const float* tail; int ntail;     // C[m][N + j] = tail[m][j], j < ntail: columns appended to the product's N (z = [proj(x) | gdir]);
-                                    // they must fall into the last column tile (N % 32 + ntail <= 32)
+  const float* tail; int ntail;     // C[m][N + j] = tail[m][j], j < ntail: columns appended to the product's N (z = [proj(x) | gdir],
+                                    // c = [inv | ng]): the last column tile's spare columns, then column tiles of their own
 };
 constexpr int TILE_WS = BT * BT + BT;
 constexpr int64_t kWsTiles = 4096;      // (split, tile) slots of the scratch buffer
@@ -100,6 +100,14 @@ __device__ __forceinline__ void sgemm_tile(const SArgs& a, float (*As)[LDP], flo
   const int k_begin = bz * a.kper, k_end = min(a.K, k_begin + a.kper);
   const bool a_vec = (a.lda & 3) == 0 && aligned16(a.A) && (!a.Amask || ((a.ldmask & 3) == 0 && aligned16(a.Amask)));
   const bool b_vec = (a.ldb & 3) == 0 && aligned16(a.B);
+  if (!AT && !BTR && a.tail && n0 >= a.N) {      // a column tile past the product: its slice of the appended block, copied
+    const int m = m0 + (t >> 3), c0 = n0 + 4 * (t & 7);
+    if (m < a.M)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (c0 + j < a.N + a.ntail) a.C[(size_t)m * a.ldc + c0 + j] = a.tail[(size_t)m * a.ntail + (c0 + j - a.N)];
+    return;
+  }
   const bool want_db = AT && a.db != nullptr && bx == 0;
   float4 dbp = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 ra[2][NLD], rb[2][NLD];               // global loads run TWO k-tiles ahead of the arithmetic
@@ -653,7 +661,7 @@ __global__ __launch_bounds__(256) void k_add_ln_bwd(const float* __restrict__ dy
 template <bool AT>
 int plan(SArgs& a, float* ws, int* tn, int* tm, int* splits_out, int64_t ws_slot0 = 0, int counter0 = 0) {
   constexpr int BK = AT ? BKW : BKF;
-  *tm = (a.M + BT - 1) / BT; *tn = (a.N + BT - 1) / BT;
+  *tm = (a.M + BT - 1) / BT; *tn = (a.N + (!AT && a.tail ? a.ntail : 0) + BT - 1) / BT;   // + the column tiles of an appended block
   const int ntiles = *tm * *tn;
   if (*tm > 65535) return tfail(SGRL_ERR_LIMIT, "train gemm: too many row tiles");
   const int ktiles = (a.K + BK - 1) / BK;
@@ -709,7 +717,7 @@ int sgrl_linear_forward_fused(const float* x, int ldx, const float* w, int ldw, 
                               const float* addend, int ldadd, const float* tail, int ntail, float* y, int ldy, int M, int N, int K,
                               int relu, void* stream) {
   if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldw < K || ldy < N + (tail ? ntail : 0) || (addend && ldadd < N) ||
-      (tail && (ntail <= 0 || (N % 32) == 0 || (N % 32) + ntail > 32)))
+      (tail && ntail <= 0))
     return tfail(SGRL_ERR_ARG, "sgrl_linear_forward_fused: bad argument");
   SArgs a{x, ldx, nullptr, 0, w, ldw, bias, relu ? 1 : 0, rowdiv, y, ldy, nullptr, M, N, K, 0, nullptr, nullptr, addend, ldadd, tail, ntail};
   return launch<false, false>(a, nullptr, (hipStream_t)stream);
@@ -773,7 +781,7 @@ int sgrl_linear_forward_twin_fused(const float* x0, const float* x1, int ldx, co
                                    int relu, void* stream) {
   if (!x0 || !x1 || !w0 || !w1 || !y0 || !y1 || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldw < K || (!b0) != (!b1) || (!rd0) != (!rd1) ||
       (!add0) != (!add1) || (!tail0) != (!tail1) || ldy < N + (tail0 ? ntail : 0) || (add0 && ldadd < N) ||
-      (tail0 && (ntail <= 0 || (N % 32) == 0 || (N % 32) + ntail > 32)))
+      (tail0 && ntail <= 0))
     return tfail(SGRL_ERR_ARG, "sgrl_linear_forward_twin_fused: bad argument");
   SArgs2 p;
   p.a[0] = SArgs{x0, ldx, nullptr, 0, w0, ldw, b0, relu ? 1 : 0, rd0, y0, ldy, nullptr, M, N, K, 0, nullptr, nullptr, add0, ldadd, tail0, ntail};

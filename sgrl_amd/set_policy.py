@@ -52,11 +52,11 @@ class ConcatPositionalEmbedding(nn.Module):
         return torch.cat([emb(idx) for emb, idx in zip(self.embeddings, positional_indices)], dim=1)
 
 
-def _invariants(x, gdir, proj, lin1, lin2):
-    """x [B,L,3,C] -> (features [B,L,out], F_norm [B,L,1])."""
+def _invariants(x, gdir, proj, lin1, lin2, tail=None):
+    """x [B,L,3,C] -> (features [B,L,out] (| tail), F_norm [B,L,1])."""
     z = proj(x, tail=gdir)                      # [proj(x) | gdir]: the appended pair rides on the projection's launch
     gram, fn = train_ops.gram_fn(z)
-    return lin2(lin1(gram, relu=True)), fn
+    return lin2(lin1(gram, relu=True), tail=tail), fn
 
 
 class SubequivariantAttention(nn.Module):
@@ -86,8 +86,7 @@ class SubequivariantAttention(nn.Module):
         B, L = ng.shape[:2]
         H = self.num_heads
         hd2 = 2 * (self.embed_dim // H)
-        inv, fn = _invariants(g, gdir, self.g_proj, self.linear_g1, self.linear_g2)
-        c = torch.cat([inv, ng], dim=-1)
+        c, fn = _invariants(g, gdir, self.g_proj, self.linear_g1, self.linear_g2, tail=ng)      # [inv | ng]
         # q, k, v share their input and their row divisor: ONE product over the stacked weights
         qkv = train_ops.linear(c, torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], dim=0),
                                torch.cat([self.q_proj.bias, self.k_proj.bias, self.v_proj.bias], dim=0), rowdiv=fn)
@@ -119,8 +118,7 @@ class SubequivariantEncoderLayer(nn.Module):
         g1, ng1 = self.self_attn(g, ng, gdir, bias)
         g = g + g1
         ng = train_ops.add_layer_norm(ng, ng1, self.norm1)
-        inv, fn = _invariants(g1, gdir, self.g_proj2, self.linear_g1, self.linear_g2)
-        c = torch.cat([inv, ng], dim=-1)
+        c, fn = _invariants(g1, gdir, self.g_proj2, self.linear_g1, self.linear_g2, tail=ng)   # [inv | ng]
         mat = self.linear4(self.linear3(c, relu=True), rowdiv=fn).view(*ng.shape[:2], Z_DIM, Z_DIM)
         z3 = self.g_proj3(g1, tail=gdir)
         g = self.linear5(train_ops.zmat(z3, mat), addend=g)
@@ -202,9 +200,8 @@ class TransformerModel(nn.Module):
         g, ng = self.transformer_encoder(g, ng, gdir, pos, graph["relation"])
         out_ng = torch.cat([n0, ng], dim=-1)
         out_g = torch.cat([g0, g], dim=-1)
-        inv, fn = _invariants(out_g, gdir, self.gg_proj, self.linear1_g, self.linear2_g)
         hng = self.linear2_ng(self.linear1_ng(out_ng, relu=True))
-        c = torch.cat([inv, hng], dim=-1)
+        c, fn = _invariants(out_g, gdir, self.gg_proj, self.linear1_g, self.linear2_g, tail=hng)       # [inv | hng]
         if self.output_size == 1:
             return self.decoder_ng(c, rowdiv=fn)
         mat = self.linear2_m(self.linear1_m(c, relu=True), rowdiv=fn).view(B, L, Z_DIM, Z_DIM)
@@ -228,18 +225,17 @@ def _norm2(n0, n1, x, res=None):
     return train_ops.add_layer_norm2(x, res, n0, n1)
 
 
-def _invariants2(x, gdir2, proj, lin1, lin2):
+def _invariants2(x, gdir2, proj, lin1, lin2, tail=None):
     z = _lin2(proj[0], proj[1], x, tail=gdir2)
     gram, fn = train_ops.gram_fn(z)
-    return _lin2(lin2[0], lin2[1], _lin2(lin1[0], lin1[1], gram, relu=True)), fn
+    return _lin2(lin2[0], lin2[1], _lin2(lin1[0], lin1[1], gram, relu=True), tail=tail), fn
 
 
 def _attention2(a, g, ng, gdir, gdir2, bias):
     """a = (SubequivariantAttention of network 0, of network 1); g [2,B,L,3,128], ng [2,B,L,128]; bias: None or a pair."""
     _, B, L = ng.shape[:3]
     hd2 = 2 * (a[0].embed_dim // a[0].num_heads)
-    inv, fn = _invariants2(g, gdir2, (a[0].g_proj, a[1].g_proj), (a[0].linear_g1, a[1].linear_g1), (a[0].linear_g2, a[1].linear_g2))
-    c = torch.cat([inv, ng], dim=-1)
+    c, fn = _invariants2(g, gdir2, (a[0].g_proj, a[1].g_proj), (a[0].linear_g1, a[1].linear_g1), (a[0].linear_g2, a[1].linear_g2), tail=ng)
     qw = [torch.cat([m.q_proj.weight, m.k_proj.weight, m.v_proj.weight], dim=0) for m in a]
     qb = [torch.cat([m.q_proj.bias, m.k_proj.bias, m.v_proj.bias], dim=0) for m in a]
     qkv = train_ops.linear2(c, qw[0], qw[1], qb[0], qb[1], rowdiv=fn)
@@ -259,8 +255,7 @@ def _layer2(l, g, ng, gdir, gdir2, bias):
     g1, ng1 = _attention2((l[0].self_attn, l[1].self_attn), g, ng, gdir, gdir2, bias)
     g = g + g1
     ng = _norm2(l[0].norm1, l[1].norm1, ng, ng1)
-    inv, fn = _invariants2(g1, gdir2, (l[0].g_proj2, l[1].g_proj2), (l[0].linear_g1, l[1].linear_g1), (l[0].linear_g2, l[1].linear_g2))
-    c = torch.cat([inv, ng], dim=-1)
+    c, fn = _invariants2(g1, gdir2, (l[0].g_proj2, l[1].g_proj2), (l[0].linear_g1, l[1].linear_g1), (l[0].linear_g2, l[1].linear_g2), tail=ng)
     mat = _lin2(l[0].linear4, l[1].linear4, _lin2(l[0].linear3, l[1].linear3, c, relu=True), rowdiv=fn)
     mat = mat.view(*ng.shape[:3], Z_DIM, Z_DIM)
     z3 = _lin2(l[0].g_proj3, l[1].g_proj3, g1, tail=gdir2)
@@ -293,9 +288,8 @@ def twin_forward(m0, m1, x, graph, geo_grad=True):
         ng = _norm2(e0.norm, e1.norm, ng)
     out_ng = torch.cat([n0.unsqueeze(0).expand(2, *n0.shape), ng], dim=-1)
     out_g = torch.cat([g0.unsqueeze(0).expand(2, *g0.shape), g], dim=-1)
-    inv, fn = _invariants2(out_g, gdir2, (m0.gg_proj, m1.gg_proj), (m0.linear1_g, m1.linear1_g), (m0.linear2_g, m1.linear2_g))
     hng = _lin2(m0.linear2_ng, m1.linear2_ng, _lin2(m0.linear1_ng, m1.linear1_ng, out_ng, relu=True))
-    c = torch.cat([inv, hng], dim=-1)
+    c, fn = _invariants2(out_g, gdir2, (m0.gg_proj, m1.gg_proj), (m0.linear1_g, m1.linear1_g), (m0.linear2_g, m1.linear2_g), tail=hng)
     return _lin2(m0.decoder_ng, m1.decoder_ng, c, rowdiv=fn)
 
 

@@ -428,3 +428,25 @@ def test_linear_followers_match_float64(twin):
         assert float((a.cpu().double() - b).abs().max()) < 2e-5 * (float(b.abs().max()) + 1.0) * 6
     got2 = run("cuda", torch.float32)
     assert all(torch.equal(a, b) for a, b in zip(got, got2))
+
+
+@pytest.mark.parametrize("N,nt", [(128, 128), (30, 2), (100, 60), (32, 1)])
+def test_wide_appended_blocks_match_cat(N, nt):
+    """tail blocks of any width ([inv | ng]: 128 + 128): the last product tile's spare columns, then column tiles of their own."""
+    from sgrl_amd import train_ops
+    g = torch.Generator().manual_seed(N + nt)
+    x = torch.randn(2, 70, 5, 64, generator=g).cuda().requires_grad_()
+    t = torch.randn(2, 70, 5, nt, generator=g).cuda().requires_grad_()
+    w = [(torch.randn(N, 64, generator=g) / 8).cuda().requires_grad_() for _ in range(2)]
+    b = [torch.randn(N, generator=g).cuda().requires_grad_() for _ in range(2)]
+    dy = torch.randn(2, 70, 5, N + nt, generator=g).cuda()
+    y1 = train_ops.linear(x[0], w[0], b[0], tail=t[0])
+    y2 = train_ops.linear2(x, w[0], w[1], b[0], b[1], tail=t)
+    ref = [torch.cat([torch.nn.functional.linear(x[i].double(), w[i].double(), b[i].double()), t[i].double()], -1) for i in range(2)]
+    assert y1.shape == (70, 5, N + nt) and y2.shape == (2, 70, 5, N + nt)
+    assert float((y1.double() - ref[0]).abs().max()) < 1e-5 and float((y2.double() - torch.stack(ref)).abs().max()) < 1e-5
+    assert torch.equal(y2[..., N:], t) and torch.equal(y1[..., N:], t[0])
+    (y2 * dy).sum().backward()
+    assert torch.equal(t.grad, dy[..., N:])
+    gx = torch.stack([dy[i, ..., :N].double() @ w[i].double() for i in range(2)])
+    assert float((x.grad.double() - gx).abs().max()) < 1e-4
