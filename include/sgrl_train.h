@@ -100,6 +100,14 @@ int sgrl_add_ln_forward(const float* x, const float* res, const float* w0, const
 int sgrl_add_ln_backward(const float* dy, const float* xhat, const float* rstd, const float* w0, const float* w1, float* dx, float* dw0,
                          float* db0, float* dw1, float* db1, int rows, int nets, void* stream);
 
+/* Three traversal-index embeddings concatenated (reference SEActor.py:18-31, ConcatPositionalEmbedding): idx [3, L] int64 (one index
+ * vector per table, all < rows), w_t [rows, n_t], n0 + n1 + n2 <= 128:  out[l][:] = w0[idx[0][l]] | w1[idx[1][l]] | w2[idx[2][l]].
+ * Backward: dw_t [rows, n_t] written densely (rows no limb points at receive zero; null = not wanted), limbs summed in order. */
+int sgrl_embed3_forward(const long long* idx, const float* w0, const float* w1, const float* w2, int n0, int n1, int n2, float* out, int L,
+                        void* stream);
+int sgrl_embed3_backward(const long long* idx, const float* dout, float* dw0, float* dw1, float* dw2, int n0, int n1, int n2, int L, int rows,
+                         void* stream);
+
 /* Limb attention of B environments with L <= 14 limbs, 2 heads x 128 channels (reference subequivariant_attentions.py:90-151
  * between the projections).  qkv [B, L, 768] = q | k | v as the stacked projection leaves them (q is multiplied by `scale` inside);
  * the vector values are given in parts and never concatenated: vgp [B, L, 3, 252] (126 projected channels per head) and gdir

@@ -652,6 +652,31 @@ __global__ __launch_bounds__(256) void k_add_ln_bwd(const float* __restrict__ dy
   }
 }
 
+// Three traversal-index embeddings concatenated (reference SEActor.py:18-31: ConcatPositionalEmbedding, widths 42 | 42 | 44 of 128):
+//   out[l][c] = W_t[idx[t][l]][c - off_t],  t = the table column c falls into;   backward: dW_t[r][j] = sum_{l: idx[t][l] == r} dout[l][off_t + j]
+// (written densely for all `rows` rows of each table, limbs summed in order: bit-reproducible).  One launch each instead of three
+// index_select + a concatenation / three times (embedding_dense_backward + fill + copy).
+struct Embed3 { const long long* idx; const float* w[3]; float* dw[3]; int n[3]; int L, rows, ld; };
+__global__ __launch_bounds__(128) void k_embed3_fwd(Embed3 e, float* __restrict__ out) {
+  const int l = blockIdx.x, c = threadIdx.x;
+  if (c >= e.ld) return;
+  const int t = c < e.n[0] ? 0 : (c < e.n[0] + e.n[1] ? 1 : 2);
+  const int off = t == 0 ? 0 : (t == 1 ? e.n[0] : e.n[0] + e.n[1]);
+  const long long r = e.idx[(size_t)t * e.L + l];
+  out[(size_t)l * e.ld + c] = e.w[t][(size_t)r * e.n[t] + (c - off)];
+}
+__global__ __launch_bounds__(128) void k_embed3_bwd(Embed3 e, const float* __restrict__ dout) {
+  const int r = blockIdx.x, c = threadIdx.x;                 // one workgroup per table row, one thread per output column
+  if (c >= e.ld) return;
+  const int t = c < e.n[0] ? 0 : (c < e.n[0] + e.n[1] ? 1 : 2);
+  const int off = t == 0 ? 0 : (t == 1 ? e.n[0] : e.n[0] + e.n[1]);
+  if (!e.dw[t]) return;
+  float s = 0.f;
+  for (int l = 0; l < e.L; l++)
+    if (e.idx[(size_t)t * e.L + l] == r) s += dout[(size_t)l * e.ld + c];
+  e.dw[t][(size_t)r * e.n[t] + (c - off)] = s;
+}
+
 // Only the weight gradient (AT) splits its contraction, and only where that pays: the release / acquire fences of the last-
 // workgroup reduction cost ~10-15 us on the eight-XCD chip, more than a few extra k-steps (measured: a 256 x 256 gradient over
 // 700 rows is 20 us unsplit, 27 us in three splits; a 30 x 128 gradient over 2 100 rows 51 us unsplit, 17 us in six).  So: a
@@ -914,6 +939,26 @@ int sgrl_add_ln_backward(const float* dy, const float* xhat, const float* rstd, 
   hipLaunchKernelGGL(k_add_ln_bwd, dim3(nrow_blocks + (params ? 4 * nets : 0)), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, w0, w1, dx,
                      dw0, db0, dw1, db1, rows, total, nrow_blocks);
   { int lrc = SGRL_OK; if (!launched("k_add_ln_bwd launch failed", &lrc)) return lrc; }
+  return SGRL_OK;
+}
+
+int sgrl_embed3_forward(const long long* idx, const float* w0, const float* w1, const float* w2, int n0, int n1, int n2, float* out, int L,
+                        void* stream) {
+  if (!idx || !w0 || !w1 || !w2 || !out || L <= 0 || n0 <= 0 || n1 <= 0 || n2 <= 0 || n0 + n1 + n2 > 128)
+    return tfail(SGRL_ERR_ARG, "sgrl_embed3_forward: bad argument");
+  Embed3 e{idx, {w0, w1, w2}, {nullptr, nullptr, nullptr}, {n0, n1, n2}, L, 0, n0 + n1 + n2};
+  hipLaunchKernelGGL(k_embed3_fwd, dim3(L), dim3(128), 0, (hipStream_t)stream, e, out);
+  { int lrc = SGRL_OK; if (!launched("k_embed3_fwd launch failed", &lrc)) return lrc; }
+  return SGRL_OK;
+}
+
+int sgrl_embed3_backward(const long long* idx, const float* dout, float* dw0, float* dw1, float* dw2, int n0, int n1, int n2, int L, int rows,
+                         void* stream) {
+  if (!idx || !dout || L <= 0 || rows <= 0 || n0 <= 0 || n1 <= 0 || n2 <= 0 || n0 + n1 + n2 > 128)
+    return tfail(SGRL_ERR_ARG, "sgrl_embed3_backward: bad argument");
+  Embed3 e{idx, {nullptr, nullptr, nullptr}, {dw0, dw1, dw2}, {n0, n1, n2}, L, rows, n0 + n1 + n2};
+  hipLaunchKernelGGL(k_embed3_bwd, dim3(rows), dim3(128), 0, (hipStream_t)stream, e, dout);
+  { int lrc = SGRL_OK; if (!launched("k_embed3_bwd launch failed", &lrc)) return lrc; }
   return SGRL_OK;
 }
 

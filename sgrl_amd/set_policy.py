@@ -49,7 +49,7 @@ class ConcatPositionalEmbedding(nn.Module):
         self.embeddings = nn.ModuleList([nn.Embedding(max_node, s) for s in sizes])
 
     def forward(self, positional_indices):
-        return torch.cat([emb(idx) for emb, idx in zip(self.embeddings, positional_indices)], dim=1)
+        return train_ops.embed3(self.embeddings, positional_indices)
 
 
 def _invariants(x, gdir, proj, lin1, lin2, tail=None):

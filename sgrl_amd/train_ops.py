@@ -41,6 +41,8 @@ def _L():
         L.sgrl_attention_backward.argtypes = [vp, vp, vp, ctypes.c_float, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]
         L.sgrl_linear_forward_fused.argtypes = [vp, ci, vp, ci, vp, vp, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp]
         L.sgrl_linear_forward_twin_fused.argtypes = [vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, ci, ci, vp]
+        L.sgrl_embed3_forward.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, ci, vp]
+        L.sgrl_embed3_backward.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
         L.sgrl_add_ln_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ctypes.c_float, vp]
         L.sgrl_add_ln_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]
         L.sgrl_train_ws_floats.restype = ctypes.c_int64
@@ -472,6 +474,35 @@ class _AddLNFn(torch.autograd.Function):
         return (dxv if need[0] else None), dres, dw0, db0, dw1, db1, None
 
 
+class _Embed3Fn(torch.autograd.Function):
+    """cat([w0[idx[0]], w1[idx[1]], w2[idx[2]]], dim=1) -- the three traversal embeddings -- one launch forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, idx, w0, w1, w2):
+        L = _L()
+        n = (w0.shape[1], w1.shape[1], w2.shape[1])
+        ws = [w if w.is_contiguous() else w.contiguous() for w in (w0, w1, w2)]
+        Ln = idx.shape[1]
+        out = torch.empty((Ln, sum(n)), dtype=torch.float32, device=w0.device)
+        st = ctypes.c_void_p(torch.cuda.current_stream(w0.device).cuda_stream)
+        _check(L, L.sgrl_embed3_forward(_p(idx), _p(ws[0]), _p(ws[1]), _p(ws[2]), n[0], n[1], n[2], _p(out), Ln, st), "sgrl_embed3_forward")
+        ctx.save_for_backward(idx)
+        ctx.n, ctx.rows = n, w0.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _L()
+        (idx,) = ctx.saved_tensors
+        d = dout if dout.is_contiguous() else dout.contiguous()
+        n, rows = ctx.n, ctx.rows
+        dws = [torch.empty((rows, n[t]), dtype=torch.float32, device=dout.device) if ctx.needs_input_grad[1 + t] else None for t in range(3)]
+        st = ctypes.c_void_p(torch.cuda.current_stream(dout.device).cuda_stream)
+        _check(L, L.sgrl_embed3_backward(_p(idx), _p(d), _p(dws[0]), _p(dws[1]), _p(dws[2]), n[0], n[1], n[2], idx.shape[1], rows, st),
+               "sgrl_embed3_backward")
+        return None, dws[0], dws[1], dws[2]
+
+
 def _on_device_with_grad(*ts):
     return ENABLED and ts[0].is_cuda and ts[0].dtype == torch.float32 and torch.is_grad_enabled() and \
         any(t is not None and t.requires_grad for t in ts)
@@ -564,3 +595,23 @@ def add_layer_norm2(x, res, n0, n1):
     s = x if res is None else x + res
     a, b = s.unbind(0)          # (not s[0], s[1]: each index costs a zero-filled gradient, a slice copy and an add going back)
     return torch.stack([n0(a), n1(b)])
+
+
+_idx3_cache = {}
+
+
+def embed3(embeddings, positional_indices):
+    """torch.cat([emb(idx) for emb, idx in zip(embeddings, positional_indices)], dim=1) for three nn.Embedding tables of equal row
+    count (the traversal embeddings of the SET models): one launch forward and one backward when autograd records on the GPU."""
+    ws = [e.weight for e in embeddings]
+    if len(ws) == 3 and _on_device_with_grad(*ws) and all(w.shape[0] == ws[0].shape[0] for w in ws) and sum(w.shape[1] for w in ws) <= 128 \
+            and all(e.padding_idx is None and e.max_norm is None for e in embeddings) and all(i.dtype == torch.int64 and i.dim() == 1 for i in positional_indices):
+        key = tuple((i.data_ptr(), i.shape[0], i._version) for i in positional_indices)
+        ent = _idx3_cache.get(key)
+        if ent is None:
+            if len(_idx3_cache) > 256:
+                _idx3_cache.clear()
+            # the index tensors are kept alive with the entry, so their addresses cannot be reused by other tensors
+            ent = _idx3_cache[key] = (torch.stack(list(positional_indices)).contiguous(), list(positional_indices))
+        return _Embed3Fn.apply(ent[0], ws[0], ws[1], ws[2])
+    return torch.cat([emb(idx) for emb, idx in zip(embeddings, positional_indices)], dim=1)

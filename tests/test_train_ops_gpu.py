@@ -450,3 +450,26 @@ def test_wide_appended_blocks_match_cat(N, nt):
     assert torch.equal(t.grad, dy[..., N:])
     gx = torch.stack([dy[i, ..., :N].double() @ w[i].double() for i in range(2)])
     assert float((x.grad.double() - gx).abs().max()) < 1e-4
+
+
+def test_embed3_matches_the_three_embeddings():
+    """train_ops.embed3 (one launch each way) against torch's three nn.Embedding lookups + cat: values bit-equal, weight
+    gradients equal (repeated indices included), rows no limb points at receive zero."""
+    from sgrl_amd import train_ops
+    torch.manual_seed(2)
+    embs = torch.nn.ModuleList([torch.nn.Embedding(15, s) for s in (42, 42, 44)]).cuda()
+    ref = torch.nn.ModuleList([torch.nn.Embedding(15, s) for s in (42, 42, 44)]).cuda()
+    ref.load_state_dict(embs.state_dict())
+    idx = [torch.tensor(v, device="cuda") for v in ([0, 1, 2, 3, 4, 5, 6], [3, 3, 0, 6, 2, 14, 1], [6, 5, 4, 3, 2, 1, 0])]
+    dy = torch.randn(7, 128, device="cuda")
+    out = train_ops.embed3(embs, idx)
+    assert type(out.grad_fn).__name__.startswith("_Embed3Fn")
+    want = torch.cat([e(i) for e, i in zip(ref, idx)], dim=1)
+    assert torch.equal(out, want)
+    out.backward(dy)
+    want.backward(dy)
+    for a, b in zip(embs, ref):
+        assert float((a.weight.grad - b.weight.grad).abs().max()) < 1e-6
+    assert float(embs[0].weight.grad[7:].abs().max()) == 0.0
+    out2 = train_ops.embed3(embs, idx)          # cached index block
+    assert torch.equal(out2, want)
