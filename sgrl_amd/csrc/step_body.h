@@ -52,8 +52,10 @@ constexpr int kPivotRows = 64;                    // ... of which the exact bloc
 constexpr int kPrevRows = 48;                     // warm-start memory (LDS): the first rows of the previous evaluation
 constexpr int kSlabLdy = 47;                      // largest Y row stride served: nv <= 46
 // per-env HBM slab (Engine::rows_hbm): factor of a <= 64-row free set | Y | five row arrays | four int row arrays
-SGRL_HD int slab_doubles(int maxrows, int ldy) { return kPivotRows * (kPivotRows + 1) / 2 + (maxrows + 1) * ldy + 5 * maxrows + 2 * maxrows + 8; }
-constexpr int kScratchDoublesMax = 2080 + 257 * 47 + 7 * 256 + 8;     // slab_doubles(kSlabRows, kSlabLdy): what a test harness may allocate
+// (+ ldy (ldy + 1) / 2 behind the slab: the Euler integrator's copy of the mass matrix, see Layout::mfull_hbm)
+SGRL_HD int slab_rows_doubles(int maxrows, int ldy) { return kPivotRows * (kPivotRows + 1) / 2 + (maxrows + 1) * ldy + 5 * maxrows + 2 * maxrows + 8; }
+SGRL_HD int slab_doubles(int maxrows, int ldy) { return slab_rows_doubles(maxrows, ldy) + ldy * (ldy + 1) / 2; }
+constexpr int kScratchDoublesMax = 2080 + 257 * 47 + 7 * 256 + 8 + 47 * 48 / 2;     // slab_doubles(kSlabRows, kSlabLdy): what a test harness may allocate
 
 // ------------------------------------------------------------------------------------------------
 // LDS layout (offsets in doubles for S, in ints for I)
@@ -69,6 +71,8 @@ struct Layout {
   int Y, eR, earef, eb, ef, eidg, prev_f;
   int misc;  // 16 scalars
   int Mfull; // Euler only: copy of M (lower triangle incl. diag)
+  int mfull_hbm;   // 1: the copy waits in the environment's HBM scratch between CRBA and the end of the substep and is
+                   // factored inside the (then idle) constraint-row block, Mfull = Y: no LDS of its own (cheetah_14: 8.3 KB)
   int model_f; // LDS copy of the float model blob (n_f64 doubles)
   int s_total;
   // I
@@ -87,8 +91,12 @@ SGRL_HD void make_layout_rows(const int32_t* hdr, Layout* o, int n_int, int n_f6
   o->ld = nv | 1;
   o->ldy = nv | 1;
   int p = 0;
-  o->qpos = p; p += nq; o->qvel = p; p += nv; o->q0 = p; p += nq; o->v0 = p; p += nv;
-  o->xv = p; p += nv; o->fq = p; p += nv; o->dvacc = p; p += nv; o->daacc = p; p += nv;
+  // the Runge-Kutta stage state (q0, v0, xv, dvacc, daacc) exists only where the integrator is RK4: the Euler step never touches it
+  const bool rk4_state = hdr[SGRL_H_INTEGRATOR] != 0;
+  o->qpos = p; p += nq; o->qvel = p; p += nv;
+  o->q0 = rk4_state ? p : o->qpos; p += rk4_state ? nq : 0; o->v0 = rk4_state ? p : o->qvel; p += rk4_state ? nv : 0;
+  o->xv = rk4_state ? p : o->qvel; p += rk4_state ? nv : 0; o->fq = p; p += nv;
+  o->dvacc = rk4_state ? p : o->qvel; p += rk4_state ? nv : 0; o->daacc = rk4_state ? p : o->qvel; p += rk4_state ? nv : 0;
   o->ctrl = p; p += nu + 1;
   o->xpos = p; p += 3 * nb; o->xaxis = p; p += 3 * nj; o->cdof = p; p += 6 * nv;
   // "dead zone": everything below is no longer needed once the constraint rows of an evaluation are built, so the
@@ -116,7 +124,11 @@ SGRL_HD void make_layout_rows(const int32_t* hdr, Layout* o, int n_int, int n_f6
   o->eidg = p; p += o->lrows; o->prev_f = p; p += prevcap;
   o->misc = p; p += 16;
   o->Mfull = p;
-  if (hdr[SGRL_H_INTEGRATOR] == 0) p += nv * (nv + 1) / 2;
+  o->mfull_hbm = 0;
+  if (hdr[SGRL_H_INTEGRATOR] == 0) {
+    if ((o->lrows + 1) * o->ldy >= nv * (nv + 1) / 2) { o->Mfull = o->Y; o->mfull_hbm = 1; }
+    else p += nv * (nv + 1) / 2;
+  }
   o->model_f = p; p += n_f64;
   o->s_total = p;
   int q = 0;
@@ -138,6 +150,7 @@ SGRL_HD int workgroups_per_cu(int lds_bytes) {
   return per > 8 ? 8 : per;
 }
 
+constexpr int kMaxRowCut = 16;
 // The layout with the LDS row arrays at their natural size (what the factor scratch can serve) -- or up to eight rows
 // shorter (never below 20) when that is what it takes to fit one more workgroup per CU: walker_7 22 392 B (32 rows, 7 per
 // CU) -> 20 344 B (24 rows, 8 per CU), measured 10 % faster on the walker mix although more evaluations (25..32 rows) then
@@ -145,7 +158,7 @@ SGRL_HD int workgroups_per_cu(int lds_bytes) {
 SGRL_HD void make_layout(const int32_t* hdr, Layout* o, int n_int = 0, int n_f64 = 0) {
   make_layout_rows(hdr, o, n_int, n_f64, 0);
   const int base = workgroups_per_cu(layout_bytes(o));
-  for (int cut = 1; cut <= 8 && o->lrows - cut >= 20; cut++) {
+  for (int cut = 1; cut <= kMaxRowCut && o->lrows - cut >= 20; cut++) {
     Layout t;
     make_layout_rows(hdr, &t, n_int, n_f64, cut);
     if (workgroups_per_cu(layout_bytes(&t)) > base) { *o = t; return; }
@@ -514,7 +527,13 @@ struct Engine {
       }
     });
     if (W::hdr_const(m, SGRL_H_INTEGRATOR) == 0) {  // Euler needs M again for (M + h D)
-      w.lanes(nv, [&](int i) { for (int k = 0; k <= i; k++) S[o.Mfull + tri(i) + k] = S[o.L + tri(i) + k]; });
+      if (o.mfull_hbm) {
+        double* const mh = big_scratch + slab_rows_doubles(o.maxrows, o.ldy);
+        const int nt = nv * (nv + 1) / 2;
+        w.lanes(64, [&](int l) { for (int k = l; k < nt; k += 64) mh[k] = S[o.L + k]; });
+      } else {
+        w.lanes(nv, [&](int i) { for (int k = 0; k <= i; k++) S[o.Mfull + tri(i) + k] = S[o.L + tri(i) + k]; });
+      }
     }
     SGRL_TICK(2);
     // small systems: Cholesky and the explicit inverse of the factor in one register sweep (wave policy); the
@@ -1280,6 +1299,11 @@ struct Engine {
       w.lanes(nv, [&](int d) { S[o.qvel + d] = S[o.v0 + d] + h * S[o.daacc + d]; });
     } else {
       // semi-implicit Euler with implicit joint damping: (M + h D) a = M qacc
+      if (o.mfull_hbm) {       // the copy of M comes back from HBM into the constraint-row block, idle once qacc is known
+        const double* const mh = big_scratch + slab_rows_doubles(o.maxrows, o.ldy);
+        const int nt = nv * (nv + 1) / 2;
+        w.lanes(64, [&](int l) { for (int k = l; k < nt; k += 64) S[o.Mfull + k] = mh[k]; });
+      }
       w.lanes(nv, [&](int i) {
         double s = 0;
         for (int j = 0; j < nv; j++) s += (j <= i ? S[o.Mfull + tri(i) + j] : S[o.Mfull + tri(j) + i]) * S[o.qacc + j];
