@@ -433,10 +433,12 @@ class HipSetActor(object):
 
     FORM_F16X3, FORM_BF16X6 = 2, 3
 
-    def gemm_form(self, form):
+    def gemm_form(self, form, _by_counter=False):
         """Form of the tile products (include/sgrl_set.h): FORM_F16X3 (default: operands beyond +-65 000 are clamped and
-        counted), FORM_BF16X6 (f32's exponent range, slower), 0 = default."""
+        counted), FORM_BF16X6 (f32's exponent range, slower), 0 = default.  A form set here is the user's: rearm_range() leaves it."""
         _check(self.L, self.L.sgrl_set_gemm_form(self.h, int(form)), "sgrl_set_gemm_form")
+        if not _by_counter:
+            self._range_fallback = False
 
     def range_events(self, reset=True):
         """Kernel threads that clamped an operand since the last reset (synchronises the device)."""
@@ -456,6 +458,8 @@ class HipSetActor(object):
         `SECritic` / `BatchedEvaluator` get what `DeviceTrainer` does once per round without asking for it.  The forward just
         enqueued is looked at by the next poll (or by check_range()).  Never synchronises while the stream is being captured
         (the capturing caller polls after the replay: td3.GraphedUpdates)."""
+        if getattr(self, "_no_poll", False):
+            return
         if self.L.sgrl_set_range_events_seen(self.h) and not torch.cuda.is_current_stream_capturing():
             self.range_events_total = getattr(self, "range_events_total", 0) + self.check_range()
 
@@ -468,8 +472,30 @@ class HipSetActor(object):
             import warnings
             warnings.warn("SET forward: %d kernel threads clamped an operand beyond +-65 000 (two-piece f16 products); "
                           "this handle now uses the bf16 x 6 form (f32 exponent range)" % n, RuntimeWarning)
-            self.gemm_form(self.FORM_BF16X6)
+            self.gemm_form(self.FORM_BF16X6, _by_counter=True)
+            self._range_fallback = True        # moved by the counter, not by the user: rearm_range() may take it back
         return n
+
+    def rearm_range(self, obs, act_ld=None):
+        """A handle that check_range() moved to the full-range form stays there for good -- unless the caller says the weights
+        have changed since (the trainer, after every round's updates): then ONE probe forward of `obs` in the two-piece form,
+        its result thrown away, tells whether the new weights keep the operands inside f16's range.  They do: the handle is
+        back on the fast form (returns True).  They do not: full-range form again, as before (returns False).  A form chosen
+        by the user (gemm_form(), SGRL_SET_GEMM) is never touched.  Synchronises the device once."""
+        if not getattr(self, "_range_fallback", False):
+            return False
+        self.range_events(reset=True)
+        self.gemm_form(self.FORM_F16X3, _by_counter=True)
+        self._no_poll = True                   # the probe's counter is read right here, not by the forward's own poll
+        try:
+            self.forward_batch(obs, act_ld=act_ld)
+        finally:
+            self._no_poll = False
+        if self.range_events(reset=True):
+            self.gemm_form(self.FORM_BF16X6, _by_counter=True)
+            return False
+        self._range_fallback = False
+        return True
 
     def peek(self, which, per_node):
         out = np.zeros((self.num_nodes, per_node), dtype=np.float32)

@@ -87,6 +87,12 @@ class DeviceTrainer(object):
         """`obs_list = envs.reset()` + fresh done / timestep lists (trainer.py:155-160, 268-275)."""
         self.ro.reset()
         self.sink.begin_round()
+        # a rollout actor the clamp counter moved to the full-range products (2.4 -> 3.0 ms per forward) gets one probe forward on
+        # the fresh observations after every round of updates: weights that keep the operands in range again take the fast form back
+        actor = getattr(self.ro, "actor", None)
+        if actor is not None and getattr(actor, "_range_fallback", False):
+            if actor.rearm_range(self.ro.env.obs, act_ld=self.ro.env.action_max_len):
+                self.range_rearms = getattr(self, "range_rearms", 0) + 1
 
     def collect_step(self, random_actions=False):
         """One time step of every environment + replay push.  Returns True when the collection round is complete."""

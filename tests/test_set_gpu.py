@@ -389,6 +389,15 @@ def test_tile_product_forms_agree_and_out_of_range_operands_are_counted(ctx):
     assert act.range_events() == 0
     out = act.forward_batch(obs).cpu().numpy()
     assert np.abs(out - outs[HipSetActor.FORM_BF16X6]).max() == 0.0
+    # the trainer's re-arm after a round of updates: a probe that still clamps leaves the handle on the full-range form, one that
+    # does not takes the two-piece form back; a form the USER chose is never touched
+    assert act.rearm_range(obs * 1e8) is False
+    assert np.abs(act.forward_batch(obs).cpu().numpy() - outs[HipSetActor.FORM_BF16X6]).max() == 0.0
+    assert act.rearm_range(obs) is True
+    assert np.abs(act.forward_batch(obs).cpu().numpy() - outs[HipSetActor.FORM_F16X3]).max() == 0.0 and act.range_events() == 0
+    act.gemm_form(HipSetActor.FORM_BF16X6)
+    assert act.rearm_range(obs) is False
+    assert np.abs(act.forward_batch(obs).cpu().numpy() - outs[HipSetActor.FORM_BF16X6]).max() == 0.0
 
 
 def test_product_forms_agree_on_engine_observations_at_size(ctx):
