@@ -66,7 +66,7 @@ def train():
         c = env.get_counters()
         pivot_fail += int(((c[:, 3] >> 8) & 0xFF).sum())
         slab += int((c[:, 3] >> 16).sum())
-        s.update({"round": rnd, "wall_s": round(time.time() - t0, 1), "range_events": int(tr.range_events),
+        s.update({"round": rnd, "wall_s": round(time.time() - t0, 1), "range_events": int(tr.range_events), "range_rearms": int(getattr(tr, "range_rearms", 0)),
                   "envs_with_dropped_rows": int((c[:, 2] > 0).sum())})
         curve.append(s)
         if rnd % 5 == 0:
