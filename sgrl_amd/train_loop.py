@@ -87,12 +87,6 @@ class DeviceTrainer(object):
         """`obs_list = envs.reset()` + fresh done / timestep lists (trainer.py:155-160, 268-275)."""
         self.ro.reset()
         self.sink.begin_round()
-        # a rollout actor the clamp counter moved to the full-range products (2.4 -> 3.0 ms per forward) gets one probe forward on
-        # the fresh observations after every round of updates: weights that keep the operands in range again take the fast form back
-        actor = getattr(self.ro, "actor", None)
-        if actor is not None and getattr(actor, "_range_fallback", False):
-            if actor.rearm_range(self.ro.env.obs, act_ld=self.ro.env.action_max_len):
-                self.range_rearms = getattr(self, "range_rearms", 0) + 1
 
     def collect_step(self, random_actions=False):
         """One time step of every environment + replay push.  Returns True when the collection round is complete."""
@@ -159,6 +153,7 @@ class DeviceTrainer(object):
             self.dist.broadcast(t, src=self.dst)
             self._tot_synced = int(t.item())
         self.broadcast_actor()
+        self._rearm_rollout_actor()          # with the weights every rank rolls out next
         self.rounds += 1
         return per_morph_iter
 
@@ -174,6 +169,28 @@ class DeviceTrainer(object):
                 n = p.numel()
                 p.data.copy_(flat[off:off + n].view_as(p))     # in place: the HIP actor reads the live storage
                 off += n
+
+    def _rearm_rollout_actor(self):
+        """A rollout actor the clamp counter moved to the full-range products (2.4 -> 3.0 ms per forward) is probed after a
+        round's updates: ONE forward of the round's LAST observations (mid-episode states, where the operands are largest --
+        not the reset poses) in the two-piece form; new weights that keep the operands in range take the fast form back
+        (HipSetActor.rearm_range).  A handle that clamps again in a round it began re-armed waits twice as many rounds for its
+        next probe (1, 2, 4 ... 64): a policy that has grown out of f16's range for good costs a handful of probes, not one
+        clamped forward per round (seen with a diverged walker policy: profiles/r3_learning_curve_walker_seed7.log)."""
+        actor = getattr(self.ro, "actor", None)
+        if actor is None or not getattr(actor, "_range_fallback", False):
+            self._rearmed = False
+            return
+        if getattr(self, "_rearmed", False):              # began this round on the fast form and was moved again: back off
+            self._rearm_wait = min(64, 2 * getattr(self, "_rearm_wait", 1))
+        self._rearmed = False
+        self._rearm_idle = getattr(self, "_rearm_idle", 0) + 1
+        if self._rearm_idle < getattr(self, "_rearm_wait", 1):
+            return
+        self._rearm_idle = 0
+        if actor.rearm_range(self.ro.env.obs, act_ld=self.ro.env.action_max_len):
+            self.range_rearms = getattr(self, "range_rearms", 0) + 1
+            self._rearmed = True
 
     def train_round(self, max_steps=None, max_iters=None):
         """Collect until every environment has finished one episode (or max_steps), update, reset.  Returns a summary."""
