@@ -508,17 +508,13 @@ def _on_device_with_grad(*ts):
         any(t is not None and t.requires_grad for t in ts)
 
 
-def _tail_fits(N, tail):
-    return True                                  # any width (the kernel copies whole column tiles of an appended block)
-
-
 def linear(x, weight, bias=None, relu=False, rowdiv=None, addend=None, tail=None):
     """act(x @ weight.T + bias) / rowdiv, differentiable in x, weight, bias and rowdiv (act = ReLU if relu; rowdiv: one value
     per row, broadcast over the output features -- the `/ F_norm` of the reference's SET layers).  Two followers can ride on
     the product's launch: `addend` (same shape as the result) is added to it -- a residual --, `tail` [..., t] is appended to it
     along the last dimension (torch.cat([result, tail], -1))."""
     if _on_device_with_grad(x, weight, bias, rowdiv, addend, tail):
-        if _tail_fits(weight.shape[0], tail) and (addend is None or (not relu and rowdiv is None and tail is None)):
+        if addend is None or (not relu and rowdiv is None and tail is None):
             return _LinearFn.apply(x, weight, bias, bool(relu), rowdiv, addend, tail)
         y = _LinearFn.apply(x, weight, bias, bool(relu), rowdiv, None, None)     # a follower the kernel does not take: own launches
     else:
@@ -533,8 +529,7 @@ def linear2(x, w0, w1, b0=None, b1=None, relu=False, rowdiv=None, shared=False, 
     """`linear` for the same layer of two networks at once: returns [2, ..., N]; x = the input both share ([..., K], shared=True) or
     their inputs stacked ([2, ..., K]); rowdiv stacked [2, ..., 1]; addend stacked [2, ..., N]; tail [2, ..., t] (or one both share,
     [..., t] / expanded)."""
-    if _on_device_with_grad(x, w0, w1, b0, b1, rowdiv, addend, tail) and _tail_fits(w0.shape[0], tail) and \
-            (addend is None or (not relu and rowdiv is None and tail is None)):
+    if _on_device_with_grad(x, w0, w1, b0, b1, rowdiv, addend, tail) and (addend is None or (not relu and rowdiv is None and tail is None)):
         if tail is not None and tail.dim() == x.dim() + (1 if shared else 0) and tail.stride(0) == 0:
             tail = tail[0]                          # an expanded pair: the one tensor both networks share
         return _Linear2Fn.apply(x, w0, w1, b0, b1, bool(relu), rowdiv, bool(shared), addend, tail)
