@@ -171,10 +171,17 @@ class Agent(nn.Module):
         draw of agent.py:128 (tests: so that a run can be compared with the reference number for number; graph capture: a
         static buffer refilled before every replay).  lazy_stats: keep the two reward statistics as device tensors instead
         of `.item()` floats (no host sync -- required inside a hipGraph capture)."""
+        reward_batch, target_Q = self.update_targets(data_batch, noise)
+        current_Q1, current_Q2 = self.update_critic_forward(data_batch)
+        return self.update_finish(data_batch, it, reward_batch, target_Q, current_Q1, current_Q2, lazy_stats, skip_unused_critic_grads)
+
+    # The three parts of an update.  The first two -- the no-grad target chain (actor_target -> critic_target) and the critics'
+    # forward with autograd -- need nothing from each other: GraphedUpdates records them as separate graphs and replays them
+    # side by side on two streams (both are chains of small latency-bound launches that leave most of the chip idle).
+    def update_targets(self, data_batch, noise=None):
         args = self.args
-        obs_batch, action_batch = data_batch["obs"], data_batch["action"]
-        next_obs_batch, reward_batch, done_batch = data_batch["next_obs"], data_batch["reward"], data_batch["done"]
-        reward_batch = reward_batch * self.reward_scale
+        action_batch, next_obs_batch = data_batch["action"], data_batch["next_obs"]
+        reward_batch, done_batch = data_batch["reward"] * self.reward_scale, data_batch["done"]
         with torch.no_grad():
             if noise is None:
                 noise = torch.zeros_like(action_batch).normal_(0, args.policy_noise)
@@ -183,7 +190,15 @@ class Agent(nn.Module):
             target_Q1, target_Q2 = self.critic_target(next_obs_batch, next_action)    # per-limb values [B, L]
             target_Q = torch.min(target_Q1, target_Q2)
             target_Q = reward_batch + ((1.0 - done_batch) * args.discount * target_Q)  # reward [B, 1] broadcast over limbs
-        current_Q1, current_Q2 = self.critic(obs_batch, action_batch)
+        return reward_batch, target_Q
+
+    def update_critic_forward(self, data_batch):
+        return self.critic(data_batch["obs"], data_batch["action"])
+
+    def update_finish(self, data_batch, it, reward_batch, target_Q, current_Q1, current_Q2, lazy_stats=False,
+                      skip_unused_critic_grads=False):
+        args = self.args
+        obs_batch = data_batch["obs"]
         critic_loss = F.mse_loss(current_Q1, target_Q) + F.mse_loss(current_Q2, target_Q)
         self.critic_optimizer.zero_grad()
         # (graphed path) the weight gradients are not on the backward pass's critical path: collected, issued together at the end
@@ -249,6 +264,39 @@ class Agent(nn.Module):
             m.train()
 
 
+def _concurrent_stream(cur, tries=8):
+    """A stream that REALLY runs beside `cur`: HIP multiplexes its streams onto a handful of hardware queues and two streams on
+    one queue execute strictly one after the other (csrc/stream_pick.h has the story); there is no query for the mapping, so it
+    is measured with two spin kernels -- one spin time when the queues differ, two when they are the same.  Rejected candidates
+    stay alive until the search ends so that the runtime does not hand the same queue out again."""
+    cycles = 400000
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+    def timed(other):
+        best = 1e9
+        for _ in range(2):
+            if other is not None:
+                other.wait_stream(cur)
+            ev[0].record(cur)
+            torch.cuda._sleep(cycles)
+            if other is not None:
+                with torch.cuda.stream(other):
+                    torch.cuda._sleep(cycles)
+                cur.wait_stream(other)
+            ev[1].record(cur)
+            ev[1].synchronize()
+            best = min(best, ev[0].elapsed_time(ev[1]))
+        return best
+    single = timed(None)
+    rejected = []
+    for _ in range(tries):
+        cand = torch.cuda.Stream()
+        if timed(cand) < 1.6 * single:
+            return cand
+        rejected.append(cand)
+    return rejected[0]
+
+
 @contextlib.contextmanager
 def _no_finalizers_during_capture():
     """Collect dead Python cycles NOW and keep the cyclic collector off until the capture has ended.  A collector pass in the
@@ -291,6 +339,9 @@ class GraphedUpdates(object):
                 g["capturable"] = True
         self.slots = {}            # key -> dict(static tensors, graphs)
         self.warmed = set()
+        # SGRL_SPLIT_UPDATE_GRAPHS=1: target chain and critic forward as graphs of their own, replayed on two streams
+        self.split = os.environ.get("SGRL_SPLIT_UPDATE_GRAPHS", "0") == "1"
+        self._cap_stream = self._side = None
         self.range_events = 0      # operands the target networks' two-piece products clamped so far (poll_range)
 
     def _slot(self, key, graph, L):
@@ -366,6 +417,24 @@ class GraphedUpdates(object):
         stamp = self._workspace_stamp()
         if flag in sl["graphs"] and sl["stamp"].get(flag) != stamp:
             del sl["graphs"][flag]
+        if flag not in sl["graphs"] and self.split:
+            # Three graphs, all recorded on ONE capture stream (autograd's nodes then belong to one stream: no cross-stream
+            # hand-overs inside the backward) but each with its own memory pool: the target chain and the critics' forward are
+            # REPLAYED side by side, so neither may reuse a block the other has freed.
+            self.agent.change_morphology(graph)
+            if self._cap_stream is None:
+                self._cap_stream, self._side = torch.cuda.Stream(), _concurrent_stream(torch.cuda.current_stream())
+            gs = [torch.cuda.CUDAGraph() for _ in range(3)]
+            with _no_finalizers_during_capture():
+                with torch.cuda.graph(gs[0], stream=self._cap_stream):
+                    rb, tq = self.agent.update_targets(sl["batch"], sl["noise"])
+                with torch.cuda.graph(gs[1], stream=self._cap_stream):
+                    q1, q2 = self.agent.update_critic_forward(sl["batch"])
+                with torch.cuda.graph(gs[2], stream=self._cap_stream):
+                    sl["out"][flag] = self.agent.update_finish(sl["batch"], flag, rb, tq, q1, q2, lazy_stats=True,
+                                                               skip_unused_critic_grads=True)
+            sl["graphs"][flag] = gs
+            sl["stamp"][flag] = self._workspace_stamp()
         if flag not in sl["graphs"]:
             self.agent.change_morphology(graph)
             g = torch.cuda.CUDAGraph()
@@ -379,6 +448,16 @@ class GraphedUpdates(object):
                 g.debug_dump(os.path.join(dump, "update_%s_flag%d.dot" % (key, flag)))
             sl["graphs"][flag] = g           # capturing records the work without running it
             sl["stamp"][flag] = self._workspace_stamp()
-        sl["graphs"][flag].replay()
+        g = sl["graphs"][flag]
+        if isinstance(g, list):
+            cur = torch.cuda.current_stream()
+            self._side.wait_stream(cur)          # the batch / noise just loaded on the caller's stream
+            g[0].replay()
+            with torch.cuda.stream(self._side):
+                g[1].replay()
+            cur.wait_stream(self._side)
+            g[2].replay()
+        else:
+            g.replay()
         # the capture's output tensors are overwritten by the next replay: hand out copies
         return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in sl["out"][flag].items()}

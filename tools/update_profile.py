@@ -40,5 +40,8 @@ for it in range(iters):
     else:
         agent.update(batch, it, lazy_stats=True)
 torch.cuda.synchronize()
-print(json.dumps({"morphology": name, "limbs": L, "batch": B, "graphed": graphed is not None, "iters": iters,
-                  "ms_per_update": round((time.time() - t0) / iters * 1e3, 3)}))
+ms = round((time.time() - t0) / iters * 1e3, 3)
+chk = float(sum(p.detach().double().abs().sum() for p in list(agent.actor.parameters()) + list(agent.critic.parameters())))
+print(json.dumps({"morphology": name, "limbs": L, "batch": B, "graphed": graphed is not None,
+                  "split_graphs": bool(graphed is not None and graphed.split), "iters": iters, "ms_per_update": ms,
+                  "param_abs_sum_after": chk}))
