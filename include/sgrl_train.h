@@ -108,6 +108,20 @@ int sgrl_embed3_forward(const long long* idx, const float* w0, const float* w1, 
 int sgrl_embed3_backward(const long long* idx, const float* dout, float* dw0, float* dw1, float* dw2, int n0, int n1, int n2, int L, int rows,
                          void* stream);
 
+/* Optimizer steps over a device TABLE of tensors instead of torch's multi-tensor launches (reference agent.py:161-177:
+ * clip_grad_norm_ + Adam.step; common/functional.py:7-10: soft target update).  table: n_tensors rows of six 64-bit words
+ * (param*, grad*, exp_avg*, exp_avg_sq*, step* (one float, the tensor's step count), numel); chunks: n_chunks pairs of int32
+ * (row, first element), each covering at most sgrl_optim_chunk() elements of one tensor.
+ *   sgrl_optim_clip_adam: max_norm > 0: total = sqrt(sum of grad^2 over every row), grads *= min(1, max_norm / (total + 1e-6)) in
+ *     place (torch.nn.utils.clip_grad_norm_); every step += 1; Adam exactly as torch's fused kernel (no weight decay, no amsgrad):
+ *     m = lerp(m, g, 1 - b1), v = b2 v + (1 - b2) g^2, p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).
+ *     scratch: 1 + n_chunks floats (total of squares, partials).  Three launches (two without clipping), fixed summation order.
+ *   sgrl_optim_lerp: rows (dst*, src*, -, -, -, numel): dst = dst (1 - tau) + tau src.  One launch. */
+int sgrl_optim_chunk(void);
+int sgrl_optim_clip_adam(const void* table, int n_tensors, const void* chunks, int n_chunks, double lr, double beta1, double beta2, double eps,
+                         float max_norm, float* scratch, void* stream);
+int sgrl_optim_lerp(const void* table, const void* chunks, int n_chunks, float tau, void* stream);
+
 /* Limb attention of B environments with L <= 14 limbs, 2 heads x 128 channels (reference subequivariant_attentions.py:90-151
  * between the projections).  qkv [B, L, 768] = q | k | v as the stacked projection leaves them (q is multiplied by `scale` inside);
  * the vector values are given in parts and never concatenated: vgp [B, L, 3, 252] (126 projected channels per head) and gdir

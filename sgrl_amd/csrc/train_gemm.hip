@@ -677,6 +677,75 @@ __global__ __launch_bounds__(128) void k_embed3_bwd(Embed3 e, const float* __res
   e.dw[t][(size_t)r * e.n[t] + (c - off)] = s;
 }
 
+// Optimizer steps over a TABLE of tensors (reference agent.py:161-177: clip_grad_norm_ + Adam.step per network; common/functional.py:
+// 7-10: the soft target update).  torch's multi-tensor kernels take a few dozen tensors per launch through their argument
+// block: gradient clipping + Adam + soft update of the ~400 parameter tensors of actor and critics are ~50 launches of ~18 us per
+// TD3 update.  Here the tensors' addresses sit in a device table (6 x int64 per tensor: param, grad, exp_avg, exp_avg_sq, step,
+// numel), the work is cut into chunks of kOptChunk elements ((tensor, first element) pairs), one workgroup per chunk:
+//   k_opt_sqnorm   partial[c] = sum of grad^2 over chunk c
+//   k_opt_total    total = sum_c partial[c] in chunk order (one workgroup; bit-reproducible); every tensor's step += 1
+//   k_opt_adam     g *= min(1, max_norm / (sqrt(total) + 1e-6))  (written back, as clip_grad_norm_ does);  Adam as torch's fused kernel
+//                  computes it: m = lerp(m, g, 1 - b1), v = b2 v + (1 - b2) g g, p -= (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+//   k_opt_lerp     dst = dst (1 - tau) + tau src   (table rows: dst, src, -, -, -, numel)
+constexpr int kOptChunk = 4096;
+struct OptRow { float* p; float* g; float* m; float* v; float* step; long long n; };
+__global__ __launch_bounds__(256) void k_opt_sqnorm(const OptRow* __restrict__ tab, const int2* __restrict__ chunks, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const int2 c = chunks[blockIdx.x];
+  const OptRow r = tab[c.x];
+  const long long end = min(r.n, (long long)c.y + kOptChunk);
+  float s = 0.f;
+  for (long long i = c.y + threadIdx.x; i < end; i += 256) { const float g = r.g[i]; s += g * g; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void k_opt_total(const float* __restrict__ partial, int n_chunks, const OptRow* __restrict__ tab, int n_tensors,
+                                                   float* __restrict__ total) {
+  __shared__ float red[256];
+  if (partial) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n_chunks; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = red[0];
+  }
+  for (int i = threadIdx.x; i < n_tensors; i += 256) *tab[i].step += 1.0f;
+}
+// (the hyper-parameters are doubles and mix into the float arithmetic exactly where torch's fused kernel lets them: fused_adam_utils.cuh)
+__global__ __launch_bounds__(256) void k_opt_adam(const OptRow* __restrict__ tab, const int2* __restrict__ chunks, double lr, double b1, double b2, double eps,
+                                                  const float* __restrict__ total, float max_norm) {
+  const int2 c = chunks[blockIdx.x];
+  const OptRow r = tab[c.x];
+  const long long end = min(r.n, (long long)c.y + kOptChunk);
+  const float coef = total ? fminf(1.0f, max_norm / (sqrtf(*total) + 1e-6f)) : 1.0f;
+  const double t = (double)*r.step;                               // already advanced by k_opt_total
+  const float bc1 = (float)(1.0 - pow(b1, t));
+  const float bc2_sqrt = sqrtf((float)(1.0 - pow(b2, t)));
+  const float step_size = (float)(lr / (double)bc1);
+  for (long long i = c.y + threadIdx.x; i < end; i += 256) {
+    float g = r.g[i];
+    if (total) { g *= coef; r.g[i] = g; }
+    const float m = (float)(b1 * (double)r.m[i] + (1.0 - b1) * (double)g);
+    const float v = (float)(b2 * (double)r.v[i] + (1.0 - b2) * (double)g * (double)g);
+    r.m[i] = m; r.v[i] = v;
+    const float denom = (float)((double)(sqrtf(v) / bc2_sqrt) + eps);
+    r.p[i] -= step_size * m / denom;
+  }
+}
+__global__ __launch_bounds__(256) void k_opt_lerp(const OptRow* __restrict__ tab, const int2* __restrict__ chunks, float tau) {
+  const int2 c = chunks[blockIdx.x];
+  const OptRow r = tab[c.x];
+  const long long end = min(r.n, (long long)c.y + kOptChunk);
+  const float keep = 1.0f - tau;
+  for (long long i = c.y + threadIdx.x; i < end; i += 256) r.p[i] = r.p[i] * keep + tau * r.g[i];
+}
+
 // Only the weight gradient (AT) splits its contraction, and only where that pays: the release / acquire fences of the last-
 // workgroup reduction cost ~10-15 us on the eight-XCD chip, more than a few extra k-steps (measured: a 256 x 256 gradient over
 // 700 rows is 20 us unsplit, 27 us in three splits; a 30 x 128 gradient over 2 100 rows 51 us unsplit, 17 us in six).  So: a
@@ -959,6 +1028,31 @@ int sgrl_embed3_backward(const long long* idx, const float* dout, float* dw0, fl
   Embed3 e{idx, {nullptr, nullptr, nullptr}, {dw0, dw1, dw2}, {n0, n1, n2}, L, rows, n0 + n1 + n2};
   hipLaunchKernelGGL(k_embed3_bwd, dim3(rows), dim3(128), 0, (hipStream_t)stream, e, dout);
   { int lrc = SGRL_OK; if (!launched("k_embed3_bwd launch failed", &lrc)) return lrc; }
+  return SGRL_OK;
+}
+
+int sgrl_optim_chunk(void) { return kOptChunk; }
+
+int sgrl_optim_clip_adam(const void* table, int n_tensors, const void* chunks, int n_chunks, double lr, double beta1, double beta2, double eps,
+                         float max_norm, float* scratch, void* stream) {
+  if (!table || !chunks || n_tensors <= 0 || n_chunks <= 0 || (max_norm > 0.f && !scratch))
+    return tfail(SGRL_ERR_ARG, "sgrl_optim_clip_adam: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const OptRow* tab = reinterpret_cast<const OptRow*>(table);
+  const int2* ch = reinterpret_cast<const int2*>(chunks);
+  const bool clip = max_norm > 0.f;
+  if (clip) hipLaunchKernelGGL(k_opt_sqnorm, dim3(n_chunks), dim3(256), 0, st, tab, ch, scratch + 1);
+  hipLaunchKernelGGL(k_opt_total, dim3(1), dim3(256), 0, st, clip ? scratch + 1 : (const float*)nullptr, n_chunks, tab, n_tensors, scratch);
+  hipLaunchKernelGGL(k_opt_adam, dim3(n_chunks), dim3(256), 0, st, tab, ch, lr, beta1, beta2, eps, clip ? scratch : (const float*)nullptr, max_norm);
+  { int lrc = SGRL_OK; if (!launched("optimizer kernels: launch failed", &lrc)) return lrc; }
+  return SGRL_OK;
+}
+
+int sgrl_optim_lerp(const void* table, const void* chunks, int n_chunks, float tau, void* stream) {
+  if (!table || !chunks || n_chunks <= 0) return tfail(SGRL_ERR_ARG, "sgrl_optim_lerp: bad argument");
+  hipLaunchKernelGGL(k_opt_lerp, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const OptRow*>(table),
+                     reinterpret_cast<const int2*>(chunks), tau);
+  { int lrc = SGRL_OK; if (!launched("k_opt_lerp launch failed", &lrc)) return lrc; }
   return SGRL_OK;
 }
 

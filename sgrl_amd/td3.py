@@ -33,6 +33,19 @@ def soft_update_network(source_network, target_network, tau):
     with torch.no_grad():
         targets = [p.data for p in target_network.parameters()]
         sources = [p.data for p in source_network.parameters()]
+        if _TABLE_OPT and targets and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and s.is_contiguous() and
+                                          s.dtype == torch.float32 and s.device == t.device and s.numel() == t.numel()
+                                          for t, s in zip(targets, sources)):
+            import ctypes
+            from . import train_ops
+            dev = targets[0].device
+            ent = _table("lerp", [(t.data_ptr(), s.data_ptr(), 0, 0, 0, t.numel()) for t, s in zip(targets, sources)], dev)
+            if ent is not None:
+                L = _optim_lib()
+                train_ops._check(L, L.sgrl_optim_lerp(ctypes.c_void_p(ent["dev_tab"].data_ptr()), ctypes.c_void_p(ent["dev_chunks"].data_ptr()),
+                                                      ent["n_chunks"], float(tau), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                                 "sgrl_optim_lerp")
+                return
         if targets and targets[0].is_cuda:
             torch._foreach_mul_(targets, 1 - tau)
             torch._foreach_add_(targets, sources, alpha=tau)
@@ -43,6 +56,130 @@ def soft_update_network(source_network, target_network, tau):
 
 # SGRL_FUSED_ADAM=0: the foreach chain (bit-compatible with torch.optim.Adam's multi-tensor path) instead of the fused kernel
 _FUSED_ADAM = os.environ.get("SGRL_FUSED_ADAM", "1") != "0" and hasattr(torch, "_fused_adam_")
+# Gradient clipping + Adam, and the soft target update, over a device TABLE of tensor addresses (csrc/train_gemm.hip k_opt_*,
+# include/sgrl_train.h sgrl_optim_*): three launches and one instead of torch's ~50 multi-tensor launches of ~18 us per update.
+_TABLE_OPT = os.environ.get("SGRL_TABLE_OPT", "1") != "0"
+_tables = {}          # key (kind, address tuple) -> dict(dev table, dev chunks, pinned copies, scratch): see _table()
+
+
+def _optim_lib():
+    import ctypes
+    from . import train_ops
+    L = train_ops._L()
+    if not getattr(L, "_sgrl_optim_bound", False):
+        vp, ci, cf, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double
+        L.sgrl_optim_chunk.restype = ci
+        L.sgrl_optim_clip_adam.argtypes = [vp, ci, vp, ci, cd, cd, cd, cd, cf, vp, vp]
+        L.sgrl_optim_lerp.argtypes = [vp, vp, ci, cf, vp]
+        L._sgrl_optim_bound = True
+    return L
+
+
+_spare_pinned = {}    # (dtype, shape) -> pinned host tensors allocated OUTSIDE captures (hipHostMalloc is not permitted inside one)
+
+
+def _stock_pinned(n=4):
+    """Before a capture: every table size seen so far has at least n spare pinned buffers."""
+    if torch.cuda.is_current_stream_capturing():
+        return
+    for (dt, shape), pool in _spare_pinned.items():
+        while len(pool) < n:
+            pool.append(torch.empty(shape, dtype=dt).pin_memory())
+
+
+def _pinned_copy(t):
+    """A pinned copy of the small CPU tensor t; during a capture from the stock (None when it is empty: the caller falls back)."""
+    pool = _spare_pinned.setdefault((t.dtype, tuple(t.shape)), [])
+    if torch.cuda.is_current_stream_capturing():
+        if not pool:
+            return None
+        buf = pool.pop()
+    else:
+        buf = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+        _stock_pinned(4)
+    buf.copy_(t)
+    return buf
+
+
+def _table(kind, rows, device):
+    """Device copy of a tensor table (rows of six int64: five addresses and the element count) and its chunk list, cached by
+    content.  The upload is a copy from PINNED host memory on the current stream: inside a hipGraph capture it becomes a memcpy
+    node of the graph, so entries made during a capture are kept (with their host buffers) for as long as the process lives."""
+    key = (kind, device.index, tuple(rows))
+    ent = _tables.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if ent is not None:
+        if capturing:
+            ent["captured"] = True                 # a graph now points at this entry's device buffers: never evicted
+        elif not ent["eager_valid"]:               # made during a capture (its upload exists only as a node of that graph)
+            ent["dev_tab"].copy_(ent["host_tab"], non_blocking=True)
+            ent["dev_chunks"].copy_(ent["host_chunks"], non_blocking=True)
+            ent["eager_valid"] = True
+        return ent
+    chunk = int(_optim_lib().sgrl_optim_chunk())
+    chunks = [(i, o) for i, r in enumerate(rows) for o in range(0, r[5], chunk)]
+    host_tab = _pinned_copy(torch.tensor(rows, dtype=torch.int64))
+    host_chunks = _pinned_copy(torch.tensor(chunks, dtype=torch.int32))
+    if host_tab is None or host_chunks is None:
+        return None                                  # capturing with no pinned buffer in stock: the caller takes torch's path
+    ent = {"host_tab": host_tab, "host_chunks": host_chunks, "n": len(rows), "n_chunks": len(chunks), "captured": capturing,
+           "dev_tab": torch.empty_like(host_tab, device=device), "dev_chunks": torch.empty_like(host_chunks, device=device),
+           "scratch": torch.zeros(1 + len(chunks), dtype=torch.float32, device=device), "eager_valid": not capturing}
+    ent["dev_tab"].copy_(host_tab, non_blocking=True)
+    ent["dev_chunks"].copy_(host_chunks, non_blocking=True)
+    if not capturing and len(_tables) > 64:          # eager callers whose gradient addresses keep changing: bounded cache
+        for k in [k for k, v in _tables.items() if not v["captured"]][:32]:
+            del _tables[k]
+    _tables[key] = ent
+    return ent
+
+
+def clip_and_step(opt, max_norm):
+    """torch.nn.utils.clip_grad_norm_(params, max_norm) (max_norm > 0) followed by opt.step() for a capturable torch.optim.Adam
+    (reference agent.py:161-164, 174-177) on the optimizer's OWN state tensors -- as three launches over a table of the tensors'
+    addresses where everything is float32 on one GPU, through clip_grad_norm_ + adam_step otherwise."""
+    params = [p for g in opt.param_groups for p in g["params"] if p.grad is not None]
+    ok = _TABLE_OPT and len(opt.param_groups) == 1 and params and all(
+        p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous() and p.grad.dtype == torch.float32
+        and p.grad.device == p.device for p in params)
+    group = opt.param_groups[0]
+    ok = ok and group.get("capturable", False) and group.get("weight_decay", 0) == 0 and not group.get("amsgrad", False) and \
+        not group.get("maximize", False)
+    if not ok:
+        if max_norm and max_norm > 0:
+            torch.nn.utils.clip_grad_norm_([p for g in opt.param_groups for p in g["params"]], max_norm)
+        return adam_step(opt)
+    host = opt.__dict__.setdefault("_sgrl_step_class", {})
+    rows = []
+    for p in params:
+        st = opt.state[p]
+        if len(st) == 0:            # torch.optim.Adam's lazy state initialisation (capturable: the counter lives on the device)
+            st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            host[id(p)] = 0
+        elif id(p) not in host:
+            host[id(p)] = int(st["step"].item())
+        host[id(p)] += 1
+        rows.append((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(), p.numel()))
+    dev = params[0].device
+    ent = _table("adam", rows, dev)
+    if ent is None:
+        for p in params:
+            host[id(p)] -= 1                        # adam_step counts the step itself
+        if max_norm and max_norm > 0:
+            torch.nn.utils.clip_grad_norm_([p for g in opt.param_groups for p in g["params"]], max_norm)
+        return adam_step(opt)
+    import ctypes
+    from . import train_ops
+    L = _optim_lib()
+    beta1, beta2 = group["betas"]
+    lr = group["lr"]
+    rc = L.sgrl_optim_clip_adam(ctypes.c_void_p(ent["dev_tab"].data_ptr()), ent["n"], ctypes.c_void_p(ent["dev_chunks"].data_ptr()),
+                                ent["n_chunks"], float(lr), float(beta1), float(beta2), float(group["eps"]),
+                                float(max_norm) if (max_norm and max_norm > 0) else 0.0, ctypes.c_void_p(ent["scratch"].data_ptr()),
+                                ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    train_ops._check(L, rc, "sgrl_optim_clip_adam")
 
 
 def adam_step(opt):
@@ -204,9 +341,7 @@ class Agent(nn.Module):
         # (graphed path) the weight gradients are not on the backward pass's critical path: collected, issued together at the end
         with train_ops.deferred_wgrads(enabled=skip_unused_critic_grads):
             critic_loss.backward()
-        if args.grad_clipping_value > 0:
-            torch.nn.utils.clip_grad_norm_(self.critic.parameters(), args.grad_clipping_value)
-        adam_step(self.critic_optimizer)
+        clip_and_step(self.critic_optimizer, args.grad_clipping_value)
         rmean, rvar = torch.mean(reward_batch), torch.var(reward_batch)
         # the losses are returned DETACHED: a loss that keeps its autograd graph alive also keeps the parameters' AccumulateGrad
         # nodes -- and the stream they were created on -- alive into the next update; a hipGraph captured on another stream then
@@ -230,9 +365,7 @@ class Agent(nn.Module):
             finally:
                 for p in critic_params:
                     p.requires_grad_(True)
-            if args.grad_clipping_value > 0:
-                torch.nn.utils.clip_grad_norm_(self.actor.parameters(), args.grad_clipping_value)
-            adam_step(self.actor_optimizer)
+            clip_and_step(self.actor_optimizer, args.grad_clipping_value)
             self.try_update_target_network()
             loss_dict.update({"loss/actor_loss": actor_loss.detach()})
         return loss_dict
@@ -425,6 +558,7 @@ class GraphedUpdates(object):
             if self._cap_stream is None:
                 self._cap_stream, self._side = torch.cuda.Stream(), _concurrent_stream(torch.cuda.current_stream())
             gs = [torch.cuda.CUDAGraph() for _ in range(3)]
+            _stock_pinned(4)
             with _no_finalizers_during_capture():
                 with torch.cuda.graph(gs[0], stream=self._cap_stream):
                     rb, tq = self.agent.update_targets(sl["batch"], sl["noise"])
@@ -441,6 +575,7 @@ class GraphedUpdates(object):
             dump = os.environ.get("SGRL_GRAPH_DUMP")      # diagnostics: <dir> receives one .dot file per captured graph
             if dump:
                 g.enable_debug_mode()
+            _stock_pinned(4)
             with _no_finalizers_during_capture(), torch.cuda.graph(g):
                 sl["out"][flag] = self.agent.update(sl["batch"], flag, noise=sl["noise"], lazy_stats=True,
                                                     skip_unused_critic_grads=True)

@@ -473,3 +473,45 @@ def test_embed3_matches_the_three_embeddings():
     assert float(embs[0].weight.grad[7:].abs().max()) == 0.0
     out2 = train_ops.embed3(embs, idx)          # cached index block
     assert torch.equal(out2, want)
+
+
+@pytest.mark.parametrize("max_norm", [0.1, 0.0, 1e9])
+def test_table_optimizer_steps_match_torch(max_norm):
+    """td3.clip_and_step (gradient clipping + Adam over a device table of tensor addresses, three launches) against
+    torch.nn.utils.clip_grad_norm_ + torch.optim.Adam on ragged tensors, three steps: parameters, both moments, step counters
+    and the clipped gradients left behind; and the soft target update against the reference's formula."""
+    from sgrl_amd import td3
+    g = torch.Generator().manual_seed(int(max_norm * 10) % 97 + 3)
+    shapes = [(256, 256), (128,), (30, 128), (1,), (15, 42), (1024, 256), (5000,), (4097,), (3, 3, 3)]
+    base = [torch.randn(s, generator=g) for s in shapes]
+    grads = [[torch.randn(s, generator=g) * (0.01 if k else 3.0) for s in shapes] for k in range(3)]
+    outs = []
+    for table in (True, False):
+        td3._TABLE_OPT = table
+        ps = [torch.nn.Parameter(b.clone().cuda()) for b in base]
+        opt = torch.optim.Adam(ps, lr=1e-4, capturable=True)
+        for k in range(3):
+            for p, gr in zip(ps, grads[k]):
+                p.grad = gr.clone().cuda()
+            td3.clip_and_step(opt, max_norm)
+        outs.append(([p.detach().clone() for p in ps], [opt.state[p]["exp_avg"].clone() for p in ps],
+                     [opt.state[p]["exp_avg_sq"].clone() for p in ps], [float(opt.state[p]["step"]) for p in ps], [p.grad.clone() for p in ps]))
+    td3._TABLE_OPT = True
+    (pa, ma, va, sa, ga), (pb, mb, vb, sb, gb) = outs
+    assert sa == sb == [3.0] * len(shapes)
+    for a, b, b0 in zip(pa, pb, base):
+        assert float((a - b).abs().max()) <= 5e-7                          # one float32 ulp of parameters of magnitude ~4
+        assert float((a.cpu() - b0).abs().max()) > 1e-5                    # and they did move
+    for a, b in zip(ma + va + ga, mb + vb + gb):
+        assert float((a - b).abs().max()) <= 2e-6 * (float(b.abs().max()) + 1e-12)
+    # soft update
+    src = [torch.nn.Parameter(torch.randn(s, generator=g).cuda()) for s in shapes]
+    dst = [torch.nn.Parameter(torch.randn(s, generator=g).cuda()) for s in shapes]
+    want = [0.005 * a.detach().double() + 0.995 * b.detach().double() for a, b in zip(src, dst)]
+    class _N(torch.nn.Module):
+        def __init__(self, ps):
+            super().__init__()
+            self.ps = torch.nn.ParameterList(ps)
+    td3.soft_update_network(_N(src), _N(dst), 0.005)
+    for b, w in zip(dst, want):
+        assert float((b.detach().double() - w).abs().max()) < 1e-6
