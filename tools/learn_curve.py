@@ -33,7 +33,7 @@ os.makedirs(OUT, exist_ok=True)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 480.0
 per = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 seed = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-family = sys.argv[4] if len(sys.argv) > 4 else "hopper"      # "walker": BASELINE.json config 3 (the eight 3D_Walker++ variants), training only
+family = sys.argv[4] if len(sys.argv) > 4 else "hopper"      # "walker" / "humanoid" / "cheetah" / "cwhh" (config 5): training only
 HOPPERS = ["3d_hopper_3_shin", "3d_hopper_4_lower_shin", "3d_hopper_5_full"]
 
 
@@ -44,7 +44,14 @@ def diag(env):
 
 def train():
     args = default_train_args()
-    names = HOPPERS if family == "hopper" else sorted(n for n in mjcf.list_assets() if "walker" in n)
+    held = {"3d_walker_3_left_knee_right_knee", "3d_walker_6_right_foot", "3d_humanoid_7_left_leg", "3d_humanoid_8_right_knee",
+            "3d_cheetah_11_leftbkneen_rightffoot", "3d_cheetah_12_tail_leftffoot"}
+    if family == "hopper":
+        names = HOPPERS
+    elif family == "cwhh":          # BASELINE.json config 5: every training morphology of the four families (23)
+        names = sorted(n for n in mjcf.list_assets() if n not in held)
+    else:
+        names = sorted(n for n in mjcf.list_assets() if family in n)
     tr = DeviceTrainer(names, per, args=args, seed=seed, device="cuda:0", max_buffer_size=400000, graph_updates=True)
     env = tr.ro.env
     curve = []
@@ -72,7 +79,7 @@ def train():
         if rnd % 5 == 0:
             print("round %d: return %.2f length %.1f iters %d wall %.0f s" % (rnd, s["performance/train_return"],
                   s["performance/train_length"], s["per_morph_iter"], s["wall_s"]), flush=True)
-    out = {"seed": seed, "config": "BASELINE.json config %s (%s) x %d envs" % ("2: 3D_Hopper++" if family == "hopper" else "3: 3D_Walker++", ", ".join(names), per),
+    out = {"seed": seed, "config": "BASELINE.json config %s (%s) x %d envs" % ({"hopper": "2: 3D_Hopper++", "walker": "3: 3D_Walker++", "humanoid": "4: 3D_Humanoid++", "cwhh": "5: 3D_CWHH++"}.get(family, family), ", ".join(names), per),
            "schedule": "reference trainer.py:143-286 (per_morph_iter updates per morphology per round, batch 100, lr 1e-4, expl_noise 0.126)",
            "random_policy": {"train_return_mean": float(np.mean(rand_returns)) if rand_returns else None,
                              "train_length_mean": float(np.mean(rand_lengths)) if rand_lengths else None, "rounds": len(rand_returns)},
