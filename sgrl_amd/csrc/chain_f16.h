@@ -1,0 +1,397 @@
+// chain_f16.h -- back-to-back products of the SET actor in ONE kernel (two-piece f16 x 3 form of gemm_f32.h):
+//
+//     out[M, 128] = epi2( relu(A[M, K1] . W1[HID, K1]^T + b1) . W2[128, HID]^T + b2 ),      HID = 256 or 128
+//
+// (reference SEActor.py:93-123 linear1 -> ReLU -> linear2 and linear_g1 -> ReLU -> linear_g2, SEActor.py:256-276 the head's
+// pairs).  A workgroup owns 64 rows from the first operand load to the last store:
+//   prologue (PROJ)  Z = X[3 rows per node, Kp] . Wp^T -- the site's stacked 30-column projections -- written to zc / z2
+//   phase 1   the WHOLE HID-wide intermediate of its rows in accumulators (8 waves = 2 row groups x 4 hidden groups, tiles kept
+//             TRANSPOSED: lane = row, registers = hidden index), operands staged per 16-wide k-tile exactly as k_gemm3 does;
+//             the first operand is either loaded (SRC 0) or GENERATED from Z as the blocked Gram triangle (SRC 1, K1 = 576)
+//   hand-off  bias + ReLU + the two-piece split happen in REGISTERS; the f16 planes of the intermediate go to LDS in 64-column
+//             slices (two slice buffers in the bytes phase 1 used for its stages) -- the intermediate never reaches memory and
+//             is split once
+//   phase 2   64 x 128 outputs (32 x 32 per wave, transposed again), k running over the slices, only W2 is staged
+//   epilogue  plain store | row division | residual + LayerNorm in place (lane = row: row sums are register sums)
+// 60 KB of LDS and 128 registers: two workgroups per CU, as the single products.
+#pragma once
+#include "gemm_f32.h"
+
+namespace sgrl_gemm {
+
+struct ChainArgs {
+  const float* A; int lda;            // SRC 0: [M, K1] float32; SRC 1: Z [M, 3, 32] (= zc when PROJ writes it)
+  const unsigned* W1; int ldw1;       // pre-split words (enc_word) [HID][ldw1]
+  const float* b1;
+  const unsigned* W2; int ldw2;       // pre-split words [128][ldw2]
+  const float* b2;
+  float* C; int ldc;                  // plain epilogue: C[m][0:128]
+  int M, K1;
+  const float* rowdiv;                // EPI_ROWDIV: value / rowdiv[m]
+  float* fn_out;                      // SRC 1: receives ||Z'Z||_F + 1 per row
+  float* ln_io; int ln_ld;            // EPI_LN: residual stream, rewritten in place
+  const float* ln_w; const float* ln_b;
+  // PROJ: X [3 M, Kp] (row stride ldx), Wp words [64][Kp] (rows 0..29 -> zc columns 0..29, rows 32..61 -> z2 columns 0..29)
+  const float* X; int ldx; int Kp;
+  const unsigned* Wp;
+  float* zc; float* z2;
+  unsigned* range_events;
+};
+
+constexpr int kChainRows = 64;
+constexpr int kChainLds = 61440;
+
+// SRC: 0 loaded operand, 1 Gram operand.  PROJ: 0 none, 1 one projection (zc), 2 two (zc and z2).
+template <int SRC, int HID, int EPI2, int PROJ>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k_chain(ChainArgs a) {
+  static_assert(HID == 256 || HID == 128, "hidden width 256 or 128");
+  static_assert(PROJ == 0 || SRC == 1, "the projection prologue feeds the Gram operand");
+  constexpr int R = kChainRows, RB = 48;        // a k-tile row: 16 f16 + 16 B pad (conflict-free ds_read_b128)
+  constexpr int TN = HID / 128;                 // 32-wide hidden tiles per wave in phase 1
+  constexpr int kPlaneA = R * RB, kPlaneW = HID * RB, kStage1 = 2 * (kPlaneA + kPlaneW);
+  constexpr int SLP = 144;                      // slice row: 64 f16 + 16 B pad
+  constexpr int kSlicePlane = R * SLP, kSliceBuf = 2 * kSlicePlane;
+  constexpr int kW2Plane = 128 * RB, kW2Stage = 2 * kW2Plane, kW2Base = 2 * kSliceBuf;
+  static_assert(2 * kStage1 <= kChainLds && kW2Base + 2 * kW2Stage <= kChainLds, "LDS image");
+  constexpr float kCorW = 1.f / kF16LowScale;
+  constexpr float kPre = SRC == 1 ? 1.f / 256.f : 1.f, kPost = SRC == 1 ? 256.f : 1.f;   // Gram entries are squares (gemm_f32.h)
+  extern __shared__ float gemm_lds[];
+  char* lds = reinterpret_cast<char*>(gemm_lds);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 2, wn = wave & 3;      // row group | hidden group (phase 1) / column group (phase 2)
+  const int m0 = blockIdx.x * R;
+  const int kq = t & 3, r4 = t >> 2;            // staging: float4 kq of tile row r4 (+ 128 i)
+  float rmax = 0.f;
+
+  // ---- prologue: the site's projections ----------------------------------------------------------------------------------
+  if (PROJ) {
+    constexpr int kPXA = 192 * RB, kPXW = 64 * RB, kPStage = 2 * (kPXA + kPXW);
+    static_assert(2 * kPStage <= kChainLds, "LDS image of the projection prologue");
+    const int rows3 = 3 * a.M, x0 = 3 * m0;
+    const float* xr0 = a.X + (size_t)min(x0 + r4, rows3 - 1) * a.ldx + 4 * kq;
+    const float* xr1 = a.X + (size_t)min(x0 + 128 + (r4 & 63), rows3 - 1) * a.ldx + 4 * kq;     // threads 0..255
+    const unsigned* wr = a.Wp + (size_t)(r4 & 63) * a.Kp + 4 * kq;                               // threads 256..511
+    const bool lowh = t < 256;
+    float4 x0v, x1v;
+    auto pload = [&](int k0) {
+      x0v = *reinterpret_cast<const float4*>(xr0 + k0);
+      x1v = lowh ? *reinterpret_cast<const float4*>(xr1 + k0) : *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(wr) + k0);
+    };
+    auto put2 = [&](char* plane0, int plane_stride, int row, const float4& vin) {
+      rmax = fmaxf(fmaxf(rmax, fabsf(vin.x)), fabsf(vin.y));
+      rmax = fmaxf(fmaxf(rmax, fabsf(vin.z)), fabsf(vin.w));
+      unsigned h0, l0, h1, l1;
+      split2h(__builtin_amdgcn_fmed3f(vin.x, -kF16Lim, kF16Lim), __builtin_amdgcn_fmed3f(vin.y, -kF16Lim, kF16Lim), h0, l0);
+      split2h(__builtin_amdgcn_fmed3f(vin.z, -kF16Lim, kF16Lim), __builtin_amdgcn_fmed3f(vin.w, -kF16Lim, kF16Lim), h1, l1);
+      char* p = plane0 + row * RB + 8 * kq;
+      *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(l0, l1);
+    };
+    auto putw = [&](char* plane0, int plane_stride, int row, const float4& v) {
+      const unsigned w0 = __float_as_uint(v.x), w1 = __float_as_uint(v.y), w2 = __float_as_uint(v.z), w3 = __float_as_uint(v.w);
+      char* p = plane0 + row * RB + 8 * kq;
+      *reinterpret_cast<uint2*>(p) = make_uint2(__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u));
+      *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u));
+    };
+    auto pstore = [&](int st) {
+      char* base = lds + st * kPStage;
+      put2(base, kPXA, r4, x0v);
+      if (lowh) put2(base, kPXA, 128 + r4, x1v);
+      else putw(base + 2 * kPXA, kPXW, r4 & 63, x1v);
+    };
+    f32x16 pacc[PROJ ? PROJ : 1], pcor[PROJ ? PROJ : 1];
+#pragma unroll
+    for (int j = 0; j < PROJ; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) { pacc[j][e] = 0.f; pcor[j][e] = 0.f; }
+    const int nkp = a.Kp / 16;
+    pload(0);
+    pstore(0);
+    __syncthreads();
+    if (nkp > 1) pload(16);
+    const int paoff = (32 * wave + li) * RB + 16 * lh;
+    const int pboff = 2 * kPXA + li * RB + 16 * lh;
+    for (int kt = 0; kt < nkp; kt++) {
+      const int st = kt & 1;
+      if (kt + 1 < nkp) pstore(st ^ 1);
+      if (kt + 2 < nkp) pload((kt + 2) * 16);
+      if (wave < 6) {
+        const char* base = lds + st * kPStage;
+        const f16x8 ah = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(base + paoff));
+        const f16x8 al = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(base + kPXA + paoff));
+#pragma unroll
+        for (int j = 0; j < PROJ; j++) {
+          const f16x8 bh = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(base + pboff + 32 * j * RB));
+          const f16x8 bl = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(base + kPXW + pboff + 32 * j * RB));
+          pacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, pacc[j], 0, 0, 0);
+          pcor[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, pcor[j], 0, 0, 0);
+          pcor[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, pcor[j], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+    if (wave < 6 && li < 30) {
+#pragma unroll
+      for (int j = 0; j < PROJ; j++) {
+        float* dst = j == 0 ? a.zc : a.z2;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int row = x0 + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if (row < rows3) dst[(size_t)row * 32 + li] = pacc[j][e] + pcor[j][e] * kCorW;
+        }
+      }
+    }
+    __syncthreads();        // the block's Z rows are in memory (same CU: visible to its other waves) and the LDS is free
+  }
+
+  // ---- phase 1 ------------------------------------------------------------------------------------------------------------
+  f32x16 acc[TN], cor[TN];
+#pragma unroll
+  for (int j = 0; j < TN; j++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) { acc[j][e] = 0.f; cor[j][e] = 0.f; }
+  const bool stage_a = t < 256;                 // waves 0..3 stage the 64 A rows (one float4 each)
+  const int arow = min(m0 + (r4 & 63), a.M - 1);
+  const float* arow_g = SRC == 1 ? a.A + (size_t)arow * 96 : a.A + (size_t)arow * a.lda + 4 * kq;
+  const unsigned* wrow_g[TN];
+#pragma unroll
+  for (int i = 0; i < TN; i++) wrow_g[i] = a.W1 + (size_t)(r4 + 128 * i) * a.ldw1 + 4 * kq;
+  float4 ra[2], rw[2][TN];
+  float gza[3];
+  float4 gzb[3];
+  int ga = 0, gb = 0;
+  auto gload_gram = [&]() {
+#pragma unroll
+    for (int sx = 0; sx < 3; sx++) gzb[sx] = *reinterpret_cast<const float4*>(arow_g + 32 * sx + 4 * gb);
+    if (gb == 0) {
+#pragma unroll
+      for (int sx = 0; sx < 3; sx++) gza[sx] = arow_g[32 * sx + 4 * ga + kq] * kPre;
+    }
+    if (++gb > ga) { ga++; gb = 0; }
+  };
+  auto gload = [&](int slot, int k0) {
+    if (SRC == 0 && stage_a) ra[slot] = *reinterpret_cast<const float4*>(arow_g + k0);
+#pragma unroll
+    for (int i = 0; i < TN; i++) rw[slot][i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(wrow_g[i]) + k0);
+  };
+  auto put = [&](char* plane0, int plane_stride, int row, const float4& vin) {
+    rmax = fmaxf(fmaxf(rmax, fabsf(vin.x)), fabsf(vin.y));
+    rmax = fmaxf(fmaxf(rmax, fabsf(vin.z)), fabsf(vin.w));
+    unsigned h0, l0, h1, l1;
+    split2h(__builtin_amdgcn_fmed3f(vin.x, -kF16Lim, kF16Lim), __builtin_amdgcn_fmed3f(vin.y, -kF16Lim, kF16Lim), h0, l0);
+    split2h(__builtin_amdgcn_fmed3f(vin.z, -kF16Lim, kF16Lim), __builtin_amdgcn_fmed3f(vin.w, -kF16Lim, kF16Lim), h1, l1);
+    char* p = plane0 + row * RB + 8 * kq;
+    *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(l0, l1);
+  };
+  auto put_words = [&](char* plane0, int plane_stride, int row, const float4& v) {
+    const unsigned w0 = __float_as_uint(v.x), w1 = __float_as_uint(v.y), w2 = __float_as_uint(v.z), w3 = __float_as_uint(v.w);
+    char* p = plane0 + row * RB + 8 * kq;
+    *reinterpret_cast<uint2*>(p) = make_uint2(__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u));
+    *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u));
+  };
+  auto sstore = [&](int slot, int st) {
+    char* base = lds + st * kStage1;
+    if (stage_a) {
+      if (SRC == 1) {
+        const float za0 = gza[0], za1 = gza[1], za2 = gza[2];
+        const float4 b0 = gzb[0], b1 = gzb[1], b2 = gzb[2];
+        put(base, kPlaneA, r4, make_float4(za0 * b0.x + za1 * b1.x + za2 * b2.x, za0 * b0.y + za1 * b1.y + za2 * b2.y,
+                                           za0 * b0.z + za1 * b1.z + za2 * b2.z, za0 * b0.w + za1 * b1.w + za2 * b2.w));
+      } else {
+        put(base, kPlaneA, r4, ra[slot]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TN; i++) put_words(base + 2 * kPlaneA, kPlaneW, r4 + 128 * i, rw[slot][i]);
+  };
+  if (SRC == 1 && a.fn_out && stage_a) {
+    // fn[m] = ||Z'Z||_F + 1 = ||Z Z'||_F + 1 (gemm_f32.h): six 32-term dot products, a quarter per staging thread of the row
+    float c[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const float4 x = *reinterpret_cast<const float4*>(arow_g + 8 * kq + 4 * h);
+      const float4 y = *reinterpret_cast<const float4*>(arow_g + 32 + 8 * kq + 4 * h);
+      const float4 z = *reinterpret_cast<const float4*>(arow_g + 64 + 8 * kq + 4 * h);
+      c[0] += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+      c[1] += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+      c[2] += z.x * z.x + z.y * z.y + z.z * z.z + z.w * z.w;
+      c[3] += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+      c[4] += x.x * z.x + x.y * z.y + x.z * z.z + x.w * z.w;
+      c[5] += y.x * z.x + y.y * z.y + y.z * z.z + y.w * z.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      c[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c[k]), 0xB1, 0xF, 0xF, true));
+      c[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c[k]), 0x4E, 0xF, 0xF, true));
+    }
+    if (kq == 0 && m0 + r4 < a.M)
+      a.fn_out[m0 + r4] = sqrtf((c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + 2.f * (c[3] * c[3] + c[4] * c[4] + c[5] * c[5])) + 1.0f;
+  }
+  const int nk = a.K1 / 16;
+  if (SRC == 1 && stage_a) gload_gram();
+  gload(0, 0);
+  sstore(0, 0);
+  __syncthreads();
+  if (SRC == 1 && stage_a && nk > 1) gload_gram();
+  if (nk > 1) gload(0, 16);
+  if (nk > 2) gload(1, 32);
+  const int aoff = (wm * 32 + li) * RB + 16 * lh;
+  const int boff = 2 * kPlaneA + (wn * 32 * TN + li) * RB + 16 * lh;
+  const bool late = wave >= 4;                  // waves w and w + 4 share a SIMD: opposite phase order (gemm_f32.h SKEW)
+  auto body = [&](int kt, int slot) {
+    const int st = kt & 1;
+    if (!late) {
+      if (kt + 1 < nk) sstore(slot, st ^ 1);
+      if (SRC == 1 && stage_a && kt + 2 < nk) gload_gram();
+      if (kt + 3 < nk) gload(slot, (kt + 3) * 16);
+    }
+    const char* base = lds + st * kStage1;
+    const f16x8 ah = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(base + aoff));
+    const f16x8 al = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(base + kPlaneA + aoff));
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const f16x8 bh = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(base + boff + 32 * j * RB));
+      const f16x8 bl = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(base + kPlaneW + boff + 32 * j * RB));
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[j], 0, 0, 0);     // transposed: registers = hidden, lanes = rows
+      cor[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, cor[j], 0, 0, 0);
+      cor[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, cor[j], 0, 0, 0);
+    }
+    if (late) {
+      if (kt + 1 < nk) sstore(slot, st ^ 1);
+      if (kt + 3 < nk) gload(slot, (kt + 3) * 16);
+    }
+    __syncthreads();
+  };
+  {
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) { body(kt, 0); body(kt + 1, 1); }
+    if (kt < nk) body(kt, 0);
+  }
+
+  // ---- hand-off: bias + ReLU + split in registers --------------------------------------------------------------------------
+  uint2 Hh[TN][4], Hl[TN][4];
+#pragma unroll
+  for (int j = 0; j < TN; j++)
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const int hid = wn * 32 * TN + 32 * j + 8 * g + 4 * lh;
+      const float4 b4 = a.b1 ? *reinterpret_cast<const float4*>(a.b1 + hid) : make_float4(0, 0, 0, 0);
+      const float v0 = fmaxf((acc[j][4 * g + 0] + cor[j][4 * g + 0] * kCorW) * kPost + b4.x, 0.f);
+      const float v1 = fmaxf((acc[j][4 * g + 1] + cor[j][4 * g + 1] * kCorW) * kPost + b4.y, 0.f);
+      const float v2 = fmaxf((acc[j][4 * g + 2] + cor[j][4 * g + 2] * kCorW) * kPost + b4.z, 0.f);
+      const float v3 = fmaxf((acc[j][4 * g + 3] + cor[j][4 * g + 3] * kCorW) * kPost + b4.w, 0.f);
+      rmax = fmaxf(fmaxf(rmax, v0), fmaxf(v1, fmaxf(v2, v3)));
+      unsigned h0, l0, h1, l1;
+      split2h(fminf(v0, kF16Lim), fminf(v1, kF16Lim), h0, l0);
+      split2h(fminf(v2, kF16Lim), fminf(v3, kF16Lim), h1, l1);
+      Hh[j][g] = make_uint2(h0, h1);
+      Hl[j][g] = make_uint2(l0, l1);
+    }
+  const int my_slice = HID == 256 ? wn : (wn >> 1);
+  auto write_slice = [&](int buf) {
+    char* sb = lds + buf * kSliceBuf + (wm * 32 + li) * SLP;
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int off = 2 * ((HID == 256 ? 32 * j : 32 * (wn & 1)) + 8 * g + 4 * lh);
+        *reinterpret_cast<uint2*>(sb + off) = Hh[j][g];
+        *reinterpret_cast<uint2*>(sb + kSlicePlane + off) = Hl[j][g];
+      }
+  };
+
+  // ---- phase 2 ------------------------------------------------------------------------------------------------------------
+  constexpr int nk2 = HID / 16;
+  f32x16 acc2, cor2;
+#pragma unroll
+  for (int e = 0; e < 16; e++) { acc2[e] = 0.f; cor2[e] = 0.f; }
+  const float* w2row = reinterpret_cast<const float*>(a.W2 + (size_t)r4 * a.ldw2 + 4 * kq);
+  float4 rw2[2];
+  auto store2 = [&](int slot, int st) { put_words(lds + kW2Base + st * kW2Stage, kW2Plane, r4, rw2[slot]); };
+  rw2[0] = *reinterpret_cast<const float4*>(w2row);
+  if (my_slice < 2) write_slice(my_slice);      // (the last barrier of phase 1 has freed the stage bytes)
+  store2(0, 0);
+  __syncthreads();
+  rw2[0] = *reinterpret_cast<const float4*>(w2row + 16);
+  if (nk2 > 2) rw2[1] = *reinterpret_cast<const float4*>(w2row + 32);
+  const int hoff = (wm * 32 + li) * SLP + 16 * lh;
+  const int w2off = kW2Base + (wn * 32 + li) * RB + 16 * lh;
+  auto body2 = [&](int kt, int slot) {
+    const int st = kt & 1;
+    if (kt + 1 < nk2) store2(slot, st ^ 1);
+    if (kt + 3 < nk2) rw2[slot] = *reinterpret_cast<const float4*>(w2row + (kt + 3) * 16);
+    if (HID == 256) {                           // slices 2 / 3 replace slices 0 / 1 once their last reader has passed its barrier
+      if (kt == 4 && my_slice == 2) write_slice(0);
+      if (kt == 8 && my_slice == 3) write_slice(1);
+    }
+    const char* hb = lds + ((kt >> 2) & 1) * kSliceBuf + hoff + 32 * (kt & 3);
+    const f16x8 hh = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(hb));
+    const f16x8 hl = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(hb + kSlicePlane));
+    const char* wb = lds + w2off + st * kW2Stage;
+    const f16x8 wh = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(wb));
+    const f16x8 wl = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(wb + kW2Plane));
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hh, acc2, 0, 0, 0);           // transposed: registers = columns, lanes = rows
+    cor2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hl, cor2, 0, 0, 0);
+    cor2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hh, cor2, 0, 0, 0);
+    __syncthreads();
+  };
+#pragma unroll
+  for (int kt = 0; kt < nk2; kt += 2) { body2(kt, 0); body2(kt + 1, 1); }
+  if (rmax > kF16Lim && a.range_events) atomicAdd(a.range_events, 1u);
+
+  // ---- epilogue: lane = row m, registers = columns 32 wn + 8 g + 4 lh + (0..3) ----------------------------------------------
+  const int m = m0 + wm * 32 + li;
+  const bool ok = m < a.M;
+  const float rd = (EPI2 & EPI_ROWDIV) ? 1.0f / a.rowdiv[ok ? m : a.M - 1] : 1.f;
+  float v[16];
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    const float4 b4 = a.b2 ? *reinterpret_cast<const float4*>(a.b2 + wn * 32 + 8 * g + 4 * lh) : make_float4(0, 0, 0, 0);
+    v[4 * g + 0] = (acc2[4 * g + 0] + cor2[4 * g + 0] * kCorW + b4.x) * rd;
+    v[4 * g + 1] = (acc2[4 * g + 1] + cor2[4 * g + 1] * kCorW + b4.y) * rd;
+    v[4 * g + 2] = (acc2[4 * g + 2] + cor2[4 * g + 2] * kCorW + b4.z) * rd;
+    v[4 * g + 3] = (acc2[4 * g + 3] + cor2[4 * g + 3] * kCorW + b4.w) * rd;
+  }
+  if (EPI2 & EPI_LN) {
+    float* red = gemm_lds;                      // [64 rows][4 column groups]; the LDS is idle (last barrier of phase 2)
+    float* rrow = a.ln_io + (size_t)(ok ? m : a.M - 1) * a.ln_ld + wn * 32 + 4 * lh;
+    float part = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const float4 x = *reinterpret_cast<const float4*>(rrow + 8 * g);
+      v[4 * g + 0] += x.x; v[4 * g + 1] += x.y; v[4 * g + 2] += x.z; v[4 * g + 3] += x.w;
+      part += (v[4 * g + 0] + v[4 * g + 1]) + (v[4 * g + 2] + v[4 * g + 3]);
+    }
+    auto row_sum = [&](float p) -> float {      // over the row's 128 columns: the other half-wave, then the four column groups
+      p += __shfl_xor(p, 32, 64);
+      __syncthreads();
+      if (lh == 0) red[(wm * 32 + li) * 4 + wn] = p;
+      __syncthreads();
+      const float4 q = *reinterpret_cast<const float4*>(red + (wm * 32 + li) * 4);
+      return (q.x + q.y) + (q.z + q.w);
+    };
+    const float mu = row_sum(part) * (1.f / 128.f);
+    part = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; e++) { v[e] -= mu; part += v[e] * v[e]; }
+    const float inv = 1.0f / sqrtf(row_sum(part) * (1.f / 128.f) + 1e-5f);
+    if (ok) {
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const float4 lw = *reinterpret_cast<const float4*>(a.ln_w + wn * 32 + 8 * g + 4 * lh);
+        const float4 lb = *reinterpret_cast<const float4*>(a.ln_b + wn * 32 + 8 * g + 4 * lh);
+        *reinterpret_cast<float4*>(rrow + 8 * g) = make_float4(v[4 * g + 0] * inv * lw.x + lb.x, v[4 * g + 1] * inv * lw.y + lb.y,
+                                                                v[4 * g + 2] * inv * lw.z + lb.z, v[4 * g + 3] * inv * lw.w + lb.w);
+      }
+    }
+    return;
+  }
+  if (ok) {
+    float* crow = a.C + (size_t)m * a.ldc + wn * 32 + 4 * lh;
+#pragma unroll
+    for (int g = 0; g < 4; g++) *reinterpret_cast<float4*>(crow + 8 * g) = make_float4(v[4 * g + 0], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+  }
+}
+
+}  // namespace sgrl_gemm

@@ -18,7 +18,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // forward by k_embed); the zero-padding columns 30, 31, 62, 63 of the stacked operand are not stored
 // EPI_LN (k_gemm3, N = 128 = one column tile): the result is not stored; it is the update of a residual stream that is layer-
 // normalised in place: ln_io[m][:] = LayerNorm(ln_io[m][:] + value[m][:]) * ln_w + ln_b over the 128 columns of the row
-enum { EPI_RELU = 1, EPI_ROWDIV = 2, EPI_ACC2 = 4, EPI_EQUIV = 8, EPI_ZSPLIT = 16, EPI_LN = 32 };
+// EPI_TR (k_gemm3): the tiles are accumulated TRANSPOSED (lane = row, registers = columns) and stored row-wise, 16 bytes per lane
+// and store instruction (plain / ReLU / row-division epilogues; one divisor per lane instead of sixteen)
+enum { EPI_RELU = 1, EPI_ROWDIV = 2, EPI_ACC2 = 4, EPI_EQUIV = 8, EPI_ZSPLIT = 16, EPI_LN = 32, EPI_TR = 64 };
 
 struct GemmArgs {
   const float* A; int lda;
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
           if (NPL == 2) {
             const f16x8 ah = __builtin_bit_cast(f16x8, av[i][0]), al = __builtin_bit_cast(f16x8, av[i][1]);
             const f16x8 bh = __builtin_bit_cast(f16x8, bv[j][0]), bl = __builtin_bit_cast(f16x8, bv[j][1]);
-            if (FLAGS & EPI_EQUIV) {          // transposed tile, as below
+            if (FLAGS & (EPI_EQUIV | EPI_TR)) {          // transposed tile, as below
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[i][j], 0, 0, 0);
               cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, cor[i][j], 0, 0, 0);
               cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, cor[i][j], 0, 0, 0);
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
               cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, cor[i][j], 0, 0, 0);   // l'h
               cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, cor[i][j], 0, 0, 0);   // hl'
             }
-          } else if (FLAGS & EPI_EQUIV) {
+          } else if (FLAGS & (EPI_EQUIV | EPI_TR)) {
             // transposed tile (W rows on the accumulator rows = registers, nodes on the lanes): the epilogue's contraction over
             // the W-row index then runs over REGISTERS of a lane instead of across lanes
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j][0], av[i][0], acc[i][j], 0, 0, 0);
@@ -626,6 +628,30 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
         float tv = ts[sx] * rd;
         tv += __shfl_xor(tv, 32, 64);
         if (ok && lh == 0) a.tout[(size_t)m * 96 + sx * 32 + cidx] = tv;
+      }
+    }
+    return;
+  }
+  if (FLAGS & EPI_TR) {
+    // Row-wise stores of transposed tiles: lane = row, registers = columns 8 g + 4 lh + (0..3) of the tile -- one float4 per g
+    static_assert(!(FLAGS & EPI_TR) || (TM == 1 && !(FLAGS & (EPI_ACC2 | EPI_ZSPLIT | EPI_LN | EPI_EQUIV)) && !CWD), "EPI_TR: plain / ReLU / row-division epilogues");
+    const int m = m0 + wm * 32 + li;
+    if (m < a.M) {
+      const float rd = (FLAGS & EPI_ROWDIV) ? 1.0f / a.rowdiv[m] : 1.f;
+#pragma unroll
+      for (int tj = 0; tj < TN; tj++) {
+        const int nb = n0 + wn * 32 * TN + tj * 32 + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int n = nb + 8 * g;
+          if (n + 3 >= a.N) continue;                  // (N is a multiple of 4 for every product of the forward)
+          const float4 b4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + n) : make_float4(0, 0, 0, 0);
+          float4 v = make_float4(fin(acc[0][tj][4 * g + 0], cor[0][tj][4 * g + 0]) + b4.x, fin(acc[0][tj][4 * g + 1], cor[0][tj][4 * g + 1]) + b4.y,
+                                 fin(acc[0][tj][4 * g + 2], cor[0][tj][4 * g + 2]) + b4.z, fin(acc[0][tj][4 * g + 3], cor[0][tj][4 * g + 3]) + b4.w);
+          if (FLAGS & EPI_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+          if (FLAGS & EPI_ROWDIV) v = make_float4(v.x * rd, v.y * rd, v.z * rd, v.w * rd);
+          *reinterpret_cast<float4*>(a.C + (size_t)m * a.ldc + n) = v;
+        }
       }
     }
     return;

@@ -25,6 +25,7 @@
 #include "../../include/sgrl_set.h"
 #include "../../include/sgrl_train.h"
 #include "gemm_f32.h"
+#include "chain_f16.h"
 #include "stream_pick.h"
 
 namespace {
@@ -729,6 +730,66 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw
   return SGRL_OK;
 }
 
+// ---- back-to-back products in one kernel (chain_f16.h; two-piece form, weights pre-split by k_pack) -----------------------
+// SGRL_SET_CHAIN=0 in the environment keeps every product a launch of its own (A/B comparisons).
+bool chain_enabled() {
+  static const bool v = [] { const char* e = getenv("SGRL_SET_CHAIN"); return !(e && e[0] == '0'); }();
+  return v;
+}
+using sgrl_gemm::ChainArgs;
+using sgrl_gemm::k_chain;
+constexpr auto kSiteA = k_chain<1, 256, 0, 1>;                         // attention site: g -> Z -> Gram -> lg1 -> ReLU -> lg2
+constexpr auto kSiteF = k_chain<1, 256, 0, 2>;                         // feed-forward site: g1 -> Z, Z2 -> ...
+constexpr auto kSiteH1 = k_chain<1, 128, 0, 1>;                        // head (critic): outg -> Z -> Gram -> l1g -> ReLU -> l2g
+constexpr auto kSiteH2 = k_chain<1, 128, 0, 2>;                        // head (actor): ... Z, Z2
+constexpr auto kChainLn = k_chain<0, 256, EPI_ROWDIV | EPI_LN, 0>;     // linear1 -> ReLU -> linear2 / fn -> residual + norm2
+constexpr auto kChainNg = k_chain<0, 128, 0, 0>;                       // linear1_ng -> ReLU -> linear2_ng
+bool chain_raise_lds_limits() {
+  const void* ks[] = {reinterpret_cast<const void*>(kSiteA), reinterpret_cast<const void*>(kSiteF), reinterpret_cast<const void*>(kSiteH1),
+                      reinterpret_cast<const void*>(kSiteH2), reinterpret_cast<const void*>(kChainLn), reinterpret_cast<const void*>(kChainNg)};
+  for (const void* k : ks)
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, sgrl_gemm::kChainLds) != hipSuccess) return false;
+  return true;
+}
+const unsigned* words_of(const float* W) { return g_gemm.w_words + (W - g_gemm.w_base); }
+// projection site + Gram pair: X [3 M, Kp] -> zc (and z2) -> fn -> relu(G(Z) . W1^T + b1) . W2^T + b2 -> C[:, 0:128]
+int launch_site(hipStream_t st, const float* X, int ldx, int Kp, const float* Wp, float* zc, float* z2, float* fn, const float* W1,
+                const float* b1, int hid, const float* W2, const float* b2, float* C, int ldc, int M) {
+  if (Kp % 16 != 0 || (ldx & 3) || (hid != 256 && hid != 128)) return sfail(SGRL_ERR_ARG, "site: K must be a multiple of 16, rows 16-byte aligned, hidden width 128 or 256");
+  ChainArgs a{};
+  a.A = zc; a.W1 = words_of(W1); a.ldw1 = GK; a.b1 = b1; a.W2 = words_of(W2); a.ldw2 = hid; a.b2 = b2; a.C = C; a.ldc = ldc; a.M = M; a.K1 = GK;
+  a.fn_out = fn; a.X = X; a.ldx = ldx; a.Kp = Kp; a.Wp = words_of(Wp); a.zc = zc; a.z2 = z2; a.range_events = g_gemm.events;
+  const dim3 grid((M + sgrl_gemm::kChainRows - 1) / sgrl_gemm::kChainRows);
+  if (hid == 256) {
+    if (z2) hipLaunchKernelGGL(kSiteF, grid, dim3(512), sgrl_gemm::kChainLds, st, a);
+    else hipLaunchKernelGGL(kSiteA, grid, dim3(512), sgrl_gemm::kChainLds, st, a);
+  } else {
+    if (z2) hipLaunchKernelGGL(kSiteH2, grid, dim3(512), sgrl_gemm::kChainLds, st, a);
+    else hipLaunchKernelGGL(kSiteH1, grid, dim3(512), sgrl_gemm::kChainLds, st, a);
+  }
+  return SGRL_OK;
+}
+// ln_io[m][:] = LayerNorm(ln_io[m][:] + (relu(A . W1^T + b1) . W2^T + b2)[m][:] / rowdiv[m])      (hidden width 256)
+int launch_chain_ln(hipStream_t st, const float* A, int lda, int K1, const float* W1, const float* b1, const float* W2, const float* b2,
+                    const float* rowdiv, float* ln_io, int ln_ld, const float* ln_w, const float* ln_b, int M) {
+  if (K1 % 16 != 0 || (lda & 3)) return sfail(SGRL_ERR_ARG, "chain: K must be a multiple of 16 and rows 16-byte aligned");
+  ChainArgs a{};
+  a.A = A; a.lda = lda; a.W1 = words_of(W1); a.ldw1 = K1; a.b1 = b1; a.W2 = words_of(W2); a.ldw2 = 256; a.b2 = b2; a.M = M; a.K1 = K1;
+  a.rowdiv = rowdiv; a.ln_io = ln_io; a.ln_ld = ln_ld; a.ln_w = ln_w; a.ln_b = ln_b; a.range_events = g_gemm.events;
+  hipLaunchKernelGGL(kChainLn, dim3((M + sgrl_gemm::kChainRows - 1) / sgrl_gemm::kChainRows), dim3(512), sgrl_gemm::kChainLds, st, a);
+  return SGRL_OK;
+}
+// C[:, 0:128] = relu(A . W1^T + b1) . W2^T + b2      (hidden width 128)
+int launch_chain_ng(hipStream_t st, const float* A, int lda, int K1, const float* W1, const float* b1, const float* W2, const float* b2,
+                    float* C, int ldc, int M) {
+  if (K1 % 16 != 0 || (lda & 3)) return sfail(SGRL_ERR_ARG, "chain: K must be a multiple of 16 and rows 16-byte aligned");
+  ChainArgs a{};
+  a.A = A; a.lda = lda; a.W1 = words_of(W1); a.ldw1 = K1; a.b1 = b1; a.W2 = words_of(W2); a.ldw2 = 128; a.b2 = b2; a.C = C; a.ldc = ldc; a.M = M;
+  a.K1 = K1; a.range_events = g_gemm.events;
+  hipLaunchKernelGGL(kChainNg, dim3((M + sgrl_gemm::kChainRows - 1) / sgrl_gemm::kChainRows), dim3(512), sgrl_gemm::kChainLds, st, a);
+  return SGRL_OK;
+}
+
 // ---- small batches ------------------------------------------------------------------------------------------------------
 // Below kSmallNodes nodes (the TD3 update's no-grad target networks: 100 transitions of one morphology = 700..1400 nodes;
 // single-environment action selection) a 128 x 128 tile kernel has a handful of workgroups that each walk the whole
@@ -821,6 +882,8 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   float* ng = s->cat + 128;
   int rc = SGRL_OK;
   const bool small = N <= (s->small_nodes >= 0 ? s->small_nodes : small_nodes());
+  // back-to-back products as one kernel each: the tile path in its two-piece form on bound (pre-split) weights
+  const bool chain = !small && chain_enabled() && gemm_use_split() && g_gemm.form == SGRL_SET_FORM_F16X3;
   float* const scratch = s->qkv;      // small path: [N, 576] Gram triangle / [N, 1024] per-node matrices (spans qkv | vg)
 #define G(...) do { rc = small ? small_gemm(st, __VA_ARGS__) : launch_gemm(st, __VA_ARGS__); if (rc != SGRL_OK) return rc; } while (0)
   auto gram_gemm = [&](const float* W_, const float* b_, float* C_, int ldc_, int N_) -> int {
@@ -895,9 +958,15 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
     // --- attention ---
     fork();
     GS(s->g, D, s->WL(l, SGRL_SET_VG_W), D, nullptr, s->vg, 256, N3, 256, D);          // U = g . (Wgo_h Wvg_h)^T, both heads
-    PG(s->g, D, D, 2 * l, nullptr);
-    GG(s->WL(l, SGRL_SET_A_LG1_W), s->WL(l, SGRL_SET_A_LG1_B), s->h256, 256, 256);
-    G(s->h256, 256, s->WL(l, SGRL_SET_A_LG2_W), 256, s->WL(l, SGRL_SET_A_LG2_B), s->cat, 256, N, 128, 256);
+    if (chain) {
+      rc = launch_site(st, s->g, D, D, site_w(2 * l), s->zc, nullptr, s->fn, s->WL(l, SGRL_SET_A_LG1_W), s->WL(l, SGRL_SET_A_LG1_B), 256,
+                       s->WL(l, SGRL_SET_A_LG2_W), s->WL(l, SGRL_SET_A_LG2_B), s->cat, 256, N);
+      if (rc != SGRL_OK) return rc;
+    } else {
+      PG(s->g, D, D, 2 * l, nullptr);
+      GG(s->WL(l, SGRL_SET_A_LG1_W), s->WL(l, SGRL_SET_A_LG1_B), s->h256, 256, 256);
+      G(s->h256, 256, s->WL(l, SGRL_SET_A_LG2_W), 256, s->WL(l, SGRL_SET_A_LG2_B), s->cat, 256, N, 128, 256);
+    }
     G(s->cat, 256, s->WL(l, SGRL_SET_QKV_W), 256, s->WL(l, SGRL_SET_QKV_B), s->qkv, 768, N, 768, 256, EPI_ROWDIV, s->fn);
     join();
     hipLaunchKernelGGL(k_attention, dim3(s->n_env), dim3(256), 0, st, s->qkv, s->vg, s->gdir, s->d_relb, et, l == 0 ? 1 : 0,
@@ -905,11 +974,17 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
                        s->g1, ng, 256, s->WL(l, SGRL_SET_N1_W), s->WL(l, SGRL_SET_N1_B));
     if (s->stop_after == 2 * l) return SGRL_OK;      // probe: g1 = attention's vector output, delta = its scalar output
     // --- equivariant feed-forward ---
-    PG(s->g1, D, D, 2 * l + 1, s->z2);
-    GG(s->WL(l, SGRL_SET_F_LG1_W), s->WL(l, SGRL_SET_F_LG1_B), s->h256, 256, 256);
-    G(s->h256, 256, s->WL(l, SGRL_SET_F_LG2_W), 256, s->WL(l, SGRL_SET_F_LG2_B), s->cat, 256, N, 128, 256);
+    if (chain) {
+      rc = launch_site(st, s->g1, D, D, site_w(2 * l + 1), s->zc, s->z2, s->fn, s->WL(l, SGRL_SET_F_LG1_W), s->WL(l, SGRL_SET_F_LG1_B), 256,
+                       s->WL(l, SGRL_SET_F_LG2_W), s->WL(l, SGRL_SET_F_LG2_B), s->cat, 256, N);
+      if (rc != SGRL_OK) return rc;
+    } else {
+      PG(s->g1, D, D, 2 * l + 1, s->z2);
+      GG(s->WL(l, SGRL_SET_F_LG1_W), s->WL(l, SGRL_SET_F_LG1_B), s->h256, 256, 256);
+      G(s->h256, 256, s->WL(l, SGRL_SET_F_LG2_W), 256, s->WL(l, SGRL_SET_F_LG2_B), s->cat, 256, N, 128, 256);
+    }
     fork();
-    GS(s->cat, 256, s->WL(l, SGRL_SET_L1_W), 256, s->WL(l, SGRL_SET_L1_B), s->t256b, 256, N, 256, 256, EPI_RELU);
+    if (!chain) GS(s->cat, 256, s->WL(l, SGRL_SET_L1_W), 256, s->WL(l, SGRL_SET_L1_B), s->t256b, 256, N, 256, 256, EPI_RELU);
     G(s->cat, 256, s->WL(l, SGRL_SET_L3_W), 256, s->WL(l, SGRL_SET_L3_B), s->t256, 256, N, 256, 256, EPI_RELU);
     // linear2 carries the scalar stream's second residual + norm2 in its epilogue (ng rewritten in place): it must not start
     // before linear3 -- the other reader of cat = [inv | ng] -- is done
@@ -922,6 +997,10 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
       if (rc != SGRL_OK) return rc;
       hipLaunchKernelGGL(k_add_ln, dim3(lnb), dim3(256), 0, st, ng, 256, s->delta, 128, s->WL(l, SGRL_SET_N2_W),
                          s->WL(l, SGRL_SET_N2_B), (float*)nullptr, 0, ng, 256, N);
+    } else if (chain) {
+      rc = launch_chain_ln(sd, s->cat, 256, 256, s->WL(l, SGRL_SET_L1_W), s->WL(l, SGRL_SET_L1_B), s->WL(l, SGRL_SET_L2_W), s->WL(l, SGRL_SET_L2_B),
+                           s->fn, ng, 256, s->WL(l, SGRL_SET_N2_W), s->WL(l, SGRL_SET_N2_B), N);
+      if (rc != SGRL_OK) return rc;
     } else {
       rc = launch_gemm_ln(sd, s->t256b, 256, s->WL(l, SGRL_SET_L2_W), 256, s->WL(l, SGRL_SET_L2_B), N, 256, s->fn, ng, 256,
                           s->WL(l, SGRL_SET_N2_W), s->WL(l, SGRL_SET_N2_B));
@@ -938,11 +1017,20 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   hipLaunchKernelGGL(k_add_ln, dim3(lnb), dim3(256), 0, st, ng, 256, (const float*)nullptr, 0, s->W(SGRL_SET_FNORM_W),
                      s->W(SGRL_SET_FNORM_B), (float*)nullptr, 0, s->outng + ngf, 160, N);
   fork();
-  GS(s->outng, 160, s->W(SGRL_SET_L1NG_W), 160, s->W(SGRL_SET_L1NG_B), s->t128b, D, N, D, 160, EPI_RELU);
-  GS(s->t128b, D, s->W(SGRL_SET_L2NG_W), D, s->W(SGRL_SET_L2NG_B), s->cat2 + 128, 256, N, D, D);
-  PG(s->outg, OGLD, OGLD, 6, critic ? (float*)nullptr : s->z2);
-  GG(s->W(SGRL_SET_L1G_W), s->W(SGRL_SET_L1G_B), s->t128a, D, D);
-  G(s->t128a, D, s->W(SGRL_SET_L2G_W), D, s->W(SGRL_SET_L2G_B), s->cat2, 256, N, D, D);
+  if (chain) {
+    rc = launch_chain_ng(sd, s->outng, 160, 160, s->W(SGRL_SET_L1NG_W), s->W(SGRL_SET_L1NG_B), s->W(SGRL_SET_L2NG_W), s->W(SGRL_SET_L2NG_B),
+                         s->cat2 + 128, 256, N);
+    if (rc == SGRL_OK)
+      rc = launch_site(st, s->outg, OGLD, OGLD, site_w(6), s->zc, critic ? (float*)nullptr : s->z2, s->fn, s->W(SGRL_SET_L1G_W),
+                       s->W(SGRL_SET_L1G_B), 128, s->W(SGRL_SET_L2G_W), s->W(SGRL_SET_L2G_B), s->cat2, 256, N);
+    if (rc != SGRL_OK) return rc;
+  } else {
+    GS(s->outng, 160, s->W(SGRL_SET_L1NG_W), 160, s->W(SGRL_SET_L1NG_B), s->t128b, D, N, D, 160, EPI_RELU);
+    GS(s->t128b, D, s->W(SGRL_SET_L2NG_W), D, s->W(SGRL_SET_L2NG_B), s->cat2 + 128, 256, N, D, D);
+    PG(s->outg, OGLD, OGLD, 6, critic ? (float*)nullptr : s->z2);
+    GG(s->W(SGRL_SET_L1G_W), s->W(SGRL_SET_L1G_B), s->t128a, D, D);
+    G(s->t128a, D, s->W(SGRL_SET_L2G_W), D, s->W(SGRL_SET_L2G_B), s->cat2, 256, N, D, D);
+  }
   join();
   if (critic) {
     // slots reused by the critic head: DECG = decoder_ng.weight [256], L1M_B = decoder_ng.bias [1]
@@ -987,7 +1075,7 @@ int sgrl_set_create(sgrl_set** out) {
                        hipFuncSetAttribute(reinterpret_cast<const void*>(kGemmLnH), hipFuncAttributeMaxDynamicSharedMemorySize, GemmKernels<0>::kSplitHLds) == hipSuccess &&
                        GemmKernels<0>::raise_lds_limits() && GemmKernels<EPI_RELU>::raise_lds_limits() &&
                        GemmKernels<EPI_ROWDIV>::raise_lds_limits() && GemmKernels<EPI_ACC2>::raise_lds_limits() &&
-                       GemmKernels<EPI_ZSPLIT>::raise_lds_limits();
+                       GemmKernels<EPI_ZSPLIT>::raise_lds_limits() && chain_raise_lds_limits();
   if (!attr_ok) {
     *out = nullptr;
     return sfail(SGRL_ERR_HIP, "cannot raise the dynamic LDS limit of the GEMM kernel");
