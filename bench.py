@@ -335,18 +335,18 @@ def main():
                               "frac_of_f32_mfma_peak_nominal": round(nodes * 10.07e6 / (ms_set * 1e-3) / 157.3e12, 4),
                               "frac_of_f32_mfma_peak_executed": round(nodes * ex / (ms_set * 1e-3) / 157.3e12, 4),
                               "product_form": os.environ.get("SGRL_SET_GEMM", "f16x3"),
-                              "range_events": ro.actor.range_events(reset=False),
+                              "fused_chains": os.environ.get("SGRL_SET_CHAIN", "1") != "0",
                               "max_action_diff_between_product_forms": forms_diff,
                               "note": "nominal = the reference's dense layer sizes; executed = what the kernels run with the symmetric Gram "
                                       "matrix taken over the 36 4x4 blocks of its lower triangle (K = 576 instead of 1024; the "
                                       "operand is generated inside the GEMM, never stored) and the attention output "
                                       "projections folded into the value projections.  The GEMMs are float32 products (f32 in, f32 out, error "
                                       "against float64 at or below an f32 FMA chain's: tools/gemm_lab.hip h) carried by the 16-bit matrix "
-                                      "cores: every operand is cut into two f16 pieces, three matrix instructions per product block "
-                                      "(gemm_f32.h; SGRL_SET_GEMM=bf16x6 selects the three-piece bf16 form with f32's exponent range); "
-                                      "range_events = kernel threads that had to clamp an operand beyond +-65 000 during this run (0 = the "
-                                      "two-piece form was exact to its stated bound everywhere).  The f32-MFMA peak is the yardstick the "
-                                      "reference arithmetic would be priced against, not a bound of this kernel"}
+                                      "cores: every operand row is scaled by a power of two into f16's range (exact, undone in the epilogue: "
+                                      "float32's exponent range, nothing clamped) and cut into two f16 pieces, three matrix instructions per "
+                                      "product block (gemm_f32.h; SGRL_SET_GEMM=bf16x6 selects the three-piece bf16 form); back-to-back products "
+                                      "run as one kernel each (chain_f16.h).  The f32-MFMA peak is the yardstick the reference arithmetic would "
+                                      "be priced against, not a bound of this kernel"}
         # the exact-f32 forward next to the two-piece one: a child process with SGRL_SET_GEMM=f32 (plain products on
         # v_mfma_f32_32x32x2_f32, the reference's arithmetic; generated-operand products bf16 x 6) -- outside the timed region
         exact = None

@@ -156,23 +156,17 @@ int sgrl_set_debug_small_nodes(sgrl_set* s, int nodes);
 /* Form of the 128 x 128 tile products (reference: plain f32 `F.linear`, subequivariant_attentions.py:90-151 / SEActor.py:82-125).
  * Both forms carry the f32 product on the 16-bit matrix cores and measure the same error against float64 as an f32 FMA chain
  * (tools/gemm_lab.hip):
- *   SGRL_SET_FORM_F16X3  (default) every operand = two f16 pieces, three matrix instructions per product block.  Operands of
- *                        magnitude above 65 000 (f16's finite range) are clamped to +-65 000 and COUNTED;
- *   SGRL_SET_FORM_BF16X6 three bf16 pieces, six instructions: f32's whole exponent range, ~25 % slower products.
- * form 0 restores the default (SGRL_SET_GEMM=bf16x6 in the environment selects the second form). */
+ *   SGRL_SET_FORM_F16X3  (default) every operand = two f16 pieces, three matrix instructions per product block.  Every operand
+ *                        ROW is first multiplied by a power of two that brings its largest magnitude into f16's range (exact; undone
+ *                        in the epilogue), so the form has float32's exponent range as the reference's `F.linear` has: nothing is
+ *                        clamped, there is no range contract to watch (csrc/gemm_f32.h, pow2_scale);
+ *   SGRL_SET_FORM_BF16X6 three bf16 pieces, six instructions, ~25 % slower products (kept for A/B comparisons).
+ * form 0 restores the default (SGRL_SET_GEMM=bf16x6 in the environment selects the second form).  The back-to-back products of a
+ * forward (projection -> Gram -> linear_g1 -> linear_g2 sites, linear1 -> linear2 + norm2, the head's linear1_ng -> linear2_ng) run
+ * as ONE kernel each in the default form (csrc/chain_f16.h; SGRL_SET_CHAIN=0 in the environment keeps them apart). */
 #define SGRL_SET_FORM_F16X3 2
 #define SGRL_SET_FORM_BF16X6 3
 int sgrl_set_gemm_form(sgrl_set* s, int form);
-/* Number of kernel threads that clamped an operand since the last reset (0 in any sane policy state: activations of 6.5e4
- * mean a diverged network in the reference too).  Synchronise the forward's stream first.  A caller that sees a non-zero count
- * repeats the forward after sgrl_set_gemm_form(s, SGRL_SET_FORM_BF16X6). */
-int sgrl_set_range_events(sgrl_set* s, unsigned* count, int reset);
-/* The same counter as the forwards that have COMPLETED so far left it: the last kernel of every forward copies it into a word of
- * pinned host memory, which this call reads -- no device synchronisation, no stream operation, safe during a graph capture.  A
- * caller polls it after enqueueing a forward and, when it is non-zero, synchronises and handles the event (sgrl_set_range_events
- * with reset, sgrl_set_gemm_form): how `SEPolicy` / `SECritic` users get the warning and the form switch without asking
- * (sgrl_amd/set_hip.py HipSetActor._poll_range).  No reference counterpart: PyTorch's f32 products have f32's range. */
-unsigned sgrl_set_range_events_seen(const sgrl_set* s);
 /* Test hook: ONE product through the production tile kernels of the forward on caller-supplied device operands (kinds: plain,
  * ReLU, row division, Gram operand, equivariant epilogue, stacked projections, residual + LayerNorm; forms as above, 1 = the
  * exact-f32 matrix instruction for the first three) -- tests/test_split_products_gpu.py holds every instantiation the forward
@@ -180,6 +174,15 @@ unsigned sgrl_set_range_events_seen(const sgrl_set* s);
 int sgrl_set_debug_product(sgrl_set* s, int kind, int form, const float* A, int lda, const float* W, int ldw, const float* bias,
                            float* C, int ldc, int M, int N, int K, const float* rowdiv, const float* aux_in, float* aux_out,
                            void* stream);
+/* Test hook for the fused back-to-back products (csrc/chain_f16.h), on caller-supplied device operands:
+ *   kind 0  C[:, 0:128] = relu(A W1' + b1) W2' + b2                            A [M, K], W1 [hid, K], W2 [128, hid], hid = 128 | 256
+ *        1  C = LayerNorm(C + (relu(A W1' + b1) W2' + b2) / rowdiv)            hid = 256; C [M, ldc] read and rewritten; ln = ln_w | ln_b [256]
+ *        2  projection site: X = A [3 M, K] -> Z (zc, z2 [3 M, 32]; z2 may be null; columns 30, 31 untouched), fn [M] = ||Z'Z||_F + 1,
+ *           C[:, 0:128] = relu(G(Z) W1' + b1) W2' + b2 with Wp [64, K] the stacked projections, W1 [hid, 576] in the folded Gram order
+ * Synchronises `stream`. */
+int sgrl_set_debug_chain(sgrl_set* s, int kind, const float* A, int lda, int K, const float* Wp, const float* W1, const float* b1, int hid,
+                         const float* W2, const float* b2, float* C, int ldc, int M, const float* rowdiv, const float* ln, float* zc,
+                         float* z2, float* fn, void* stream);
 const char* sgrl_set_last_error(void);
 
 #ifdef __cplusplus

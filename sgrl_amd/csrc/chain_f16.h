@@ -14,6 +14,10 @@
 //   phase 2   64 x 128 outputs (32 x 32 per wave, transposed again), k running over the slices, only W2 is staged
 //   epilogue  plain store | row division | residual + LayerNorm in place (lane = row: row sums are register sums)
 // 60 KB of LDS and 128 registers: two workgroups per CU, as the single products.
+// Range (gemm_f32.h, pow2_scale): every operand row is scaled by a power of two before it is split -- weights by k_encode_rows,
+// the Gram rows by ||Z'Z||_F, loaded rows (A, X) by a first-tile estimate with a workgroup-uniform repeat on the exact maxima
+// if the estimate fell short, the intermediate by its exact row maximum (lane = row: a register maximum, one LDS exchange
+// between the four hidden groups) -- and every epilogue multiplies the inverse powers back.
 #pragma once
 #include "gemm_f32.h"
 
@@ -35,7 +39,8 @@ struct ChainArgs {
   const float* X; int ldx; int Kp;
   const unsigned* Wp;
   float* zc; float* z2;
-  unsigned* range_events;
+  // inverse row scales of the three weight operands (k_encode_rows): ws1 [HID], ws2 [128], wsp [64]
+  const float* ws1; const float* ws2; const float* wsp;
 };
 
 constexpr int kChainRows = 64;
@@ -54,14 +59,36 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
   constexpr int kW2Plane = 128 * RB, kW2Stage = 2 * kW2Plane, kW2Base = 2 * kSliceBuf;
   static_assert(2 * kStage1 <= kChainLds && kW2Base + 2 * kW2Stage <= kChainLds, "LDS image");
   constexpr float kCorW = 1.f / kF16LowScale;
-  constexpr float kPre = SRC == 1 ? 1.f / 256.f : 1.f, kPost = SRC == 1 ? 256.f : 1.f;   // Gram entries are squares (gemm_f32.h)
-  extern __shared__ float gemm_lds[];
+  extern __shared__ __attribute__((aligned(16))) float gemm_lds[];     // (aligned: static LDS precedes it)
   char* lds = reinterpret_cast<char*>(gemm_lds);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
   const int wm = wave >> 2, wn = wave & 3;      // row group | hidden group (phase 1) / column group (phase 2)
   const int m0 = blockIdx.x * R;
   const int kq = t & 3, r4 = t >> 2;            // staging: float4 kq of tile row r4 (+ 128 i)
-  float rmax = 0.f;
+  __shared__ float rs_sh[R];                    // 1 / scale of the workgroup's A rows (phase 1)
+  __shared__ float px_sh[PROJ ? 192 : 1];       // 1 / scale of its X rows (projection prologue)
+  __shared__ float hm_sh[R * 4];                // row maxima of the intermediate, per hidden group
+  __shared__ unsigned redo_sh;
+  if (t == 0) redo_sh = 0;
+  auto quad_max = [&](float m) -> float { m = fmaxf(m, __shfl_xor(m, 1, 64)); return fmaxf(m, __shfl_xor(m, 2, 64)); };
+  // split a float4 of a row scaled by sc (a power of two) into the two f16 planes; mx keeps the largest SCALED magnitude: one
+  // beyond the f16 range (possible under an estimated scale only) makes the workgroup repeat the phase with the exact maxima
+  auto put = [&](char* plane0, int plane_stride, int row, const float4& vin, float sc, float* mx) {
+    const float4 v = make_float4(vin.x * sc, vin.y * sc, vin.z * sc, vin.w * sc);
+    if (mx) { *mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), *mx); *mx = fmaxf(fmaxf(fabsf(v.z), fabsf(v.w)), *mx); }
+    unsigned h0, l0, h1, l1;
+    split2h(v.x, v.y, h0, l0);
+    split2h(v.z, v.w, h1, l1);
+    char* p = plane0 + row * RB + 8 * kq;
+    *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(l0, l1);
+  };
+  auto put_words = [&](char* plane0, int plane_stride, int row, const float4& v) {
+    const unsigned w0 = __float_as_uint(v.x), w1 = __float_as_uint(v.y), w2 = __float_as_uint(v.z), w3 = __float_as_uint(v.w);
+    char* p = plane0 + row * RB + 8 * kq;
+    *reinterpret_cast<uint2*>(p) = make_uint2(__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u));
+    *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u));
+  };
 
   // ---- prologue: the site's projections ----------------------------------------------------------------------------------
   if (PROJ) {
@@ -77,67 +104,85 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
       x0v = *reinterpret_cast<const float4*>(xr0 + k0);
       x1v = lowh ? *reinterpret_cast<const float4*>(xr1 + k0) : *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(wr) + k0);
     };
-    auto put2 = [&](char* plane0, int plane_stride, int row, const float4& vin) {
-      rmax = fmaxf(fmaxf(rmax, fabsf(vin.x)), fabsf(vin.y));
-      rmax = fmaxf(fmaxf(rmax, fabsf(vin.z)), fabsf(vin.w));
-      unsigned h0, l0, h1, l1;
-      split2h(__builtin_amdgcn_fmed3f(vin.x, -kF16Lim, kF16Lim), __builtin_amdgcn_fmed3f(vin.y, -kF16Lim, kF16Lim), h0, l0);
-      split2h(__builtin_amdgcn_fmed3f(vin.z, -kF16Lim, kF16Lim), __builtin_amdgcn_fmed3f(vin.w, -kF16Lim, kF16Lim), h1, l1);
-      char* p = plane0 + row * RB + 8 * kq;
-      *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(l0, l1);
-    };
-    auto putw = [&](char* plane0, int plane_stride, int row, const float4& v) {
-      const unsigned w0 = __float_as_uint(v.x), w1 = __float_as_uint(v.y), w2 = __float_as_uint(v.z), w3 = __float_as_uint(v.w);
-      char* p = plane0 + row * RB + 8 * kq;
-      *reinterpret_cast<uint2*>(p) = make_uint2(__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u));
-      *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u));
-    };
+    float psc[2] = {1.f, 1.f}, pmx[2] = {0.f, 0.f};     // scale / true maximum of X rows r4 and (threads 0..255) 128 + r4
     auto pstore = [&](int st) {
       char* base = lds + st * kPStage;
-      put2(base, kPXA, r4, x0v);
-      if (lowh) put2(base, kPXA, 128 + r4, x1v);
-      else putw(base + 2 * kPXA, kPXW, r4 & 63, x1v);
+      put(base, kPXA, r4, x0v, psc[0], &pmx[0]);
+      if (lowh) put(base, kPXA, 128 + r4, x1v, psc[1], &pmx[1]);
+      else put_words(base + 2 * kPXA, kPXW, r4 & 63, x1v);
     };
     f32x16 pacc[PROJ ? PROJ : 1], pcor[PROJ ? PROJ : 1];
-#pragma unroll
-    for (int j = 0; j < PROJ; j++)
-#pragma unroll
-      for (int e = 0; e < 16; e++) { pacc[j][e] = 0.f; pcor[j][e] = 0.f; }
     const int nkp = a.Kp / 16;
-    pload(0);
-    pstore(0);
-    __syncthreads();
-    if (nkp > 1) pload(16);
     const int paoff = (32 * wave + li) * RB + 16 * lh;
     const int pboff = 2 * kPXA + li * RB + 16 * lh;
-    for (int kt = 0; kt < nkp; kt++) {
-      const int st = kt & 1;
-      if (kt + 1 < nkp) pstore(st ^ 1);
-      if (kt + 2 < nkp) pload((kt + 2) * 16);
-      if (wave < 6) {
-        const char* base = lds + st * kPStage;
-        const f16x8 ah = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(base + paoff));
-        const f16x8 al = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(base + kPXA + paoff));
+    for (int attempt = 0;; attempt++) {
 #pragma unroll
-        for (int j = 0; j < PROJ; j++) {
-          const f16x8 bh = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(base + pboff + 32 * j * RB));
-          const f16x8 bl = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(base + kPXW + pboff + 32 * j * RB));
-          pacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, pacc[j], 0, 0, 0);
-          pcor[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, pcor[j], 0, 0, 0);
-          pcor[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, pcor[j], 0, 0, 0);
+      for (int j = 0; j < PROJ; j++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) { pacc[j][e] = 0.f; pcor[j][e] = 0.f; }
+      pload(0);
+      if (attempt == 0) {                     // estimates from three sampled k-tiles of each row (gemm_f32.h, pow2_scale)
+        auto m4 = [](const float4& v, float m) { m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), m); return fmaxf(fmaxf(fabsf(v.z), fabsf(v.w)), m); };
+        const int km = (nkp >> 1) * 16, kl = (nkp - 1) * 16;
+        float e0 = m4(x0v, 0.f), e1 = lowh ? m4(x1v, 0.f) : 0.f;
+        e0 = m4(*reinterpret_cast<const float4*>(xr0 + km), e0); e0 = m4(*reinterpret_cast<const float4*>(xr0 + kl), e0);
+        if (lowh) { e1 = m4(*reinterpret_cast<const float4*>(xr1 + km), e1); e1 = m4(*reinterpret_cast<const float4*>(xr1 + kl), e1); }
+        psc[0] = pow2_scale(quad_max(e0), kScaleEstimate);
+        psc[1] = pow2_scale(quad_max(e1), kScaleEstimate);
+      }
+      if (kq == 0) { px_sh[r4] = pow2_inv(psc[0]); if (lowh) px_sh[128 + r4] = pow2_inv(psc[1]); }
+      pstore(0);
+      __syncthreads();
+      if (nkp > 1) pload(16);
+      for (int kt = 0; kt < nkp; kt++) {
+        const int st = kt & 1;
+        if (kt + 1 < nkp) pstore(st ^ 1);
+        if (kt + 2 < nkp) pload((kt + 2) * 16);
+        if (wave < 6) {
+          const char* base = lds + st * kPStage;
+          const f16x8 ah = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(base + paoff));
+          const f16x8 al = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(base + kPXA + paoff));
+#pragma unroll
+          for (int j = 0; j < PROJ; j++) {
+            const f16x8 bh = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(base + pboff + 32 * j * RB));
+            const f16x8 bl = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(base + kPXW + pboff + 32 * j * RB));
+            pacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, pacc[j], 0, 0, 0);
+            pcor[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, pcor[j], 0, 0, 0);
+            pcor[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, pcor[j], 0, 0, 0);
+          }
         }
+        __syncthreads();
+      }
+      if (attempt == 1) break;
+      if (!(pmx[0] <= kF16Lim) || !(pmx[1] <= kF16Lim)) redo_sh = 1u;
+      __syncthreads();
+      if (redo_sh == 0u) break;               // (block-uniform) the usual exit
+      {                                       // the rare path: exact maxima of this thread's X rows (read again), then once more
+        float t0 = 0.f, t1 = 0.f;
+        for (int kt = 0; kt < nkp; kt++) {
+          const float4 x = *reinterpret_cast<const float4*>(xr0 + 16 * kt);
+          t0 = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), t0); t0 = fmaxf(fmaxf(fabsf(x.z), fabsf(x.w)), t0);
+          if (lowh) {
+            const float4 y = *reinterpret_cast<const float4*>(xr1 + 16 * kt);
+            t1 = fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), t1); t1 = fmaxf(fmaxf(fabsf(y.z), fabsf(y.w)), t1);
+          }
+        }
+        psc[0] = pow2_scale(quad_max(t0), kScaleExact);
+        psc[1] = pow2_scale(quad_max(t1), kScaleExact);
+        pmx[0] = 0.f; pmx[1] = 0.f;
       }
       __syncthreads();
+      if (t == 0) redo_sh = 0;                // phase 1 votes again
     }
     if (wave < 6 && li < 30) {
 #pragma unroll
       for (int j = 0; j < PROJ; j++) {
         float* dst = j == 0 ? a.zc : a.z2;
+        const float wsn = a.wsp ? a.wsp[32 * j + li] : 1.f;
 #pragma unroll
         for (int e = 0; e < 16; e++) {
-          const int row = x0 + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * lh;
-          if (row < rows3) dst[(size_t)row * 32 + li] = pacc[j][e] + pcor[j][e] * kCorW;
+          const int rl = 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * lh, row = x0 + rl;
+          if (row < rows3) dst[(size_t)row * 32 + li] = (pacc[j][e] + pcor[j][e] * kCorW) * (px_sh[rl] * wsn);
         }
       }
     }
@@ -157,6 +202,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
 #pragma unroll
   for (int i = 0; i < TN; i++) wrow_g[i] = a.W1 + (size_t)(r4 + 128 * i) * a.ldw1 + 4 * kq;
   float4 ra[2], rw[2][TN];
+  float asc = 1.f, amx = 0.f;                   // scale of this staging thread's A row | its largest magnitude so far
   float gza[3];
   float4 gzb[3];
   int ga = 0, gb = 0;
@@ -165,7 +211,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     for (int sx = 0; sx < 3; sx++) gzb[sx] = *reinterpret_cast<const float4*>(arow_g + 32 * sx + 4 * gb);
     if (gb == 0) {
 #pragma unroll
-      for (int sx = 0; sx < 3; sx++) gza[sx] = arow_g[32 * sx + 4 * ga + kq] * kPre;
+      for (int sx = 0; sx < 3; sx++) gza[sx] = arow_g[32 * sx + 4 * ga + kq] * asc;      // the Gram entries scaled by the row's power of two
     }
     if (++gb > ga) { ga++; gb = 0; }
   };
@@ -174,22 +220,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
 #pragma unroll
     for (int i = 0; i < TN; i++) rw[slot][i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(wrow_g[i]) + k0);
   };
-  auto put = [&](char* plane0, int plane_stride, int row, const float4& vin) {
-    rmax = fmaxf(fmaxf(rmax, fabsf(vin.x)), fabsf(vin.y));
-    rmax = fmaxf(fmaxf(rmax, fabsf(vin.z)), fabsf(vin.w));
-    unsigned h0, l0, h1, l1;
-    split2h(__builtin_amdgcn_fmed3f(vin.x, -kF16Lim, kF16Lim), __builtin_amdgcn_fmed3f(vin.y, -kF16Lim, kF16Lim), h0, l0);
-    split2h(__builtin_amdgcn_fmed3f(vin.z, -kF16Lim, kF16Lim), __builtin_amdgcn_fmed3f(vin.w, -kF16Lim, kF16Lim), h1, l1);
-    char* p = plane0 + row * RB + 8 * kq;
-    *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
-    *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(l0, l1);
-  };
-  auto put_words = [&](char* plane0, int plane_stride, int row, const float4& v) {
-    const unsigned w0 = __float_as_uint(v.x), w1 = __float_as_uint(v.y), w2 = __float_as_uint(v.z), w3 = __float_as_uint(v.w);
-    char* p = plane0 + row * RB + 8 * kq;
-    *reinterpret_cast<uint2*>(p) = make_uint2(__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u));
-    *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u));
-  };
   auto sstore = [&](int slot, int st) {
     char* base = lds + st * kStage1;
     if (stage_a) {
@@ -197,16 +227,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
         const float za0 = gza[0], za1 = gza[1], za2 = gza[2];
         const float4 b0 = gzb[0], b1 = gzb[1], b2 = gzb[2];
         put(base, kPlaneA, r4, make_float4(za0 * b0.x + za1 * b1.x + za2 * b2.x, za0 * b0.y + za1 * b1.y + za2 * b2.y,
-                                           za0 * b0.z + za1 * b1.z + za2 * b2.z, za0 * b0.w + za1 * b1.w + za2 * b2.w));
+                                           za0 * b0.z + za1 * b1.z + za2 * b2.z, za0 * b0.w + za1 * b1.w + za2 * b2.w), 1.f, nullptr);
       } else {
-        put(base, kPlaneA, r4, ra[slot]);
+        put(base, kPlaneA, r4, ra[slot], asc, &amx);
       }
     }
 #pragma unroll
     for (int i = 0; i < TN; i++) put_words(base + 2 * kPlaneA, kPlaneW, r4 + 128 * i, rw[slot][i]);
   };
-  if (SRC == 1 && a.fn_out && stage_a) {
-    // fn[m] = ||Z'Z||_F + 1 = ||Z Z'||_F + 1 (gemm_f32.h): six 32-term dot products, a quarter per staging thread of the row
+  if (SRC == 1 && stage_a) {
+    // fn[m] = ||Z'Z||_F + 1 = ||Z Z'||_F + 1 (gemm_f32.h): six 32-term dot products, a quarter per staging thread of the row;
+    // the norm bounds every entry of the row's Gram matrix and is the scale of the generated operand
     float c[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -225,17 +256,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
       c[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c[k]), 0xB1, 0xF, 0xF, true));
       c[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c[k]), 0x4E, 0xF, 0xF, true));
     }
-    if (kq == 0 && m0 + r4 < a.M)
-      a.fn_out[m0 + r4] = sqrtf((c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + 2.f * (c[3] * c[3] + c[4] * c[4] + c[5] * c[5])) + 1.0f;
+    const float frob = sqrtf((c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + 2.f * (c[3] * c[3] + c[4] * c[4] + c[5] * c[5]));
+    if (kq == 0 && m0 + r4 < a.M && a.fn_out) a.fn_out[m0 + r4] = frob + 1.0f;
+    asc = pow2_scale(frob, kScaleExact);
+    if (kq == 0) rs_sh[r4] = pow2_inv(asc);
   }
   const int nk = a.K1 / 16;
-  if (SRC == 1 && stage_a) gload_gram();
-  gload(0, 0);
-  sstore(0, 0);
-  __syncthreads();
-  if (SRC == 1 && stage_a && nk > 1) gload_gram();
-  if (nk > 1) gload(0, 16);
-  if (nk > 2) gload(1, 32);
   const int aoff = (wm * 32 + li) * RB + 16 * lh;
   const int boff = 2 * kPlaneA + (wn * 32 * TN + li) * RB + 16 * lh;
   const bool late = wave >= 4;                  // waves w and w + 4 share a SIMD: opposite phase order (gemm_f32.h SKEW)
@@ -263,31 +289,82 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     }
     __syncthreads();
   };
-  {
+  for (int attempt = 0;; attempt++) {
+    if (SRC == 1 && stage_a) { ga = 0; gb = 0; gload_gram(); }
+    gload(0, 0);
+    if (SRC == 0 && stage_a) {
+      if (attempt == 0) {                       // estimate from three sampled k-tiles of the row (gemm_f32.h, pow2_scale)
+        auto m4 = [](const float4& v, float m) { m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), m); return fmaxf(fmaxf(fabsf(v.z), fabsf(v.w)), m); };
+        float e = m4(ra[0], 0.f);
+        e = m4(*reinterpret_cast<const float4*>(arow_g + (nk >> 1) * 16), e);
+        e = m4(*reinterpret_cast<const float4*>(arow_g + (nk - 1) * 16), e);
+        asc = pow2_scale(quad_max(e), kScaleEstimate);
+      }
+      if (kq == 0) rs_sh[r4] = pow2_inv(asc);
+    }
+    sstore(0, 0);
+    __syncthreads();
+    if (SRC == 1 && stage_a && nk > 1) gload_gram();
+    if (nk > 1) gload(0, 16);
+    if (nk > 2) gload(1, 32);
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) { body(kt, 0); body(kt + 1, 1); }
     if (kt < nk) body(kt, 0);
+    if (SRC != 0 || attempt == 1) break;
+    if (!(amx <= kF16Lim)) redo_sh = 1u;
+    __syncthreads();
+    if (redo_sh == 0u) break;                   // (block-uniform) the usual exit: the estimate held
+    {                                           // the rare path: the exact maximum of this thread's A row (read again), then once more
+      float tm = 0.f;
+      if (stage_a)
+        for (int k2 = 0; k2 < nk; k2++) {
+          const float4 x = *reinterpret_cast<const float4*>(arow_g + 16 * k2);
+          tm = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), tm); tm = fmaxf(fmaxf(fabsf(x.z), fabsf(x.w)), tm);
+        }
+      asc = pow2_scale(quad_max(tm), kScaleExact);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) { acc[j][e] = 0.f; cor[j][e] = 0.f; }
   }
 
-  // ---- hand-off: bias + ReLU + split in registers --------------------------------------------------------------------------
+  // ---- hand-off: undo the operand scales, bias + ReLU, the row's exact maximum, split in registers ------------------------------
   uint2 Hh[TN][4], Hl[TN][4];
+  float hs;                                     // this lane's row (wm * 32 + li): scale of the intermediate
+  {
+    const float rsn = rs_sh[wm * 32 + li];
+    float hv[TN][16];
+    float hmax = 0.f;
 #pragma unroll
-  for (int j = 0; j < TN; j++)
+    for (int j = 0; j < TN; j++)
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-      const int hid = wn * 32 * TN + 32 * j + 8 * g + 4 * lh;
-      const float4 b4 = a.b1 ? *reinterpret_cast<const float4*>(a.b1 + hid) : make_float4(0, 0, 0, 0);
-      const float v0 = fmaxf((acc[j][4 * g + 0] + cor[j][4 * g + 0] * kCorW) * kPost + b4.x, 0.f);
-      const float v1 = fmaxf((acc[j][4 * g + 1] + cor[j][4 * g + 1] * kCorW) * kPost + b4.y, 0.f);
-      const float v2 = fmaxf((acc[j][4 * g + 2] + cor[j][4 * g + 2] * kCorW) * kPost + b4.z, 0.f);
-      const float v3 = fmaxf((acc[j][4 * g + 3] + cor[j][4 * g + 3] * kCorW) * kPost + b4.w, 0.f);
-      rmax = fmaxf(fmaxf(rmax, v0), fmaxf(v1, fmaxf(v2, v3)));
-      unsigned h0, l0, h1, l1;
-      split2h(fminf(v0, kF16Lim), fminf(v1, kF16Lim), h0, l0);
-      split2h(fminf(v2, kF16Lim), fminf(v3, kF16Lim), h1, l1);
-      Hh[j][g] = make_uint2(h0, h1);
-      Hl[j][g] = make_uint2(l0, l1);
-    }
+      for (int g = 0; g < 4; g++) {
+        const int hid = wn * 32 * TN + 32 * j + 8 * g + 4 * lh;
+        const float4 b4 = a.b1 ? *reinterpret_cast<const float4*>(a.b1 + hid) : make_float4(0, 0, 0, 0);
+        const float4 w4 = a.ws1 ? *reinterpret_cast<const float4*>(a.ws1 + hid) : make_float4(1, 1, 1, 1);
+        hv[j][4 * g + 0] = fmaxf((acc[j][4 * g + 0] + cor[j][4 * g + 0] * kCorW) * (rsn * w4.x) + b4.x, 0.f);
+        hv[j][4 * g + 1] = fmaxf((acc[j][4 * g + 1] + cor[j][4 * g + 1] * kCorW) * (rsn * w4.y) + b4.y, 0.f);
+        hv[j][4 * g + 2] = fmaxf((acc[j][4 * g + 2] + cor[j][4 * g + 2] * kCorW) * (rsn * w4.z) + b4.z, 0.f);
+        hv[j][4 * g + 3] = fmaxf((acc[j][4 * g + 3] + cor[j][4 * g + 3] * kCorW) * (rsn * w4.w) + b4.w, 0.f);
+        hmax = fmaxf(fmaxf(hmax, fmaxf(hv[j][4 * g + 0], hv[j][4 * g + 1])), fmaxf(hv[j][4 * g + 2], hv[j][4 * g + 3]));
+      }
+    hmax = fmaxf(hmax, __shfl_xor(hmax, 32, 64));
+    if (lh == 0) hm_sh[(wm * 32 + li) * 4 + wn] = hmax;
+    __syncthreads();
+    const float4 q = *reinterpret_cast<const float4*>(hm_sh + (wm * 32 + li) * 4);
+    hs = pow2_scale(fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)), kScaleExact);
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        unsigned h0, l0, h1, l1;
+        split2h(hv[j][4 * g + 0] * hs, hv[j][4 * g + 1] * hs, h0, l0);
+        split2h(hv[j][4 * g + 2] * hs, hv[j][4 * g + 3] * hs, h1, l1);
+        Hh[j][g] = make_uint2(h0, h1);
+        Hl[j][g] = make_uint2(l0, l1);
+      }
+  }
   const int my_slice = HID == 256 ? wn : (wn >> 1);
   auto write_slice = [&](int buf) {
     char* sb = lds + buf * kSliceBuf + (wm * 32 + li) * SLP;
@@ -338,20 +415,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
   };
 #pragma unroll
   for (int kt = 0; kt < nk2; kt += 2) { body2(kt, 0); body2(kt + 1, 1); }
-  if (rmax > kF16Lim && a.range_events) atomicAdd(a.range_events, 1u);
 
   // ---- epilogue: lane = row m, registers = columns 32 wn + 8 g + 4 lh + (0..3) ----------------------------------------------
   const int m = m0 + wm * 32 + li;
   const bool ok = m < a.M;
   const float rd = (EPI2 & EPI_ROWDIV) ? 1.0f / a.rowdiv[ok ? m : a.M - 1] : 1.f;
+  const float hsi = pow2_inv(hs);
   float v[16];
 #pragma unroll
   for (int g = 0; g < 4; g++) {
     const float4 b4 = a.b2 ? *reinterpret_cast<const float4*>(a.b2 + wn * 32 + 8 * g + 4 * lh) : make_float4(0, 0, 0, 0);
-    v[4 * g + 0] = (acc2[4 * g + 0] + cor2[4 * g + 0] * kCorW + b4.x) * rd;
-    v[4 * g + 1] = (acc2[4 * g + 1] + cor2[4 * g + 1] * kCorW + b4.y) * rd;
-    v[4 * g + 2] = (acc2[4 * g + 2] + cor2[4 * g + 2] * kCorW + b4.z) * rd;
-    v[4 * g + 3] = (acc2[4 * g + 3] + cor2[4 * g + 3] * kCorW + b4.w) * rd;
+    const float4 w4 = a.ws2 ? *reinterpret_cast<const float4*>(a.ws2 + wn * 32 + 8 * g + 4 * lh) : make_float4(1, 1, 1, 1);
+    v[4 * g + 0] = ((acc2[4 * g + 0] + cor2[4 * g + 0] * kCorW) * (hsi * w4.x) + b4.x) * rd;
+    v[4 * g + 1] = ((acc2[4 * g + 1] + cor2[4 * g + 1] * kCorW) * (hsi * w4.y) + b4.y) * rd;
+    v[4 * g + 2] = ((acc2[4 * g + 2] + cor2[4 * g + 2] * kCorW) * (hsi * w4.z) + b4.z) * rd;
+    v[4 * g + 3] = ((acc2[4 * g + 3] + cor2[4 * g + 3] * kCorW) * (hsi * w4.w) + b4.w) * rd;
   }
   if (EPI2 & EPI_LN) {
     float* red = gemm_lds;                      // [64 rows][4 column groups]; the LDS is idle (last barrier of phase 2)

@@ -43,7 +43,8 @@ struct GemmArgs {
   const float* ln_w = nullptr; const float* ln_b = nullptr;
   float* rowdiv_out = nullptr;   // GRAM: receives ||Z'Z||_F + 1 per row (from the blocks of the first column tile)
   int phase_sleep = 0;                // k_gemm3: blocks of odd dispatch rounds start this many x 64 clocks late (see the kernel)
-  unsigned* range_events = nullptr;   // two-piece f16 kernel: incremented by every thread that had to clamp an operand (see split2h)
+  // two-piece f16 form: W arrives as words of its rows PRE-SCALED by powers of two (k_encode_rows); wscale[n] undoes row n's scale
+  const float* wscale = nullptr;
 };
 
 // BKT = k extent of an LDS tile (16 or 32); row stride BKT + 4 floats (conflict-free ds_read_b128, see above).
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
   constexpr int NPA = BMT / RPP, NPW = BNT / RPP;
   constexpr int KH = BKT / 2;                 // k values per MFMA half (lanes 0..31 | 32..63)
   constexpr int NQ = KH / 4;                  // float4 per lane per operand row per tile
-  extern __shared__ float gemm_lds[];
+  extern __shared__ __attribute__((aligned(16))) float gemm_lds[];     // (aligned: static LDS precedes it)
   float* As = gemm_lds;                        // [2][BMT][SK]
   float* Ws = gemm_lds + 2 * BMT * SK;         // [2][BNT][SK]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -235,14 +236,34 @@ __device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return _
 // <= 2^-22 |x|.  a.b is rebuilt from hh + (h l' + l' h) / 2^11 -- THREE v_mfma_f32_32x32x16_f16 instead of six bf16 ones, two
 // LDS planes per operand instead of three; dropped: l'l' / 2^22 <= 2^-22 |a||b|.  An f16 x f16 product is exact in f32 and the
 // matrix core accumulates in f32.  The scaling of l' keeps the small piece in f16's NORMAL range wherever h is normal: full
-// accuracy for 6.1e-5 <= |x| <= 65 000; below, the absolute error stays under 2^-36 (h and l' turn subnormal, x - h is still
-// exact); above, the operand is CLAMPED to +-65 000 (f16 has no larger finite values worth having) and the event is counted
-// in GemmArgs::range_events -- the host surfaces the counter and can switch the handle to the bf16 x 6 form, which has
-// f32's full exponent range.  tools/gemm_lab.hip measures both forms against float64.
+// accuracy for 6.1e-5 <= |x| <= 65 000.  RANGE: f16 ends at 65 504 and loses precision below 6.1e-5, float32 does neither -- so no
+// operand is split as it stands.  Every ROW of an operand (a row of A = one node's activations, a row of W = one output
+// feature's weights) is first multiplied by a power of two that brings its largest magnitude to 2^14 .. 2^15 (exact in f32), the
+// pieces are taken of the scaled values, and the epilogue multiplies the result by the two inverse powers (exact again):
+//   * weights: k_encode_rows scales each row by its exact maximum when the flat weight buffer is rebuilt (once per forward);
+//   * generated Gram rows: by ||Z'Z||_F, which bounds every entry and is computed in the kernel's prologue anyway;
+//   * loaded activation rows: by an ESTIMATE -- the largest magnitude in three sampled k-tiles of the row (first, middle, last: the
+//     operands of the forward are concatenations such as [invariants | scalars] whose halves differ in size), placed at 2^6:
+//     512 x headroom above, 20 octaves of full precision below; the staging threads keep the largest scaled magnitude they
+//     split, and a workgroup that did meet a value beyond the headroom repeats its tile with the exact row maxima -- a
+//     block-uniform branch for data no sane network state produces, so the common case costs two extra loads per staging
+//     thread, two cross-lane maxima and one vote;
+//   * intermediates of the fused chains (chain_f16.h): by their exact row maxima, known in registers.
+// Elements more than 2^-22 below their row's maximum lose relative (not absolute) accuracy, as they do in any float32 sum
+// dominated by the large terms.  Nothing is clamped, nothing is counted: the form has float32's range by construction
+// (tests/test_split_products_gpu.py holds it against float64 at operand magnitudes 1e-20 .. 1e8).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 constexpr float kF16Lim = 65000.f;
 constexpr float kF16LowScale = 2048.f;
+constexpr int kScaleExact = 14, kScaleEstimate = 6;     // where a row's exact maximum / sampled estimate is placed (powers of two)
+// 2^(target - floor(log2 est)) with the exponent kept inside +-100; est <= 0 or NaN -> 1
+__device__ __forceinline__ float pow2_scale(float est, int target) {
+  const int e = (int)((__float_as_uint(est) >> 23) & 0xFFu) - 127;
+  const int se = est > 0.f ? min(max(target - e, -100), 100) : 0;
+  return __uint_as_float((unsigned)(se + 127) << 23);
+}
+__device__ __forceinline__ float pow2_inv(float s) { return __uint_as_float(0x7F000000u - __float_as_uint(s)); }   // 1 / 2^k, exact
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2h(float x0, float x1, unsigned& h, unsigned& l) {
   const f16x2 hv = __builtin_convertvector(f32x2{x0, x1}, f16x2);                        // one v_cvt_pk_f16_f32 (round to nearest)
@@ -258,8 +279,7 @@ __device__ __forceinline__ void split2h(float x0, float x1, unsigned& h, unsigne
 // consumer.  On gfx950 VALU instructions do not issue under matrix instructions (tools/micro/mfma_valu_overlap.hip: the times
 // add), so the ~22 VALU operations per four elements of an in-loop split cost matrix time; a word operand costs four byte
 // permutes per four elements.
-__device__ __forceinline__ unsigned enc_word(float x, float& rmax) {
-  rmax = fmaxf(rmax, fabsf(x));
+__device__ __forceinline__ unsigned enc_word(float x) {      // x: already scaled into the f16 range by its row's power of two
   const float c = __builtin_amdgcn_fmed3f(x, -kF16Lim, kF16Lim);
   const _Float16 h = (_Float16)c;
   const _Float16 l = (_Float16)((c - (float)h) * kF16LowScale);
@@ -308,22 +328,16 @@ template <int FLAGS, int WM, int WN, int TM, int TN, int BKT = 32, int PF = 1, b
 __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SGRL_GEMM_WPE))) void k_gemm3(GemmArgs a) {
   using Cfg = TileCfg3<WM, WN, TM, TN, BKT, NPL>;
   static_assert(NPL == 3 || (NPL == 2 && !PLA && !PLW && ABL != 3), "two-piece form: f32 operands only");
-  // two-piece form: the correction accumulator holds 2^11 x its sum; the Gram operand is generated 2^-8 x its value (entries
-  // are SQUARES of the projections' size: the clamp moves out to 1.6e7) and the result scaled back -- both exact
+  // two-piece form: the correction accumulator holds 2^11 x its sum; the accumulators hold the product of the ROW-SCALED operands
+  // (see pow2_scale): the epilogues multiply by rs_sh[row] (A) and a.wscale[column] (W), both powers of two
   constexpr float kCorW = NPL == 2 ? 1.f / kF16LowScale : 1.f;
-  constexpr float kPre = (NPL == 2 && GRAM) ? 1.f / 256.f : 1.f;
-  constexpr float kPost = (NPL == 2 && GRAM) ? 256.f : 1.f;
-  auto fin = [&](float hi, float co) -> float {
-    if (NPL == 2) { const float v = hi + co * kCorW; return GRAM ? v * kPost : v; }
-    return hi + co;
-  };
+  constexpr bool SCL = NPL == 2;
+  auto fin = [&](float hi, float co) -> float { return NPL == 2 ? hi + co * kCorW : hi + co; };
   static_assert(!SKEW || (!LATE && ABL == 0 && WM * WN == 8), "the skew assumes eight waves (w and w + 4 on one SIMD)");
-  // WORDS: bit 0 = A arrives as words (enc_word), bit 1 = W arrives as words, bit 2 = the plain epilogue (and EPI_LN's copy of
-  // its output for the following products) WRITES words
-  static_assert(WORDS == 0 || NPL == 2, "pre-split words belong to the two-piece form");
-  static_assert(!(WORDS & 1) || !GRAM, "the Gram operand is generated, not loaded");
-  constexpr bool AWD = (WORDS & 1) != 0, WWD = (WORDS & 2) != 0, CWD = (WORDS & 4) != 0;
-  float rmax = 0.f;                           // largest operand magnitude this thread has staged (two-piece form)
+  // WORDS: bit 1 = W arrives as pre-scaled, pre-split words (k_encode_rows); an f32 W of the two-piece form is split as it stands
+  // (lab / diagnostics only: no row scaling on that side)
+  static_assert(WORDS == 0 || (NPL == 2 && WORDS == 2), "pre-split words: the W operand of the two-piece form");
+  constexpr bool WWD = (WORDS & 2) != 0;
   constexpr int T = Cfg::kThreads, BMT = Cfg::kBM, BNT = Cfg::kBN, RB = Cfg::kRowBytes;
   constexpr int QPR = BKT / 4;                // float4 per tile row
   constexpr int RPP = T / QPR;                // tile rows covered per staging pass
@@ -331,8 +345,10 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
   constexpr int NPA = (BMT + RPP - 1) / RPP, NPW = (BNT + RPP - 1) / RPP;    // a pass may be partly idle (more threads than float4s)
   constexpr int KS = BKT / 16;                // MFMA k-steps per LDS tile
   static_assert(!GRAM || (BKT == 16 && RPP == BMT && !PLA), "the Gram operand needs one 16-wide k-tile per block pair and one staging pass");
-  extern __shared__ float gemm_lds[];
+  extern __shared__ __attribute__((aligned(16))) float gemm_lds[];     // (aligned: static LDS precedes it)
   char* lds = reinterpret_cast<char*>(gemm_lds);
+  __shared__ float rs_sh[SCL ? BMT : 1];      // two-piece form: 1 / (scale of A row r of the tile), for the epilogue
+  __shared__ unsigned redo_sh;                // ... and the workgroup vote on repeating the tile with exact row maxima
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (a.N + BNT - 1) / BNT;
@@ -344,6 +360,14 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
   const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
   const int m0 = tile_m * BMT, n0 = tile_n * BNT;
   const int kq = t % QPR, r0 = t / QPR;
+  float asc[NPA], amx[NPA];                   // scale of this staging thread's A rows | the largest scaled magnitude it has split
+#pragma unroll
+  for (int i = 0; i < NPA; i++) { asc[i] = 1.f; amx[i] = 0.f; }
+  auto quad_max = [&](float m) -> float {     // over the QPR staging threads of a row (adjacent lanes)
+#pragma unroll
+    for (int o = 1; o < QPR; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    return m;
+  };
   f32x16 acc[TM][TN], cor[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; i++)
@@ -381,7 +405,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
     for (int sx = 0; sx < 3; sx++) gzb[sx] = *reinterpret_cast<const float4*>(arow_g[0] + 32 * sx + 4 * gb);
     if (gb == 0) {                            // a new block row: this thread's a = 4 A + kq changes (uniform branch)
 #pragma unroll
-      for (int sx = 0; sx < 3; sx++) gza[sx] = arow_g[0][32 * sx + 4 * ga + kq] * kPre;
+      for (int sx = 0; sx < 3; sx++) gza[sx] = arow_g[0][32 * sx + 4 * ga + kq] * asc[0];     // G entries scaled by the row's power of two
     }
     if (++gb > ga) { ga++; gb = 0; }
   };
@@ -422,13 +446,12 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
     *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u));
   };
   // split a float4 into its three bf16 planes and store 8 bytes into each
-  auto put = [&](char* plane0, int plane_stride, int row, const float4& vin) {
+  auto put = [&](char* plane0, int plane_stride, int row, const float4& vin, float sc = 1.f, float* mx = nullptr) {
     if (NPL == 2) {
-      float4 v;                               // branch-free: always clamped, the running maximum tells at the end whether it bit
-      rmax = fmaxf(fmaxf(rmax, fabsf(vin.x)), fabsf(vin.y));
-      rmax = fmaxf(fmaxf(rmax, fabsf(vin.z)), fabsf(vin.w));
-      v.x = __builtin_amdgcn_fmed3f(vin.x, -kF16Lim, kF16Lim); v.y = __builtin_amdgcn_fmed3f(vin.y, -kF16Lim, kF16Lim);
-      v.z = __builtin_amdgcn_fmed3f(vin.z, -kF16Lim, kF16Lim); v.w = __builtin_amdgcn_fmed3f(vin.w, -kF16Lim, kF16Lim);
+      // the row's power of two first (exact).  Nothing is clamped: `mx` keeps the largest SCALED magnitude this thread has split,
+      // and a value beyond the f16 range (possible only under an estimated scale) makes the workgroup repeat the tile
+      const float4 v = make_float4(vin.x * sc, vin.y * sc, vin.z * sc, vin.w * sc);
+      if (mx) { *mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), *mx); *mx = fmaxf(fmaxf(fabsf(v.z), fabsf(v.w)), *mx); }
       unsigned h0, l0, h1, l1;
       split2h(v.x, v.y, h0, l0); split2h(v.z, v.w, h1, l1);
       char* p = plane0 + row * RB + 8 * kq;
@@ -459,10 +482,9 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
           const float4 b0 = gzb[0], b1 = gzb[1], b2 = gzb[2];
           const float4 gv = make_float4(za0 * b0.x + za1 * b1.x + za2 * b2.x, za0 * b0.y + za1 * b1.y + za2 * b2.y,
                                         za0 * b0.z + za1 * b1.z + za2 * b2.z, za0 * b0.w + za1 * b1.w + za2 * b2.w);
-          put(base, Cfg::kPlaneA, r0, gv);
+          put(base, Cfg::kPlaneA, r0, gv);      // (scaled through gza; bounded by the row's ||Z'Z||_F)
         } else if (PLA) put_planes(base, Cfg::kPlaneA, r0 + RPP * i, pa[slot][PLA ? i : 0]);
-        else if (AWD) put_words(base, Cfg::kPlaneA, r0 + RPP * i, ra[slot][i]);
-        else put(base, Cfg::kPlaneA, r0 + RPP * i, ra[slot][i]);
+        else put(base, Cfg::kPlaneA, r0 + RPP * i, ra[slot][i], asc[i], &amx[i]);
       }
 #pragma unroll
     for (int i = 0; i < NPW; i++)
@@ -479,9 +501,10 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
   // (phase_sleep bits 16..: which blocks are delayed -- 0: the second half of a 512-block round, 1: every second block of an XCD)
   if ((a.phase_sleep & 0xFFFF) > 0 && (((a.phase_sleep >> 16) == 0 ? (blockIdx.x >> 8) : (blockIdx.x >> 3)) & 1))
     for (int q = 0; q < (a.phase_sleep & 0xFFFF); q++) __builtin_amdgcn_s_sleep(1);
-  if (GRAM && a.rowdiv_out && tile_n == 0) {
+  if (GRAM && (SCL || (a.rowdiv_out && tile_n == 0))) {
     // fn[m] = ||Z'Z||_F + 1 = ||Z Z'||_F + 1: six 32-term dot products of the row's three vectors, a quarter (eight columns)
-    // per staging thread of the row, folded over the four adjacent lanes; written by the first column tile only
+    // per staging thread of the row, folded over the four adjacent lanes; written by the first column tile only.  The norm
+    // bounds every entry of the row's Gram matrix: it is also what the two-piece form scales the generated operand by.
     float c[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -500,16 +523,14 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
       c[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c[k]), 0xB1, 0xF, 0xF, true));
       c[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c[k]), 0x4E, 0xF, 0xF, true));
     }
-    if (kq == 0 && m0 + r0 < a.M)
-      a.rowdiv_out[m0 + r0] = sqrtf((c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + 2.f * (c[3] * c[3] + c[4] * c[4] + c[5] * c[5])) + 1.0f;
+    const float frob = sqrtf((c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + 2.f * (c[3] * c[3] + c[4] * c[4] + c[5] * c[5]));
+    if (kq == 0 && m0 + r0 < a.M && a.rowdiv_out && tile_n == 0) a.rowdiv_out[m0 + r0] = frob + 1.0f;
+    if (SCL) {
+      asc[0] = pow2_scale(frob, kScaleExact);
+      if (kq == 0) rs_sh[r0] = pow2_inv(asc[0]);
+    }
   }
-  if (GRAM) gload_gram();
-  gload(0, 0);
-  sstore(0, 0);
-  __syncthreads();
-  if (GRAM && nk > 1) gload_gram();
-  if (nk > 1) gload(0, BKT);
-  if (PF == 2 && nk > 2) gload(1, 2 * BKT);
+  if (SCL && t == 0) redo_sh = 0;
   const int li = lane & 31, lh = lane >> 5;
   const int aoff = (wm * 32 * TM + li) * RB + 16 * lh;        // this lane's 8 bf16 of k-step 0; k-step 1 is 32 bytes on
   const int boff = NPL * Cfg::kPlaneA + (wn * 32 * TN + li) * RB + 16 * lh;
@@ -578,15 +599,65 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
     }
     __syncthreads();
   };
-  if (PF == 1) {
-    for (int kt = 0; kt < nk; kt++) body(kt, 0);
-  } else {
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) { body(kt, 0); body(kt + 1, 1); }
-    if (kt < nk) body(kt, 0);
+  constexpr bool EST = SCL && !GRAM && !PLA;  // loaded f32 activation rows: scaled by an estimate, repeated with the exact maxima if it fell short
+  for (int attempt = 0;; attempt++) {
+    if (GRAM) { ga = 0; gb = 0; gload_gram(); }
+    gload(0, 0);
+    if (EST && attempt == 0) {
+#pragma unroll
+      for (int i = 0; i < NPA; i++) {
+        const float4 v0 = ra[0][i];
+        float est = fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w)));
+        if (nk > 2) {                          // two more samples of the row: its middle and its last k-tile
+          const float4 v1 = *reinterpret_cast<const float4*>(arow_g[i] + (nk >> 1) * BKT), v2 = *reinterpret_cast<const float4*>(arow_g[i] + (nk - 1) * BKT);
+          est = fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), est); est = fmaxf(fmaxf(fabsf(v1.z), fabsf(v1.w)), est);
+          est = fmaxf(fmaxf(fabsf(v2.x), fabsf(v2.y)), est); est = fmaxf(fmaxf(fabsf(v2.z), fabsf(v2.w)), est);
+        }
+        asc[i] = pow2_scale(quad_max(est), kScaleEstimate);
+      }
+    }
+    if (EST && kq == 0) {
+#pragma unroll
+      for (int i = 0; i < NPA; i++) if (BMT % RPP == 0 || r0 + RPP * i < BMT) rs_sh[r0 + RPP * i] = pow2_inv(asc[i]);
+    }
+    sstore(0, 0);
+    __syncthreads();
+    if (GRAM && nk > 1) gload_gram();
+    if (nk > 1) gload(0, BKT);
+    if (PF == 2 && nk > 2) gload(1, 2 * BKT);
+    if (PF == 1) {
+      for (int kt = 0; kt < nk; kt++) body(kt, 0);
+    } else {
+      int kt = 0;
+      for (; kt + 1 < nk; kt += 2) { body(kt, 0); body(kt + 1, 1); }
+      if (kt < nk) body(kt, 0);
+    }
+    if (!EST || attempt == 1) break;
+    {
+      bool over = false;
+#pragma unroll
+      for (int i = 0; i < NPA; i++) over = over || !(amx[i] <= kF16Lim);
+      if (over) redo_sh = 1u;
+    }
+    __syncthreads();
+    if (redo_sh == 0u) break;                 // (block-uniform) the usual exit: no scaled value left the f16 range
+    // the rare path: exact maxima of the rows this thread stages (its quarter of every k-tile, read again), then once more
+#pragma unroll
+    for (int i = 0; i < NPA; i++) {
+      float tm = 0.f;
+      for (int kt = 0; kt < nk; kt++) {
+        const float4 x = *reinterpret_cast<const float4*>(arow_g[i] + kt * BKT);
+        tm = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), tm); tm = fmaxf(fmaxf(fabsf(x.z), fabsf(x.w)), tm);
+      }
+      asc[i] = pow2_scale(quad_max(tm), kScaleExact);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) { acc[i][j][e] = 0.f; cor[i][j][e] = 0.f; }
   }
-  if (NPL == 2 && rmax > kF16Lim && a.range_events) atomicAdd(a.range_events, 1u);
-  float rmax2 = 0.f;                          // largest value this thread encodes in its epilogue (CWD)
   if (FLAGS & EPI_EQUIV) {
     // Equivariant epilogue.  The accumulators hold TRANSPOSED 32 x 32 tiles: lane = node (column li of the tile), registers
     // = W rows q (row (e & 3) + 8 (e >> 2) + 4 lh); one tile = mat[node][q][c] for ONE c (output columns ordered c * 32 + q).
@@ -605,6 +676,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
     const int mloc = wm * 32 + li, m = m0 + mloc;
     const bool ok = m < a.M;
     const float rd = (FLAGS & EPI_ROWDIV) ? 1.0f / (ok ? a.rowdiv[m] : 1.f) : 1.f;
+    const float rsn = SCL ? rs_sh[mloc] : 1.f;
 #pragma unroll
     for (int tj = 0; tj < TN; tj++) {
       const int cidx = (n0 + wn * 32 * TN + tj * 32) >> 5;
@@ -613,10 +685,12 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
       for (int g4 = 0; g4 < 4; g4++) {
         const int q0 = 8 * g4 + 4 * lh;
         const float4 b4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + cidx * 32 + q0) : make_float4(0, 0, 0, 0);
-        const float v0 = fin(acc[0][tj][4 * g4 + 0], cor[0][tj][4 * g4 + 0]) + b4.x;
-        const float v1 = fin(acc[0][tj][4 * g4 + 1], cor[0][tj][4 * g4 + 1]) + b4.y;
-        const float v2 = fin(acc[0][tj][4 * g4 + 2], cor[0][tj][4 * g4 + 2]) + b4.z;
-        const float v3 = fin(acc[0][tj][4 * g4 + 3], cor[0][tj][4 * g4 + 3]) + b4.w;
+        float4 u4 = make_float4(rsn, rsn, rsn, rsn);                 // undo the row scales of A (node) and W (rows c * 32 + q)
+        if (SCL && a.wscale) { const float4 w4 = *reinterpret_cast<const float4*>(a.wscale + cidx * 32 + q0); u4 = make_float4(rsn * w4.x, rsn * w4.y, rsn * w4.z, rsn * w4.w); }
+        const float v0 = fin(acc[0][tj][4 * g4 + 0], cor[0][tj][4 * g4 + 0]) * u4.x + b4.x;
+        const float v1 = fin(acc[0][tj][4 * g4 + 1], cor[0][tj][4 * g4 + 1]) * u4.y + b4.y;
+        const float v2 = fin(acc[0][tj][4 * g4 + 2], cor[0][tj][4 * g4 + 2]) * u4.z + b4.z;
+        const float v3 = fin(acc[0][tj][4 * g4 + 3], cor[0][tj][4 * g4 + 3]) * u4.w + b4.w;
 #pragma unroll
         for (int sx = 0; sx < 3; sx++) {
           const float4 z4 = *reinterpret_cast<const float4*>(zs + mloc * ZS + sx * 32 + q0);
@@ -634,10 +708,11 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
   }
   if (FLAGS & EPI_TR) {
     // Row-wise stores of transposed tiles: lane = row, registers = columns 8 g + 4 lh + (0..3) of the tile -- one float4 per g
-    static_assert(!(FLAGS & EPI_TR) || (TM == 1 && !(FLAGS & (EPI_ACC2 | EPI_ZSPLIT | EPI_LN | EPI_EQUIV)) && !CWD), "EPI_TR: plain / ReLU / row-division epilogues");
+    static_assert(!(FLAGS & EPI_TR) || (TM == 1 && !(FLAGS & (EPI_ACC2 | EPI_ZSPLIT | EPI_LN | EPI_EQUIV))), "EPI_TR: plain / ReLU / row-division epilogues");
     const int m = m0 + wm * 32 + li;
     if (m < a.M) {
       const float rd = (FLAGS & EPI_ROWDIV) ? 1.0f / a.rowdiv[m] : 1.f;
+      const float rsn = SCL ? rs_sh[wm * 32 + li] : 1.f;
 #pragma unroll
       for (int tj = 0; tj < TN; tj++) {
         const int nb = n0 + wn * 32 * TN + tj * 32 + 4 * lh;
@@ -646,8 +721,10 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
           const int n = nb + 8 * g;
           if (n + 3 >= a.N) continue;                  // (N is a multiple of 4 for every product of the forward)
           const float4 b4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + n) : make_float4(0, 0, 0, 0);
-          float4 v = make_float4(fin(acc[0][tj][4 * g + 0], cor[0][tj][4 * g + 0]) + b4.x, fin(acc[0][tj][4 * g + 1], cor[0][tj][4 * g + 1]) + b4.y,
-                                 fin(acc[0][tj][4 * g + 2], cor[0][tj][4 * g + 2]) + b4.z, fin(acc[0][tj][4 * g + 3], cor[0][tj][4 * g + 3]) + b4.w);
+          float4 u4 = make_float4(rsn, rsn, rsn, rsn);
+          if (SCL && a.wscale) { const float4 w4 = *reinterpret_cast<const float4*>(a.wscale + n); u4 = make_float4(rsn * w4.x, rsn * w4.y, rsn * w4.z, rsn * w4.w); }
+          float4 v = make_float4(fin(acc[0][tj][4 * g + 0], cor[0][tj][4 * g + 0]) * u4.x + b4.x, fin(acc[0][tj][4 * g + 1], cor[0][tj][4 * g + 1]) * u4.y + b4.y,
+                                 fin(acc[0][tj][4 * g + 2], cor[0][tj][4 * g + 2]) * u4.z + b4.z, fin(acc[0][tj][4 * g + 3], cor[0][tj][4 * g + 3]) * u4.w + b4.w);
           if (FLAGS & EPI_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
           if (FLAGS & EPI_ROWDIV) v = make_float4(v.x * rd, v.y * rd, v.z * rd, v.w * rd);
           *reinterpret_cast<float4*>(a.C + (size_t)m * a.ldc + n) = v;
@@ -667,9 +744,12 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
 #pragma unroll
     for (int tj = 0; tj < 2; tj++) {
       const float bvv = a.bias ? a.bias[wn * 64 + tj * 32 + li] : 0.f;
+      const float wsn = (SCL && a.wscale) ? a.wscale[wn * 64 + tj * 32 + li] : 1.f;
 #pragma unroll
       for (int e = 0; e < 16; e++) {
-        float v = fin(acc[0][tj][e], cor[0][tj][e]) + bvv;
+        float v = fin(acc[0][tj][e], cor[0][tj][e]);
+        if (SCL) v *= rs_sh[wm * 32 + 4 * lh + (e & 3) + 8 * (e >> 2)] * wsn;
+        v += bvv;
         if (FLAGS & EPI_RELU) v = fmaxf(v, 0.f);
         acc[0][tj][e] = v;
       }
@@ -722,17 +802,15 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
         if (m < a.M) {
           const float y = acc[0][tj][e] * part[e] * lw + lb;
           a.ln_io[(size_t)m * a.ln_ld + n] = y;
-          if (CWD) reinterpret_cast<unsigned*>(a.C)[(size_t)m * a.ldc + n] = enc_word(y, rmax2);
         }
       }
     }
-    if (CWD && rmax2 > kF16Lim && a.range_events) atomicAdd(a.range_events, 1u);
     return;
   }
 #pragma unroll
   for (int ti = 0; ti < TM; ti++) {
     const int mb = m0 + wm * 32 * TM + ti * 32 + 4 * lh;
-    float rdiv[16];
+    float rdiv[16], rsc[16];
     if (FLAGS & EPI_ROWDIV) {
 #pragma unroll
       for (int e = 0; e < 16; e++) {
@@ -740,11 +818,16 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
         rdiv[e] = 1.0f / ((m < a.M) ? a.rowdiv[m] : 1.f);
       }
     }
+    if (SCL) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) rsc[e] = rs_sh[wm * 32 * TM + ti * 32 + 4 * lh + (e & 3) + 8 * (e >> 2)];
+    }
 #pragma unroll
     for (int tj = 0; tj < TN; tj++) {
       const int n = n0 + wn * 32 * TN + tj * 32 + li;
       if (n >= a.N) continue;
       const float bvv = a.bias ? a.bias[n] : 0.f;
+      const float wsn = (SCL && a.wscale) ? a.wscale[n] : 1.f;
       float old2[16];
       if (FLAGS & EPI_ACC2) {
 #pragma unroll
@@ -757,7 +840,9 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
       for (int e = 0; e < 16; e++) {
         const int m = mb + (e & 3) + 8 * (e >> 2);
         if (m >= a.M) continue;
-        float v = fin(acc[ti][tj][e], cor[ti][tj][e]) + bvv;
+        float v = fin(acc[ti][tj][e], cor[ti][tj][e]);
+        if (SCL) v *= rsc[e] * wsn;
+        v += bvv;
         if (FLAGS & EPI_RELU) v = fmaxf(v, 0.f);
         if (FLAGS & EPI_ROWDIV) v = v * rdiv[e];
         if (FLAGS & EPI_ZSPLIT) {               // stacked projections: see the enum's comment
@@ -765,27 +850,43 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
           else if (n >= 32 && n < 62) a.C2[(size_t)m * 32 + (n - 32)] = v;
           continue;
         }
-        if (CWD) reinterpret_cast<unsigned*>(a.C)[(size_t)m * a.ldc + n] = enc_word(v, rmax2);
-        else a.C[(size_t)m * a.ldc + n] = v;
+        a.C[(size_t)m * a.ldc + n] = v;
         if (FLAGS & EPI_ACC2) a.C2[(size_t)m * a.ldc2 + n] = old2[e] + v;
       }
     }
   }
-  if (CWD && rmax2 > kF16Lim && a.range_events) atomicAdd(a.range_events, 1u);
 }
 
-// f32 [n] -> words [n] (weights of the two-piece form: once per forward behind the packer, or once per weight upload)
-__global__ __launch_bounds__(256) void k_encode_words(const float* __restrict__ src, unsigned* __restrict__ dst, long long n, unsigned* events) {
-  float rmax = 0.f;
-  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 1024) {
-    if (i + 3 < n) {
-      const float4 v = *reinterpret_cast<const float4*>(src + i);
-      *reinterpret_cast<uint4*>(dst + i) = make_uint4(enc_word(v.x, rmax), enc_word(v.y, rmax), enc_word(v.z, rmax), enc_word(v.w, rmax));
-    } else {
-      for (long long j = i; j < n; j++) dst[j] = enc_word(src[j], rmax);
-    }
+// Weights of the two-piece form: every row of every product matrix of the flat weight buffer, scaled by the power of two that
+// brings its largest magnitude to 2^14 .. 2^15 and cut into words (once per forward, behind the packer).  One wave per row;
+// wsc[first_row + r] receives the INVERSE scale of row r (what the consumer's epilogue multiplies by).
+struct EncMat { long long off; int rows, K, first_row; };          // K % 4 == 0, K <= 1024; rows of the matrix contiguous in `w`
+__global__ __launch_bounds__(256) void k_encode_rows(const float* __restrict__ w, unsigned* __restrict__ ww, float* __restrict__ wsc,
+                                                     const EncMat* __restrict__ mats, int n_mats, int total_rows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= total_rows) return;
+  int mi = 0;
+  while (mi + 1 < n_mats && mats[mi + 1].first_row <= row) mi++;          // (wave-uniform; a few dozen matrices)
+  const EncMat mt = mats[mi];
+  const long long base = mt.off + (long long)(row - mt.first_row) * mt.K;
+  const int nq = mt.K >> 2;
+  float4 v[4];
+  float mx = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int i = lane + 64 * q;
+    v[q] = i < nq ? *reinterpret_cast<const float4*>(w + base + 4 * i) : make_float4(0, 0, 0, 0);
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[q].x), fabsf(v[q].y)), fmaxf(fabsf(v[q].z), fabsf(v[q].w))));
   }
-  if (rmax > kF16Lim && events) atomicAdd(events, 1u);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  const float sc = pow2_scale(mx, kScaleExact);
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int i = lane + 64 * q;
+    if (i < nq) *reinterpret_cast<uint4*>(ww + base + 4 * i) = make_uint4(enc_word(v[q].x * sc), enc_word(v[q].y * sc), enc_word(v[q].z * sc), enc_word(v[q].w * sc));
+  }
+  if (lane == 0) wsc[row] = pow2_inv(sc);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -800,7 +901,7 @@ __global__ __launch_bounds__(1024) void k_gemm4(GemmArgs a) {
   constexpr int BMT = 128, BNT = 128, RB = Cfg::kRowBytes, TN = 2;
   constexpr int QPR = BKT / 4, RPP = 512 / QPR, NP = 128 / RPP;   // producer staging: NP float4 of A and of W per thread
   constexpr int KS = BKT / 16;
-  extern __shared__ float gemm_lds[];
+  extern __shared__ __attribute__((aligned(16))) float gemm_lds[];     // (aligned: static LDS precedes it)
   char* lds = reinterpret_cast<char*>(gemm_lds);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const bool producer = wave >= 8;              // wave-uniform

@@ -155,9 +155,7 @@ __global__ void k_stack_proj(const float* __restrict__ Wp, const float* __restri
 constexpr int PACK_CHUNK = 4096;
 constexpr int PACK_CHUNK_MM = 256;      // matrix-product segments: one output (a dot product) per thread
 __global__ __launch_bounds__(256) void k_pack(const sgrl_pack_seg* __restrict__ segs, const int2* __restrict__ chunks,
-                                              const unsigned short* __restrict__ tri, float* w, unsigned* ww, unsigned* events) {
-  // ww: the same buffer as pre-split words (gemm_f32.h enc_word) -- the W operand of the two-piece tile products
-  float rmax = 0.f;
+                                              const unsigned short* __restrict__ tri, float* w) {
   const int2 ch = chunks[blockIdx.x];
   const sgrl_pack_seg sg = segs[ch.x];
   const float* s0 = static_cast<const float*>(sg.src0);
@@ -221,9 +219,7 @@ __global__ __launch_bounds__(256) void k_pack(const sgrl_pack_seg* __restrict__ 
       default: break;
     }
     w[sg.dst + i] = v;
-    if (ww) ww[sg.dst + i] = sgrl_gemm::enc_word(v, rmax);
   }
-  if (ww && rmax > sgrl_gemm::kF16Lim && events) atomicAdd(events, 1u);
 }
 
 // relation bias per morphology: relb[off + (h*L + i)*L + j] = rel_encoder(relation[i,j])[h]
@@ -448,9 +444,7 @@ __global__ __launch_bounds__(128) void k_equiv(const float* __restrict__ T, cons
 // axis_k[s] * vec[s]); 32 lanes per node
 __global__ __launch_bounds__(128) void k_head_out(const float* __restrict__ T, const float* __restrict__ wdec,
                                                   const float* __restrict__ obs, int obs_ld, NodeTab nt, float* act, int act_ld,
-                                                  float max_action, int N, const unsigned* events, unsigned* events_host) {
-  // last kernel of a forward: hand the clamp counter to the pinned host word the handle polls (sgrl_set_range_events_seen)
-  if (blockIdx.x == 0 && threadIdx.x == 0 && events_host) __hip_atomic_store(events_host, *events, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                                  float max_action, int N) {
   const int n = blockIdx.x * 4 + (threadIdx.x >> 5), c = threadIdx.x & 31;
   if (n >= N) return;
   float vec[3];
@@ -471,9 +465,7 @@ __global__ __launch_bounds__(128) void k_head_out(const float* __restrict__ T, c
 
 // critic head: q[env][limb] = (w . c[n] + b) / fn[n]   (reference SEActor.py:279-281 with output_size = 1); one wave per node
 __global__ __launch_bounds__(256) void k_q_head(const float* __restrict__ c, const float* __restrict__ w, const float* __restrict__ b,
-                                                const float* __restrict__ fn, NodeTab nt, float* q, int q_ld, int N,
-                                                const unsigned* events, unsigned* events_host) {
-  if (blockIdx.x == 0 && threadIdx.x == 0 && events_host) __hip_atomic_store(events_host, *events, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                                const float* __restrict__ fn, NodeTab nt, float* q, int q_ld, int N) {
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (n >= N) return;
   const float* row = c + (size_t)n * 256;
@@ -530,11 +522,11 @@ struct sgrl_set {
   int stop_after = -1;         // parity probes: leave run_forward after this stage (sgrl_set_debug_stop_after)
   int small_nodes = -1;        // batches of at most this many nodes take the small-batch products; -1: SGRL_SET_SMALL_NODES / default
   int gemm_form = 0;           // SGRL_SET_FORM_* of the tile products; 0: SGRL_SET_GEMM / default (sgrl_set_gemm_form)
-  unsigned* d_range_events = nullptr;   // operands the two-piece f16 form had to clamp (sgrl_set_range_events)
-  // the same counter as the LAST kernel of every forward leaves it in pinned host memory: the host reads it without touching the
-  // device (sgrl_set_range_events_seen), so the module surface notices clamped operands by itself
-  unsigned* h_events = nullptr;         // host address
-  unsigned* d_events_host = nullptr;    // device address of the same word
+  // two-piece products: the product matrices of the flat buffer, cut into row-scaled words by k_encode_rows behind every k_pack
+  sgrl_gemm::EncMat* d_enc = nullptr;   // [n_enc] (offset, rows, K, first row)
+  int n_enc = 0, enc_rows = 0;
+  float* wsc = nullptr;                 // [enc_rows] inverse row scales
+  std::vector<std::pair<int64_t, int>> enc_index;   // flat offset of a matrix -> its first row in wsc
   // live weights (sgrl_set_bind_params)
   bool live = false;
   float* wflat = nullptr;
@@ -620,11 +612,13 @@ bool gemm_use_split() {
   return v;
 }
 // Split form of the forward in flight (set by run_forward from its handle): SGRL_SET_FORM_F16X3 = two f16 pieces, three matrix
-// instructions per product block (default; operands beyond +-65 000 are clamped and counted in `events`), SGRL_SET_FORM_BF16X6 =
+// instructions per product block (default; every operand row pre-scaled by a power of two: float32's range), SGRL_SET_FORM_BF16X6 =
 // three bf16 pieces, six instructions, f32's exponent range (gemm_f32.h).  SGRL_SET_GEMM=bf16x6 makes the latter the default.
 struct GemmCtx {
-  int form = SGRL_SET_FORM_F16X3; unsigned* events = nullptr;
-  const float* w_base = nullptr; const unsigned* w_words = nullptr;   // flat weight buffer and its pre-split twin (k_pack)
+  int form = SGRL_SET_FORM_F16X3;
+  const float* w_base = nullptr; const unsigned* w_words = nullptr;   // flat weight buffer and its row-scaled, pre-split twin (k_encode_rows)
+  const float* wsc = nullptr;                                         // inverse row scales of the twin's matrices ...
+  const std::vector<std::pair<int64_t, int>>* enc_index = nullptr;    // ... found by a matrix' flat offset
 };
 thread_local GemmCtx g_gemm;
 int gemm_default_form() {
@@ -632,10 +626,17 @@ int gemm_default_form() {
   return v;
 }
 // arguments of a two-piece launch: the event counter, and W taken from the pre-split twin of the weight buffer
-GemmArgs with_events(const GemmArgs& a) {
+// inverse row scales of the product matrix that starts at W (null: W is not a whole matrix of the table -> unscaled words do not exist)
+const float* wsc_of(const float* W) {
+  if (!g_gemm.enc_index) return nullptr;
+  const int64_t off = W - g_gemm.w_base;
+  for (const auto& e : *g_gemm.enc_index) if (e.first == off) return g_gemm.wsc + e.second;
+  return nullptr;
+}
+GemmArgs with_words(const GemmArgs& a) {
   GemmArgs b = a;
-  b.range_events = g_gemm.events;
   b.W = reinterpret_cast<const float*>(g_gemm.w_words + (a.W - g_gemm.w_base));
+  b.wscale = wsc_of(a.W);
   return b;
 }
 template <int F> struct GemmKernels {
@@ -661,7 +662,7 @@ template <int F> struct GemmKernels {
     if (a.N <= 64 || (a.K % 32) != 0) {
       hipLaunchKernelGGL(kNarrow, dim3(((a.M + 127) / 128) * ((a.N + 63) / 64)), dim3(256), kNarrowLds, st, a);
     } else if (gemm_use_split()) {
-      if (g_gemm.form == SGRL_SET_FORM_F16X3) hipLaunchKernelGGL(kSplitH, dim3(tiles128), dim3(512), kSplitHLds, st, with_events(a));
+      if (g_gemm.form == SGRL_SET_FORM_F16X3) hipLaunchKernelGGL(kSplitH, dim3(tiles128), dim3(512), kSplitHLds, st, with_words(a));
       else hipLaunchKernelGGL(kSplit, dim3(tiles128), dim3(512), kSplitLds, st, a);
     } else if (tiles128 < 512) {
       hipLaunchKernelGGL(kNarrow, dim3(((a.M + 127) / 128) * ((a.N + 63) / 64)), dim3(256), kNarrowLds, st, a);
@@ -686,7 +687,7 @@ int launch_gemm_equiv(hipStream_t st, const float* A, int lda, const float* W, i
   if (K % 32 != 0 || (lda & 3) || (ldw & 3)) return sfail(SGRL_ERR_ARG, "gemm_equiv: K must be a multiple of 32 and rows 16-byte aligned");
   GemmArgs a{A, lda, W, ldw, bias, nullptr, 0, M, 1024, K, EPI_ROWDIV | EPI_EQUIV, rowdiv, nullptr, 0};
   a.zq = zq; a.tout = tout;
-  if (g_gemm.form == SGRL_SET_FORM_F16X3) hipLaunchKernelGGL(kGemmEquivH, dim3(((M + 127) / 128) * 8), dim3(512), GemmKernels<0>::kSplitLds, st, with_events(a));
+  if (g_gemm.form == SGRL_SET_FORM_F16X3) hipLaunchKernelGGL(kGemmEquivH, dim3(((M + 127) / 128) * 8), dim3(512), GemmKernels<0>::kSplitLds, st, with_words(a));
   else hipLaunchKernelGGL(kGemmEquiv, dim3(((M + 127) / 128) * 8), dim3(512), GemmKernels<0>::kSplitLds, st, a);
   return SGRL_OK;
 }
@@ -698,7 +699,7 @@ int launch_gemm_gram(hipStream_t st, const float* zc, const float* W, const floa
   if (N % 128 != 0) return sfail(SGRL_ERR_ARG, "gemm_gram: N must be a multiple of 128");
   GemmArgs a{zc, 96, W, GK, bias, C, ldc, M, N, GK, EPI_RELU, nullptr, nullptr, 0};
   a.rowdiv_out = fn;
-  if (g_gemm.form == SGRL_SET_FORM_F16X3) hipLaunchKernelGGL(kGemmGramH, dim3(((M + 127) / 128) * (N / 128)), dim3(512), GemmKernels<0>::kSplitHLds, st, with_events(a));
+  if (g_gemm.form == SGRL_SET_FORM_F16X3) hipLaunchKernelGGL(kGemmGramH, dim3(((M + 127) / 128) * (N / 128)), dim3(512), GemmKernels<0>::kSplitHLds, st, with_words(a));
   else hipLaunchKernelGGL(kGemmGram, dim3(((M + 127) / 128) * (N / 128)), dim3(512), GemmKernels<0>::kSplitLds, st, a);
   return SGRL_OK;
 }
@@ -711,7 +712,7 @@ int launch_gemm_ln(hipStream_t st, const float* A, int lda, const float* W, int 
   if (K % 32 != 0 || (lda & 3) || (ldw & 3)) return sfail(SGRL_ERR_ARG, "gemm_ln: K must be a multiple of 32 and rows 16-byte aligned");
   GemmArgs a{A, lda, W, ldw, bias, nullptr, 0, M, 128, K, EPI_ROWDIV | EPI_LN, rowdiv, nullptr, 0};
   a.ln_io = ln_io; a.ln_ld = ln_ld; a.ln_w = ln_w; a.ln_b = ln_b;
-  if (g_gemm.form == SGRL_SET_FORM_F16X3) hipLaunchKernelGGL(kGemmLnH, dim3((M + 127) / 128), dim3(512), GemmKernels<0>::kSplitHLds, st, with_events(a));
+  if (g_gemm.form == SGRL_SET_FORM_F16X3) hipLaunchKernelGGL(kGemmLnH, dim3((M + 127) / 128), dim3(512), GemmKernels<0>::kSplitHLds, st, with_words(a));
   else hipLaunchKernelGGL(kGemmLn, dim3((M + 127) / 128), dim3(512), GemmKernels<0>::kSplitLds, st, a);
   return SGRL_OK;
 }
@@ -744,9 +745,11 @@ constexpr auto kSiteH1 = k_chain<1, 128, 0, 1>;                        // head (
 constexpr auto kSiteH2 = k_chain<1, 128, 0, 2>;                        // head (actor): ... Z, Z2
 constexpr auto kChainLn = k_chain<0, 256, EPI_ROWDIV | EPI_LN, 0>;     // linear1 -> ReLU -> linear2 / fn -> residual + norm2
 constexpr auto kChainNg = k_chain<0, 128, 0, 0>;                       // linear1_ng -> ReLU -> linear2_ng
+constexpr auto kChainPlain = k_chain<0, 256, 0, 0>;                    // (test hook: the plain pair at hidden width 256)
 bool chain_raise_lds_limits() {
   const void* ks[] = {reinterpret_cast<const void*>(kSiteA), reinterpret_cast<const void*>(kSiteF), reinterpret_cast<const void*>(kSiteH1),
-                      reinterpret_cast<const void*>(kSiteH2), reinterpret_cast<const void*>(kChainLn), reinterpret_cast<const void*>(kChainNg)};
+                      reinterpret_cast<const void*>(kSiteH2), reinterpret_cast<const void*>(kChainLn), reinterpret_cast<const void*>(kChainNg),
+                      reinterpret_cast<const void*>(kChainPlain)};
   for (const void* k : ks)
     if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, sgrl_gemm::kChainLds) != hipSuccess) return false;
   return true;
@@ -758,7 +761,9 @@ int launch_site(hipStream_t st, const float* X, int ldx, int Kp, const float* Wp
   if (Kp % 16 != 0 || (ldx & 3) || (hid != 256 && hid != 128)) return sfail(SGRL_ERR_ARG, "site: K must be a multiple of 16, rows 16-byte aligned, hidden width 128 or 256");
   ChainArgs a{};
   a.A = zc; a.W1 = words_of(W1); a.ldw1 = GK; a.b1 = b1; a.W2 = words_of(W2); a.ldw2 = hid; a.b2 = b2; a.C = C; a.ldc = ldc; a.M = M; a.K1 = GK;
-  a.fn_out = fn; a.X = X; a.ldx = ldx; a.Kp = Kp; a.Wp = words_of(Wp); a.zc = zc; a.z2 = z2; a.range_events = g_gemm.events;
+  a.fn_out = fn; a.X = X; a.ldx = ldx; a.Kp = Kp; a.Wp = words_of(Wp); a.zc = zc; a.z2 = z2;
+  a.ws1 = wsc_of(W1); a.ws2 = wsc_of(W2); a.wsp = wsc_of(Wp);
+  if (!a.ws1 || !a.ws2 || !a.wsp) return sfail(SGRL_ERR_ARG, "site: a weight operand is not a matrix of the row-scale table");
   const dim3 grid((M + sgrl_gemm::kChainRows - 1) / sgrl_gemm::kChainRows);
   if (hid == 256) {
     if (z2) hipLaunchKernelGGL(kSiteF, grid, dim3(512), sgrl_gemm::kChainLds, st, a);
@@ -775,7 +780,9 @@ int launch_chain_ln(hipStream_t st, const float* A, int lda, int K1, const float
   if (K1 % 16 != 0 || (lda & 3)) return sfail(SGRL_ERR_ARG, "chain: K must be a multiple of 16 and rows 16-byte aligned");
   ChainArgs a{};
   a.A = A; a.lda = lda; a.W1 = words_of(W1); a.ldw1 = K1; a.b1 = b1; a.W2 = words_of(W2); a.ldw2 = 256; a.b2 = b2; a.M = M; a.K1 = K1;
-  a.rowdiv = rowdiv; a.ln_io = ln_io; a.ln_ld = ln_ld; a.ln_w = ln_w; a.ln_b = ln_b; a.range_events = g_gemm.events;
+  a.rowdiv = rowdiv; a.ln_io = ln_io; a.ln_ld = ln_ld; a.ln_w = ln_w; a.ln_b = ln_b;
+  a.ws1 = wsc_of(W1); a.ws2 = wsc_of(W2);
+  if (!a.ws1 || !a.ws2) return sfail(SGRL_ERR_ARG, "chain: a weight operand is not a matrix of the row-scale table");
   hipLaunchKernelGGL(kChainLn, dim3((M + sgrl_gemm::kChainRows - 1) / sgrl_gemm::kChainRows), dim3(512), sgrl_gemm::kChainLds, st, a);
   return SGRL_OK;
 }
@@ -785,7 +792,8 @@ int launch_chain_ng(hipStream_t st, const float* A, int lda, int K1, const float
   if (K1 % 16 != 0 || (lda & 3)) return sfail(SGRL_ERR_ARG, "chain: K must be a multiple of 16 and rows 16-byte aligned");
   ChainArgs a{};
   a.A = A; a.lda = lda; a.W1 = words_of(W1); a.ldw1 = K1; a.b1 = b1; a.W2 = words_of(W2); a.ldw2 = 128; a.b2 = b2; a.C = C; a.ldc = ldc; a.M = M;
-  a.K1 = K1; a.range_events = g_gemm.events;
+  a.K1 = K1; a.ws1 = wsc_of(W1); a.ws2 = wsc_of(W2);
+  if (!a.ws1 || !a.ws2) return sfail(SGRL_ERR_ARG, "chain: a weight operand is not a matrix of the row-scale table");
   hipLaunchKernelGGL(kChainNg, dim3((M + sgrl_gemm::kChainRows - 1) / sgrl_gemm::kChainRows), dim3(512), sgrl_gemm::kChainLds, st, a);
   return SGRL_OK;
 }
@@ -865,15 +873,18 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   const int ngf = critic ? 20 : 17;
   g_gemm.form = s->gemm_form ? s->gemm_form : gemm_default_form();
   if (!s->live || !s->wwords) g_gemm.form = SGRL_SET_FORM_BF16X6;   // the two-piece form takes W pre-split by k_pack (bound parameters)
-  g_gemm.events = s->d_range_events;
   g_gemm.w_base = s->w;
   g_gemm.w_words = s->wwords;
+  g_gemm.wsc = s->wsc;
+  g_gemm.enc_index = &s->enc_index;
   NodeTab nt{s->d_node_env, s->d_node_limb, s->d_node_mnode, s->d_trav, s->TM};
   EnvTab et{s->d_env_off, s->d_env_L, s->d_env_relb};
   (void)hipMemsetAsync(act, 0, sizeof(float) * (size_t)s->n_env * act_ld, st);
   if (s->live)           // live weights: flat buffer (and the stacked projection operands in it) rebuilt from the parameters
-    hipLaunchKernelGGL(k_pack, dim3(s->n_chunks), dim3(256), 0, st, s->d_segs, s->d_chunks, s->d_tri, s->wflat,
-                       g_gemm.form == SGRL_SET_FORM_F16X3 ? s->wwords : (unsigned*)nullptr, s->d_range_events);
+    hipLaunchKernelGGL(k_pack, dim3(s->n_chunks), dim3(256), 0, st, s->d_segs, s->d_chunks, s->d_tri, s->wflat);
+  if (s->live && g_gemm.form == SGRL_SET_FORM_F16X3 && gemm_use_split())     // the product matrices as row-scaled words
+    hipLaunchKernelGGL(sgrl_gemm::k_encode_rows, dim3((s->enc_rows + 3) / 4), dim3(256), 0, st, s->wflat, s->wwords, s->wsc, s->d_enc, s->n_enc,
+                       s->enc_rows);
   hipLaunchKernelGGL(k_relbias, dim3(s->n_morph), dim3(256), 0, st, s->d_rel, s->W(SGRL_SET_REL_W), s->W(SGRL_SET_REL_B),
                      s->d_relb, s->d_m_off, s->d_m_L, s->n_morph);
   hipLaunchKernelGGL(k_embed, dim3((N + kEmbedNodes - 1) / kEmbedNodes), dim3(128), 0, st, obs, obs_ld, action, action_ld, ngf, nt,
@@ -926,7 +937,7 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
     }
     GemmArgs a{X, ldx, site_w(site), K, nullptr, s->zc, ZD, N3, z2 ? 64 : 32, K, EPI_ZSPLIT, nullptr, z2, ZD};
     if (g_gemm.form == SGRL_SET_FORM_F16X3 && gemm_use_split())      // 128 x 64 tiles, four waves, W pre-split
-      hipLaunchKernelGGL(kProjH, dim3(((a.M + 127) / 128) * ((a.N + 63) / 64)), dim3(256), kProjHLds, st, with_events(a));
+      hipLaunchKernelGGL(kProjH, dim3(((a.M + 127) / 128) * ((a.N + 63) / 64)), dim3(256), kProjHLds, st, with_words(a));
     else
       GemmKernels<EPI_ZSPLIT>::launch(st, a);
     return SGRL_OK;
@@ -1035,13 +1046,13 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   if (critic) {
     // slots reused by the critic head: DECG = decoder_ng.weight [256], L1M_B = decoder_ng.bias [1]
     hipLaunchKernelGGL(k_q_head, dim3((N + 3) / 4), dim3(256), 0, st, s->cat2, s->W(SGRL_SET_DECG), s->W(SGRL_SET_L1M_B), s->fn,
-                       nt, act, act_ld, N, s->d_range_events, s->d_events_host);
+                       nt, act, act_ld, N);
   } else {
     G(s->cat2, 256, s->W(SGRL_SET_L1M_W), 256, s->W(SGRL_SET_L1M_B), s->t256, 256, N, 256, 256, EPI_RELU);
     rc = equiv_gemm(s->t256, s->W(SGRL_SET_L2M_W), s->W(SGRL_SET_L2M_B));
     if (rc != SGRL_OK) return rc;
     hipLaunchKernelGGL(k_head_out, dim3((N + 3) / 4), dim3(128), 0, st, s->mat, s->W(SGRL_SET_DECG), obs, obs_ld, nt,
-                       act, act_ld, max_action, N, s->d_range_events, s->d_events_host);
+                       act, act_ld, max_action, N);
   }
 #undef GS
 #undef GG
@@ -1099,31 +1110,25 @@ int sgrl_set_create(sgrl_set** out) {
     return sfail(SGRL_ERR_HIP, "cannot create the side stream of the SET actor");
   }
   if (hipMalloc(&s->wstack, sizeof(float) * wstack_floats) != hipSuccess || hipMalloc(&s->d_tri, sizeof(unsigned short) * GK) != hipSuccess ||
-      hipMalloc(&s->d_range_events, sizeof(unsigned)) != hipSuccess || hipMemset(s->d_range_events, 0, sizeof(unsigned)) != hipSuccess ||
-      hipHostMalloc(reinterpret_cast<void**>(&s->h_events), sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
-      hipHostGetDevicePointer(reinterpret_cast<void**>(&s->d_events_host), s->h_events, 0) != hipSuccess ||
       hipMemcpy(s->d_tri, tri.data(), sizeof(unsigned short) * GK, hipMemcpyHostToDevice) != hipSuccess) {
-    if (s->d_range_events) (void)hipFree(s->d_range_events);
-    if (s->h_events) (void)hipHostFree(s->h_events);
     if (s->wstack) (void)hipFree(s->wstack);
     if (s->d_tri) (void)hipFree(s->d_tri);
     delete s;
     *out = nullptr;
     return sfail(SGRL_ERR_HIP, "device allocation failed in sgrl_set_create");
   }
-  *s->h_events = 0;
   *out = s;
   return SGRL_OK;
 }
 
 void sgrl_set_destroy(sgrl_set* s) {
   if (!s) return;
-  if (s->h_events) { (void)hipDeviceSynchronize(); (void)hipHostFree(s->h_events); s->h_events = nullptr; }
   if (s->side) (void)hipStreamSynchronize(s->side);
   free_graphs(s);
   if (s->wstack) (void)hipFree(s->wstack);
   if (s->d_tri) (void)hipFree(s->d_tri);
-  if (s->d_range_events) (void)hipFree(s->d_range_events);
+  if (s->d_enc) (void)hipFree(s->d_enc);
+  if (s->wsc) (void)hipFree(s->wsc);
   if (s->wflat) (void)hipFree(s->wflat);
   if (s->wwords) (void)hipFree(s->wwords);
   if (s->d_segs) (void)hipFree(s->d_segs);
@@ -1192,6 +1197,40 @@ int sgrl_set_bind_params(sgrl_set* s, const sgrl_pack_seg* segs, int n_segs, con
       hipMemcpy(s->d_chunks, chunks.data(), sizeof(int2) * chunks.size(), hipMemcpyHostToDevice) != hipSuccess)
     return sfail(SGRL_ERR_HIP, "device allocation failed in sgrl_set_bind_params");
   s->wflat_floats = total_floats;
+  {
+    // the product matrices of the buffer (slot shapes: include/sgrl_set.h), for k_encode_rows.  A slot the bound network does not
+    // fill (the critic has no linear1_m / linear2_m) is shorter than its matrix and is left out.
+    std::vector<int64_t> bounds(offsets, offsets + n_offsets);
+    bounds.push_back(total_floats);
+    std::sort(bounds.begin(), bounds.end());
+    std::vector<sgrl_gemm::EncMat> mats;
+    s->enc_index.clear();
+    int rows_total = 0;
+    auto add = [&](int64_t off, int rows, int K) {
+      const int64_t next = *std::upper_bound(bounds.begin(), bounds.end(), off);
+      if (next - off < (int64_t)rows * K) return;
+      mats.push_back(sgrl_gemm::EncMat{off, rows, K, rows_total});
+      s->enc_index.emplace_back(off, rows_total);
+      rows_total += rows;
+    };
+    add(offsets[SGRL_SET_L1G_W], 128, GK); add(offsets[SGRL_SET_L2G_W], 128, 128);
+    add(offsets[SGRL_SET_L1NG_W], 128, 160); add(offsets[SGRL_SET_L2NG_W], 128, 128);
+    add(offsets[SGRL_SET_L1M_W], 256, 256); add(offsets[SGRL_SET_L2M_W], 1024, 256);
+    for (int l = 0; l < SGRL_SET_LAYERS; l++) {
+      const int64_t* o = offsets + SGRL_SET_NGLOBAL + l * SGRL_SET_NLAYER;
+      add(o[SGRL_SET_A_LG1_W], 256, GK); add(o[SGRL_SET_A_LG2_W], 128, 256); add(o[SGRL_SET_QKV_W], 768, 256); add(o[SGRL_SET_VG_W], 256, 128);
+      add(o[SGRL_SET_F_LG1_W], 256, GK); add(o[SGRL_SET_F_LG2_W], 128, 256); add(o[SGRL_SET_L3_W], 256, 256); add(o[SGRL_SET_L4_W], 1024, 256);
+      add(o[SGRL_SET_L1_W], 256, 256); add(o[SGRL_SET_L2_W], 128, 256);
+    }
+    for (int k = 0; k < SGRL_SET_NSITES; k++) add(offsets[SGRL_SET_NW + k], 64, k == 6 ? OGLD : 128);
+    if (s->d_enc) (void)hipFree(s->d_enc);
+    if (s->wsc) (void)hipFree(s->wsc);
+    s->d_enc = nullptr; s->wsc = nullptr;
+    s->n_enc = (int)mats.size(); s->enc_rows = rows_total;
+    if (hipMalloc(&s->d_enc, sizeof(sgrl_gemm::EncMat) * mats.size()) != hipSuccess || hipMalloc(&s->wsc, sizeof(float) * rows_total) != hipSuccess ||
+        hipMemcpy(s->d_enc, mats.data(), sizeof(sgrl_gemm::EncMat) * mats.size(), hipMemcpyHostToDevice) != hipSuccess)
+      return sfail(SGRL_ERR_HIP, "device allocation failed in sgrl_set_bind_params (row-scale table)");
+  }
   s->n_chunks = (int)chunks.size();
   s->w = s->wflat;
   std::memcpy(s->off, offsets, sizeof(int64_t) * SGRL_SET_NW);
@@ -1356,18 +1395,21 @@ int sgrl_set_gemm_form(sgrl_set* s, int form) {
   return SGRL_OK;
 }
 
-int sgrl_set_range_events(sgrl_set* s, unsigned* count, int reset) {
-  if (!s || !count) return sfail(SGRL_ERR_ARG, "sgrl_set_range_events: bad argument");
-  // the null stream orders this copy behind the forwards of blocking streams only: callers synchronise their stream first
-  if (hipMemcpy(count, s->d_range_events, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return sfail(SGRL_ERR_HIP, "sgrl_set_range_events: copy failed");
-  if (reset && *count && hipMemset(s->d_range_events, 0, sizeof(unsigned)) != hipSuccess) return sfail(SGRL_ERR_HIP, "sgrl_set_range_events: reset failed");
-  if (reset && s->h_events) *s->h_events = 0;
-  return SGRL_OK;
-}
-
-unsigned sgrl_set_range_events_seen(const sgrl_set* s) {
-  return (s && s->h_events) ? *reinterpret_cast<volatile const unsigned*>(s->h_events) : 0u;
-}
+namespace {
+// a caller-supplied weight matrix as k_encode_rows leaves the bound weights: row-scaled words + inverse scales (test hooks)
+struct TempWords {
+  unsigned* w = nullptr; float* sc = nullptr; sgrl_gemm::EncMat* dm = nullptr;
+  ~TempWords() { if (w) (void)hipFree(w); if (sc) (void)hipFree(sc); if (dm) (void)hipFree(dm); }
+  int make(hipStream_t st, const float* W, int rows, int K) {
+    const sgrl_gemm::EncMat m{0, rows, K, 0};
+    if (hipMalloc(&w, sizeof(unsigned) * (size_t)rows * K) != hipSuccess || hipMalloc(&sc, sizeof(float) * rows) != hipSuccess ||
+        hipMalloc(&dm, sizeof(m)) != hipSuccess || hipMemcpy(dm, &m, sizeof(m), hipMemcpyHostToDevice) != hipSuccess)
+      return sfail(SGRL_ERR_HIP, "debug product: allocation failed");
+    hipLaunchKernelGGL(sgrl_gemm::k_encode_rows, dim3((rows + 3) / 4), dim3(256), 0, st, W, w, sc, dm, 1, rows);
+    return SGRL_OK;
+  }
+};
+}  // namespace
 
 // Test hook (tests/test_split_products_gpu.py): ONE product through the production tile kernels on caller-supplied operands, so
 // that every k_gemm3 instantiation the forward launches is held against float64 by `pytest -m gpu`, not only by a lab executable.
@@ -1377,7 +1419,7 @@ unsigned sgrl_set_range_events_seen(const sgrl_set* s) {
 //        5 stacked projections (N = 64: C [M, 32] <- columns 0..29, aux_out [M, 32] <- columns 32..61)
 //        6 residual + LayerNorm epilogue (N = 128: rowdiv; C [M, 128] is ln_io, read and rewritten; aux_in = ln_w | ln_b [256])
 //   form SGRL_SET_FORM_F16X3 | SGRL_SET_FORM_BF16X6 | 1 = the exact-f32 matrix instruction (k_gemm2; kinds 0..2 only)
-// Weights of the two-piece form are pre-split here exactly as k_pack does for the forward (k_encode_words).
+// Weights of the two-piece form are cut into row-scaled words here exactly as the forward does behind k_pack (k_encode_rows).
 int sgrl_set_debug_product(sgrl_set* s, int kind, int form, const float* A, int lda, const float* W, int ldw, const float* bias,
                            float* C, int ldc, int M, int N, int K, const float* rowdiv, const float* aux_in, float* aux_out,
                            void* stream) {
@@ -1385,16 +1427,15 @@ int sgrl_set_debug_product(sgrl_set* s, int kind, int form, const float* A, int 
   hipStream_t st = (hipStream_t)stream;
   if (!GemmKernels<0>::raise_lds_limits() || !GemmKernels<EPI_RELU>::raise_lds_limits() || !GemmKernels<EPI_ROWDIV>::raise_lds_limits())
     return sfail(SGRL_ERR_HIP, "cannot raise the dynamic LDS limit of the tile kernels");
-  unsigned* words = nullptr;
-  const size_t wn = (size_t)N * ldw;
+  TempWords tw;
+  const std::vector<std::pair<int64_t, int>> index{{0, 0}};
   g_gemm.form = form == 1 ? SGRL_SET_FORM_BF16X6 : form;
-  g_gemm.events = s->d_range_events;
   g_gemm.w_base = W;
-  g_gemm.w_words = nullptr;
+  g_gemm.w_words = nullptr; g_gemm.wsc = nullptr; g_gemm.enc_index = nullptr;
   if (form == SGRL_SET_FORM_F16X3) {
-    if (hipMalloc(&words, sizeof(unsigned) * wn) != hipSuccess) return sfail(SGRL_ERR_HIP, "debug product: allocation failed");
-    hipLaunchKernelGGL(sgrl_gemm::k_encode_words, dim3(256), dim3(256), 0, st, W, words, (long long)wn, s->d_range_events);
-    g_gemm.w_words = words;
+    if (ldw != K) return sfail(SGRL_ERR_ARG, "debug product: the two-piece form takes W rows of K contiguous floats");
+    if (tw.make(st, W, N, K) != SGRL_OK) return SGRL_ERR_HIP;
+    g_gemm.w_words = tw.w; g_gemm.wsc = tw.sc; g_gemm.enc_index = &index;
   }
   int rc = SGRL_OK;
   if (form == 1) {
@@ -1422,7 +1463,7 @@ int sgrl_set_debug_product(sgrl_set* s, int kind, int form, const float* A, int 
       if (form == SGRL_SET_FORM_F16X3) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kProjH), hipFuncAttributeMaxDynamicSharedMemorySize, kProjHLds) != hipSuccess)
           rc = sfail(SGRL_ERR_HIP, "debug product: LDS limit");
-        else hipLaunchKernelGGL(kProjH, dim3(((M + 127) / 128) * 1), dim3(256), kProjHLds, st, with_events(a));
+        else hipLaunchKernelGGL(kProjH, dim3(((M + 127) / 128) * 1), dim3(256), kProjHLds, st, with_words(a));
       } else if (GemmKernels<EPI_ZSPLIT>::raise_lds_limits()) GemmKernels<EPI_ZSPLIT>::launch(st, a);
       else rc = sfail(SGRL_ERR_HIP, "debug product: LDS limit");
     }
@@ -1433,7 +1474,56 @@ int sgrl_set_debug_product(sgrl_set* s, int kind, int form, const float* A, int 
   const hipError_t le = hipGetLastError();
   if (rc == SGRL_OK && le != hipSuccess) rc = sfail(SGRL_ERR_HIP, std::string("debug product: launch failed: ") + hipGetErrorString(le));
   (void)hipStreamSynchronize(st);
-  if (words) (void)hipFree(words);
+  g_gemm.enc_index = nullptr;
+  return rc;
+}
+
+// Test hook for the fused back-to-back products (chain_f16.h), same idea:
+//   kind 0  C[:, 0:128] = relu(A W1' + b1) W2' + b2                               A [M, K], W1 [hid, K], W2 [128, hid]
+//        1  ln_io = LayerNorm(ln_io + (relu(A W1' + b1) W2' + b2) / rowdiv)       hid = 256; C [M, ldc] is ln_io; ln = ln_w | ln_b [256]
+//        2  projection site: X = A [3 M, K] -> Z (zc, z2 [3 M, 32]; z2 may be null), fn [M], C[:, 0:128] = relu(G(Z) W1' + b1) W2' + b2
+//           with Wp [64, K] the stacked projections and W1 [hid, 576] in the folded Gram order
+int sgrl_set_debug_chain(sgrl_set* s, int kind, const float* A, int lda, int K, const float* Wp, const float* W1, const float* b1, int hid,
+                         const float* W2, const float* b2, float* C, int ldc, int M, const float* rowdiv, const float* ln, float* zc,
+                         float* z2, float* fn, void* stream) {
+  if (!s || !A || !W1 || !W2 || !C || M <= 0 || K <= 0 || (K % 16) || (lda & 3) || (hid != 128 && hid != 256))
+    return sfail(SGRL_ERR_ARG, "sgrl_set_debug_chain: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (!chain_raise_lds_limits()) return sfail(SGRL_ERR_HIP, "cannot raise the dynamic LDS limit of the chain kernels");
+  TempWords t1, t2, tp;
+  const int K1 = kind == 2 ? GK : K;
+  if (t1.make(st, W1, hid, K1) != SGRL_OK || t2.make(st, W2, 128, hid) != SGRL_OK) return SGRL_ERR_HIP;
+  ChainArgs a{};
+  a.W1 = t1.w; a.ldw1 = K1; a.b1 = b1; a.W2 = t2.w; a.ldw2 = hid; a.b2 = b2; a.M = M; a.K1 = K1; a.ws1 = t1.sc; a.ws2 = t2.sc;
+  const dim3 grid((M + sgrl_gemm::kChainRows - 1) / sgrl_gemm::kChainRows);
+  int rc = SGRL_OK;
+  if (kind == 0) {
+    a.A = A; a.lda = lda; a.C = C; a.ldc = ldc;
+    if (hid == 256) hipLaunchKernelGGL(kChainPlain, grid, dim3(512), sgrl_gemm::kChainLds, st, a);
+    else hipLaunchKernelGGL(kChainNg, grid, dim3(512), sgrl_gemm::kChainLds, st, a);
+  } else if (kind == 1) {
+    if (hid != 256 || !rowdiv || !ln) rc = sfail(SGRL_ERR_ARG, "debug chain: the LayerNorm pair needs hid = 256, rowdiv, ln_w | ln_b");
+    else {
+      a.A = A; a.lda = lda; a.rowdiv = rowdiv; a.ln_io = C; a.ln_ld = ldc; a.ln_w = ln; a.ln_b = ln + 128;
+      hipLaunchKernelGGL(kChainLn, grid, dim3(512), sgrl_gemm::kChainLds, st, a);
+    }
+  } else if (kind == 2) {
+    if (!Wp || !zc || !fn) rc = sfail(SGRL_ERR_ARG, "debug chain: the site needs Wp, zc, fn");
+    else if (tp.make(st, Wp, 64, K) != SGRL_OK) rc = SGRL_ERR_HIP;
+    else {
+      a.A = zc; a.C = C; a.ldc = ldc; a.fn_out = fn; a.X = A; a.ldx = lda; a.Kp = K; a.Wp = tp.w; a.wsp = tp.sc; a.zc = zc; a.z2 = z2;
+      if (hid == 256) {
+        if (z2) hipLaunchKernelGGL(kSiteF, grid, dim3(512), sgrl_gemm::kChainLds, st, a);
+        else hipLaunchKernelGGL(kSiteA, grid, dim3(512), sgrl_gemm::kChainLds, st, a);
+      } else {
+        if (z2) hipLaunchKernelGGL(kSiteH2, grid, dim3(512), sgrl_gemm::kChainLds, st, a);
+        else hipLaunchKernelGGL(kSiteH1, grid, dim3(512), sgrl_gemm::kChainLds, st, a);
+      }
+    }
+  } else rc = sfail(SGRL_ERR_ARG, "debug chain: unknown kind");
+  const hipError_t le = hipGetLastError();
+  if (rc == SGRL_OK && le != hipSuccess) rc = sfail(SGRL_ERR_HIP, std::string("debug chain: launch failed: ") + hipGetErrorString(le));
+  (void)hipStreamSynchronize(st);
   return rc;
 }
 

@@ -42,12 +42,10 @@ def _bind(L):
     L.sgrl_set_debug_stop_after.argtypes = [vp, ctypes.c_int]
     L.sgrl_set_debug_small_nodes.argtypes = [vp, ctypes.c_int]
     L.sgrl_set_gemm_form.argtypes = [vp, ctypes.c_int]
-    L.sgrl_set_range_events.argtypes = [vp, ctypes.POINTER(ctypes.c_uint), ctypes.c_int]
-    L.sgrl_set_range_events_seen.argtypes = [vp]
-    L.sgrl_set_range_events_seen.restype = ctypes.c_uint
     L.sgrl_set_last_error.restype = ctypes.c_char_p
     ci = ctypes.c_int
     L.sgrl_set_debug_product.argtypes = [vp, ci, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp]
+    L.sgrl_set_debug_chain.argtypes = [vp, ci, vp, ci, ci, vp, vp, vp, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp]
     L._set_bound = True
 
 
@@ -386,7 +384,6 @@ class HipSetActor(object):
                                                ctypes.c_void_p(out.data_ptr()), int(act_ld),
                                                ctypes.c_float(float(self.policy.max_action)), self._stream()),
                "sgrl_set_forward")
-        self._poll_range()
         return out
 
     def forward_q(self, obs, action, out=None, q_ld=None):
@@ -405,7 +402,6 @@ class HipSetActor(object):
                                                  ctypes.c_void_p(action.data_ptr()), self._ld(action),
                                                  ctypes.c_void_p(out.data_ptr()), int(q_ld), self._stream()),
                "sgrl_set_forward_q")
-        self._poll_range()
         return out
 
     def time_forward(self, obs, out, reps):
@@ -433,69 +429,10 @@ class HipSetActor(object):
 
     FORM_F16X3, FORM_BF16X6 = 2, 3
 
-    def gemm_form(self, form, _by_counter=False):
-        """Form of the tile products (include/sgrl_set.h): FORM_F16X3 (default: operands beyond +-65 000 are clamped and
-        counted), FORM_BF16X6 (f32's exponent range, slower), 0 = default.  A form set here is the user's: rearm_range() leaves it."""
+    def gemm_form(self, form):
+        """Form of the tile products (include/sgrl_set.h): FORM_F16X3 (default: two f16 pieces of every row-scaled operand,
+        float32's range), FORM_BF16X6 (three bf16 pieces, slower; A/B comparisons), 0 = default."""
         _check(self.L, self.L.sgrl_set_gemm_form(self.h, int(form)), "sgrl_set_gemm_form")
-        if not _by_counter:
-            self._range_fallback = False
-
-    def range_events(self, reset=True):
-        """Kernel threads that clamped an operand since the last reset (synchronises the device)."""
-        torch.cuda.synchronize(self.device)
-        n = ctypes.c_uint(0)
-        _check(self.L, self.L.sgrl_set_range_events(self.h, ctypes.byref(n), 1 if reset else 0), "sgrl_set_range_events")
-        return int(n.value)
-
-    def range_events_seen(self):
-        """Clamped operands as the forwards COMPLETED so far left the counter (a word of pinned host memory the last kernel of
-        every forward writes; include/sgrl_set.h sgrl_set_range_events_seen): no synchronisation, callable during a capture."""
-        return int(self.L.sgrl_set_range_events_seen(self.h))
-
-    def _poll_range(self):
-        """After every forward through the module / driver surface: if an EARLIER forward of this handle clamped an operand,
-        warn and switch to the full-range form now (one synchronisation, only in that case) -- users of `SEPolicy` /
-        `SECritic` / `BatchedEvaluator` get what `DeviceTrainer` does once per round without asking for it.  The forward just
-        enqueued is looked at by the next poll (or by check_range()).  Never synchronises while the stream is being captured
-        (the capturing caller polls after the replay: td3.GraphedUpdates)."""
-        if getattr(self, "_no_poll", False):
-            return
-        if self.L.sgrl_set_range_events_seen(self.h) and not torch.cuda.is_current_stream_capturing():
-            self.range_events_total = getattr(self, "range_events_total", 0) + self.check_range()
-
-    def check_range(self):
-        """Call at a point where a device synchronisation is affordable (end of a collection round, of an evaluation):
-        if the two-piece products met an operand outside f16's range since the last check, warn and move this handle to
-        the full-range form for good.  Returns the number of events seen."""
-        n = self.range_events(reset=True)
-        if n:
-            import warnings
-            warnings.warn("SET forward: %d kernel threads clamped an operand beyond +-65 000 (two-piece f16 products); "
-                          "this handle now uses the bf16 x 6 form (f32 exponent range)" % n, RuntimeWarning)
-            self.gemm_form(self.FORM_BF16X6, _by_counter=True)
-            self._range_fallback = True        # moved by the counter, not by the user: rearm_range() may take it back
-        return n
-
-    def rearm_range(self, obs, act_ld=None):
-        """A handle that check_range() moved to the full-range form stays there for good -- unless the caller says the weights
-        have changed since (the trainer, after every round's updates): then ONE probe forward of `obs` in the two-piece form,
-        its result thrown away, tells whether the new weights keep the operands inside f16's range.  They do: the handle is
-        back on the fast form (returns True).  They do not: full-range form again, as before (returns False).  A form chosen
-        by the user (gemm_form(), SGRL_SET_GEMM) is never touched.  Synchronises the device once."""
-        if not getattr(self, "_range_fallback", False):
-            return False
-        self.range_events(reset=True)
-        self.gemm_form(self.FORM_F16X3, _by_counter=True)
-        self._no_poll = True                   # the probe's counter is read right here, not by the forward's own poll
-        try:
-            self.forward_batch(obs, act_ld=act_ld)
-        finally:
-            self._no_poll = False
-        if self.range_events(reset=True):
-            self.gemm_form(self.FORM_BF16X6, _by_counter=True)
-            return False
-        self._range_fallback = False
-        return True
 
     def peek(self, which, per_node):
         out = np.zeros((self.num_nodes, per_node), dtype=np.float32)

@@ -475,7 +475,6 @@ class GraphedUpdates(object):
         # SGRL_SPLIT_UPDATE_GRAPHS=1: target chain and critic forward as graphs of their own, replayed on two streams
         self.split = os.environ.get("SGRL_SPLIT_UPDATE_GRAPHS", "0") == "1"
         self._cap_stream = self._side = None
-        self.range_events = 0      # operands the target networks' two-piece products clamped so far (poll_range)
 
     def _slot(self, key, graph, L):
         sl = self.slots.get(key)
@@ -499,18 +498,8 @@ class GraphedUpdates(object):
         """What the captured HIP target kernels point into, per handle: the workspace's size and the handle's GENERATION
         (include/sgrl_set.h sgrl_set_generation: bumped whenever the handle frees device memory a recorded forward may
         reference -- a batch structure evicted from its cache, the flat weight buffers of a rebinding, a regrown workspace --
-        or changes the form of its tile products)."""
+        or is told to change the form of its tile products)."""
         return tuple((int(hh.L.sgrl_set_workspace_bytes(hh.h)), int(hh.L.sgrl_set_generation(hh.h))) for hh in self._hip_handles())
-
-    def poll_range(self):
-        """Clamped operands in the target networks' forwards (they run inside replayed graphs, where nothing can poll): warn,
-        move the handle to the full-range form (its generation changes, so the graphs are captured again).  Returns events."""
-        n = 0
-        for hh in self._hip_handles():
-            if hh.range_events_seen():
-                n += hh.check_range()
-        self.range_events += n
-        return n
 
     def _load(self, sl, data_batch):
         for k, t in sl["batch"].items():

@@ -63,7 +63,6 @@ class DeviceTrainer(object):
         self._updates = 0            # TD3 updates so far (the reference adds them to tot_env_steps: trainer.py:250)
         self._tot_synced = 0         # non-learner ranks: the learner's count as of the last round end
         self.rounds = 0
-        self.range_events = 0        # operands the rollout actor clamped so far (HipSetActor.check_range)
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(int(seed) * 7919 + 13)
         self.last_losses = {}
@@ -141,19 +140,11 @@ class DeviceTrainer(object):
                         self.last_losses[name] = self.agent.update(batch, it)
                     self._updates += 1                         # the reference counts updates too (trainer.py:250)
             self.agent.models2eval()
-            if self.graphed is not None:     # the target networks' forwards ran inside replayed graphs: look at their counters now
-                self.range_events += self.graphed.poll_range()
-        # the rollout actor polls its clamp counter by itself after every forward (set_hip.HipSetActor._poll_range); once per round
-        # a synchronisation is affordable: also catch the events of the round's LAST forwards
-        if getattr(self.ro, "actor", None) is not None:
-            self.range_events += self.ro.actor.check_range() + getattr(self.ro.actor, "range_events_total", 0)
-            self.ro.actor.range_events_total = 0
         if self.world > 1:                   # every rank reports the learner's step count (checkpoints, stopping rule)
             t = torch.tensor([self.tot_env_steps if self.is_learner else 0], dtype=torch.long, device=self.device)
             self.dist.broadcast(t, src=self.dst)
             self._tot_synced = int(t.item())
         self.broadcast_actor()
-        self._rearm_rollout_actor()          # with the weights every rank rolls out next
         self.rounds += 1
         return per_morph_iter
 
@@ -169,28 +160,6 @@ class DeviceTrainer(object):
                 n = p.numel()
                 p.data.copy_(flat[off:off + n].view_as(p))     # in place: the HIP actor reads the live storage
                 off += n
-
-    def _rearm_rollout_actor(self):
-        """A rollout actor the clamp counter moved to the full-range products (2.4 -> 3.0 ms per forward) is probed after a
-        round's updates: ONE forward of the round's LAST observations (mid-episode states, where the operands are largest --
-        not the reset poses) in the two-piece form; new weights that keep the operands in range take the fast form back
-        (HipSetActor.rearm_range).  A handle that clamps again in a round it began re-armed waits twice as many rounds for its
-        next probe (1, 2, 4 ... 64): a policy that has grown out of f16's range for good costs a handful of probes, not one
-        clamped forward per round (seen with a diverged walker policy: profiles/r3_learning_curve_walker_seed7.log)."""
-        actor = getattr(self.ro, "actor", None)
-        if actor is None or not getattr(actor, "_range_fallback", False):
-            self._rearmed = False
-            return
-        if getattr(self, "_rearmed", False):              # began this round on the fast form and was moved again: back off
-            self._rearm_wait = min(64, 2 * getattr(self, "_rearm_wait", 1))
-        self._rearmed = False
-        self._rearm_idle = getattr(self, "_rearm_idle", 0) + 1
-        if self._rearm_idle < getattr(self, "_rearm_wait", 1):
-            return
-        self._rearm_idle = 0
-        if actor.rearm_range(self.ro.env.obs, act_ld=self.ro.env.action_max_len):
-            self.range_rearms = getattr(self, "range_rearms", 0) + 1
-            self._rearmed = True
 
     def train_round(self, max_steps=None, max_iters=None):
         """Collect until every environment has finished one episode (or max_steps), update, reset.  Returns a summary."""

@@ -1,6 +1,7 @@
 // tools/chain_lab.hip -- diagnostic only: the fused back-to-back products of chain_f16.h against the single products they
-// replace (gemm_f32.h), on the shapes of one SET forward: time of each form and the largest difference between their outputs.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -o tools/chain_lab.exe tools/chain_lab.hip && tools/chain_lab.exe [nodes]
+// replace (gemm_f32.h), on the shapes of one SET forward: time of each form, the largest difference between their outputs, and
+// (mode r) both forms against float64 with operands at 1e-20 .. 1e8 -- the range check of the row-scaled two-piece products.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -o tools/chain_lab.exe tools/chain_lab.hip && tools/chain_lab.exe [nodes] [r]
 #include "../sgrl_amd/csrc/chain_f16.h"
 
 #include <cmath>
@@ -29,6 +30,7 @@ static float time_us(F&& launch, int reps = 20) {
 
 constexpr auto kSplitPlain = k_gemm3<0, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2, true, 2>;
 constexpr auto kSplitRelu = k_gemm3<EPI_RELU, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2, true, 2>;
+constexpr auto kSplitRowdiv = k_gemm3<EPI_ROWDIV, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2, true, 2>;
 constexpr auto kSplitLn = k_gemm3<EPI_ROWDIV | EPI_LN, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2, true, 2>;
 constexpr auto kGram = k_gemm3<EPI_RELU, 4, 2, 1, 2, 16, 2, false, false, false, 0, true, 2, true, 2>;
 constexpr auto kProj = k_gemm3<EPI_ZSPLIT, 4, 1, 1, 2, 16, 2, false, false, false, 0, false, 2, false, 2>;
@@ -55,51 +57,115 @@ static void report(const char* what, const std::vector<float>& a, const std::vec
   printf("      %-28s max |fused - single| %.3e (largest value %.3e, NaN %zu)\n", what, worst, mag, bad);
 }
 
+static unsigned g_seed = 12345;
+static float rnd() { g_seed = g_seed * 1664525u + 1013904223u; return ((g_seed >> 8) & 0xffff) / 65536.0f - 0.5f; }
+struct Host { std::vector<float> h; float* d; };
+static Host dev(size_t n, float scale, float offset = 0.f) {
+  Host r; r.h.resize(n);
+  for (auto& v : r.h) v = rnd() * scale + offset;
+  CK(hipMalloc(&r.d, n * 4)); CK(hipMemcpy(r.d, r.h.data(), n * 4, hipMemcpyHostToDevice));
+  return r;
+}
+// weights as k_encode_rows leaves them: words of the rows scaled by powers of two + the inverse scales
+struct Wt { unsigned* w; float* sc; };
+static Wt words(const float* w, int rows, int K) {
+  Wt r;
+  CK(hipMalloc(&r.w, (size_t)rows * K * 4)); CK(hipMalloc(&r.sc, (size_t)rows * 4));
+  EncMat m{0, rows, K, 0};
+  EncMat* dm; CK(hipMalloc(&dm, sizeof(EncMat))); CK(hipMemcpy(dm, &m, sizeof(EncMat), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_encode_rows, dim3((rows + 3) / 4), dim3(256), 0, 0, w, r.w, r.sc, dm, 1, rows);
+  return r;
+}
+static GemmArgs gemm(const float* A, int lda, const Wt& W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K, int flags,
+                     const float* rowdiv = nullptr, float* C2 = nullptr, int ldc2 = 0) {
+  GemmArgs g{A, lda, reinterpret_cast<const float*>(W.w), ldw, bias, C, ldc, M, N, K, flags, rowdiv, C2, ldc2};
+  g.wscale = W.sc;
+  return g;
+}
+
 int main(int argc, char** argv) {
   const int N = argc > 1 ? atoi(argv[1]) : 35840;
   const int N3 = 3 * N;
-  unsigned s = 12345;
-  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
-  auto dev = [&](size_t n, float scale, float offset = 0.f) {
-    std::vector<float> h(n);
-    for (auto& v : h) v = rnd() * scale + offset;
-    float* d; CK(hipMalloc(&d, n * 4)); CK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
-    return d;
-  };
-  auto words = [&](const float* w, size_t n) {
-    unsigned* d; CK(hipMalloc(&d, n * 4));
-    hipLaunchKernelGGL(k_encode_words, dim3(256), dim3(256), 0, 0, w, d, (long long)n, (unsigned*)nullptr);
-    return d;
-  };
-  raise(kSplitPlain, kLds128); raise(kSplitRelu, kLds128); raise(kSplitLn, kLds128); raise(kGram, kLds128); raise(kProj, kLdsProj);
+  const char mode = argc > 2 ? argv[2][0] : ' ';
+  raise(kSplitPlain, kLds128); raise(kSplitRelu, kLds128); raise(kSplitRowdiv, kLds128); raise(kSplitLn, kLds128); raise(kGram, kLds128); raise(kProj, kLdsProj);
   raise(k_chain<0, 256, EPI_ROWDIV | EPI_LN, 0>, kChainLds); raise(k_chain<0, 256, 0, 0>, kChainLds); raise(k_chain<1, 256, 0, 0>, kChainLds);
   raise(k_chain<1, 256, 0, 1>, kChainLds); raise(k_chain<1, 256, 0, 2>, kChainLds); raise(k_chain<0, 128, 0, 0>, kChainLds);
   raise(k_chain<1, 128, 0, 2>, kChainLds);
-  unsigned* ev; CK(hipMalloc(&ev, 4)); CK(hipMemset(ev, 0, 4));
   const int tiles = (N + 127) / 128, blocks = (N + kChainRows - 1) / kChainRows;
 
-  float* cat = dev((size_t)N * 256, 2.0f);               // [inv | ng]
-  float* fn = dev((size_t)N, 1.0f, 2.0f);
-  float* W1 = dev(256 * 256, 0.2f); float* b1 = dev(256, 1.0f);
-  float* W2 = dev(128 * 256, 0.2f); float* b2 = dev(128, 1.0f);
-  float* lnw = dev(128, 1.0f, 1.0f); float* lnb = dev(128, 1.0f);
-  unsigned* W1w = words(W1, 256 * 256); unsigned* W2w = words(W2, 128 * 256);
+  Host cat = dev((size_t)N * 256, 2.0f);               // [inv | ng]
+  Host fn = dev((size_t)N, 1.0f, 2.0f);
+  Host W1 = dev(256 * 256, 0.2f), b1 = dev(256, 1.0f), W2 = dev(128 * 256, 0.2f), b2 = dev(128, 1.0f);
+  Host lnw = dev(128, 1.0f, 1.0f), lnb = dev(128, 1.0f);
+  Wt W1w = words(W1.d, 256, 256), W2w = words(W2.d, 128, 256);
   float *h256, *out_a, *out_b, *ng_a, *ng_b;
   CK(hipMalloc(&h256, (size_t)N * 256 * 4)); CK(hipMalloc(&out_a, (size_t)N * 256 * 4)); CK(hipMalloc(&out_b, (size_t)N * 256 * 4));
   CK(hipMalloc(&ng_a, (size_t)N * 256 * 4)); CK(hipMalloc(&ng_b, (size_t)N * 256 * 4));
   CK(hipMemset(out_a, 0, (size_t)N * 256 * 4)); CK(hipMemset(out_b, 0, (size_t)N * 256 * 4));
-
   printf("chain lab: %d nodes (%d row tiles of 128, %d workgroups of %d rows)\n", N, tiles, blocks, kChainRows);
+
+  if (mode == 'r') {
+    // ---- range: single product and fused pair against float64, activations x sa, weights x sw -----------------------------------
+    const int M = 4096;
+    for (float sa : {1.f, 1e8f, 1e-20f, 3e4f})
+      for (float sw : {1.f, 1e4f, 1e-6f}) {
+        std::vector<float> hA((size_t)M * 256), hW1(256 * 256), hW2(128 * 256);
+        for (auto& v : hA) v = rnd() * 2.0f * sa * std::pow(10.0f, 3.0f * rnd());      // three decades inside a row
+        for (int r = 0; r < M; r += 7) for (int k = 0; k < 16; k++) hA[(size_t)r * 256 + k] = 0.f;   // rows whose first k-tile is zero: the estimate fails
+        for (int r = 3; r < M; r += 11) for (int k = 0; k < 16; k++) hA[(size_t)r * 256 + k] *= 1e-4f; // ... or is far too small
+        for (auto& v : hW1) v = rnd() * 0.2f * sw;
+        for (auto& v : hW2) v = rnd() * 0.2f * sw;
+        float *dA, *dW1, *dW2, *dC, *dH;
+        CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dW1, hW1.size() * 4)); CK(hipMalloc(&dW2, hW2.size() * 4));
+        CK(hipMalloc(&dC, (size_t)M * 256 * 4)); CK(hipMalloc(&dH, (size_t)M * 256 * 4));
+        CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dW1, hW1.data(), hW1.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dW2, hW2.data(), hW2.size() * 4, hipMemcpyHostToDevice));
+        Wt w1 = words(dW1, 256, 256), w2 = words(dW2, 128, 256);
+        GemmArgs g1 = gemm(dA, 256, w1, 256, b1.d, dH, 256, M, 256, 256, EPI_RELU);
+        hipLaunchKernelGGL(kSplitRelu, dim3((M / 128) * 2), dim3(512), kLds128, 0, g1);
+        ChainArgs c{};
+        c.A = dA; c.lda = 256; c.W1 = w1.w; c.ldw1 = 256; c.b1 = b1.d; c.W2 = w2.w; c.ldw2 = 256; c.b2 = b2.d; c.C = dC; c.ldc = 256; c.M = M; c.K1 = 256;
+        c.ws1 = w1.sc; c.ws2 = w2.sc;
+        hipLaunchKernelGGL((k_chain<0, 256, 0, 0>), dim3(M / kChainRows), dim3(512), kChainLds, 0, c);
+        CK(hipDeviceSynchronize());
+        std::vector<float> gH = fetch(dH, (size_t)M * 256), gC = fetch(dC, (size_t)M * 256);
+        double w1e = 0, w2e = 0;
+        size_t nan = 0;
+        unsigned q = 777;
+        for (int smp = 0; smp < 3000; smp++) {
+          q = q * 1664525u + 1013904223u;
+          const int m = smp < 600 ? (smp % 2 ? 7 * (smp % 500) : 3 + 11 * (smp % 300)) % M : (q >> 4) % M;
+          q = q * 1664525u + 1013904223u; const int n = (q >> 4) % 128;
+          std::vector<double> H(256);
+          for (int h = 0; h < 256; h++) {
+            double r = b1.h[h], mag = fabs((double)b1.h[h]);
+            for (int k = 0; k < 256; k++) { const double p = (double)hA[(size_t)m * 256 + k] * hW1[(size_t)h * 256 + k]; r += p; mag += fabs(p); }
+            H[h] = r > 0 ? r : 0;
+            if (h == n || h == n + 128) {
+              const double e = fabs((double)gH[(size_t)m * 256 + h] - H[h]) / mag;
+              if (!(e == e)) nan++; else if (e > w1e) w1e = e;
+            }
+          }
+          double r = b2.h[n], mag = fabs((double)b2.h[n]);
+          for (int h = 0; h < 256; h++) { const double p = H[h] * hW2[(size_t)n * 256 + h]; r += p; mag += fabs(p); }
+          const double e = fabs((double)gC[(size_t)m * 256 + n] - r) / mag;
+          if (!(e == e)) nan++; else if (e > w2e) w2e = e;
+        }
+        printf("  activations x %-7.0e weights x %-6.0e: single product err/sum|a w| %.2e | fused pair %.2e | NaN %zu\n", sa, sw, w1e, w2e, nan);
+        hipFree(dA); hipFree(dW1); hipFree(dW2); hipFree(dC); hipFree(dH);
+      }
+    return 0;
+  }
+
   // ---- (1) linear1 -> ReLU -> linear2 -> / fn -> residual + LayerNorm (in place on ng = cat[:, 128:]) ----------------------
   {
-    GemmArgs g1{cat, 256, reinterpret_cast<const float*>(W1w), 256, b1, h256, 256, N, 256, 256, EPI_RELU, nullptr, nullptr, 0};
-    g1.range_events = ev;
-    GemmArgs g2{h256, 256, reinterpret_cast<const float*>(W2w), 256, b2, nullptr, 0, N, 128, 256, EPI_ROWDIV | EPI_LN, fn, nullptr, 0};
-    g2.ln_io = ng_a + 128; g2.ln_ld = 256; g2.ln_w = lnw; g2.ln_b = lnb; g2.range_events = ev;
+    GemmArgs g1 = gemm(cat.d, 256, W1w, 256, b1.d, h256, 256, N, 256, 256, EPI_RELU);
+    GemmArgs g2 = gemm(h256, 256, W2w, 256, b2.d, nullptr, 0, N, 128, 256, EPI_ROWDIV | EPI_LN, fn.d);
+    g2.ln_io = ng_a + 128; g2.ln_ld = 256; g2.ln_w = lnw.d; g2.ln_b = lnb.d;
     ChainArgs c{};
-    c.A = cat; c.lda = 256; c.W1 = W1w; c.ldw1 = 256; c.b1 = b1; c.W2 = W2w; c.ldw2 = 256; c.b2 = b2; c.M = N; c.K1 = 256;
-    c.rowdiv = fn; c.ln_io = ng_b + 128; c.ln_ld = 256; c.ln_w = lnw; c.ln_b = lnb; c.range_events = ev;
-    CK(hipMemcpy(ng_a, cat, (size_t)N * 256 * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(ng_b, cat, (size_t)N * 256 * 4, hipMemcpyDeviceToDevice));
+    c.A = cat.d; c.lda = 256; c.W1 = W1w.w; c.ldw1 = 256; c.b1 = b1.d; c.W2 = W2w.w; c.ldw2 = 256; c.b2 = b2.d; c.M = N; c.K1 = 256;
+    c.rowdiv = fn.d; c.ln_io = ng_b + 128; c.ln_ld = 256; c.ln_w = lnw.d; c.ln_b = lnb.d; c.ws1 = W1w.sc; c.ws2 = W2w.sc;
+    CK(hipMemcpy(ng_a, cat.d, (size_t)N * 256 * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(ng_b, cat.d, (size_t)N * 256 * 4, hipMemcpyDeviceToDevice));
     hipLaunchKernelGGL(kSplitRelu, dim3(tiles * 2), dim3(512), kLds128, 0, g1);
     hipLaunchKernelGGL(kSplitLn, dim3(tiles), dim3(512), kLds128, 0, g2);
     hipLaunchKernelGGL((k_chain<0, 256, EPI_ROWDIV | EPI_LN, 0>), dim3(blocks), dim3(512), kChainLds, 0, c);
@@ -110,9 +176,7 @@ int main(int argc, char** argv) {
     const float tab = time_us([&] { hipLaunchKernelGGL(kSplitRelu, dim3(tiles * 2), dim3(512), kLds128, 0, g1); hipLaunchKernelGGL(kSplitLn, dim3(tiles), dim3(512), kLds128, 0, g2); });
     const float tf = time_us([&] { hipLaunchKernelGGL((k_chain<0, 256, EPI_ROWDIV | EPI_LN, 0>), dim3(blocks), dim3(512), kChainLds, 0, c); });
     printf("  l1 -> l2 + LN   : single products %.1f + %.1f us (back to back %.1f) | fused %.1f us\n", ta, tb, tab, tf);
-    // plain second epilogue (the same pair as linear3-shaped products would use it)
-    GemmArgs g2p{h256, 256, reinterpret_cast<const float*>(W2w), 256, b2, out_a, 256, N, 128, 256, 0, nullptr, nullptr, 0};
-    g2p.range_events = ev;
+    GemmArgs g2p = gemm(h256, 256, W2w, 256, b2.d, out_a, 256, N, 128, 256, 0);
     ChainArgs cp = c; cp.C = out_b; cp.ldc = 256;
     hipLaunchKernelGGL(kSplitRelu, dim3(tiles * 2), dim3(512), kLds128, 0, g1);
     hipLaunchKernelGGL(kSplitPlain, dim3(tiles), dim3(512), kLds128, 0, g2p);
@@ -125,29 +189,28 @@ int main(int argc, char** argv) {
   }
   // ---- (2) projection -> Gram operand -> linear_g1 -> ReLU -> linear_g2 ----------------------------------------------------
   {
-    float* g = dev((size_t)N3 * 128, 2.0f);
-    float* Wp = dev(64 * 128, 0.3f);
-    CK(hipMemset(Wp + 30 * 128, 0, 2 * 128 * 4)); CK(hipMemset(Wp + 62 * 128, 0, 2 * 128 * 4));
-    unsigned* Wpw = words(Wp, 64 * 128);
-    float* Wg = dev(256 * 576, 0.05f); float* bg = dev(256, 1.0f);
-    unsigned* Wgw = words(Wg, 256 * 576);
-    float* zc_a = dev((size_t)N3 * 32, 1.0f);
-    float *zc_b, *z2_a, *z2_b, *fn_a, *fn_b;
+    Host g = dev((size_t)N3 * 128, 2.0f);
+    Host Wp = dev(64 * 128, 0.3f);
+    CK(hipMemset(Wp.d + 30 * 128, 0, 2 * 128 * 4)); CK(hipMemset(Wp.d + 62 * 128, 0, 2 * 128 * 4));
+    Wt Wpw = words(Wp.d, 64, 128);
+    Host Wg = dev(256 * 576, 0.05f), bg = dev(256, 1.0f);
+    Wt Wgw = words(Wg.d, 256, 576);
+    Host zc0 = dev((size_t)N3 * 32, 1.0f);
+    float *zc_a = zc0.d, *zc_b, *z2_a, *z2_b, *fn_a, *fn_b;
     CK(hipMalloc(&zc_b, (size_t)N3 * 32 * 4)); CK(hipMalloc(&z2_a, (size_t)N3 * 32 * 4)); CK(hipMalloc(&z2_b, (size_t)N3 * 32 * 4));
     CK(hipMalloc(&fn_a, (size_t)N * 4)); CK(hipMalloc(&fn_b, (size_t)N * 4));
     CK(hipMemcpy(zc_b, zc_a, (size_t)N3 * 32 * 4, hipMemcpyDeviceToDevice));
     CK(hipMemcpy(z2_a, zc_a, (size_t)N3 * 32 * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(z2_b, zc_a, (size_t)N3 * 32 * 4, hipMemcpyDeviceToDevice));
     for (int nz = 1; nz <= 2; nz++) {
-      GemmArgs p{g, 128, reinterpret_cast<const float*>(Wpw), 128, nullptr, zc_a, 32, N3, nz == 2 ? 64 : 32, 128, EPI_ZSPLIT, nullptr, nz == 2 ? z2_a : nullptr, 32};
-      p.range_events = ev;
-      GemmArgs gg{zc_a, 96, reinterpret_cast<const float*>(Wgw), 576, bg, h256, 256, N, 256, 576, EPI_RELU, nullptr, nullptr, 0};
-      gg.rowdiv_out = fn_a; gg.range_events = ev;
-      GemmArgs g2p{h256, 256, reinterpret_cast<const float*>(W2w), 256, b2, out_a, 256, N, 128, 256, 0, nullptr, nullptr, 0};
-      g2p.range_events = ev;
+      GemmArgs p = gemm(g.d, 128, Wpw, 128, nullptr, zc_a, 32, N3, nz == 2 ? 64 : 32, 128, EPI_ZSPLIT, nullptr, nz == 2 ? z2_a : nullptr, 32);
+      GemmArgs gg = gemm(zc_a, 96, Wgw, 576, bg.d, h256, 256, N, 256, 576, EPI_RELU);
+      gg.rowdiv_out = fn_a;
+      GemmArgs g2p = gemm(h256, 256, W2w, 256, b2.d, out_a, 256, N, 128, 256, 0);
       ChainArgs c{};
-      c.A = zc_b; c.W1 = Wgw; c.ldw1 = 576; c.b1 = bg; c.W2 = W2w; c.ldw2 = 256; c.b2 = b2; c.C = out_b; c.ldc = 256; c.M = N; c.K1 = 576;
-      c.fn_out = fn_b; c.X = g; c.ldx = 128; c.Kp = 128; c.Wp = Wpw; c.zc = zc_b; c.z2 = nz == 2 ? z2_b : nullptr; c.range_events = ev;
-      const int pgrid = ((N3 + 127) / 128) * (nz == 2 ? 1 : 1);
+      c.A = zc_b; c.W1 = Wgw.w; c.ldw1 = 576; c.b1 = bg.d; c.W2 = W2w.w; c.ldw2 = 256; c.b2 = b2.d; c.C = out_b; c.ldc = 256; c.M = N; c.K1 = 576;
+      c.fn_out = fn_b; c.X = g.d; c.ldx = 128; c.Kp = 128; c.Wp = Wpw.w; c.zc = zc_b; c.z2 = nz == 2 ? z2_b : nullptr;
+      c.ws1 = Wgw.sc; c.ws2 = W2w.sc; c.wsp = Wpw.sc;
+      const int pgrid = (N3 + 127) / 128;
       auto single = [&] {
         hipLaunchKernelGGL(kProj, dim3(pgrid), dim3(256), kLdsProj, 0, p);
         hipLaunchKernelGGL(kGram, dim3(tiles * 2), dim3(512), kLds128, 0, gg);
@@ -173,22 +236,17 @@ int main(int argc, char** argv) {
       printf("    single products proj %.1f + lg1 %.1f + lg2 %.1f us (back to back %.1f) | fused site %.1f us | fused lg1 -> lg2 without the projection %.1f us\n",
              t1, t2, t3, ts, tf, tf0);
     }
-    // the head's site: K = 144 projections, hidden width 128
     {
-      float* og = dev((size_t)N3 * 144, 2.0f);
-      float* Wp2 = dev(64 * 144, 0.3f);
-      unsigned* Wp2w = words(Wp2, 64 * 144);
-      float* Wh = dev(128 * 576, 0.05f); unsigned* Whw = words(Wh, 128 * 576);
-      float* W2h = dev(128 * 128, 0.2f); unsigned* W2hw = words(W2h, 128 * 128);
-      GemmArgs p{og, 144, reinterpret_cast<const float*>(Wp2w), 144, nullptr, zc_a, 32, N3, 64, 144, EPI_ZSPLIT, nullptr, z2_a, 32};
-      p.range_events = ev;
-      GemmArgs gg{zc_a, 96, reinterpret_cast<const float*>(Whw), 576, bg, h256, 128, N, 128, 576, EPI_RELU, nullptr, nullptr, 0};
-      gg.rowdiv_out = fn_a; gg.range_events = ev;
-      GemmArgs g2p{h256, 128, reinterpret_cast<const float*>(W2hw), 128, b2, out_a, 256, N, 128, 128, 0, nullptr, nullptr, 0};
-      g2p.range_events = ev;
+      // the head's site: K = 144 projections, hidden width 128; linear1_ng -> linear2_ng: K 160, hidden 128
+      Host og = dev((size_t)N3 * 144, 2.0f), Wp2 = dev(64 * 144, 0.3f), Wh = dev(128 * 576, 0.05f), W2h = dev(128 * 128, 0.2f);
+      Wt Wp2w = words(Wp2.d, 64, 144), Whw = words(Wh.d, 128, 576), W2hw = words(W2h.d, 128, 128);
+      GemmArgs p = gemm(og.d, 144, Wp2w, 144, nullptr, zc_a, 32, N3, 64, 144, EPI_ZSPLIT, nullptr, z2_a, 32);
+      GemmArgs gg = gemm(zc_a, 96, Whw, 576, bg.d, h256, 128, N, 128, 576, EPI_RELU);
+      gg.rowdiv_out = fn_a;
+      GemmArgs g2p = gemm(h256, 128, W2hw, 128, b2.d, out_a, 256, N, 128, 128, 0);
       ChainArgs c{};
-      c.A = zc_b; c.W1 = Whw; c.ldw1 = 576; c.b1 = bg; c.W2 = W2hw; c.ldw2 = 128; c.b2 = b2; c.C = out_b; c.ldc = 256; c.M = N; c.K1 = 576;
-      c.fn_out = fn_b; c.X = og; c.ldx = 144; c.Kp = 144; c.Wp = Wp2w; c.zc = zc_b; c.z2 = z2_b; c.range_events = ev;
+      c.A = zc_b; c.W1 = Whw.w; c.ldw1 = 576; c.b1 = bg.d; c.W2 = W2hw.w; c.ldw2 = 128; c.b2 = b2.d; c.C = out_b; c.ldc = 256; c.M = N; c.K1 = 576;
+      c.fn_out = fn_b; c.X = og.d; c.ldx = 144; c.Kp = 144; c.Wp = Wp2w.w; c.zc = zc_b; c.z2 = z2_b; c.ws1 = Whw.sc; c.ws2 = W2hw.sc; c.wsp = Wp2w.sc;
       auto single = [&] {
         hipLaunchKernelGGL(kProj, dim3((N3 + 127) / 128), dim3(256), kLdsProj, 0, p);
         hipLaunchKernelGGL(kGram, dim3(tiles), dim3(512), kLds128, 0, gg);
@@ -202,14 +260,12 @@ int main(int argc, char** argv) {
       report("z2", fetch(z2_a, (size_t)N3 * 32), fetch(z2_b, (size_t)N3 * 32), 32, 32);
       report("proj -> l1g -> l2g", fetch(out_a, (size_t)N * 256), fetch(out_b, (size_t)N * 256), 256, 128);
       printf("    single products back to back %.1f us | fused %.1f us\n", time_us(single), time_us(fused));
-      // linear1_ng -> linear2_ng: K 160, hidden 128
-      float* ong = dev((size_t)N * 160, 2.0f);
-      float* Wn = dev(128 * 160, 0.2f); unsigned* Wnw = words(Wn, 128 * 160);
-      GemmArgs n1{ong, 160, reinterpret_cast<const float*>(Wnw), 160, b1, h256, 128, N, 128, 160, EPI_RELU, nullptr, nullptr, 0};
-      n1.range_events = ev;
+      Host ong = dev((size_t)N * 160, 2.0f), Wn = dev(128 * 160, 0.2f);
+      Wt Wnw = words(Wn.d, 128, 160);
+      GemmArgs n1 = gemm(ong.d, 160, Wnw, 160, b1.d, h256, 128, N, 128, 160, EPI_RELU);
       ChainArgs cn{};
-      cn.A = ong; cn.lda = 160; cn.W1 = Wnw; cn.ldw1 = 160; cn.b1 = b1; cn.W2 = W2hw; cn.ldw2 = 128; cn.b2 = b2; cn.C = out_b; cn.ldc = 256; cn.M = N; cn.K1 = 160;
-      cn.range_events = ev;
+      cn.A = ong.d; cn.lda = 160; cn.W1 = Wnw.w; cn.ldw1 = 160; cn.b1 = b1.d; cn.W2 = W2hw.w; cn.ldw2 = 128; cn.b2 = b2.d; cn.C = out_b; cn.ldc = 256; cn.M = N; cn.K1 = 160;
+      cn.ws1 = Wnw.sc; cn.ws2 = W2hw.sc;
       auto single_n = [&] {
         hipLaunchKernelGGL(kSplitRelu, dim3(tiles), dim3(512), kLds128, 0, n1);
         hipLaunchKernelGGL(kSplitPlain, dim3(tiles), dim3(512), kLds128, 0, g2p);
@@ -221,52 +277,19 @@ int main(int argc, char** argv) {
       printf("    l1ng -> l2ng: single products back to back %.1f us | fused %.1f us\n", time_us(single_n), time_us(fused_n));
     }
   }
-  // ---- (3) row-wise stores of transposed tiles (EPI_TR) on the wide plain products ------------------------------------------
+  // ---- (3) the wide single products (reference timings for the forward's budget) -------------------------------------------------
   {
-    constexpr auto kRowdiv = k_gemm3<EPI_ROWDIV, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2, true, 2>;
-    constexpr auto kRowdivT = k_gemm3<EPI_ROWDIV | EPI_TR, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2, true, 2>;
-    constexpr auto kPlainT = k_gemm3<EPI_TR, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2, true, 2>;
-    constexpr auto kReluT = k_gemm3<EPI_RELU | EPI_TR, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2, true, 2>;
-    raise(kRowdiv, kLds128); raise(kRowdivT, kLds128); raise(kPlainT, kLds128); raise(kReluT, kLds128);
-    float* Wq = dev(768 * 256, 0.2f); unsigned* Wqw = words(Wq, 768 * 256);
-    float* bq = dev(768, 1.0f);
-    float *q_a, *q_b;
-    CK(hipMalloc(&q_a, (size_t)N3 * 256 * 4)); CK(hipMalloc(&q_b, (size_t)N3 * 256 * 4));
-    GemmArgs q{cat, 256, reinterpret_cast<const float*>(Wqw), 256, bq, q_a, 768, N, 768, 256, EPI_ROWDIV, fn, nullptr, 0};
-    q.range_events = ev;
-    GemmArgs qt = q; qt.C = q_b;
-    hipLaunchKernelGGL(kRowdiv, dim3(tiles * 6), dim3(512), kLds128, 0, q);
-    hipLaunchKernelGGL(kRowdivT, dim3(tiles * 6), dim3(512), kLds128, 0, qt);
-    CK(hipDeviceSynchronize());
-    report("qkv: row-wise stores", fetch(q_a, (size_t)N * 768), fetch(q_b, (size_t)N * 768), 768, 768);
-    printf("  qkv (N 768, K 256, / fn): column-wise stores %.1f us | row-wise stores of transposed tiles %.1f us\n",
-           time_us([&] { hipLaunchKernelGGL(kRowdiv, dim3(tiles * 6), dim3(512), kLds128, 0, q); }),
-           time_us([&] { hipLaunchKernelGGL(kRowdivT, dim3(tiles * 6), dim3(512), kLds128, 0, qt); }));
-    float* g = dev((size_t)N3 * 128, 2.0f);
-    float* Wu = dev(256 * 128, 0.2f); unsigned* Wuw = words(Wu, 256 * 128);
-    const int tiles3 = (N3 + 127) / 128;
-    GemmArgs u{g, 128, reinterpret_cast<const float*>(Wuw), 128, nullptr, q_a, 256, N3, 256, 128, 0, nullptr, nullptr, 0};
-    u.range_events = ev;
-    GemmArgs ut = u; ut.C = q_b;
-    hipLaunchKernelGGL(kSplitPlain, dim3(tiles3 * 2), dim3(512), kLds128, 0, u);
-    hipLaunchKernelGGL(kPlainT, dim3(tiles3 * 2), dim3(512), kLds128, 0, ut);
-    CK(hipDeviceSynchronize());
-    report("U: row-wise stores", fetch(q_a, (size_t)N3 * 256), fetch(q_b, (size_t)N3 * 256), 256, 256);
-    printf("  U (3 x nodes, N 256, K 128): column-wise stores %.1f us | row-wise stores %.1f us\n",
-           time_us([&] { hipLaunchKernelGGL(kSplitPlain, dim3(tiles3 * 2), dim3(512), kLds128, 0, u); }),
-           time_us([&] { hipLaunchKernelGGL(kPlainT, dim3(tiles3 * 2), dim3(512), kLds128, 0, ut); }));
-    GemmArgs l3{cat, 256, reinterpret_cast<const float*>(W1w), 256, b1, q_a, 256, N, 256, 256, EPI_RELU, nullptr, nullptr, 0};
-    l3.range_events = ev;
-    GemmArgs l3t = l3; l3t.C = q_b;
-    hipLaunchKernelGGL(kSplitRelu, dim3(tiles * 2), dim3(512), kLds128, 0, l3);
-    hipLaunchKernelGGL(kReluT, dim3(tiles * 2), dim3(512), kLds128, 0, l3t);
-    CK(hipDeviceSynchronize());
-    report("l3: row-wise stores", fetch(q_a, (size_t)N * 256), fetch(q_b, (size_t)N * 256), 256, 256);
-    printf("  l3 (N 256, K 256, ReLU): column-wise stores %.1f us | row-wise stores %.1f us\n",
-           time_us([&] { hipLaunchKernelGGL(kSplitRelu, dim3(tiles * 2), dim3(512), kLds128, 0, l3); }),
-           time_us([&] { hipLaunchKernelGGL(kReluT, dim3(tiles * 2), dim3(512), kLds128, 0, l3t); }));
+    Host Wq = dev(1024 * 256, 0.2f), bq = dev(1024, 1.0f);
+    Wt Wqw = words(Wq.d, 1024, 256);
+    float* big; CK(hipMalloc(&big, (size_t)N * 1024 * 4));
+    for (int Nx : {1024, 768, 256}) {
+      GemmArgs q = gemm(cat.d, 256, Wqw, 256, bq.d, big, Nx, N, Nx, 256, EPI_ROWDIV, fn.d);
+      GemmArgs q2 = q; q2.flags = EPI_RELU;
+      const float tq = time_us([&] { hipLaunchKernelGGL(kSplitRowdiv, dim3(tiles * (Nx / 128)), dim3(512), kLds128, 0, q); });
+      const float tr = time_us([&] { hipLaunchKernelGGL(kSplitRelu, dim3(tiles * (Nx / 128)), dim3(512), kLds128, 0, q2); });
+      const float tq2 = time_us([&] { hipLaunchKernelGGL(kSplitRowdiv, dim3(tiles * (Nx / 128)), dim3(512), kLds128, 0, q); });
+      printf("  product M %d N %4d K 256: row division %.1f us | ReLU %.1f us | row division again %.1f us\n", N, Nx, tq, tr, tq2);
+    }
   }
-  unsigned hev = 0; CK(hipMemcpy(&hev, ev, 4, hipMemcpyDeviceToHost));
-  printf("range events: %u\n", hev);
   return 0;
 }

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
   static_assert(!(FLAGS & (EPI_EQUIV | EPI_LN | EPI_ZSPLIT)), "plain epilogues only");
   constexpr bool CWD = (WORDS & 4) != 0;
   constexpr float kCorW = 1.f / kF16LowScale;
-  extern __shared__ float gemm_lds[];
+  extern __shared__ __attribute__((aligned(16))) float gemm_lds[];     // (aligned: static LDS precedes it)
   char* lds = reinterpret_cast<char*>(gemm_lds);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;

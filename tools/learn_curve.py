@@ -73,8 +73,7 @@ def train():
         c = env.get_counters()
         pivot_fail += int(((c[:, 3] >> 8) & 0xFF).sum())
         slab += int((c[:, 3] >> 16).sum())
-        s.update({"round": rnd, "wall_s": round(time.time() - t0, 1), "range_events": int(tr.range_events), "range_rearms": int(getattr(tr, "range_rearms", 0)),
-                  "envs_with_dropped_rows": int((c[:, 2] > 0).sum())})
+        s.update({"round": rnd, "wall_s": round(time.time() - t0, 1), "envs_with_dropped_rows": int((c[:, 2] > 0).sum())})
         curve.append(s)
         if rnd % 5 == 0:
             print("round %d: return %.2f length %.1f iters %d wall %.0f s" % (rnd, s["performance/train_return"],
@@ -84,7 +83,6 @@ def train():
            "random_policy": {"train_return_mean": float(np.mean(rand_returns)) if rand_returns else None,
                              "train_length_mean": float(np.mean(rand_lengths)) if rand_lengths else None, "rounds": len(rand_returns)},
            "rounds": curve, "block_pivot_failures_last_step_sum": pivot_fail, "hbm_slab_solves_last_step_sum": slab,
-           "final_range_events": int(tr.range_events),
            "summary": {"first5_return": float(np.mean([r["performance/train_return"] for r in curve[:5]])) if curve else None,
                        "last5_return": float(np.mean([r["performance/train_return"] for r in curve[-5:]])) if curve else None,
                        "first5_length": float(np.mean([r["performance/train_length"] for r in curve[:5]])) if curve else None,

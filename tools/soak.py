@@ -85,8 +85,7 @@ def run_phase(driver, nsteps):
           "episode_length_histogram": {"%d-%d" % (BINS[i], BINS[i + 1] - 1) if i < len(BINS) - 2 else ">=%d" % BINS[i]: int(hist[i].item())
                                        for i in range(len(BINS) - 1)},
           "envs_with_dropped_rows_by_family": {f: int(sum(int((cnt[sl, 2] > 0).sum()) for k, sl in enumerate(env.morph_slices) if f in names[k]))
-                                               for f in ("hopper", "walker", "humanoid", "cheetah") if any(f in nm for nm in names)},
-          "range_events": ro.actor.check_range() if driver == "policy" else None}
+                                               for f in ("hopper", "walker", "humanoid", "cheetah") if any(f in nm for nm in names)}}
     print(json.dumps(ph), flush=True)
     out["phases"].append(ph)
 
