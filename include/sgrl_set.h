@@ -183,6 +183,10 @@ int sgrl_set_debug_product(sgrl_set* s, int kind, int form, const float* A, int 
 int sgrl_set_debug_chain(sgrl_set* s, int kind, const float* A, int lda, int K, const float* Wp, const float* W1, const float* b1, int hid,
                          const float* W2, const float* b2, float* C, int ldc, int M, const float* rowdiv, const float* ln, float* zc,
                          float* z2, float* fn, void* stream);
+/* Diagnostics of the row scaling (csrc/gemm_f32.h): workgroups of the two-piece products that had to repeat a tile because a
+ * sampled estimate of a row's magnitude fell short, since the last reset (process-wide; synchronises the device; -1 on error).
+ * Zero on every input a working policy produces -- the tests and the bench line say so. */
+long long sgrl_set_debug_redos(int reset);
 const char* sgrl_set_last_error(void);
 
 #ifdef __cplusplus

@@ -66,6 +66,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
   const int m0 = blockIdx.x * R;
   const int kq = t & 3, r4 = t >> 2;            // staging: float4 kq of tile row r4 (+ 128 i)
   __shared__ float rs_sh[R];                    // 1 / scale of the workgroup's A rows (phase 1)
+  __shared__ float as_sh[SRC == 1 ? R : 1];     // Gram operand: the scale itself
   __shared__ float px_sh[PROJ ? 192 : 1];       // 1 / scale of its X rows (projection prologue)
   __shared__ float hm_sh[R * 4];                // row maxima of the intermediate, per hidden group
   __shared__ unsigned redo_sh;
@@ -120,13 +121,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
       for (int j = 0; j < PROJ; j++)
 #pragma unroll
         for (int e = 0; e < 16; e++) { pacc[j][e] = 0.f; pcor[j][e] = 0.f; }
+      // samples of each row's middle (staging thread 0 of the row) and last k-tile (thread 1), four values each, in flight with tile 0
+      float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+      if (attempt == 0 && kq < 2) {
+        const int ks = (kq == 0 ? (nkp >> 1) : nkp - 1) * 16 - 4 * kq;
+        s0 = *reinterpret_cast<const float4*>(xr0 + ks);
+        if (lowh) s1 = *reinterpret_cast<const float4*>(xr1 + ks);
+      }
       pload(0);
-      if (attempt == 0) {                     // estimates from three sampled k-tiles of each row (gemm_f32.h, pow2_scale)
+      if (attempt == 0) {                     // estimates of the rows' magnitudes (gemm_f32.h, pow2_scale)
         auto m4 = [](const float4& v, float m) { m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), m); return fmaxf(fmaxf(fabsf(v.z), fabsf(v.w)), m); };
-        const int km = (nkp >> 1) * 16, kl = (nkp - 1) * 16;
-        float e0 = m4(x0v, 0.f), e1 = lowh ? m4(x1v, 0.f) : 0.f;
-        e0 = m4(*reinterpret_cast<const float4*>(xr0 + km), e0); e0 = m4(*reinterpret_cast<const float4*>(xr0 + kl), e0);
-        if (lowh) { e1 = m4(*reinterpret_cast<const float4*>(xr1 + km), e1); e1 = m4(*reinterpret_cast<const float4*>(xr1 + kl), e1); }
+        float e0 = m4(s0, m4(x0v, 0.f)), e1 = lowh ? m4(s1, m4(x1v, 0.f)) : 0.f;
         psc[0] = pow2_scale(quad_max(e0), kScaleEstimate);
         psc[1] = pow2_scale(quad_max(e1), kScaleEstimate);
       }
@@ -151,12 +156,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
             pcor[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, pcor[j], 0, 0, 0);
           }
         }
+        if (kt == nkp - 1 && (!(pmx[0] <= kF16Lim) || !(pmx[1] <= kF16Lim))) redo_sh = 1u;   // the vote rides on the last barrier
         __syncthreads();
       }
       if (attempt == 1) break;
-      if (!(pmx[0] <= kF16Lim) || !(pmx[1] <= kF16Lim)) redo_sh = 1u;
-      __syncthreads();
       if (redo_sh == 0u) break;               // (block-uniform) the usual exit
+      if (t == 0) atomicAdd(&g_scale_redos, 1u);
       {                                       // the rare path: exact maxima of this thread's X rows (read again), then once more
         float t0 = 0.f, t1 = 0.f;
         for (int kt = 0; kt < nkp; kt++) {
@@ -201,7 +206,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
   const unsigned* wrow_g[TN];
 #pragma unroll
   for (int i = 0; i < TN; i++) wrow_g[i] = a.W1 + (size_t)(r4 + 128 * i) * a.ldw1 + 4 * kq;
-  float4 ra[2], rw[2][TN];
+  // global loads run PF k-tiles ahead of the LDS stage they are written to: two for a loaded first operand (it streams from HBM), one
+  // for the Gram form (only W is loaded, out of L2; the eight registers are what keeps its loop free of spills)
+  constexpr int PF = SRC == 1 ? 1 : 2;
+  float4 ra[PF], rw[PF][TN];
   float asc = 1.f, amx = 0.f;                   // scale of this staging thread's A row | its largest magnitude so far
   float gza[3];
   float4 gzb[3];
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     for (int sx = 0; sx < 3; sx++) gzb[sx] = *reinterpret_cast<const float4*>(arow_g + 32 * sx + 4 * gb);
     if (gb == 0) {
 #pragma unroll
-      for (int sx = 0; sx < 3; sx++) gza[sx] = arow_g[32 * sx + 4 * ga + kq] * asc;      // the Gram entries scaled by the row's power of two
+      for (int sx = 0; sx < 3; sx++) gza[sx] = arow_g[32 * sx + 4 * ga + kq] * as_sh[r4 & 63];      // the Gram entries scaled by the row's power of two (kept in LDS: eight reads per workgroup, no register)
     }
     if (++gb > ga) { ga++; gb = 0; }
   };
@@ -258,9 +266,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     }
     const float frob = sqrtf((c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + 2.f * (c[3] * c[3] + c[4] * c[4] + c[5] * c[5]));
     if (kq == 0 && m0 + r4 < a.M && a.fn_out) a.fn_out[m0 + r4] = frob + 1.0f;
-    asc = pow2_scale(frob, kScaleExact);
-    if (kq == 0) rs_sh[r4] = pow2_inv(asc);
+    const float gs = pow2_scale(frob, kScaleExact);
+    if (kq == 0) { rs_sh[r4] = pow2_inv(gs); as_sh[r4] = gs; }
   }
+  if (SRC == 1) __syncthreads();                // as_sh is read by the row's four staging threads
   const int nk = a.K1 / 16;
   const int aoff = (wm * 32 + li) * RB + 16 * lh;
   const int boff = 2 * kPlaneA + (wn * 32 * TN + li) * RB + 16 * lh;
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     if (!late) {
       if (kt + 1 < nk) sstore(slot, st ^ 1);
       if (SRC == 1 && stage_a && kt + 2 < nk) gload_gram();
-      if (kt + 3 < nk) gload(slot, (kt + 3) * 16);
+      if (kt + 1 + PF < nk) gload(slot, (kt + 1 + PF) * 16);
     }
     const char* base = lds + st * kStage1;
     const f16x8 ah = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(base + aoff));
@@ -285,20 +294,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     }
     if (late) {
       if (kt + 1 < nk) sstore(slot, st ^ 1);
-      if (kt + 3 < nk) gload(slot, (kt + 3) * 16);
+      if (kt + 1 + PF < nk) gload(slot, (kt + 1 + PF) * 16);
     }
+    if (SRC == 0 && kt == nk - 1 && !(amx <= kF16Lim)) redo_sh = 1u;       // the vote on repeating rides on the last barrier
     __syncthreads();
   };
   for (int attempt = 0;; attempt++) {
     if (SRC == 1 && stage_a) { ga = 0; gb = 0; gload_gram(); }
+    float4 sma = make_float4(0.f, 0.f, 0.f, 0.f);      // a sample of the row's middle (staging thread 0) / last (thread 1) k-tile, in flight with tile 0
+    if (SRC == 0 && stage_a && attempt == 0 && kq < 2) sma = *reinterpret_cast<const float4*>(arow_g - 4 * kq + (kq == 0 ? (nk >> 1) : nk - 1) * 16);
     gload(0, 0);
     if (SRC == 0 && stage_a) {
       if (attempt == 0) {                       // estimate from three sampled k-tiles of the row (gemm_f32.h, pow2_scale)
         auto m4 = [](const float4& v, float m) { m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), m); return fmaxf(fmaxf(fabsf(v.z), fabsf(v.w)), m); };
-        float e = m4(ra[0], 0.f);
-        e = m4(*reinterpret_cast<const float4*>(arow_g + (nk >> 1) * 16), e);
-        e = m4(*reinterpret_cast<const float4*>(arow_g + (nk - 1) * 16), e);
-        asc = pow2_scale(quad_max(e), kScaleEstimate);
+        asc = pow2_scale(quad_max(m4(sma, m4(ra[0], 0.f))), kScaleEstimate);
       }
       if (kq == 0) rs_sh[r4] = pow2_inv(asc);
     }
@@ -306,14 +315,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     __syncthreads();
     if (SRC == 1 && stage_a && nk > 1) gload_gram();
     if (nk > 1) gload(0, 16);
-    if (nk > 2) gload(1, 32);
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) { body(kt, 0); body(kt + 1, 1); }
-    if (kt < nk) body(kt, 0);
+    if (PF == 2 && nk > 2) gload(PF - 1, 32);
+    if (PF == 1) {
+      for (int kt = 0; kt < nk; kt++) body(kt, 0);
+    } else {
+      int kt = 0;
+      for (; kt + 1 < nk; kt += 2) { body(kt, 0); body(kt + 1, PF - 1); }
+      if (kt < nk) body(kt, 0);
+    }
     if (SRC != 0 || attempt == 1) break;
-    if (!(amx <= kF16Lim)) redo_sh = 1u;
-    __syncthreads();
     if (redo_sh == 0u) break;                   // (block-uniform) the usual exit: the estimate held
+    if (t == 0) atomicAdd(&g_scale_redos, 1u);
     {                                           // the rare path: the exact maximum of this thread's A row (read again), then once more
       float tm = 0.f;
       if (stage_a)

@@ -242,8 +242,9 @@ __device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return _
 // pieces are taken of the scaled values, and the epilogue multiplies the result by the two inverse powers (exact again):
 //   * weights: k_encode_rows scales each row by its exact maximum when the flat weight buffer is rebuilt (once per forward);
 //   * generated Gram rows: by ||Z'Z||_F, which bounds every entry and is computed in the kernel's prologue anyway;
-//   * loaded activation rows: by an ESTIMATE -- the largest magnitude in three sampled k-tiles of the row (first, middle, last: the
-//     operands of the forward are concatenations such as [invariants | scalars] whose halves differ in size), placed at 2^6:
+//   * loaded activation rows: by an ESTIMATE -- the largest magnitude in the row's first k-tile and in the first four values of
+//     its middle and last k-tiles (the operands of the forward are concatenations such as [invariants | scalars] whose halves
+//     differ in size), placed at 2^6:
 //     512 x headroom above, 20 octaves of full precision below; the staging threads keep the largest scaled magnitude they
 //     split, and a workgroup that did meet a value beyond the headroom repeats its tile with the exact row maxima -- a
 //     block-uniform branch for data no sane network state produces, so the common case costs two extra loads per staging
@@ -263,6 +264,9 @@ __device__ __forceinline__ float pow2_scale(float est, int target) {
   const int se = est > 0.f ? min(max(target - e, -100), 100) : 0;
   return __uint_as_float((unsigned)(se + 127) << 23);
 }
+// diagnostics: workgroups that repeated a tile / a phase with exact row maxima since the counter was last cleared (the rare path;
+// tests assert that sane inputs never take it: sgrl_set_debug_redos)
+__device__ unsigned g_scale_redos;
 __device__ __forceinline__ float pow2_inv(float s) { return __uint_as_float(0x7F000000u - __float_as_uint(s)); }   // 1 / 2^k, exact
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2h(float x0, float x1, unsigned& h, unsigned& l) {
@@ -535,6 +539,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
   const int aoff = (wm * 32 * TM + li) * RB + 16 * lh;        // this lane's 8 bf16 of k-step 0; k-step 1 is 32 bytes on
   const int boff = NPL * Cfg::kPlaneA + (wn * 32 * TN + li) * RB + 16 * lh;
   const bool late = SKEW ? (wave >= 4) : LATE;                   // wave-uniform
+  constexpr bool EST = SCL && !GRAM && !PLA;  // loaded f32 activation rows: scaled by an estimate, repeated with the exact maxima if it fell short
   auto body = [&](int kt, int slot) {
     const int st = kt & 1;
     if (!late && ABL != 1) {
@@ -597,22 +602,31 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
       if (GRAM && kt + 2 < nk) gload_gram();
       if (kt + 1 + PF < nk) gload(slot, (kt + 1 + PF) * BKT);
     }
+    if (EST && kt == nk - 1) {                // every tile has been split by now: the vote on repeating rides on the last barrier
+      bool over = false;
+#pragma unroll
+      for (int i = 0; i < NPA; i++) over = over || !(amx[i] <= kF16Lim);
+      if (over) redo_sh = 1u;
+    }
     __syncthreads();
   };
-  constexpr bool EST = SCL && !GRAM && !PLA;  // loaded f32 activation rows: scaled by an estimate, repeated with the exact maxima if it fell short
   for (int attempt = 0;; attempt++) {
     if (GRAM) { ga = 0; gb = 0; gload_gram(); }
+    // two more samples of each row, in flight with tile 0: the first four values of its middle k-tile (staging thread 0 of the row)
+    // and of its last one (thread 1) -- 32 bytes per row, not two more tiles: every workgroup of a dispatch round starts at once
+    float4 smp[NPA];
+    if (EST && attempt == 0) {
+#pragma unroll
+      for (int i = 0; i < NPA; i++)
+        smp[i] = kq < 2 ? *reinterpret_cast<const float4*>(arow_g[i] - 4 * kq + (kq == 0 ? (nk >> 1) : nk - 1) * BKT) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     gload(0, 0);
     if (EST && attempt == 0) {
 #pragma unroll
       for (int i = 0; i < NPA; i++) {
-        const float4 v0 = ra[0][i];
+        const float4 v0 = ra[0][i], v1 = smp[i];
         float est = fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w)));
-        if (nk > 2) {                          // two more samples of the row: its middle and its last k-tile
-          const float4 v1 = *reinterpret_cast<const float4*>(arow_g[i] + (nk >> 1) * BKT), v2 = *reinterpret_cast<const float4*>(arow_g[i] + (nk - 1) * BKT);
-          est = fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), est); est = fmaxf(fmaxf(fabsf(v1.z), fabsf(v1.w)), est);
-          est = fmaxf(fmaxf(fabsf(v2.x), fabsf(v2.y)), est); est = fmaxf(fmaxf(fabsf(v2.z), fabsf(v2.w)), est);
-        }
+        est = fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), est); est = fmaxf(fmaxf(fabsf(v1.z), fabsf(v1.w)), est);
         asc[i] = pow2_scale(quad_max(est), kScaleEstimate);
       }
     }
@@ -633,14 +647,8 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
       if (kt < nk) body(kt, 0);
     }
     if (!EST || attempt == 1) break;
-    {
-      bool over = false;
-#pragma unroll
-      for (int i = 0; i < NPA; i++) over = over || !(amx[i] <= kF16Lim);
-      if (over) redo_sh = 1u;
-    }
-    __syncthreads();
     if (redo_sh == 0u) break;                 // (block-uniform) the usual exit: no scaled value left the f16 range
+    if (t == 0) atomicAdd(&g_scale_redos, 1u);
     // the rare path: exact maxima of the rows this thread stages (its quarter of every k-tile, read again), then once more
 #pragma unroll
     for (int i = 0; i < NPA; i++) {
@@ -680,17 +688,17 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
 #pragma unroll
     for (int tj = 0; tj < TN; tj++) {
       const int cidx = (n0 + wn * 32 * TN + tj * 32) >> 5;
+      const float un = (SCL && a.wscale) ? rsn * a.wscale[cidx * 32] : rsn;
       float ts[3] = {0.f, 0.f, 0.f};
 #pragma unroll
       for (int g4 = 0; g4 < 4; g4++) {
         const int q0 = 8 * g4 + 4 * lh;
         const float4 b4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + cidx * 32 + q0) : make_float4(0, 0, 0, 0);
-        float4 u4 = make_float4(rsn, rsn, rsn, rsn);                 // undo the row scales of A (node) and W (rows c * 32 + q)
-        if (SCL && a.wscale) { const float4 w4 = *reinterpret_cast<const float4*>(a.wscale + cidx * 32 + q0); u4 = make_float4(rsn * w4.x, rsn * w4.y, rsn * w4.z, rsn * w4.w); }
-        const float v0 = fin(acc[0][tj][4 * g4 + 0], cor[0][tj][4 * g4 + 0]) * u4.x + b4.x;
-        const float v1 = fin(acc[0][tj][4 * g4 + 1], cor[0][tj][4 * g4 + 1]) * u4.y + b4.y;
-        const float v2 = fin(acc[0][tj][4 * g4 + 2], cor[0][tj][4 * g4 + 2]) * u4.z + b4.z;
-        const float v3 = fin(acc[0][tj][4 * g4 + 3], cor[0][tj][4 * g4 + 3]) * u4.w + b4.w;
+        // undo the row scales of A (this lane's node) and W (ONE scale per 32-row block c: EncMat::group -- a scalar, not a vector)
+        const float v0 = fin(acc[0][tj][4 * g4 + 0], cor[0][tj][4 * g4 + 0]) * un + b4.x;
+        const float v1 = fin(acc[0][tj][4 * g4 + 1], cor[0][tj][4 * g4 + 1]) * un + b4.y;
+        const float v2 = fin(acc[0][tj][4 * g4 + 2], cor[0][tj][4 * g4 + 2]) * un + b4.z;
+        const float v3 = fin(acc[0][tj][4 * g4 + 3], cor[0][tj][4 * g4 + 3]) * un + b4.w;
 #pragma unroll
         for (int sx = 0; sx < 3; sx++) {
           const float4 z4 = *reinterpret_cast<const float4*>(zs + mloc * ZS + sx * 32 + q0);
@@ -860,7 +868,9 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
 // Weights of the two-piece form: every row of every product matrix of the flat weight buffer, scaled by the power of two that
 // brings its largest magnitude to 2^14 .. 2^15 and cut into words (once per forward, behind the packer).  One wave per row;
 // wsc[first_row + r] receives the INVERSE scale of row r (what the consumer's epilogue multiplies by).
-struct EncMat { long long off; int rows, K, first_row; };          // K % 4 == 0, K <= 1024; rows of the matrix contiguous in `w`
+// group = 32: the rows of every aligned block of 32 share one scale (the 32 x 32 matrix blocks of linear4 / linear2_m, whose
+// equivariant epilogue then undoes ONE scale per block); group = 1: a scale per row
+struct EncMat { long long off; int rows, K, first_row, group; };   // K % 4 == 0, K <= 1024; rows of the matrix contiguous in `w`
 __global__ __launch_bounds__(256) void k_encode_rows(const float* __restrict__ w, unsigned* __restrict__ ww, float* __restrict__ wsc,
                                                      const EncMat* __restrict__ mats, int n_mats, int total_rows) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -880,6 +890,17 @@ __global__ __launch_bounds__(256) void k_encode_rows(const float* __restrict__ w
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if (mt.group == 32) {                       // the maximum over the block of 32 rows (8 workgroups of 4 rows, all of this matrix)
+    const float* blk = w + mt.off + (long long)((row - mt.first_row) & ~31) * mt.K;
+    float bm = 0.f;
+    for (int i = lane; i < 8 * mt.K; i += 64) {
+      const float4 x = *reinterpret_cast<const float4*>(blk + 4 * i);
+      bm = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), bm); bm = fmaxf(fmaxf(fabsf(x.z), fabsf(x.w)), bm);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bm = fmaxf(bm, __shfl_xor(bm, o, 64));
+    mx = bm;
+  }
   const float sc = pow2_scale(mx, kScaleExact);
 #pragma unroll
   for (int q = 0; q < 4; q++) {

@@ -879,20 +879,45 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   g_gemm.enc_index = &s->enc_index;
   NodeTab nt{s->d_node_env, s->d_node_limb, s->d_node_mnode, s->d_trav, s->TM};
   EnvTab et{s->d_env_off, s->d_env_L, s->d_env_relb};
+  const bool small = N <= (s->small_nodes >= 0 ? s->small_nodes : small_nodes());
+  // Independent GEMM chains go to the side stream: fork() makes it wait for everything issued so far on `st`, join()
+  // makes `st` wait for it.  The chains' store-heavy epilogues and partial last tile waves overlap each other.
+  // While `st` is being captured into a hipGraph (the TD3 update graphs, td3.GraphedUpdates: batches of 100 environments,
+  // where every kernel is far too small to gain from overlap) everything stays on ONE stream: a graph with cross-stream
+  // forks costs ~7 us of hipGraphLaunch CPU time per node on this ROCm, a single-stream graph ~0.4 us.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cap);
+  static const bool serial_env = [] { const char* e = getenv("SGRL_SET_ONE_STREAM"); return e && e[0] == '1'; }();   // diagnostics: per-kernel times without overlap
+  const bool one_stream = small || cap != hipStreamCaptureStatusNone || serial_env;
+  if (!one_stream && sgrl_streams::enabled() && s->side_picks < 6 &&
+      std::find(s->side_ok_for.begin(), s->side_ok_for.end(), st) == s->side_ok_for.end()) {
+    // first forward on this caller stream: make sure the side stream sits on another hardware queue (stream_pick.h)
+    s->side_picks++;
+    hipStream_t chosen = sgrl_streams::pick({st}, s->side);
+    if (chosen != s->side) s->side_ok_for.clear();     // a new side stream: nothing is known about the other callers
+    s->side = chosen;
+    s->side_ok_for.push_back(st);
+  }
+  hipStream_t sd = one_stream ? st : s->side;
+  auto fork = [&]() { if (!one_stream) { (void)hipEventRecord(s->ev_fork, st); (void)hipStreamWaitEvent(sd, s->ev_fork, 0); } };
+  auto join = [&]() { if (!one_stream) { (void)hipEventRecord(s->ev_join, sd); (void)hipStreamWaitEvent(st, s->ev_join, 0); } };
   (void)hipMemsetAsync(act, 0, sizeof(float) * (size_t)s->n_env * act_ld, st);
   if (s->live)           // live weights: flat buffer (and the stacked projection operands in it) rebuilt from the parameters
     hipLaunchKernelGGL(k_pack, dim3(s->n_chunks), dim3(256), 0, st, s->d_segs, s->d_chunks, s->d_tri, s->wflat);
-  if (s->live && g_gemm.form == SGRL_SET_FORM_F16X3 && gemm_use_split())     // the product matrices as row-scaled words
-    hipLaunchKernelGGL(sgrl_gemm::k_encode_rows, dim3((s->enc_rows + 3) / 4), dim3(256), 0, st, s->wflat, s->wwords, s->wsc, s->d_enc, s->n_enc,
+  const bool encode = s->live && !small && g_gemm.form == SGRL_SET_FORM_F16X3 && gemm_use_split();
+  if (encode) {          // the product matrices as row-scaled words: beside the embedding, which reads the f32 buffer only
+    fork();
+    hipLaunchKernelGGL(sgrl_gemm::k_encode_rows, dim3((s->enc_rows + 3) / 4), dim3(256), 0, sd, s->wflat, s->wwords, s->wsc, s->d_enc, s->n_enc,
                        s->enc_rows);
+  }
   hipLaunchKernelGGL(k_relbias, dim3(s->n_morph), dim3(256), 0, st, s->d_rel, s->W(SGRL_SET_REL_W), s->W(SGRL_SET_REL_B),
                      s->d_relb, s->d_m_off, s->d_m_L, s->n_morph);
   hipLaunchKernelGGL(k_embed, dim3((N + kEmbedNodes - 1) / kEmbedNodes), dim3(128), 0, st, obs, obs_ld, action, action_ld, ngf, nt,
                      s->W(SGRL_SET_GENC), s->W(SGRL_SET_ENC_W), s->W(SGRL_SET_ENC_B), s->W(SGRL_SET_EMB0), s->W(SGRL_SET_EMB1),
                      s->W(SGRL_SET_EMB2), s->g, s->cat, s->outg, s->outng, s->gdir, s->zc, s->z2, N);
+  if (encode) join();
   float* ng = s->cat + 128;
   int rc = SGRL_OK;
-  const bool small = N <= (s->small_nodes >= 0 ? s->small_nodes : small_nodes());
   // back-to-back products as one kernel each: the tile path in its two-piece form on bound (pre-split) weights
   const bool chain = !small && chain_enabled() && gemm_use_split() && g_gemm.form == SGRL_SET_FORM_F16X3;
   float* const scratch = s->qkv;      // small path: [N, 576] Gram triangle / [N, 1024] per-node matrices (spans qkv | vg)
@@ -944,26 +969,6 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   };
 #define PG(...) do { rc = pg(__VA_ARGS__); if (rc != SGRL_OK) return rc; } while (0)
   const int lnb = (N + 3) / 4;
-  // Independent GEMM chains go to the side stream: fork() makes it wait for everything issued so far on `st`, join()
-  // makes `st` wait for it.  The chains' store-heavy epilogues and partial last tile waves overlap each other.
-  // While `st` is being captured into a hipGraph (the TD3 update graphs, td3.GraphedUpdates: batches of 100 environments,
-  // where every kernel is far too small to gain from overlap) everything stays on ONE stream: a graph with cross-stream
-  // forks costs ~7 us of hipGraphLaunch CPU time per node on this ROCm, a single-stream graph ~0.4 us.
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  (void)hipStreamIsCapturing(st, &cap);
-  const bool one_stream = small || cap != hipStreamCaptureStatusNone;
-  if (!one_stream && sgrl_streams::enabled() && s->side_picks < 6 &&
-      std::find(s->side_ok_for.begin(), s->side_ok_for.end(), st) == s->side_ok_for.end()) {
-    // first forward on this caller stream: make sure the side stream sits on another hardware queue (stream_pick.h)
-    s->side_picks++;
-    hipStream_t chosen = sgrl_streams::pick({st}, s->side);
-    if (chosen != s->side) s->side_ok_for.clear();     // a new side stream: nothing is known about the other callers
-    s->side = chosen;
-    s->side_ok_for.push_back(st);
-  }
-  hipStream_t sd = one_stream ? st : s->side;
-  auto fork = [&]() { if (!one_stream) { (void)hipEventRecord(s->ev_fork, st); (void)hipStreamWaitEvent(sd, s->ev_fork, 0); } };
-  auto join = [&]() { if (!one_stream) { (void)hipEventRecord(s->ev_join, sd); (void)hipStreamWaitEvent(st, s->ev_join, 0); } };
 #define GS(...) do { rc = small ? small_gemm(sd, __VA_ARGS__) : launch_gemm(sd, __VA_ARGS__); if (rc != SGRL_OK) return rc; } while (0)
   for (int l = 0; l < SGRL_SET_LAYERS; l++) {
     // --- attention ---
@@ -1206,20 +1211,20 @@ int sgrl_set_bind_params(sgrl_set* s, const sgrl_pack_seg* segs, int n_segs, con
     std::vector<sgrl_gemm::EncMat> mats;
     s->enc_index.clear();
     int rows_total = 0;
-    auto add = [&](int64_t off, int rows, int K) {
+    auto add = [&](int64_t off, int rows, int K, int group = 1) {
       const int64_t next = *std::upper_bound(bounds.begin(), bounds.end(), off);
       if (next - off < (int64_t)rows * K) return;
-      mats.push_back(sgrl_gemm::EncMat{off, rows, K, rows_total});
+      mats.push_back(sgrl_gemm::EncMat{off, rows, K, rows_total, group});
       s->enc_index.emplace_back(off, rows_total);
       rows_total += rows;
     };
     add(offsets[SGRL_SET_L1G_W], 128, GK); add(offsets[SGRL_SET_L2G_W], 128, 128);
     add(offsets[SGRL_SET_L1NG_W], 128, 160); add(offsets[SGRL_SET_L2NG_W], 128, 128);
-    add(offsets[SGRL_SET_L1M_W], 256, 256); add(offsets[SGRL_SET_L2M_W], 1024, 256);
+    add(offsets[SGRL_SET_L1M_W], 256, 256); add(offsets[SGRL_SET_L2M_W], 1024, 256, 32);
     for (int l = 0; l < SGRL_SET_LAYERS; l++) {
       const int64_t* o = offsets + SGRL_SET_NGLOBAL + l * SGRL_SET_NLAYER;
       add(o[SGRL_SET_A_LG1_W], 256, GK); add(o[SGRL_SET_A_LG2_W], 128, 256); add(o[SGRL_SET_QKV_W], 768, 256); add(o[SGRL_SET_VG_W], 256, 128);
-      add(o[SGRL_SET_F_LG1_W], 256, GK); add(o[SGRL_SET_F_LG2_W], 128, 256); add(o[SGRL_SET_L3_W], 256, 256); add(o[SGRL_SET_L4_W], 1024, 256);
+      add(o[SGRL_SET_F_LG1_W], 256, GK); add(o[SGRL_SET_F_LG2_W], 128, 256); add(o[SGRL_SET_L3_W], 256, 256); add(o[SGRL_SET_L4_W], 1024, 256, 32);
       add(o[SGRL_SET_L1_W], 256, 256); add(o[SGRL_SET_L2_W], 128, 256);
     }
     for (int k = 0; k < SGRL_SET_NSITES; k++) add(offsets[SGRL_SET_NW + k], 64, k == 6 ? OGLD : 128);
@@ -1400,8 +1405,8 @@ namespace {
 struct TempWords {
   unsigned* w = nullptr; float* sc = nullptr; sgrl_gemm::EncMat* dm = nullptr;
   ~TempWords() { if (w) (void)hipFree(w); if (sc) (void)hipFree(sc); if (dm) (void)hipFree(dm); }
-  int make(hipStream_t st, const float* W, int rows, int K) {
-    const sgrl_gemm::EncMat m{0, rows, K, 0};
+  int make(hipStream_t st, const float* W, int rows, int K, int group = 1) {
+    const sgrl_gemm::EncMat m{0, rows, K, 0, group};
     if (hipMalloc(&w, sizeof(unsigned) * (size_t)rows * K) != hipSuccess || hipMalloc(&sc, sizeof(float) * rows) != hipSuccess ||
         hipMalloc(&dm, sizeof(m)) != hipSuccess || hipMemcpy(dm, &m, sizeof(m), hipMemcpyHostToDevice) != hipSuccess)
       return sfail(SGRL_ERR_HIP, "debug product: allocation failed");
@@ -1434,7 +1439,7 @@ int sgrl_set_debug_product(sgrl_set* s, int kind, int form, const float* A, int 
   g_gemm.w_words = nullptr; g_gemm.wsc = nullptr; g_gemm.enc_index = nullptr;
   if (form == SGRL_SET_FORM_F16X3) {
     if (ldw != K) return sfail(SGRL_ERR_ARG, "debug product: the two-piece form takes W rows of K contiguous floats");
-    if (tw.make(st, W, N, K) != SGRL_OK) return SGRL_ERR_HIP;
+    if (tw.make(st, W, N, K, kind == 4 ? 32 : 1) != SGRL_OK) return SGRL_ERR_HIP;
     g_gemm.w_words = tw.w; g_gemm.wsc = tw.sc; g_gemm.enc_index = &index;
   }
   int rc = SGRL_OK;
@@ -1525,6 +1530,14 @@ int sgrl_set_debug_chain(sgrl_set* s, int kind, const float* A, int lda, int K, 
   if (rc == SGRL_OK && le != hipSuccess) rc = sfail(SGRL_ERR_HIP, std::string("debug chain: launch failed: ") + hipGetErrorString(le));
   (void)hipStreamSynchronize(st);
   return rc;
+}
+
+long long sgrl_set_debug_redos(int reset) {
+  unsigned n = 0;
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(&n, HIP_SYMBOL(sgrl_gemm::g_scale_redos), sizeof(n)) != hipSuccess) return -1;
+  const unsigned zero = 0;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(sgrl_gemm::g_scale_redos), &zero, sizeof(zero)) != hipSuccess) return -1;
+  return (long long)n;
 }
 
 const char* sgrl_set_last_error(void) { return g_set_err.c_str(); }

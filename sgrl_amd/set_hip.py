@@ -43,6 +43,8 @@ def _bind(L):
     L.sgrl_set_debug_small_nodes.argtypes = [vp, ctypes.c_int]
     L.sgrl_set_gemm_form.argtypes = [vp, ctypes.c_int]
     L.sgrl_set_last_error.restype = ctypes.c_char_p
+    L.sgrl_set_debug_redos.argtypes = [ctypes.c_int]
+    L.sgrl_set_debug_redos.restype = ctypes.c_longlong
     ci = ctypes.c_int
     L.sgrl_set_debug_product.argtypes = [vp, ci, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp]
     L.sgrl_set_debug_chain.argtypes = [vp, ci, vp, ci, ci, vp, vp, vp, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp]
@@ -433,6 +435,11 @@ class HipSetActor(object):
         """Form of the tile products (include/sgrl_set.h): FORM_F16X3 (default: two f16 pieces of every row-scaled operand,
         float32's range), FORM_BF16X6 (three bf16 pieces, slower; A/B comparisons), 0 = default."""
         _check(self.L, self.L.sgrl_set_gemm_form(self.h, int(form)), "sgrl_set_gemm_form")
+
+    def scale_redos(self, reset=True):
+        """Workgroups that repeated a tile with exact row maxima since the last reset (include/sgrl_set.h sgrl_set_debug_redos;
+        process-wide, synchronises): 0 unless an operand row's sampled estimate was more than 512 x below its maximum."""
+        return int(self.L.sgrl_set_debug_redos(1 if reset else 0))
 
     def peek(self, which, per_node):
         out = np.zeros((self.num_nodes, per_node), dtype=np.float32)

@@ -71,7 +71,7 @@ struct Wt { unsigned* w; float* sc; };
 static Wt words(const float* w, int rows, int K) {
   Wt r;
   CK(hipMalloc(&r.w, (size_t)rows * K * 4)); CK(hipMalloc(&r.sc, (size_t)rows * 4));
-  EncMat m{0, rows, K, 0};
+  EncMat m{0, rows, K, 0, 1};
   EncMat* dm; CK(hipMalloc(&dm, sizeof(EncMat))); CK(hipMemcpy(dm, &m, sizeof(EncMat), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_encode_rows, dim3((rows + 3) / 4), dim3(256), 0, 0, w, r.w, r.sc, dm, 1, rows);
   return r;

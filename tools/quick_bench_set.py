@@ -15,7 +15,9 @@ act.configure(gds, [per] * len(names))
 obs = torch.randn((per * len(names), 287), device="cuda") * 0.5
 out = act.forward_batch(obs)
 torch.cuda.synchronize()
+act.scale_redos()
 ms = act.time_forward(obs, out, 5)
 nodes = act.num_nodes
+print("tile repeats (row-scale estimates that fell short) in the timed forwards:", act.scale_redos())
 print("envs %d nodes %d: %.3f ms/forward = %.2f us/env-step, %.1f TFLOP/s (10.07 MFLOP/node)" % (
     per * len(names), nodes, ms, ms * 1e3 / (per * len(names)), nodes * 10.07e6 / (ms * 1e-3) / 1e12))
