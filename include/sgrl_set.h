@@ -179,6 +179,8 @@ int sgrl_set_debug_product(sgrl_set* s, int kind, int form, const float* A, int 
  *        1  C = LayerNorm(C + (relu(A W1' + b1) W2' + b2) / rowdiv)            hid = 256; C [M, ldc] read and rewritten; ln = ln_w | ln_b [256]
  *        2  projection site: X = A [3 M, K] -> Z (zc, z2 [3 M, 32]; z2 may be null; columns 30, 31 untouched), fn [M] = ||Z'Z||_F + 1,
  *           C[:, 0:128] = relu(G(Z) W1' + b1) W2' + b2 with Wp [64, K] the stacked projections, W1 [hid, 576] in the folded Gram order
+ *        3  equivariant pair (linear3 -> ReLU -> linear4 -> contraction): C [M, 96] = tout[m][s][c] = sum_q zq[m][s][q] *
+ *           (relu(A W1' + b1) W2' + b2)[m][c * 32 + q] / rowdiv[m]; hid = 256, W2 [1024, 256], b2 [1024], zq [M, 96] passed in `ln`
  * Synchronises `stream`. */
 int sgrl_set_debug_chain(sgrl_set* s, int kind, const float* A, int lda, int K, const float* Wp, const float* W1, const float* b1, int hid,
                          const float* W2, const float* b2, float* C, int ldc, int M, const float* rowdiv, const float* ln, float* zc,

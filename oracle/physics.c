@@ -662,8 +662,8 @@ static void solve_constraints(const SgrlModelView* m, Work* w) {
     w->pgs_iters_used = it + 1;
     if (change < thresh) break;
   }
-  /* the warm-start memory keeps the first 48 rows (the engine's LDS arrays: step_body.h kPrevRows) */
-  w->prev_n = n < 48 ? n : 48;
+  /* the warm-start memory keeps every row (the engine: the first kPrevRows in LDS, the rest in its HBM slab) */
+  w->prev_n = n;
   for (int r = 0; r < w->prev_n; r++) { w->prev_key[r] = w->row_key[r]; w->prev_f[r] = w->efc_f[r]; }
   solve_upper(nv, w->L, v); /* M^-1 J' f = L^-T (Y' f) */
   for (int d = 0; d < nv; d++) w->qacc[d] += v[d];

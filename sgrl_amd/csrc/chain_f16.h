@@ -41,13 +41,27 @@ struct ChainArgs {
   float* zc; float* z2;
   // inverse row scales of the three weight operands (k_encode_rows): ws1 [HID], ws2 [128], wsp [64]
   const float* ws1; const float* ws2; const float* wsp;
+  float* ln_out;                      // EPI_LN: where the normalised rows go (row stride ln_ld); null = in place
+  // EPI_EQUIV (second product N = 1024 in the c * 32 + q order, W2 [1024][HID], b2 [1024], ws2 one scale per 32-row block): the
+  // [M, 1024] result -- a 32 x 32 matrix per row -- is contracted with zq [M, 3, 32] on the fly, only tout [M, 3, 32] is stored
+  const float* zq; float* tout;
+  // ... and, with g != null, the update of the vector stream that consumes tout (reference SEActor.py:89, 108-114) rides on the same
+  // workgroup, which holds all 32 columns of its rows' tout:  g[r][:] += g1[r][:] + tout[r][0:32] . W5[0:128][0:32]^T  for its 3 x 64
+  // rows r = 3 m + s (W5 as row-scaled words, ws5 its inverse scales); outg != null: the new g also into outg[r][8:136] (row
+  // stride outg_ld, zero K-padding columns 136 .. outg_ld - 1)
+  float* g; const float* g1; const unsigned* W5; const float* ws5; float* outg; int outg_ld;
 };
 
 constexpr int kChainRows = 64;
 constexpr int kChainLds = 61440;
+// EPI_EQUIV: two 32-column sub-slice buffers | two W2 stages | the block's z rows (pitch 100 floats) | the bias b2 [1024]
+constexpr int kChainEqSub = 2 * kChainRows * 80, kChainEqW2 = 2 * kChainEqSub, kChainEqZ = kChainEqW2 + 2 * 2 * 128 * 48,
+              kChainEqB = kChainEqZ + kChainRows * 100 * 4, kChainEqLds = kChainEqB + 1024 * 4;
 
 // SRC: 0 loaded operand, 1 Gram operand.  PROJ: 0 none, 1 one projection (zc), 2 two (zc and z2).
-template <int SRC, int HID, int EPI2, int PROJ>
+// DBG (tools/chain_lab.hip only; the results are wrong): 1 = no sub-slice hand-over inside the passes, 2 = no contraction epilogue,
+// 4 = no W2 staging inside the passes -- what each part of the equivariant phase costs
+template <int SRC, int HID, int EPI2, int PROJ, int DBG = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k_chain(ChainArgs a) {
   static_assert(HID == 256 || HID == 128, "hidden width 256 or 128");
   static_assert(PROJ == 0 || SRC == 1, "the projection prologue feeds the Gram operand");
@@ -58,6 +72,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
   constexpr int kSlicePlane = R * SLP, kSliceBuf = 2 * kSlicePlane;
   constexpr int kW2Plane = 128 * RB, kW2Stage = 2 * kW2Plane, kW2Base = 2 * kSliceBuf;
   static_assert(2 * kStage1 <= kChainLds && kW2Base + 2 * kW2Stage <= kChainLds, "LDS image");
+  static_assert(!(EPI2 & EPI_EQUIV) || (HID == 256 && !(EPI2 & EPI_LN) && kChainEqLds >= kChainLds && kChainEqLds <= 80 * 1024), "equivariant second product");
   constexpr float kCorW = 1.f / kF16LowScale;
   extern __shared__ __attribute__((aligned(16))) float gemm_lds[];     // (aligned: static LDS precedes it)
   char* lds = reinterpret_cast<char*>(gemm_lds);
@@ -390,6 +405,165 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
       }
   };
 
+  if constexpr ((EPI2 & EPI_EQUIV) != 0) {
+    // ---- phase 2, equivariant form: 1024 outputs per row in eight passes of 128 (four 32 x 32 matrices blocks c = 4 p + wn) ----------
+    // The planes of the intermediate stay in REGISTERS (Hh / Hl) and are handed to the other waves again in every pass, through two
+    // 32-column sub-slice buffers: k-steps 2 u, 2 u + 1 read sub-slice u from buffer u & 1 while its owners write sub-slice u + 1
+    // into the other one.  Only W2 is staged (the pass's 128 rows, one k-step at a time); z rows and the bias wait in LDS.
+    constexpr int kSubPlane = R * 80, kSubBuf = kChainEqSub;
+    float* zs = reinterpret_cast<float*>(lds + kChainEqZ);
+    float* bs = reinterpret_cast<float*>(lds + kChainEqB);
+    const float* w2base = reinterpret_cast<const float*>(a.W2 + (size_t)r4 * a.ldw2 + 4 * kq);
+    auto w2ptr = [&](int gs) { return w2base + (size_t)(gs >> 4) * 128 * a.ldw2 + (gs & 15) * 16; };
+    auto store2 = [&](const float4& v, int st) { put_words(lds + kChainEqW2 + st * (2 * 128 * RB), 128 * RB, r4, v); };
+    auto write_sub = [&](int u, int buf) {      // sub-slice u = hidden 32 u .. 32 u + 31: tile u & 1 of the waves with wn == u >> 1
+      if (wn == (u >> 1)) {
+        char* sb = lds + buf * kSubBuf + (wm * 32 + li) * 80;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int off = 2 * (8 * g + 4 * lh);
+          *reinterpret_cast<uint2*>(sb + off) = (u & 1) ? Hh[1][g] : Hh[0][g];
+          *reinterpret_cast<uint2*>(sb + kSubPlane + off) = (u & 1) ? Hl[1][g] : Hl[0][g];
+        }
+      }
+    };
+    for (int idx = t; idx < R * 24; idx += 512) {                 // z rows of the block (rows beyond M: the last valid one)
+      const int r = idx / 24, q4 = idx % 24;
+      *reinterpret_cast<float4*>(zs + r * 100 + 4 * q4) = *reinterpret_cast<const float4*>(a.zq + (size_t)min(m0 + r, a.M - 1) * 96 + 4 * q4);
+    }
+    for (int idx = t; idx < 256; idx += 512) *reinterpret_cast<float4*>(bs + 4 * idx) = a.b2 ? *reinterpret_cast<const float4*>(a.b2 + 4 * idx) : make_float4(0, 0, 0, 0);
+    float4 rw2[2];
+    rw2[0] = *reinterpret_cast<const float4*>(w2ptr(0));
+    write_sub(0, 0);
+    store2(rw2[0], 0);
+    __syncthreads();
+    rw2[0] = *reinterpret_cast<const float4*>(w2ptr(1));
+    rw2[1] = *reinterpret_cast<const float4*>(w2ptr(2));
+    const int m = m0 + wm * 32 + li;
+    const bool ok = m < a.M;
+    const float rd = (EPI2 & EPI_ROWDIV) ? 1.0f / a.rowdiv[ok ? m : a.M - 1] : 1.f;
+    const float hsi = pow2_inv(hs);
+    const int hoff = (wm * 32 + li) * 80 + 16 * lh;
+    const int w2off = kChainEqW2 + (wn * 32 + li) * RB + 16 * lh;
+    for (int p = 0; p < 8; p++) {
+      f32x16 acc2, cor2;
+#pragma unroll
+      for (int e = 0; e < 16; e++) { acc2[e] = 0.f; cor2[e] = 0.f; }
+#pragma unroll
+      for (int kt = 0; kt < 16; kt++) {
+        const int gs = 16 * p + kt, st = kt & 1;
+        if (!(DBG & 4)) {
+          if (gs + 1 < 128) store2(rw2[st], st ^ 1);
+          if (gs + 3 < 128) rw2[st] = *reinterpret_cast<const float4*>(w2ptr(gs + 3));
+        }
+        if (!(DBG & 1) && (kt & 1) == 0) write_sub(((kt >> 1) + 1) & 7, ((kt >> 1) + 1) & 1);
+        const char* hb = lds + ((kt >> 1) & 1) * kSubBuf + hoff + 32 * (kt & 1);
+        const f16x8 hh = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(hb));
+        const f16x8 hl = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(hb + kSubPlane));
+        const char* wb = lds + w2off + st * (2 * 128 * RB);
+        const f16x8 wh = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(wb));
+        const f16x8 wl = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(wb + 128 * RB));
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hh, acc2, 0, 0, 0);       // registers = q (W2 rows c * 32 + q), lanes = rows
+        cor2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hl, cor2, 0, 0, 0);
+        cor2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hh, cor2, 0, 0, 0);
+        __syncthreads();
+      }
+      if (DBG & 2) { if (ok && lh == 0 && acc2[0] + cor2[0] == 12345.f) a.tout[m] = 1.f; continue; }
+      // contraction of this pass's block c with the row's three z vectors (16 register FMAs per s, one exchange between the halves)
+      const int c = 4 * p + wn;
+      const float un = hsi * (a.ws2 ? a.ws2[c * 32] : 1.f);
+      float ts[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int q0 = 8 * g + 4 * lh;
+        const float4 b4 = *reinterpret_cast<const float4*>(bs + c * 32 + q0);
+        const float v0 = (acc2[4 * g + 0] + cor2[4 * g + 0] * kCorW) * un + b4.x, v1 = (acc2[4 * g + 1] + cor2[4 * g + 1] * kCorW) * un + b4.y;
+        const float v2 = (acc2[4 * g + 2] + cor2[4 * g + 2] * kCorW) * un + b4.z, v3 = (acc2[4 * g + 3] + cor2[4 * g + 3] * kCorW) * un + b4.w;
+#pragma unroll
+        for (int sx = 0; sx < 3; sx++) {
+          const float4 z4 = *reinterpret_cast<const float4*>(zs + (wm * 32 + li) * 100 + sx * 32 + q0);
+          ts[sx] += z4.x * v0 + z4.y * v1 + z4.z * v2 + z4.w * v3;
+        }
+      }
+#pragma unroll
+      for (int sx = 0; sx < 3; sx++) {
+        float tv = ts[sx] * rd;
+        tv += __shfl_xor(tv, 32, 64);
+        if (ok && lh == 0) a.tout[(size_t)m * 96 + sx * 32 + c] = tv;
+      }
+    }
+    if (a.g == nullptr) return;                 // (uniform over the launch)
+    // ---- the vector stream's update for the block's 192 rows: a [192, 32] x [32, 128] product on the matrix cores ------------------
+    __syncthreads();                            // every wave's tout rows are in memory (same CU) and the LDS is free
+    {
+      constexpr int kTP = 192 * 80, kWB = 2 * kTP, kWP = 128 * 80;        // T planes | W5 planes, rows of 32 f16 + 16 B pad
+      static_assert(kWB + 2 * kWP + 192 * 4 <= kChainEqLds, "LDS image of the update");
+      float* ts_sh = reinterpret_cast<float*>(lds + kWB + 2 * kWP);       // 1 / scale of the 192 T rows (sub-slices, stages, z rows: all dead)
+      const int rows3 = 3 * a.M, x0 = 3 * m0;
+#pragma unroll
+      for (int i = 0; i < 3; i++) {             // T rows: eight staging threads per row, exact row maximum, split, store
+        const int idx = t + 512 * i, r = idx >> 3, q = idx & 7;
+        const float4 v = *reinterpret_cast<const float4*>(a.tout + (size_t)min(x0 + r, rows3 - 1) * 32 + 4 * q);
+        float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64)); mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+        const float sc = pow2_scale(mx, kScaleExact);
+        if (q == 0) ts_sh[r] = pow2_inv(sc);
+        unsigned h0, l0, h1, l1;
+        split2h(v.x * sc, v.y * sc, h0, l0);
+        split2h(v.z * sc, v.w * sc, h1, l1);
+        char* pp = lds + r * 80 + 8 * q;
+        *reinterpret_cast<uint2*>(pp) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(pp + kTP) = make_uint2(l0, l1);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++) {             // W5 words [128][32]
+        const int idx = t + 512 * i, r = idx >> 3, q = idx & 7;
+        const uint4 w = *reinterpret_cast<const uint4*>(a.W5 + (size_t)r * 32 + 4 * q);
+        char* pp = lds + kWB + r * 80 + 8 * q;
+        *reinterpret_cast<uint2*>(pp) = make_uint2(__builtin_amdgcn_perm(w.y, w.x, 0x05040100u), __builtin_amdgcn_perm(w.w, w.z, 0x05040100u));
+        *reinterpret_cast<uint2*>(pp + kWP) = make_uint2(__builtin_amdgcn_perm(w.y, w.x, 0x07060302u), __builtin_amdgcn_perm(w.w, w.z, 0x07060302u));
+      }
+      __syncthreads();
+      const int ct = wave & 3;                  // this wave's 32 output columns; its three row tiles: (wave >> 2) + 2 i
+      const float4 w5s[4] = {*reinterpret_cast<const float4*>(a.ws5 + ct * 32 + 4 * lh), *reinterpret_cast<const float4*>(a.ws5 + ct * 32 + 8 + 4 * lh),
+                             *reinterpret_cast<const float4*>(a.ws5 + ct * 32 + 16 + 4 * lh), *reinterpret_cast<const float4*>(a.ws5 + ct * 32 + 24 + 4 * lh)};
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const int rt = (wave >> 2) + 2 * i, rl = 32 * rt + li, row = x0 + rl;
+        f32x16 ua, uc;
+#pragma unroll
+        for (int e = 0; e < 16; e++) { ua[e] = 0.f; uc[e] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+          const char* tb = lds + rl * 80 + 32 * ks + 16 * lh;
+          const char* wb5 = lds + kWB + (ct * 32 + li) * 80 + 32 * ks + 16 * lh;
+          const f16x8 th = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(tb)), tl = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(tb + kTP));
+          const f16x8 wh = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(wb5)), wl = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(wb5 + kWP));
+          ua = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, th, ua, 0, 0, 0);          // registers = output columns, lanes = rows
+          uc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, tl, uc, 0, 0, 0);
+          uc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, th, uc, 0, 0, 0);
+        }
+        if (row < rows3) {
+          const float rs = ts_sh[rl];
+          float* grow = a.g + (size_t)row * 128 + ct * 32 + 4 * lh;
+          const float* g1row = a.g1 + (size_t)row * 128 + ct * 32 + 4 * lh;
+#pragma unroll
+          for (int gq = 0; gq < 4; gq++) {
+            const float4 x = *reinterpret_cast<const float4*>(grow + 8 * gq), y = *reinterpret_cast<const float4*>(g1row + 8 * gq);
+            const float4 u = w5s[gq];
+            const float4 gn = make_float4(x.x + (y.x + (ua[4 * gq + 0] + uc[4 * gq + 0] * kCorW) * (rs * u.x)), x.y + (y.y + (ua[4 * gq + 1] + uc[4 * gq + 1] * kCorW) * (rs * u.y)),
+                                          x.z + (y.z + (ua[4 * gq + 2] + uc[4 * gq + 2] * kCorW) * (rs * u.z)), x.w + (y.w + (ua[4 * gq + 3] + uc[4 * gq + 3] * kCorW) * (rs * u.w)));
+            *reinterpret_cast<float4*>(grow + 8 * gq) = gn;
+            if (a.outg) *reinterpret_cast<float4*>(a.outg + (size_t)row * a.outg_ld + 8 + ct * 32 + 4 * lh + 8 * gq) = gn;
+          }
+          if (a.outg && ct == 3 && lh == 1) {   // the zero K-padding columns of the read-out operand (136 .. outg_ld - 1)
+            for (int cpad = 136; cpad < a.outg_ld; cpad += 4) *reinterpret_cast<float4*>(a.outg + (size_t)row * a.outg_ld + cpad) = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+      }
+    }
+    return;
+  }
   // ---- phase 2 ------------------------------------------------------------------------------------------------------------
   constexpr int nk2 = HID / 16;
   f32x16 acc2, cor2;
@@ -446,6 +620,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
   if (EPI2 & EPI_LN) {
     float* red = gemm_lds;                      // [64 rows][4 column groups]; the LDS is idle (last barrier of phase 2)
     float* rrow = a.ln_io + (size_t)(ok ? m : a.M - 1) * a.ln_ld + wn * 32 + 4 * lh;
+    float* orow = a.ln_out ? a.ln_out + (size_t)(ok ? m : a.M - 1) * a.ln_ld + wn * 32 + 4 * lh : rrow;
     float part = 0.f;
 #pragma unroll
     for (int g = 0; g < 4; g++) {
@@ -471,7 +646,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
       for (int g = 0; g < 4; g++) {
         const float4 lw = *reinterpret_cast<const float4*>(a.ln_w + wn * 32 + 8 * g + 4 * lh);
         const float4 lb = *reinterpret_cast<const float4*>(a.ln_b + wn * 32 + 8 * g + 4 * lh);
-        *reinterpret_cast<float4*>(rrow + 8 * g) = make_float4(v[4 * g + 0] * inv * lw.x + lb.x, v[4 * g + 1] * inv * lw.y + lb.y,
+        *reinterpret_cast<float4*>(orow + 8 * g) = make_float4(v[4 * g + 0] * inv * lw.x + lb.x, v[4 * g + 1] * inv * lw.y + lb.y,
                                                                 v[4 * g + 2] * inv * lw.z + lb.z, v[4 * g + 3] * inv * lw.w + lb.w);
       }
     }

@@ -416,26 +416,34 @@ __global__ __launch_bounds__(128) void k_equiv(const float* __restrict__ T, cons
                                                const float* __restrict__ g1, float* g, float* outg, int N) {
   __shared__ float Ts[8 * 96];
   const int t = threadIdx.x, n0 = blockIdx.x * 8;
+  const int rows = min(8, N - n0) * 3;            // (node, s) rows of this block
+  // the block's 24 rows of g and g1 are requested up front (the kernel is bandwidth-bound: 48 loads in flight per thread), the
+  // products run while they arrive
+  float gv[24], g1v[24];
+#pragma unroll
+  for (int r = 0; r < 24; r++) {
+    const size_t row = (size_t)n0 * 3 + (r < rows ? r : 0);
+    gv[r] = g[row * D + t];
+    g1v[r] = g1[row * D + t];
+  }
   for (int o = t; o < 8 * 96; o += 128) Ts[o] = (n0 + o / 96 < N) ? T[(size_t)n0 * 96 + o] : 0.f;
   float w[32];
 #pragma unroll
   for (int c = 0; c < 32; c++) w[c] = W5[t * 32 + c];
   __syncthreads();
-  for (int node = 0; node < 8; node++) {
-    if (n0 + node >= N) break;
 #pragma unroll
-    for (int s = 0; s < 3; s++) {
-      const float* tt = Ts + node * 96 + s * 32;
-      float v = 0.f;
+  for (int r = 0; r < 24; r++) {
+    if (r >= rows) break;
+    const float* tt = Ts + r * 32;
+    float v = 0.f;
 #pragma unroll
-      for (int c = 0; c < 32; c++) v += tt[c] * w[c];
-      const size_t row = (size_t)(n0 + node) * 3 + s;
-      const float gn = g[row * D + t] + (g1[row * D + t] + v);
-      g[row * D + t] = gn;
-      if (outg) {
-        outg[row * OGLD + 8 + t] = gn;
-        if (t < OGLD - 136) outg[row * OGLD + 136 + t] = 0.f;
-      }
+    for (int c = 0; c < 32; c++) v += tt[c] * w[c];
+    const size_t row = (size_t)n0 * 3 + r;
+    const float gn = gv[r] + (g1v[r] + v);
+    g[row * D + t] = gn;
+    if (outg) {
+      outg[row * OGLD + 8 + t] = gn;
+      if (t < OGLD - 136) outg[row * OGLD + 136 + t] = 0.f;
     }
   }
 }
@@ -510,6 +518,7 @@ struct sgrl_set {
   float* ws = nullptr;
   int64_t ws_floats = 0;
   int carved_N = 0;
+  float* cat_cur = nullptr;    // which of cat / cat2 holds [inv | ng] after the last forward (the fused form alternates: run_forward)
   float *g, *cat, *cat2, *zc, *fn, *h256, *qkv, *vg, *g1, *z2, *mat, *t256, *t256b, *t128a, *t128b, *delta,
       *outg, *outng, *gdir;
   // stacked projection weights of the 7 proj+gram sites: static weights -> own buffer rebuilt on the forward stream after
@@ -752,7 +761,8 @@ bool chain_raise_lds_limits() {
                       reinterpret_cast<const void*>(kChainPlain)};
   for (const void* k : ks)
     if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, sgrl_gemm::kChainLds) != hipSuccess) return false;
-  return true;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain<0, 256, EPI_ROWDIV | EPI_EQUIV, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             sgrl_gemm::kChainEqLds) == hipSuccess;
 }
 const unsigned* words_of(const float* W) { return g_gemm.w_words + (W - g_gemm.w_base); }
 // projection site + Gram pair: X [3 M, Kp] -> zc (and z2) -> fn -> relu(G(Z) . W1^T + b1) . W2^T + b2 -> C[:, 0:128]
@@ -776,14 +786,31 @@ int launch_site(hipStream_t st, const float* X, int ldx, int Kp, const float* Wp
 }
 // ln_io[m][:] = LayerNorm(ln_io[m][:] + (relu(A . W1^T + b1) . W2^T + b2)[m][:] / rowdiv[m])      (hidden width 256)
 int launch_chain_ln(hipStream_t st, const float* A, int lda, int K1, const float* W1, const float* b1, const float* W2, const float* b2,
-                    const float* rowdiv, float* ln_io, int ln_ld, const float* ln_w, const float* ln_b, int M) {
+                    const float* rowdiv, float* ln_io, int ln_ld, const float* ln_w, const float* ln_b, int M, float* ln_out = nullptr) {
   if (K1 % 16 != 0 || (lda & 3)) return sfail(SGRL_ERR_ARG, "chain: K must be a multiple of 16 and rows 16-byte aligned");
   ChainArgs a{};
   a.A = A; a.lda = lda; a.W1 = words_of(W1); a.ldw1 = K1; a.b1 = b1; a.W2 = words_of(W2); a.ldw2 = 256; a.b2 = b2; a.M = M; a.K1 = K1;
-  a.rowdiv = rowdiv; a.ln_io = ln_io; a.ln_ld = ln_ld; a.ln_w = ln_w; a.ln_b = ln_b;
+  a.rowdiv = rowdiv; a.ln_io = ln_io; a.ln_ld = ln_ld; a.ln_w = ln_w; a.ln_b = ln_b; a.ln_out = ln_out;
   a.ws1 = wsc_of(W1); a.ws2 = wsc_of(W2);
   if (!a.ws1 || !a.ws2) return sfail(SGRL_ERR_ARG, "chain: a weight operand is not a matrix of the row-scale table");
   hipLaunchKernelGGL(kChainLn, dim3((M + sgrl_gemm::kChainRows - 1) / sgrl_gemm::kChainRows), dim3(512), sgrl_gemm::kChainLds, st, a);
+  return SGRL_OK;
+}
+// tout[m][s][c] = sum_q zq[m][s][q] * ((relu(A . W1^T + b1) . W2^T + b2)[m][c * 32 + q] / rowdiv[m])      (hidden width 256, N = 1024)
+constexpr auto kChainEq = k_chain<0, 256, EPI_ROWDIV | EPI_EQUIV, 0>;   // linear3 -> ReLU -> linear4 -> contraction (and the head's linear1_m -> linear2_m)
+int launch_chain_equiv(hipStream_t st, const float* A, int lda, int K1, const float* W1, const float* b1, const float* W2, const float* b2,
+                       const float* rowdiv, const float* zq, float* tout, int M, float* g = nullptr, const float* g1 = nullptr,
+                       const float* W5 = nullptr, float* outg = nullptr) {
+  if (K1 % 16 != 0 || (lda & 3)) return sfail(SGRL_ERR_ARG, "chain: K must be a multiple of 16 and rows 16-byte aligned");
+  ChainArgs a{};
+  a.A = A; a.lda = lda; a.W1 = words_of(W1); a.ldw1 = K1; a.b1 = b1; a.W2 = words_of(W2); a.ldw2 = 256; a.b2 = b2; a.M = M; a.K1 = K1;
+  a.rowdiv = rowdiv; a.zq = zq; a.tout = tout; a.ws1 = wsc_of(W1); a.ws2 = wsc_of(W2);
+  if (!a.ws1 || !a.ws2) return sfail(SGRL_ERR_ARG, "chain: a weight operand is not a matrix of the row-scale table");
+  if (g) {               // the vector stream's update in the same kernel
+    a.g = g; a.g1 = g1; a.W5 = words_of(W5); a.ws5 = wsc_of(W5); a.outg = outg; a.outg_ld = OGLD;
+    if (!a.ws5) return sfail(SGRL_ERR_ARG, "chain: linear5 is not a matrix of the row-scale table");
+  }
+  hipLaunchKernelGGL(kChainEq, dim3((M + sgrl_gemm::kChainRows - 1) / sgrl_gemm::kChainRows), dim3(512), sgrl_gemm::kChainEqLds, st, a);
   return SGRL_OK;
 }
 // C[:, 0:128] = relu(A . W1^T + b1) . W2^T + b2      (hidden width 128)
@@ -916,10 +943,22 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
                      s->W(SGRL_SET_GENC), s->W(SGRL_SET_ENC_W), s->W(SGRL_SET_ENC_B), s->W(SGRL_SET_EMB0), s->W(SGRL_SET_EMB1),
                      s->W(SGRL_SET_EMB2), s->g, s->cat, s->outg, s->outng, s->gdir, s->zc, s->z2, N);
   if (encode) join();
-  float* ng = s->cat + 128;
+  // cat = [invariants | ng] is double-buffered in the fused form: norm2 writes the next ng into the OTHER buffer, so that the two
+  // readers of [inv | ng] behind the feed-forward site (linear1 -> linear2 -> norm2 on the side stream, linear3 -> linear4 on the
+  // main one) never wait for each other
+  float* catc = s->cat;
+  float* cato = s->cat2;
+  s->cat_cur = catc;
+  float* ng = catc + 128;
   int rc = SGRL_OK;
   // back-to-back products as one kernel each: the tile path in its two-piece form on bound (pre-split) weights
   const bool chain = !small && chain_enabled() && gemm_use_split() && g_gemm.form == SGRL_SET_FORM_F16X3;
+  // linear3 -> linear4 -> contraction (-> vector-stream update) as ONE kernel exists (chain_f16.h, EPI_EQUIV; tests hold it against
+  // float64) but LOSES to the two launches: a 64-row workgroup streams the 1 MB of linear4 words out of L2 twice as often as the
+  // 128-row tiles do (587 MB per launch) and its three-instruction k-steps are barrier-bound -- 151 us against 135 us
+  // (profiles/r4_chain_lab_ffn.txt).  SGRL_SET_CHAIN_EQ=1 selects it for A/B runs (SGRL_SET_FUSE_UPDATE=0: k_equiv stays a launch).
+  static const bool chain_eq = [] { const char* e = getenv("SGRL_SET_CHAIN_EQ"); return e && e[0] == '1'; }();
+  static const bool fuse_update = [] { const char* e = getenv("SGRL_SET_FUSE_UPDATE"); return !(e && e[0] == '0'); }();
   float* const scratch = s->qkv;      // small path: [N, 576] Gram triangle / [N, 1024] per-node matrices (spans qkv | vg)
 #define G(...) do { rc = small ? small_gemm(st, __VA_ARGS__) : launch_gemm(st, __VA_ARGS__); if (rc != SGRL_OK) return rc; } while (0)
   auto gram_gemm = [&](const float* W_, const float* b_, float* C_, int ldc_, int N_) -> int {
@@ -976,14 +1015,14 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
     GS(s->g, D, s->WL(l, SGRL_SET_VG_W), D, nullptr, s->vg, 256, N3, 256, D);          // U = g . (Wgo_h Wvg_h)^T, both heads
     if (chain) {
       rc = launch_site(st, s->g, D, D, site_w(2 * l), s->zc, nullptr, s->fn, s->WL(l, SGRL_SET_A_LG1_W), s->WL(l, SGRL_SET_A_LG1_B), 256,
-                       s->WL(l, SGRL_SET_A_LG2_W), s->WL(l, SGRL_SET_A_LG2_B), s->cat, 256, N);
+                       s->WL(l, SGRL_SET_A_LG2_W), s->WL(l, SGRL_SET_A_LG2_B), catc, 256, N);
       if (rc != SGRL_OK) return rc;
     } else {
       PG(s->g, D, D, 2 * l, nullptr);
       GG(s->WL(l, SGRL_SET_A_LG1_W), s->WL(l, SGRL_SET_A_LG1_B), s->h256, 256, 256);
-      G(s->h256, 256, s->WL(l, SGRL_SET_A_LG2_W), 256, s->WL(l, SGRL_SET_A_LG2_B), s->cat, 256, N, 128, 256);
+      G(s->h256, 256, s->WL(l, SGRL_SET_A_LG2_W), 256, s->WL(l, SGRL_SET_A_LG2_B), catc, 256, N, 128, 256);
     }
-    G(s->cat, 256, s->WL(l, SGRL_SET_QKV_W), 256, s->WL(l, SGRL_SET_QKV_B), s->qkv, 768, N, 768, 256, EPI_ROWDIV, s->fn);
+    G(catc, 256, s->WL(l, SGRL_SET_QKV_W), 256, s->WL(l, SGRL_SET_QKV_B), s->qkv, 768, N, 768, 256, EPI_ROWDIV, s->fn);
     join();
     hipLaunchKernelGGL(k_attention, dim3(s->n_env), dim3(256), 0, st, s->qkv, s->vg, s->gdir, s->d_relb, et, l == 0 ? 1 : 0,
                        s->WL(l, SGRL_SET_NGOUT_B), s->WL(l, SGRL_SET_A_GD), s->stop_after == 2 * l ? s->delta : (float*)nullptr,
@@ -992,15 +1031,39 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
     // --- equivariant feed-forward ---
     if (chain) {
       rc = launch_site(st, s->g1, D, D, site_w(2 * l + 1), s->zc, s->z2, s->fn, s->WL(l, SGRL_SET_F_LG1_W), s->WL(l, SGRL_SET_F_LG1_B), 256,
-                       s->WL(l, SGRL_SET_F_LG2_W), s->WL(l, SGRL_SET_F_LG2_B), s->cat, 256, N);
+                       s->WL(l, SGRL_SET_F_LG2_W), s->WL(l, SGRL_SET_F_LG2_B), catc, 256, N);
       if (rc != SGRL_OK) return rc;
     } else {
       PG(s->g1, D, D, 2 * l + 1, s->z2);
       GG(s->WL(l, SGRL_SET_F_LG1_W), s->WL(l, SGRL_SET_F_LG1_B), s->h256, 256, 256);
-      G(s->h256, 256, s->WL(l, SGRL_SET_F_LG2_W), 256, s->WL(l, SGRL_SET_F_LG2_B), s->cat, 256, N, 128, 256);
+      G(s->h256, 256, s->WL(l, SGRL_SET_F_LG2_W), 256, s->WL(l, SGRL_SET_F_LG2_B), catc, 256, N, 128, 256);
     }
     fork();
-    if (!chain) GS(s->cat, 256, s->WL(l, SGRL_SET_L1_W), 256, s->WL(l, SGRL_SET_L1_B), s->t256b, 256, N, 256, 256, EPI_RELU);
+    if (chain) {
+      // side: linear1 -> ReLU -> linear2 -> / fn -> residual + norm2, the new ng into the other buffer; main: linear3 -> ReLU ->
+      // linear4 -> contraction with z, then the update of the vector stream
+      rc = launch_chain_ln(sd, catc, 256, 256, s->WL(l, SGRL_SET_L1_W), s->WL(l, SGRL_SET_L1_B), s->WL(l, SGRL_SET_L2_W), s->WL(l, SGRL_SET_L2_B),
+                           s->fn, ng, 256, s->WL(l, SGRL_SET_N2_W), s->WL(l, SGRL_SET_N2_B), N, cato + 128);
+      if (rc == SGRL_OK && chain_eq) {
+        rc = launch_chain_equiv(st, catc, 256, 256, s->WL(l, SGRL_SET_L3_W), s->WL(l, SGRL_SET_L3_B), s->WL(l, SGRL_SET_L4_W), s->WL(l, SGRL_SET_L4_B),
+                                s->fn, s->z2, s->mat, N, fuse_update ? s->g : (float*)nullptr, s->g1, s->WL(l, SGRL_SET_L5_W),
+                                l == SGRL_SET_LAYERS - 1 ? s->outg : (float*)nullptr);
+      } else if (rc == SGRL_OK) {
+        rc = launch_gemm(st, catc, 256, s->WL(l, SGRL_SET_L3_W), 256, s->WL(l, SGRL_SET_L3_B), s->t256, 256, N, 256, 256, EPI_RELU);
+        if (rc == SGRL_OK) rc = equiv_gemm(s->t256, s->WL(l, SGRL_SET_L4_W), s->WL(l, SGRL_SET_L4_B));
+      }
+      if (rc != SGRL_OK) return rc;
+      if (!(chain_eq && fuse_update))
+        hipLaunchKernelGGL(k_equiv, dim3((N + 7) / 8), dim3(128), 0, st, s->mat, s->WL(l, SGRL_SET_L5_W), s->g1, s->g,
+                           l == SGRL_SET_LAYERS - 1 ? s->outg : (float*)nullptr, N);
+      join();
+      std::swap(catc, cato);
+      ng = catc + 128;
+      s->cat_cur = catc;
+      if (s->stop_after == 2 * l + 1) return SGRL_OK;  // probe: g / ng (= the current cat[:, 128:]) are this layer's outputs
+      continue;
+    }
+    GS(s->cat, 256, s->WL(l, SGRL_SET_L1_W), 256, s->WL(l, SGRL_SET_L1_B), s->t256b, 256, N, 256, 256, EPI_RELU);
     G(s->cat, 256, s->WL(l, SGRL_SET_L3_W), 256, s->WL(l, SGRL_SET_L3_B), s->t256, 256, N, 256, 256, EPI_RELU);
     // linear2 carries the scalar stream's second residual + norm2 in its epilogue (ng rewritten in place): it must not start
     // before linear3 -- the other reader of cat = [inv | ng] -- is done
@@ -1013,10 +1076,6 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
       if (rc != SGRL_OK) return rc;
       hipLaunchKernelGGL(k_add_ln, dim3(lnb), dim3(256), 0, st, ng, 256, s->delta, 128, s->WL(l, SGRL_SET_N2_W),
                          s->WL(l, SGRL_SET_N2_B), (float*)nullptr, 0, ng, 256, N);
-    } else if (chain) {
-      rc = launch_chain_ln(sd, s->cat, 256, 256, s->WL(l, SGRL_SET_L1_W), s->WL(l, SGRL_SET_L1_B), s->WL(l, SGRL_SET_L2_W), s->WL(l, SGRL_SET_L2_B),
-                           s->fn, ng, 256, s->WL(l, SGRL_SET_N2_W), s->WL(l, SGRL_SET_N2_B), N);
-      if (rc != SGRL_OK) return rc;
     } else {
       rc = launch_gemm_ln(sd, s->t256b, 256, s->WL(l, SGRL_SET_L2_W), 256, s->WL(l, SGRL_SET_L2_B), N, 256, s->fn, ng, 256,
                           s->WL(l, SGRL_SET_N2_W), s->WL(l, SGRL_SET_N2_B));
@@ -1032,13 +1091,14 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   // final norm -> outng[:, 17:145]; head
   hipLaunchKernelGGL(k_add_ln, dim3(lnb), dim3(256), 0, st, ng, 256, (const float*)nullptr, 0, s->W(SGRL_SET_FNORM_W),
                      s->W(SGRL_SET_FNORM_B), (float*)nullptr, 0, s->outng + ngf, 160, N);
+  float* const hd = chain ? cato : s->cat2;     // the head's [l2g | l2ng] rows: the buffer the last norm2 did not write
   fork();
   if (chain) {
     rc = launch_chain_ng(sd, s->outng, 160, 160, s->W(SGRL_SET_L1NG_W), s->W(SGRL_SET_L1NG_B), s->W(SGRL_SET_L2NG_W), s->W(SGRL_SET_L2NG_B),
-                         s->cat2 + 128, 256, N);
+                         hd + 128, 256, N);
     if (rc == SGRL_OK)
       rc = launch_site(st, s->outg, OGLD, OGLD, site_w(6), s->zc, critic ? (float*)nullptr : s->z2, s->fn, s->W(SGRL_SET_L1G_W),
-                       s->W(SGRL_SET_L1G_B), 128, s->W(SGRL_SET_L2G_W), s->W(SGRL_SET_L2G_B), s->cat2, 256, N);
+                       s->W(SGRL_SET_L1G_B), 128, s->W(SGRL_SET_L2G_W), s->W(SGRL_SET_L2G_B), hd, 256, N);
     if (rc != SGRL_OK) return rc;
   } else {
     GS(s->outng, 160, s->W(SGRL_SET_L1NG_W), 160, s->W(SGRL_SET_L1NG_B), s->t128b, D, N, D, 160, EPI_RELU);
@@ -1050,11 +1110,16 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   join();
   if (critic) {
     // slots reused by the critic head: DECG = decoder_ng.weight [256], L1M_B = decoder_ng.bias [1]
-    hipLaunchKernelGGL(k_q_head, dim3((N + 3) / 4), dim3(256), 0, st, s->cat2, s->W(SGRL_SET_DECG), s->W(SGRL_SET_L1M_B), s->fn,
+    hipLaunchKernelGGL(k_q_head, dim3((N + 3) / 4), dim3(256), 0, st, hd, s->W(SGRL_SET_DECG), s->W(SGRL_SET_L1M_B), s->fn,
                        nt, act, act_ld, N);
   } else {
-    G(s->cat2, 256, s->W(SGRL_SET_L1M_W), 256, s->W(SGRL_SET_L1M_B), s->t256, 256, N, 256, 256, EPI_RELU);
-    rc = equiv_gemm(s->t256, s->W(SGRL_SET_L2M_W), s->W(SGRL_SET_L2M_B));
+    if (chain && chain_eq) {
+      rc = launch_chain_equiv(st, hd, 256, 256, s->W(SGRL_SET_L1M_W), s->W(SGRL_SET_L1M_B), s->W(SGRL_SET_L2M_W), s->W(SGRL_SET_L2M_B), s->fn, s->z2,
+                              s->mat, N);
+    } else {
+      G(hd, 256, s->W(SGRL_SET_L1M_W), 256, s->W(SGRL_SET_L1M_B), s->t256, 256, N, 256, 256, EPI_RELU);
+      rc = equiv_gemm(s->t256, s->W(SGRL_SET_L2M_W), s->W(SGRL_SET_L2M_B));
+    }
     if (rc != SGRL_OK) return rc;
     hipLaunchKernelGGL(k_head_out, dim3((N + 3) / 4), dim3(128), 0, st, s->mat, s->W(SGRL_SET_DECG), obs, obs_ld, nt,
                        act, act_ld, max_action, N);
@@ -1225,7 +1290,7 @@ int sgrl_set_bind_params(sgrl_set* s, const sgrl_pack_seg* segs, int n_segs, con
       const int64_t* o = offsets + SGRL_SET_NGLOBAL + l * SGRL_SET_NLAYER;
       add(o[SGRL_SET_A_LG1_W], 256, GK); add(o[SGRL_SET_A_LG2_W], 128, 256); add(o[SGRL_SET_QKV_W], 768, 256); add(o[SGRL_SET_VG_W], 256, 128);
       add(o[SGRL_SET_F_LG1_W], 256, GK); add(o[SGRL_SET_F_LG2_W], 128, 256); add(o[SGRL_SET_L3_W], 256, 256); add(o[SGRL_SET_L4_W], 1024, 256, 32);
-      add(o[SGRL_SET_L1_W], 256, 256); add(o[SGRL_SET_L2_W], 128, 256);
+      add(o[SGRL_SET_L1_W], 256, 256); add(o[SGRL_SET_L2_W], 128, 256); add(o[SGRL_SET_L5_W], 128, 32);
     }
     for (int k = 0; k < SGRL_SET_NSITES; k++) add(offsets[SGRL_SET_NW + k], 64, k == 6 ? OGLD : 128);
     if (s->d_enc) (void)hipFree(s->d_enc);
@@ -1373,7 +1438,7 @@ int64_t sgrl_set_generation(const sgrl_set* s) { return s ? s->generation : -1; 
 
 int sgrl_set_peek(sgrl_set* s, int which, float* host, int64_t n_floats) {
   if (!s || !host || !s->have_graph) return sfail(SGRL_ERR_ARG, "sgrl_set_peek: bad argument");
-  const float* src[] = {s->g, s->cat, s->zc, s->fn, s->qkv, nullptr, nullptr, s->mat, s->g1, s->delta, s->outng};
+  const float* src[] = {s->g, s->cat_cur ? s->cat_cur : s->cat, s->zc, s->fn, s->qkv, nullptr, nullptr, s->mat, s->g1, s->delta, s->outng};
   const int64_t per[] = {384, 256, 96, 1, 768, 0, 0, 96, 384, 128, 160};
   if (which < 0 || which > 10 || !src[which] || n_floats > per[which] * s->N) return sfail(SGRL_ERR_ARG, "sgrl_set_peek: bad buffer or size");
   SHIP_TRY(hipDeviceSynchronize());
@@ -1488,6 +1553,8 @@ int sgrl_set_debug_product(sgrl_set* s, int kind, int form, const float* A, int 
 //        1  ln_io = LayerNorm(ln_io + (relu(A W1' + b1) W2' + b2) / rowdiv)       hid = 256; C [M, ldc] is ln_io; ln = ln_w | ln_b [256]
 //        2  projection site: X = A [3 M, K] -> Z (zc, z2 [3 M, 32]; z2 may be null), fn [M], C[:, 0:128] = relu(G(Z) W1' + b1) W2' + b2
 //           with Wp [64, K] the stacked projections and W1 [hid, 576] in the folded Gram order
+//        3  equivariant pair: C [M, 96] = tout[m][s][c] = sum_q zq[m][s][q] (relu(A W1' + b1) W2' + b2)[m][c * 32 + q] / rowdiv[m], hid = 256,
+//           W2 [1024, 256], b2 [1024], zq [M, 96] passed in `ln`
 int sgrl_set_debug_chain(sgrl_set* s, int kind, const float* A, int lda, int K, const float* Wp, const float* W1, const float* b1, int hid,
                          const float* W2, const float* b2, float* C, int ldc, int M, const float* rowdiv, const float* ln, float* zc,
                          float* z2, float* fn, void* stream) {
@@ -1497,7 +1564,7 @@ int sgrl_set_debug_chain(sgrl_set* s, int kind, const float* A, int lda, int K, 
   if (!chain_raise_lds_limits()) return sfail(SGRL_ERR_HIP, "cannot raise the dynamic LDS limit of the chain kernels");
   TempWords t1, t2, tp;
   const int K1 = kind == 2 ? GK : K;
-  if (t1.make(st, W1, hid, K1) != SGRL_OK || t2.make(st, W2, 128, hid) != SGRL_OK) return SGRL_ERR_HIP;
+  if (t1.make(st, W1, hid, K1) != SGRL_OK || t2.make(st, W2, kind == 3 ? 1024 : 128, hid, kind == 3 ? 32 : 1) != SGRL_OK) return SGRL_ERR_HIP;
   ChainArgs a{};
   a.W1 = t1.w; a.ldw1 = K1; a.b1 = b1; a.W2 = t2.w; a.ldw2 = hid; a.b2 = b2; a.M = M; a.K1 = K1; a.ws1 = t1.sc; a.ws2 = t2.sc;
   const dim3 grid((M + sgrl_gemm::kChainRows - 1) / sgrl_gemm::kChainRows);
@@ -1524,6 +1591,12 @@ int sgrl_set_debug_chain(sgrl_set* s, int kind, const float* A, int lda, int K, 
         if (z2) hipLaunchKernelGGL(kSiteH2, grid, dim3(512), sgrl_gemm::kChainLds, st, a);
         else hipLaunchKernelGGL(kSiteH1, grid, dim3(512), sgrl_gemm::kChainLds, st, a);
       }
+    }
+  } else if (kind == 3) {
+    if (hid != 256 || !rowdiv || !ln) rc = sfail(SGRL_ERR_ARG, "debug chain: the equivariant pair needs hid = 256, rowdiv, zq (in `ln`)");
+    else {
+      a.A = A; a.lda = lda; a.rowdiv = rowdiv; a.zq = ln; a.tout = C;
+      hipLaunchKernelGGL(kChainEq, grid, dim3(512), sgrl_gemm::kChainEqLds, st, a);
     }
   } else rc = sfail(SGRL_ERR_ARG, "debug chain: unknown kind");
   const hipError_t le = hipGetLastError();

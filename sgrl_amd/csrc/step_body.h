@@ -49,13 +49,15 @@ constexpr int kBppMaxIter = 40;                   // block-pivot rounds before g
 constexpr int kSlabRows = 256;                    // most constraint rows an evaluation may have (HBM slab path; the row cap of a morphology)
 constexpr int kPivotRows = 64;                    // ... of which the exact block-pivot solve takes up to this many (free set = 64-bit mask);
                                                   // evaluations with more rows run Gauss-Seidel over the rows in the slab (pgs_big)
-constexpr int kPrevRows = 48;                     // warm-start memory (LDS): the first rows of the previous evaluation
+constexpr int kPrevRows = 48;                     // warm-start memory in LDS: the first rows of the previous evaluation (the rest: HBM slab)
 constexpr int kSlabLdy = 47;                      // largest Y row stride served: nv <= 46
-// per-env HBM slab (Engine::rows_hbm): factor of a <= 64-row free set | Y | five row arrays | four int row arrays
-// (+ ldy (ldy + 1) / 2 behind the slab: the Euler integrator's copy of the mass matrix, see Layout::mfull_hbm)
-SGRL_HD int slab_rows_doubles(int maxrows, int ldy) { return kPivotRows * (kPivotRows + 1) / 2 + (maxrows + 1) * ldy + 5 * maxrows + 2 * maxrows + 8; }
+// per-env HBM slab (Engine::rows_hbm): factor of a <= 64-row free set | Y | five row arrays | four int row arrays | warm-start
+// memory of the rows beyond kPrevRows (forces, then keys) (+ ldy (ldy + 1) / 2 behind the slab: the Euler integrator's copy of
+// the mass matrix, see Layout::mfull_hbm)
+SGRL_HD int slab_prev_offset(int maxrows, int ldy) { return kPivotRows * (kPivotRows + 1) / 2 + (maxrows + 1) * ldy + 5 * maxrows + 2 * maxrows; }
+SGRL_HD int slab_rows_doubles(int maxrows, int ldy) { return slab_prev_offset(maxrows, ldy) + maxrows + maxrows / 2 + 1 + 8; }
 SGRL_HD int slab_doubles(int maxrows, int ldy) { return slab_rows_doubles(maxrows, ldy) + ldy * (ldy + 1) / 2; }
-constexpr int kScratchDoublesMax = 2080 + 257 * 47 + 7 * 256 + 8 + 47 * 48 / 2;     // slab_doubles(kSlabRows, kSlabLdy): what a test harness may allocate
+constexpr int kScratchDoublesMax = 2080 + 257 * 47 + 7 * 256 + 256 + 129 + 8 + 47 * 48 / 2;     // slab_doubles(kSlabRows, kSlabLdy): what a test harness may allocate
 
 // ------------------------------------------------------------------------------------------------
 // LDS layout (offsets in doubles for S, in ints for I)
@@ -964,11 +966,18 @@ struct Engine {
         aref = -B * vel - K * imp * (dist - margin);
       }
       R.eR[r] = Rreg; R.earef[r] = aref;
-      // warm start from the previous evaluation of this env-step: same constraint (kind, source, edge) -> same force
+      // warm start from the previous evaluation of this env-step: same constraint (kind, source, edge) -> same force.  The
+      // memory of the first kPrevRows rows is in LDS, that of the rest (contact-rich states only) in the environment's HBM slab
       const int key = (kind << 16) | (src << 3) | sub;
       double f0 = 0;
       const int pn = I[o.icnt + IC_PREV_N];
-      for (int k = 0; k < pn; k++) if (I[o.prev_key + k] == key) f0 = S[o.prev_f + k];
+      const int pcap = o.maxrows < kPrevRows ? o.maxrows : kPrevRows, pl = pn < pcap ? pn : pcap;
+      for (int k = 0; k < pl; k++) if (I[o.prev_key + k] == key) f0 = S[o.prev_f + k];
+      if (pn > pcap) {
+        const double* hf = big_scratch + slab_prev_offset(o.maxrows, o.ldy);
+        const int32_t* hk = reinterpret_cast<const int32_t*>(hf + o.maxrows);
+        for (int k = pcap; k < pn; k++) if (hk[k] == key) f0 = hf[k];
+      }
       R.ef[r] = f0;
     });
     SGRL_TICK(6);
@@ -1184,12 +1193,19 @@ struct Engine {
     }
     SGRL_TICK(7);
     // remember the solution for the next evaluation's warm start
-    const int prevcap = o.maxrows < kPrevRows ? o.maxrows : kPrevRows;       // the warm-start memory keeps the first rows
-    const int nkeep = nrow < prevcap ? nrow : prevcap;
+    const int prevcap = o.maxrows < kPrevRows ? o.maxrows : kPrevRows;       // LDS keeps the first rows, the HBM slab the others
+    const int nkeep = (nrow <= prevcap || big_scratch != nullptr) ? nrow : prevcap;
     w.lanes(nkeep > 0 ? nkeep : 1, [&](int r) {
       if (r < nkeep) {
-        I[o.prev_key + r] = (R.kind[r] << 16) | (R.src[r] << 3) | R.sub[r];
-        S[o.prev_f + r] = R.ef[r];
+        const int key = (R.kind[r] << 16) | (R.src[r] << 3) | R.sub[r];
+        if (r < prevcap) {
+          I[o.prev_key + r] = key;
+          S[o.prev_f + r] = R.ef[r];
+        } else {
+          double* hf = big_scratch + slab_prev_offset(o.maxrows, o.ldy);
+          hf[r] = R.ef[r];
+          reinterpret_cast<int32_t*>(hf + o.maxrows)[r] = key;
+        }
       }
       if (r == 0) { I[o.icnt + IC_PREV_N] = nkeep; I[o.icnt + IC_SWEEPS] += sweeps; I[o.icnt + IC_ROWSUM] += diag_code; }
     });
@@ -1486,7 +1502,8 @@ struct StepIO {
   float* reward; uint8_t* done; float* dist; uint8_t* truncated;  // scalars for this env (nullable)
   double* reward64;      // nullable
   int obs_max_len;
-  double* scratch;       // per-env HBM slab (slab_doubles(max_rows, ldy) doubles) or null
+  double* scratch;       // per-env HBM slab (slab_doubles(max_rows, ldy) doubles).  Never null in the engine and the emulator: Euler
+                         // layouts keep their mass-matrix copy there (Layout::mfull_hbm) and the warm start its rows beyond kPrevRows
   uint64_t seed; uint32_t env_id; int max_episode_steps; int auto_reset;
 };
 

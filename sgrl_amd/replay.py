@@ -37,6 +37,8 @@ class DeviceReplayBuffer(object):
 
     @curr.setter
     def curr(self, v):
+        if self._sync_hook is not None:      # increments a device-side writer still holds belong to the pointer being replaced
+            self._sync_hook()
         self._curr = int(v)
 
     @property
@@ -47,6 +49,8 @@ class DeviceReplayBuffer(object):
 
     @max_sample_size.setter
     def max_sample_size(self, v):
+        if self._sync_hook is not None:
+            self._sync_hook()
         self._fill = int(v)
 
     def clear(self):

@@ -62,6 +62,7 @@ class DeviceTrainer(object):
         self.num_envs_global = env.num_envs * self.world
         self._updates = 0            # TD3 updates so far (the reference adds them to tot_env_steps: trainer.py:250)
         self._tot_synced = 0         # non-learner ranks: the learner's count as of the last round end
+        self._tot_base = 0           # count restored from a snapshot (tot_env_steps setter)
         self.rounds = 0
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(int(seed) * 7919 + 13)
@@ -78,8 +79,24 @@ class DeviceTrainer(object):
         ingest counters in (one synchronisation -- nothing in the per-step path reads it); the other ranks hold the value the
         learner broadcast at the last round end."""
         if self.is_learner:
-            return self.sink.stored + self._updates
+            return self._tot_base + self.sink.stored + self._updates
         return self._tot_synced
+
+    @tot_env_steps.setter
+    def tot_env_steps(self, v):
+        """Resume from a snapshot (snapshot.load_snapshot returns the count, reference common/trainer.py:296-322): the restored
+        value becomes the base the live counters are added to."""
+        if self.is_learner:
+            self._tot_base = int(v) - (self.sink.stored + self._updates)
+        self._tot_synced = int(v)
+
+    def sync_step_count(self):
+        """Every rank learns the learner's count (called at the round ends and after the warm-up: rank-local logic that reads the
+        count before the first update then agrees with the learner)."""
+        if self.world > 1:
+            t = torch.tensor([self.tot_env_steps if self.is_learner else 0], dtype=torch.long, device=self.device)
+            self.dist.broadcast(t, src=self.dst)
+            self._tot_synced = int(t.item())
 
     # ---- collection ----------------------------------------------------------------------------------
     def begin_round(self):
@@ -108,6 +125,7 @@ class DeviceTrainer(object):
         for _ in range(int(timesteps)):
             if self.collect_step(random_actions=True):
                 self.begin_round()
+        self.sync_step_count()
 
     # ---- learning --------------------------------------------------------------------------------------
     def update_after_round(self, max_iters=None):
@@ -140,10 +158,7 @@ class DeviceTrainer(object):
                         self.last_losses[name] = self.agent.update(batch, it)
                     self._updates += 1                         # the reference counts updates too (trainer.py:250)
             self.agent.models2eval()
-        if self.world > 1:                   # every rank reports the learner's step count (checkpoints, stopping rule)
-            t = torch.tensor([self.tot_env_steps if self.is_learner else 0], dtype=torch.long, device=self.device)
-            self.dist.broadcast(t, src=self.dst)
-            self._tot_synced = int(t.item())
+        self.sync_step_count()               # every rank reports the learner's step count (checkpoints, stopping rule)
         self.broadcast_actor()
         self.rounds += 1
         return per_morph_iter

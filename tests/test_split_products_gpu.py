@@ -336,3 +336,32 @@ def test_residual_layernorm_epilogue_product(handle, form):
     e_split = float((io.double() - ref).abs().max())
     e_exact = float((exact.double() - ref).abs().max())
     assert e_split <= max(1.5 * e_exact, 2e-6), (e_split, e_exact)
+
+
+@pytest.mark.parametrize("dist", ["normal", "huge", "ragged"])
+def test_fused_equivariant_pair(handle, dist):
+    """chain kind 3: linear3 -> ReLU -> linear4 -> contraction with z in one kernel (the [M, 1024] matrix and the 256-wide
+    intermediate never reach memory), against float64 and against the two launches it replaces (ReLU product, equivariant-epilogue
+    product)."""
+    import torch
+    K = 256
+    A, W1, b1 = _operands(dist, 256, K, seed=91)
+    g = torch.Generator(device="cuda").manual_seed(8)
+    W2 = (torch.randn((1024, 256), device="cuda", generator=g) / 16.0).contiguous()
+    b2 = torch.randn(1024, device="cuda", generator=g)
+    zq = torch.randn((M, 3, 32), device="cuda", generator=g).contiguous()
+    rd = (torch.rand(M, device="cuda", generator=g) * 3 + 1).contiguous()
+    H = (A.double() @ W1.double().t() + b1.double()).clamp_min(0)
+    mat = (H @ W2.double().t() + b2.double()).view(M, 32, 32)                       # [m][c][q]
+    ref = torch.einsum("msq,mcq->msc", zq.double(), mat) / rd.double()[:, None, None]
+    smat = (H.abs() @ W2.double().abs().t() + b2.double().abs()).view(M, 32, 32)
+    scale = torch.einsum("msq,mcq->msc", zq.double().abs(), smat) / rd.double()[:, None, None] + 1e-300
+    T = torch.full((M, 96), float("nan"), device="cuda")
+    _chain(handle, 3, A, K, W1, b1, 256, W2, b2, T, rowdiv=rd, ln=zq.view(M, 96))
+    Hs = torch.empty((M, 256), device="cuda")
+    _run(handle, 1, F16X3, A, W1, b1, Hs, 256, K)
+    Ts = torch.empty((M, 96), device="cuda")
+    _run(handle, 4, F16X3, Hs, W2, b2, Ts, 1024, 256, rowdiv=rd, aux_in=zq.view(M, 96))
+    assert torch.isfinite(T).all()
+    e_f, e_s = _rel_err(T.view(M, 3, 32), ref, scale), _rel_err(Ts.view(M, 3, 32), ref, scale)
+    assert e_f <= max(1.05 * e_s, 3e-7), (e_f, e_s, dist)

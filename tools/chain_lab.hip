@@ -277,6 +277,38 @@ int main(int argc, char** argv) {
       printf("    l1ng -> l2ng: single products back to back %.1f us | fused %.1f us\n", time_us(single_n), time_us(fused_n));
     }
   }
+  // ---- (2b) linear3 -> ReLU -> linear4 -> contraction: fused vs the two launches; what the parts of the fused phase cost -----------
+  {
+    constexpr auto kEquivG = k_gemm3<EPI_ROWDIV | EPI_EQUIV, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2, true, 2>;
+    constexpr int kLdsEq = TileCfg3<4, 2, 1, 2, 16, 3>::kLdsBytes;
+    raise(kEquivG, kLdsEq);
+    Host W4 = dev(1024 * 256, 0.2f), b4 = dev(1024, 1.0f), zq = dev((size_t)N * 96, 2.0f);
+    Wt W4w = words(W4.d, 1024, 256);
+    float *t_a, *t_b;
+    CK(hipMalloc(&t_a, (size_t)N * 96 * 4)); CK(hipMalloc(&t_b, (size_t)N * 96 * 4));
+    GemmArgs g1 = gemm(cat.d, 256, W1w, 256, b1.d, h256, 256, N, 256, 256, EPI_RELU);
+    GemmArgs g4 = gemm(h256, 256, W4w, 256, b4.d, nullptr, 0, N, 1024, 256, EPI_ROWDIV | EPI_EQUIV, fn.d);
+    g4.zq = zq.d; g4.tout = t_a;
+    ChainArgs c{};
+    c.A = cat.d; c.lda = 256; c.W1 = W1w.w; c.ldw1 = 256; c.b1 = b1.d; c.W2 = W4w.w; c.ldw2 = 256; c.b2 = b4.d; c.M = N; c.K1 = 256;
+    c.rowdiv = fn.d; c.zq = zq.d; c.tout = t_b; c.ws1 = W1w.sc; c.ws2 = W4w.sc;
+    auto single = [&] {
+      hipLaunchKernelGGL(kSplitRelu, dim3(tiles * 2), dim3(512), kLds128, 0, g1);
+      hipLaunchKernelGGL(kEquivG, dim3(tiles * 8), dim3(512), kLdsEq, 0, g4);
+    };
+#define EQ(D) k_chain<0, 256, EPI_ROWDIV | EPI_EQUIV, 0, D>
+    raise(EQ(0), kChainEqLds); raise(EQ(1), kChainEqLds); raise(EQ(2), kChainEqLds); raise(EQ(4), kChainEqLds); raise(EQ(7), kChainEqLds);
+    single();
+    hipLaunchKernelGGL((EQ(0)), dim3(blocks), dim3(512), kChainEqLds, 0, c);
+    CK(hipDeviceSynchronize());
+    report("l3 -> l4 -> contraction", fetch(t_a, (size_t)N * 96), fetch(t_b, (size_t)N * 96), 96, 96);
+    printf("  l3 -> l4 -> contraction: single products back to back %.1f us | fused %.1f us | without sub-slice hand-over %.1f | without the contraction %.1f | without W2 staging %.1f | none of the three %.1f\n",
+           time_us(single), time_us([&] { hipLaunchKernelGGL((EQ(0)), dim3(blocks), dim3(512), kChainEqLds, 0, c); }),
+           time_us([&] { hipLaunchKernelGGL((EQ(1)), dim3(blocks), dim3(512), kChainEqLds, 0, c); }),
+           time_us([&] { hipLaunchKernelGGL((EQ(2)), dim3(blocks), dim3(512), kChainEqLds, 0, c); }),
+           time_us([&] { hipLaunchKernelGGL((EQ(4)), dim3(blocks), dim3(512), kChainEqLds, 0, c); }),
+           time_us([&] { hipLaunchKernelGGL((EQ(7)), dim3(blocks), dim3(512), kChainEqLds, 0, c); }));
+  }
   // ---- (3) the wide single products (reference timings for the forward's budget) -------------------------------------------------
   {
     Host Wq = dev(1024 * 256, 0.2f), bq = dev(1024, 1.0f);
