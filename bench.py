@@ -196,7 +196,9 @@ def main():
     from sgrl_amd.set_policy import make_policy
     torch.manual_seed(args.seed)
     policy = make_policy(device=dev).eval()          # random-init weights of the reference architecture
-    ro = Rollout(WALKERS, args.envs_per_morph, policy=policy, seed=args.seed, device=dev, rank=rank)
+    # the policy's weights never change during this rollout: the actor packs them once (include/sgrl_set.h sgrl_set_hold_weights; the
+    # training loop holds them the same way between two rounds of updates)
+    ro = Rollout(WALKERS, args.envs_per_morph, policy=policy, seed=args.seed, device=dev, rank=rank, hold_weights=True)
     env = ro.env
     n_local = env.num_envs
     if args.set_forward_only:

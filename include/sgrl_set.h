@@ -82,7 +82,7 @@ int sgrl_set_weights(sgrl_set* s, const float* w, const int64_t* offsets, int n_
  *   PERM32 dst [1024, a]: row c * 32 + q = src0 row q * 32 + c   (L4_W / L4_B / L2M_W / L2M_B: the 1024 outputs are a 32 x 32
  *          matrix mat[q][c] per node, reference SEActor.py:105-107; stored c-major so that one 32-column GEMM tile holds all q of
  *          one c and the epilogue can contract it with z[s][q] without ever writing the matrix: the GEMM emits z . mat [3, 32])
- * offsets: HOST int64[SGRL_SET_NW + SGRL_SET_NSITES] -- the slot table followed by the offsets of the seven stacked
+ * offsets: HOST int64[SGRL_SET_NW + SGRL_SET_NSITES + SGRL_SET_NEXTRA] -- the slot table followed by the offsets of the seven stacked
  * projection operands (sites 2l = attention g_proj of layer l [64,128]; 2l+1 = g_proj2 | g_proj3 [64,128];
  * 6 = gg_proj | g_proj (actor) [64,144]).  The segments must cover [0, total_floats) entirely.  Parameter storage must
  * stay allocated while the handle is bound; re-bind after anything that moves it (module.to(), new tensors). */
@@ -100,8 +100,22 @@ typedef struct sgrl_pack_seg {
   int32_t reserved;
 } sgrl_pack_seg;
 #define SGRL_SET_NSITES 7
+/* ... followed by SGRL_SET_NEXTRA more offsets: the actor head with decoder_g FOLDED through linear2_m (exact algebra, reference
+ * SEActor.py:272-279: decoder_g(z . mat) = z . (mat . w_dec), so only the 32 numbers m2[q] = sum_c mat[q][c] w_dec[c] per node are
+ * needed):  [32, 256] rows q = sum_c w_dec[c] * linear2_m.weight[q * 32 + c]  and  [32] = sum_c w_dec[c] * linear2_m.bias[q * 32 + c]
+ * (MATMUL segments over the live parameters).  A critic network binds 64-float fillers there. */
+#define SGRL_SET_NEXTRA 2
 int sgrl_set_bind_params(sgrl_set* s, const sgrl_pack_seg* segs, int n_segs, const int64_t* offsets, int n_offsets,
                          int64_t total_floats);
+
+/* Weight hold.  By default every forward of a bound handle rebuilds its flat buffer from the live parameters (~55 us at the top of
+ * the forward).  A rollout loop knows better: between two rounds of updates the actor's parameters do not change (reference
+ * trainer.py:155-251: collect a round with `select_action`, then `agent.update`).  sgrl_set_hold_weights(s, 1) is the caller's promise
+ * that the parameters stay as they are until the next call of this function: the first forward after it packs, the following ones
+ * reuse that buffer.  Every call (hold = 1 again, or 0 = back to packing on every forward) also means "the parameters may just have
+ * changed".  Forwards recorded into a hipGraph always pack.  `DeviceTrainer` holds across a collection round and calls again after
+ * every round's updates / actor broadcast; bench.py's rollout (constant random-init weights) holds throughout. */
+int sgrl_set_hold_weights(sgrl_set* s, int hold);
 
 /* Batch structure (SEPolicy.change_morphology for every morphology at once, reference SEActor.py:349-355):
  *   n_morph, morph_L[n_morph] limbs, morph_count[n_morph] envs per morphology (env blocks in this order),

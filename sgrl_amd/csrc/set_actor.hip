@@ -471,6 +471,27 @@ __global__ __launch_bounds__(128) void k_head_out(const float* __restrict__ T, c
 }
 
 
+// head with decoder_g folded through linear2_m (include/sgrl_set.h): m2[n][q] = (Wf . h[n] + bf)[q] / fn[n] comes out of a 32-wide
+// product; vec[s] = z[n][s][:] . m2[n][:]; action_k = max_action * tanh(sum_s axis_k[s] * vec[s]); 32 lanes per node
+__global__ __launch_bounds__(128) void k_head_out2(const float* __restrict__ m2, const float* __restrict__ z, const float* __restrict__ obs,
+                                                   int obs_ld, NodeTab nt, float* act, int act_ld, float max_action, int N) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 5), c = threadIdx.x & 31;
+  if (n >= N) return;
+  float vec[3];
+  const float mq = m2[(size_t)n * 32 + c];
+  for (int s = 0; s < 3; s++) {
+    float v = z[(size_t)n * 96 + s * 32 + c] * mq;
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
+    vec[s] = v;
+  }
+  if (c < 3) {
+    const int env = nt.node_env[n], limb = nt.node_limb[n];
+    const float* o = obs + (size_t)env * obs_ld + 41 * limb + 3 * (5 + c);
+    const float a = o[0] * vec[0] + o[1] * vec[1] + o[2] * vec[2];
+    act[(size_t)env * act_ld + 3 * limb + c] = max_action * tanhf(a);
+  }
+}
+
 // critic head: q[env][limb] = (w . c[n] + b) / fn[n]   (reference SEActor.py:279-281 with output_size = 1); one wave per node
 __global__ __launch_bounds__(256) void k_q_head(const float* __restrict__ c, const float* __restrict__ w, const float* __restrict__ b,
                                                 const float* __restrict__ fn, NodeTab nt, float* q, int q_ld, int N) {
@@ -525,6 +546,13 @@ struct sgrl_set {
   // sgrl_set_weights; live weights -> part of the flat buffer, rebuilt by k_pack with everything else
   float* wstack = nullptr;
   const float* site_ptr[SGRL_SET_NSITES];
+  // sgrl_set_hold_weights: the caller promises the bound parameters do not change while the hold lasts -- the flat buffer (and its
+  // row-scaled words) built by the first forward after the promise serves the following ones
+  bool hold = false, packed_ok = false;
+  int packed_form = 0;
+  hipEvent_t ev_pack = nullptr;
+  const float* l2mf_w = nullptr;   // live weights: decoder_g folded through linear2_m [32, 256] and its bias [32] (null: unfolded head)
+  const float* l2mf_b = nullptr;
   unsigned short* d_tri = nullptr;
   bool stack_dirty = true;
   bool stack_critic = false;   // mode the stacked operands were built for
@@ -929,9 +957,14 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   auto fork = [&]() { if (!one_stream) { (void)hipEventRecord(s->ev_fork, st); (void)hipStreamWaitEvent(sd, s->ev_fork, 0); } };
   auto join = [&]() { if (!one_stream) { (void)hipEventRecord(s->ev_join, sd); (void)hipStreamWaitEvent(st, s->ev_join, 0); } };
   (void)hipMemsetAsync(act, 0, sizeof(float) * (size_t)s->n_env * act_ld, st);
-  if (s->live)           // live weights: flat buffer (and the stacked projection operands in it) rebuilt from the parameters
+  // live weights: flat buffer (and the stacked projection operands in it) rebuilt from the parameters -- by every forward, unless
+  // the caller holds the weights (sgrl_set_hold_weights) and this handle has packed them in the same product form since
+  const bool want_words = !small && g_gemm.form == SGRL_SET_FORM_F16X3 && gemm_use_split();
+  const bool reuse = s->live && s->hold && s->packed_ok && (!want_words || s->packed_form == SGRL_SET_FORM_F16X3) && cap == hipStreamCaptureStatusNone;
+  if (reuse) (void)hipStreamWaitEvent(st, s->ev_pack, 0);      // (a forward on another stream than the one that packed)
+  if (s->live && !reuse)
     hipLaunchKernelGGL(k_pack, dim3(s->n_chunks), dim3(256), 0, st, s->d_segs, s->d_chunks, s->d_tri, s->wflat);
-  const bool encode = s->live && !small && g_gemm.form == SGRL_SET_FORM_F16X3 && gemm_use_split();
+  const bool encode = s->live && !reuse && want_words;
   if (encode) {          // the product matrices as row-scaled words: beside the embedding, which reads the f32 buffer only
     fork();
     hipLaunchKernelGGL(sgrl_gemm::k_encode_rows, dim3((s->enc_rows + 3) / 4), dim3(256), 0, sd, s->wflat, s->wwords, s->wsc, s->d_enc, s->n_enc,
@@ -943,6 +976,11 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
                      s->W(SGRL_SET_GENC), s->W(SGRL_SET_ENC_W), s->W(SGRL_SET_ENC_B), s->W(SGRL_SET_EMB0), s->W(SGRL_SET_EMB1),
                      s->W(SGRL_SET_EMB2), s->g, s->cat, s->outg, s->outng, s->gdir, s->zc, s->z2, N);
   if (encode) join();
+  if (s->live && !reuse && cap == hipStreamCaptureStatusNone) {
+    s->packed_ok = s->hold;
+    s->packed_form = want_words ? SGRL_SET_FORM_F16X3 : SGRL_SET_FORM_BF16X6;
+    if (s->hold) (void)hipEventRecord(s->ev_pack, st);
+  }
   // cat = [invariants | ng] is double-buffered in the fused form: norm2 writes the next ng into the OTHER buffer, so that the two
   // readers of [inv | ng] behind the feed-forward site (linear1 -> linear2 -> norm2 on the side stream, linear3 -> linear4 on the
   // main one) never wait for each other
@@ -958,6 +996,7 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   // 128-row tiles do (587 MB per launch) and its three-instruction k-steps are barrier-bound -- 151 us against 135 us
   // (profiles/r4_chain_lab_ffn.txt).  SGRL_SET_CHAIN_EQ=1 selects it for A/B runs (SGRL_SET_FUSE_UPDATE=0: k_equiv stays a launch).
   static const bool chain_eq = [] { const char* e = getenv("SGRL_SET_CHAIN_EQ"); return e && e[0] == '1'; }();
+  static const bool head_fold = [] { const char* e = getenv("SGRL_SET_HEAD_FOLD"); return !(e && e[0] == '0'); }();     // A/B: the unfolded head
   static const bool fuse_update = [] { const char* e = getenv("SGRL_SET_FUSE_UPDATE"); return !(e && e[0] == '0'); }();
   float* const scratch = s->qkv;      // small path: [N, 576] Gram triangle / [N, 1024] per-node matrices (spans qkv | vg)
 #define G(...) do { rc = small ? small_gemm(st, __VA_ARGS__) : launch_gemm(st, __VA_ARGS__); if (rc != SGRL_OK) return rc; } while (0)
@@ -1113,7 +1152,13 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
     hipLaunchKernelGGL(k_q_head, dim3((N + 3) / 4), dim3(256), 0, st, hd, s->W(SGRL_SET_DECG), s->W(SGRL_SET_L1M_B), s->fn,
                        nt, act, act_ld, N);
   } else {
-    if (chain && chain_eq) {
+    const bool folded = !small && s->live && s->l2mf_w && head_fold;
+    if (folded) {
+      // decoder_g folded through linear2_m: the 1024-wide product and its contraction collapse into a 32-wide product
+      G(hd, 256, s->W(SGRL_SET_L1M_W), 256, s->W(SGRL_SET_L1M_B), s->t256, 256, N, 256, 256, EPI_RELU);
+      G(s->t256, 256, s->l2mf_w, 256, s->l2mf_b, s->mat, 32, N, 32, 256, EPI_ROWDIV, s->fn);
+      hipLaunchKernelGGL(k_head_out2, dim3((N + 3) / 4), dim3(128), 0, st, s->mat, s->z2, obs, obs_ld, nt, act, act_ld, max_action, N);
+    } else if (chain && chain_eq) {
       rc = launch_chain_equiv(st, hd, 256, 256, s->W(SGRL_SET_L1M_W), s->W(SGRL_SET_L1M_B), s->W(SGRL_SET_L2M_W), s->W(SGRL_SET_L2M_B), s->fn, s->z2,
                               s->mat, N);
     } else {
@@ -1121,8 +1166,9 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
       rc = equiv_gemm(s->t256, s->W(SGRL_SET_L2M_W), s->W(SGRL_SET_L2M_B));
     }
     if (rc != SGRL_OK) return rc;
-    hipLaunchKernelGGL(k_head_out, dim3((N + 3) / 4), dim3(128), 0, st, s->mat, s->W(SGRL_SET_DECG), obs, obs_ld, nt,
-                       act, act_ld, max_action, N);
+    if (!folded)
+      hipLaunchKernelGGL(k_head_out, dim3((N + 3) / 4), dim3(128), 0, st, s->mat, s->W(SGRL_SET_DECG), obs, obs_ld, nt,
+                         act, act_ld, max_action, N);
   }
 #undef GS
 #undef GG
@@ -1174,7 +1220,8 @@ int sgrl_set_create(sgrl_set** out) {
   if (hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&s->ev_l3, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&s->ev_l3, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&s->ev_pack, hipEventDisableTiming) != hipSuccess) {
     delete s;
     *out = nullptr;
     return sfail(SGRL_ERR_HIP, "cannot create the side stream of the SET actor");
@@ -1207,6 +1254,7 @@ void sgrl_set_destroy(sgrl_set* s) {
   if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   if (s->ev_l3) (void)hipEventDestroy(s->ev_l3);
+  if (s->ev_pack) (void)hipEventDestroy(s->ev_pack);
   delete s;
 }
 
@@ -1216,13 +1264,14 @@ int sgrl_set_weights(sgrl_set* s, const float* w, const int64_t* offsets, int n_
   std::memcpy(s->off, offsets, sizeof(int64_t) * SGRL_SET_NW);
   s->have_w = true;
   s->live = false;
+  s->l2mf_w = nullptr; s->l2mf_b = nullptr;
   s->stack_dirty = true;   // the stacked projection operands are rebuilt by the next forward, on its stream
   return SGRL_OK;
 }
 
 int sgrl_set_bind_params(sgrl_set* s, const sgrl_pack_seg* segs, int n_segs, const int64_t* offsets, int n_offsets,
                          int64_t total_floats) {
-  if (!s || !segs || n_segs <= 0 || !offsets || n_offsets != SGRL_SET_NW + SGRL_SET_NSITES || total_floats <= 0)
+  if (!s || !segs || n_segs <= 0 || !offsets || n_offsets != SGRL_SET_NW + SGRL_SET_NSITES + SGRL_SET_NEXTRA || total_floats <= 0)
     return sfail(SGRL_ERR_ARG, "sgrl_set_bind_params: bad argument");
   // the segments must tile [0, total_floats) exactly (sorted by dst): every float of the buffer is rewritten per forward
   std::vector<int> order(n_segs);
@@ -1258,6 +1307,7 @@ int sgrl_set_bind_params(sgrl_set* s, const sgrl_pack_seg* segs, int n_segs, con
   if (s->d_segs) (void)hipFree(s->d_segs);
   if (s->d_chunks) (void)hipFree(s->d_chunks);
   s->wwords = nullptr;
+  s->packed_ok = false;
   s->wflat = nullptr; s->d_segs = nullptr; s->d_chunks = nullptr; s->live = false; s->have_w = false;
   if (hipMalloc(&s->wflat, sizeof(float) * total_floats) != hipSuccess ||
       hipMalloc(&s->wwords, sizeof(unsigned) * total_floats) != hipSuccess ||
@@ -1305,6 +1355,16 @@ int sgrl_set_bind_params(sgrl_set* s, const sgrl_pack_seg* segs, int n_segs, con
   s->w = s->wflat;
   std::memcpy(s->off, offsets, sizeof(int64_t) * SGRL_SET_NW);
   for (int k = 0; k < SGRL_SET_NSITES; k++) s->site_ptr[k] = s->wflat + offsets[SGRL_SET_NW + k];
+  {
+    // the folded head exists when its slot is long enough for the [32, 256] matrix (an actor network; the critic binds a filler)
+    std::vector<int64_t> b2(offsets, offsets + n_offsets);
+    b2.push_back(total_floats);
+    std::sort(b2.begin(), b2.end());
+    const int64_t ow = offsets[SGRL_SET_NW + SGRL_SET_NSITES], ob = offsets[SGRL_SET_NW + SGRL_SET_NSITES + 1];
+    const bool have = *std::upper_bound(b2.begin(), b2.end(), ow) - ow >= 32 * 256;
+    s->l2mf_w = have ? s->wflat + ow : nullptr;
+    s->l2mf_b = have ? s->wflat + ob : nullptr;
+  }
   s->live = true;
   s->have_w = true;
   return SGRL_OK;
@@ -1429,6 +1489,13 @@ int sgrl_set_time_forward(sgrl_set* s, const float* obs, int obs_ld, float* act,
   (void)hipEventDestroy(t0);
   (void)hipEventDestroy(t1);
   *ms_out = ms / reps;
+  return SGRL_OK;
+}
+
+int sgrl_set_hold_weights(sgrl_set* s, int hold) {
+  if (!s) return sfail(SGRL_ERR_ARG, "sgrl_set_hold_weights: null handle");
+  s->hold = hold != 0;
+  s->packed_ok = false;          // every call is also "the weights may have changed just now": the next forward packs
   return SGRL_OK;
 }
 

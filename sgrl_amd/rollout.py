@@ -22,7 +22,7 @@ FUSED_INGEST = os.environ.get("SGRL_FUSED_INGEST", "1") != "0"
 class Rollout(object):
     """Environments of one rank + the shared SET actor."""
 
-    def __init__(self, env_names, envs_per_morph, policy=None, seed=0, device="cuda:0", rank=0, **env_kw):
+    def __init__(self, env_names, envs_per_morph, policy=None, seed=0, device="cuda:0", rank=0, hold_weights=False, **env_kw):
         counts = [envs_per_morph] * len(env_names) if np.isscalar(envs_per_morph) else list(envs_per_morph)
         n_local = int(sum(counts))
         self.env = BatchedModularVecEnv(env_names, counts, seed=seed, device=device, env_id_base=rank * n_local, **env_kw)
@@ -33,6 +33,9 @@ class Rollout(object):
             self.graph_dicts = [G.getGraphDict(m.parents, TRAV, [], device=self.device) for m in self.env.models]
             self.actor = HipSetActor(policy, device=self.device)
             self.actor.configure(self.graph_dicts, counts)
+            if hold_weights:      # the owner of the loop says when the policy's parameters change (weights_changed)
+                self.actor.hold_weights(True)
+        self.holds_weights = bool(hold_weights) and policy is not None
         n, amax = self.env.num_envs, self.env.action_max_len
         self.actions = torch.zeros((n, amax), dtype=torch.float32, device=self.device)
         self.policy_actions = torch.zeros((n, amax), dtype=torch.float32, device=self.device)
@@ -43,6 +46,12 @@ class Rollout(object):
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(int(seed) * 1000003 + rank)
         self.obs = None
+
+    def weights_changed(self):
+        """The policy's parameters were just updated (optimizer steps, soft updates, a broadcast): a rollout that holds its actor's
+        packed weights (hold_weights=True) packs again on its next forward."""
+        if self.holds_weights:
+            self.actor.hold_weights(True)
 
     def reset(self):
         self.obs = self.env.reset_device()

@@ -43,6 +43,7 @@ def _bind(L):
     L.sgrl_set_debug_small_nodes.argtypes = [vp, ctypes.c_int]
     L.sgrl_set_gemm_form.argtypes = [vp, ctypes.c_int]
     L.sgrl_set_last_error.restype = ctypes.c_char_p
+    L.sgrl_set_hold_weights.argtypes = [vp, ctypes.c_int]
     L.sgrl_set_debug_redos.argtypes = [ctypes.c_int]
     L.sgrl_set_debug_redos.restype = ctypes.c_longlong
     ci = ctypes.c_int
@@ -140,6 +141,7 @@ def pack_tensors(sd, prefix="actor.", critic=False):
 
 
 NSITES = 7
+NEXTRA = 2          # folded head: decoder_g . linear2_m  [32, 256] and its bias [32] (include/sgrl_set.h)
 PACK_COPY, PACK_PADCOL, PACK_FOLD, PACK_STACK, PACK_MATMUL, PACK_SUBMAT, PACK_PERM32 = 0, 1, 2, 3, 4, 5, 6
 # struct sgrl_pack_seg (include/sgrl_set.h)
 SEG_DTYPE = np.dtype([("dst", "<i8"), ("src0", "<u8"), ("src1", "<u8"), ("n", "<i4"), ("kind", "<i4"), ("a", "<i4"),
@@ -154,7 +156,7 @@ def plan_segments(net, critic=False):
     stacked projection operands, expressed as runs whose SOURCE is the parameter's own storage (`data_ptr()`), so the
     library can rebuild the buffer on the device whenever it wants."""
     sd = dict(net.named_parameters())
-    segs, srcs, offs, pos = [], [], np.zeros(NW + NSITES, dtype=np.int64), [0]
+    segs, srcs, offs, pos = [], [], np.zeros(NW + NSITES + NEXTRA, dtype=np.int64), [0]
 
     def p(name):
         t = sd[name]
@@ -277,6 +279,20 @@ def plan_segments(net, critic=False):
         slot(NW + 2 * l, stack, lp + "self_attn.g_proj.weight", None, 128, 128)
         slot(NW + 2 * l + 1, stack, lp + "g_proj2.weight", lp + "g_proj3.weight", 128, 128)
     slot(NW + 6, stack, "gg_proj.weight", None if critic else "g_proj.weight", 136, 144)
+
+    def head_fold(kind):
+        """decoder_g folded through linear2_m (exact algebra, reference SEActor.py:272-279: decoder_g(z . mat) = z . (mat . wdec)):
+        row q = sum_c wdec[c] * linear2_m[q * 32 + c] -- the head's 1024-wide product becomes a 32-wide one."""
+        wd, t = p("decoder_g.weight"), p("linear2_m." + kind)
+        for q in range(32):
+            if kind == "weight":
+                emit(PACK_MATMUL, wd, 256, a=32, b=256, t1=t, off1=q * 32 * 256, lda=32, ldb=256)
+            else:
+                emit(PACK_MATMUL, wd, 1, a=32, b=1, t1=t, off1=q * 32, lda=32, ldb=1)
+    if critic:
+        slot(NW + 7, zero); slot(NW + 8, zero)
+    else:
+        slot(NW + 7, head_fold, "weight"); slot(NW + 8, head_fold, "bias")
     align()
     return np.array(segs, dtype=SEG_DTYPE), offs, pos[0], srcs
 
@@ -435,6 +451,13 @@ class HipSetActor(object):
         """Form of the tile products (include/sgrl_set.h): FORM_F16X3 (default: two f16 pieces of every row-scaled operand,
         float32's range), FORM_BF16X6 (three bf16 pieces, slower; A/B comparisons), 0 = default."""
         _check(self.L, self.L.sgrl_set_gemm_form(self.h, int(form)), "sgrl_set_gemm_form")
+
+    def hold_weights(self, hold=True):
+        """Promise that the bound parameters do not change until the next call (include/sgrl_set.h sgrl_set_hold_weights): the next
+        forward packs the weights, the following ones reuse them.  Call again (True) right after anything that changes the
+        parameters -- an optimizer step, a soft update, a broadcast -- or with False to go back to packing on every forward."""
+        self.sync_weights()
+        _check(self.L, self.L.sgrl_set_hold_weights(self.h, 1 if hold else 0), "sgrl_set_hold_weights")
 
     def scale_redos(self, reset=True):
         """Workgroups that repeated a tile with exact row maxima since the last reset (include/sgrl_set.h sgrl_set_debug_redos;

@@ -45,8 +45,10 @@ class DeviceTrainer(object):
         if rollout is not None:
             self.ro = rollout(self.agent.actor, self.rank) if callable(rollout) else rollout
         else:
+            # the actor's parameters change only in update_after_round (updates on the learner, the broadcast on the others): the
+            # rollout holds its packed weights across a collection round
             self.ro = Rollout(self.env_names, envs_per_morph, policy=self.agent.actor, seed=seed, device=device, rank=self.rank,
-                              max_episode_steps=self.args.max_episode_steps, **env_kw)
+                              max_episode_steps=self.args.max_episode_steps, hold_weights=True, **env_kw)
         env = self.ro.env
         self.device = env.device
         self.graph_dicts = self.ro.graph_dicts
@@ -160,6 +162,8 @@ class DeviceTrainer(object):
             self.agent.models2eval()
         self.sync_step_count()               # every rank reports the learner's step count (checkpoints, stopping rule)
         self.broadcast_actor()
+        if hasattr(self.ro, "weights_changed"):
+            self.ro.weights_changed()          # with the weights every rank rolls out next
         self.rounds += 1
         return per_morph_iter
 

@@ -423,3 +423,34 @@ def test_product_forms_agree_on_engine_observations_at_size(ctx):
     assert ro.actor.num_nodes > 2048                               # the tile kernels, not the small-batch products
     assert worst < 1e-5, worst
     print("two-piece vs three-piece products on engine observations: max |action diff| = %.2e" % worst)
+
+
+def test_weight_hold_packs_once_and_again_when_told(ctx):
+    """sgrl_set_hold_weights (include/sgrl_set.h): a rollout loop promises that the parameters do not change between two calls -- the
+    forwards in between reuse the packed weights (so an in-place change is NOT seen: the contract), the call after the change makes
+    the next forward pack again; without the hold every forward reads the live parameters (the default, tested above)."""
+    torch, pol, graphs, keys, z = ctx
+    from sgrl_amd.set_hip import HipSetActor
+    from sgrl_amd.set_policy import make_policy
+    name = "3d_walker_7_full"
+    pol2 = make_policy(device="cuda:0").eval()
+    pol2.load_state_dict(pol.state_dict())
+    act = HipSetActor(pol2)
+    act.configure([_gd(torch, graphs[name])], [5])
+    act.debug_small_nodes(0)
+    obs = torch.from_numpy(z["%s/B5/obs" % name]).cuda()
+    base = act.forward_batch(obs).clone()
+    act.hold_weights(True)
+    held = act.forward_batch(obs).clone()
+    assert torch.equal(held, base)
+    with torch.no_grad():
+        pol2.actor.linear1_m.weight.mul_(1.5)                 # an in-place update the holder has not been told about
+    assert torch.equal(act.forward_batch(obs), base)              # still the packed weights: that is the promise
+    act.hold_weights(True)                                        # "the parameters just changed"
+    changed = act.forward_batch(obs).clone()
+    assert not torch.equal(changed, base)
+    assert torch.equal(act.forward_batch(obs), changed)
+    act.hold_weights(False)                                       # back to the default: live reads on every forward
+    with torch.no_grad():
+        pol2.actor.linear1_m.weight.div_(1.5)
+    assert float((act.forward_batch(obs) - base).abs().max()) < 1e-6

@@ -106,6 +106,16 @@ def test_plan_reproduces_the_host_pack(critic):
             else:
                 np.testing.assert_array_equal(blk[:30], layer.g_proj2.weight.detach().numpy())
                 np.testing.assert_array_equal(blk[32:62], layer.g_proj3.weight.detach().numpy())
+    # the folded head (decoder_g through linear2_m): [32, 256] and [32] behind the sites; a zero filler for the critic
+    o_w, o_b = offs[set_hip.NW + set_hip.NSITES], offs[set_hip.NW + set_hip.NSITES + 1]
+    if critic:
+        assert (flat[o_w:o_w + 64] == 0).all() and (flat[o_b:o_b + 64] == 0).all()
+    else:
+        wd = net.decoder_g.weight.detach().double().numpy().reshape(32)
+        w2 = net.linear2_m.weight.detach().double().numpy().reshape(32, 32, 256)       # [q][c][k]
+        b2 = net.linear2_m.bias.detach().double().numpy().reshape(32, 32)
+        np.testing.assert_allclose(flat[o_w:o_w + 32 * 256].reshape(32, 256), np.einsum("c,qck->qk", wd, w2), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(flat[o_b:o_b + 32], b2 @ wd, rtol=1e-5, atol=1e-7)
 
 
 def test_plan_sources_are_the_live_parameter_storage():
