@@ -309,21 +309,25 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
 #pragma unroll
       for (int i = 0; i < LT; i++) out[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       const float* wh = sc + h * L * L;
-      if (L <= 8) {          // all value rows in flight at once (one 16-byte load per key limb), then the products
-        float4 v[8];
+      if (L <= 8) {          // value rows four at a time (one 16-byte load per key limb in flight, then the products)
 #pragma unroll
-        for (int j = 0; j < 8; j++)
-          v[j] = j < L ? *reinterpret_cast<const float4*>(vbase + (size_t)j * 768) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int jb = 0; jb < 8; jb += 4) {
+          if (jb >= L) break;
+          float4 v[4];
 #pragma unroll
-        for (int j = 0; j < 8; j++)
-          if (j < L) {
+          for (int j = 0; j < 4; j++)
+            v[j] = jb + j < L ? *reinterpret_cast<const float4*>(vbase + (size_t)(jb + j) * 768) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int i = 0; i < LT; i++)
-              if (i0 + i < L) {
-                const float w = wh[(i0 + i) * L + j];
-                out[i].x += w * v[j].x; out[i].y += w * v[j].y; out[i].z += w * v[j].z; out[i].w += w * v[j].w;
-              }
-          }
+          for (int j = 0; j < 4; j++)
+            if (jb + j < L) {
+#pragma unroll
+              for (int i = 0; i < LT; i++)
+                if (i0 + i < L) {
+                  const float w = wh[(i0 + i) * L + jb + j];
+                  out[i].x += w * v[j].x; out[i].y += w * v[j].y; out[i].z += w * v[j].z; out[i].w += w * v[j].w;
+                }
+            }
+        }
       } else {               // more than 8 key limbs: stream them, the next row in flight while this one is used
         float4 v = *reinterpret_cast<const float4*>(vbase);
         for (int j = 0; j < L; j++) {
@@ -370,11 +374,9 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
           }
         }
     };
-    if (L <= 4) {
-      body(std::integral_constant<int, 4>{}, 0);
-    } else {                                       // more than 8 limbs: two passes over the value rows (they come from L1 / L2)
-      for (int i0 = 0; i0 < L; i0 += 8) body(std::integral_constant<int, 8>{}, i0);
-    }
+    // four output rows at a time: 16 + 32 registers of row and value data keep the kernel at six waves per SIMD (eight rows at a
+    // time: 114 registers, four waves); the value rows of the later passes come from L1 / L2
+    for (int i0 = 0; i0 < L; i0 += 4) body(std::integral_constant<int, 4>{}, i0);
   }
   __syncthreads();
   const int lane = t & 63;
@@ -417,33 +419,37 @@ __global__ __launch_bounds__(128) void k_equiv(const float* __restrict__ T, cons
   __shared__ float Ts[8 * 96];
   const int t = threadIdx.x, n0 = blockIdx.x * 8;
   const int rows = min(8, N - n0) * 3;            // (node, s) rows of this block
-  // the block's 24 rows of g and g1 are requested up front (the kernel is bandwidth-bound: 48 loads in flight per thread), the
-  // products run while they arrive
-  float gv[24], g1v[24];
-#pragma unroll
-  for (int r = 0; r < 24; r++) {
-    const size_t row = (size_t)n0 * 3 + (r < rows ? r : 0);
-    gv[r] = g[row * D + t];
-    g1v[r] = g1[row * D + t];
-  }
   for (int o = t; o < 8 * 96; o += 128) Ts[o] = (n0 + o / 96 < N) ? T[(size_t)n0 * 96 + o] : 0.f;
   float w[32];
 #pragma unroll
   for (int c = 0; c < 32; c++) w[c] = W5[t * 32 + c];
   __syncthreads();
+  // eight rows of g and g1 are requested at a time (the kernel is bandwidth-bound: 16 loads in flight per thread at seven waves
+  // per SIMD), the products run while they arrive
 #pragma unroll
-  for (int r = 0; r < 24; r++) {
-    if (r >= rows) break;
-    const float* tt = Ts + r * 32;
-    float v = 0.f;
+  for (int rb = 0; rb < 24; rb += 8) {
+    if (rb >= rows) break;
+    float gv[8], g1v[8];
 #pragma unroll
-    for (int c = 0; c < 32; c++) v += tt[c] * w[c];
-    const size_t row = (size_t)n0 * 3 + r;
-    const float gn = gv[r] + (g1v[r] + v);
-    g[row * D + t] = gn;
-    if (outg) {
-      outg[row * OGLD + 8 + t] = gn;
-      if (t < OGLD - 136) outg[row * OGLD + 136 + t] = 0.f;
+    for (int r = 0; r < 8; r++) {
+      const size_t row = (size_t)n0 * 3 + (rb + r < rows ? rb + r : 0);
+      gv[r] = g[row * D + t];
+      g1v[r] = g1[row * D + t];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      if (rb + r >= rows) break;
+      const float* tt = Ts + (rb + r) * 32;
+      float v = 0.f;
+#pragma unroll
+      for (int c = 0; c < 32; c++) v += tt[c] * w[c];
+      const size_t row = (size_t)n0 * 3 + rb + r;
+      const float gn = gv[r] + (g1v[r] + v);
+      g[row * D + t] = gn;
+      if (outg) {
+        outg[row * OGLD + 8 + t] = gn;
+        if (t < OGLD - 136) outg[row * OGLD + 136 + t] = 0.f;
+      }
     }
   }
 }
