@@ -142,7 +142,8 @@ def _cpu_worker(job):
 def set_executed_flops_per_node():
     layer = (3 * 128 * 32) + 576 * 256 + 256 * 128 + 256 * 768 + 3 * 128 * 256                                     # attention
     layer += (3 * 128 * 64) + 576 * 256 + 256 * 128 + 2 * (256 * 256) + 256 * 128 + 256 * 1024 + 3 * 32 * 32 + 3 * 32 * 128
-    head = (3 * 144 * 64) + 576 * 128 + 128 * 128 + 160 * 128 + 128 * 128 + 256 * 256 + 256 * 1024 + 3 * 32 * 32
+    # head: decoder_g is folded through linear2_m (the 1024-wide product is a 32-wide one: include/sgrl_set.h)
+    head = (3 * 144 * 64) + 576 * 128 + 128 * 128 + 160 * 128 + 128 * 128 + 256 * 256 + 256 * 32 + 3 * 32
     return 2 * (3 * layer + head)
 
 
@@ -338,6 +339,9 @@ def main():
                               "frac_of_f32_mfma_peak_executed": round(nodes * ex / (ms_set * 1e-3) / 157.3e12, 4),
                               "product_form": os.environ.get("SGRL_SET_GEMM", "f16x3"),
                               "fused_chains": os.environ.get("SGRL_SET_CHAIN", "1") != "0",
+                              "product_launches_per_forward": 25 if os.environ.get("SGRL_SET_CHAIN", "1") != "0" else 42,
+                              "weights_held": bool(getattr(ro, "holds_weights", False)),
+                              "row_scale_tile_repeats": ro.actor.scale_redos(reset=False),
                               "max_action_diff_between_product_forms": forms_diff,
                               "note": "nominal = the reference's dense layer sizes; executed = what the kernels run with the symmetric Gram "
                                       "matrix taken over the 36 4x4 blocks of its lower triangle (K = 576 instead of 1024; the "
@@ -347,8 +351,11 @@ def main():
                                       "cores: every operand row is scaled by a power of two into f16's range (exact, undone in the epilogue: "
                                       "float32's exponent range, nothing clamped) and cut into two f16 pieces, three matrix instructions per "
                                       "product block (gemm_f32.h; SGRL_SET_GEMM=bf16x6 selects the three-piece bf16 form); back-to-back products "
-                                      "run as one kernel each (chain_f16.h).  The f32-MFMA peak is the yardstick the reference arithmetic would "
-                                      "be priced against, not a bound of this kernel"}
+                                      "run as one kernel each (chain_f16.h), decoder_g is folded through linear2_m; weights_held: the rollout "
+                                      "promised constant weights, so the forward packs them once, not per call (sgrl_set_hold_weights: what the "
+                                      "training loop does between two rounds of updates); row_scale_tile_repeats = workgroups that had to "
+                                      "repeat a tile with exact row maxima (0 = every sampled estimate held).  The f32-MFMA peak is the "
+                                      "yardstick the reference arithmetic would be priced against, not a bound of this kernel"}
         # the exact-f32 forward next to the two-piece one: a child process with SGRL_SET_GEMM=f32 (plain products on
         # v_mfma_f32_32x32x2_f32, the reference's arithmetic; generated-operand products bf16 x 6) -- outside the timed region
         exact = None

@@ -5,8 +5,8 @@ number of forwards in the run (= launches of k_embed).  Usage: set_traffic.py <t
 import csv, json, sys
 tag = sys.argv[1]
 nodes = int(sys.argv[2]) if len(sys.argv) > 2 else 35840
-SET = ("k_gemm3", "k_gemm2", "k_attention", "k_equiv", "k_embed", "k_pack", "k_add_ln", "k_head_out", "k_q_head", "k_relbias", "k_stack_proj",
-       "k_sgemm", "k_gram576", "k_zmat_perm")
+SET = ("k_gemm3", "k_gemm2", "k_chain", "k_attention", "k_equiv", "k_embed", "k_pack", "k_encode_rows", "k_add_ln", "k_head_out", "k_head_out2",
+       "k_q_head", "k_relbias", "k_stack_proj", "k_sgemm", "k_gram576", "k_zmat_perm")
 tab = {}
 for name in ("fetch", "write"):
     for r in csv.DictReader(open("profiles/%s_pmc_%s_size_summary.csv" % (tag, name))):
