@@ -2,6 +2,9 @@
 // exact-f32 MFMA kernel vs the split-precision bf16x6 kernel in several tile configurations, with the error of each against
 // a float64 host reference on sampled outputs.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/gemm_lab tools/gemm_lab.hip && /tmp/gemm_lab
+// ARCHIVE of the round-3 lab (profiles/r3_gemm_lab*.txt): it is written against the round-3 gemm_f32.h (clamped words,
+// range events; `git show 6977511:sgrl_amd/csrc/gemm_f32.h`) and does not build against the row-scaled header of round 4.
+// The round-4 lab is tools/chain_lab.hip.
 #include "../sgrl_amd/csrc/gemm_f32.h"
 
 #include <cmath>
