@@ -81,6 +81,39 @@ class SubequivariantAttention(nn.Module):
         self.g_proj = Linear(embed_dim, Z_DIM - 2, bias=False)
         self.linear_g1 = Linear(Z_DIM * Z_DIM, e2)
         self.linear_g2 = Linear(e2, embed_dim)
+        self._adjoin()
+
+    def _adjoin(self):
+        """q / k / v share their input, so the training path multiplies by their weights stacked: keep the three weights (and the
+        three biases) back to back in ONE allocation, each parameter a view of its third, and the stack is there without a copy
+        (train_ops.stacked3; 44 concatenations per TD3 policy iteration otherwise).  The parameters keep their names and shapes
+        (state_dict compatible with the reference's q_proj / k_proj / v_proj, SEActor.py:34-46)."""
+        with torch.no_grad():
+            for attr in ("weight", "bias"):
+                ps = [getattr(m, attr) for m in (self.q_proj, self.k_proj, self.v_proj)]
+                if train_ops.adjacent3(*ps):
+                    continue
+                flat = torch.cat([p.data for p in ps], dim=0)
+                n = ps[0].shape[0]
+                for i, p in enumerate(ps):
+                    p.data = flat[i * n:(i + 1) * n]
+
+    def _apply(self, fn, *a, **kw):
+        """`.to()` / `.cuda()` / `.float()` give every parameter its own new storage: lay the three out again afterwards."""
+        out = super()._apply(fn, *a, **kw)
+        self._adjoin()
+        return out
+
+    def __deepcopy__(self, memo):
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        new.__dict__.update(copy.deepcopy(self.__dict__, memo))
+        new._adjoin()
+        return new
+
+    def qkv_stacked(self):
+        return (train_ops.stacked3(self.q_proj.weight, self.k_proj.weight, self.v_proj.weight),
+                train_ops.stacked3(self.q_proj.bias, self.k_proj.bias, self.v_proj.bias))
 
     def forward(self, g, ng, gdir, bias=None):
         B, L = ng.shape[:2]
@@ -88,8 +121,8 @@ class SubequivariantAttention(nn.Module):
         hd2 = 2 * (self.embed_dim // H)
         c, fn = _invariants(g, gdir, self.g_proj, self.linear_g1, self.linear_g2, tail=ng)      # [inv | ng]
         # q, k, v share their input and their row divisor: ONE product over the stacked weights
-        qkv = train_ops.linear(c, torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], dim=0),
-                               torch.cat([self.q_proj.bias, self.k_proj.bias, self.v_proj.bias], dim=0), rowdiv=fn)
+        qw, qb = self.qkv_stacked()
+        qkv = train_ops.linear(c, qw, qb, rowdiv=fn)
         # H = 2 heads of hd2 = 128 channels (the SET configuration): scores, softmax and both weighted sums in one operation on the
         # stacked qkv and on the vector values in parts (projected channels | the node's gravity / direction pair)
         o, og = train_ops.set_attention(qkv, self.vg_proj(g), gdir, bias, float(hd2) ** -0.5)
@@ -236,9 +269,8 @@ def _attention2(a, g, ng, gdir, gdir2, bias):
     _, B, L = ng.shape[:3]
     hd2 = 2 * (a[0].embed_dim // a[0].num_heads)
     c, fn = _invariants2(g, gdir2, (a[0].g_proj, a[1].g_proj), (a[0].linear_g1, a[1].linear_g1), (a[0].linear_g2, a[1].linear_g2), tail=ng)
-    qw = [torch.cat([m.q_proj.weight, m.k_proj.weight, m.v_proj.weight], dim=0) for m in a]
-    qb = [torch.cat([m.q_proj.bias, m.k_proj.bias, m.v_proj.bias], dim=0) for m in a]
-    qkv = train_ops.linear2(c, qw[0], qw[1], qb[0], qb[1], rowdiv=fn)
+    (qw0, qb0), (qw1, qb1) = a[0].qkv_stacked(), a[1].qkv_stacked()
+    qkv = train_ops.linear2(c, qw0, qw1, qb0, qb1, rowdiv=fn)
     vg = _lin2(a[0].vg_proj, a[1].vg_proj, g)
     scale = float(hd2) ** -0.5
     if bias is None:            # the two networks' environments as one batch of 2 B

@@ -525,6 +525,39 @@ def linear(x, weight, bias=None, relu=False, rowdiv=None, addend=None, tail=None
     return y if tail is None else torch.cat([y, tail], dim=-1)
 
 
+class _Adjacent3Fn(torch.autograd.Function):
+    """Three parameters that lie back to back in one allocation, seen as the one stacked tensor they already are: no launch in
+    the forward, views of the incoming gradient in the backward (what `torch.cat` + its backward produce with two copies)."""
+
+    @staticmethod
+    def forward(ctx, a, b, c):
+        ctx.n = a.shape[0]
+        return a.detach().as_strided((3 * a.shape[0],) + tuple(a.shape[1:]), a.stride(), a.storage_offset())
+
+    @staticmethod
+    def backward(ctx, d):
+        n = ctx.n
+        return d[:n], d[n:2 * n], d[2 * n:]
+
+
+def adjacent3(a, b, c):
+    """True if b starts where a ends and c where b ends (same shape, dtype, contiguous): SubequivariantAttention lays its q / k / v
+    projections out that way (set_policy.py `_adjoin`)."""
+    if not (a.shape == b.shape == c.shape and a.dtype == b.dtype == c.dtype and a.is_contiguous() and b.is_contiguous()
+            and c.is_contiguous() and a.device == b.device == c.device):
+        return False
+    step = a.numel() * a.element_size()
+    return b.data_ptr() == a.data_ptr() + step and c.data_ptr() == b.data_ptr() + step and \
+        a.untyped_storage().data_ptr() == c.untyped_storage().data_ptr()
+
+
+def stacked3(a, b, c):
+    """torch.cat([a, b, c], 0) -- without the copy when the three already lie back to back."""
+    if adjacent3(a, b, c):
+        return _Adjacent3Fn.apply(a, b, c)
+    return torch.cat([a, b, c], dim=0)
+
+
 def linear2(x, w0, w1, b0=None, b1=None, relu=False, rowdiv=None, shared=False, addend=None, tail=None):
     """`linear` for the same layer of two networks at once: returns [2, ..., N]; x = the input both share ([..., K], shared=True) or
     their inputs stacked ([2, ..., K]); rowdiv stacked [2, ..., 1]; addend stacked [2, ..., N]; tail [2, ..., t] (or one both share,

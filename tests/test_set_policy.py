@@ -115,3 +115,37 @@ def test_linear_followers_and_fused_norm_fall_back_to_the_plain_operations_on_th
     assert torch.equal(train_ops.add_layer_norm(a[0], None, n0), n0(a[0]))
     y = train_ops.add_layer_norm2(a, b, n0, n1)
     assert torch.equal(y[0], n0(a[0] + b[0])) and torch.equal(y[1], n1(a[1] + b[1]))
+
+
+def test_qkv_projections_lie_back_to_back_and_stack_without_a_copy():
+    """The training path multiplies by [Wq; Wk; Wv] (one product, SEActor.py:34-46 shares the input): the three parameters are
+    views of one allocation, the stack is that allocation, gradients come back as its thirds; construction, deepcopy, dtype / device
+    moves and load_state_dict keep the layout, separated tensors fall back to a concatenation with the same values."""
+    import copy
+    from sgrl_amd import train_ops
+    pol = make_policy(device="cpu")
+    attn = [m for m in pol.modules() if hasattr(m, "qkv_stacked")]
+    assert len(attn) == 3
+    for net in (pol, copy.deepcopy(pol), copy.deepcopy(pol).double().float()):
+        for m in (x for x in net.modules() if hasattr(x, "qkv_stacked")):
+            assert train_ops.adjacent3(m.q_proj.weight, m.k_proj.weight, m.v_proj.weight)
+            assert train_ops.adjacent3(m.q_proj.bias, m.k_proj.bias, m.v_proj.bias)
+    m = attn[0]
+    w, b = m.qkv_stacked()
+    assert w.data_ptr() == m.q_proj.weight.data_ptr() and w.shape == (768, 256) and b.shape == (768,)
+    assert torch.equal(w, torch.cat([m.q_proj.weight, m.k_proj.weight, m.v_proj.weight]))
+    coef = torch.arange(768, dtype=torch.float32)[:, None]
+    ((w * coef).sum() + (b * coef[:, 0]).sum()).backward()
+    for i, p in enumerate((m.q_proj, m.k_proj, m.v_proj)):
+        assert torch.equal(p.weight.grad, coef[256 * i:256 * (i + 1)].expand(256, 256))
+        assert torch.equal(p.bias.grad, coef[256 * i:256 * (i + 1), 0])
+    other = copy.deepcopy(pol)
+    sd = {k: v + 1.0 for k, v in pol.state_dict().items()}
+    other.load_state_dict(sd)
+    m2 = [x for x in other.modules() if hasattr(x, "qkv_stacked")][0]
+    assert train_ops.adjacent3(m2.q_proj.weight, m2.k_proj.weight, m2.v_proj.weight)
+    assert torch.equal(m2.qkv_stacked()[0], w.detach() + 1.0)
+    # separate tensors: the plain concatenation
+    a, b_, c = (torch.randn(4, 5, requires_grad=True) for _ in range(3))
+    assert not train_ops.adjacent3(a, b_, c)
+    assert torch.equal(train_ops.stacked3(a, b_, c), torch.cat([a, b_, c]))
