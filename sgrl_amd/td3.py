@@ -60,6 +60,7 @@ _FUSED_ADAM = os.environ.get("SGRL_FUSED_ADAM", "1") != "0" and hasattr(torch, "
 # include/sgrl_train.h sgrl_optim_*): three launches and one instead of torch's ~50 multi-tensor launches of ~18 us per update.
 _TABLE_OPT = os.environ.get("SGRL_TABLE_OPT", "1") != "0"
 _tables = {}          # key (kind, address tuple) -> dict(dev table, dev chunks, pinned copies, scratch): see _table()
+_capture_owner = None  # whoever is capturing a hipGraph right now (GraphedUpdates: (id, morphology key, flag)); see release_tables()
 
 
 def _optim_lib():
@@ -110,7 +111,8 @@ def _table(kind, rows, device):
     capturing = torch.cuda.is_current_stream_capturing()
     if ent is not None:
         if capturing:
-            ent["captured"] = True                 # a graph now points at this entry's device buffers: never evicted
+            ent["captured"] = True                 # a graph now points at this entry's device buffers: kept while an owner lives
+            ent["owners"].add(_capture_owner)
         elif not ent["eager_valid"]:               # made during a capture (its upload exists only as a node of that graph)
             ent["dev_tab"].copy_(ent["host_tab"], non_blocking=True)
             ent["dev_chunks"].copy_(ent["host_chunks"], non_blocking=True)
@@ -124,7 +126,8 @@ def _table(kind, rows, device):
         return None                                  # capturing with no pinned buffer in stock: the caller takes torch's path
     ent = {"host_tab": host_tab, "host_chunks": host_chunks, "n": len(rows), "n_chunks": len(chunks), "captured": capturing,
            "dev_tab": torch.empty_like(host_tab, device=device), "dev_chunks": torch.empty_like(host_chunks, device=device),
-           "scratch": torch.zeros(1 + len(chunks), dtype=torch.float32, device=device), "eager_valid": not capturing}
+           "scratch": torch.zeros(1 + len(chunks), dtype=torch.float32, device=device), "eager_valid": not capturing,
+           "owners": {_capture_owner} if capturing else set()}
     ent["dev_tab"].copy_(host_tab, non_blocking=True)
     ent["dev_chunks"].copy_(host_chunks, non_blocking=True)
     if not capturing and len(_tables) > 64:          # eager callers whose gradient addresses keep changing: bounded cache
@@ -132,6 +135,16 @@ def _table(kind, rows, device):
             del _tables[k]
     _tables[key] = ent
     return ent
+
+
+def release_tables(owner):
+    """The graph(s) captured under `owner` are gone (GraphedUpdates dropped them to capture again): table entries that only they
+    pointed at become ordinary cache entries again -- evictable -- instead of living as long as the process."""
+    for ent in _tables.values():
+        if owner in ent["owners"]:
+            ent["owners"].discard(owner)
+            if not ent["owners"]:
+                ent["captured"] = False
 
 
 def clip_and_step(opt, max_norm):
@@ -537,8 +550,11 @@ class GraphedUpdates(object):
         # before any capture -- but a graph captured before a LATER regrowth would fault on replay (a GPU memory fault, not an
         # exception): the workspaces' sizes are compared with those at capture time and such a graph is captured again.
         stamp = self._workspace_stamp()
+        owner = (id(self), key, flag)
         if flag in sl["graphs"] and sl["stamp"].get(flag) != stamp:
             del sl["graphs"][flag]
+            release_tables(owner)
+        global _capture_owner
         if flag not in sl["graphs"] and self.split:
             # Three graphs, all recorded on ONE capture stream (autograd's nodes then belong to one stream: no cross-stream
             # hand-overs inside the backward) but each with its own memory pool: the target chain and the critics' forward are
@@ -548,6 +564,7 @@ class GraphedUpdates(object):
                 self._cap_stream, self._side = torch.cuda.Stream(), _concurrent_stream(torch.cuda.current_stream())
             gs = [torch.cuda.CUDAGraph() for _ in range(3)]
             _stock_pinned(4)
+            _capture_owner = owner
             with _no_finalizers_during_capture():
                 with torch.cuda.graph(gs[0], stream=self._cap_stream):
                     rb, tq = self.agent.update_targets(sl["batch"], sl["noise"])
@@ -556,6 +573,7 @@ class GraphedUpdates(object):
                 with torch.cuda.graph(gs[2], stream=self._cap_stream):
                     sl["out"][flag] = self.agent.update_finish(sl["batch"], flag, rb, tq, q1, q2, lazy_stats=True,
                                                                skip_unused_critic_grads=True)
+            _capture_owner = None
             sl["graphs"][flag] = gs
             sl["stamp"][flag] = self._workspace_stamp()
         if flag not in sl["graphs"]:
@@ -565,9 +583,13 @@ class GraphedUpdates(object):
             if dump:
                 g.enable_debug_mode()
             _stock_pinned(4)
-            with _no_finalizers_during_capture(), torch.cuda.graph(g):
-                sl["out"][flag] = self.agent.update(sl["batch"], flag, noise=sl["noise"], lazy_stats=True,
-                                                    skip_unused_critic_grads=True)
+            _capture_owner = owner
+            try:
+                with _no_finalizers_during_capture(), torch.cuda.graph(g):
+                    sl["out"][flag] = self.agent.update(sl["batch"], flag, noise=sl["noise"], lazy_stats=True,
+                                                        skip_unused_critic_grads=True)
+            finally:
+                _capture_owner = None
             if dump:
                 g.debug_dump(os.path.join(dump, "update_%s_flag%d.dot" % (key, flag)))
             sl["graphs"][flag] = g           # capturing records the work without running it

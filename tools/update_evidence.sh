@@ -28,5 +28,6 @@ json.dump({"launches_per_update": round(tot_calls / iters, 1), "gpu_ms_per_updat
 print(open("$O/${TAG}_update_launches.json").read())
 PY
 SGRL_GRAPH_UPDATES=1 timeout 300 python3 tools/update_profile.py 3d_walker_7_full 50 > $O/update_graphed.log 2>&1
-SGRL_TUNE_GEMMS=0 timeout 900 python3 tools/train_bench.py > /tmp/upd/train.log 2>&1; cp gpurun_out/train_bench.json $O/${TAG}_config5_train_bench.json 2>/dev/null
+if [ -z "$SKIP_TRAIN" ]; then SGRL_TUNE_GEMMS=0 timeout 900 python3 tools/train_bench.py > /tmp/upd/train.log 2>&1; cp gpurun_out/train_bench.json $O/${TAG}_config5_train_bench.json 2>/dev/null; fi
+timeout 300 python3 tools/diag/update_launch_sources.py > $O/${TAG}_update_launch_sources.txt 2>&1
 for f in $O/update_eager.log $O/update_graphed.log /tmp/upd/train.log /tmp/upd/stats.err; do tail -n 2 $f; done
