@@ -635,7 +635,15 @@ __global__ __launch_bounds__(256) void k_add_ln_bwd(const float* __restrict__ dy
   if (!dw && !db) return;
   float aw = 0.f, ab = 0.f;
   const size_t base = (size_t)net * rows * 128 + c;
-  for (int r = grp; r < rows; r += 8) {
+  int r = grp;
+  for (; r + 56 < rows; r += 64) {       // eight of this group's rows in flight; summed in the same order as one at a time
+    float g[8], xh[8];                   // (26 -> 7 us for the update's 700 rows: the loop was a chain of dependent-latency loads)
+#pragma unroll
+    for (int u = 0; u < 8; u++) { g[u] = dy[base + (size_t)(r + 8 * u) * 128]; xh[u] = xhat[base + (size_t)(r + 8 * u) * 128]; }
+#pragma unroll
+    for (int u = 0; u < 8; u++) { aw += g[u] * xh[u]; ab += g[u]; }
+  }
+  for (; r < rows; r += 8) {
     const float g = dy[base + (size_t)r * 128];
     aw += g * xhat[base + (size_t)r * 128];
     ab += g;
