@@ -239,3 +239,25 @@ def test_skipping_the_unused_critic_gradients_changes_nothing_that_is_used():
         for p, q in zip(getattr(a1, nm).parameters(), getattr(a2, nm).parameters()):
             assert float((p - q).abs().max()) < 3e-6, nm          # three Adam steps of 1e-4 each: agreement to a few % of one step
     assert all(p.requires_grad for p in a2.critic.parameters())
+
+
+def test_captured_optimizer_tables_are_released_with_their_graphs():
+    """td3._table keeps an entry a hipGraph points at for as long as an owner (a captured graph) lives; GraphedUpdates names the
+    owner while it captures and releases it when it drops the graph: bookkeeping only, checked without a device."""
+    from sgrl_amd import td3
+    saved = dict(td3._tables)
+    try:
+        td3._tables.clear()
+        a, b = ("g", 0, 0), ("g", 0, 1)
+        td3._tables["shared"] = {"owners": {a, b}, "captured": True}
+        td3._tables["only_a"] = {"owners": {a}, "captured": True}
+        td3._tables["eager"] = {"owners": set(), "captured": False}
+        td3.release_tables(a)
+        assert td3._tables["shared"]["captured"] is True and td3._tables["shared"]["owners"] == {b}
+        assert td3._tables["only_a"]["captured"] is False and not td3._tables["only_a"]["owners"]
+        assert td3._tables["eager"]["captured"] is False
+        td3.release_tables(b)
+        assert td3._tables["shared"]["captured"] is False
+    finally:
+        td3._tables.clear()
+        td3._tables.update(saved)
