@@ -7,6 +7,9 @@ from sgrl_amd.vec_env import BatchedModularVecEnv
 names = sorted(["3d_walker_2_right_leg_left_knee", "3d_walker_3_left_leg_right_foot", "3d_walker_3_left_knee_right_knee",
          "3d_walker_4_right_knee_left_foot", "3d_walker_5_foot", "3d_walker_5_left_knee", "3d_walker_6_right_foot",
          "3d_walker_7_full"])
+if os.environ.get("QB_FAMILY"):      # e.g. QB_FAMILY=hopper: every shipped morphology of that family
+    from sgrl_amd import mjcf
+    names = sorted(n for n in mjcf.list_assets() if n.split("_")[1] == os.environ["QB_FAMILY"])
 per = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 kw = {}
