@@ -62,6 +62,9 @@ int sgrl_launch_groups(const sgrl_engine* e);   /* concurrent k_env_step dispatc
 /* How many of those dispatches run on a FIXED-DIMENSION kernel (sgrl_amd/csrc/step_spec.hip: the dimension sets of a shipped
  * morphology family as compile-time constants) instead of the generic one; 0 for custom XMLs / row caps, or with SGRL_SPECS=0. */
 int sgrl_fixed_dim_groups(const sgrl_engine* e);
+/* How many environments step TWO to a wavefront (sgrl_amd/csrc/wave_half.h): environments of the light morphologies (nv <= 12)
+ * on a fixed-dimension kernel, paired with a neighbour of the same morphology; 0 with SGRL_PAIR=0.  Same results to rounding. */
+int sgrl_paired_envs(const sgrl_engine* e);
 
 /* VecEnv.reset(): every env starts a new episode.  obs: DEV float[n_env*obs_max_len]; obs64: DEV double[...] or NULL. */
 int sgrl_reset(sgrl_engine* e, float* obs, double* obs64, void* stream);

@@ -23,6 +23,7 @@
 #include "../../include/sgrl.h"
 #include "step_body.h"
 #include "wave_hip.h"
+#include "wave_half.h"
 
 namespace sgrl_engine_dev {
 
@@ -40,6 +41,8 @@ struct BatchArgs {
   const MorphDev* morphs;     // [n_morph]
   const int32_t* env_morph;   // [n_env]
   const int32_t* block_env;   // [n_env] workgroup -> env, most expensive morphologies first (tail balance)
+  const int32_t* block_mate;  // fixed-dimension step kernels: [n_workgroups] the SECOND environment of a workgroup that steps two
+                              // environments of one light morphology (wave_half.h), -1 for one environment; null elsewhere
   double* rec;                // [n_env * stride]
   int32_t* cnt;               // [n_env * 4]
   double* scratch;            // [n_env * scratch_stride] HBM slabs for the constraint solves with more rows than the LDS arrays hold
@@ -133,8 +136,7 @@ __device__ __forceinline__ sgrl::StepIO make_io(const BatchArgs& a, const StepOu
 
 // the step of one environment by one wavefront (kernel body shared by every instance)
 template <class D, class W>
-__device__ __forceinline__ void env_step_wave(const BatchArgs& a, const StepOut& out) {
-  const int env = __builtin_amdgcn_readfirstlane(a.block_env[blockIdx.x]);
+__device__ __forceinline__ void env_step_wave(const BatchArgs& a, const StepOut& out, int env) {
   SgrlModelView m; sgrl::Layout o; double* S; int32_t* I;
   setup<D>(a, env, &m, &o, &S, &I);
   W w;
@@ -149,14 +151,49 @@ __device__ __forceinline__ void env_step_wave(const BatchArgs& a, const StepOut&
 #endif
 }
 
-// one kernel, several dimension sets: the workgroup's morphology says which instance runs (wave-uniform branch)
+// The step of TWO environments of one morphology by one wavefront (wave_half.h): lanes 0..31 environment `env_a` on the first LDS
+// slab, lanes 32..63 `env_b` on the second, one shared copy of the int tables behind both (Layout::pair_stride).  The model view,
+// the layout and every dimension stay wave-uniform; the slab pointers and the StepIO are per lane.
+template <class D, class W>
+__device__ __forceinline__ void env_step_pair(const BatchArgs& a, const StepOut& out, int env_a, int env_b) {
+  static_assert(!SGRL_STAGE_FLOATS, "the pair layout shares the int tables only");
+  const int mi = __builtin_amdgcn_readfirstlane(a.env_morph[env_a]);     // the host pairs environments of ONE morphology
+  const MorphDev md = a.morphs[mi];
+  int32_t hdr[SGRL_NHDR];
+#pragma unroll
+  for (int k = 0; k < SGRL_NHDR; k++) hdr[k] = __builtin_amdgcn_readfirstlane(md.ib[k]);
+  D::apply(hdr);
+  int n_int, n_f64;
+  sgrl_model_blob_sizes(hdr, &n_int, &n_f64);
+  sgrl::Layout o;
+  sgrl::make_layout(hdr, &o, n_int, 0, true);
+  int32_t* const ia = reinterpret_cast<int32_t*>(sgrl_lds + o.s_total);
+  for (int k = threadIdx.x; k < n_int; k += 64) ia[o.model_i + k] = md.ib[k];
+  __syncthreads();
+  SgrlModelView m;
+  sgrl_model_view_dims(hdr, (sgrl_hdr_t)md.ib, (sgrl_fhdr_t)md.fb, (sgrl_itab_t)(ia + o.model_i), (sgrl_ftab_t)md.fb, &m);
+  W w;
+  double* const S = sgrl_lds + w.half * o.pair_stride;
+  int32_t* const I = ia + 2 * w.half * o.pair_stride;
+  const sgrl::StepIO io = make_io(a, out, w.half ? env_b : env_a);
+  sgrl::env_step(w, m, o, S, I, io);
+}
+
+// one kernel, several dimension sets: the workgroup's morphology says which instance runs (wave-uniform branch); a workgroup
+// with a mate (>= 0) steps two environments on the half-wave instance of its set
 template <int I, class... Ds> struct FamilyRun {
-  __device__ static __forceinline__ void run(int, const BatchArgs&, const StepOut&) {}
+  __device__ static __forceinline__ void run(int, int, int, const BatchArgs&, const StepOut&) {}
 };
 template <int I, class D, class... Rest> struct FamilyRun<I, D, Rest...> {
-  __device__ static __forceinline__ void run(int slot, const BatchArgs& a, const StepOut& out) {
-    if (slot == I) { env_step_wave<D, sgrl::HipWaveT<(D::kNv <= 24 ? D::kNv : 24), D>>(a, out); return; }
-    FamilyRun<I + 1, Rest...>::run(slot, a, out);
+  __device__ static __forceinline__ void run(int slot, int env, int mate, const BatchArgs& a, const StepOut& out) {
+    if (slot == I) {
+      if constexpr (D::kPair) {
+        if (mate >= 0) { env_step_pair<D, sgrl::HalfWaveT<D::kNv, sgrl::HipHalfPrim<D>>>(a, out, env, mate); return; }
+      }
+      env_step_wave<D, sgrl::HipWaveT<(D::kNv <= 24 ? D::kNv : 24), D>>(a, out, env);
+      return;
+    }
+    FamilyRun<I + 1, Rest...>::run(slot, env, mate, a, out);
   }
 };
 

@@ -81,10 +81,14 @@ struct Layout {
   int con_valid, row_kind, row_src, row_sub, prev_key, flist, ecnt, icnt;
   int model_i; // LDS copy of the int model blob (n_int ints)
   int i_total;
+  // TWO environments of one morphology per workgroup (wave_half.h): environment B's slab lies pair_stride doubles behind A's
+  // (S_B = S_A + pair_stride, I_B = I_A + 2 pair_stride) and ONE copy of the int model tables behind both (model_i is relative
+  // to I_A).  0: one environment per workgroup.
+  int pair_stride;
 };
 
 // lrows_cut: rows taken off the natural size of the LDS row arrays (make_layout picks it)
-SGRL_HD void make_layout_rows(const int32_t* hdr, Layout* o, int n_int, int n_f64, int lrows_cut) {
+SGRL_HD void make_layout_rows(const int32_t* hdr, Layout* o, int n_int, int n_f64, int lrows_cut, bool pair = false) {
   const int nb = hdr[SGRL_H_NBODY], nj = hdr[SGRL_H_NJNT], nq = hdr[SGRL_H_NQ], nv = hdr[SGRL_H_NV];
   const int nu = hdr[SGRL_H_NU], np = hdr[SGRL_H_NPAIR];
   o->nb = nb; o->nj = nj; o->nq = nq; o->nv = nv; o->nu = nu; o->np = np;
@@ -140,6 +144,12 @@ SGRL_HD void make_layout_rows(const int32_t* hdr, Layout* o, int n_int, int n_f6
   o->flist = q; q += o->lrows;
   o->ecnt = q; q += 2 * nj + o->ncon;
   o->icnt = q; q += 8;
+  o->pair_stride = 0;
+  if (pair) {      // [S_A | I_A] [S_B | I_B] [model ints]: the shared tables start where environment B's slab ends
+    q = (q + 1) & ~1;
+    o->pair_stride = o->s_total + q / 2;
+    q += 2 * o->pair_stride;
+  }
   o->model_i = q; q += n_int;
   o->i_total = q;
 }
@@ -157,12 +167,12 @@ constexpr int kMaxRowCut = 16;
 // shorter (never below 20) when that is what it takes to fit one more workgroup per CU: walker_7 22 392 B (32 rows, 7 per
 // CU) -> 20 344 B (24 rows, 8 per CU), measured 10 % faster on the walker mix although more evaluations (25..32 rows) then
 // take the HBM slab path.  Evaluations with more rows than the arrays hold use the slab either way: nothing is dropped.
-SGRL_HD void make_layout(const int32_t* hdr, Layout* o, int n_int = 0, int n_f64 = 0) {
-  make_layout_rows(hdr, o, n_int, n_f64, 0);
+SGRL_HD void make_layout(const int32_t* hdr, Layout* o, int n_int = 0, int n_f64 = 0, bool pair = false) {
+  make_layout_rows(hdr, o, n_int, n_f64, 0, pair);
   const int base = workgroups_per_cu(layout_bytes(o));
   for (int cut = 1; cut <= kMaxRowCut && o->lrows - cut >= 20; cut++) {
     Layout t;
-    make_layout_rows(hdr, &t, n_int, n_f64, cut);
+    make_layout_rows(hdr, &t, n_int, n_f64, cut, pair);
     if (workgroups_per_cu(layout_bytes(&t)) > base) { *o = t; return; }
   }
 }

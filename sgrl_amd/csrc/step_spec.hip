@@ -18,8 +18,9 @@ using namespace sgrl_engine_dev;
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGRL_SPEC_WAVES, SGRL_SPEC_WAVES))) void k_env_step_spec(BatchArgs a, StepOut out) {
   const int env = __builtin_amdgcn_readfirstlane(a.block_env[blockIdx.x]);
+  const int mate = __builtin_amdgcn_readfirstlane(a.block_mate[blockIdx.x]);
   const int slot = __builtin_amdgcn_readfirstlane(a.morphs[__builtin_amdgcn_readfirstlane(a.env_morph[env])].slot);
-  FamilyRun<0, SGRL_SPEC_FAMILY>::run(slot, a, out);
+  FamilyRun<0, SGRL_SPEC_FAMILY>::run(slot, env, mate, a, out);
 }
 }  // namespace
 

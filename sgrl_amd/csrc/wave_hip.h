@@ -44,13 +44,16 @@ __device__ __forceinline__ double wave_max(double x) {
 // whose header matches it field for field (engine.hip spec_for).
 struct DimsAny {
   static constexpr bool kFixed = false;
+  static constexpr bool kPair = false;
   __device__ static __forceinline__ void apply(int32_t*) {}
   template <class M> __device__ static __forceinline__ int hdr_const(const M& m, int idx) { return m.hdr[idx]; }
 };
-template <int NB, int NJ, int NQ, int NV, int NU, int NG, int NP, int INTEG, int FSKIP, int MAXROWS, int SOLVER>
+struct DimsAny;
+template <int NB, int NJ, int NQ, int NV, int NU, int NG, int NP, int INTEG, int FSKIP, int MAXROWS, int SOLVER, int PAIR = 0>
 struct DimsFixed {
   static constexpr bool kFixed = true;
   static constexpr int kNv = NV;
+  static constexpr bool kPair = PAIR != 0;     // the family kernel also holds the two-environments-per-wavefront instance of this set
   __device__ static __forceinline__ void apply(int32_t* hdr) {
     hdr[SGRL_H_NBODY] = NB; hdr[SGRL_H_NJNT] = NJ; hdr[SGRL_H_NQ] = NQ; hdr[SGRL_H_NV] = NV; hdr[SGRL_H_NU] = NU;
     hdr[SGRL_H_NGEOM] = NG; hdr[SGRL_H_NPAIR] = NP; hdr[SGRL_H_INTEGRATOR] = INTEG; hdr[SGRL_H_FRAME_SKIP] = FSKIP;
@@ -482,5 +485,71 @@ struct HipWaveT {
   }
 };
 using HipWave = HipWaveT<24>;
+
+// gfx950 primitives of the half-wave interface (wave_half.h): lanes 0..31 = environment A, 32..63 = environment B.  A half is two
+// 16-lane DPP rows; everything here stays inside the caller's half, so it also holds when only one half is active (the two
+// environments' data-dependent branches diverge at half granularity).
+template <class D>
+struct HipHalfPrim {
+  static constexpr bool kFixedDims = D::kFixed;
+  template <class M> __device__ static __forceinline__ int hdr_const(const M& m, int idx) { return D::hdr_const(m, idx); }
+  int lane;      // logical lane inside the half
+  int half;
+  __device__ __forceinline__ HipHalfPrim() : lane(threadIdx.x & 31), half((threadIdx.x >> 5) & 1) {}
+#ifdef SGRL_PHASE_PROF
+  __device__ __forceinline__ void tick(int) {}      // the phase profile is taken on the one-environment instances
+#endif
+  __device__ __forceinline__ void fence_lane() { asm volatile("" : "+v"(lane)); }
+  template <class T> __device__ __forceinline__ T fenced(T v) {
+    int t = __builtin_amdgcn_readfirstlane((int)(unsigned)(__UINTPTR_TYPE__)v);
+    asm volatile("" : "+s"(t));
+    return (T)(__UINTPTR_TYPE__)(unsigned)t;
+  }
+  __device__ static __forceinline__ void sync() { __syncthreads(); }
+  // row_newbcast:j -- lane j of every 16-lane row to the whole row.  The callers keep their operands in logical lanes 0..15 = the
+  // FIRST row of the half and read the result there (the second row computes on its own lanes' values, never stored).
+  __device__ static __forceinline__ double bcast16(double x, int j) {
+    switch (j) {       // j is a constant after unrolling: one DPP move per half of the double
+      case 0: return dpp_move<0x150>(x);   case 1: return dpp_move<0x151>(x);   case 2: return dpp_move<0x152>(x);
+      case 3: return dpp_move<0x153>(x);   case 4: return dpp_move<0x154>(x);   case 5: return dpp_move<0x155>(x);
+      case 6: return dpp_move<0x156>(x);   case 7: return dpp_move<0x157>(x);   case 8: return dpp_move<0x158>(x);
+      case 9: return dpp_move<0x159>(x);   case 10: return dpp_move<0x15A>(x);  case 11: return dpp_move<0x15B>(x);
+      case 12: return dpp_move<0x15C>(x);  case 13: return dpp_move<0x15D>(x);  case 14: return dpp_move<0x15E>(x);
+      default: return dpp_move<0x15F>(x);
+    }
+  }
+  __device__ static __forceinline__ double xor1(double x) { return dpp_move<0xB1>(x); }      // quad_perm [1,0,3,2]
+  // v_permlane16_swap (gfx950): odd rows of the first operand <-> even rows of the second; with both = x the pair comes back as
+  // (row0 row0 row2 row2), (row1 row1 row3 row3): every lane holds both row values of its half
+  __device__ static __forceinline__ void rows_of_half(double x, double* even, double* odd) {
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    *even = __hiloint2double((int)h[0], (int)l[0]);
+    *odd = __hiloint2double((int)h[1], (int)l[1]);
+  }
+  __device__ static __forceinline__ double half_sum(double x) {
+    x += dpp_move<0xB1>(x);
+    x += dpp_move<0x4E>(x);
+    x += dpp_move<0x141>(x);
+    x += dpp_move<0x140>(x);
+    double e, o;
+    rows_of_half(x, &e, &o);
+    return e + o;
+  }
+  __device__ static __forceinline__ double half_max(double x) {
+    x = fmax(x, dpp_move<0xB1>(x));
+    x = fmax(x, dpp_move<0x4E>(x));
+    x = fmax(x, dpp_move<0x141>(x));
+    x = fmax(x, dpp_move<0x140>(x));
+    double e, o;
+    rows_of_half(x, &e, &o);
+    return fmax(e, o);
+  }
+  __device__ __forceinline__ uint32_t half_ballot(bool p) const {
+    const uint64_t b = (uint64_t)__ballot(p);
+    return half ? (uint32_t)(b >> 32) : (uint32_t)b;
+  }
+};
 
 }  // namespace sgrl

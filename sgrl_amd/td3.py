@@ -256,8 +256,14 @@ def adam_step(opt):
 
 
 def default_train_args(**over):
-    """The reference's TD3 / SET hyper-parameters (reference arguments.py:55-160, configs/default.py:9-12)."""
+    """The reference's TD3 / SET hyper-parameters (reference arguments.py:55-160, configs/default.py:9-12).
+
+    Two batch sizes, as in the reference: `agent_batch_size` = 256 is what an update SAMPLES (configs/default.py:61 "trainer":
+    {"agent_batch_size": 256}, passed as **args['trainer'] at main.py:164-171, read at trainer.py:289-291
+    `self.env_buffer[name].sample(self.agent_batch_size)`); `batch_size` = 100 (arguments.py:66-68 --batch_size) only reaches the
+    policies' constructor argument, which none of them uses (agent.py:42)."""
     a = default_args()
+    a.agent_batch_size = 256
     a.actor_type = a.critic_type = "set"
     a.limb_obs_size, a.limb_action_size = 41, 3
     a.msg_dim, a.batch_size, a.max_action, a.max_children = 32, 100, 1.0, 3

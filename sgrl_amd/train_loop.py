@@ -26,7 +26,8 @@ class DeviceTrainer(object):
                  batch_size=None, dst=0, graph_updates=False, tune_gemms=False, rollout=None, **env_kw):
         """graph_updates: replay the TD3 update from hipGraphs (td3.GraphedUpdates); tune_gemms: let PyTorch's TunableOp pick
         the rocBLAS / hipBLASLt algorithm per GEMM shape on first use (the defaults choose 256 x 256 tiles for the 700-row
-        weight-gradient GEMMs of a batch-100 update: 50 -> 38 ms per update)."""
+        weight-gradient GEMMs of a 100-row update: 50 -> 38 ms per update, round 1).  batch_size: rows per TD3 update, default
+        args.agent_batch_size = 256 (the reference's trainer.py:289-291)."""
         import torch.distributed as dist
         self.dist = dist
         self.rank = dist.get_rank() if dist.is_initialized() else 0
@@ -53,7 +54,9 @@ class DeviceTrainer(object):
         self.device = env.device
         self.graph_dicts = self.ro.graph_dicts
         self.is_learner = self.rank == dst
-        self.batch_size = int(batch_size if batch_size is not None else self.args.batch_size)
+        # rows per TD3 update: the reference's trainer samples `agent_batch_size` (configs/default.py:61 = 256, main.py:164-171,
+        # trainer.py:289-291); args.batch_size (100) is only the policies' unused constructor argument
+        self.batch_size = int(batch_size if batch_size is not None else getattr(self.args, "agent_batch_size", 256))
         self.buffers = None
         if self.is_learner:     # one ring buffer per morphology (reference main.py:141-155), rows cut to 41 L / 3 L
             self.buffers = [DeviceReplayBuffer(41 * L, 3 * L, max_buffer_size, device=self.device) for L in env.num_limbs]

@@ -116,6 +116,7 @@ class BatchedModularVecEnv(VecEnv):
         self.lds_bytes = L.sgrl_lds_bytes(h)
         self.launch_groups = L.sgrl_launch_groups(h)
         self.fixed_dim_groups = L.sgrl_fixed_dim_groups(h)     # launch groups on a fixed-dimension kernel (csrc/step_spec.hip)
+        self.paired_envs = L.sgrl_paired_envs(h)               # environments that step two to a wavefront (csrc/wave_half.h)
         dev = self.device
         self.obs = torch.zeros((n, self.obs_max_len), dtype=torch.float32, device=dev)
         self.rew = torch.zeros(n, dtype=torch.float32, device=dev)

@@ -96,3 +96,64 @@ def set_reverse(flag):
 def set_linv(flag):
     """True (default): small systems take the explicit-inverse path, as HipWave does; False: always the L path."""
     lib().sgrl_emu_set_linv(int(bool(flag)))
+
+
+# ---- two environments per wavefront (sgrl_amd/csrc/wave_half.h) on the SIMT fiber emulator (tests/emu/emu_pair.cpp) --------------
+_PAIR_LIB = None
+
+
+def pair_lib():
+    global _PAIR_LIB
+    if _PAIR_LIB is None:
+        d = os.path.join(_HERE, "emu")
+        so = os.path.join(d, "libsgrl_emu_pair.so")
+        csrc = os.path.join(_HERE, "..", "sgrl_amd", "csrc")
+        srcs = [os.path.join(d, "emu_pair.cpp"), os.path.join(csrc, "step_body.h"), os.path.join(csrc, "wave_half.h"),
+                os.path.join(_HERE, "..", "include", "sgrl_model.h")]
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
+            subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, srcs[0], "-lm"])
+        _PAIR_LIB = ctypes.CDLL(so)
+    return _PAIR_LIB
+
+
+class PairEmu(object):
+    """Two environments of ONE morphology stepped by one emulated wavefront (lanes 0..31 / 32..63)."""
+
+    def __init__(self, ib, fb, seed=0, env_ids=(0, 1), max_episode_steps=1000, obs_max_len=None):
+        self.envs = [EmuEnv(ib, fb, seed=seed, env_id=e, max_episode_steps=max_episode_steps, obs_max_len=obs_max_len) for e in env_ids]
+        self.ib, self.fb = self.envs[0].ib, self.envs[0].fb
+        self.seed, self.max_episode_steps = seed, max_episode_steps
+        self.obs_max_len = self.envs[0].obs_max_len
+
+    def layout_bytes(self):
+        return pair_lib().sgrl_emu_pair_layout_bytes(_p(self.ib, _i32p), _p(self.fb, _f64p))
+
+    def _call(self, op, actions=None, auto_reset=True):
+        n = self.obs_max_len
+        obs32 = [np.zeros(n, dtype=np.float32) for _ in range(2)]
+        obs64 = [np.zeros(n) for _ in range(2)]
+        rew = [np.zeros(1) for _ in range(2)]
+        done = [np.zeros(1, dtype=np.uint8) for _ in range(2)]
+        trunc = [np.zeros(1, dtype=np.uint8) for _ in range(2)]
+        dist = [np.zeros(1, dtype=np.float32) for _ in range(2)]
+        acts = None if actions is None else [np.ascontiguousarray(a, dtype=np.float32) for a in actions]
+
+        def arr(xs, t):
+            return (t * 2)(*[x.ctypes.data_as(t) for x in xs])
+        ids = (ctypes.c_uint32 * 2)(*[e.env_id for e in self.envs])
+        rc = pair_lib().sgrl_emu_pair_env(
+            op, _p(self.ib, _i32p), _p(self.fb, _f64p), arr([e.rec for e in self.envs], _f64p), arr([e.cnt for e in self.envs], _i32p),
+            None if acts is None else arr(acts, _f32p), arr(obs32, _f32p), arr(obs64, _f64p), n, ctypes.c_uint64(self.seed), ids,
+            self.max_episode_steps, int(auto_reset), arr(rew, _f64p), arr(done, _u8p), arr(dist, _f32p), arr(trunc, _u8p))
+        assert rc == 0, {-1: "bad model", -2: "the lanes of a half diverged (deadlock)", -3: "an access left its slab"}.get(rc, rc)
+        return [(obs64[h], float(rew[h][0]), bool(done[h][0]), {"dist": float(dist[h][0]), "TimeLimit.truncated": bool(trunc[h][0]),
+                                                                "obs32": obs32[h]}) for h in range(2)]
+
+    def reset(self):
+        return [r[0] for r in self._call(0)]
+
+    def refresh(self):
+        return [r[0] for r in self._call(2)]
+
+    def step(self, actions, auto_reset=True):
+        return self._call(1, actions, auto_reset)

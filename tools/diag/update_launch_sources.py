@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Which source lines of one TD3 update launch how many kernels (torch.profiler, eager, walker_7, batch 100): the launches of a
+"""Which source lines of one TD3 update launch how many kernels (torch.profiler, eager, walker_7, batch = agent_batch_size = 256): the launches of a
 policy iteration (it % policy_freq == 0: critic + actor + target updates) grouped by the innermost frame inside sgrl_amd/ and by
 kernel name.  Usage: update_launch_sources.py [morphology]"""
 import os, sys, collections, re
@@ -12,12 +12,13 @@ from sgrl_amd.td3 import Agent, default_train_args
 name = sys.argv[1] if len(sys.argv) > 1 else "3d_walker_7_full"
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-agent = Agent(default_train_args(), device=dev)
+targs = default_train_args()
+agent = Agent(targs, device=dev)
 m = mjcf.load_asset(name)
 gd = G.getGraphDict(m.parents, TRAV, [], device=dev)
 agent.change_morphology(gd)
 agent.models2train()
-B, L = 100, m.num_limbs
+B, L = targs.agent_batch_size, m.num_limbs
 g = torch.Generator(device=dev).manual_seed(1)
 def obs():
     o = torch.randn((B, L, 41), device=dev, generator=g) * 0.5

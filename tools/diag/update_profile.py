@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""How launch-bound is one TD3 update?  Counts kernels and GPU-busy time of 20 updates on walker_7 (B = 100)."""
+"""How launch-bound is one TD3 update?  Counts kernels and GPU-busy time of 20 updates on walker_7 (B = agent_batch_size = 256)."""
 import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
@@ -13,7 +13,7 @@ agent = Agent(args, device="cuda:0")
 m = mjcf.load_asset("3d_walker_7_full")
 gd = G.getGraphDict(m.parents, ["pre", "inlcrs", "postlcrs"], [], device=torch.device("cuda:0"))
 agent.change_morphology(gd)
-B, L = 100, 7
+B, L = args.agent_batch_size, 7
 batch = {"obs": torch.from_numpy(synth_obs(L, B, 1).astype(np.float32)).cuda(), "next_obs": torch.from_numpy(synth_obs(L, B, 2).astype(np.float32)).cuda(),
          "action": torch.rand(B, 3 * L, device="cuda") * 2 - 1, "reward": torch.randn(B, 1, device="cuda"), "done": torch.zeros(B, 1, device="cuda")}
 agent.models2train()

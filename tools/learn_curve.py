@@ -79,7 +79,7 @@ def train():
             print("round %d: return %.2f length %.1f iters %d wall %.0f s" % (rnd, s["performance/train_return"],
                   s["performance/train_length"], s["per_morph_iter"], s["wall_s"]), flush=True)
     out = {"seed": seed, "config": "BASELINE.json config %s (%s) x %d envs" % ({"hopper": "2: 3D_Hopper++", "walker": "3: 3D_Walker++", "humanoid": "4: 3D_Humanoid++", "cwhh": "5: 3D_CWHH++"}.get(family, family), ", ".join(names), per),
-           "schedule": "reference trainer.py:143-286 (per_morph_iter updates per morphology per round, batch 100, lr 1e-4, expl_noise 0.126)",
+           "schedule": "reference trainer.py:143-286 (per_morph_iter updates per morphology per round, batch %d (agent_batch_size, reference configs/default.py:61), lr 1e-4, expl_noise 0.126)" % tr.batch_size,
            "random_policy": {"train_return_mean": float(np.mean(rand_returns)) if rand_returns else None,
                              "train_length_mean": float(np.mean(rand_lengths)) if rand_lengths else None, "rounds": len(rand_returns)},
            "rounds": curve, "block_pivot_failures_last_step_sum": pivot_fail, "hbm_slab_solves_last_step_sum": slab,

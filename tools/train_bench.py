@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE.json config 5 on one GPU: the 23 cwhh training morphologies x 356 envs, DeviceTrainer (collection rounds +
 TD3 update schedule).  Reports collection env-steps/s (policy forward + exploration noise + engine step + replay ingest)
-and TD3 updates/s (batch 100, one morphology per update, PyTorch-ROCm autograd with HIP no-grad targets).
+and TD3 updates/s (batch = args.agent_batch_size = 256, the reference's configs/default.py:61; one morphology per update, PyTorch-ROCm autograd with HIP no-grad targets).
 Writes gpurun_out/train_bench.json."""
 import json, os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,7 +37,7 @@ U = 10 * len(names)
 t_update = (time.time() - t0) / U
 out = {"morphologies": len(names), "envs": n, "ms_per_collection_step": round(t_collect * 1e3, 3),
        "collection_env_steps_per_s": round(n / t_collect, 1), "ms_per_td3_update": round(t_update * 1e3, 3),
-       "td3_updates_per_s": round(1.0 / t_update, 2), "batch_size": args.batch_size, "hipgraph_updates": GRAPH, "tunableop": TUNE,
+       "td3_updates_per_s": round(1.0 / t_update, 2), "batch_size": tr.batch_size, "hipgraph_updates": GRAPH, "tunableop": TUNE,
        "row_overflow_envs": tr.ro.env.row_overflow_envs(), "buffer_rows": [b.max_sample_size for b in tr.buffers]}
 print(json.dumps(out))
 os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)

@@ -15,7 +15,7 @@ f = sorted(glob.glob("/tmp/upd/stats/**/*kernel_stats.csv", recursive=True))
 rows = list(csv.DictReader(open(f[0]))) if f else []
 iters = 20 + 4
 out = open("$O/${TAG}_update_kernel_stats.csv", "w")
-out.write("# one TD3 update of 3d_walker_7_full, batch 100, eager (tools/update_profile.py under rocprofv3 --kernel-trace --stats); %d updates in the run\n" % iters)
+out.write("# one TD3 update of 3d_walker_7_full, batch 256 (agent_batch_size), eager (tools/update_profile.py under rocprofv3 --kernel-trace --stats); %d updates in the run\n" % iters)
 out.write("Name,Calls,CallsPerUpdate,TotalDurationNs,AverageNs,Percentage\n")
 tot_calls = 0
 for r in rows:

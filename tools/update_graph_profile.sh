@@ -14,7 +14,7 @@ f = sorted(glob.glob("/tmp/updg/stats/**/*kernel_stats.csv", recursive=True))
 rows = list(csv.DictReader(open(f[0]))) if f else []
 iters = 50 + 4 + 3          # timed + untimed replays + the eager warm-up updates (close enough for shares)
 out = open("$O/${TAG}_update_graphed_kernel_stats.csv", "w")
-out.write("# hipGraph-replayed TD3 update of 3d_walker_7_full, batch 100 (tools/update_graph_profile.sh): %d updates in the run (3 eager warm-ups)\n" % iters)
+out.write("# hipGraph-replayed TD3 update of 3d_walker_7_full, batch 256 (agent_batch_size) (tools/update_graph_profile.sh): %d updates in the run (3 eager warm-ups)\n" % iters)
 out.write("Name,Calls,CallsPerUpdate,TotalDurationNs,AverageNs,Percentage\n")
 tc = tn = 0
 for r in rows:

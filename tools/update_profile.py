@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""One morphology's TD3 update in isolation (batch 100, synthetic batch): eager timing and, under rocprofv3, the per-kernel
+"""One morphology's TD3 update in isolation (synthetic batch of args.agent_batch_size = 256 rows, the reference's
+configs/default.py:61; SGRL_UPDATE_BATCH=<n> overrides): eager timing and, under rocprofv3, the per-kernel
 decomposition of the update's GPU time.  Usage: update_profile.py [morphology] [iters]; SGRL_GRAPH_UPDATES=1 replays hipGraphs."""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,12 +12,13 @@ name = sys.argv[1] if len(sys.argv) > 1 else "3d_walker_7_full"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-agent = Agent(default_train_args(), device=dev)
+targs = default_train_args()
+agent = Agent(targs, device=dev)
 m = mjcf.load_asset(name)
 gd = G.getGraphDict(m.parents, TRAV, [], device=dev)
 agent.change_morphology(gd)
 agent.models2train()
-B, L = 100, m.num_limbs
+B, L = int(os.environ.get("SGRL_UPDATE_BATCH", targs.agent_batch_size)), m.num_limbs
 def synth_obs(seed):     # plausible magnitudes: positions / velocities O(1), the constant columns of the 41-float limb row
     g = torch.Generator(device=dev).manual_seed(seed)
     o = torch.randn((B, L, 41), device=dev, generator=g) * 0.5
