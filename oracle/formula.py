@@ -95,3 +95,14 @@ def synth_obs(num_limbs, batch, seed):
     obs[:, 0, 36:40] = [1, 0, 0, 0]
     obs[:, :, 40] = rng.uniform(0.0, 1.6, size=(batch, L))
     return obs.reshape(batch, L * 41)
+
+
+def scripted_batch(L, B, seed):
+    """A replay batch made from seeds only (tools/capture_golden_update.py feeds it to the reference's Agent.update; the tests
+    regenerate it instead of storing a 256-row batch): observations synth_obs(seed) / synth_obs(seed + 1), uniform actions,
+    N(1, 0.5) rewards, 30 % done flags.  float32, the dtype the replay buffer hands out."""
+    rng = np.random.RandomState(seed)
+    return dict(obs=synth_obs(L, B, seed).astype(np.float32), next_obs=synth_obs(L, B, seed + 1).astype(np.float32),
+                action=rng.uniform(-1, 1, size=(B, 3 * L)).astype(np.float32),
+                reward=rng.normal(1.0, 0.5, size=(B, 1)).astype(np.float32),
+                done=(rng.uniform(size=(B, 1)) < 0.3).astype(np.float32))

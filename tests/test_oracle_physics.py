@@ -334,6 +334,41 @@ def test_random_rollouts_stay_finite_and_terminate():
         assert dones >= 1, name  # random actions make every morphology fall within 150 steps
 
 
+@pytest.mark.parametrize("name,stands", [("3d_cheetah_14_full", True), ("3d_walker_7_full", False), ("3d_hopper_5_full", False),
+                                         ("3d_humanoid_9_full", False)])
+def test_zero_action_settle_from_qpos0(name, stands):
+    """From qpos0 exactly (no reset noise) with zero action, one morphology per family (tools/diag/termination_clauses.py,
+    profiles/r5_termination_clauses.json).  The quadruped must STAND: the cheetah drops from z = 0.7 onto its four feet and rests at
+    z = 0.487 with roll 0 and |qvel|^2 -> 1e-8 (an unstable equilibrium about the roll axis: rounding noise tips the 0.24 m wide
+    stance after ~200 steps, so it is checked at 150) -- the restated model holds a pose, so the cheetah family's short episodes
+    come from the reset distribution (reference 3d_cheetah_14_full.py:157-159: U(+-0.1) on every qpos, quaternion included), not
+    from the physics.  The unactuated bipeds / monopeds fall, as they must; left-right symmetric ones fall in the sagittal plane
+    (roll stays at rounding level), nothing tunnels through the floor and everything comes to rest."""
+    m, om = oracle_model(name)
+    env = physics_ref.OracleEnv(om, seed=0)
+    env.reset()
+    env.qpos[:] = om.fb[16:16 + om.nq]
+    env.qvel[:] = 0
+    env.refresh()
+    zero = np.zeros(3 * om.L)
+
+    def roll_of(q):
+        w, x, y, z = q
+        return np.arctan2(2 * y * z + 2 * x * w, 1 - 2 * x * x - 2 * y * y)
+    for t in range(150):
+        obs = env.step(zero, auto_reset=False)[0]
+        assert np.isfinite(obs).all()
+    if stands:
+        assert 0.48 < env.qpos[2] < 0.495 and abs(roll_of(env.qpos[3:7])) < 1e-4 and np.square(env.qvel).sum() < 1e-6
+    elif "humanoid" not in name:
+        assert abs(roll_of(env.qpos[3:7])) < 1e-6 or abs(abs(roll_of(env.qpos[3:7])) - np.pi) < 1e-6      # sagittal fall of a symmetric body
+    for t in range(150):
+        obs = env.step(zero, auto_reset=False)[0]
+    zs = obs.reshape(om.L, 41)[:, 40]
+    assert np.isfinite(obs).all() and zs.min() > 0.02            # every limb origin above the floor (capsule radii >= 0.04)
+    assert np.square(env.qvel).sum() < 1.0                       # at rest (or nearly)
+
+
 def test_time_limit_truncation():
     m, om = oracle_model("3d_walker_7_full")
     env = physics_ref.OracleEnv(om, seed=1, max_episode_steps=3)

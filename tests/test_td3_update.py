@@ -49,7 +49,12 @@ def run_script(z, device, use_hip):
         tag = "it%d/" % it
         m = mjcf.load_asset(str(z[tag + "name"]))
         agent.change_morphology(G.getGraphDict(m.parents, TRAV, [], device=torch.device(device)))
-        batch = {k: torch.from_numpy(z[tag + k]).to(device) for k in ("obs", "action", "next_obs", "reward", "done")}
+        if tag + "obs" in z.files:
+            rows = {k: z[tag + k] for k in ("obs", "action", "next_obs", "reward", "done")}
+        else:       # the 256-row fixture stores seeds, not rows (tools/capture_golden_update.py)
+            from oracle.formula import scripted_batch
+            rows = scripted_batch(m.num_limbs, int(hyper["batch"]), int(z[tag + "batch_seed"]))
+        batch = {k: torch.from_numpy(rows[k]).to(device) for k in ("obs", "action", "next_obs", "reward", "done")}
         before = {nm: _sums(getattr(agent, nm)) for nm in ("actor", "critic", "actor_target", "critic_target")}
         loss = agent.update(batch, it, noise=torch.from_numpy(z[tag + "noise"]).to(device))
         rec = {"critic_loss": float(loss["loss/critic_loss"]),
@@ -100,9 +105,11 @@ def check_against_golden(z, agent, hyper, out, loss_rtol=1e-4, grad_tol=2e-3, st
     np.testing.assert_allclose(out[3], z["select_action/action"], atol=5e-5)
 
 
-@pytest.fixture(scope="module")
-def golden(golden_dir):
-    return np.load(os.path.join(golden_dir, "td3_update.npz"))
+@pytest.fixture(scope="module", params=["td3_update.npz", "td3_update_b256.npz"], ids=["batch6", "batch256"])
+def golden(golden_dir, request):
+    """batch6: rows stored in the fixture; batch256: the reference's own agent_batch_size (configs/default.py:61,
+    trainer.py:289-291), rows regenerated from their seeds."""
+    return np.load(os.path.join(golden_dir, request.param))
 
 
 def test_update_matches_the_reference_on_cpu(golden):

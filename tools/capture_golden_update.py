@@ -30,7 +30,7 @@ sys.modules["numpy.lib.arraysetops"] = _shim
 import utils as ref_utils  # noqa: E402
 from agent import Agent  # noqa: E402
 from capture_golden import _args_ns  # noqa: E402
-from oracle.formula import apply_formula_, synth_obs  # noqa: E402
+from oracle.formula import apply_formula_, scripted_batch  # noqa: E402
 
 HYPER = dict(lr=1e-4, policy_noise=0.2, noise_clip=0.5, discount=0.99, policy_freq=2, grad_clipping_value=0.1,
              max_action=1.0, target_smoothing_tau=0.005, reward_scale=1.0, batch=6)
@@ -47,14 +47,6 @@ def make_args():
     return a
 
 
-def scripted_batch(L, B, seed):
-    rng = np.random.RandomState(seed)
-    return dict(obs=synth_obs(L, B, seed).astype(np.float32), next_obs=synth_obs(L, B, seed + 1).astype(np.float32),
-                action=rng.uniform(-1, 1, size=(B, 3 * L)).astype(np.float32),
-                reward=rng.normal(1.0, 0.5, size=(B, 1)).astype(np.float32),
-                done=(rng.uniform(size=(B, 1)) < 0.3).astype(np.float32))
-
-
 def tensor_sums(module, grads=False):
     out = []
     for _, p in module.named_parameters():
@@ -63,7 +55,13 @@ def tensor_sums(module, grads=False):
     return np.array(out)
 
 
-def main():
+def main(batch=None, out_name="td3_update.npz"):
+    """batch: rows per update (default HYPER["batch"] = 6, batches stored in the fixture).  `python tools/capture_golden_update.py 256`
+    writes tests/golden/td3_update_b256.npz at the reference's own agent_batch_size (configs/default.py:61): the batches are NOT
+    stored (1.8 MB of synthetic rows), only their seeds -- the tests regenerate them with oracle.formula.scripted_batch."""
+    if batch is not None:
+        HYPER["batch"] = int(batch)
+    store_batches = HYPER["batch"] <= 16
     xm = refstub.all_xmls()
     agent = Agent(make_args())
     apply_formula_(agent.actor)
@@ -89,8 +87,10 @@ def main():
         loss = agent.update({k: torch.from_numpy(v) for k, v in b.items()}, it)
         tag = "it%d/" % it
         res[tag + "name"] = np.array(name)
-        for k, v in b.items():
-            res[tag + k] = v
+        res[tag + "batch_seed"] = np.array(seed)
+        if store_batches:
+            for k, v in b.items():
+                res[tag + k] = v
         res[tag + "noise"] = noise
         res[tag + "critic_loss"] = np.array(float(loss["loss/critic_loss"]))
         res[tag + "actor_loss"] = np.array(float(loss["loss/actor_loss"]) if "loss/actor_loss" in loss else np.nan)
@@ -106,9 +106,12 @@ def main():
     ob = scripted_batch(3, 1, 99)["obs"][0]
     res["select_action/obs"] = ob
     res["select_action/action"] = agent.select_action(ob)
-    np.savez_compressed(os.path.join(REPO, "tests", "golden", "td3_update.npz"), **res)
-    print("td3_update.npz written")
+    np.savez_compressed(os.path.join(REPO, "tests", "golden", out_name), **res)
+    print(out_name, "written")
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1:
+        main(int(sys.argv[1]), "td3_update_b%d.npz" % int(sys.argv[1]))
+    else:
+        main()
