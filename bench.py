@@ -330,16 +330,24 @@ def main():
             a_b = ro.actor.forward_batch(env.obs, act_ld=env.action_max_len)
             ro.actor.gemm_form(0)
             forms_diff = float((a_h - a_b).abs().max())
+        # the same forward WITHOUT the weight hold (k_pack + k_encode_rows at the top of every call: what round 3 timed, and what a
+        # caller that cannot promise constant weights pays)
+        ms_unheld = None
+        if getattr(ro, "holds_weights", False):
+            ro.actor.hold_weights(False)
+            ms_unheld = ro.actor.time_forward(env.obs, ro.policy_actions, 5)
+            ro.actor.hold_weights(True)
         extra["set_actor"] = {"ms_per_forward": round(ms_set, 4), "us_per_env_step": round(ms_set * 1e3 / n_local, 4),
+                              "ms_per_forward_weights_not_held": None if ms_unheld is None else round(ms_unheld, 4),
+                              "weights_pack_ms_hoisted": None if ms_unheld is None else round(ms_unheld - ms_set, 4),
                               "nodes": nodes, "nominal_flops_per_node": 10.07e6, "executed_flops_per_node": ex,
                               "tflops_nominal": round(nodes * 10.07e6 / (ms_set * 1e-3) / 1e12, 2),
                               "tflops_executed": round(nodes * ex / (ms_set * 1e-3) / 1e12, 2),
-                              "mfma_f32_peak_tflops": 157.3,
-                              "frac_of_f32_mfma_peak_nominal": round(nodes * 10.07e6 / (ms_set * 1e-3) / 157.3e12, 4),
-                              "frac_of_f32_mfma_peak_executed": round(nodes * ex / (ms_set * 1e-3) / 157.3e12, 4),
+                              "mfma_f16_dense_peak_tflops": 2500.0,
+                              "frac_of_f16_mfma_peak_executed_x3": round(3 * nodes * ex / (ms_set * 1e-3) / 2.5e15, 4),
                               "product_form": os.environ.get("SGRL_SET_GEMM", "f16x3"),
                               "fused_chains": os.environ.get("SGRL_SET_CHAIN", "1") != "0",
-                              "product_launches_per_forward": 25 if os.environ.get("SGRL_SET_CHAIN", "1") != "0" else 42,
+                              "product_launches_per_forward_by_construction": 25 if os.environ.get("SGRL_SET_CHAIN", "1") != "0" else 42,
                               "weights_held": bool(getattr(ro, "holds_weights", False)),
                               "row_scale_tile_repeats": ro.actor.scale_redos(reset=False),
                               "max_action_diff_between_product_forms": forms_diff,
@@ -354,8 +362,12 @@ def main():
                                       "run as one kernel each (chain_f16.h), decoder_g is folded through linear2_m; weights_held: the rollout "
                                       "promised constant weights, so the forward packs them once, not per call (sgrl_set_hold_weights: what the "
                                       "training loop does between two rounds of updates); row_scale_tile_repeats = workgroups that had to "
-                                      "repeat a tile with exact row maxima (0 = every sampled estimate held).  The f32-MFMA peak is the "
-                                      "yardstick the reference arithmetic would be priced against, not a bound of this kernel"}
+                                      "repeat a tile with exact row maxima (0 = every sampled estimate held).  "
+                                      "frac_of_f16_mfma_peak_executed_x3 = 3 matrix instructions per product block x executed flops / time / the "
+                                      "dense f16 peak (2.5 PF): the share of the matrix pipe's peak the forward's matrix work amounts to; "
+                                      "weights_pack_ms_hoisted = what the weight hold moved out of the timed forward (ms_per_forward_weights_not_held "
+                                      "- ms_per_forward); product_launches_per_forward_by_construction: the count of set_actor.hip forward(), "
+                                      "checked against the kernel trace in profiles/<tag>_kernel_stats.csv, not measured in this run"}
         # the exact-f32 forward next to the two-piece one: a child process with SGRL_SET_GEMM=f32 (plain products on
         # v_mfma_f32_32x32x2_f32, the reference's arithmetic; generated-operand products bf16 x 6) -- outside the timed region
         exact = None
@@ -395,11 +407,26 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ms_ing = e0.elapsed_time(e1) / 10
+            # the learner's ingest at N = 8 as it would run: the eight ranks' blocks arrive in ONE contiguous tensor (ReplayGather
+            # recv_flat) and are ingested by one sgrl_ingest_block call = two launches, whatever N -- measured here on 8 copies
+            flat8 = blk.repeat(8, 1).contiguous()
+            bufs8 = [DeviceReplayBuffer(41 * L, 3 * L, 8 * n_local, device=dev) for L in env.num_limbs]
+            sk8 = TransitionSink(env.env_morph, env.num_limbs, env.obs_max_len, env.action_max_len, device=dev, buffers=bufs8, dst=0)
+            for _ in range(3):
+                assert sk8._ingest_block_hip(flat8)
+            e0.record()
+            for _ in range(10):
+                sk8._ingest_block_hip(flat8)
+            e1.record()
+            torch.cuda.synchronize()
+            ms_ing8 = e0.elapsed_time(e1) / 10
             extra["replay_ingest"] = {"ms_ingest_per_block": round(ms_ing, 4), "rows_per_block": n_local,
-                                      "projected_learner_ms_per_step_at_8_gpus": round(8 * ms_ing, 3),
-                                      "note": "learner-side ingest of one rank's gathered block (all rows stored): one "
-                                              "sgrl_ingest_rows launch + the slot arithmetic, no host synchronisation; at N ranks the "
-                                              "learner ingests N blocks per step, inside the timed region of an N > 1 run"}
+                                      "projected_learner_ms_per_step_at_8_gpus": round(ms_ing8, 3),
+                                      "note": "learner-side ingest (all rows stored): sgrl_ingest_block = k_ingest_keys + k_ingest_put, "
+                                              "slots on the device, no host synchronisation.  ms_ingest_per_block: one rank's block; "
+                                              "projected_learner_ms_per_step_at_8_gpus: MEASURED on this GPU on a contiguous tensor of "
+                                              "8 such blocks (what the learner receives at N = 8: one call, two launches), inside the "
+                                              "timed region of an N > 1 run"}
         except Exception as e:
             extra["replay_ingest"] = {"error": repr(e)}
         rec, cnt = env.get_records()

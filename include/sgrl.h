@@ -112,10 +112,13 @@ typedef struct sgrl_ring {
 } sgrl_ring;
 int sgrl_ingest_rows(const float* block, int n_rows, int obs_len, int act_len, const int64_t* slot, const sgrl_ring* rings,
                      int n_rings, void* stream);
-/* The same with the slot arithmetic on the device too (two launches, no host involvement): `pos` / `cap` / `pending` are DEVICE
+/* The same with the slot arithmetic on the device too (two launches for ANY number of rows -- one rank's block or the learner's
+ * whole gather of N ranks, laid out contiguously in rank order -- and no host involvement): `pos` / `cap` / `pending` are DEVICE
  * arrays of n_rings (<= 32) int64 -- the rings' write pointers (read and advanced), capacities, and a running count of rows stored
- * per ring that the host folds into its own pointers when it next looks (rollout.py TransitionSink.fold_counters); `slot_ws`
- * receives the n_rows slots.  Same result as sgrl_ingest_rows with the caller's slots, bit for bit. */
+ * per ring that the host folds into its own pointers when it next looks (rollout.py TransitionSink.fold_counters); `slot_ws` is a
+ * DEVICE workspace of at least n_rows + 64 + 16 * ceil(n_rows / 256) int64 (row keys, per-chunk counts, a ticket).  Same rings,
+ * bit for bit, as sgrl_ingest_rows with the caller's slots (row order = the reference's `for i in range(num_envs)` order,
+ * common/buffer.py:75-84 per row). */
 int sgrl_ingest_block(const float* block, int n_rows, int obs_len, int act_len, const sgrl_ring* rings, int n_rings, int64_t* pos,
                       const int64_t* cap, int64_t* pending, int64_t* slot_ws, void* stream);
 

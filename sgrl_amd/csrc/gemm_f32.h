@@ -258,10 +258,15 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 constexpr float kF16Lim = 65000.f;
 constexpr float kF16LowScale = 2048.f;
 constexpr int kScaleExact = 14, kScaleEstimate = 6;     // where a row's exact maximum / sampled estimate is placed (powers of two)
-// 2^(target - floor(log2 est)) with the exponent kept inside +-100; est <= 0 or NaN -> 1
+// 2^(target - floor(log2 est)) with the exponent kept inside +-100; est <= 0 or NaN -> 2^100.
+// A ZERO estimate means "unknown", not "small": an exact maximum of zero is an all-zero row (any scale will do), but a SAMPLED
+// estimate of zero (every sampled entry of a sparse post-ReLU row is 0) says nothing about the rest of the row -- split unscaled,
+// entries below f16's normal range (6e-5) would lose bits and those below 6e-8 flush to zero where float32 would not.  At 2^100
+// every entry a float32 sum could care about (>= 2^-84) lands beyond the f16 range, the overflow vote fires and the tile is
+// repeated on the exact row maxima (counted in g_scale_redos); an all-zero row overflows nothing and costs nothing.
 __device__ __forceinline__ float pow2_scale(float est, int target) {
   const int e = (int)((__float_as_uint(est) >> 23) & 0xFFu) - 127;
-  const int se = est > 0.f ? min(max(target - e, -100), 100) : 0;
+  const int se = est > 0.f ? min(max(target - e, -100), 100) : 100;
   return __uint_as_float((unsigned)(se + 127) << 23);
 }
 // diagnostics: workgroups that repeated a tile / a phase with exact row maxima since the counter was last cleared (the rare path;

@@ -36,6 +36,7 @@ class Rollout(object):
             if hold_weights:      # the owner of the loop says when the policy's parameters change (weights_changed)
                 self.actor.hold_weights(True)
         self.holds_weights = bool(hold_weights) and policy is not None
+        self._weights_seen = self._weights_fingerprint()
         n, amax = self.env.num_envs, self.env.action_max_len
         self.actions = torch.zeros((n, amax), dtype=torch.float32, device=self.device)
         self.policy_actions = torch.zeros((n, amax), dtype=torch.float32, device=self.device)
@@ -47,11 +48,21 @@ class Rollout(object):
         self.gen.manual_seed(int(seed) * 1000003 + rank)
         self.obs = None
 
+    def _weights_fingerprint(self):
+        """(storage address, in-place version counter) of every parameter: changes with optimizer steps, load_state_dict, copy_,
+        soft updates, broadcasts into the parameters and re-assigned .data -- everything PyTorch itself can see.  Host-side only."""
+        if self.policy is None:
+            return None
+        return tuple((p.data_ptr(), p._version) for p in self.policy.parameters())
+
     def weights_changed(self):
         """The policy's parameters were just updated (optimizer steps, soft updates, a broadcast): a rollout that holds its actor's
-        packed weights (hold_weights=True) packs again on its next forward."""
+        packed weights (hold_weights=True) packs again on its next forward.  policy_forward() also notices by itself when a
+        parameter's version counter or storage moved (load_state_dict, a snapshot restore, a manual update), so a forgotten call
+        costs nothing but the check; only writes PyTorch cannot see (a raw kernel into the parameter's memory) need this call."""
         if self.holds_weights:
             self.actor.hold_weights(True)
+            self._weights_seen = self._weights_fingerprint()
 
     def reset(self):
         self.obs = self.env.reset_device()
@@ -65,6 +76,8 @@ class Rollout(object):
 
     def policy_forward(self, obs=None):
         """One batched SET forward over every environment (replaces n x Agent.select_action, reference agent.py:189-198)."""
+        if self.holds_weights and self._weights_fingerprint() != self._weights_seen:
+            self.weights_changed()          # the held pack is stale (ADVICE r4): pack again, keep holding
         return self.actor.forward_batch(self.env.obs if obs is None else obs, out=self.policy_actions,
                                         act_ld=self.env.action_max_len)
 
@@ -105,9 +118,15 @@ class ReplayGather(object):
             b[:, 2 * obs_max_len + action_max_len + 2] = 1.0      # store flag defaults to "keep"
         self.block = self.blocks[0]        # the block packed last
         self.recvs = [None] * self.depth
+        self.recv_flats = [None] * self.depth
         if self.rank == dst:
-            self.recvs = [[torch.zeros_like(self.blocks[0]) for _ in range(self.world)] for _ in range(self.depth)]
+            # the learner receives into ONE contiguous [world * n, row] tensor per slot (rank order = global environment order);
+            # the gather's per-rank list are views of it, so the ingest is one pair of launches over the whole thing whatever N
+            self.recv_flats = [torch.zeros((self.world * n_env_local, self.row), dtype=torch.float32, device=device)
+                               for _ in range(self.depth)]
+            self.recvs = [list(f.split(n_env_local, dim=0)) for f in self.recv_flats]
         self.recv = self.recvs[0]
+        self.recv_flat = self.recv_flats[0]
         self._works = [None] * self.depth
         self._k = 0
 
@@ -126,6 +145,7 @@ class ReplayGather(object):
         self._wait(slot)                   # the gather that last used this block (depth pushes ago) must be done
         self.block = self.blocks[slot]
         self.recv = self.recvs[slot]
+        self.recv_flat = self.recv_flats[slot]
         return self.block
 
     def _write(self, b, obs, action, next_obs, reward, done, store, morph_id):
@@ -343,7 +363,7 @@ class TransitionSink(object):
             finished = bool(flag.item())
         return finished
 
-    # ---- learner: one launch per gathered block (CUDA) -----------------------------------------------------------------
+    # ---- learner: one pair of launches per step (CUDA) -------------------------------------------------------------------
     def _ring_table(self):
         """Device array of include/sgrl.h sgrl_ring descriptors (one per morphology) + the capacities; rebuilt if a buffer's
         storage has moved."""
@@ -388,8 +408,9 @@ class TransitionSink(object):
                 else:
                     self._pend_buf.zero_()
                 self._pend = self._pend_buf
-            if getattr(self, "_slot_ws", None) is None or self._slot_ws.numel() < blk.shape[0]:
-                self._slot_ws = torch.empty(int(blk.shape[0]), dtype=torch.long, device=self.device)
+            need = int(blk.shape[0]) + 64 + 16 * ((int(blk.shape[0]) + 255) // 256)      # include/sgrl.h sgrl_ingest_block: workspace
+            if getattr(self, "_slot_ws", None) is None or self._slot_ws.numel() < need:
+                self._slot_ws = torch.empty(need, dtype=torch.long, device=self.device)
             _lib.check(L.sgrl_ingest_block(ctypes.c_void_p(blk.data_ptr()), int(blk.shape[0]), int(self.gather.o), int(self.gather.a),
                                            ctypes.c_void_p(rings.data_ptr()), len(self.buffers), ctypes.c_void_p(self._pos_dev.data_ptr()),
                                            ctypes.c_void_p(self._ring_cap.data_ptr()), ctypes.c_void_p(self._pend.data_ptr()),
@@ -411,6 +432,12 @@ class TransitionSink(object):
 
     def ingest(self, blocks):
         fast = FUSED_INGEST and self.device.type == "cuda" and all(isinstance(b, DeviceReplayBuffer) for b in self.buffers)
+        # the learner's whole gather at once: the per-rank blocks are views of one contiguous tensor in rank order (ReplayGather),
+        # so N ranks cost one pair of launches per step, not N (k_ingest_keys + k_ingest_put)
+        flat = getattr(self.gather, "recv_flat", None)
+        if (fast and len(blocks) > 1 and flat is not None and blocks[0].data_ptr() == flat.data_ptr()
+                and sum(int(b.shape[0]) for b in blocks) == int(flat.shape[0]) and self._ingest_block_hip(flat)):
+            return
         for blk in blocks:                                   # rank order = global environment order
             if fast and self._ingest_block_hip(blk):
                 continue

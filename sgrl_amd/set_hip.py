@@ -461,7 +461,8 @@ class HipSetActor(object):
 
     def scale_redos(self, reset=True):
         """Workgroups that repeated a tile with exact row maxima since the last reset (include/sgrl_set.h sgrl_set_debug_redos;
-        process-wide, synchronises): 0 unless an operand row's sampled estimate was more than 512 x below its maximum."""
+        process-wide, synchronises): 0 unless an operand row's sampled estimate was more than 512 x below its maximum -- or zero
+        (every sampled entry of a sparse row 0: "unknown", the tile is repeated on the exact maxima unless the whole row is zero)."""
         return int(self.L.sgrl_set_debug_redos(1 if reset else 0))
 
     def peek(self, which, per_node):

@@ -454,3 +454,27 @@ def test_weight_hold_packs_once_and_again_when_told(ctx):
     with torch.no_grad():
         pol2.actor.linear1_m.weight.div_(1.5)
     assert float((act.forward_batch(obs) - base).abs().max()) < 1e-6
+
+
+def test_rollout_notices_parameter_changes_under_a_weight_hold():
+    """a Rollout that holds its actor's packed weights compares the parameters' (storage, version) fingerprint before
+    every policy forward -- load_state_dict, an optimizer step or a manual in-place edit between two rounds is picked up without
+    anybody calling weights_changed(); unchanged parameters keep the pack (same actions, bit for bit)."""
+    import torch
+    from sgrl_amd.rollout import Rollout
+    from sgrl_amd.set_policy import make_policy
+    pol = make_policy(device="cuda:0").eval()
+    ro = Rollout(["3d_walker_7_full", "3d_hopper_3_shin"], 3, policy=pol, seed=1, device="cuda:0", hold_weights=True)
+    ro.reset()
+    a0 = ro.policy_forward().clone()
+    assert torch.equal(ro.policy_forward(), a0)
+    with torch.no_grad():
+        pol.actor.linear1_m.weight.mul_(1.5)                      # nobody tells the rollout
+    a1 = ro.policy_forward().clone()
+    assert not torch.equal(a1, a0)
+    sd = {k: v.clone() for k, v in pol.state_dict().items()}
+    with torch.no_grad():
+        pol.actor.linear1_m.weight.div_(1.5)
+    assert not torch.equal(ro.policy_forward(), a1)
+    pol.load_state_dict(sd)                                       # e.g. a snapshot restore
+    assert torch.equal(ro.policy_forward(), a1)

@@ -64,6 +64,13 @@ def _operands(dist, N, K, seed):
         A[2::7, :16] *= 1e-6
         W = r(N, K) * torch.pow(10.0, (torch.rand((N, 1), device="cuda", generator=g) * 8 - 4))
         b = torch.zeros(N, device="cuda")
+    elif dist == "sparse":                # rows whose SAMPLED entries are all zero (first k-tile, first four values of every later k-tile):
+        # the row-scale estimate sees nothing; the rest of the row sits at 1e-9, 1e-3 or 1e5 -- must be split on the exact maxima
+        A = r(M, K) * torch.pow(10.0, torch.tensor([-9.0, -3.0, 5.0], device="cuda")[torch.arange(M, device="cuda") % 3])[:, None]
+        cols = torch.arange(K, device="cuda")
+        A[:, (cols < 32) | (cols % 16 < 4)] = 0.0
+        A[::11] = 0.0                      # and some rows that ARE all zero (nothing to repeat for)
+        W, b = r(N, K) / K ** 0.5, torch.zeros(N, device="cuda")
     else:                                 # heavy cancellation: the second half of every row nearly undoes the first
         A = r(M, K)
         A[:, K // 2:] = -A[:, :K // 2] + 1e-4 * r(M, K // 2)
@@ -76,7 +83,7 @@ def _rel_err(C, ref64, scale64):
     return float(((C.double() - ref64).abs() / scale64).max())
 
 
-@pytest.mark.parametrize("dist", ["normal", "tiny", "large", "huge", "minute", "ragged", "cancel"])
+@pytest.mark.parametrize("dist", ["normal", "tiny", "large", "huge", "minute", "ragged", "sparse", "cancel"])
 @pytest.mark.parametrize("shape", [(128, 256), (256, 128), (768, 256), (256, 256)])
 @pytest.mark.parametrize("kind", [0, 1, 2])
 def test_plain_products_are_float32_products(handle, kind, shape, dist):
@@ -93,9 +100,14 @@ def test_plain_products_are_float32_products(handle, kind, shape, dist):
     errs = {}
     for form in (EXACT, F16X3, BF16X6):
         C = torch.full((M, N), float("nan"), device="cuda")
+        handle.scale_redos(reset=True)
         _run(handle, kind, form, A, W, b, C, N, K, rowdiv=rd)
         assert torch.isfinite(C).all()
         errs[form] = _rel_err(C, ref, scale)
+        if form == F16X3 and dist == "sparse":
+            assert handle.scale_redos(reset=True) > 0      # a zero ESTIMATE is "unknown": the tiles were repeated on exact maxima
+        if form == F16X3 and dist == "normal":
+            assert handle.scale_redos(reset=True) == 0
     # the exact-f32 chain itself: a few 1e-7 of sum |a w| (K <= 256)
     assert errs[EXACT] < 6e-7, errs
     # the split forms are float32 products: no worse than the exact chain on the same operands (their accumulation error is
@@ -138,7 +150,7 @@ def _chain(h, kind, A, K, W1, b1, hid, W2, b2, C, rowdiv=None, ln=None, Wp=None,
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("dist", ["normal", "huge", "minute", "ragged"])
+@pytest.mark.parametrize("dist", ["normal", "huge", "minute", "ragged", "sparse"])
 @pytest.mark.parametrize("hid,K", [(256, 256), (128, 160)])
 def test_fused_pair_is_the_two_single_products(handle, hid, K, dist):
     """chain kind 0: relu(A W1' + b1) W2' + b2 in one kernel = the ReLU product followed by the plain product (the intermediate is
