@@ -116,7 +116,8 @@ int sgrl_ingest_rows(const float* block, int n_rows, int obs_len, int act_len, c
  * whole gather of N ranks, laid out contiguously in rank order -- and no host involvement): `pos` / `cap` / `pending` are DEVICE
  * arrays of n_rings (<= 32) int64 -- the rings' write pointers (read and advanced), capacities, and a running count of rows stored
  * per ring that the host folds into its own pointers when it next looks (rollout.py TransitionSink.fold_counters); `slot_ws` is a
- * DEVICE workspace of at least n_rows + 64 + 16 * ceil(n_rows / 256) int64 (row keys, per-chunk counts, a ticket).  Same rings,
+ * DEVICE workspace of at least n_rows + 64 + 16 * ceil(n_rows / 256) int64 (a ticket, the write pointers before the block, per-chunk
+ * counts, row keys) whose FIRST int64 must be zero before the first call (the calls leave it zero).  Same rings,
  * bit for bit, as sgrl_ingest_rows with the caller's slots (row order = the reference's `for i in range(num_envs)` order,
  * common/buffer.py:75-84 per row). */
 int sgrl_ingest_block(const float* block, int n_rows, int obs_len, int act_len, const sgrl_ring* rings, int n_rings, int64_t* pos,

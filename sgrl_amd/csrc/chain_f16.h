@@ -23,6 +23,16 @@
 
 namespace sgrl_gemm {
 
+// -DSGRL_CHAIN_PROF (tools/chain_lab.hip only): s_memtime stamps at the phase boundaries of k_chain, wave 0 of every workgroup adds its
+// deltas to g_chain_prof[8] (0 prologue | 1 phase-1 set-up (Gram norm, first stage) | 2 phase-1 k-loop | 3 hand-off | 4 phase 2 |
+// 5 epilogue | 6 whole kernel | 7 workgroups)
+#ifdef SGRL_CHAIN_PROF
+__device__ unsigned long long g_chain_prof[8];
+#define SGRL_CSTAMP(id) do { const long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_chain_prof[id], (unsigned long long)(now_ - cp_last)); cp_last = __builtin_readcyclecounter(); } while (0)
+#else
+#define SGRL_CSTAMP(id)
+#endif
+
 struct ChainArgs {
   const float* A; int lda;            // SRC 0: [M, K1] float32; SRC 1: Z [M, 3, 32] (= zc when PROJ writes it)
   const unsigned* W1; int ldw1;       // pre-split words (enc_word) [HID][ldw1]
@@ -86,6 +96,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
   __shared__ float hm_sh[R * 4];                // row maxima of the intermediate, per hidden group
   __shared__ unsigned redo_sh;
   if (t == 0) redo_sh = 0;
+#ifdef SGRL_CHAIN_PROF
+  long long cp_last = __builtin_readcyclecounter();
+  const long long cp_begin = cp_last;
+#endif
   auto quad_max = [&](float m) -> float { m = fmaxf(m, __shfl_xor(m, 1, 64)); return fmaxf(m, __shfl_xor(m, 2, 64)); };
   // split a float4 of a row scaled by sc (a power of two) into the two f16 planes; mx keeps the largest SCALED magnitude: one
   // beyond the f16 range (possible under an estimated scale only) makes the workgroup repeat the phase with the exact maxima
@@ -208,6 +222,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     }
     __syncthreads();        // the block's Z rows are in memory (same CU: visible to its other waves) and the LDS is free
   }
+  SGRL_CSTAMP(0);
 
   // ---- phase 1 ------------------------------------------------------------------------------------------------------------
   f32x16 acc[TN], cor[TN];
@@ -328,6 +343,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     }
     sstore(0, 0);
     __syncthreads();
+    SGRL_CSTAMP(1);
     if (SRC == 1 && stage_a && nk > 1) gload_gram();
     if (nk > 1) gload(0, 16);
     if (PF == 2 && nk > 2) gload(PF - 1, 32);
@@ -356,6 +372,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
       for (int e = 0; e < 16; e++) { acc[j][e] = 0.f; cor[j][e] = 0.f; }
   }
 
+  SGRL_CSTAMP(2);
   // ---- hand-off: undo the operand scales, bias + ReLU, the row's exact maximum, split in registers ------------------------------
   uint2 Hh[TN][4], Hl[TN][4];
   float hs;                                     // this lane's row (wm * 32 + li): scale of the intermediate
@@ -564,6 +581,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     }
     return;
   }
+  SGRL_CSTAMP(3);
   // ---- phase 2 ------------------------------------------------------------------------------------------------------------
   constexpr int nk2 = HID / 16;
   f32x16 acc2, cor2;
@@ -602,6 +620,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
 #pragma unroll
   for (int kt = 0; kt < nk2; kt += 2) { body2(kt, 0); body2(kt + 1, 1); }
 
+  SGRL_CSTAMP(4);
   // ---- epilogue: lane = row m, registers = columns 32 wn + 8 g + 4 lh + (0..3) ----------------------------------------------
   const int m = m0 + wm * 32 + li;
   const bool ok = m < a.M;
@@ -657,6 +676,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
 #pragma unroll
     for (int g = 0; g < 4; g++) *reinterpret_cast<float4*>(crow + 8 * g) = make_float4(v[4 * g + 0], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
   }
+  SGRL_CSTAMP(5);
+#ifdef SGRL_CHAIN_PROF
+  if (threadIdx.x == 0) { atomicAdd(&g_chain_prof[6], (unsigned long long)(__builtin_readcyclecounter() - cp_begin)); atomicAdd(&g_chain_prof[7], 1ull); }
+#endif
 }
 
 }  // namespace sgrl_gemm

@@ -410,7 +410,7 @@ class TransitionSink(object):
                 self._pend = self._pend_buf
             need = int(blk.shape[0]) + 64 + 16 * ((int(blk.shape[0]) + 255) // 256)      # include/sgrl.h sgrl_ingest_block: workspace
             if getattr(self, "_slot_ws", None) is None or self._slot_ws.numel() < need:
-                self._slot_ws = torch.empty(need, dtype=torch.long, device=self.device)
+                self._slot_ws = torch.zeros(need, dtype=torch.long, device=self.device)      # word 0 = the ticket: zero before the first call
             _lib.check(L.sgrl_ingest_block(ctypes.c_void_p(blk.data_ptr()), int(blk.shape[0]), int(self.gather.o), int(self.gather.a),
                                            ctypes.c_void_p(rings.data_ptr()), len(self.buffers), ctypes.c_void_p(self._pos_dev.data_ptr()),
                                            ctypes.c_void_p(self._ring_cap.data_ptr()), ctypes.c_void_p(self._pend.data_ptr()),

@@ -1,7 +1,7 @@
 // tests/emu/emu_pair.cpp -- TEST HARNESS ONLY (never loaded by the product).
 //
 // SIMT emulator of the TWO-ENVIRONMENTS-PER-WAVEFRONT instance of the step kernel (sgrl_amd/csrc/wave_half.h + step_body.h): 64 lane
-// fibers (ucontext), lanes 0..31 = environment A, 32..63 = environment B, every fiber runs the whole env_step() exactly as a GPU
+// fibers (a register-and-stack switch of its own), lanes 0..31 = environment A, 32..63 = environment B, every fiber runs the whole env_step() exactly as a GPU
 // lane does -- own copy of the wave object, per-lane slab pointers into ONE shared "LDS" buffer with the pair layout
 // (Layout::pair_stride, one shared copy of the int tables behind both slabs), per-lane StepIO.  Cross-lane primitives
 // (wave_hip.h HipHalfPrim on the GPU) are rendezvous points of the 32 fibers of a half: a lane publishes its operand, waits for
@@ -9,7 +9,6 @@
 // environments' data-dependent branches diverge -- and a lane that takes a different path from its half shows up as a deadlock,
 // which the scheduler reports instead of hanging.  What this leaves to the GPU: the DPP / permlane encodings of the primitives
 // themselves (tools/micro/halfwave_prims.hip checks those on the device).
-#include <ucontext.h>
 
 #include <cmath>
 #include <cstdint>
@@ -24,8 +23,38 @@ namespace {
 constexpr int NL = 32, NF = 64;
 constexpr size_t kStack = 512 * 1024;
 
+// A context switch without the two sigprocmask system calls per swapcontext() (a wavefront step is ~10^5 switches): the callee-saved
+// registers and the stack pointer, x86-64 System V (what the build container and the GPU box's host are).
+struct Ctx { void* sp; };
+extern "C" void sgrl_emu_ctx_switch(Ctx* from, Ctx* to);
+asm(R"(
+.text
+.globl sgrl_emu_ctx_switch
+.type sgrl_emu_ctx_switch,@function
+sgrl_emu_ctx_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq (%rsi), %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size sgrl_emu_ctx_switch,.-sgrl_emu_ctx_switch
+)");
+#if !defined(__x86_64__)
+#error "tests/emu/emu_pair.cpp: the fiber switch is written for x86-64"
+#endif
+
 struct Sched {
-  ucontext_t main_ctx, ctx[NF];
+  Ctx main_ctx, ctx[NF];
   std::vector<char> stacks;
   bool finished[NF];
   int cur = -1;
@@ -39,7 +68,7 @@ struct Sched {
 };
 Sched* g = nullptr;
 
-void yield_() { const int me = g->cur; swapcontext(&g->ctx[me], &g->main_ctx); }
+void yield_() { const int me = g->cur; sgrl_emu_ctx_switch(&g->ctx[me], &g->main_ctx); }
 
 void half_sync() {
   const int h = g->cur >> 5;
@@ -57,11 +86,13 @@ template <class F> double exchange(double x, F src) {
   return r;
 }
 
-void trampoline(int idx) {
+void trampoline() {
+  const int idx = g->cur;
   g->body(idx);
   g->finished[idx] = true;
   g->progress++;
-  swapcontext(&g->ctx[idx], &g->main_ctx);
+  sgrl_emu_ctx_switch(&g->ctx[idx], &g->main_ctx);
+  abort();      // a finished fiber is never resumed
 }
 
 // runs body(lane) on 64 fibers; returns 0, or -1 if the lanes of a half stopped meeting (divergence inside a half)
@@ -72,11 +103,13 @@ int run_wave(void (*body)(int)) {
   s.stacks.resize(kStack * NF);
   for (int i = 0; i < NF; i++) {
     s.finished[i] = false;
-    getcontext(&s.ctx[i]);
-    s.ctx[i].uc_stack.ss_sp = s.stacks.data() + kStack * i;
-    s.ctx[i].uc_stack.ss_size = kStack;
-    s.ctx[i].uc_link = &s.main_ctx;
-    makecontext(&s.ctx[i], (void (*)())trampoline, 1, i);
+    // first switch into the fiber: six zeroed callee-saved registers, then `ret` into trampoline() with the stack 8 mod 16
+    uintptr_t top = (reinterpret_cast<uintptr_t>(s.stacks.data() + kStack * (i + 1))) & ~uintptr_t(15);
+    void** sp = reinterpret_cast<void**>(top);
+    *--sp = nullptr;                                   // return address of trampoline (never used)
+    *--sp = reinterpret_cast<void*>(&trampoline);
+    for (int k = 0; k < 6; k++) *--sp = nullptr;
+    s.ctx[i].sp = sp;
   }
   int rc = 0;
   for (;;) {
@@ -86,7 +119,7 @@ int run_wave(void (*body)(int)) {
       if (s.finished[i]) continue;
       any = true;
       s.cur = i;
-      swapcontext(&s.main_ctx, &s.ctx[i]);
+      sgrl_emu_ctx_switch(&s.main_ctx, &s.ctx[i]);
     }
     if (!any) break;
     if (s.progress == p0) { rc = -1; break; }     // a full round without a rendezvous completing or a lane finishing

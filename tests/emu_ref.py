@@ -111,7 +111,7 @@ def pair_lib():
         srcs = [os.path.join(d, "emu_pair.cpp"), os.path.join(csrc, "step_body.h"), os.path.join(csrc, "wave_half.h"),
                 os.path.join(_HERE, "..", "include", "sgrl_model.h")]
         if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
-            subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, srcs[0], "-lm"])
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, srcs[0], "-lm"])
         _PAIR_LIB = ctypes.CDLL(so)
     return _PAIR_LIB
 

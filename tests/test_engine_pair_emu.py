@@ -26,16 +26,16 @@ def test_paired_episodes_match_oracle_and_the_single_lane_emulator(name):
     m, ib, fb = packed(name)
     _, om = oracle_model(name)
     ids = (3, 4)
-    pe = emu_ref.PairEmu(ib, fb, seed=7, env_ids=ids, max_episode_steps=60)
-    singles = [emu_ref.EmuEnv(ib, fb, seed=7, env_id=e, max_episode_steps=60) for e in ids]
-    oracles = [physics_ref.OracleEnv(om, seed=7, env_id=e, max_episode_steps=60) for e in ids]
+    pe = emu_ref.PairEmu(ib, fb, seed=7, env_ids=ids, max_episode_steps=45)
+    singles = [emu_ref.EmuEnv(ib, fb, seed=7, env_id=e, max_episode_steps=45) for e in ids]
+    oracles = [physics_ref.OracleEnv(om, seed=7, env_id=e, max_episode_steps=45) for e in ids]
     o_pair = pe.reset()
     for h in range(2):
         assert np.abs(o_pair[h] - oracles[h].reset()).max() < 1e-13
         assert np.abs(o_pair[h] - singles[h].reset()).max() < 1e-13
     rng = np.random.RandomState(1)
     ndone = 0
-    for t in range(130):
+    for t in range(100):
         acts = [rng.uniform(-1, 1, size=3 * om.L).astype(np.float32) for _ in range(2)]
         res = pe.step(acts)
         for h in range(2):

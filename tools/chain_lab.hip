@@ -2,6 +2,7 @@
 // replace (gemm_f32.h), on the shapes of one SET forward: time of each form, the largest difference between their outputs, and
 // (mode r) both forms against float64 with operands at 1e-20 .. 1e8 -- the range check of the row-scaled two-piece products.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -o tools/chain_lab.exe tools/chain_lab.hip && tools/chain_lab.exe [nodes] [r]
+//   ... -DSGRL_CHAIN_PROF -o tools/chain_lab_prof.exe: also prints the per-phase cycle shares of the site kernel (s_memtime stamps)
 #include "../sgrl_amd/csrc/chain_f16.h"
 
 #include <cmath>
@@ -235,6 +236,19 @@ int main(int argc, char** argv) {
       const float tf0 = time_us([&] { hipLaunchKernelGGL((k_chain<1, 256, 0, 0>), dim3(blocks), dim3(512), kChainLds, 0, c0); });
       printf("    single products proj %.1f + lg1 %.1f + lg2 %.1f us (back to back %.1f) | fused site %.1f us | fused lg1 -> lg2 without the projection %.1f us\n",
              t1, t2, t3, ts, tf, tf0);
+#ifdef SGRL_CHAIN_PROF
+      {   // where a workgroup of the site kernel spends its cycles (s_memtime at the phase boundaries, wave 0 of every workgroup)
+        unsigned long long z8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pr[8];
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_chain_prof), z8, sizeof(z8)));
+        fused();
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_chain_prof), sizeof(pr)));
+        const char* nm[6] = {"prologue (projections)", "phase-1 set-up (Gram norm, stage 0)", "phase-1 k-loop (36 k-tiles)", "hand-off (bias, ReLU, split)", "phase 2 (16 k-steps)", "epilogue (stores)"};
+        const double wg = (double)pr[7], tot = (double)pr[6];
+        printf("    site kernel, %d workgroups, mean %.0f cycles (100 MHz s_memtime ticks x clock ratio; shares matter) per workgroup:\n", (int)wg, tot / wg);
+        for (int i = 0; i < 6; i++) printf("      %-40s %8.0f  %5.1f %%\n", nm[i], pr[i] / wg, 100.0 * pr[i] / tot);
+      }
+#endif
     }
     {
       // the head's site: K = 144 projections, hidden width 128; linear1_ng -> linear2_ng: K 160, hidden 128
