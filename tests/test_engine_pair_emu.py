@@ -63,9 +63,10 @@ def test_halves_in_different_contact_situations(name):
     for oe in oracles:
         oe.reset()
     nq = om.nq
-    lying = np.array(pe.envs[0].qpos)
-    lying[2] = 0.12
-    lying[3:7] = [np.cos(np.pi / 4), np.sin(np.pi / 4), 0, 0]      # rolled 90 degrees: limbs on the ground
+    lying = np.array(pe.envs[0].qpos)             # pressed flat into the floor with every hinge beyond its limit: 18 .. 30 rows, more than
+    lying[2] = 0.03                               # the LDS row arrays of walker_3 / hopper_3 hold (22 / 23) -> the HBM-slab row path
+    lying[3:7] = [0.70710678, 0, 0.70710678, 0] if "hopper" in name else [1, 0, 0, 0]
+    lying[7:] = 0.8
     air = np.array(pe.envs[1].qpos)
     air[2] += 1.0
     for h, q in enumerate((lying, air)):
@@ -88,4 +89,27 @@ def test_halves_in_different_contact_situations(name):
             o3, r3, d3, _ = res[h]
             assert d1 == d3
             assert np.abs(o1 - o3).max() < 1e-7, (t, h)
-    assert rows_seen[0] > rows_seen[1] or rows_seen[0] >= 8      # the halves did see different constraint problems
+    assert rows_seen[0] > rows_seen[1] and rows_seen[0] >= 18      # the halves did see different constraint problems
+    if "walker_2" not in name:
+        assert rows_seen[0] > 23                  # ... and half A left the LDS row arrays for the slab
+
+
+def test_gauss_seidel_fallback_of_the_half_wave():
+    """The half wave's projected Gauss-Seidel (wave_half.h pgs: the fallback when block pivoting gives up, and the whole solver of a
+    model packed with solver = 0) never runs in the product's pair instances on sane states -- here it is the only solver."""
+    from sgrl_amd import model_pack
+    name = "3d_walker_3_left_knee_right_knee"
+    m, ib, fb = packed(name, solver=0)
+    _, om = oracle_model(name, solver=0)
+    pe = emu_ref.PairEmu(ib, fb, seed=5, env_ids=(0, 1))
+    oracles = [physics_ref.OracleEnv(om, seed=5, env_id=e) for e in (0, 1)]
+    o = pe.reset()
+    for h in range(2):
+        assert np.abs(o[h] - oracles[h].reset()).max() < 1e-13
+    rng = np.random.RandomState(2)
+    for t in range(30):
+        acts = [rng.uniform(-1, 1, size=3 * om.L).astype(np.float32) for _ in range(2)]
+        res = pe.step(acts)
+        for h in range(2):
+            o1, r1, d1, _ = oracles[h].step(acts[h].astype(np.float64))
+            assert d1 == res[h][2] and np.abs(o1 - res[h][0]).max() < 1e-6      # an iteration stopped by tolerance: 1e-6, not rounding

@@ -86,9 +86,10 @@ def test_teacher_forced_parity_with_divergent_halves(monkeypatch):
     oes = _oracles(env, 4)
     for i, oe in enumerate(oes):
         oe.reset()
-        if i % 2 == 0:
-            oe.qpos[2] = 0.12
-            oe.qpos[3:7] = [np.cos(np.pi / 4), np.sin(np.pi / 4), 0, 0]
+        if i % 2 == 0:        # pressed flat into the floor, every hinge beyond its limit: 18 .. 30 rows (walker_3 / hopper_3: the slab path)
+            oe.qpos[2] = 0.03
+            oe.qpos[3:7] = [0.70710678, 0, 0.70710678, 0] if "hopper" in NAMES[env.env_morph[i]] else [1, 0, 0, 0]
+            oe.qpos[7:env.models[env.env_morph[i]].nq] = 0.8
         else:
             oe.qpos[2] += 0.8
         oe.qvel[:] = 0
@@ -122,4 +123,5 @@ def test_teacher_forced_parity_with_divergent_halves(monkeypatch):
                 oe.counters[1] += 1
                 oe.reset()
     print("evaluations on the HBM-slab row path:", slab_evals)
+    assert slab_evals > 0
     env.close()
