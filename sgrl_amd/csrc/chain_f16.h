@@ -65,7 +65,7 @@ struct ChainArgs {
 constexpr int kChainRows = 64;
 constexpr int kChainLds = 61440;
 // EPI_EQUIV: two 32-column sub-slice buffers | two W2 stages | the block's z rows (pitch 100 floats) | the bias b2 [1024]
-constexpr int kChainEqSub = 2 * kChainRows * 80, kChainEqW2 = 2 * kChainEqSub, kChainEqZ = kChainEqW2 + 2 * 2 * 128 * 48,
+constexpr int kChainEqSub = 2 * kChainRows * 80, kChainEqW2 = 2 * kChainEqSub, kChainEqZ = kChainEqW2 + 2 * 2 * 128 * kTileRB16,
               kChainEqB = kChainEqZ + kChainRows * 100 * 4, kChainEqLds = kChainEqB + 1024 * 4;
 
 // SRC: 0 loaded operand, 1 Gram operand.  PROJ: 0 none, 1 one projection (zc), 2 two (zc and z2).
@@ -75,7 +75,7 @@ template <int SRC, int HID, int EPI2, int PROJ, int DBG = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k_chain(ChainArgs a) {
   static_assert(HID == 256 || HID == 128, "hidden width 256 or 128");
   static_assert(PROJ == 0 || SRC == 1, "the projection prologue feeds the Gram operand");
-  constexpr int R = kChainRows, RB = 48;        // a k-tile row: 16 f16 + 16 B pad (conflict-free ds_read_b128)
+  constexpr int R = kChainRows, RB = kTileRB16;  // a k-tile row: 16 f16, halves swizzled (gemm_f32.h lds_wr / lds_rd: stores and reads conflict-free)
   constexpr int TN = HID / 128;                 // 32-wide hidden tiles per wave in phase 1
   constexpr int kPlaneA = R * RB, kPlaneW = HID * RB, kStage1 = 2 * (kPlaneA + kPlaneW);
   constexpr int SLP = 144;                      // slice row: 64 f16 + 16 B pad
@@ -109,13 +109,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     unsigned h0, l0, h1, l1;
     split2h(v.x, v.y, h0, l0);
     split2h(v.z, v.w, h1, l1);
-    char* p = plane0 + row * RB + 8 * kq;
+    char* p = plane0 + lds_wr<RB>(row, kq);
     *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
     *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(l0, l1);
   };
   auto put_words = [&](char* plane0, int plane_stride, int row, const float4& v) {
     const unsigned w0 = __float_as_uint(v.x), w1 = __float_as_uint(v.y), w2 = __float_as_uint(v.z), w3 = __float_as_uint(v.w);
-    char* p = plane0 + row * RB + 8 * kq;
+    char* p = plane0 + lds_wr<RB>(row, kq);
     *reinterpret_cast<uint2*>(p) = make_uint2(__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u));
     *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u));
   };
@@ -143,8 +143,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     };
     f32x16 pacc[PROJ ? PROJ : 1], pcor[PROJ ? PROJ : 1];
     const int nkp = a.Kp / 16;
-    const int paoff = (32 * wave + li) * RB + 16 * lh;
-    const int pboff = 2 * kPXA + li * RB + 16 * lh;
+    const int paoff = lds_rd<RB>(32 * wave + li, lh);
+    const int pboff = 2 * kPXA + lds_rd<RB>(li, lh);
     for (int attempt = 0;; attempt++) {
 #pragma unroll
       for (int j = 0; j < PROJ; j++)
@@ -301,8 +301,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
   }
   if (SRC == 1) __syncthreads();                // as_sh is read by the row's four staging threads
   const int nk = a.K1 / 16;
-  const int aoff = (wm * 32 + li) * RB + 16 * lh;
-  const int boff = 2 * kPlaneA + (wn * 32 * TN + li) * RB + 16 * lh;
+  const int aoff = lds_rd<RB>(wm * 32 + li, lh);
+  const int boff = 2 * kPlaneA + lds_rd<RB>(wn * 32 * TN + li, lh);
   const bool late = wave >= 4;                  // waves w and w + 4 share a SIMD: opposite phase order (gemm_f32.h SKEW)
   auto body = [&](int kt, int slot) {
     const int st = kt & 1;
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     const float rd = (EPI2 & EPI_ROWDIV) ? 1.0f / a.rowdiv[ok ? m : a.M - 1] : 1.f;
     const float hsi = pow2_inv(hs);
     const int hoff = (wm * 32 + li) * 80 + 16 * lh;
-    const int w2off = kChainEqW2 + (wn * 32 + li) * RB + 16 * lh;
+    const int w2off = kChainEqW2 + lds_rd<RB>(wn * 32 + li, lh);
     for (int p = 0; p < 8; p++) {
       f32x16 acc2, cor2;
 #pragma unroll
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
   rw2[0] = *reinterpret_cast<const float4*>(w2row + 16);
   if (nk2 > 2) rw2[1] = *reinterpret_cast<const float4*>(w2row + 32);
   const int hoff = (wm * 32 + li) * SLP + 16 * lh;
-  const int w2off = kW2Base + (wn * 32 + li) * RB + 16 * lh;
+  const int w2off = kW2Base + lds_rd<RB>(wn * 32 + li, lh);
   auto body2 = [&](int kt, int slot) {
     const int st = kt & 1;
     if (kt + 1 < nk2) store2(slot, st ^ 1);

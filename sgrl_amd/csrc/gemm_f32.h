@@ -299,12 +299,29 @@ __device__ __forceinline__ float dec_word(unsigned w) {
   return (float)h + (float)l * (1.f / kF16LowScale);
 }
 
+// LDS image of one k-tile row of a plane.  16-wide k-tiles (every product kernel in use): rows of 32 bytes, NO padding, the two
+// 16-byte halves of rows 4..7 of every eight swapped (XOR swizzle) -- the matrix operands' ds_read_b128 (lane = row, 16 bytes) and
+// the staging threads' ds_write_b64 (four threads per row, 8 bytes each) are BOTH bank-conflict free.  Rounds 2-4 used rows of
+// 32 + 16 pad bytes: conflict-free reads, but four consecutive rows' 32-byte windows fold onto 96 bytes of banks -- the stores ran
+// 2-way conflicted on a quarter of the banks (tools/micro/lds_pattern_lab.hip: 32.0 -> 24.0 ticks per four stores, reads 33.5 ->
+// 34.0; SQ_LDS_BANK_CONFLICT 17-24 % of the LDS cycles of every product kernel) -- and took half again the LDS.
+// 32-wide k-tiles (lab configurations only) keep the padded rows.
+template <int RB> __device__ __forceinline__ int lds_wr(int row, int kq) {      // a staging thread's 8 bytes: quarter kq of the row
+  if (RB == 32) return row * 32 + ((((kq >> 1) ^ (row >> 2)) & 1) << 4) + ((kq & 1) << 3);
+  return row * RB + 8 * kq;
+}
+template <int RB> __device__ __forceinline__ int lds_rd(int row, int lh) {      // a lane's 16-byte operand: k-half lh of the row
+  if (RB == 32) return row * 32 + (((lh ^ (row >> 2)) & 1) << 4);
+  return row * RB + 16 * lh;
+}
+constexpr int kTileRB16 = 32;                                                   // row bytes of a 16-wide k-tile plane
+
 template <int WM, int WN, int TM, int TN, int BKT = 32, int NPL = 3>
 struct TileCfg3 {
   static constexpr int kThreads = 64 * WM * WN;
   static constexpr int kBM = 32 * TM * WM, kBN = 32 * TN * WN;
   static constexpr int kBK = BKT;
-  static constexpr int kRowBytes = 2 * kBK + 16;          // BK bf16 + 16 B pad (20 / 12 dwords): conflict-free ds_read_b128
+  static constexpr int kRowBytes = BKT == 16 ? kTileRB16 : 2 * kBK + 16;     // lds_wr / lds_rd above
   static constexpr int kPlaneA = kBM * kRowBytes, kPlaneW = kBN * kRowBytes;
   static constexpr int kStageBytes = NPL * (kPlaneA + kPlaneW);
   static constexpr int kLdsBytes = 2 * kStageBytes;
@@ -442,7 +459,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
     }
   };
   auto put_planes = [&](char* plane0, int plane_stride, int row, const uint2* v) {
-    char* p = plane0 + row * RB + 8 * kq;
+    char* p = plane0 + lds_wr<RB>(row, kq);
     *reinterpret_cast<uint2*>(p) = v[0];
     *reinterpret_cast<uint2*>(p + plane_stride) = v[1];
     *reinterpret_cast<uint2*>(p + 2 * plane_stride) = v[2];
@@ -450,7 +467,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
   // four pre-split words -> 8 bytes of h and 8 bytes of l' (two byte permutes each)
   auto put_words = [&](char* plane0, int plane_stride, int row, const float4& v) {
     const unsigned w0 = __float_as_uint(v.x), w1 = __float_as_uint(v.y), w2 = __float_as_uint(v.z), w3 = __float_as_uint(v.w);
-    char* p = plane0 + row * RB + 8 * kq;
+    char* p = plane0 + lds_wr<RB>(row, kq);
     *reinterpret_cast<uint2*>(p) = make_uint2(__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u));
     *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u));
   };
@@ -463,7 +480,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
       if (mx) { *mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), *mx); *mx = fmaxf(fmaxf(fabsf(v.z), fabsf(v.w)), *mx); }
       unsigned h0, l0, h1, l1;
       split2h(v.x, v.y, h0, l0); split2h(v.z, v.w, h1, l1);
-      char* p = plane0 + row * RB + 8 * kq;
+      char* p = plane0 + lds_wr<RB>(row, kq);
       *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
       *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(l0, l1);
       return;
@@ -476,7 +493,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
     } else {
       split3(v.x, h[0], m[0], l[0]); split3(v.y, h[1], m[1], l[1]); split3(v.z, h[2], m[2], l[2]); split3(v.w, h[3], m[3], l[3]);
     }
-    char* p = plane0 + row * RB + 8 * kq;
+    char* p = plane0 + lds_wr<RB>(row, kq);
     *reinterpret_cast<uint2*>(p) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
     *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
     *reinterpret_cast<uint2*>(p + 2 * plane_stride) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
@@ -541,8 +558,8 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
   }
   if (SCL && t == 0) redo_sh = 0;
   const int li = lane & 31, lh = lane >> 5;
-  const int aoff = (wm * 32 * TM + li) * RB + 16 * lh;        // this lane's 8 bf16 of k-step 0; k-step 1 is 32 bytes on
-  const int boff = NPL * Cfg::kPlaneA + (wn * 32 * TN + li) * RB + 16 * lh;
+  const int aoff = lds_rd<RB>(wm * 32 * TM + li, lh);        // this lane's 8 bf16 of k-step 0; k-step 1 (32-wide k-tiles) is 32 bytes on
+  const int boff = NPL * Cfg::kPlaneA + lds_rd<RB>(wn * 32 * TN + li, lh);
   const bool late = SKEW ? (wave >= 4) : LATE;                   // wave-uniform
   constexpr bool EST = SCL && !GRAM && !PLA;  // loaded f32 activation rows: scaled by an estimate, repeated with the exact maxima if it fell short
   auto body = [&](int kt, int slot) {
@@ -957,7 +974,7 @@ __global__ __launch_bounds__(1024) void k_gemm4(GemmArgs a) {
   auto put = [&](char* plane0, int plane_stride, int row, const float4& v) {
     unsigned h[4], m[4], l[4];
     split3(v.x, h[0], m[0], l[0]); split3(v.y, h[1], m[1], l[1]); split3(v.z, h[2], m[2], l[2]); split3(v.w, h[3], m[3], l[3]);
-    char* p = plane0 + row * RB + 8 * kq;
+    char* p = plane0 + lds_wr<RB>(row, kq);
     *reinterpret_cast<uint2*>(p) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
     *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
     *reinterpret_cast<uint2*>(p + 2 * plane_stride) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
@@ -970,8 +987,8 @@ __global__ __launch_bounds__(1024) void k_gemm4(GemmArgs a) {
   // ---- consumer state
   const int cw = wave & 7, wm = cw >> 1, wn = cw & 1;
   const int li = lane & 31, lh = lane >> 5;
-  const int aoff = (wm * 32 + li) * RB + 16 * lh;
-  const int boff = 3 * Cfg::kPlaneA + (wn * 64 + li) * RB + 16 * lh;
+  const int aoff = lds_rd<RB>(wm * 32 + li, lh);
+  const int boff = 3 * Cfg::kPlaneA + lds_rd<RB>(wn * 64 + li, lh);
   f32x16 acc[TN], cor[TN];
 #pragma unroll
   for (int j = 0; j < TN; j++)

@@ -725,13 +725,15 @@ constexpr int kProjHLds = sgrl_gemm::TileCfg3<4, 1, 1, 2, 16, 2>::kLdsBytes;
 // tout[m][s][c] = sum_a zq[m][s][a] * ((A . W^T + b)[m][c * 32 + a] / rowdiv[m]); always the split-precision kernel
 constexpr auto kGemmEquiv = sgrl_gemm::k_gemm3<EPI_ROWDIV | EPI_EQUIV, 4, 2, 1, 2, 16, 2>;
 constexpr auto kGemmEquivH = sgrl_gemm::k_gemm3<EPI_ROWDIV | EPI_EQUIV, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2, true, 2>;
+// the equivariant epilogue stages the block's 128 z rows (pitch 100 floats) in the tile's LDS: more than the k-tile stages need
+constexpr int kEquivLds = GemmKernels<0>::kSplitLds > 128 * 100 * 4 ? GemmKernels<0>::kSplitLds : 128 * 100 * 4;
 int launch_gemm_equiv(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, int M, int K,
                       const float* rowdiv, const float* zq, float* tout) {
   if (K % 32 != 0 || (lda & 3) || (ldw & 3)) return sfail(SGRL_ERR_ARG, "gemm_equiv: K must be a multiple of 32 and rows 16-byte aligned");
   GemmArgs a{A, lda, W, ldw, bias, nullptr, 0, M, 1024, K, EPI_ROWDIV | EPI_EQUIV, rowdiv, nullptr, 0};
   a.zq = zq; a.tout = tout;
-  if (g_gemm.form == SGRL_SET_FORM_F16X3) hipLaunchKernelGGL(kGemmEquivH, dim3(((M + 127) / 128) * 8), dim3(512), GemmKernels<0>::kSplitLds, st, with_words(a));
-  else hipLaunchKernelGGL(kGemmEquiv, dim3(((M + 127) / 128) * 8), dim3(512), GemmKernels<0>::kSplitLds, st, a);
+  if (g_gemm.form == SGRL_SET_FORM_F16X3) hipLaunchKernelGGL(kGemmEquivH, dim3(((M + 127) / 128) * 8), dim3(512), kEquivLds, st, with_words(a));
+  else hipLaunchKernelGGL(kGemmEquiv, dim3(((M + 127) / 128) * 8), dim3(512), kEquivLds, st, a);
   return SGRL_OK;
 }
 
@@ -1199,11 +1201,10 @@ int sgrl_set_create(sgrl_set** out) {
     *out = nullptr;
     return sfail(SGRL_ERR_HIP, "no HIP device visible: the SET actor fast path needs an MI355X (there is no CPU fallback)");
   }
-  const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kGemmEquiv), hipFuncAttributeMaxDynamicSharedMemorySize, GemmKernels<0>::kSplitLds) == hipSuccess &&
+  const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kGemmEquiv), hipFuncAttributeMaxDynamicSharedMemorySize, kEquivLds) == hipSuccess &&
                        hipFuncSetAttribute(reinterpret_cast<const void*>(kGemmGram), hipFuncAttributeMaxDynamicSharedMemorySize, GemmKernels<0>::kSplitLds) == hipSuccess &&
                        hipFuncSetAttribute(reinterpret_cast<const void*>(kGemmLn), hipFuncAttributeMaxDynamicSharedMemorySize, GemmKernels<0>::kSplitLds) == hipSuccess &&
-                       // the equivariant epilogue stages 128 z rows of 100 floats in the tile's LDS: that kernel keeps the larger request
-                       hipFuncSetAttribute(reinterpret_cast<const void*>(kGemmEquivH), hipFuncAttributeMaxDynamicSharedMemorySize, GemmKernels<0>::kSplitLds) == hipSuccess &&
+                       hipFuncSetAttribute(reinterpret_cast<const void*>(kGemmEquivH), hipFuncAttributeMaxDynamicSharedMemorySize, kEquivLds) == hipSuccess &&
                        hipFuncSetAttribute(reinterpret_cast<const void*>(kGemmGramH), hipFuncAttributeMaxDynamicSharedMemorySize, GemmKernels<0>::kSplitHLds) == hipSuccess &&
                        hipFuncSetAttribute(reinterpret_cast<const void*>(kGemmLnH), hipFuncAttributeMaxDynamicSharedMemorySize, GemmKernels<0>::kSplitHLds) == hipSuccess &&
                        GemmKernels<0>::raise_lds_limits() && GemmKernels<EPI_RELU>::raise_lds_limits() &&

@@ -434,8 +434,10 @@ class TransitionSink(object):
         fast = FUSED_INGEST and self.device.type == "cuda" and all(isinstance(b, DeviceReplayBuffer) for b in self.buffers)
         # the learner's whole gather at once: the per-rank blocks are views of one contiguous tensor in rank order (ReplayGather),
         # so N ranks cost one pair of launches per step, not N (k_ingest_keys + k_ingest_put)
-        flat = getattr(self.gather, "recv_flat", None)
-        if (fast and len(blocks) > 1 and flat is not None and blocks[0].data_ptr() == flat.data_ptr()
+        flat = getattr(blocks[0], "_base", None) if len(blocks) > 1 else None      # the tensor the per-rank views were split from
+        if (fast and flat is not None and flat.dim() == 2 and flat.is_contiguous() and blocks[0].data_ptr() == flat.data_ptr()
+                and all(getattr(b, "_base", None) is flat for b in blocks)
+                and all(b.data_ptr() == flat.data_ptr() + 4 * flat.shape[1] * sum(int(x.shape[0]) for x in blocks[:i]) for i, b in enumerate(blocks))
                 and sum(int(b.shape[0]) for b in blocks) == int(flat.shape[0]) and self._ingest_block_hip(flat)):
             return
         for blk in blocks:                                   # rank order = global environment order

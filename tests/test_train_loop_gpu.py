@@ -273,3 +273,46 @@ def test_fused_ingest_writes_exactly_what_the_row_by_row_path_writes():
     s1.ingest([blocks[6]])
     for x, y in zip(tiny, ref):
         assert torch.equal(x.obs_buffer, y.obs_buffer) and (x.curr, x.max_sample_size) == (y.curr, y.max_sample_size)
+
+
+def test_whole_gather_ingest_equals_block_by_block():
+    """The learner at N > 1: the gather arrives in ONE contiguous [N * rows, row] tensor whose per-rank blocks are
+    views (rollout.ReplayGather recv_flat); TransitionSink.ingest recognises them and runs sgrl_ingest_block ONCE over the whole
+    tensor (k_ingest_keys + k_ingest_put, two launches whatever N).  Rings, write pointers and fill levels must equal what the
+    block-by-block ingest of the same views writes, over several steps, with random store flags, a ring that wraps, and more
+    rows than one 256-row chunk per morphology (ranks of rows span chunks)."""
+    import torch
+    from sgrl_amd import rollout
+    from sgrl_amd.replay import DeviceReplayBuffer
+    dev = torch.device("cuda:0")
+    limbs = [2, 7, 4, 5]
+    per = [300, 130, 350, 20]
+    env_morph = sum(([k] * n for k, n in enumerate(per)), [])
+    n, omax, amax, world = len(env_morph), 41 * 7, 3 * 7, 3
+    caps = [100000, 2500, 100000, 4000]                 # ring 1 wraps after a few steps; every ring holds one whole gather
+    g = torch.Generator().manual_seed(9)
+    steps = []
+    for t in range(6):
+        flat = torch.randn(world * n, 2 * omax + amax + 4, generator=g)
+        flat[:, 2 * omax + amax + 2] = (torch.rand(world * n, generator=g) < (0.0 if t == 2 else 0.8)).float()
+        flat[:, 2 * omax + amax + 3] = torch.tensor(env_morph * world, dtype=torch.float32)
+        steps.append(flat.to(dev))
+    out = {}
+    for whole in (False, True):
+        bufs = [DeviceReplayBuffer(41 * L, 3 * L, max_buffer_size=c, device=dev) for L, c in zip(limbs, caps)]
+        sink = rollout.TransitionSink(env_morph, limbs, omax, amax, device=dev, buffers=bufs)
+        for flat in steps:
+            views = list(flat.split(n, dim=0))
+            if whole:
+                sink.ingest(views)                      # views of one tensor, rank order: one call over the whole gather
+            else:
+                for v in views:
+                    sink.ingest([v.clone()])            # clones: no common base, block by block
+        torch.cuda.synchronize()
+        out[whole] = ([(x.obs_buffer.clone(), x.action_buffer.clone(), x.next_obs_buffer.clone(), x.reward_buffer.clone(), x.done_buffer.clone(),
+                        x.curr, x.max_sample_size) for x in bufs], sink.stored)
+    assert out[True][1] == out[False][1] > 0
+    for a, b in zip(out[False][0], out[True][0]):
+        assert a[5:] == b[5:]
+        for ta, tb in zip(a[:5], b[:5]):
+            assert torch.equal(ta, tb)

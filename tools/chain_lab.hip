@@ -294,7 +294,7 @@ int main(int argc, char** argv) {
   // ---- (2b) linear3 -> ReLU -> linear4 -> contraction: fused vs the two launches; what the parts of the fused phase cost -----------
   {
     constexpr auto kEquivG = k_gemm3<EPI_ROWDIV | EPI_EQUIV, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2, true, 2>;
-    constexpr int kLdsEq = TileCfg3<4, 2, 1, 2, 16, 3>::kLdsBytes;
+    constexpr int kLdsEq = TileCfg3<4, 2, 1, 2, 16, 3>::kLdsBytes > 128 * 100 * 4 ? TileCfg3<4, 2, 1, 2, 16, 3>::kLdsBytes : 128 * 100 * 4;   // + the epilogue's z rows
     raise(kEquivG, kLdsEq);
     Host W4 = dev(1024 * 256, 0.2f), b4 = dev(1024, 1.0f), zq = dev((size_t)N * 96, 2.0f);
     Wt W4w = words(W4.d, 1024, 256);
