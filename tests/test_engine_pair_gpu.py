@@ -125,3 +125,41 @@ def test_teacher_forced_parity_with_divergent_halves(monkeypatch):
     print("evaluations on the HBM-slab row path:", slab_evals)
     assert slab_evals > 0
     env.close()
+
+
+def test_all_light_batches_take_the_paired_family_kernels(monkeypatch):
+    """A batch of light morphologies only used to run on the four-waves-per-SIMD light kernel; with every morphology pairable it
+    now takes the family kernels two environments per wavefront (profiles/r5_light_pair_probe.txt: 21-28 % faster).
+    SGRL_LIGHT_KERNEL=1 keeps the light kernel.  Both agree with the oracle."""
+    import torch
+    from sgrl_amd.vec_env import BatchedModularVecEnv
+    names = ["3d_hopper_3_shin", "3d_walker_3_left_knee_right_knee"]
+    monkeypatch.delenv("SGRL_SPECS", raising=False)
+    monkeypatch.setenv("SGRL_PAIR", "1")
+    outs = []
+    for lk in (None, "1"):
+        if lk is None:
+            monkeypatch.delenv("SGRL_LIGHT_KERNEL", raising=False)
+        else:
+            monkeypatch.setenv("SGRL_LIGHT_KERNEL", lk)
+        env = BatchedModularVecEnv(names, 4, seed=6, device="cuda:0")
+        assert env.fixed_dim_groups == 2 and env.paired_envs == (8 if lk is None else 0)
+        env.enable_f64_outputs()
+        env.reset_device()
+        oes = _oracles(env, 6)
+        for oe in oes:
+            oe.reset()
+        rng = np.random.RandomState(1)
+        for t in range(40):
+            a = rng.uniform(-1, 1, size=(env.num_envs, env.action_max_len)).astype(np.float32)
+            env.step_device(torch.from_numpy(a).cuda())
+            for i, oe in enumerate(oes):
+                oe.step(a[i].astype(np.float64))
+        torch.cuda.synchronize()
+        rec, cnt = env.get_records()
+        for i, oe in enumerate(oes):
+            q, v, xy, tg = env.state_of(rec, i)
+            assert cnt[i, 1] == oe.counters[1] and np.abs(q - oe.qpos).max() < 1e-7 * (1 + np.abs(oe.qpos).max())
+        outs.append(rec)
+        env.close()
+    assert np.abs(outs[0] - outs[1]).max() < 1e-7

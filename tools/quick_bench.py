@@ -10,6 +10,8 @@ names = sorted(["3d_walker_2_right_leg_left_knee", "3d_walker_3_left_leg_right_f
 if os.environ.get("QB_FAMILY"):      # e.g. QB_FAMILY=hopper: every shipped morphology of that family
     from sgrl_amd import mjcf
     names = sorted(n for n in mjcf.list_assets() if n.split("_")[1] == os.environ["QB_FAMILY"])
+if os.environ.get("QB_NAMES"):       # explicit comma-separated morphology list
+    names = os.environ["QB_NAMES"].split(",")
 per = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 kw = {}
