@@ -355,7 +355,7 @@ def main():
                                       "matrix taken over the 36 4x4 blocks of its lower triangle (K = 576 instead of 1024; the "
                                       "operand is generated inside the GEMM, never stored) and the attention output "
                                       "projections folded into the value projections.  The GEMMs are float32 products (f32 in, f32 out, error "
-                                      "against float64 at or below an f32 FMA chain's: tools/gemm_lab.hip h) carried by the 16-bit matrix "
+                                      "against float64 at or below an f32 FMA chain's: tests/test_split_products_gpu.py, tools/chain_lab.hip r) carried by the 16-bit matrix "
                                       "cores: every operand row is scaled by a power of two into f16's range (exact, undone in the epilogue: "
                                       "float32's exponent range, nothing clamped) and cut into two f16 pieces, three matrix instructions per "
                                       "product block (gemm_f32.h; SGRL_SET_GEMM=bf16x6 selects the three-piece bf16 form); back-to-back products "

@@ -169,7 +169,7 @@ int sgrl_set_debug_stop_after(sgrl_set* s, int stage);
 int sgrl_set_debug_small_nodes(sgrl_set* s, int nodes);
 /* Form of the 128 x 128 tile products (reference: plain f32 `F.linear`, subequivariant_attentions.py:90-151 / SEActor.py:82-125).
  * Both forms carry the f32 product on the 16-bit matrix cores and measure the same error against float64 as an f32 FMA chain
- * (tools/gemm_lab.hip):
+ * (tests/test_split_products_gpu.py):
  *   SGRL_SET_FORM_F16X3  (default) every operand = two f16 pieces, three matrix instructions per product block.  Every operand
  *                        ROW is first multiplied by a power of two that brings its largest magnitude into f16's range (exact; undone
  *                        in the epilogue), so the form has float32's exponent range as the reference's `F.linear` has: nothing is

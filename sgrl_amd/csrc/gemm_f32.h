@@ -218,7 +218,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
 // correction products accumulate in separate registers and are added once in the epilogue, so the small terms are not
 // rounded against the large running sum.  Six v_mfma_f32_32x32x16_bf16 (32 cycles, k = 16) replace eight
 // v_mfma_f32_32x32x2_f32 (64 cycles, k = 2) per 16 k-steps: 2.67x fewer matrix-pipe cycles.
-// tools/gemm_lab.hip measures the result against float64: same error as the exact-f32 kernel.
+// tests/test_split_products_gpu.py (every instantiation, through sgrl_set_debug_product) and tools/chain_lab.hip mode r hold the result
+// against float64: same error as the exact-f32 kernel (the round-3 lab tools/gemm_lab.hip is an archive that no longer builds).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
@@ -330,7 +331,7 @@ struct TileCfg3 {
 // PLA / PLW: operand A / W is given as bf16 planes (GemmArgs::a_plane / w_plane) and is copied to LDS as is
 // LATE: the next tile is split and written to LDS AFTER this tile's MFMAs have been issued (the matrix pipe runs them
 // while the wave does the VALU / LDS-write work) instead of before
-// ABL (diagnostics, tools/gemm_lab.hip): 1 = no staging in the loop (LDS keeps tile 0: MFMA + operand reads + barrier only),
+// ABL (diagnostics of the archived round-3 lab, profiles/r2_gemm_lab_ablation.log): 1 = no staging in the loop (LDS keeps tile 0: MFMA + operand reads + barrier only),
 // 2 = staging only (no operand reads / MFMA), 3 = staging without the split arithmetic (raw bit copies)
 // GRAM: the A operand is GENERATED, not loaded: a.A points at Z [M][3][32] (three 32-vectors per row) and A[m][k] is the
 // entry G[a][b] = sum_s Z[m][s][a] Z[m][s][b] of the row's 32 x 32 Gram matrix Z'Z, with k running over the 36 blocks
@@ -344,12 +345,12 @@ constexpr int kGramK = 576;
 // split + LDS store of tile kt + 1), the lower half in the early order.  Waves w and w + 4 of a block share a SIMD, and the
 // barrier keeps all waves of a block in lockstep: without the skew both waves of a SIMD (and, started together, those of the
 // co-resident block) sit in their VALU phase at the same time and in their matrix phase at the same time -- the phases ADD
-// (tools/gemm_lab.hip a: full = matrix part + staging part).  With it one wave's split arithmetic runs under the other's matrix
+// (profiles/r2_gemm_lab_ablation.log: full = matrix part + staging part).  With it one wave's split arithmetic runs under the other's matrix
 // instructions by construction.  Both orders keep the same invariant at the barrier (LDS stage kt & 1 = tile kt, register
 // slots = tiles kt + 1, kt + 2).
 template <int FLAGS, int WM, int WN, int TM, int TN, int BKT = 32, int PF = 1, bool PLA = false, bool PLW = false, bool LATE = false, int ABL = 0, bool GRAM = false, int NPL = 3, bool SKEW = false, int WORDS = 0>
 #ifndef SGRL_GEMM_WPE
-#define SGRL_GEMM_WPE 4        // tools/gemm_lab.hip compiles variants with another register budget (-DSGRL_GEMM_WPE=6 / 8)
+#define SGRL_GEMM_WPE 4        // lab builds compile variants with another register budget (-DSGRL_GEMM_WPE=6 / 8: profiles/r2_gemm_lab_wpe6.log)
 #endif
 __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SGRL_GEMM_WPE))) void k_gemm3(GemmArgs a) {
   using Cfg = TileCfg3<WM, WN, TM, TN, BKT, NPL>;

@@ -640,7 +640,7 @@ int use_cfg(sgrl_set* s, GraphCfg* c) {
   return SGRL_OK;
 }
 
-// Tile configurations (measured on the shapes of one forward, tools/gemm_lab.hip).  Default: the split-precision kernel
+// Tile configurations (measured on the shapes of one forward: profiles/r2_gemm_lab_*.log, r3_gemm_*_lab.txt -- the lab of those rounds, tools/gemm_lab.hip, is an archive; the live labs are tools/chain_lab.hip and tools/wdirect_lab.hip).  Default: the split-precision kernel
 // k_gemm3 in its two-piece form (three f16 MFMAs per product block, weights pre-split by k_pack; float32 result -- its
 // error against float64 is BELOW that of the exact-f32 MFMA chain, gemm_f32.h) on 128 x 128 tiles with 8 waves, the stacked
 // projections on 128 x 64 tiles (kProjH); SGRL_SET_GEMM=bf16x6 / sgrl_set_gemm_form select the three-piece bf16 form.  The

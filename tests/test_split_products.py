@@ -2,7 +2,7 @@
 restated in NumPy and held to its stated bounds on the CPU.  The reference computes these products as plain float32
 `F.linear` (subequivariant_attentions.py:90-151, SEActor.py:82-125): what is checked here is that cutting every operand into
 two float16 pieces (h = f16(x), l' = f16((x - h) * 2^11), round to nearest) and rebuilding a.b from hh + (h l' + l' h) / 2^11 with
-float32 accumulation loses nothing against a float32 FMA chain.  The GPU side of the same statement is tools/gemm_lab.hip
+float32 accumulation loses nothing against a float32 FMA chain.  The GPU side of the same statement is tests/test_split_products_gpu.py (and tools/chain_lab.hip mode r; the round-3 lab tools/gemm_lab.hip is an archive)
 (error of the kernels against float64) and tests/test_set_gpu.py (both product forms against the reference fixtures)."""
 import numpy as np
 
@@ -101,7 +101,7 @@ def test_three_products_match_float64_as_well_as_a_float32_chain_does():
     e_chain = (np.abs(chain.astype(np.float64) - ref) / mag).max()
     print("max |err| / sum |a w|: two-piece products %.2e, float32 chain %.2e" % (e_split, e_chain))
     # (this model adds the products one k at a time in float32 -- the matrix core adds sixteen per instruction with less
-    # rounding: the kernels measure 1.3-1.8e-7 on these operands, tools/gemm_lab.hip)
+    # rounding: the kernels measure 1.3-1.8e-7 on these operands, profiles/r2_gemm_lab_forms.log)
     assert e_split < 5e-7, e_split
     assert e_split <= 1.25 * e_chain + 1e-8, (e_split, e_chain)
     # dropping the cross products would NOT do: the leading products alone are a float16-grade result
