@@ -408,7 +408,7 @@ def main():
             torch.cuda.synchronize()
             ms_ing = e0.elapsed_time(e1) / 10
             # the learner's ingest at N = 8 as it would run: the eight ranks' blocks arrive in ONE contiguous tensor (ReplayGather
-            # recv_flat) and are ingested by one sgrl_ingest_block call = two launches, whatever N -- measured here on 8 copies
+            # recv_flat) and are ingested by one sgrl_ingest_block call = three launches, whatever N -- measured here on 8 copies
             flat8 = blk.repeat(8, 1).contiguous()
             bufs8 = [DeviceReplayBuffer(41 * L, 3 * L, 8 * n_local, device=dev) for L in env.num_limbs]
             sk8 = TransitionSink(env.env_morph, env.num_limbs, env.obs_max_len, env.action_max_len, device=dev, buffers=bufs8, dst=0)
@@ -422,10 +422,10 @@ def main():
             ms_ing8 = e0.elapsed_time(e1) / 10
             extra["replay_ingest"] = {"ms_ingest_per_block": round(ms_ing, 4), "rows_per_block": n_local,
                                       "projected_learner_ms_per_step_at_8_gpus": round(ms_ing8, 3),
-                                      "note": "learner-side ingest (all rows stored): sgrl_ingest_block = k_ingest_keys + k_ingest_put, "
+                                      "note": "learner-side ingest (all rows stored): sgrl_ingest_block = k_ingest_keys + k_ingest_slots + k_ingest_rows, "
                                               "slots on the device, no host synchronisation.  ms_ingest_per_block: one rank's block; "
                                               "projected_learner_ms_per_step_at_8_gpus: MEASURED on this GPU on a contiguous tensor of "
-                                              "8 such blocks (what the learner receives at N = 8: one call, two launches), inside the "
+                                              "8 such blocks (what the learner receives at N = 8: one call, three launches), inside the "
                                               "timed region of an N > 1 run"}
         except Exception as e:
             extra["replay_ingest"] = {"error": repr(e)}

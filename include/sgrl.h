@@ -112,12 +112,12 @@ typedef struct sgrl_ring {
 } sgrl_ring;
 int sgrl_ingest_rows(const float* block, int n_rows, int obs_len, int act_len, const int64_t* slot, const sgrl_ring* rings,
                      int n_rings, void* stream);
-/* The same with the slot arithmetic on the device too (two launches for ANY number of rows -- one rank's block or the learner's
+/* The same with the slot arithmetic on the device too (three launches for ANY number of rows -- one rank's block or the learner's
  * whole gather of N ranks, laid out contiguously in rank order -- and no host involvement): `pos` / `cap` / `pending` are DEVICE
  * arrays of n_rings (<= 32) int64 -- the rings' write pointers (read and advanced), capacities, and a running count of rows stored
  * per ring that the host folds into its own pointers when it next looks (rollout.py TransitionSink.fold_counters); `slot_ws` is a
- * DEVICE workspace of at least n_rows + 64 + 16 * ceil(n_rows / 256) int64 (a ticket, the write pointers before the block, per-chunk
- * counts, row keys) whose FIRST int64 must be zero before the first call (the calls leave it zero).  Same rings,
+ * DEVICE workspace of at least 2 * n_rows + 64 + 16 * ceil(n_rows / 256) int64 (a ticket, the write pointers before the block, per-chunk
+ * counts, row keys, the rows' slots) whose FIRST int64 must be zero before the first call (the calls leave it zero).  Same rings,
  * bit for bit, as sgrl_ingest_rows with the caller's slots (row order = the reference's `for i in range(num_envs)` order,
  * common/buffer.py:75-84 per row). */
 int sgrl_ingest_block(const float* block, int n_rows, int obs_len, int act_len, const sgrl_ring* rings, int n_rings, int64_t* pos,

@@ -400,7 +400,7 @@ class TransitionSink(object):
         stream = torch.cuda.current_stream(self.device).cuda_stream
         L = _lib.lib()
         if len(self.buffers) <= 32:
-            # slots, write pointers and the pending counts on the device (include/sgrl.h sgrl_ingest_block): two launches
+            # slots, write pointers and the pending counts on the device (include/sgrl.h sgrl_ingest_block): three launches
             if self._pend is None:
                 self._pend_buf = getattr(self, "_pend_buf", None)
                 if self._pend_buf is None:
@@ -408,7 +408,7 @@ class TransitionSink(object):
                 else:
                     self._pend_buf.zero_()
                 self._pend = self._pend_buf
-            need = int(blk.shape[0]) + 64 + 16 * ((int(blk.shape[0]) + 255) // 256)      # include/sgrl.h sgrl_ingest_block: workspace
+            need = 2 * int(blk.shape[0]) + 64 + 16 * ((int(blk.shape[0]) + 255) // 256)      # include/sgrl.h sgrl_ingest_block: workspace
             if getattr(self, "_slot_ws", None) is None or self._slot_ws.numel() < need:
                 self._slot_ws = torch.zeros(need, dtype=torch.long, device=self.device)      # word 0 = the ticket: zero before the first call
             _lib.check(L.sgrl_ingest_block(ctypes.c_void_p(blk.data_ptr()), int(blk.shape[0]), int(self.gather.o), int(self.gather.a),
@@ -433,7 +433,7 @@ class TransitionSink(object):
     def ingest(self, blocks):
         fast = FUSED_INGEST and self.device.type == "cuda" and all(isinstance(b, DeviceReplayBuffer) for b in self.buffers)
         # the learner's whole gather at once: the per-rank blocks are views of one contiguous tensor in rank order (ReplayGather),
-        # so N ranks cost one pair of launches per step, not N (k_ingest_keys + k_ingest_put)
+        # so N ranks cost three launches per step, not 2 N (k_ingest_keys + k_ingest_slots + k_ingest_rows)
         flat = getattr(blocks[0], "_base", None) if len(blocks) > 1 else None      # the tensor the per-rank views were split from
         if (fast and flat is not None and flat.dim() == 2 and flat.is_contiguous() and blocks[0].data_ptr() == flat.data_ptr()
                 and all(getattr(b, "_base", None) is flat for b in blocks)

@@ -278,7 +278,7 @@ def test_fused_ingest_writes_exactly_what_the_row_by_row_path_writes():
 def test_whole_gather_ingest_equals_block_by_block():
     """The learner at N > 1: the gather arrives in ONE contiguous [N * rows, row] tensor whose per-rank blocks are
     views (rollout.ReplayGather recv_flat); TransitionSink.ingest recognises them and runs sgrl_ingest_block ONCE over the whole
-    tensor (k_ingest_keys + k_ingest_put, two launches whatever N).  Rings, write pointers and fill levels must equal what the
+    tensor (k_ingest_keys + k_ingest_slots + k_ingest_rows, three launches whatever N).  Rings, write pointers and fill levels must equal what the
     block-by-block ingest of the same views writes, over several steps, with random store flags, a ring that wraps, and more
     rows than one 256-row chunk per morphology (ranks of rows span chunks)."""
     import torch
