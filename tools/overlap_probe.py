@@ -28,12 +28,12 @@ def run(ros, streams, steps=30, preroll=150):
     n = sum(ro.env.num_envs for ro in ros)
     return n * steps / dt, dt / steps * 1e3
 
-one = Rollout(WALKERS, 1024, policy=policy, seed=1, device=dev)
+one = Rollout(WALKERS, 1024, policy=policy, seed=1, device=dev, hold_weights=True)
 v, ms = run([one], [torch.cuda.current_stream()])
 print("single pipeline 8192 envs: %.0f env-steps/s (%.2f ms/step)" % (v, ms))
 del one
 import copy
-halves = [Rollout(WALKERS, 512, policy=policy if k == 0 else copy.deepcopy(policy), seed=1, device=dev, rank=k) for k in range(2)]
+halves = [Rollout(WALKERS, 512, policy=policy if k == 0 else copy.deepcopy(policy), seed=1, device=dev, rank=k, hold_weights=True) for k in range(2)]
 v, ms = run(halves, [torch.cuda.Stream(), torch.cuda.Stream()])
 print("two pipelines 2 x 4096 envs on two streams: %.0f env-steps/s (%.2f ms per 8192 env-steps)" % (v, ms))
 v, ms = run(halves, [torch.cuda.current_stream(), torch.cuda.current_stream()])
