@@ -97,7 +97,6 @@ def test_halves_in_different_contact_situations(name):
 def test_gauss_seidel_fallback_of_the_half_wave():
     """The half wave's projected Gauss-Seidel (wave_half.h pgs: the fallback when block pivoting gives up, and the whole solver of a
     model packed with solver = 0) never runs in the product's pair instances on sane states -- here it is the only solver."""
-    from sgrl_amd import model_pack
     name = "3d_walker_3_left_knee_right_knee"
     m, ib, fb = packed(name, solver=0)
     _, om = oracle_model(name, solver=0)

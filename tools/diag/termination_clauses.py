@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Which clause of the done rule ends episodes, per morphology family (CPU only, on the oracle).
 
-For one morphology per family and three action sources -- zero, U(-1, 1) random, joint-space PD about the reset pose -- runs
+For one morphology per family and three action sources -- zero, U(-1, 1) random, a proportional joint-space controller holding the reset pose ("pd") -- runs
 episodes from the reference's reset distribution (reference src/environments/<name>.py:150-164: qpos0 + U(+-noise) on EVERY
 coordinate, the root quaternion included) and records the episode length and which clause of `done` (reference <name>.py:29-37)
 was violated at the terminal step; plus the stand test: from qpos0 exactly (no reset noise) with zero action, does the model
@@ -95,7 +95,7 @@ def run(name, episodes, max_steps=300):
                     a = rng.uniform(-1, 1, size=3 * L)
                 else:
                     o = obs.reshape(L, 41)
-                    a = np.clip(4.0 * (q_ref - o[:, 24:27]) - 0.3 * 0.0, -1, 1).ravel()      # joint k of limb l is driven by action 3 l + k
+                    a = np.clip(4.0 * (q_ref - o[:, 24:27]), -1, 1).ravel()      # proportional hold of the reset pose: joint k of limb l is driven by action 3 l + k
                 obs, r, d, info = env.step(a, auto_reset=False)
                 if d:
                     if info["TimeLimit.truncated"]:
