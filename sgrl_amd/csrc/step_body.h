@@ -63,6 +63,8 @@ constexpr int kScratchDoublesMax = 2080 + 257 * 47 + 7 * 256 + 256 + 129 + 8 + 4
 // LDS layout (offsets in doubles for S, in ints for I)
 struct Layout {
   int nb, nj, nq, nv, nu, np, ncon, maxrows, lrows, ld, ldy;
+  int prevcap;     // warm-start rows remembered in LDS (the rest: the HBM slab): min(maxrows, kPrevRows); paired layouts: no more than lrows
+  int fstride;     // doubles per contact frame slot: 9 (normal, tangent 1, [tangent 2: recomputed, slot unused]); paired layouts 6
   // S
   int qpos, qvel, q0, v0, xv, fq, dvacc, daacc, ctrl, act;
   int xpos, xquat, xmat, xipos, xanchor, xaxis;
@@ -87,6 +89,11 @@ struct Layout {
   int pair_stride;
 };
 
+SGRL_HD int full_na(int len) {      // rows whose packed factor fits `len` doubles (at most kNAMax)
+  int na = 0;
+  while (na < kNAMax && (na + 1) * (na + 2) / 2 <= len) na++;
+  return na;
+}
 // lrows_cut: rows taken off the natural size of the LDS row arrays (make_layout picks it)
 SGRL_HD void make_layout_rows(const int32_t* hdr, Layout* o, int n_int, int n_f64, int lrows_cut, bool pair = false) {
   const int nb = hdr[SGRL_H_NBODY], nj = hdr[SGRL_H_NJNT], nq = hdr[SGRL_H_NQ], nv = hdr[SGRL_H_NV];
@@ -101,7 +108,13 @@ SGRL_HD void make_layout_rows(const int32_t* hdr, Layout* o, int n_int, int n_f6
   const bool rk4_state = hdr[SGRL_H_INTEGRATOR] != 0;
   o->qpos = p; p += nq; o->qvel = p; p += nv;
   o->q0 = rk4_state ? p : o->qpos; p += rk4_state ? nq : 0; o->v0 = rk4_state ? p : o->qvel; p += rk4_state ? nv : 0;
-  o->xv = rk4_state ? p : o->qvel; p += rk4_state ? nv : 0; o->fq = p; p += nv;
+  // PAIRED layouts (two slabs must fit one workgroup's LDS at eight workgroups per CU: wave_half.h) are put on a diet that the
+  // one-environment layouts do not need (theirs stay byte for byte what rounds 3-4 tuned): xv is qvel (mj_step writes both with the
+  // same value and nothing changes qvel in between), the composite inertias live in the constraint-row block (dead until the rows
+  // are built), contact frames keep two vectors (the third is their cross product), the reciprocal pivots of the unused in-place
+  // factorisation have no array, the warm-start memory in LDS ends with the LDS rows.
+  const bool xv_own = rk4_state && !pair;
+  o->xv = xv_own ? p : o->qvel; p += xv_own ? nv : 0; o->fq = p; p += nv;
   o->dvacc = rk4_state ? p : o->qvel; p += rk4_state ? nv : 0; o->daacc = rk4_state ? p : o->qvel; p += rk4_state ? nv : 0;
   o->ctrl = p; p += nu + 1;
   o->xpos = p; p += 3 * nb; o->xaxis = p; p += 3 * nj; o->cdof = p; p += 6 * nv;
@@ -109,24 +122,42 @@ SGRL_HD void make_layout_rows(const int32_t* hdr, Layout* o, int n_int, int n_f6
   // LCP solver reuses the span as scratch for its Cholesky factor
   o->dead = p;
   o->xquat = p; p += 4 * nb; o->xmat = p; p += 9 * nb; o->xipos = p; p += 3 * nb; o->xanchor = p; p += 3 * nj;
-  o->cinert = p; p += 10 * nb; o->crb = p; p += 10 * nb; o->cfrc = p; p += 6 * nb;
-  o->con_pos = p; p += 3 * o->ncon; o->con_frame = p; p += 9 * o->ncon; o->con_dist = p; p += o->ncon;
+  o->fstride = pair ? 6 : 9;
+  o->cinert = p; p += 10 * nb; o->crb = p; p += pair ? 0 : 10 * nb; o->cfrc = p; p += 6 * nb;
+  o->con_pos = p; p += 3 * o->ncon; o->con_frame = p; p += o->fstride * o->ncon; o->con_dist = p; p += o->ncon;
   o->dead_len = p - o->dead;
+  // rows the factor scratch can serve: from the span a one-environment layout has (a paired layout keeps the same LDS row count and
+  // pads its shorter span up to the factor's size below)
+  const int full_len = o->dead_len + (pair ? 10 * nb + 3 * o->ncon : 0);
   {
     int na = 0;
-    while (na < kNAMax && (na + 1) * (na + 2) / 2 <= o->dead_len) na++;
+    while (na < kNAMax && (na + 1) * (na + 2) / 2 <= full_len) na++;
     o->na_max = na;
   }
-  o->L = p; p += nv * (nv + 1) / 2; o->dinv = p; p += nv;
+  if (pair) {
+    const int want = (o->maxrows < o->na_max ? o->maxrows : o->na_max) - lrows_cut;      // = lrows below
+    const int need = want * (want + 1) / 2;
+    if (o->dead_len < need) { p += need - o->dead_len; o->dead_len = need; }
+    int na = 0;
+    while (na < kNAMax && (na + 1) * (na + 2) / 2 <= o->dead_len) na++;
+    o->na_max = na < want ? want : na;          // (na >= want by construction; the scratch serves free sets up to na rows)
+  }
+  const bool dinv_own = !(pair && rk4_state && nv <= 16);      // paired RK4 sets factor on registers with the explicit inverse: dinv is never touched
+  o->L = p; p += nv * (nv + 1) / 2; o->dinv = dinv_own ? p : o->L; p += dinv_own ? nv : 0;
   o->qfs = p; p += nv; o->qacc = p; p += nv; o->vpgs = p; p += nv;
   // The constraint-row arrays in LDS hold `lrows` rows: as many as the factor scratch (dead zone) can serve.  The rare
   // evaluations with more rows (up to maxrows <= 64) run their whole constraint stage out of the environment's HBM slab
   // instead (Engine::Rows) -- sizing the slab for the common case buys one or two more workgroups per CU.
-  o->lrows = (o->maxrows < o->na_max ? o->maxrows : o->na_max) - lrows_cut;
+  o->lrows = pair ? (o->maxrows < full_na(full_len) ? o->maxrows : full_na(full_len)) - lrows_cut
+                  : (o->maxrows < o->na_max ? o->maxrows : o->na_max) - lrows_cut;
   o->Y = p; p += (o->lrows + 1) * o->ldy;
+  if (pair) o->crb = o->Y;      // 10 nb doubles of a block of (lrows + 1) ldy: written and read inside crba_and_factor only
   o->eR = p; p += o->lrows; o->earef = p; p += o->lrows; o->eb = p; p += o->lrows;
   o->ef = p; p += o->lrows;
-  const int prevcap = o->maxrows < kPrevRows ? o->maxrows : kPrevRows;
+  // (the block-pivot solve parks up to lrows values in prev_f: at least lrows entries)
+  const int prevfull = o->maxrows < kPrevRows ? o->maxrows : kPrevRows;
+  const int prevcap = (pair && o->lrows < prevfull) ? o->lrows : prevfull;
+  o->prevcap = prevcap;
   o->eidg = p; p += o->lrows; o->prev_f = p; p += prevcap;
   o->misc = p; p += 16;
   o->Mfull = p;
@@ -170,6 +201,15 @@ constexpr int kMaxRowCut = 16;
 SGRL_HD void make_layout(const int32_t* hdr, Layout* o, int n_int = 0, int n_f64 = 0, bool pair = false) {
   make_layout_rows(hdr, o, n_int, n_f64, 0, pair);
   const int base = workgroups_per_cu(layout_bytes(o));
+  if (pair && base < 8) {
+    // a slab pair is only used at eight workgroups per CU (the engine declines it otherwise): the smallest cut that gets there
+    for (int cut = 1; cut <= kMaxRowCut && o->lrows - cut >= 20; cut++) {
+      Layout t;
+      make_layout_rows(hdr, &t, n_int, n_f64, cut, pair);
+      if (workgroups_per_cu(layout_bytes(&t)) >= 8) { *o = t; return; }
+    }
+    return;
+  }
   for (int cut = 1; cut <= kMaxRowCut && o->lrows - cut >= 20; cut++) {
     Layout t;
     make_layout_rows(hdr, &t, n_int, n_f64, cut, pair);
@@ -623,7 +663,7 @@ struct Engine {
     make_frame(fr);
     S[o.con_dist + slot] = dist;
     for (int k = 0; k < 3; k++) S[o.con_pos + 3 * slot + k] = pos[k];
-    for (int k = 0; k < 9; k++) S[o.con_frame + 9 * slot + k] = fr[k];
+    for (int k = 0; k < 6; k++) S[o.con_frame + o.fstride * slot + k] = fr[k];      // normal, tangent 1 (tangent 2 = normal x tangent 1: build_rows)
   }
   SGRL_DEV void plane_sphere(int slot, double margin, const double* ppos, const double* n, const double* c, double r, const double* tangent) {
     const double d[3] = {c[0] - ppos[0], c[1] - ppos[1], c[2] - ppos[2]};
@@ -931,14 +971,16 @@ struct Engine {
         const int b1 = m.geom_body[m.pair_g1[p]], b2 = m.geom_body[m.pair_g2[p]];
         const double margin = m.pair_margin[p], dist = S[o.con_dist + s], mu = m.pair_mu[p];
         double off[3], dir[3];
-        const double* fr = S + o.con_frame + 9 * s;     // rows: normal, tangent 1, tangent 2
+        const double* fr = S + o.con_frame + o.fstride * s;     // normal, tangent 1; tangent 2 is their cross product (make_frame)
         for (int k = 0; k < 3; k++) off[k] = S[o.con_pos + 3 * s + k] - S[o.misc + MS_COM + k];
         if (kind == ROW_CON1) {
           for (int k = 0; k < 3; k++) dir[k] = fr[k];
         } else {
-          const int t = 1 + (sub >> 1);
           const double sg = (sub & 1) ? -mu : mu;
-          for (int k = 0; k < 3; k++) dir[k] = fr[k] + sg * fr[3 * t + k];
+          double tg[3];
+          if (sub >> 1) cross3(tg, fr, fr + 3);                    // tangent 2 (what make_frame left in fr[6..8])
+          else ld3(tg, fr + 3);
+          for (int k = 0; k < 3; k++) dir[k] = fr[k] + sg * tg[k];
         }
         sgrl_itab_t mk1 = m.body_dofmask + 2 * b1;
         sgrl_itab_t mk2 = m.body_dofmask + 2 * b2;
@@ -981,7 +1023,7 @@ struct Engine {
       const int key = (kind << 16) | (src << 3) | sub;
       double f0 = 0;
       const int pn = I[o.icnt + IC_PREV_N];
-      const int pcap = o.maxrows < kPrevRows ? o.maxrows : kPrevRows, pl = pn < pcap ? pn : pcap;
+      const int pcap = o.prevcap, pl = pn < pcap ? pn : pcap;
       for (int k = 0; k < pl; k++) if (I[o.prev_key + k] == key) f0 = S[o.prev_f + k];
       if (pn > pcap) {
         const double* hf = big_scratch + slab_prev_offset(o.maxrows, o.ldy);
@@ -1203,7 +1245,7 @@ struct Engine {
     }
     SGRL_TICK(7);
     // remember the solution for the next evaluation's warm start
-    const int prevcap = o.maxrows < kPrevRows ? o.maxrows : kPrevRows;       // LDS keeps the first rows, the HBM slab the others
+    const int prevcap = o.prevcap;       // LDS keeps the first rows, the HBM slab the others
     const int nkeep = (nrow <= prevcap || big_scratch != nullptr) ? nrow : prevcap;
     w.lanes(nkeep > 0 ? nkeep : 1, [&](int r) {
       if (r < nkeep) {

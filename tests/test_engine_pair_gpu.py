@@ -9,8 +9,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 NAMES = ["3d_hopper_3_shin", "3d_walker_2_right_leg_left_knee", "3d_walker_3_left_knee_right_knee", "3d_walker_3_left_leg_right_foot",
-         "3d_walker_7_full", "3d_walker_v2_3_left_leg_right_foot"]      # the last: a `_v2_` task (near targets, resampled on arrival) of a paired set
-COUNTS = [4, 3, 5, 2, 2, 2]
+         "3d_walker_7_full", "3d_walker_v2_3_left_leg_right_foot",      # a `_v2_` task (near targets, resampled on arrival) of a paired set
+         "3d_walker_4_right_knee_left_foot"]                             # nv = 15: pairs on the dieted slab (20 LDS rows)
+COUNTS = [4, 3, 5, 2, 2, 2, 3]
 
 
 def _make(monkeypatch, pair, names=NAMES, counts=COUNTS, seed=9, **kw):
@@ -30,7 +31,7 @@ def _oracles(env, seed):
 def test_pairing_is_what_the_engine_reports(monkeypatch):
     env = _make(monkeypatch, True)
     assert env.fixed_dim_groups == 2
-    assert env.paired_envs == 4 + 2 + 4 + 2 + 2      # hopper_3 4 of 4, walker_2 2 of 3, walker_3 4 of 5, 2 of 2 and (v2) 2 of 2; walker_7 never
+    assert env.paired_envs == 4 + 2 + 4 + 2 + 2 + 2  # hopper_3 4 of 4, walker_2 2 of 3, walker_3 4 of 5, 2 of 2 and (v2) 2 of 2, walker_4 2 of 3; walker_7 never
     assert env.lds_bytes <= 20480                    # the slab pairs keep eight workgroups per CU
     env.close()
     env = _make(monkeypatch, False)
