@@ -203,7 +203,8 @@ SGRL_HD void make_layout(const int32_t* hdr, Layout* o, int n_int = 0, int n_f64
   const int base = workgroups_per_cu(layout_bytes(o));
   if (pair && base < 8) {
     // a slab pair is only used at eight workgroups per CU (the engine declines it otherwise): the smallest cut that gets there
-    for (int cut = 1; cut <= kMaxRowCut && o->lrows - cut >= 20; cut++) {
+    // (never below 16 rows: a foot flat on the floor is 8 rows, two are 16)
+    for (int cut = 1; cut <= kMaxRowCut && o->lrows - cut >= 16; cut++) {
       Layout t;
       make_layout_rows(hdr, &t, n_int, n_f64, cut, pair);
       if (workgroups_per_cu(layout_bytes(&t)) >= 8) { *o = t; return; }

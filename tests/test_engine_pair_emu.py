@@ -10,7 +10,8 @@ import emu_ref
 from helpers import packed, oracle_model
 from oracle import physics_ref
 
-LIGHT = ["3d_walker_2_right_leg_left_knee", "3d_walker_3_left_knee_right_knee", "3d_hopper_3_shin", "3d_walker_4_right_knee_left_foot"]
+LIGHT = ["3d_walker_2_right_leg_left_knee", "3d_walker_3_left_knee_right_knee", "3d_hopper_3_shin", "3d_walker_4_right_knee_left_foot",
+         "3d_hopper_4_lower_shin"]
 
 
 @pytest.mark.parametrize("name", LIGHT)

@@ -1,5 +1,5 @@
 """Two environments per wavefront on the MI355X (sgrl_amd/csrc/wave_half.h, engine_kernel.h env_step_pair): the light morphologies
-(nv <= 12: walker_2, walker_3, hopper_3) of a batch on a fixed-dimension kernel step in pairs -- lanes 0..31 one environment, lanes
+(walker_2, walker_3, walker_4, hopper_3, hopper_4: up to 15 dofs) of a batch on a fixed-dimension kernel step in pairs -- lanes 0..31 one environment, lanes
 32..63 its neighbour of the same morphology.  Checked against the oracle, against the same engine with SGRL_PAIR=0 (one
 environment per wavefront), with odd counts (the last environment steps alone) and with the two halves of a wavefront in very
 different contact situations (their data-dependent branches diverge)."""
@@ -10,8 +10,9 @@ pytestmark = pytest.mark.gpu
 
 NAMES = ["3d_hopper_3_shin", "3d_walker_2_right_leg_left_knee", "3d_walker_3_left_knee_right_knee", "3d_walker_3_left_leg_right_foot",
          "3d_walker_7_full", "3d_walker_v2_3_left_leg_right_foot",      # a `_v2_` task (near targets, resampled on arrival) of a paired set
-         "3d_walker_4_right_knee_left_foot"]                             # nv = 15: pairs on the dieted slab (20 LDS rows)
-COUNTS = [4, 3, 5, 2, 2, 2, 3]
+         "3d_walker_4_right_knee_left_foot",                             # nv = 15: pairs on the dieted slab (20 LDS rows)
+         "3d_hopper_4_lower_shin"]                                       # nv = 15, 14 contact candidates: 17 LDS rows
+COUNTS = [4, 3, 5, 2, 2, 2, 3, 4]
 
 
 def _make(monkeypatch, pair, names=NAMES, counts=COUNTS, seed=9, **kw):
@@ -31,7 +32,7 @@ def _oracles(env, seed):
 def test_pairing_is_what_the_engine_reports(monkeypatch):
     env = _make(monkeypatch, True)
     assert env.fixed_dim_groups == 2
-    assert env.paired_envs == 4 + 2 + 4 + 2 + 2 + 2  # hopper_3 4 of 4, walker_2 2 of 3, walker_3 4 of 5, 2 of 2 and (v2) 2 of 2, walker_4 2 of 3; walker_7 never
+    assert env.paired_envs == 4 + 2 + 4 + 2 + 2 + 2 + 4  # hopper_3 4 of 4, walker_2 2 of 3, walker_3 4 of 5, 2 of 2 and (v2) 2 of 2, walker_4 2 of 3, hopper_4 4 of 4; walker_7 never
     assert env.lds_bytes <= 20480                    # the slab pairs keep eight workgroups per CU
     env.close()
     env = _make(monkeypatch, False)
