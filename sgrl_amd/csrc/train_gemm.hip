@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 #include <type_traits>
 
@@ -90,10 +91,20 @@ __device__ __forceinline__ float4 relu_mask(float4 v, float4 y) {
 // otherwise its row index is the output index and the contraction runs along the row (thread = (output row, four k), rows
 // on adjacent lanes so that the transposing LDS stores fall on distinct banks).
 // One output tile (bx = column tile, by = row tile, bz = contraction split of nz, on a grid of gx x gy tiles).
-template <bool AT, bool BTR, int BK>
+// RM (round 5): an operand whose contraction index is contiguous is staged ROW-major (pitch BK + 4 floats) instead of being
+// transposed on its way into LDS: its global loads are coalesced (32 lanes = 512 contiguous bytes of one row; the transposing
+// form reads 32 rows x 16 bytes per instruction), its LDS stores are one conflict-free 16-byte store per load instead of four
+// 4-byte stores, and a lane fetches FOUR matrix instructions' worth of its row with one 16-byte LDS read (lane (i, h) of group g
+// takes k = 8 g + 4 h + j for instruction j: both operands follow the same order, so the contraction is complete).
+template <bool AT, bool BTR, int BK, bool RM = true>
 __device__ __forceinline__ void sgemm_tile(const SArgs& a, float (*As)[LDP], float (*Bs)[LDP], int* s_last_p, int bx, int by,
                                            int bz, int gx, int gy, int nz) {
   constexpr int NLD = BT * BK / 4 / 256;   // float4 loads per thread, operand and k-tile
+  constexpr int Q = BK / 4;                // float4s per staged row of a row-major tile
+  constexpr int PR = BK + 4;               // its pitch: 16-byte aligned rows, rows i and i + 1 four banks apart
+  static_assert(BT * PR <= BK * LDP, "a row-major tile fits the k-major tile's LDS");
+  float* const Ar = &As[0][0];
+  float* const Br = &Bs[0][0];
   int& s_last = *s_last_p;
   const int t = threadIdx.x;
   const int m0 = by * BT, n0 = bx * BT;
@@ -127,8 +138,8 @@ __device__ __forceinline__ void sgemm_tile(const SArgs& a, float (*As)[LDP], flo
         }
         ra[slot][i] = v;
         if (want_db) { dbp.x += v.x; dbp.y += v.y; dbp.z += v.z; dbp.w += v.w; }
-      } else {                              // A[m][k]: m = idx % 32, k = k0 + 4 (idx / 32)
-        const int m = m0 + (idx & 31), c = k0 + 4 * (idx >> 5);
+      } else {                              // A[m][k]: m = idx % 32, k = k0 + 4 (idx / 32); row-major staging: m = idx / Q, k = k0 + 4 (idx % Q)
+        const int m = m0 + (RM ? idx / Q : (idx & 31)), c = k0 + 4 * (RM ? idx % Q : (idx >> 5));
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (m < a.M) {
           v = load4(a.A + (size_t)m * a.lda, c, k_end, a_vec);
@@ -141,7 +152,7 @@ __device__ __forceinline__ void sgemm_tile(const SArgs& a, float (*As)[LDP], flo
         const int k = k0 + (idx >> 3), c = n0 + 4 * (idx & 7);
         rb[slot][i] = k < k_end ? load4(a.B + (size_t)k * a.ldb, c, a.N, b_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
-        const int n = n0 + (idx & 31), c = k0 + 4 * (idx >> 5);
+        const int n = n0 + (RM ? idx / Q : (idx & 31)), c = k0 + 4 * (RM ? idx % Q : (idx >> 5));
         rb[slot][i] = n < a.N ? load4(a.B + (size_t)n * a.ldb, c, k_end, b_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
@@ -153,8 +164,10 @@ __device__ __forceinline__ void sgemm_tile(const SArgs& a, float (*As)[LDP], flo
       const int idx = t + 256 * i;
       const float4 va = ra[slot][i], vb = rb[slot][i];
       if (AT) *reinterpret_cast<float4*>(&As[idx >> 3][4 * (idx & 7)]) = va;
+      else if (RM) *reinterpret_cast<float4*>(Ar + (idx / Q) * PR + 4 * (idx % Q)) = va;
       else { const int k = 4 * (idx >> 5), m = idx & 31; As[k][m] = va.x; As[k + 1][m] = va.y; As[k + 2][m] = va.z; As[k + 3][m] = va.w; }
       if (BTR) *reinterpret_cast<float4*>(&Bs[idx >> 3][4 * (idx & 7)]) = vb;
+      else if (RM) *reinterpret_cast<float4*>(Br + (idx / Q) * PR + 4 * (idx % Q)) = vb;
       else { const int k = 4 * (idx >> 5), n = idx & 31; Bs[k][n] = vb.x; Bs[k + 1][n] = vb.y; Bs[k + 2][n] = vb.z; Bs[k + 3][n] = vb.w; }
     }
   };
@@ -170,10 +183,35 @@ __device__ __forceinline__ void sgemm_tile(const SArgs& a, float (*As)[LDP], flo
     if (k0 + 2 * BK < k_end) load_tiles(slot_c, k0 + 2 * BK);   // in flight underneath this tile's and the next tile's arithmetic
     const int kn = min(BK, k_end - k0);              // rows kn .. BK - 1 of the tiles are zero (load_tiles): harmless
     const int kw = wave * (BK / 4);
+    if constexpr (RM && !(AT && BTR)) {
 #pragma unroll
-    for (int kk = 0; kk < BK / 4; kk += 2)
-      if (kw + kk < kn)                              // wave-uniform: skip the all-zero tail of a short contraction
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kw + kk + lh][li], Bs[kw + kk + lh][li], acc, 0, 0, 0);
+      for (int g8 = 0; g8 < BK / 4; g8 += 8)
+        if (kw + g8 < kn) {                          // wave-uniform: skip the all-zero tail of a short contraction
+          const int kq = kw + g8 + 4 * lh;           // this lane's four contraction indices of the group
+          float av[4], bv[4];
+          if (AT) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) av[j] = As[kq + j][li];
+          } else {
+            const float4 q = *reinterpret_cast<const float4*>(Ar + li * PR + kq);
+            av[0] = q.x; av[1] = q.y; av[2] = q.z; av[3] = q.w;
+          }
+          if (BTR) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) bv[j] = Bs[kq + j][li];
+          } else {
+            const float4 q = *reinterpret_cast<const float4*>(Br + li * PR + kq);
+            bv[0] = q.x; bv[1] = q.y; bv[2] = q.z; bv[3] = q.w;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < BK / 4; kk += 2)
+        if (kw + kk < kn)                              // wave-uniform: skip the all-zero tail of a short contraction
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kw + kk + lh][li], Bs[kw + kk + lh][li], acc, 0, 0, 0);
+    }
     __syncthreads();
   };
   constexpr std::integral_constant<int, 0> S0{};
@@ -248,25 +286,25 @@ __device__ __forceinline__ void sgemm_tile(const SArgs& a, float (*As)[LDP], flo
   }
 }
 
-template <bool AT, bool BTR, int BK>
+template <bool AT, bool BTR, int BK, bool RM>
 __global__ __launch_bounds__(256) void k_sgemm(SArgs a) {
   __shared__ __attribute__((aligned(16))) float As[BK][LDP];
   __shared__ __attribute__((aligned(16))) float Bs[BK][LDP];
   __shared__ int s_last;
-  sgemm_tile<AT, BTR, BK>(a, As, Bs, &s_last, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z);
+  sgemm_tile<AT, BTR, BK, RM>(a, As, Bs, &s_last, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z);
 }
 
 // Twin launch: TWO independent products of the same shape (the layers of the twin critics, reference SECritic.py: critic1 /
 // critic2 are two TransformerModels applied to the same batch) in one grid -- blockIdx.z picks the argument set.  Half the
 // launches of a critic pass; forward and input-gradient products only (their contractions are never split).
 struct SArgs2 { SArgs a[2]; };
-template <bool BTR>
+template <bool BTR, bool RM>
 __global__ __launch_bounds__(256) void k_sgemm_twin(SArgs2 p) {
   __shared__ __attribute__((aligned(16))) float As[BKF][LDP];
   __shared__ __attribute__((aligned(16))) float Bs[BKF][LDP];
   __shared__ int s_last;
   const SArgs a = p.a[blockIdx.z];              // uniform: scalar loads from the kernel-argument segment
-  sgemm_tile<false, BTR, BKF>(a, As, Bs, &s_last, blockIdx.x, blockIdx.y, 0, gridDim.x, gridDim.y, 1);
+  sgemm_tile<false, BTR, BKF, RM>(a, As, Bs, &s_last, blockIdx.x, blockIdx.y, 0, gridDim.x, gridDim.y, 1);
 }
 
 // The two products of a layer's backward pass -- input gradient and weight (+ bias) gradient -- need the same dy and nothing
@@ -274,6 +312,7 @@ __global__ __launch_bounds__(256) void k_sgemm_twin(SArgs2 p) {
 // gradient (and its contraction splits).  Half the launches of the update's backward GEMMs, and each small product no longer
 // waits for the other to drain.
 struct BwdArgs { SArgs d; SArgs w; int nd, dgx, dgy, wgx, wgy, wnz; };
+template <bool RM>
 __global__ __launch_bounds__(256) void k_sgemm_bwd(BwdArgs p) {
   __shared__ __attribute__((aligned(16))) float As[BKF][LDP];
   __shared__ __attribute__((aligned(16))) float Bs[BKF][LDP];
@@ -281,7 +320,7 @@ __global__ __launch_bounds__(256) void k_sgemm_bwd(BwdArgs p) {
   static_assert(BKW == BKF, "the fused backward kernel shares one pair of LDS tiles");
   const int id = blockIdx.x;
   if (id < p.nd) {
-    sgemm_tile<false, true, BKF>(p.d, As, Bs, &s_last, id % p.dgx, id / p.dgx, 0, p.dgx, p.dgy, 1);
+    sgemm_tile<false, true, BKF, RM>(p.d, As, Bs, &s_last, id % p.dgx, id / p.dgx, 0, p.dgx, p.dgy, 1);
   } else {
     const int r = id - p.nd, per = p.wgx * p.wgy;
     sgemm_tile<true, true, BKW>(p.w, As, Bs, &s_last, (r % per) % p.wgx, (r % per) / p.wgx, r / per, p.wgx, p.wgy, p.wnz);
@@ -760,6 +799,11 @@ __global__ __launch_bounds__(256) void k_opt_lerp(const OptRow* __restrict__ tab
 // handful of tiles, or a contraction of a dozen k-tiles and more.  At least two k-tiles per split, never more (split, tile)
 // slots than the scratch holds.
 // grid of one product: tiles + the contraction split (weight gradient only, see above); fills a.kper / a.ws / a.counters
+// SGRL_TRAIN_RM=0 (probe): the transposing staging of rounds 2-4 instead of the row-major one
+bool row_major_staging() {
+  static const bool on = [] { const char* e = getenv("SGRL_TRAIN_RM"); return !(e && e[0] == '0'); }();
+  return on;
+}
 template <bool AT>
 int plan(SArgs& a, float* ws, int* tn, int* tm, int* splits_out, int64_t ws_slot0 = 0, int counter0 = 0) {
   constexpr int BK = AT ? BKW : BKF;
@@ -782,7 +826,8 @@ int launch(SArgs a, float* ws, hipStream_t st) {
   int tn, tm, splits;
   const int rc = plan<AT>(a, ws, &tn, &tm, &splits);
   if (rc != SGRL_OK) return rc;
-  hipLaunchKernelGGL((k_sgemm<AT, BTR, BK>), dim3(tn, tm, splits), dim3(256), 0, st, a);
+  if (row_major_staging()) hipLaunchKernelGGL((k_sgemm<AT, BTR, BK, true>), dim3(tn, tm, splits), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((k_sgemm<AT, BTR, BK, false>), dim3(tn, tm, splits), dim3(256), 0, st, a);
   { int lrc = SGRL_OK; if (!launched("train gemm: kernel launch failed", &lrc)) return lrc; }
   return SGRL_OK;
 }
@@ -794,7 +839,8 @@ int launch_bwd(SArgs d, SArgs w, float* ws, hipStream_t st) {
   rc = plan<true>(w, ws, &p.wgx, &p.wgy, &p.wnz);
   if (rc != SGRL_OK) return rc;
   p.d = d; p.w = w; p.nd = p.dgx * p.dgy;
-  hipLaunchKernelGGL(k_sgemm_bwd, dim3(p.nd + p.wgx * p.wgy * p.wnz), dim3(256), 0, st, p);
+  if (row_major_staging()) hipLaunchKernelGGL(k_sgemm_bwd<true>, dim3(p.nd + p.wgx * p.wgy * p.wnz), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(k_sgemm_bwd<false>, dim3(p.nd + p.wgx * p.wgy * p.wnz), dim3(256), 0, st, p);
   { int lrc = SGRL_OK; if (!launched("train gemm: backward kernel launch failed", &lrc)) return lrc; }
   return SGRL_OK;
 }
@@ -872,7 +918,8 @@ int sgrl_linear_forward_twin(const float* x0, const float* x1, int ldx, const fl
   p.a[1] = SArgs{x1, ldx, nullptr, 0, w1, ldw, b1, relu ? 1 : 0, rd1, y1, ldy, nullptr, M, N, K, 0, nullptr, nullptr};
   int tn, tm, splits;
   for (int i = 0; i < 2; i++) { const int rc = plan<false>(p.a[i], nullptr, &tn, &tm, &splits); if (rc != SGRL_OK) return rc; }
-  hipLaunchKernelGGL(k_sgemm_twin<false>, dim3(tn, tm, 2), dim3(256), 0, (hipStream_t)stream, p);
+  if (row_major_staging()) hipLaunchKernelGGL((k_sgemm_twin<false, true>), dim3(tn, tm, 2), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((k_sgemm_twin<false, false>), dim3(tn, tm, 2), dim3(256), 0, (hipStream_t)stream, p);
   { int lrc = SGRL_OK; if (!launched("k_sgemm_twin launch failed", &lrc)) return lrc; }
   return SGRL_OK;
 }
@@ -890,7 +937,8 @@ int sgrl_linear_forward_twin_fused(const float* x0, const float* x1, int ldx, co
   p.a[1] = SArgs{x1, ldx, nullptr, 0, w1, ldw, b1, relu ? 1 : 0, rd1, y1, ldy, nullptr, M, N, K, 0, nullptr, nullptr, add1, ldadd, tail1, ntail};
   int tn, tm, splits;
   for (int i = 0; i < 2; i++) { const int rc = plan<false>(p.a[i], nullptr, &tn, &tm, &splits); if (rc != SGRL_OK) return rc; }
-  hipLaunchKernelGGL(k_sgemm_twin<false>, dim3(tn, tm, 2), dim3(256), 0, (hipStream_t)stream, p);
+  if (row_major_staging()) hipLaunchKernelGGL((k_sgemm_twin<false, true>), dim3(tn, tm, 2), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((k_sgemm_twin<false, false>), dim3(tn, tm, 2), dim3(256), 0, (hipStream_t)stream, p);
   { int lrc = SGRL_OK; if (!launched("k_sgemm_twin launch failed", &lrc)) return lrc; }
   return SGRL_OK;
 }
@@ -911,7 +959,8 @@ int sgrl_linear_dgrad_twin(const float* dy0, const float* dy1, int lddy, const f
   p.a[1] = SArgs{dy1, lddy, relu ? y1 : nullptr, ldyo, w1, ldw, nullptr, 0, rd1, dx1, lddx, nullptr, M, K, N, 0, nullptr, nullptr};
   int tn, tm, splits;
   for (int i = 0; i < 2; i++) { const int rc = plan<false>(p.a[i], nullptr, &tn, &tm, &splits); if (rc != SGRL_OK) return rc; }
-  hipLaunchKernelGGL(k_sgemm_twin<true>, dim3(tn, tm, 2), dim3(256), 0, st, p);
+  if (row_major_staging()) hipLaunchKernelGGL((k_sgemm_twin<true, true>), dim3(tn, tm, 2), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((k_sgemm_twin<true, false>), dim3(tn, tm, 2), dim3(256), 0, st, p);
   { int lrc = SGRL_OK; if (!launched("k_sgemm_twin (input gradient) launch failed", &lrc)) return lrc; }
   return SGRL_OK;
 }
