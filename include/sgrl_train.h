@@ -56,6 +56,14 @@ int sgrl_linear_forward_twin_fused(const float* x0, const float* x1, int ldx, co
 int sgrl_linear_backward(const float* dy, int lddy, const float* y, int ldyo, int relu, const float* rowdiv, const float* x,
                          int ldx, const float* w, int ldw, float* dx, int lddx, float* dw, int lddw, float* db,
                          float* drowdiv, int M, int N, int K, float* ws, void* stream);
+/* The same with the ReLU of the layer BELOW folded into the input gradient's epilogue: x_relu != 0 says that this layer's input x is
+ * the output of a ReLU layer (x = max(., 0): linear1 -> ReLU -> linear2 of the reference's feed-forward pairs, SEActor.py:101-121),
+ * and dx comes out masked by x > 0 -- which is the gradient that layer's backward needs, so it is then called with relu = 0 and
+ * reads no mask in its two products (mask applied once per element here instead of once per k-tile there, twice).  The twin form
+ * takes the two inputs x0 / x1 (both null: no mask). */
+int sgrl_linear_backward_xrelu(const float* dy, int lddy, const float* y, int ldyo, int relu, const float* rowdiv, const float* x,
+                               int ldx, const float* w, int ldw, float* dx, int lddx, float* dw, int lddw, float* db,
+                               float* drowdiv, int M, int N, int K, int x_relu, float* ws, void* stream);
 
 /* The weight (+ bias) gradients of several layers in one launch per 12 layers: dw = g^T x, db = column sums of g, g as in
  * sgrl_linear_backward (which then is called with dw = db = null).  They are not on the backward pass's critical path -- only the
@@ -78,6 +86,10 @@ int sgrl_linear_forward_twin(const float* x0, const float* x1, int ldx, const fl
 int sgrl_linear_dgrad_twin(const float* dy0, const float* dy1, int lddy, const float* y0, const float* y1, int ldyo, int relu,
                            const float* rd0, const float* rd1, const float* w0, const float* w1, int ldw, float* dx0, float* dx1,
                            int lddx, float* drd0, float* drd1, int M, int N, int K, void* stream);
+int sgrl_linear_dgrad_twin_xrelu(const float* dy0, const float* dy1, int lddy, const float* y0, const float* y1, int ldyo, int relu,
+                                 const float* rd0, const float* rd1, const float* w0, const float* w1, int ldw, float* dx0, float* dx1,
+                                 int lddx, float* drd0, float* drd1, const float* x0, const float* x1, int ldx, int M, int N, int K,
+                                 void* stream);
 
 /* Gram invariants of M nodes' three 32-vectors z[M, 3, 32] (reference SEActor.py:94-98): gram[M, 1024] = vec(Z'Z),
  * fn[M] = ||Z'Z||_F + 1; and their backward: dz = Z (D + D'), D = dgram + (dfn / ||Z'Z||_F) Z'Z (dgram or dfn may be null). */

@@ -65,6 +65,9 @@ struct SArgs {
   const float* addend; int ldadd;   // C[m][n] += addend[m][n] after the epilogue (a residual stream: g + linear5(...))
   const float* tail; int ntail;     // C[m][N + j] = tail[m][j], j < ntail: columns appended to the product's N (z = [proj(x) | gdir],
                                     // c = [inv | ng]): the last column tile's spare columns, then column tiles of their own
+  const float* omask; int ldomask;  // C[m][n] = 0 where omask[m][n] <= 0 (same layout as C): the ReLU mask of the layer BELOW applied
+                                    // in this input gradient's epilogue (dx = (g . w) masked by x > 0), once per output element,
+                                    // instead of on the fly in every k-tile of that layer's two backward products
 };
 constexpr int TILE_WS = BT * BT + BT;
 constexpr int64_t kWsTiles = 4096;      // (split, tile) slots of the scratch buffer
@@ -282,6 +285,7 @@ __device__ __forceinline__ void sgemm_tile(const SArgs& a, float (*As)[LDP], flo
     if (a.relu) o = fmaxf(o, 0.f);
     if (!AT && !BTR && a.rowdiv) o = o / a.rowdiv[m];
     if (!AT && !BTR && a.addend) o += a.addend[(size_t)m * a.ldadd + n];
+    if (!AT && BTR && a.omask && !(a.omask[(size_t)m * a.ldomask + n] > 0.f)) o = 0.f;
     a.C[(size_t)m * a.ldc + n] = o;
   }
 }
@@ -874,6 +878,13 @@ int sgrl_linear_forward_fused(const float* x, int ldx, const float* w, int ldw, 
 int sgrl_linear_backward(const float* dy, int lddy, const float* y, int ldyo, int relu, const float* rowdiv, const float* x,
                          int ldx, const float* w, int ldw, float* dx, int lddx, float* dw, int lddw, float* db,
                          float* drowdiv, int M, int N, int K, float* ws, void* stream) {
+  return sgrl_linear_backward_xrelu(dy, lddy, y, ldyo, relu, rowdiv, x, ldx, w, ldw, dx, lddx, dw, lddw, db, drowdiv, M, N, K, 0, ws, stream);
+}
+
+int sgrl_linear_backward_xrelu(const float* dy, int lddy, const float* y, int ldyo, int relu, const float* rowdiv, const float* x,
+                               int ldx, const float* w, int ldw, float* dx, int lddx, float* dw, int lddw, float* db,
+                               float* drowdiv, int M, int N, int K, int x_relu, float* ws, void* stream) {
+  if (x_relu && dx && (!x || ldx < K)) return tfail(SGRL_ERR_ARG, "sgrl_linear_backward_xrelu: x_relu needs the layer's input");
   if (!dy || M <= 0 || N <= 0 || K <= 0 || lddy < N || ((relu || drowdiv) && (!y || ldyo < N)) || (drowdiv && !rowdiv) ||
       (relu && rowdiv))
     return tfail(SGRL_ERR_ARG, "sgrl_linear_backward: bad argument");
@@ -888,6 +899,7 @@ int sgrl_linear_backward(const float* dy, int lddy, const float* y, int ldyo, in
   if (dw && (!x || ldx < K || lddw < K)) return tfail(SGRL_ERR_ARG, "sgrl_linear_backward: bad input / dw argument");
   // dx[M][K] = g[M][N] . w[N][K]: contraction N, contiguous in g, the row index of w
   SArgs ad{dy, lddy, mask, ldyo, w, ldw, nullptr, 0, rowdiv, dx, lddx, nullptr, M, K, N, 0, nullptr, nullptr};
+  if (x_relu) { ad.omask = x; ad.ldomask = ldx; }
   // dw[N][K] = g^T . x: contraction M, the row index of both operands; db rides along
   SArgs aw{dy, lddy, mask, ldyo, x, ldx, nullptr, 0, rowdiv, dw, lddw, db, N, K, M, 0, nullptr, nullptr};
   if (dx && dw) {
@@ -946,6 +958,15 @@ int sgrl_linear_forward_twin_fused(const float* x0, const float* x1, int ldx, co
 int sgrl_linear_dgrad_twin(const float* dy0, const float* dy1, int lddy, const float* y0, const float* y1, int ldyo, int relu,
                            const float* rd0, const float* rd1, const float* w0, const float* w1, int ldw, float* dx0, float* dx1,
                            int lddx, float* drd0, float* drd1, int M, int N, int K, void* stream) {
+  return sgrl_linear_dgrad_twin_xrelu(dy0, dy1, lddy, y0, y1, ldyo, relu, rd0, rd1, w0, w1, ldw, dx0, dx1, lddx, drd0, drd1, nullptr, nullptr,
+                                      0, M, N, K, stream);
+}
+
+int sgrl_linear_dgrad_twin_xrelu(const float* dy0, const float* dy1, int lddy, const float* y0, const float* y1, int ldyo, int relu,
+                                 const float* rd0, const float* rd1, const float* w0, const float* w1, int ldw, float* dx0, float* dx1,
+                                 int lddx, float* drd0, float* drd1, const float* x0, const float* x1, int ldx, int M, int N, int K,
+                                 void* stream) {
+  if ((!x0) != (!x1) || (x0 && ldx < K)) return tfail(SGRL_ERR_ARG, "sgrl_linear_dgrad_twin_xrelu: bad input-mask argument");
   if (!dy0 || !dy1 || !w0 || !w1 || !dx0 || !dx1 || M <= 0 || N <= 0 || K <= 0 || lddy < N || ldw < K || lddx < K ||
       ((relu || drd0) && (!y0 || !y1 || ldyo < N)) || (!rd0) != (!rd1) || (!drd0) != (!drd1) || (drd0 && !rd0) || (relu && rd0))
     return tfail(SGRL_ERR_ARG, "sgrl_linear_dgrad_twin: bad argument");
@@ -957,6 +978,7 @@ int sgrl_linear_dgrad_twin(const float* dy0, const float* dy1, int lddy, const f
   SArgs2 p;
   p.a[0] = SArgs{dy0, lddy, relu ? y0 : nullptr, ldyo, w0, ldw, nullptr, 0, rd0, dx0, lddx, nullptr, M, K, N, 0, nullptr, nullptr};
   p.a[1] = SArgs{dy1, lddy, relu ? y1 : nullptr, ldyo, w1, ldw, nullptr, 0, rd1, dx1, lddx, nullptr, M, K, N, 0, nullptr, nullptr};
+  if (x0) { p.a[0].omask = x0; p.a[1].omask = x1; p.a[0].ldomask = p.a[1].ldomask = ldx; }
   int tn, tm, splits;
   for (int i = 0; i < 2; i++) { const int rc = plan<false>(p.a[i], nullptr, &tn, &tm, &splits); if (rc != SGRL_OK) return rc; }
   if (row_major_staging()) hipLaunchKernelGGL((k_sgemm_twin<true, true>), dim3(tn, tm, 2), dim3(256), 0, st, p);

@@ -35,8 +35,14 @@ class Linear(nn.Linear):
     weight / bias gradient -- runs on this library's small-product kernels (train_ops.linear, csrc/train_gemm.hip); `relu`
     folds the activation that follows the layer into the product's epilogue and its mask into the backward products."""
 
-    def forward(self, x, relu=False, rowdiv=None, addend=None, tail=None):
-        return train_ops.linear(x, self.weight, self.bias, relu, rowdiv, addend, tail)
+    def forward(self, x, relu=False, rowdiv=None, addend=None, tail=None, x_relu=False, premasked=False):
+        return train_ops.linear(x, self.weight, self.bias, relu, rowdiv, addend, tail, x_relu, premasked)
+
+
+def _mlp(lin1, lin2, x, rowdiv=None, tail=None):
+    """lin2(relu(lin1(x))) (/ rowdiv, | tail): the reference's feed-forward pairs (SEActor.py:101-121).  The hidden activation has
+    no other consumer, so its ReLU mask is applied once, in the epilogue of lin2's input gradient (train_ops.linear x_relu / premasked)."""
+    return lin2(lin1(x, relu=True, premasked=True), rowdiv=rowdiv, tail=tail, x_relu=True)
 
 
 class ConcatPositionalEmbedding(nn.Module):
@@ -56,7 +62,7 @@ def _invariants(x, gdir, proj, lin1, lin2, tail=None):
     """x [B,L,3,C] -> (features [B,L,out] (| tail), F_norm [B,L,1])."""
     z = proj(x, tail=gdir)                      # [proj(x) | gdir]: the appended pair rides on the projection's launch
     gram, fn = train_ops.gram_fn(z)
-    return lin2(lin1(gram, relu=True), tail=tail), fn
+    return _mlp(lin1, lin2, gram, tail=tail), fn
 
 
 class SubequivariantAttention(nn.Module):
@@ -152,10 +158,10 @@ class SubequivariantEncoderLayer(nn.Module):
         g = g + g1
         ng = train_ops.add_layer_norm(ng, ng1, self.norm1)
         c, fn = _invariants(g1, gdir, self.g_proj2, self.linear_g1, self.linear_g2, tail=ng)   # [inv | ng]
-        mat = self.linear4(self.linear3(c, relu=True), rowdiv=fn).view(*ng.shape[:2], Z_DIM, Z_DIM)
+        mat = _mlp(self.linear3, self.linear4, c, rowdiv=fn).view(*ng.shape[:2], Z_DIM, Z_DIM)
         z3 = self.g_proj3(g1, tail=gdir)
         g = self.linear5(train_ops.zmat(z3, mat), addend=g)
-        ng = train_ops.add_layer_norm(ng, self.linear2(self.linear1(c, relu=True), rowdiv=fn), self.norm2)
+        ng = train_ops.add_layer_norm(ng, _mlp(self.linear1, self.linear2, c, rowdiv=fn), self.norm2)
         return g, ng
 
 
@@ -233,11 +239,11 @@ class TransformerModel(nn.Module):
         g, ng = self.transformer_encoder(g, ng, gdir, pos, graph["relation"])
         out_ng = torch.cat([n0, ng], dim=-1)
         out_g = torch.cat([g0, g], dim=-1)
-        hng = self.linear2_ng(self.linear1_ng(out_ng, relu=True))
+        hng = _mlp(self.linear1_ng, self.linear2_ng, out_ng)
         c, fn = _invariants(out_g, gdir, self.gg_proj, self.linear1_g, self.linear2_g, tail=hng)       # [inv | hng]
         if self.output_size == 1:
             return self.decoder_ng(c, rowdiv=fn)
-        mat = self.linear2_m(self.linear1_m(c, relu=True), rowdiv=fn).view(B, L, Z_DIM, Z_DIM)
+        mat = _mlp(self.linear1_m, self.linear2_m, c, rowdiv=fn).view(B, L, Z_DIM, Z_DIM)
         zh = self.g_proj(out_g, tail=gdir)
         vec = self.decoder_g(train_ops.zmat(zh, mat)).squeeze(-1)   # [B,L,3]
         return torch.einsum("blsk,bls->blk", g0[..., 5:8], vec)
@@ -250,8 +256,13 @@ class TransformerModel(nn.Module):
 # is one launch for the pair (train_ops.linear2), and the weight-free operations (Gram invariants, attention, the equivariant
 # contraction, residual adds, concatenations) simply see twice the nodes.  Same arithmetic per network as
 # TransformerModel.forward, operation by operation (tests/test_set_critic.py, tests/test_train_ops_gpu.py).
-def _lin2(l0, l1, x, relu=False, rowdiv=None, shared=False, addend=None, tail=None):
-    return train_ops.linear2(x, l0.weight, l1.weight, l0.bias, l1.bias, relu, rowdiv, shared, addend, tail)
+def _lin2(l0, l1, x, relu=False, rowdiv=None, shared=False, addend=None, tail=None, x_relu=False, premasked=False):
+    return train_ops.linear2(x, l0.weight, l1.weight, l0.bias, l1.bias, relu, rowdiv, shared, addend, tail, x_relu, premasked)
+
+
+def _mlp2(lin1, lin2, x, rowdiv=None, tail=None):
+    """`_mlp` for the two critics at once (lin1 / lin2: pairs of layers)."""
+    return _lin2(lin2[0], lin2[1], _lin2(lin1[0], lin1[1], x, relu=True, premasked=True), rowdiv=rowdiv, tail=tail, x_relu=True)
 
 
 def _norm2(n0, n1, x, res=None):
@@ -261,7 +272,7 @@ def _norm2(n0, n1, x, res=None):
 def _invariants2(x, gdir2, proj, lin1, lin2, tail=None):
     z = _lin2(proj[0], proj[1], x, tail=gdir2)
     gram, fn = train_ops.gram_fn(z)
-    return _lin2(lin2[0], lin2[1], _lin2(lin1[0], lin1[1], gram, relu=True), tail=tail), fn
+    return _mlp2(lin1, lin2, gram, tail=tail), fn
 
 
 def _attention2(a, g, ng, gdir, gdir2, bias):
@@ -288,11 +299,11 @@ def _layer2(l, g, ng, gdir, gdir2, bias):
     g = g + g1
     ng = _norm2(l[0].norm1, l[1].norm1, ng, ng1)
     c, fn = _invariants2(g1, gdir2, (l[0].g_proj2, l[1].g_proj2), (l[0].linear_g1, l[1].linear_g1), (l[0].linear_g2, l[1].linear_g2), tail=ng)
-    mat = _lin2(l[0].linear4, l[1].linear4, _lin2(l[0].linear3, l[1].linear3, c, relu=True), rowdiv=fn)
+    mat = _mlp2((l[0].linear3, l[1].linear3), (l[0].linear4, l[1].linear4), c, rowdiv=fn)
     mat = mat.view(*ng.shape[:3], Z_DIM, Z_DIM)
     z3 = _lin2(l[0].g_proj3, l[1].g_proj3, g1, tail=gdir2)
     g = _lin2(l[0].linear5, l[1].linear5, train_ops.zmat(z3, mat), addend=g)
-    ng = _norm2(l[0].norm2, l[1].norm2, ng, _lin2(l[0].linear2, l[1].linear2, _lin2(l[0].linear1, l[1].linear1, c, relu=True), rowdiv=fn))
+    ng = _norm2(l[0].norm2, l[1].norm2, ng, _mlp2((l[0].linear1, l[1].linear1), (l[0].linear2, l[1].linear2), c, rowdiv=fn))
     return g, ng
 
 
@@ -320,7 +331,7 @@ def twin_forward(m0, m1, x, graph, geo_grad=True):
         ng = _norm2(e0.norm, e1.norm, ng)
     out_ng = torch.cat([n0.unsqueeze(0).expand(2, *n0.shape), ng], dim=-1)
     out_g = torch.cat([g0.unsqueeze(0).expand(2, *g0.shape), g], dim=-1)
-    hng = _lin2(m0.linear2_ng, m1.linear2_ng, _lin2(m0.linear1_ng, m1.linear1_ng, out_ng, relu=True))
+    hng = _mlp2((m0.linear1_ng, m1.linear1_ng), (m0.linear2_ng, m1.linear2_ng), out_ng)
     c, fn = _invariants2(out_g, gdir2, (m0.gg_proj, m1.gg_proj), (m0.linear1_g, m1.linear1_g), (m0.linear2_g, m1.linear2_g), tail=hng)
     return _lin2(m0.decoder_ng, m1.decoder_ng, c, rowdiv=fn)
 

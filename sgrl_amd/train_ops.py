@@ -30,6 +30,8 @@ def _L():
         vp, ci = ctypes.c_void_p, ctypes.c_int
         L.sgrl_linear_forward.argtypes = [vp, ci, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]
         L.sgrl_linear_backward.argtypes = [vp, ci, vp, ci, ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, vp, vp]
+        L.sgrl_linear_backward_xrelu.argtypes = [vp, ci, vp, ci, ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp]
+        L.sgrl_linear_dgrad_twin_xrelu.argtypes = [vp, vp, ci, vp, vp, ci, ci, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp]
         L.sgrl_linear_forward_twin.argtypes = [vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
         L.sgrl_linear_dgrad_twin.argtypes = [vp, vp, ci, vp, vp, ci, ci, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, vp]
         L.sgrl_gram_forward.argtypes = [vp, vp, vp, ci, vp]
@@ -125,9 +127,13 @@ def _p(t):
 
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, relu, rowdiv, addend=None, tail=None):
+    def forward(ctx, x, weight, bias, relu, rowdiv, addend=None, tail=None, x_relu=False, premasked=False):
+        # x_relu: x is the output of a ReLU layer whose backward is told `premasked` -- this layer's input gradient comes out masked
+        # by x > 0 (the dgrad kernel's epilogue), and THAT layer's two backward products read no mask (include/sgrl_train.h
+        # sgrl_linear_backward_xrelu).  Valid when nothing else consumes the ReLU layer's output (the SET feed-forward pairs).
         L = _L()
         N, K = weight.shape
+        assert not premasked or relu
         x2 = x.reshape(-1, K)
         if x2.stride(1) != 1 or x2.stride(0) < K:
             x2 = x2.contiguous()
@@ -161,6 +167,7 @@ class _LinearFn(torch.autograd.Function):
         ctx.tail_shape = None if tail is None else tail.shape
         ctx.save_for_backward(x2, w, y if (relu or rd is not None) else None, rd)
         ctx.has_bias, ctx.relu = bias is not None, bool(relu)
+        ctx.x_relu, ctx.mask = bool(x_relu), bool(relu) and not premasked       # mask: dy still has to be masked by y > 0 here
         # leaf parameters (what deferred_wgrads may postpone): kept by reference so that their .grad can be set at the flush
         ctx.leaf = (weight, bias) if (weight.is_leaf and (bias is None or bias.is_leaf)) else None
         ctx.x_shape = x.shape
@@ -192,19 +199,19 @@ class _LinearFn(torch.autograd.Function):
         now_w, now_b = dw, db
         deferred = _pending is not None and need_w and ctx.leaf is not None
         if deferred:                              # postponed: computed and stored into .grad when the deferred_wgrads context exits
-            _pending.append({"dy": dy2, "y": yo if ctx.relu else None, "rowdiv": rd, "x": x2, "dw": dw, "db": db, "M": M, "N": N,
-                             "K": K, "relu": ctx.relu, "dev": dy.device, "stream": stream, "ldy": ldyo,
+            _pending.append({"dy": dy2, "y": yo if ctx.mask else None, "rowdiv": rd, "x": x2, "dw": dw, "db": db, "M": M, "N": N,
+                             "K": K, "relu": ctx.mask, "dev": dy.device, "stream": stream, "ldy": ldyo,
                              "w_param": ctx.leaf[0] if ctx.needs_input_grad[1] else None,
                              "b_param": ctx.leaf[1] if need_b else None})
             now_w = now_b = None
         if dx is not None or now_w is not None or now_b is not None or drd is not None:
-            _check(L, L.sgrl_linear_backward(_p(dy2), dy2.stride(0), _p(yo), ldyo, 1 if ctx.relu else 0, _p(rd), _p(x2), x2.stride(0),
-                                             _p(w), K, _p(dx), K, _p(now_w), K, _p(now_b), _p(drd), M, N, K, _p(_scratch(dy.device)), st),
-                   "sgrl_linear_backward")
+            _check(L, L.sgrl_linear_backward_xrelu(_p(dy2), dy2.stride(0), _p(yo), ldyo, 1 if ctx.mask else 0, _p(rd), _p(x2), x2.stride(0),
+                                                   _p(w), K, _p(dx), K, _p(now_w), K, _p(now_b), _p(drd), M, N, K, 1 if ctx.x_relu else 0,
+                                                   _p(_scratch(dy.device)), st), "sgrl_linear_backward_xrelu")
         dadd = dy.reshape(ctx.ad_shape) if (ctx.ad_shape is not None and ctx.needs_input_grad[5]) else None
         dtail = dyf[:, N:].reshape(ctx.tail_shape) if (nt and ctx.needs_input_grad[6]) else None
         return (dx.view(ctx.x_shape) if need_x else None), (None if deferred else (dw if ctx.needs_input_grad[1] else None)), \
-               (None if deferred else db), None, (drd.view(ctx.rd_shape) if need_rd else None), dadd, dtail
+               (None if deferred else db), None, (drd.view(ctx.rd_shape) if need_rd else None), dadd, dtail, None, None
 
 
 class _Linear2Fn(torch.autograd.Function):
@@ -212,10 +219,11 @@ class _Linear2Fn(torch.autograd.Function):
     x is either ONE input both share, [..., K], or their two inputs stacked, [2, ..., K]; the result is stacked, [2, ..., N]."""
 
     @staticmethod
-    def forward(ctx, x, w0, w1, b0, b1, relu, rowdiv, shared, addend=None, tail=None):
+    def forward(ctx, x, w0, w1, b0, b1, relu, rowdiv, shared, addend=None, tail=None, x_relu=False, premasked=False):
         L = _L()
         N, K = w0.shape
         assert w1.shape == w0.shape and (b0 is None) == (b1 is None)
+        assert (not premasked or relu) and not (x_relu and shared)        # x_relu / premasked: see _LinearFn
         lead = x.shape[:-1] if shared else x.shape[1:-1]
         xs = x.reshape(-1, K) if shared else x.reshape(2, -1, K)
         if xs.stride(-1) != 1 or xs.stride(-2) < K or (not shared and xs.stride(0) < 0):
@@ -259,6 +267,7 @@ class _Linear2Fn(torch.autograd.Function):
         ctx.tail_shape = None if tail is None else tail.shape
         ctx.save_for_backward(xs, w0, w1, y if (relu or rd is not None) else None, rd)
         ctx.has_bias, ctx.relu, ctx.shared = b0 is not None, bool(relu), bool(shared)
+        ctx.x_relu, ctx.mask = bool(x_relu), bool(relu) and not premasked
         ctx.leaf = [((w, b) if (w.is_leaf and (b is None or b.is_leaf)) else None) for w, b in params]
         ctx.params = params
         ctx.x_shape = x.shape
@@ -288,10 +297,13 @@ class _Linear2Fn(torch.autograd.Function):
         dx = torch.empty((2, M, K), dtype=torch.float32, device=dev) if need_x else None
         drd = torch.empty((2, M), dtype=torch.float32, device=dev) if need_rd else None
         if need_x:
-            _check(L, L.sgrl_linear_dgrad_twin(_p(dy2[0]), _p(dy2[1]), lddy, _p(None if yo is None else yo[0]), _p(None if yo is None else yo[1]),
-                                               ldyo, 1 if ctx.relu else 0, _p(None if rd is None else rd[0]), _p(None if rd is None else rd[1]),
-                                               _p(w0), _p(w1), K, _p(dx[0]), _p(dx[1]), K, _p(None if drd is None else drd[0]),
-                                               _p(None if drd is None else drd[1]), M, N, K, st), "sgrl_linear_dgrad_twin")
+            xm = (xs[0], xs[1]) if ctx.x_relu else (None, None)
+            _check(L, L.sgrl_linear_dgrad_twin_xrelu(_p(dy2[0]), _p(dy2[1]), lddy, _p(None if yo is None else yo[0]),
+                                                     _p(None if yo is None else yo[1]), ldyo, 1 if ctx.mask else 0,
+                                                     _p(None if rd is None else rd[0]), _p(None if rd is None else rd[1]),
+                                                     _p(w0), _p(w1), K, _p(dx[0]), _p(dx[1]), K, _p(None if drd is None else drd[0]),
+                                                     _p(None if drd is None else drd[1]), _p(xm[0]), _p(xm[1]), xs.stride(-2), M, N, K, st),
+                   "sgrl_linear_dgrad_twin_xrelu")
         elif need_rd:                               # the row divisor's gradient without an input gradient: the single-network kernel twice
             for i in range(2):
                 _check(L, L.sgrl_linear_backward(_p(dy2[i]), lddy, _p(yo[i]), ldyo, 0, _p(rd[i]), _p(None), 0, _p(None), 0, _p(None), 0,
@@ -305,8 +317,8 @@ class _Linear2Fn(torch.autograd.Function):
             dw = torch.empty((N, K), dtype=torch.float32, device=dev)
             db = torch.empty((N,), dtype=torch.float32, device=dev) if need_b[i] else None
             deferred = _pending is not None and ctx.leaf[i] is not None
-            rec = {"dy": dy2[i], "y": yo[i] if ctx.relu else None, "rowdiv": None if rd is None else rd[i], "x": x_i, "dw": dw, "db": db,
-                   "M": M, "N": N, "K": K, "relu": ctx.relu, "dev": dev, "stream": stream, "ldy": ldyo,
+            rec = {"dy": dy2[i], "y": yo[i] if ctx.mask else None, "rowdiv": None if rd is None else rd[i], "x": x_i, "dw": dw, "db": db,
+                   "M": M, "N": N, "K": K, "relu": ctx.mask, "dev": dev, "stream": stream, "ldy": ldyo,
                    "w_param": (w if need_w[i] else None) if deferred else None, "b_param": (b if need_b[i] else None) if deferred else None}
             if deferred:
                 _pending.append(rec)
@@ -322,7 +334,8 @@ class _Linear2Fn(torch.autograd.Function):
         dtail = None
         if nt and ctx.needs_input_grad[9]:
             dtail = dyf[:, :, N:].reshape(2, *ctx.x_shape[(0 if ctx.shared else 1):-1], nt).sum_to_size(ctx.tail_shape)
-        return dx_out, grads_w[0], grads_w[1], grads_b[0], grads_b[1], None, (drd.view(ctx.rd_shape) if need_rd else None), None, dadd, dtail
+        return dx_out, grads_w[0], grads_w[1], grads_b[0], grads_b[1], None, (drd.view(ctx.rd_shape) if need_rd else None), None, dadd, dtail, \
+            None, None
 
 
 class _GramFn(torch.autograd.Function):
@@ -508,15 +521,17 @@ def _on_device_with_grad(*ts):
         any(t is not None and t.requires_grad for t in ts)
 
 
-def linear(x, weight, bias=None, relu=False, rowdiv=None, addend=None, tail=None):
+def linear(x, weight, bias=None, relu=False, rowdiv=None, addend=None, tail=None, x_relu=False, premasked=False):
     """act(x @ weight.T + bias) / rowdiv, differentiable in x, weight, bias and rowdiv (act = ReLU if relu; rowdiv: one value
     per row, broadcast over the output features -- the `/ F_norm` of the reference's SET layers).  Two followers can ride on
     the product's launch: `addend` (same shape as the result) is added to it -- a residual --, `tail` [..., t] is appended to it
-    along the last dimension (torch.cat([result, tail], -1))."""
+    along the last dimension (torch.cat([result, tail], -1)).  x_relu / premasked: a ReLU layer feeding ONLY this one -- the pair
+    linear(linear(x, w1, relu=True, premasked=True), w2, x_relu=True) applies the ReLU's mask once, in the epilogue of the second
+    layer's input gradient (_LinearFn); they change nothing in the forward and nothing outside the HIP path."""
     if _on_device_with_grad(x, weight, bias, rowdiv, addend, tail):
         if addend is None or (not relu and rowdiv is None and tail is None):
-            return _LinearFn.apply(x, weight, bias, bool(relu), rowdiv, addend, tail)
-        y = _LinearFn.apply(x, weight, bias, bool(relu), rowdiv, None, None)     # a follower the kernel does not take: own launches
+            return _LinearFn.apply(x, weight, bias, bool(relu), rowdiv, addend, tail, bool(x_relu), bool(premasked))
+        y = _LinearFn.apply(x, weight, bias, bool(relu), rowdiv, None, None, bool(x_relu), bool(premasked))     # a follower the kernel does not take: own launches
     else:
         y = F.linear(x, weight, bias)
         y = F.relu(y) if relu else y
@@ -558,14 +573,14 @@ def stacked3(a, b, c):
     return torch.cat([a, b, c], dim=0)
 
 
-def linear2(x, w0, w1, b0=None, b1=None, relu=False, rowdiv=None, shared=False, addend=None, tail=None):
+def linear2(x, w0, w1, b0=None, b1=None, relu=False, rowdiv=None, shared=False, addend=None, tail=None, x_relu=False, premasked=False):
     """`linear` for the same layer of two networks at once: returns [2, ..., N]; x = the input both share ([..., K], shared=True) or
     their inputs stacked ([2, ..., K]); rowdiv stacked [2, ..., 1]; addend stacked [2, ..., N]; tail [2, ..., t] (or one both share,
     [..., t] / expanded)."""
     if _on_device_with_grad(x, w0, w1, b0, b1, rowdiv, addend, tail) and (addend is None or (not relu and rowdiv is None and tail is None)):
         if tail is not None and tail.dim() == x.dim() + (1 if shared else 0) and tail.stride(0) == 0:
             tail = tail[0]                          # an expanded pair: the one tensor both networks share
-        return _Linear2Fn.apply(x, w0, w1, b0, b1, bool(relu), rowdiv, bool(shared), addend, tail)
+        return _Linear2Fn.apply(x, w0, w1, b0, b1, bool(relu), rowdiv, bool(shared), addend, tail, bool(x_relu), bool(premasked))
     xs = (x, x) if shared else (x[0], x[1])
     ts = (None, None) if tail is None else ((tail[0], tail[1]) if tail.dim() == xs[0].dim() + 1 else (tail, tail))
     return torch.stack([linear(xs[0], w0, b0, relu, None if rowdiv is None else rowdiv[0], None if addend is None else addend[0], ts[0]),

@@ -515,3 +515,81 @@ def test_table_optimizer_steps_match_torch(max_norm):
     td3.soft_update_network(_N(src), _N(dst), 0.005)
     for b, w in zip(dst, want):
         assert float((b.detach().double() - w).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("M,K,H,N,rowdiv,tail,deferred", [(1792, 256, 1024, 256, True, False, False), (700, 1024, 256, 128, False, True, True),
+                                                          (1792, 256, 256, 1024, True, False, True), (65, 145, 128, 20, False, False, False)])
+def test_feed_forward_pair_with_the_mask_in_the_second_layers_epilogue(M, K, H, N, rowdiv, tail, deferred):
+    """lin2(relu(lin1(x))) with the ReLU mask applied ONCE, in the epilogue of lin2's input gradient (x_relu / premasked:
+    include/sgrl_train.h sgrl_linear_backward_xrelu) against float64, and against the same pair with the mask read by lin1's two
+    backward products (the form of rounds 2-4)."""
+    from sgrl_amd import train_ops
+    g = torch.Generator().manual_seed(M + K + H + N)
+    x = torch.randn(M, K, generator=g)
+    w1, b1 = torch.randn(H, K, generator=g) / np.sqrt(K), torch.randn(H, generator=g)
+    w2, b2 = torch.randn(N, H, generator=g) / np.sqrt(H), torch.randn(N, generator=g)
+    rd = (torch.rand(M, 1, generator=g) + 0.5) if rowdiv else None
+    tl = torch.randn(M, 5, generator=g) if tail else None
+    dy = torch.randn(M, N + (5 if tail else 0), generator=g)
+    ref = [t.double().requires_grad_() for t in (x, w1, b1, w2, b2)]
+    rdr = rd.double().requires_grad_() if rowdiv else None
+    yr = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(ref[0], ref[1], ref[2])), ref[3], ref[4])
+    yr = yr / rdr if rowdiv else yr
+    yr = torch.cat([yr, tl.double()], -1) if tail else yr
+    yr.backward(dy.double())
+
+    def run(fused):
+        leaves = [torch.nn.Parameter(t.cuda()) for t in (x, w1, b1, w2, b2)]
+        rdd = rd.cuda().requires_grad_() if rowdiv else None
+        tld = tl.cuda() if tail else None
+        with train_ops.deferred_wgrads(deferred):
+            h = train_ops.linear(leaves[0], leaves[1], leaves[2], relu=True, premasked=fused)
+            y = train_ops.linear(h, leaves[3], leaves[4], rowdiv=rdd, tail=tld, x_relu=fused)
+            y.backward(dy.cuda())
+        return y, leaves, rdd
+
+    y, lv, rdd = run(True)
+    y0, lv0, rdd0 = run(False)
+    assert torch.equal(y, y0)
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) < 3e-6 * (float(yr.abs().max()) + 1.0)
+    for a, a0, r in zip(lv, lv0, ref):
+        tol = 3e-6 * (float(r.grad.abs().max()) + 1.0) * np.sqrt(M / 64 + 1)
+        assert float((a.grad.cpu().double() - r.grad).abs().max()) < tol
+        assert float((a.grad - a0.grad).abs().max()) < tol
+    if rowdiv:
+        assert float((rdd.grad.cpu().double() - rdr.grad).abs().max()) < 3e-6 * (float(rdr.grad.abs().max()) + 1.0) * np.sqrt(N / 64 + 1)
+
+
+def test_twin_feed_forward_pair_with_the_mask_in_the_second_layers_epilogue():
+    """The same for the two critics' layers in one launch (linear2: k_sgemm_twin): both forms against each other and float64."""
+    from sgrl_amd import train_ops
+    M, K, H, N = 1792, 256, 1024, 256
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, M, K, generator=g)
+    ws = [torch.randn(H, K, generator=g) / np.sqrt(K) for _ in range(2)] + [torch.randn(N, H, generator=g) / np.sqrt(H) for _ in range(2)]
+    bs = [torch.randn(H, generator=g) for _ in range(2)] + [torch.randn(N, generator=g) for _ in range(2)]
+    rd = torch.rand(2, M, 1, generator=g) + 0.5
+    dy = torch.randn(2, M, N, generator=g)
+    xr = x.double().requires_grad_()
+    wr, br = [w.double().requires_grad_() for w in ws], [b.double().requires_grad_() for b in bs]
+    yr = torch.stack([torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(xr[i], wr[i], br[i])), wr[2 + i], br[2 + i]) / rd[i].double()
+                      for i in range(2)])
+    yr.backward(dy.double())
+
+    def run(fused):
+        xd = x.cuda().requires_grad_()
+        wd, bd = [torch.nn.Parameter(w.cuda()) for w in ws], [torch.nn.Parameter(b.cuda()) for b in bs]
+        with train_ops.deferred_wgrads(True):
+            h = train_ops.linear2(xd, wd[0], wd[1], bd[0], bd[1], relu=True, premasked=fused)
+            y = train_ops.linear2(h, wd[2], wd[3], bd[2], bd[3], rowdiv=rd.cuda(), x_relu=fused)
+            assert type(y.grad_fn).__name__.startswith("_Linear2Fn")
+            y.backward(dy.cuda())
+        return y, [xd] + wd + bd
+
+    y, lv = run(True)
+    y0, lv0 = run(False)
+    assert torch.equal(y, y0)
+    for a, a0, r in zip(lv, lv0, [xr] + wr + br):
+        tol = 3e-6 * (float(r.grad.abs().max()) + 1.0) * np.sqrt(M / 64 + 1)
+        assert float((a.grad.cpu().double() - r.grad).abs().max()) < tol
+        assert float((a.grad - a0.grad).abs().max()) < tol

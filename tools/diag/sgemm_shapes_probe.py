@@ -13,6 +13,7 @@ ws = T._scratch(dev)
 st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 P = T._p
 REPS = int(os.environ.get("REPS", "200"))
+RELU = int(os.environ.get("DGRAD_RELU", "1"))      # 0: the input gradients without the ReLU mask of the forward output
 
 def timed(fn):
     for _ in range(10): fn()
@@ -35,21 +36,21 @@ for (M, N, K) in SHAPES:
     x1 = torch.randn(M, K, device=dev); w1 = torch.randn(N, K, device=dev) / K ** 0.5; y1 = torch.empty(M, N, device=dev)
     g1 = torch.randn(M, N, device=dev); dx1 = torch.empty(M, K, device=dev)
     def fwd(): T._check(L, L.sgrl_linear_forward(P(x), K, P(w), K, P(b), None, P(y), N, M, N, K, 1, st), "fwd")
-    def dgrad(): T._check(L, L.sgrl_linear_backward(P(g), N, P(y), N, 1, None, None, 0, P(w), K, P(dx), K, None, 0, None, None, M, N, K, P(ws), st), "dgrad")
+    def dgrad(): T._check(L, L.sgrl_linear_backward(P(g), N, P(y), N, RELU, None, None, 0, P(w), K, P(dx), K, None, 0, None, None, M, N, K, P(ws), st), "dgrad")
     def fwd2(): T._check(L, L.sgrl_linear_forward_twin(P(x), P(x1), K, P(w), P(w1), K, P(b), P(b), None, None, P(y), P(y1), N, M, N, K, 1, st), "fwd2")
-    def dgrad2(): T._check(L, L.sgrl_linear_dgrad_twin(P(g), P(g1), N, P(y), P(y1), N, 1, None, None, P(w), P(w1), K, P(dx), P(dx1), K, None, None, M, N, K, st), "dgrad2")
+    def dgrad2(): T._check(L, L.sgrl_linear_dgrad_twin(P(g), P(g1), N, P(y), P(y1), N, RELU, None, None, P(w), P(w1), K, P(dx), P(dx1), K, None, None, M, N, K, st), "dgrad2")
     r = {}
     r["fwd_us"] = round(timed(fwd), 2)
     ref = torch.relu(x.double() @ w.double().t() + b.double())
     r["fwd_err"] = "%.1e" % float((y.double() - ref).abs().max())
     r["dgrad_us"] = round(timed(dgrad), 2)
-    refd = (g.double() * (y > 0)) @ w.double()
+    refd = (g.double() * (y > 0) if RELU else g.double()) @ w.double()
     r["dgrad_err"] = "%.1e" % float((dx.double() - refd).abs().max())
     r["fwd_twin_us"] = round(timed(fwd2), 2)
     ref1 = torch.relu(x1.double() @ w1.double().t() + b.double())
     r["fwd_twin_err"] = "%.1e" % float((y1.double() - ref1).abs().max())
     r["dgrad_twin_us"] = round(timed(dgrad2), 2)
-    refd1 = (g1.double() * (y1 > 0)) @ w1.double()
+    refd1 = (g1.double() * (y1 > 0) if RELU else g1.double()) @ w1.double()
     r["dgrad_twin_err"] = "%.1e" % float((dx1.double() - refd1).abs().max())
     # one grouped weight-gradient launch of 12 such layers
     recs = []
