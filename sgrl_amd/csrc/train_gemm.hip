@@ -55,7 +55,7 @@ struct SArgs {
   const float* Amask; int ldmask;   // null, or: a(m, k) counts only where Amask (same layout as A) is > 0
   const float* B; int ldb;
   const float* bias; int relu;
-  const float* rowdiv;              // forward: C[m][:] /= rowdiv[m]; backward: the A operand's row of index m is divided by rowdiv[m]
+  const float* rowdiv;              // forward and input gradient: C[m][:] /= rowdiv[m]; weight gradient: the A operand's row k is divided by rowdiv[k]
   float* C; int ldc;
   float* db;                        // wgrad only: column sums of the (masked) A operand = rows of C
   int M, N, K;
@@ -137,7 +137,7 @@ __device__ __forceinline__ void sgemm_tile(const SArgs& a, float (*As)[LDP], flo
         if (k < k_end) {
           v = load4(a.A + (size_t)k * a.lda, c, a.M, a_vec);
           if (a.Amask) v = relu_mask(v, load4(a.Amask + (size_t)k * a.ldmask, c, a.M, a_vec));
-          if (a.rowdiv) { const float f = a.rowdiv[k]; v.x /= f; v.y /= f; v.z /= f; v.w /= f; }   // wgrad: g = dy / fn, row k
+          if (a.rowdiv) { const float f = 1.f / a.rowdiv[k]; v.x *= f; v.y *= f; v.z *= f; v.w *= f; }   // wgrad: g = dy / fn, row k (one reciprocal per load)
         }
         ra[slot][i] = v;
         if (want_db) { dbp.x += v.x; dbp.y += v.y; dbp.z += v.z; dbp.w += v.w; }
@@ -147,7 +147,6 @@ __device__ __forceinline__ void sgemm_tile(const SArgs& a, float (*As)[LDP], flo
         if (m < a.M) {
           v = load4(a.A + (size_t)m * a.lda, c, k_end, a_vec);
           if (a.Amask) v = relu_mask(v, load4(a.Amask + (size_t)m * a.ldmask, c, k_end, a_vec));
-          if (a.rowdiv && BTR) { const float f = a.rowdiv[m]; v.x /= f; v.y /= f; v.z /= f; v.w /= f; }   // dgrad: g = dy / fn, row m
         }
         ra[slot][i] = v;
       }
@@ -283,7 +282,7 @@ __device__ __forceinline__ void sgemm_tile(const SArgs& a, float (*As)[LDP], flo
     }
     float o = v[j] + (a.bias ? a.bias[n] : 0.f);
     if (a.relu) o = fmaxf(o, 0.f);
-    if (!AT && !BTR && a.rowdiv) o = o / a.rowdiv[m];
+    if (!AT && a.rowdiv) o = o / a.rowdiv[m];          // forward: y / fn; input gradient: (dy / fn) . w = (dy . w) / fn, row by row
     if (!AT && !BTR && a.addend) o += a.addend[(size_t)m * a.ldadd + n];
     if (!AT && BTR && a.omask && !(a.omask[(size_t)m * a.ldomask + n] > 0.f)) o = 0.f;
     a.C[(size_t)m * a.ldc + n] = o;
