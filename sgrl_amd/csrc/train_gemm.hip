@@ -808,7 +808,7 @@ bool row_major_staging() {
   return on;
 }
 template <bool AT>
-int plan(SArgs& a, float* ws, int* tn, int* tm, int* splits_out, int64_t ws_slot0 = 0, int counter0 = 0) {
+int plan(SArgs& a, float* ws, int* tn, int* tm, int* splits_out, int64_t ws_slot0 = 0, int counter0 = 0, int force_splits = 0) {
   constexpr int BK = AT ? BKW : BKF;
   *tm = (a.M + BT - 1) / BT; *tn = (a.N + (!AT && a.tail ? a.ntail : 0) + BT - 1) / BT;   // + the column tiles of an appended block
   const int ntiles = *tm * *tn;
@@ -817,6 +817,8 @@ int plan(SArgs& a, float* ws, int* tn, int* tm, int* splits_out, int64_t ws_slot
   int splits = 1;
   if (AT && ws && ktiles >= 4 && (ntiles <= 8 || (ktiles >= 12 && ntiles <= 128)) && counter0 + ntiles <= kCounters)
     splits = std::max(1, std::min({(256 + ntiles - 1) / ntiles, ktiles / 2, (int)((kWsTiles - ws_slot0) / ntiles)}));
+  if (AT && ws && force_splits > 1 && counter0 + ntiles <= kCounters)       // the grouped launch evens out its contractions (below)
+    splits = std::max(1, std::min({force_splits, ktiles / 2, (int)((kWsTiles - ws_slot0) / ntiles)}));
   a.kper = ((ktiles + splits - 1) / splits) * BK;
   *splits_out = (a.K + a.kper - 1) / a.kper;                  // no empty splits
   a.ws = ws ? ws + ws_slot0 * TILE_WS : nullptr;      // this product's own (split, tile) slots and counters
@@ -1032,6 +1034,12 @@ int sgrl_linear_wgrad_group(int n, const sgrl_wgrad_desc* d, float* ws, void* st
     int unsplit_tiles = 0;
     for (int g = 0; g < p.n; g++) unsplit_tiles += ((d[i0 + g].N + BT - 1) / BT) * ((d[i0 + g].K + BT - 1) / BT);
     float* const ws_eff = unsplit_tiles >= kGroupNoSplitTiles ? nullptr : ws;
+    // ... but such a launch lasts as long as its LONGEST contraction: at the update batch of 256 the three-vector channels contract
+    // over 5 376 rows (42 k-tiles) beside 1 792-row products (14).  A product at least twice as long as the group's shortest is cut
+    // into that many splits, so that every workgroup of the launch walks about the same number of k-tiles (these products have few
+    // output tiles: a few dozen fencing workgroups, not hundreds).
+    int kt_min = 1 << 30;
+    for (int g = 0; g < p.n; g++) kt_min = std::min(kt_min, (d[i0 + g].M + BKW - 1) / BKW);
     for (int g = 0; g < p.n; g++) {
       const sgrl_wgrad_desc& q = d[i0 + g];
       if (!q.dy || !q.x || !q.dw || q.M <= 0 || q.N <= 0 || q.K <= 0 || q.lddy < q.N || q.ldx < q.K || q.lddw < q.K ||
@@ -1039,7 +1047,9 @@ int sgrl_linear_wgrad_group(int n, const sgrl_wgrad_desc* d, float* ws, void* st
         return tfail(SGRL_ERR_ARG, "sgrl_linear_wgrad_group: bad descriptor " + std::to_string(i0 + g));
       SArgs a{q.dy, q.lddy, q.relu ? q.y : nullptr, q.ldy, q.x, q.ldx, nullptr, 0, q.rowdiv, q.dw, q.lddw, q.db, q.N, q.K, q.M,
               0, nullptr, nullptr};
-      const int rc = plan<true>(a, ws_eff, &p.gx[g], &p.gy[g], &p.nz[g], slot, counter);
+      const int kt = (q.M + BKW - 1) / BKW;
+      const int even = (!ws_eff && ws && kt_min >= 4 && kt >= 2 * kt_min) ? kt / kt_min : 0;
+      const int rc = plan<true>(a, even ? ws : ws_eff, &p.gx[g], &p.gy[g], &p.nz[g], slot, counter, even);
       if (rc != SGRL_OK) return rc;
       if (p.nz[g] > 1) { slot += (int64_t)p.gx[g] * p.gy[g] * p.nz[g]; counter += p.gx[g] * p.gy[g]; }
       p.w[g] = a;
