@@ -126,12 +126,40 @@ __device__ __forceinline__ void sgemm_tile(const SArgs& a, float (*As)[LDP], flo
   float4 dbp = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 ra[2][NLD], rb[2][NLD];               // global loads run TWO k-tiles ahead of the arithmetic
 
+  // INTERIOR tiles of the forward / input-gradient products (the tile's 32 rows / columns inside the operand, the k-tile inside the
+  // contraction, 16-byte aligned rows, no mask) load through one base pointer per thread and operand, set up once: the general path
+  // below spends ~25 vector instructions per 16-byte load on 64-bit addresses, bounds and zero fills, and the counters showed the
+  // vector ALU busier than the matrix pipe (profiles/r5_sgemm_pmc.txt).  Element (k-tile at k0, load i) of thread t lies at
+  // base + k0 * kmul + i * imul.  Not in the weight-gradient instance: the second path costs it 16 registers and its third wave
+  // per SIMD (55 -> 82 us per grouped launch), and an instance with ONLY this path gains 10 % in isolation but nothing in the update
+  // (its groups of twelve are rarely all regular; grouping them by kind adds launches: 8.03 -> 8.25 ms).
+  const bool a_in = !AT && a_vec && !a.Amask && m0 + BT <= a.M;
+  const bool b_in = !AT && b_vec && n0 + BT <= a.N;
+  const size_t b_kmul = BTR ? (size_t)a.ldb : 1;
+  const size_t a_imul = RM ? (size_t)(256 / Q) * a.lda : 32;
+  const size_t b_imul = BTR ? (size_t)32 * a.ldb : (RM ? (size_t)(256 / Q) * a.ldb : 32);
+  const float* const a_base = RM ? a.A + (size_t)(m0 + t / Q) * a.lda + 4 * (t % Q) : a.A + (size_t)(m0 + (t & 31)) * a.lda + 4 * (t >> 5);
+  const float* const b_base = BTR ? a.B + (size_t)(t >> 3) * a.ldb + n0 + 4 * (t & 7)
+                                  : (RM ? a.B + (size_t)(n0 + t / Q) * a.ldb + 4 * (t % Q) : a.B + (size_t)(n0 + (t & 31)) * a.ldb + 4 * (t >> 5));
+
   auto load_tiles = [&](auto slot_c, int k0) __attribute__((always_inline)) {     // slot as a compile-time constant: the staging arrays stay in registers
     constexpr int slot = decltype(slot_c)::value;
+    const bool k_in = k0 + BK <= k_end;
+    if (a_in && k_in) {
+      const float* pa = a_base + k0;
+#pragma unroll
+      for (int i = 0; i < NLD; i++) ra[slot][i] = *reinterpret_cast<const float4*>(pa + i * a_imul);
+    }
+    if (b_in && k_in) {
+      const float* pb = b_base + (size_t)k0 * b_kmul;
+#pragma unroll
+      for (int i = 0; i < NLD; i++) rb[slot][i] = *reinterpret_cast<const float4*>(pb + i * b_imul);
+    }
 #pragma unroll
     for (int i = 0; i < NLD; i++) {
       const int idx = t + 256 * i;
-      if (AT) {                             // A[k][m]: k = idx / 8, columns m0 + 4 (idx % 8)
+      if (a_in && k_in) {
+      } else if (AT) {                             // A[k][m]: k = idx / 8, columns m0 + 4 (idx % 8)
         const int k = k0 + (idx >> 3), c = m0 + 4 * (idx & 7);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < k_end) {
@@ -150,7 +178,8 @@ __device__ __forceinline__ void sgemm_tile(const SArgs& a, float (*As)[LDP], flo
         }
         ra[slot][i] = v;
       }
-      if (BTR) {
+      if (b_in && k_in) {
+      } else if (BTR) {
         const int k = k0 + (idx >> 3), c = n0 + 4 * (idx & 7);
         rb[slot][i] = k < k_end ? load4(a.B + (size_t)k * a.ldb, c, a.N, b_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
