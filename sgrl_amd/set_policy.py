@@ -401,6 +401,9 @@ def make_policy(device=None, use_hip=True, max_action=1.0):
     return SEPolicy(41, 3, 32, 1, max_action, 3, True, False, False, default_args(), device=device, use_hip=use_hip)
 
 
+TWIN_TARGETS = os.environ.get("SGRL_TWIN_TARGETS", "1") != "0"     # the no-grad target critics through twin_forward (0: two passes of set_actor.hip)
+
+
 class SECritic(nn.Module):
     """Twin SET critics behind the reference's module surface (reference src/SECritic.py:8-124): same constructor
     signature, `critic1` / `critic2` state_dict prefixes, `forward(state, action) -> (q1, q2)` with per-limb Q values
@@ -450,6 +453,13 @@ class SECritic(nn.Module):
 
     def forward(self, state, action):
         if self._hip_path(state):           # target values under no_grad (reference agent.py:136-148): HIP kernels
+            if TWIN_TARGETS and TWIN_CRITICS and train_ops.ENABLED and state.dtype == torch.float32:
+                # both target networks in ONE pass of the training kernels (every linear layer one launch for the pair) instead of
+                # two passes of the rollout kernels' small-batch products one after the other
+                x = self._input(state, action)
+                with train_ops.no_grad_kernels():
+                    q1, q2 = twin_forward(self.critic1, self.critic2, x, self.graph, False).unbind(0)
+                return q1.reshape(x.shape[0], -1), q2.reshape(x.shape[0], -1)
             return self._hip_handles().forward_single(state, action, self.graph)
         x = self._input(state, action)
         B, gg = x.shape[0], state.requires_grad

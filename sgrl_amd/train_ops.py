@@ -516,9 +516,27 @@ class _Embed3Fn(torch.autograd.Function):
         return None, dws[0], dws[1], dws[2]
 
 
+_NO_GRAD_KERNELS = False      # no_grad_kernels(): the own kernels also where nothing is differentiated
+
+
+@contextlib.contextmanager
+def no_grad_kernels(enabled=True):
+    """Inside this context (meant for torch.no_grad() passes) the operations of this module launch their own kernels although nothing
+    requires a gradient -- the twin target critics of a TD3 update walk both networks in one pass that way (set_policy.SECritic)."""
+    global _NO_GRAD_KERNELS
+    old, _NO_GRAD_KERNELS = _NO_GRAD_KERNELS, bool(enabled) or _NO_GRAD_KERNELS
+    try:
+        yield
+    finally:
+        _NO_GRAD_KERNELS = old
+
+
 def _on_device_with_grad(*ts):
-    return ENABLED and ts[0].is_cuda and ts[0].dtype == torch.float32 and torch.is_grad_enabled() and \
-        any(t is not None and t.requires_grad for t in ts)
+    if not (ENABLED and ts[0].is_cuda and ts[0].dtype == torch.float32):
+        return False
+    if _NO_GRAD_KERNELS and not torch.is_grad_enabled():
+        return True
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
 
 
 def linear(x, weight, bias=None, relu=False, rowdiv=None, addend=None, tail=None, x_relu=False, premasked=False):

@@ -155,18 +155,26 @@ def test_critic_hip_path_matches_reference_fixtures_and_torch_path():
     import torch
     from oracle.formula import apply_formula_
     from sgrl_amd import graph as G, mjcf
+    from sgrl_amd import set_policy
     from sgrl_amd.set_policy import make_critic
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "critic_forward.npz"))
     crit = make_critic(device="cuda:0").eval()
     apply_formula_(crit)
+    assert set_policy.TWIN_TARGETS
     for name in sorted({k.split("/")[0] for k in z.files}):
         m = mjcf.load_asset(name)
         crit.change_morphology(G.getGraphDict(m.parents, ["pre", "inlcrs", "postlcrs"], [], device=torch.device("cuda:0")))
         obs, act = torch.from_numpy(z[name + "/obs"]).cuda(), torch.from_numpy(z[name + "/act"]).cuda()
         with torch.no_grad():
-            q1, q2 = crit(obs, act)                       # HIP path
-            q1b = crit.Q1(obs, act)
+            q1, q2 = crit(obs, act)                       # HIP path: both networks in one pass of the training kernels (TWIN_TARGETS)
+            q1b = crit.Q1(obs, act)                       # HIP path: the rollout kernels (sgrl_set_forward_q)
+            set_policy.TWIN_TARGETS = False
+            try:
+                r1, r2 = crit(obs, act)                   # both networks on the rollout kernels, one after the other
+            finally:
+                set_policy.TWIN_TARGETS = True
         assert crit._hip is not None and q1.shape == (4, m.num_limbs)
+        assert float((q1 - r1).abs().max()) < 2e-5 * np.abs(z[name + "/q1"]).max() and float((q2 - r2).abs().max()) < 2e-5 * np.abs(z[name + "/q2"]).max()
         crit.use_hip = False
         with torch.no_grad():
             t1, t2 = crit(obs, act)                       # PyTorch path, same weights
