@@ -95,6 +95,16 @@ int sgrl_linear_dgrad_twin_xrelu(const float* dy0, const float* dy1, int lddy, c
  * fn[M] = ||Z'Z||_F + 1; and their backward: dz = Z (D + D'), D = dgram + (dfn / ||Z'Z||_F) Z'Z (dgram or dfn may be null). */
 int sgrl_gram_forward(const float* z, float* gram, float* fn, int M, void* stream);
 int sgrl_gram_backward(const float* z, const float* dgram, const float* dfn, const float* fn, float* dz, int M, void* stream);
+/* The same invariants on the lower triangle of the symmetric Z'Z only: tri[M, 528], tri[m][a (a + 1) / 2 + b] = (Z'Z)[a][b], a >= b
+ * (fn as above, the norm of the FULL matrix).  A linear layer W on vec(Z'Z) equals W' on tri(Z'Z) with the mirror columns of W added
+ * (sgrl_sym_fold), so its three products run over 528 columns instead of 1 024; dz = Z S with S[a][b] = S[b][a] = dtri[k] +
+ * 2 (dfn / ||Z'Z||_F) (Z'Z)[a][b], the diagonal with 2 dtri[k].
+ * sgrl_sym_fold: n <= 16 matrices per launch.  unfold == 0: wtri[i][rows[i], 528] = fold of w[i][rows[i], 1024] (W'[r][k] = W[r][a 32 + b] +
+ * W[r][b 32 + a], the diagonal once); unfold != 0: w[i][r][a 32 + b] = w[i][r][b 32 + a] = wtri[i][r][k] -- the gradient of the fold
+ * (w is then written, wtri read). */
+int sgrl_gram_tri_forward(const float* z, float* tri, float* fn, int M, void* stream);
+int sgrl_gram_tri_backward(const float* z, const float* dtri, const float* dfn, const float* fn, float* dz, int M, void* stream);
+int sgrl_sym_fold(int n, const float* const* w, float* const* wtri, const int* rows, int unfold, void* stream);
 
 /* Equivariant contraction of M nodes' three 32-vectors with their 32 x 32 matrices (reference SEActor.py:108-110, 262-264):
  * t[M, 3, 32] = z[M, 3, 32] . mat[M, 32, 32] per node; backward: dz = dt . mat', dmat = z' . dt. */

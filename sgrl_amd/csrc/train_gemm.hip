@@ -452,6 +452,91 @@ __global__ __launch_bounds__(256) void k_gram_bwd(const float* __restrict__ z, c
   }
 }
 
+// The same invariants on the LOWER TRIANGLE of the symmetric Z'Z only, packed k = a (a + 1) / 2 + b (a >= b): 528 values instead of
+// 1 024.  A linear layer on vec(Z'Z) sees every off-diagonal entry twice, so  W vec(G) = W' tri(G)  with W'[n][k] = W[n][a 32 + b] +
+// W[n][b 32 + a] (a > b), W[n][a 33] (a = b): the layer's three products (forward, input gradient, weight gradient) contract over /
+// produce 528 columns instead of 1 024 (what the rollout's weight pack does for its blocked 576: csrc/set_actor.hip k_pack FOLD).
+constexpr int TRI = 528;
+__device__ __forceinline__ void tri_ab(int k, int* a, int* b) {
+  int r = (int)((sqrtf(8.f * k + 1.f) - 1.f) * 0.5f);
+  while ((r + 1) * (r + 2) / 2 <= k) r++;
+  while (r * (r + 1) / 2 > k) r--;
+  *a = r; *b = k - r * (r + 1) / 2;
+}
+__global__ __launch_bounds__(256) void k_gram_tri_fwd(const float* __restrict__ z, float* gram, float* fn, int M) {
+  __shared__ float zs[96];
+  __shared__ float red[4];
+  const int m = blockIdx.x, t = threadIdx.x;
+  if (t < 96) zs[t] = z[(size_t)m * 96 + t];
+  __syncthreads();
+  float sq = 0.f;
+  for (int k = t; k < TRI; k += 256) {
+    int a, c;
+    tri_ab(k, &a, &c);
+    const float g = zs[a] * zs[c] + zs[32 + a] * zs[32 + c] + zs[64 + a] * zs[64 + c];
+    gram[(size_t)m * TRI + k] = g;
+    sq += (a == c ? 1.f : 2.f) * g * g;
+  }
+  for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+  if ((t & 63) == 0) red[t >> 6] = sq;
+  __syncthreads();
+  if (t == 0) fn[m] = sqrtf((red[0] + red[1]) + (red[2] + red[3])) + 1.0f;
+}
+// dz = Z S,  S symmetric: S[a][b] = S[b][a] = dtri[k(a, b)] + 2 c G[a][b] (a > b), S[a][a] = 2 dtri[k(a, a)] + 2 c G[a][a],  c = dfn / ||G||
+__global__ __launch_bounds__(256) void k_gram_tri_bwd(const float* __restrict__ z, const float* __restrict__ dtri,
+                                                      const float* __restrict__ dfn, const float* __restrict__ fn, float* dz, int M) {
+  __shared__ float zs[96];
+  __shared__ float S[32][33];
+  const int m = blockIdx.x, t = threadIdx.x;
+  if (t < 96) zs[t] = z[(size_t)m * 96 + t];
+  __syncthreads();
+  const float nrm = fn[m] - 1.0f;
+  const float coef = (dfn && nrm > 0.f) ? dfn[m] / nrm : 0.f;
+  for (int k = t; k < TRI; k += 256) {
+    int a, c;
+    tri_ab(k, &a, &c);
+    const float g = zs[a] * zs[c] + zs[32 + a] * zs[32 + c] + zs[64 + a] * zs[64 + c];
+    const float d = dtri ? dtri[(size_t)m * TRI + k] : 0.f;
+    const float v = (a == c ? 2.f * d : d) + 2.f * coef * g;
+    S[a][c] = v;
+    S[c][a] = v;
+  }
+  __syncthreads();
+  if (t < 96) {
+    const int sx = t >> 5, a = t & 31;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; c++) acc += S[a][c] * zs[32 * sx + c];
+    dz[(size_t)m * 96 + t] = acc;
+  }
+}
+// W [rows][1024] -> W' [rows][528] (fold) and dW' [rows][528] -> dW [rows][1024] (unfold: both mirror entries get dW'[k]) for up to
+// kFoldMax matrices per launch (blockIdx.y picks one): all the invariant layers of a network at once
+constexpr int kFoldMax = 16;
+struct FoldArgs { const float* src[kFoldMax]; float* dst[kFoldMax]; int rows[kFoldMax]; };
+__global__ __launch_bounds__(256) void k_fold_sym(FoldArgs p) {
+  const float* src = p.src[blockIdx.y];
+  float* dst = p.dst[blockIdx.y];
+  const int n = p.rows[blockIdx.y] * TRI;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int r = i / TRI, k = i - r * TRI;
+    int a, b;
+    tri_ab(k, &a, &b);
+    const float* row = src + (size_t)r * 1024;
+    dst[i] = a == b ? row[a * 33] : row[a * 32 + b] + row[b * 32 + a];
+  }
+}
+__global__ __launch_bounds__(256) void k_unfold_sym(FoldArgs p) {
+  const float* src = p.src[blockIdx.y];
+  float* dst = p.dst[blockIdx.y];
+  const int n = p.rows[blockIdx.y] * 1024;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int r = i >> 10, o = i & 1023, x = o >> 5, y = o & 31;
+    const int a = x > y ? x : y, b = x > y ? y : x;
+    dst[i] = src[(size_t)r * TRI + a * (a + 1) / 2 + b];
+  }
+}
+
 // Limb attention of one environment (reference subequivariant_attentions.py:90-151 between the projections): H = 2 heads of
 // 128 channels, L <= 14 limbs.  qkv [B, L, 768] = (q | k | v) as the stacked projection leaves them (q is scaled by `scale`
 // here); the vector values vg[j][s][h][d] are vgp [B, L, 3, 252] (d < 126: the projected part, 126 per head) and the node's
@@ -1028,6 +1113,38 @@ int sgrl_gram_backward(const float* z, const float* dgram, const float* dfn, con
   if (!z || !fn || !dz || M <= 0 || (!dgram && !dfn)) return tfail(SGRL_ERR_ARG, "sgrl_gram_backward: bad argument");
   hipLaunchKernelGGL(k_gram_bwd, dim3(M), dim3(256), 0, (hipStream_t)stream, z, dgram, dfn, fn, dz, M);
   { int lrc = SGRL_OK; if (!launched("k_gram_bwd launch failed", &lrc)) return lrc; }
+  return SGRL_OK;
+}
+
+int sgrl_gram_tri_forward(const float* z, float* tri, float* fn, int M, void* stream) {
+  if (!z || !tri || !fn || M <= 0) return tfail(SGRL_ERR_ARG, "sgrl_gram_tri_forward: bad argument");
+  hipLaunchKernelGGL(k_gram_tri_fwd, dim3(M), dim3(256), 0, (hipStream_t)stream, z, tri, fn, M);
+  { int lrc = SGRL_OK; if (!launched("k_gram_tri_fwd launch failed", &lrc)) return lrc; }
+  return SGRL_OK;
+}
+
+int sgrl_gram_tri_backward(const float* z, const float* dtri, const float* dfn, const float* fn, float* dz, int M, void* stream) {
+  if (!z || !fn || !dz || M <= 0 || (!dtri && !dfn)) return tfail(SGRL_ERR_ARG, "sgrl_gram_tri_backward: bad argument");
+  hipLaunchKernelGGL(k_gram_tri_bwd, dim3(M), dim3(256), 0, (hipStream_t)stream, z, dtri, dfn, fn, dz, M);
+  { int lrc = SGRL_OK; if (!launched("k_gram_tri_bwd launch failed", &lrc)) return lrc; }
+  return SGRL_OK;
+}
+
+int sgrl_sym_fold(int n, const float* const* w, float* const* wtri, const int* rows, int unfold, void* stream) {
+  if (n <= 0 || n > kFoldMax || !w || !wtri || !rows) return tfail(SGRL_ERR_ARG, "sgrl_sym_fold: bad argument (at most 16 matrices per call)");
+  FoldArgs p;
+  int most = 0;
+  for (int i = 0; i < n; i++) {
+    if (!w[i] || !wtri[i] || rows[i] <= 0) return tfail(SGRL_ERR_ARG, "sgrl_sym_fold: bad matrix " + std::to_string(i));
+    p.src[i] = unfold ? wtri[i] : w[i];
+    p.dst[i] = unfold ? const_cast<float*>(w[i]) : wtri[i];
+    p.rows[i] = rows[i];
+    most = std::max(most, rows[i]);
+  }
+  const int per = most * (unfold ? 1024 : TRI);
+  if (unfold) hipLaunchKernelGGL(k_unfold_sym, dim3((per + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(k_fold_sym, dim3((per + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, p);
+  { int lrc = SGRL_OK; if (!launched("k_fold_sym launch failed", &lrc)) return lrc; }
   return SGRL_OK;
 }
 

@@ -58,11 +58,25 @@ class ConcatPositionalEmbedding(nn.Module):
         return train_ops.embed3(self.embeddings, positional_indices)
 
 
-def _invariants(x, gdir, proj, lin1, lin2, tail=None):
-    """x [B,L,3,C] -> (features [B,L,out] (| tail), F_norm [B,L,1])."""
+def _invariants(x, gdir, proj, lin1, lin2, tail=None, w1tri=None):
+    """x [B,L,3,C] -> (features [B,L,out] (| tail), F_norm [B,L,1]).  w1tri: lin1's weight folded onto the lower triangle of the
+    symmetric Z'Z (train_ops.tri_weights): lin1 then contracts over 528 invariants instead of 1 024, same sum."""
     z = proj(x, tail=gdir)                      # [proj(x) | gdir]: the appended pair rides on the projection's launch
+    if w1tri is not None:
+        tri, fn = train_ops.gram_tri_fn(z)
+        h = train_ops.linear(tri, w1tri, lin1.bias, relu=True, premasked=True)
+        return lin2(h, tail=tail, x_relu=True), fn
     gram, fn = train_ops.gram_fn(z)
     return _mlp(lin1, lin2, gram, tail=tail), fn
+
+
+def _invariant_weights(m):
+    """The lin1 weights [*, 1024] of a TransformerModel's invariant sites in the order the forward meets them: per layer the attention's
+    and the feed-forward block's, then the head's."""
+    ws = []
+    for layer in m.transformer_encoder.layers:
+        ws += [layer.self_attn.linear_g1.weight, layer.linear_g1.weight]
+    return ws + [m.linear1_g.weight]
 
 
 class SubequivariantAttention(nn.Module):
@@ -121,11 +135,11 @@ class SubequivariantAttention(nn.Module):
         return (train_ops.stacked3(self.q_proj.weight, self.k_proj.weight, self.v_proj.weight),
                 train_ops.stacked3(self.q_proj.bias, self.k_proj.bias, self.v_proj.bias))
 
-    def forward(self, g, ng, gdir, bias=None):
+    def forward(self, g, ng, gdir, bias=None, w1tri=None):
         B, L = ng.shape[:2]
         H = self.num_heads
         hd2 = 2 * (self.embed_dim // H)
-        c, fn = _invariants(g, gdir, self.g_proj, self.linear_g1, self.linear_g2, tail=ng)      # [inv | ng]
+        c, fn = _invariants(g, gdir, self.g_proj, self.linear_g1, self.linear_g2, tail=ng, w1tri=w1tri)      # [inv | ng]
         # q, k, v share their input and their row divisor: ONE product over the stacked weights
         qw, qb = self.qkv_stacked()
         qkv = train_ops.linear(c, qw, qb, rowdiv=fn)
@@ -153,11 +167,11 @@ class SubequivariantEncoderLayer(nn.Module):
         self.linear4 = Linear(dim_feedforward, Z_DIM * Z_DIM)
         self.linear5 = Linear(Z_DIM, d_model, bias=False)
 
-    def forward(self, g, ng, gdir, bias=None):
-        g1, ng1 = self.self_attn(g, ng, gdir, bias)
+    def forward(self, g, ng, gdir, bias=None, w1tri=(None, None)):
+        g1, ng1 = self.self_attn(g, ng, gdir, bias, w1tri[0])
         g = g + g1
         ng = train_ops.add_layer_norm(ng, ng1, self.norm1)
-        c, fn = _invariants(g1, gdir, self.g_proj2, self.linear_g1, self.linear_g2, tail=ng)   # [inv | ng]
+        c, fn = _invariants(g1, gdir, self.g_proj2, self.linear_g1, self.linear_g2, tail=ng, w1tri=w1tri[1])   # [inv | ng]
         mat = _mlp(self.linear3, self.linear4, c, rowdiv=fn).view(*ng.shape[:2], Z_DIM, Z_DIM)
         z3 = self.g_proj3(g1, tail=gdir)
         g = self.linear5(train_ops.zmat(z3, mat), addend=g)
@@ -176,11 +190,11 @@ class RepeatTransformerEncoder(nn.Module):
         self.nhead = nhead
         self.rel_encoder = Linear(d_rel, nhead)
 
-    def forward(self, g, ng, gdir, pos, rel):
+    def forward(self, g, ng, gdir, pos, rel, w1tri=None):
         ng = ng + pos.unsqueeze(0)
         bias = self.rel_encoder(rel).permute(2, 0, 1)   # [H, i, j]
         for i, layer in enumerate(self.layers):
-            g, ng = layer(g, ng, gdir, bias if i == 0 else None)
+            g, ng = layer(g, ng, gdir, bias if i == 0 else None, (None, None) if w1tri is None else (w1tri[2 * i], w1tri[2 * i + 1]))
         if self.norm is not None:
             ng = train_ops.add_layer_norm(ng, None, self.norm)
         return g, ng
@@ -236,11 +250,14 @@ class TransformerModel(nn.Module):
         g = self.g_encoder(g0) * scale
         ng = self.encoder(n0) * scale
         pos = self.pos_encoder(graph["traversals"])
-        g, ng = self.transformer_encoder(g, ng, gdir, pos, graph["relation"])
+        # the seven invariant layers' weights folded onto the lower triangle of the symmetric Z'Z, one launch (None off the own kernels)
+        w1tri = train_ops.tri_weights(_invariant_weights(self), x)
+        g, ng = self.transformer_encoder(g, ng, gdir, pos, graph["relation"], w1tri)
         out_ng = torch.cat([n0, ng], dim=-1)
         out_g = torch.cat([g0, g], dim=-1)
         hng = _mlp(self.linear1_ng, self.linear2_ng, out_ng)
-        c, fn = _invariants(out_g, gdir, self.gg_proj, self.linear1_g, self.linear2_g, tail=hng)       # [inv | hng]
+        c, fn = _invariants(out_g, gdir, self.gg_proj, self.linear1_g, self.linear2_g, tail=hng,
+                            w1tri=None if w1tri is None else w1tri[-1])       # [inv | hng]
         if self.output_size == 1:
             return self.decoder_ng(c, rowdiv=fn)
         mat = _mlp(self.linear1_m, self.linear2_m, c, rowdiv=fn).view(B, L, Z_DIM, Z_DIM)
@@ -269,17 +286,22 @@ def _norm2(n0, n1, x, res=None):
     return train_ops.add_layer_norm2(x, res, n0, n1)
 
 
-def _invariants2(x, gdir2, proj, lin1, lin2, tail=None):
+def _invariants2(x, gdir2, proj, lin1, lin2, tail=None, w1tri=None):
     z = _lin2(proj[0], proj[1], x, tail=gdir2)
+    if w1tri is not None:        # (folded lin1 weight of network 0, of network 1): train_ops.tri_weights
+        tri, fn = train_ops.gram_tri_fn(z)
+        h = train_ops.linear2(tri, w1tri[0], w1tri[1], lin1[0].bias, lin1[1].bias, relu=True, premasked=True)
+        return _lin2(lin2[0], lin2[1], h, tail=tail, x_relu=True), fn
     gram, fn = train_ops.gram_fn(z)
     return _mlp2(lin1, lin2, gram, tail=tail), fn
 
 
-def _attention2(a, g, ng, gdir, gdir2, bias):
+def _attention2(a, g, ng, gdir, gdir2, bias, w1tri=None):
     """a = (SubequivariantAttention of network 0, of network 1); g [2,B,L,3,128], ng [2,B,L,128]; bias: None or a pair."""
     _, B, L = ng.shape[:3]
     hd2 = 2 * (a[0].embed_dim // a[0].num_heads)
-    c, fn = _invariants2(g, gdir2, (a[0].g_proj, a[1].g_proj), (a[0].linear_g1, a[1].linear_g1), (a[0].linear_g2, a[1].linear_g2), tail=ng)
+    c, fn = _invariants2(g, gdir2, (a[0].g_proj, a[1].g_proj), (a[0].linear_g1, a[1].linear_g1), (a[0].linear_g2, a[1].linear_g2), tail=ng,
+                         w1tri=w1tri)
     (qw0, qb0), (qw1, qb1) = a[0].qkv_stacked(), a[1].qkv_stacked()
     qkv = train_ops.linear2(c, qw0, qw1, qb0, qb1, rowdiv=fn)
     vg = _lin2(a[0].vg_proj, a[1].vg_proj, g)
@@ -294,11 +316,12 @@ def _attention2(a, g, ng, gdir, gdir2, bias):
     return _lin2(a[0].g_out, a[1].g_out, og), _lin2(a[0].ng_out, a[1].ng_out, o)
 
 
-def _layer2(l, g, ng, gdir, gdir2, bias):
-    g1, ng1 = _attention2((l[0].self_attn, l[1].self_attn), g, ng, gdir, gdir2, bias)
+def _layer2(l, g, ng, gdir, gdir2, bias, w1tri=(None, None)):
+    g1, ng1 = _attention2((l[0].self_attn, l[1].self_attn), g, ng, gdir, gdir2, bias, w1tri[0])
     g = g + g1
     ng = _norm2(l[0].norm1, l[1].norm1, ng, ng1)
-    c, fn = _invariants2(g1, gdir2, (l[0].g_proj2, l[1].g_proj2), (l[0].linear_g1, l[1].linear_g1), (l[0].linear_g2, l[1].linear_g2), tail=ng)
+    c, fn = _invariants2(g1, gdir2, (l[0].g_proj2, l[1].g_proj2), (l[0].linear_g1, l[1].linear_g1), (l[0].linear_g2, l[1].linear_g2), tail=ng,
+                         w1tri=w1tri[1])
     mat = _mlp2((l[0].linear3, l[1].linear3), (l[0].linear4, l[1].linear4), c, rowdiv=fn)
     mat = mat.view(*ng.shape[:3], Z_DIM, Z_DIM)
     z3 = _lin2(l[0].g_proj3, l[1].g_proj3, g1, tail=gdir2)
@@ -325,14 +348,19 @@ def twin_forward(m0, m1, x, graph, geo_grad=True):
     pos = torch.stack([m0.pos_encoder(graph["traversals"]), m1.pos_encoder(graph["traversals"])])
     ng = ng + pos.unsqueeze(1)
     bias = [e.rel_encoder(graph["relation"]).permute(2, 0, 1) for e in (e0, e1)]
+    # both networks' invariant weights folded onto the lower triangle in one launch: [net 0's seven, net 1's seven]
+    iw0, iw1 = _invariant_weights(m0), _invariant_weights(m1)
+    wt = train_ops.tri_weights(iw0 + iw1, x)
+    pair = (lambda k: None) if wt is None else (lambda k: (wt[k], wt[len(iw0) + k]))
     for i in range(e0.num_layers):
-        g, ng = _layer2((e0.layers[i], e1.layers[i]), g, ng, gdir, gdir2, bias if i == 0 else None)
+        g, ng = _layer2((e0.layers[i], e1.layers[i]), g, ng, gdir, gdir2, bias if i == 0 else None, (pair(2 * i), pair(2 * i + 1)))
     if e0.norm is not None:
         ng = _norm2(e0.norm, e1.norm, ng)
     out_ng = torch.cat([n0.unsqueeze(0).expand(2, *n0.shape), ng], dim=-1)
     out_g = torch.cat([g0.unsqueeze(0).expand(2, *g0.shape), g], dim=-1)
     hng = _mlp2((m0.linear1_ng, m1.linear1_ng), (m0.linear2_ng, m1.linear2_ng), out_ng)
-    c, fn = _invariants2(out_g, gdir2, (m0.gg_proj, m1.gg_proj), (m0.linear1_g, m1.linear1_g), (m0.linear2_g, m1.linear2_g), tail=hng)
+    c, fn = _invariants2(out_g, gdir2, (m0.gg_proj, m1.gg_proj), (m0.linear1_g, m1.linear1_g), (m0.linear2_g, m1.linear2_g), tail=hng,
+                         w1tri=pair(2 * e0.num_layers))
     return _lin2(m0.decoder_ng, m1.decoder_ng, c, rowdiv=fn)
 
 

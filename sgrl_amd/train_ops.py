@@ -36,6 +36,9 @@ def _L():
         L.sgrl_linear_dgrad_twin.argtypes = [vp, vp, ci, vp, vp, ci, ci, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, vp]
         L.sgrl_gram_forward.argtypes = [vp, vp, vp, ci, vp]
         L.sgrl_gram_backward.argtypes = [vp, vp, vp, vp, vp, ci, vp]
+        L.sgrl_gram_tri_forward.argtypes = [vp, vp, vp, ci, vp]
+        L.sgrl_gram_tri_backward.argtypes = [vp, vp, vp, vp, vp, ci, vp]
+        L.sgrl_sym_fold.argtypes = [ci, vp, vp, vp, ci, vp]
         L.sgrl_linear_wgrad_group.argtypes = [ci, vp, vp, vp]
         L.sgrl_zmat_forward.argtypes = [vp, vp, vp, ci, vp]
         L.sgrl_zmat_backward.argtypes = [vp, vp, vp, vp, vp, ci, vp]
@@ -110,6 +113,14 @@ def flush_wgrads(todo):
         _check(L, L.sgrl_linear_wgrad_group(len(recs), ctypes.c_void_p(d.ctypes.data), _p(_scratch(dev)), ctypes.c_void_p(stream)),
                "sgrl_linear_wgrad_group")
         with torch.no_grad():
+            # gradients of FOLDED weights (tri_weights): spread onto both mirror columns of their leaf parameters, one launch for all
+            folded = [r for r in recs if r.get("fold_param") is not None]
+            for i0 in range(0, len(folded), 16):
+                part = folded[i0:i0 + 16]
+                full = [torch.empty_like(r["fold_param"]) for r in part]
+                _sym_fold_call(full, [r["dw"] for r in part], True, dev)
+                for r, f in zip(part, full):
+                    r["w_param"], r["dw"] = r["fold_param"], f
             for r in recs:
                 for prm, g in ((r["w_param"], r["dw"]), (r["b_param"], r["db"])):
                     if prm is None:
@@ -170,6 +181,10 @@ class _LinearFn(torch.autograd.Function):
         ctx.x_relu, ctx.mask = bool(x_relu), bool(relu) and not premasked       # mask: dy still has to be masked by y > 0 here
         # leaf parameters (what deferred_wgrads may postpone): kept by reference so that their .grad can be set at the flush
         ctx.leaf = (weight, bias) if (weight.is_leaf and (bias is None or bias.is_leaf)) else None
+        # a folded weight (tri_weights) whose leaf is known: its gradient may be postponed too -- it is unfolded into the leaf's .grad
+        # at the flush, and autograd sees no gradient for the folded tensor
+        ctx.fold_leaf = getattr(weight, "_sgrl_fold_leaf", None) if (ctx.leaf is None and (bias is None or bias.is_leaf)) else None
+        ctx.bias_leaf = bias if (bias is not None and bias.is_leaf) else None
         ctx.x_shape = x.shape
         ctx.rd_shape = None if rowdiv is None else rowdiv.shape
         return y.view(*x.shape[:-1], N + nt)
@@ -197,12 +212,14 @@ class _LinearFn(torch.autograd.Function):
         stream = torch.cuda.current_stream(dy.device).cuda_stream
         st = ctypes.c_void_p(stream)
         now_w, now_b = dw, db
-        deferred = _pending is not None and need_w and ctx.leaf is not None
+        deferred = _pending is not None and need_w and (ctx.leaf is not None or ctx.fold_leaf is not None)
         if deferred:                              # postponed: computed and stored into .grad when the deferred_wgrads context exits
+            folded = ctx.leaf is None
             _pending.append({"dy": dy2, "y": yo if ctx.mask else None, "rowdiv": rd, "x": x2, "dw": dw, "db": db, "M": M, "N": N,
                              "K": K, "relu": ctx.mask, "dev": dy.device, "stream": stream, "ldy": ldyo,
-                             "w_param": ctx.leaf[0] if ctx.needs_input_grad[1] else None,
-                             "b_param": ctx.leaf[1] if need_b else None})
+                             "w_param": ctx.leaf[0] if (not folded and ctx.needs_input_grad[1]) else None,
+                             "fold_param": ctx.fold_leaf if (folded and ctx.needs_input_grad[1]) else None,
+                             "b_param": (ctx.bias_leaf if need_b else None)})
             now_w = now_b = None
         if dx is not None or now_w is not None or now_b is not None or drd is not None:
             _check(L, L.sgrl_linear_backward_xrelu(_p(dy2), dy2.stride(0), _p(yo), ldyo, 1 if ctx.mask else 0, _p(rd), _p(x2), x2.stride(0),
@@ -269,6 +286,8 @@ class _Linear2Fn(torch.autograd.Function):
         ctx.has_bias, ctx.relu, ctx.shared = b0 is not None, bool(relu), bool(shared)
         ctx.x_relu, ctx.mask = bool(x_relu), bool(relu) and not premasked
         ctx.leaf = [((w, b) if (w.is_leaf and (b is None or b.is_leaf)) else None) for w, b in params]
+        ctx.fold_leaf = [(getattr(w, "_sgrl_fold_leaf", None) if (lf is None and (b is None or b.is_leaf)) else None)
+                         for (w, b), lf in zip(params, ctx.leaf)]
         ctx.params = params
         ctx.x_shape = x.shape
         ctx.rd_shape = None if rowdiv is None else rowdiv.shape
@@ -316,10 +335,13 @@ class _Linear2Fn(torch.autograd.Function):
             x_i = xs if ctx.shared else xs[i]
             dw = torch.empty((N, K), dtype=torch.float32, device=dev)
             db = torch.empty((N,), dtype=torch.float32, device=dev) if need_b[i] else None
-            deferred = _pending is not None and ctx.leaf[i] is not None
+            folded = ctx.leaf[i] is None and ctx.fold_leaf[i] is not None
+            deferred = _pending is not None and (ctx.leaf[i] is not None or folded)
             rec = {"dy": dy2[i], "y": yo[i] if ctx.mask else None, "rowdiv": None if rd is None else rd[i], "x": x_i, "dw": dw, "db": db,
                    "M": M, "N": N, "K": K, "relu": ctx.mask, "dev": dev, "stream": stream, "ldy": ldyo,
-                   "w_param": (w if need_w[i] else None) if deferred else None, "b_param": (b if need_b[i] else None) if deferred else None}
+                   "w_param": (w if need_w[i] else None) if (deferred and not folded) else None,
+                   "fold_param": (ctx.fold_leaf[i] if need_w[i] else None) if (deferred and folded) else None,
+                   "b_param": (b if need_b[i] else None) if deferred else None}
             if deferred:
                 _pending.append(rec)
             else:
@@ -371,6 +393,78 @@ class _GramFn(torch.autograd.Function):
         st = ctypes.c_void_p(torch.cuda.current_stream(z2.device).cuda_stream)
         _check(L, L.sgrl_gram_backward(_p(z2), _p(dg), _p(df), _p(fn), _p(dz), M, st), "sgrl_gram_backward")
         return dz.view(ctx.z_shape)
+
+
+TRI = 528      # lower triangle of a symmetric 32 x 32 matrix, packed k = a (a + 1) / 2 + b (include/sgrl_train.h)
+
+
+class _GramTriFn(torch.autograd.Function):
+    """z [..., 3, 32] -> (tri(Z'Z) [..., 528], ||Z'Z||_F + 1 [..., 1]): the invariants without their mirror copies."""
+
+    @staticmethod
+    def forward(ctx, z):
+        L = _L()
+        z2 = z.reshape(-1, 96)
+        z2 = z2 if z2.is_contiguous() else z2.contiguous()
+        M = z2.shape[0]
+        tri = torch.empty((M, TRI), dtype=torch.float32, device=z.device)
+        fn = torch.empty((M,), dtype=torch.float32, device=z.device)
+        st = ctypes.c_void_p(torch.cuda.current_stream(z.device).cuda_stream)
+        _check(L, L.sgrl_gram_tri_forward(_p(z2), _p(tri), _p(fn), M, st), "sgrl_gram_tri_forward")
+        ctx.save_for_backward(z2, fn)
+        ctx.z_shape = z.shape
+        lead = z.shape[:-2]
+        return tri.view(*lead, TRI), fn.view(*lead, 1)
+
+    @staticmethod
+    def backward(ctx, dtri, dfn):
+        L = _L()
+        z2, fn = ctx.saved_tensors
+        M = z2.shape[0]
+        dg = None if dtri is None else dtri.reshape(M, TRI)
+        if dg is not None and not dg.is_contiguous():
+            dg = dg.contiguous()
+        df = None if dfn is None else dfn.reshape(M)
+        if df is not None and not df.is_contiguous():
+            df = df.contiguous()
+        dz = torch.empty((M, 96), dtype=torch.float32, device=z2.device)
+        st = ctypes.c_void_p(torch.cuda.current_stream(z2.device).cuda_stream)
+        _check(L, L.sgrl_gram_tri_backward(_p(z2), _p(dg), _p(df), _p(fn), _p(dz), M, st), "sgrl_gram_tri_backward")
+        return dz.view(ctx.z_shape)
+
+
+def _sym_fold_call(full, tri, unfold, device):
+    n = len(full)
+    pw = (ctypes.c_void_p * n)(*[t.data_ptr() for t in full])
+    pt = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tri])
+    rows = (ctypes.c_int * n)(*[t.shape[0] for t in full])
+    st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    _check(_L(), _L().sgrl_sym_fold(n, pw, pt, rows, 1 if unfold else 0, st), "sgrl_sym_fold")
+
+
+class _FoldFn(torch.autograd.Function):
+    """Weights [rows, 1024] acting on vec(G), G symmetric -> [rows, 528] acting on tri(G) (mirror columns added), up to 16 matrices in
+    one launch; the backward spreads a folded gradient onto both mirror columns, one launch too."""
+
+    @staticmethod
+    def forward(ctx, *ws):
+        ws = [w if w.is_contiguous() else w.contiguous() for w in ws]
+        out = [torch.empty((w.shape[0], TRI), dtype=torch.float32, device=w.device) for w in ws]
+        _sym_fold_call(ws, out, False, ws[0].device)
+        ctx.shapes = [w.shape for w in ws]
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *ds):
+        idx = [i for i, d in enumerate(ds) if d is not None and ctx.needs_input_grad[i]]
+        res = [None] * len(ds)
+        if idx:
+            src = [ds[i] if ds[i].is_contiguous() else ds[i].contiguous() for i in idx]
+            full = [torch.empty(tuple(ctx.shapes[i]), dtype=torch.float32, device=src[0].device) for i in idx]
+            _sym_fold_call(full, src, True, src[0].device)
+            for i, f in zip(idx, full):
+                res[i] = f
+        return tuple(res)
 
 
 class _ZmatFn(torch.autograd.Function):
@@ -611,6 +705,27 @@ def gram_fn(z):
         return _GramFn.apply(z)
     gram = torch.einsum("...sa,...sc->...ac", z, z).flatten(-2)
     return gram, gram.norm(dim=-1, keepdim=True) + 1.0
+
+
+TRI_GRAM = os.environ.get("SGRL_TRI_GRAM", "1") != "0"      # 0: the invariant layers on all 1 024 entries of Z'Z (rounds 2-4)
+
+
+def tri_weights(weights, like):
+    """The invariant layers' weights [rows, 1024] folded onto the lower triangle, [rows, 528] each (one launch for up to 16), or None
+    where the own kernels do not run for a pass over `like` (the pass's input): then `gram_fn` and the unfolded weights are used
+    (gram_tri_fn pairs with the folded ones)."""
+    if not (TRI_GRAM and _on_device_with_grad(like, *weights) and len(weights) <= 16 and all(w.dim() == 2 and w.shape[1] == 1024 for w in weights)):
+        return None
+    out = _FoldFn.apply(*weights)
+    for o, w in zip(out, weights):
+        if w.is_leaf and w.requires_grad:
+            o._sgrl_fold_leaf = w          # deferred_wgrads may postpone the folded weight's gradient and unfold it into w.grad (flush_wgrads)
+    return out
+
+
+def gram_tri_fn(z):
+    """z [..., 3, 32] -> (tri(Z'Z) [..., 528], ||Z'Z||_F + 1 [..., 1]); only on the own kernels (callers hold folded weights)."""
+    return _GramTriFn.apply(z)
 
 
 def set_attention(qkv, vgp, gdir, bias, scale):

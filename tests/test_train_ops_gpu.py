@@ -593,3 +593,40 @@ def test_twin_feed_forward_pair_with_the_mask_in_the_second_layers_epilogue():
         tol = 3e-6 * (float(r.grad.abs().max()) + 1.0) * np.sqrt(M / 64 + 1)
         assert float((a.grad.cpu().double() - r.grad).abs().max()) < tol
         assert float((a.grad - a0.grad).abs().max()) < tol
+
+
+@pytest.mark.parametrize("deferred", [False, True])
+def test_triangular_gram_and_folded_weights_match_the_full_form(deferred):
+    """tri(Z'Z) [528] with the invariant layer's weight folded onto the lower triangle (sgrl_gram_tri_*, sgrl_sym_fold) against the
+    full vec(Z'Z) [1024] form in float64: values, dz, the weight gradient (unfolded onto both mirror columns), the norm's gradient."""
+    from sgrl_amd import train_ops
+    M = 300
+    g = torch.Generator().manual_seed(11)
+    z = torch.randn(M, 3, 32, generator=g)
+    w = torch.randn(256, 1024, generator=g) / 32
+    w2 = torch.randn(64, 1024, generator=g) / 32
+    b = torch.randn(256, generator=g)
+    dy, dfn = torch.randn(M, 256, generator=g), torch.randn(M, 1, generator=g)
+    dy2 = torch.randn(M, 64, generator=g)
+    zr, wr, w2r, br = z.double().requires_grad_(), w.double().requires_grad_(), w2.double().requires_grad_(), b.double().requires_grad_()
+    gram = torch.einsum("msa,msc->mac", zr, zr).flatten(-2)
+    fnr = gram.norm(dim=-1, keepdim=True) + 1.0
+    yr = torch.relu(torch.nn.functional.linear(gram, wr, br))
+    y2r = torch.nn.functional.linear(gram, w2r)
+    ((yr * dy.double()).sum() + (fnr * dfn.double()).sum() + (y2r * dy2.double()).sum()).backward()
+    zd, wd, w2d, bd = z.cuda().requires_grad_(), torch.nn.Parameter(w.cuda()), torch.nn.Parameter(w2.cuda()), torch.nn.Parameter(b.cuda())
+    with train_ops.deferred_wgrads(deferred):       # deferred: the folded weights' gradients are grouped and unfolded at the flush
+        wt = train_ops.tri_weights([wd, w2d], zd)
+        assert wt is not None and wt[0].shape == (256, 528) and wt[1].shape == (64, 528)
+        tri, fn = train_ops.gram_tri_fn(zd)
+        y = train_ops.linear(tri, wt[0], bd, relu=True)
+        y2 = train_ops.linear(tri, wt[1])
+        ((y * dy.cuda()).sum() + (fn * dfn.cuda()).sum() + (y2 * dy2.cuda()).sum()).backward()
+    assert float((fn.detach().cpu().double() - fnr.detach()).abs().max()) < 1e-5 * float(fnr.abs().max())
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) < 1e-5 * (float(yr.abs().max()) + 1)
+    assert float((y2.detach().cpu().double() - y2r.detach()).abs().max()) < 1e-5 * (float(y2r.abs().max()) + 1)
+    for got, ref in ((zd.grad, zr.grad), (wd.grad, wr.grad), (w2d.grad, w2r.grad), (bd.grad, br.grad)):
+        assert float((got.cpu().double() - ref).abs().max()) < 2e-5 * (float(ref.abs().max()) + 1), (got.shape,)
+    # the folded weight's gradient lands on both mirror columns
+    gw = wd.grad.view(256, 32, 32)
+    assert torch.equal(gw, gw.transpose(1, 2))
