@@ -448,6 +448,7 @@ class _FoldFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, *ws):
+        ctx.set_materialize_grads(False)       # a folded weight whose gradient was postponed (deferred_wgrads) gets None here, not zeros to unfold
         ws = [w if w.is_contiguous() else w.contiguous() for w in ws]
         out = [torch.empty((w.shape[0], TRI), dtype=torch.float32, device=w.device) for w in ws]
         _sym_fold_call(ws, out, False, ws[0].device)
