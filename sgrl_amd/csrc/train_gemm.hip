@@ -14,8 +14,9 @@
 // VALU 2 x 2 micro-tile version of this kernel was LDS-bandwidth bound at 4x the time), the four partial tiles meet in LDS
 // in wave order, and the next k-tile's global loads are issued before the current tile's arithmetic.  A weight gradient
 // with a long contraction and a small output (30 x 128 over 2 100 rows: four tiles) is split along the contraction over
-// blockIdx.z: partial tiles go to scratch and the LAST workgroup to arrive at a tile adds them in split order and applies
-// the epilogue -- no floating-point atomics, the result is bit-reproducible.  g may be masked on the
+// blockIdx.z: partial tiles go to scratch (agent-scope stores / loads, no cache write-back: st_agent below) and the LAST
+// workgroup to arrive at a tile adds them in split order and applies the epilogue -- no floating-point atomics, the result
+// is bit-reproducible.  g may be masked on the
 // fly by the forward's output (ReLU backward), and the weight gradient's workgroups of the first column tile also produce
 // the bias gradient (column sums of g).
 #include <hip/hip_runtime.h>
@@ -70,10 +71,17 @@ struct SArgs {
                                     // instead of on the fly in every k-tile of that layer's two backward products
 };
 constexpr int TILE_WS = BT * BT + BT;
-constexpr int64_t kWsTiles = 4096;      // (split, tile) slots of the scratch buffer
+constexpr int64_t kWsTiles = 8192;      // (split, tile) slots of the scratch buffer (a 64 x 64 partial tile takes four)
 constexpr int kCounters = 4096;
 
 __device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// Partial tiles of a split contraction travel between workgroups WITHOUT cache maintenance: agent-scope relaxed stores / loads
+// (write-through / bypass of the XCD's non-coherent L2, `sc1`), a wait for the stores' completion and a barrier before the arrival
+// counter -- instead of two device-scope fences per workgroup, each of which writes back / invalidates a whole L2 and serialises
+// when hundreds of workgroups fence at once (LAB_LOG round 5).
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 
 // four consecutive elements of a row starting at column c (valid columns: c + j < cmax), zero filled
 __device__ __forceinline__ float4 load4(const float* row, int c, int cmax, bool vec_ok) {
@@ -281,21 +289,21 @@ __device__ __forceinline__ void sgemm_tile(const SArgs& a, float (*As)[LDP], flo
   if (splits > 1) {
     const int ntiles = gx * gy, tile = by * gx + bx;
     float* mine = a.ws + ((size_t)bz * ntiles + tile) * TILE_WS;
-    *reinterpret_cast<float4*>(mine + r * BT + c0) = make_float4(v[0], v[1], v[2], v[3]);
-    if (want_db && t < BT) mine[BT * BT + t] = dbv;
-    __threadfence();
-    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++) st_agent(mine + r * BT + c0 + j, v[j]);
+    if (want_db && t < BT) st_agent(mine + BT * BT + t, dbv);
+    __builtin_amdgcn_s_waitcnt(0);                 // this thread's stores have reached the coherent level ...
+    __syncthreads();                               // ... and so have the workgroup's, before its arrival is counted
     if (t == 0) s_last = atomicAdd(&a.counters[tile], 1u) == (unsigned)(splits - 1);
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     v[0] = v[1] = v[2] = v[3] = 0.f;
     dbv = 0.f;
     for (int sp = 0; sp < splits; sp++) {                      // fixed order: the sum does not depend on who arrived when
       const float* p = a.ws + ((size_t)sp * ntiles + tile) * TILE_WS;
-      const float4 q = *reinterpret_cast<const float4*>(p + r * BT + c0);
-      v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
-      if (want_db && t < BT) dbv += p[BT * BT + t];
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] += ld_agent(p + r * BT + c0 + j);
+      if (want_db && t < BT) dbv += ld_agent(p + BT * BT + t);
     }
     if (t == 0) a.counters[tile] = 0;                         // left zero for the next call on this stream
   }
@@ -362,9 +370,123 @@ __global__ __launch_bounds__(256) void k_sgemm_bwd(BwdArgs p) {
 // Weight (+ bias) gradients of up to kGroup layers in ONE launch: they are needed only when the optimizer steps, not by the
 // backward pass itself, so the autograd functions can postpone them (train_ops.py) and the serial chain of a backward pass
 // shrinks to its input-gradient products.  first[g] = first workgroup of problem g.
+// A REGULAR weight gradient (output dimensions multiples of 64, 16-byte aligned rows, no mask; the host checks) on 64 x 64 output
+// tiles: the workgroup's four waves own a 32 x 32 quadrant each and walk the WHOLE k-tile (64 contraction rows) -- no partial tiles
+// to merge in LDS, and every staged float feeds two matrix instructions instead of one (the 32 x 32 tile loads 256 bytes per
+// contraction row for 1 024 multiply-adds, this one 512 for 4 096).  Tiles k-major in LDS without padding, the column index rotated
+// by 32 on odd rows: lane (i, h) of a matrix instruction reads row k + h, so the two half-waves fall on the two halves of the banks.
+// The contraction is split over workgroups; the partial tiles travel through scratch WITHOUT cache maintenance: agent-scope relaxed
+// stores / loads (write-through / bypass of the XCD's L2) around the tile's counter, instead of the two device-scope fences of the
+// small tile's protocol, which write back and invalidate a whole L2 each and serialise when hundreds of workgroups fence at once
+// (twelve 256 x 256 gradients, contraction cut four ways: 141 us with fences).  The last workgroup of a tile adds the partial tiles
+// in split order: bit-reproducible.
+constexpr int T64 = 64;
+constexpr int kSlots64 = 4;                       // 32 x 32 scratch slots one 64 x 64 partial tile (+ its 64 bias sums) takes
+static_assert(kSlots64 * TILE_WS >= T64 * T64 + T64, "a 64 x 64 partial tile fits four scratch slots");
+static_assert(2 * T64 * T64 <= 2 * BKW * LDP, "the 64 x 64 tiles fit the small tile's LDS");
+__device__ __forceinline__ void wgrad_tile64(const SArgs& a, float* As, float* Bs, int* s_last_p, int bx, int by, int bz, int gx,
+                                             int gy, int nz) {
+  int& s_last = *s_last_p;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
+  const int m0 = by * T64, n0 = bx * T64;         // output rows (columns of A = dy), output columns (columns of B = x)
+  const int k_begin = bz * a.kper, k_end = min(a.K, k_begin + a.kper);
+  const bool want_db = a.db != nullptr && bx == 0;
+  const int lr = t >> 4, lc = 4 * (t & 15);       // this thread's slot of a k-tile: rows lr + 16 i, four columns at lc
+  const float* const pa = a.A + (size_t)lr * a.lda + m0 + lc;
+  const float* const pb = a.B + (size_t)lr * a.ldb + n0 + lc;
+  float4 ra[2][4], rb[2][4];
+  float4 dbp = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_tiles = [&](auto slot_c, int k0) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slot_c)::value;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int k = k0 + 16 * i;                   // + lr: inside pa / pb
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f), u = v;
+      if (k + lr < k_end) {
+        v = *reinterpret_cast<const float4*>(pa + (size_t)k * a.lda);
+        u = *reinterpret_cast<const float4*>(pb + (size_t)k * a.ldb);
+        if (a.rowdiv) { const float f = 1.f / a.rowdiv[k + lr]; v.x *= f; v.y *= f; v.z *= f; v.w *= f; }
+      }
+      if (want_db) { dbp.x += v.x; dbp.y += v.y; dbp.z += v.z; dbp.w += v.w; }
+      ra[slot][i] = v; rb[slot][i] = u;
+    }
+  };
+  auto store_tiles = [&](auto slot_c) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slot_c)::value;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int r = lr + 16 * i, c = (lc + 32 * (r & 1)) & 63;
+      *reinterpret_cast<float4*>(As + r * T64 + c) = ra[slot][i];
+      *reinterpret_cast<float4*>(Bs + r * T64 + c) = rb[slot][i];
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; e++) acc[e] = 0.f;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int ca = (32 * wr + li + 32 * lh) & 63, cb = (32 * wc + li + 32 * lh) & 63;   // rows kk + lh have parity lh (kk even)
+  auto body = [&](int k0, auto slot_c) __attribute__((always_inline)) {
+    store_tiles(slot_c);
+    __syncthreads();
+    if (k0 + 2 * T64 < k_end) load_tiles(slot_c, k0 + 2 * T64);
+    const int kn = min(T64, k_end - k0);
+#pragma unroll
+    for (int kk = 0; kk < T64; kk += 2)
+      if (kk < kn) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(kk + lh) * T64 + ca], Bs[(kk + lh) * T64 + cb], acc, 0, 0, 0);
+    __syncthreads();
+  };
+  constexpr std::integral_constant<int, 0> S0{};
+  constexpr std::integral_constant<int, 1> S1{};
+  load_tiles(S0, k_begin);
+  if (k_begin + T64 < k_end) load_tiles(S1, k_begin + T64);
+  {
+    int k0 = k_begin;
+    for (; k0 + T64 < k_end; k0 += 2 * T64) { body(k0, S0); body(k0 + T64, S1); }
+    if (k0 < k_end) body(k0, S0);
+  }
+  // bias gradient: the 16 row groups' partial column sums meet in LDS (the tiles are dead)
+  float dbv = 0.f;
+  if (want_db) {
+    *reinterpret_cast<float4*>(As + lr * T64 + lc) = dbp;
+    __syncthreads();
+    if (t < T64) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) dbv += As[r * T64 + t];
+    }
+  }
+  // this wave's quadrant, C layout of the instruction: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+  const int splits = nz;
+  if (splits > 1) {
+    const int ntiles = gx * gy, tile = by * gx + bx;
+    float* mine = a.ws + ((size_t)bz * ntiles + tile) * (kSlots64 * TILE_WS);
+#pragma unroll
+    for (int e = 0; e < 16; e++) st_agent(mine + (32 * wr + (e & 3) + 8 * (e >> 2) + 4 * lh) * T64 + 32 * wc + li, acc[e]);
+    if (want_db && t < T64) st_agent(mine + T64 * T64 + t, dbv);
+    __builtin_amdgcn_s_waitcnt(0);                 // every store of this thread has reached the coherent level ...
+    __syncthreads();                               // ... and so have the workgroup's, before its arrival is counted
+    if (t == 0) s_last = atomicAdd(&a.counters[tile], 1u) == (unsigned)(splits - 1);
+    __syncthreads();
+    if (!s_last) return;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.f;
+    dbv = 0.f;
+    for (int sp = 0; sp < splits; sp++) {                      // fixed order: the sum does not depend on who arrived when
+      const float* q = a.ws + ((size_t)sp * ntiles + tile) * (kSlots64 * TILE_WS);
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[e] += ld_agent(q + (32 * wr + (e & 3) + 8 * (e >> 2) + 4 * lh) * T64 + 32 * wc + li);
+      if (want_db && t < T64) dbv += ld_agent(q + T64 * T64 + t);
+    }
+    if (t == 0) a.counters[tile] = 0;
+  }
+  if (want_db && t < T64) a.db[m0 + t] = dbv;
+#pragma unroll
+  for (int e = 0; e < 16; e++)
+    a.C[(size_t)(m0 + 32 * wr + (e & 3) + 8 * (e >> 2) + 4 * lh) * a.ldc + n0 + 32 * wc + li] = acc[e];
+}
+
 constexpr int kGroup = 12;
 constexpr int kGroupNoSplitTiles = 256;       // sgrl_linear_wgrad_group: launches with at least this many output tiles do not split
-struct GroupArgs { SArgs w[kGroup]; int first[kGroup + 1]; int gx[kGroup], gy[kGroup], nz[kGroup]; int n; };
+struct GroupArgs { SArgs w[kGroup]; int first[kGroup + 1]; int gx[kGroup], gy[kGroup], nz[kGroup]; int big[kGroup]; int n; };
 __global__ __launch_bounds__(256) void k_sgemm_wgroup(GroupArgs p) {
   __shared__ __attribute__((aligned(16))) float As[BKW][LDP];
   __shared__ __attribute__((aligned(16))) float Bs[BKW][LDP];
@@ -374,7 +496,8 @@ __global__ __launch_bounds__(256) void k_sgemm_wgroup(GroupArgs p) {
   const SArgs a = p.w[g];                       // g is uniform: scalar loads from the kernel-argument segment
   const int gx = p.gx[g], gy = p.gy[g], nz = p.nz[g];
   const int r = blockIdx.x - p.first[g], per = gx * gy;
-  sgemm_tile<true, true, BKW>(a, As, Bs, &s_last, (r % per) % gx, (r % per) / gx, r / per, gx, gy, nz);
+  if (p.big[g]) wgrad_tile64(a, &As[0][0], &Bs[0][0], &s_last, (r % per) % gx, (r % per) / gx, r / per, gx, gy, nz);
+  else sgemm_tile<true, true, BKW>(a, As, Bs, &s_last, (r % per) % gx, (r % per) / gx, r / per, gx, gy, nz);
 }
 
 // db alone (no weight gradient requested): column sums of the masked g, 64 columns per workgroup
@@ -1186,6 +1309,7 @@ int sgrl_linear_wgrad_group(int n, const sgrl_wgrad_desc* d, float* ws, void* st
     // output tiles: a few dozen fencing workgroups, not hundreds).
     int kt_min = 1 << 30;
     for (int g = 0; g < p.n; g++) kt_min = std::min(kt_min, (d[i0 + g].M + BKW - 1) / BKW);
+    static const bool big_on = [] { const char* e = getenv("SGRL_TRAIN_WGRAD64"); return !(e && e[0] == '0'); }();   // =0: probe, 32 x 32 tiles only
     for (int g = 0; g < p.n; g++) {
       const sgrl_wgrad_desc& q = d[i0 + g];
       if (!q.dy || !q.x || !q.dw || q.M <= 0 || q.N <= 0 || q.K <= 0 || q.lddy < q.N || q.ldx < q.K || q.lddw < q.K ||
@@ -1194,10 +1318,32 @@ int sgrl_linear_wgrad_group(int n, const sgrl_wgrad_desc* d, float* ws, void* st
       SArgs a{q.dy, q.lddy, q.relu ? q.y : nullptr, q.ldy, q.x, q.ldx, nullptr, 0, q.rowdiv, q.dw, q.lddw, q.db, q.N, q.K, q.M,
               0, nullptr, nullptr};
       const int kt = (q.M + BKW - 1) / BKW;
-      const int even = (!ws_eff && ws && kt_min >= 4 && kt >= 2 * kt_min) ? kt / kt_min : 0;
-      const int rc = plan<true>(a, even ? ws : ws_eff, &p.gx[g], &p.gy[g], &p.nz[g], slot, counter, even);
-      if (rc != SGRL_OK) return rc;
-      if (p.nz[g] > 1) { slot += (int64_t)p.gx[g] * p.gy[g] * p.nz[g]; counter += p.gx[g] * p.gy[g]; }
+      p.big[g] = 0;
+      // regular products on 64 x 64 tiles (wgrad_tile64), their contraction cut into pieces of about seven 64-row k-tiles
+      if (big_on && ws && !q.relu && q.N % T64 == 0 && q.K % T64 == 0 && (q.lddy & 3) == 0 && (q.ldx & 3) == 0 &&
+          (reinterpret_cast<uintptr_t>(q.dy) & 15) == 0 && (reinterpret_cast<uintptr_t>(q.x) & 15) == 0) {
+        const int tiles = (q.N / T64) * (q.K / T64), kt64 = (q.M + T64 - 1) / T64;
+        // every workgroup of the launch walks about the same short chain of k-tiles whatever its product's size: in twelve EQUAL
+        // products fewer, longer pieces win for the large outputs (1 024 x 256 unsplit: 127 us against 177), but in the update's mixed
+        // groups the longest chain is the launch (7.31 ms per update with pieces of seven k-tiles, 7.69 with ~64 workgroups per product)
+        static const int per_split = [] { const char* e = getenv("SGRL_W64_KT"); return e ? std::max(1, atoi(e)) : 7; }();   // probe
+        const int splits = std::max(1, std::min(kt64 / per_split, 16));
+        if (slot + (int64_t)tiles * splits * kSlots64 <= kWsTiles && counter + tiles <= kCounters) {
+          p.big[g] = 1;
+          p.gx[g] = q.K / T64; p.gy[g] = q.N / T64;
+          a.kper = ((kt64 + splits - 1) / splits) * T64;
+          p.nz[g] = (q.M + a.kper - 1) / a.kper;
+          a.ws = ws + slot * TILE_WS;
+          a.counters = reinterpret_cast<unsigned*>(ws + kWsTiles * TILE_WS) + counter;
+          slot += (int64_t)tiles * p.nz[g] * kSlots64; counter += tiles;
+        }
+      }
+      if (!p.big[g]) {
+        const int even = (!ws_eff && ws && kt_min >= 4 && kt >= 2 * kt_min) ? kt / kt_min : 0;
+        const int rc = plan<true>(a, even ? ws : ws_eff, &p.gx[g], &p.gy[g], &p.nz[g], slot, counter, even);
+        if (rc != SGRL_OK) return rc;
+        if (p.nz[g] > 1) { slot += (int64_t)p.gx[g] * p.gy[g] * p.nz[g]; counter += p.gx[g] * p.gy[g]; }
+      }
       p.w[g] = a;
       p.first[g] = blocks;
       blocks += p.gx[g] * p.gy[g] * p.nz[g];
