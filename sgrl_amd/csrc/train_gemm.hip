@@ -974,7 +974,7 @@ __global__ __launch_bounds__(128) void k_embed3_bwd(Embed3 e, const float* __res
 //   k_opt_adam     g *= min(1, max_norm / (sqrt(total) + 1e-6))  (written back, as clip_grad_norm_ does);  Adam as torch's fused kernel
 //                  computes it: m = lerp(m, g, 1 - b1), v = b2 v + (1 - b2) g g, p -= (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 //   k_opt_lerp     dst = dst (1 - tau) + tau src   (table rows: dst, src, -, -, -, numel)
-constexpr int kOptChunk = 4096;
+constexpr int kOptChunk = 1024;
 struct OptRow { float* p; float* g; float* m; float* v; float* step; long long n; };
 __global__ __launch_bounds__(256) void k_opt_sqnorm(const OptRow* __restrict__ tab, const int2* __restrict__ chunks, float* __restrict__ partial) {
   __shared__ float red[4];
