@@ -326,12 +326,20 @@ __device__ __forceinline__ void sgemm_tile(const SArgs& a, float (*As)[LDP], flo
   }
 }
 
+// Workgroups b and b + 8 of a dispatch share an XCD (round-robin): renumber so that each XCD works on a contiguous run of output
+// tiles -- the column tiles of one row tile then re-read the same operand rows out of ONE L2 instead of pulling them into eight.
+// Speed only, never correctness.  id = linear workgroup index in a grid of n tiles, column tiles fastest.
+__device__ __forceinline__ int xcd_tile(int id, int n) {
+  const int per = n >> 3, rem = n & 7, x = id & 7, i = id >> 3;
+  return (x < rem) ? x * (per + 1) + i : rem * (per + 1) + (x - rem) * per + i;
+}
 template <bool AT, bool BTR, int BK, bool RM>
 __global__ __launch_bounds__(256) void k_sgemm(SArgs a) {
   __shared__ __attribute__((aligned(16))) float As[BK][LDP];
   __shared__ __attribute__((aligned(16))) float Bs[BK][LDP];
   __shared__ int s_last;
-  sgemm_tile<AT, BTR, BK, RM>(a, As, Bs, &s_last, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z);
+  const int tile = xcd_tile(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  sgemm_tile<AT, BTR, BK, RM>(a, As, Bs, &s_last, tile % gridDim.x, tile / gridDim.x, blockIdx.z, gridDim.x, gridDim.y, gridDim.z);
 }
 
 // Twin launch: TWO independent products of the same shape (the layers of the twin critics, reference SECritic.py: critic1 /
@@ -344,7 +352,8 @@ __global__ __launch_bounds__(256) void k_sgemm_twin(SArgs2 p) {
   __shared__ __attribute__((aligned(16))) float Bs[BKF][LDP];
   __shared__ int s_last;
   const SArgs a = p.a[blockIdx.z];              // uniform: scalar loads from the kernel-argument segment
-  sgemm_tile<false, BTR, BKF, RM>(a, As, Bs, &s_last, blockIdx.x, blockIdx.y, 0, gridDim.x, gridDim.y, 1);
+  const int tile = xcd_tile(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  sgemm_tile<false, BTR, BKF, RM>(a, As, Bs, &s_last, tile % gridDim.x, tile / gridDim.x, 0, gridDim.x, gridDim.y, 1);
 }
 
 // The two products of a layer's backward pass -- input gradient and weight (+ bias) gradient -- need the same dy and nothing
