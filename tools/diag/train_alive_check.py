@@ -35,4 +35,8 @@ for r in range(rounds):
     na = sum(1 for p in tr.agent.actor.parameters() if p.grad is None)
     print("          actor |grad| %.3e (%d params without grad)  critic |grad| %.3e  last losses %s" % (ag, na, cg,
           {k: {kk: float(vv) for kk, vv in v.items() if torch.is_tensor(vv)} for k, v in list(tr.last_losses.items())[:2]}), flush=True)
+    from sgrl_amd import td3 as _td3
+    tot = sorted(float(e["scratch"][0]) for e in _td3._tables.values() if "scratch" in e)
+    print("          squared gradient norms in the optimizer tables (min / median / max of %d): %.3e %.3e %.3e" % (
+        len(tot), tot[0] if tot else -1, tot[len(tot) // 2] if tot else -1, tot[-1] if tot else -1), flush=True)
     a0, c0 = a1, c1
