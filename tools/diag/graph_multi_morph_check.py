@@ -46,6 +46,19 @@ def run(graphed):
                 agent.update(batch_for(m.num_limbs, 100 + k), it, lazy_stats=True, skip_unused_critic_grads=True); it += 1
     moved = []
     for rnd in range(ROUNDS):
+        if gu is not None and rnd > 0 and os.environ.get("FORCE_RECAPTURE"):      # what a changed workspace stamp does in the trainer
+            from sgrl_amd import td3 as _td3
+            for key, sl in gu.slots.items():
+                for flag in list(sl["graphs"]):
+                    del sl["graphs"][flag]
+                    _td3.release_tables((id(gu), key, flag))
+        if rnd > 0 and os.environ.get("ROLLOUT_BETWEEN"):                          # the collection between two rounds: no-grad actor forwards
+            agent.models2eval()
+            with torch.no_grad():
+                for k2, (m2, gd2) in enumerate(zip(ms, gds)):
+                    agent.change_morphology(gd2)
+                    agent.actor(batch_for(m2.num_limbs, 7)["obs"][:24])
+            agent.models2train()
         for k, (m, gd) in enumerate(zip(ms, gds)):
             for j in range(4):
                 a0, c0 = snap(agent.actor), snap(agent.critic)

@@ -40,3 +40,19 @@ for r in range(rounds):
     print("          squared gradient norms in the optimizer tables (min / median / max of %d): %.3e %.3e %.3e" % (
         len(tot), tot[0] if tot else -1, tot[len(tot) // 2] if tot else -1, tot[-1] if tot else -1), flush=True)
     a0, c0 = a1, c1
+# the target critics on REAL replay rows through both paths (the synthetic rows of twin_target_check.py agree to 1e-6)
+from sgrl_amd import set_policy
+tr.agent.models2train()
+for k in range(0, len(names), max(1, len(names) // 6)):
+    b = tr.buffers[k].sample(tr.batch_size, generator=tr.gen)
+    tr.agent.change_morphology(tr.graph_dicts[k])
+    with torch.no_grad():
+        na = tr.agent.actor_target(b["next_obs"])
+        old = set_policy.TWIN_TARGETS
+        set_policy.TWIN_TARGETS = True
+        q1, q2 = tr.agent.critic_target(b["next_obs"], na)
+        set_policy.TWIN_TARGETS = False
+        r1, r2 = tr.agent.critic_target(b["next_obs"], na)
+        set_policy.TWIN_TARGETS = old
+    print("%-38s real rows: max |twin - rollout kernels| %.3e / %.3e  scale %.3e  |next_obs| max %.3e" % (
+        names[k], float((q1 - r1).abs().max()), float((q2 - r2).abs().max()), float(r1.abs().max()), float(b["next_obs"].abs().max())), flush=True)
