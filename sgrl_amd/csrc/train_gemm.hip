@@ -1042,9 +1042,10 @@ __global__ __launch_bounds__(256) void k_opt_lerp(const OptRow* __restrict__ tab
   for (long long i = c.y + threadIdx.x; i < end; i += 256) r.p[i] = r.p[i] * keep + tau * r.g[i];
 }
 
-// Only the weight gradient (AT) splits its contraction, and only where that pays: the release / acquire fences of the last-
-// workgroup reduction cost ~10-15 us on the eight-XCD chip, more than a few extra k-steps (measured: a 256 x 256 gradient over
-// 700 rows is 20 us unsplit, 27 us in three splits; a 30 x 128 gradient over 2 100 rows 51 us unsplit, 17 us in six).  So: a
+// Only the weight gradient (AT) splits its contraction, and only where that pays.  (These thresholds date from rounds 2-4, when the
+// last-workgroup reduction went through two device-scope fences that cost ~10-15 us on the eight-XCD chip -- a 256 x 256 gradient over
+// 700 rows was 20 us unsplit, 27 us in three splits; a 30 x 128 gradient over 2 100 rows 51 us unsplit, 17 us in six.  Since the
+// partial tiles travel as agent-scope stores / loads (st_agent above) a split costs a few microseconds; the rule was kept.)  So: a
 // handful of tiles, or a contraction of a dozen k-tiles and more.  At least two k-tiles per split, never more (split, tile)
 // slots than the scratch holds.
 // grid of one product: tiles + the contraction split (weight gradient only, see above); fills a.kper / a.ws / a.counters
@@ -1305,17 +1306,17 @@ int sgrl_linear_wgrad_group(int n, const sgrl_wgrad_desc* d, float* ws, void* st
     p.n = std::min(kGroup, n - i0);
     int64_t slot = 0;
     int counter = 0, blocks = 0;
-    // Contraction splits exist to give a LONE small product enough workgroups; their price is two device-scope fences per
-    // workgroup, and hundreds of workgroups fencing at once serialise (tools/diag/wgroup_probe.py: twelve 64 x 128 gradients over
-    // 2 100 rows take 73 us in one launch, 14.7 us each alone).  A launch whose products already put a workgroup on every CU
-    // without splitting runs them unsplit: its duration is then its longest contraction, not the fences.
+    // Contraction splits exist to give a LONE small product enough workgroups.  A launch whose 32 x 32-tile products already put a
+    // workgroup on every CU without splitting runs them unsplit (a rule from the time a split cost two device-scope fences per
+    // workgroup: twelve 64 x 128 gradients over 2 100 rows took 73 us in one launch, 14.7 us each alone; kept with the fence-free
+    // exchange, where the 64 x 64 tile below takes the regular products and cuts their contractions anyway).
     int unsplit_tiles = 0;
     for (int g = 0; g < p.n; g++) unsplit_tiles += ((d[i0 + g].N + BT - 1) / BT) * ((d[i0 + g].K + BT - 1) / BT);
     float* const ws_eff = unsplit_tiles >= kGroupNoSplitTiles ? nullptr : ws;
     // ... but such a launch lasts as long as its LONGEST contraction: at the update batch of 256 the three-vector channels contract
     // over 5 376 rows (42 k-tiles) beside 1 792-row products (14).  A product at least twice as long as the group's shortest is cut
     // into that many splits, so that every workgroup of the launch walks about the same number of k-tiles (these products have few
-    // output tiles: a few dozen fencing workgroups, not hundreds).
+    // output tiles).
     int kt_min = 1 << 30;
     for (int g = 0; g < p.n; g++) kt_min = std::min(kt_min, (d[i0 + g].M + BKW - 1) / BKW);
     static const bool big_on = [] { const char* e = getenv("SGRL_TRAIN_WGRAD64"); return !(e && e[0] == '0'); }();   // =0: probe, 32 x 32 tiles only
