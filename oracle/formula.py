@@ -106,3 +106,55 @@ def scripted_batch(L, B, seed):
                 action=rng.uniform(-1, 1, size=(B, 3 * L)).astype(np.float32),
                 reward=rng.normal(1.0, 0.5, size=(B, 1)).astype(np.float32),
                 done=(rng.uniform(size=(B, 1)) < 0.3).astype(np.float32))
+
+
+# ---- default-LIKE initial weights, regenerated from seeds (tests/golden/td3_update_default_init.npz) -------------------------
+# The TD3 fixtures above use formula weights (every branch O(0.1..1)).  The regime that decides whether config 5 takes off is the
+# reference's DEFAULT initialisation (actor gradients through a critic that does not depend on the action yet).  A default-init
+# state_dict is 57 MB, so the fixture stores the per-tensor RULE instead -- checked by tools/capture_golden_update_init.py against
+# the reference's own freshly constructed networks (constant tensors equal, bounds never exceeded, spread within sampling error)
+# -- and both sides regenerate identical values from (rule, name, seed).  The three encoder layers of the reference are deepcopy
+# clones (SEActor.py:14-15): a name's `.layers.N.` is read as `.layers.0.` so that the clones stay identical.
+def default_like_rule(name, shape):
+    """(kind, value): 'c' constant value, 'n' normal(0, value), 'u' uniform(-value, value) -- torch's default initialisers for the
+    module types the SET networks are made of, plus the two explicit U(-0.1, 0.1) of reference SEActor.py:232-235."""
+    leaf = name.split(".")[-1]
+    mod = name.split(".")[-2] if "." in name else ""
+    if "embeddings" in name:
+        return "n", 1.0                                           # nn.Embedding
+    if mod.startswith("norm") and leaf in ("weight", "bias"):
+        return "c", 1.0 if leaf == "weight" else 0.0              # nn.LayerNorm
+    if leaf == "in_proj_weight":
+        return "u", float(np.sqrt(6.0 / (shape[0] + shape[1])))   # nn.MultiheadAttention: xavier_uniform_
+    if leaf == "in_proj_bias" or name.endswith("out_proj.bias"):
+        return "c", 0.0
+    if name.endswith(("g_encoder.weight", ".encoder.weight")) or name in ("encoder.weight",):
+        return "u", 0.1                                           # init_weights(): uniform_(-0.1, 0.1)
+    return "u", None                                              # nn.Linear: U(+-1/sqrt(fan_in)); a bias takes its weight's fan_in
+
+
+def default_like_values(name, shape, seed, fan_in=None):
+    kind, val = default_like_rule(name, shape)
+    if kind == "c":
+        return np.full(shape, val, dtype=np.float32)
+    canon = name.replace(".layers.1.", ".layers.0.").replace(".layers.2.", ".layers.0.")
+    rng = np.random.RandomState((zlib.crc32(canon.encode("utf-8")) + 7919 * int(seed)) % (2 ** 32))
+    if kind == "n":
+        return rng.normal(0.0, val, size=shape).astype(np.float32)
+    if val is None:
+        val = 1.0 / np.sqrt(shape[1] if len(shape) == 2 else fan_in)
+    return rng.uniform(-val, val, size=shape).astype(np.float32)
+
+
+def apply_default_like_(module, seed):
+    """Overwrite every parameter of `module` (an SEPolicy / SECritic of either side) with default-like values of `seed`."""
+    import torch
+    sd = module.state_dict()
+    with torch.no_grad():
+        for name, p in sd.items():
+            fan_in = None
+            if p.dim() == 1 and name.endswith(".bias"):
+                w = sd.get(name[:-len("bias")] + "weight")
+                fan_in = int(w.shape[1]) if w is not None and w.dim() == 2 else None
+            p.copy_(torch.from_numpy(default_like_values(name, tuple(p.shape), seed, fan_in)).to(p.dtype))
+    return module
