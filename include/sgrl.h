@@ -62,8 +62,8 @@ int sgrl_launch_groups(const sgrl_engine* e);   /* concurrent k_env_step dispatc
 /* How many of those dispatches run on a FIXED-DIMENSION kernel (sgrl_amd/csrc/step_spec.hip: the dimension sets of a shipped
  * morphology family as compile-time constants) instead of the generic one; 0 for custom XMLs / row caps, or with SGRL_SPECS=0. */
 int sgrl_fixed_dim_groups(const sgrl_engine* e);
-/* How many environments step TWO to a wavefront (sgrl_amd/csrc/wave_half.h): environments of the light morphologies (nv <= 12)
- * on a fixed-dimension kernel, paired with a neighbour of the same morphology; 0 with SGRL_PAIR=0.  Same results to rounding. */
+/* How many environments step TWO to a wavefront (sgrl_amd/csrc/wave_half.h): environments of the light morphologies (walker_2 / _3 / _4,
+ * hopper_3 / _4: at most 15 dofs) on a fixed-dimension kernel, paired with a neighbour of the same morphology; 0 with SGRL_PAIR=0.  Same results to rounding. */
 int sgrl_paired_envs(const sgrl_engine* e);
 
 /* VecEnv.reset(): every env starts a new episode.  obs: DEV float[n_env*obs_max_len]; obs64: DEV double[...] or NULL. */
@@ -116,10 +116,12 @@ int sgrl_ingest_rows(const float* block, int n_rows, int obs_len, int act_len, c
  * whole gather of N ranks, laid out contiguously in rank order -- and no host involvement): `pos` / `cap` / `pending` are DEVICE
  * arrays of n_rings (<= 32) int64 -- the rings' write pointers (read and advanced), capacities, and a running count of rows stored
  * per ring that the host folds into its own pointers when it next looks (rollout.py TransitionSink.fold_counters); `slot_ws` is a
- * DEVICE workspace of at least 2 * n_rows + 64 + 16 * ceil(n_rows / 256) int64 (a ticket, the write pointers before the block, per-chunk
- * counts, row keys, the rows' slots) whose FIRST int64 must be zero before the first call (the calls leave it zero).  Same rings,
+ * DEVICE workspace of at least sgrl_ingest_ws_words(n_rows) int64 (a ticket, the write pointers before the block, per-chunk
+ * counts, row keys, the rows' slots); its contents on entry do not matter (the call zeroes its ticket on the stream), but two
+ * calls in flight on different streams need a workspace each.  Library version 0.1.0 took an n_rows-word buffer here.  Same rings,
  * bit for bit, as sgrl_ingest_rows with the caller's slots (row order = the reference's `for i in range(num_envs)` order,
  * common/buffer.py:75-84 per row). */
+int64_t sgrl_ingest_ws_words(int n_rows);
 int sgrl_ingest_block(const float* block, int n_rows, int obs_len, int act_len, const sgrl_ring* rings, int n_rings, int64_t* pos,
                       const int64_t* cap, int64_t* pending, int64_t* slot_ws, void* stream);
 

@@ -142,7 +142,7 @@ SGRL_HD void make_layout_rows(const int32_t* hdr, Layout* o, int n_int, int n_f6
     while (na < kNAMax && (na + 1) * (na + 2) / 2 <= o->dead_len) na++;
     o->na_max = na < want ? want : na;          // (na >= want by construction; the scratch serves free sets up to na rows)
   }
-  const bool dinv_own = !(pair && rk4_state && nv <= 16);      // paired RK4 sets factor on registers with the explicit inverse: dinv is never touched
+  const bool dinv_own = !(pair && rk4_state && nv <= 15);      // paired RK4 sets factor on registers with the explicit inverse (HalfWaveT::chol_inv_packed: n <= 15, the same bound): dinv is never touched
   o->L = p; p += nv * (nv + 1) / 2; o->dinv = dinv_own ? p : o->L; p += dinv_own ? nv : 0;
   o->qfs = p; p += nv; o->qacc = p; p += nv; o->vpgs = p; p += nv;
   // The constraint-row arrays in LDS hold `lrows` rows: as many as the factor scratch (dead zone) can serve.  The rare

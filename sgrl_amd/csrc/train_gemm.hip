@@ -79,6 +79,19 @@ __device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_c
 // (write-through / bypass of the XCD's non-coherent L2, `sc1`), a wait for the stores' completion and a barrier before the arrival
 // counter -- instead of two device-scope fences per workgroup, each of which writes back / invalidates a whole L2 and serialises
 // when hundreds of workgroups fence at once (LAB_LOG round 5).
+// The protocol leans on this target: `sc1` stores are written through to the level every XCD sees and have completed when
+// s_waitcnt vmcnt(0) returns; `sc1` loads bypass the reader's L2.  Nothing in the HIP memory model promises that elsewhere.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "train_gemm.hip: the fence-free partial-tile exchange is written for gfx942 / gfx950 (sc1 write-through); use __threadfence() elsewhere"
+#endif
+// store side: wait for this thread's stores, keep the compiler from sinking them below the barrier (a workgroup-scope release
+// fence costs no cache maintenance)
+__device__ __forceinline__ void publish_partials() {
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+}
+// load side: nothing the last workgroup reads may be hoisted above its arrival
+__device__ __forceinline__ void acquire_partials() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -292,11 +305,12 @@ __device__ __forceinline__ void sgemm_tile(const SArgs& a, float (*As)[LDP], flo
 #pragma unroll
     for (int j = 0; j < 4; j++) st_agent(mine + r * BT + c0 + j, v[j]);
     if (want_db && t < BT) st_agent(mine + BT * BT + t, dbv);
-    __builtin_amdgcn_s_waitcnt(0);                 // this thread's stores have reached the coherent level ...
+    publish_partials();                            // this thread's stores have reached the coherent level ...
     __syncthreads();                               // ... and so have the workgroup's, before its arrival is counted
     if (t == 0) s_last = atomicAdd(&a.counters[tile], 1u) == (unsigned)(splits - 1);
     __syncthreads();
     if (!s_last) return;
+    acquire_partials();
     v[0] = v[1] = v[2] = v[3] = 0.f;
     dbv = 0.f;
     for (int sp = 0; sp < splits; sp++) {                      // fixed order: the sum does not depend on who arrived when
@@ -471,11 +485,12 @@ __device__ __forceinline__ void wgrad_tile64(const SArgs& a, float* As, float* B
 #pragma unroll
     for (int e = 0; e < 16; e++) st_agent(mine + (32 * wr + (e & 3) + 8 * (e >> 2) + 4 * lh) * T64 + 32 * wc + li, acc[e]);
     if (want_db && t < T64) st_agent(mine + T64 * T64 + t, dbv);
-    __builtin_amdgcn_s_waitcnt(0);                 // every store of this thread has reached the coherent level ...
+    publish_partials();                            // every store of this thread has reached the coherent level ...
     __syncthreads();                               // ... and so have the workgroup's, before its arrival is counted
     if (t == 0) s_last = atomicAdd(&a.counters[tile], 1u) == (unsigned)(splits - 1);
     __syncthreads();
     if (!s_last) return;
+    acquire_partials();
 #pragma unroll
     for (int e = 0; e < 16; e++) acc[e] = 0.f;
     dbv = 0.f;

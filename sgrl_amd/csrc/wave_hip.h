@@ -54,6 +54,8 @@ struct DimsFixed {
   static constexpr bool kFixed = true;
   static constexpr int kNv = NV;
   static constexpr bool kPair = PAIR != 0;     // the family kernel also holds the two-environments-per-wavefront instance of this set
+  // a half wave factors on registers up to 15 dofs (wave_half.h chol_inv_packed) and the pair layout aliases dinv onto L on that promise
+  static_assert(PAIR == 0 || NV <= 15, "two-environments-per-wavefront instances are built for at most 15 dofs");
   __device__ static __forceinline__ void apply(int32_t* hdr) {
     hdr[SGRL_H_NBODY] = NB; hdr[SGRL_H_NJNT] = NJ; hdr[SGRL_H_NQ] = NQ; hdr[SGRL_H_NV] = NV; hdr[SGRL_H_NU] = NU;
     hdr[SGRL_H_NGEOM] = NG; hdr[SGRL_H_NPAIR] = NP; hdr[SGRL_H_INTEGRATOR] = INTEG; hdr[SGRL_H_FRAME_SKIP] = FSKIP;

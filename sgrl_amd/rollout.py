@@ -58,8 +58,10 @@ class Rollout(object):
     def weights_changed(self):
         """The policy's parameters were just updated (optimizer steps, soft updates, a broadcast): a rollout that holds its actor's
         packed weights (hold_weights=True) packs again on its next forward.  policy_forward() also notices by itself when a
-        parameter's version counter or storage moved (load_state_dict, a snapshot restore, a manual update), so a forgotten call
-        costs nothing but the check; only writes PyTorch cannot see (a raw kernel into the parameter's memory) need this call."""
+        parameter's version counter or storage moved (load_state_dict, a snapshot restore, a manual update, and this library's
+        own raw-pointer writers -- td3.clip_and_step, the table soft update, a GraphedUpdates replay -- which bump the counters
+        themselves: td3._touched), so a forgotten call costs nothing but the check; only a foreign kernel writing into a
+        parameter's memory behind PyTorch's back needs this call."""
         if self.holds_weights:
             self.actor.hold_weights(True)
             self._weights_seen = self._weights_fingerprint()
@@ -269,9 +271,11 @@ class RoundCollector(object):
         self.episode_reward = torch.zeros(self.n, dtype=torch.float32, device=self.device)
         self._reward_buf = torch.zeros(self.n, dtype=torch.float32, device=self.device)
 
-    def record(self, reward, curr_done):
+    def record(self, reward, curr_done, sync=True):
         """reward float[n], curr_done bool/uint8[n] as returned by VecEnv.step.  Returns (store_mask bool[n],
-        done_to_store float[n], round_finished bool).  Rows where store_mask is False are dropped (trainer.py:218)."""
+        done_to_store float[n], round_finished).  Rows where store_mask is False are dropped (trainer.py:218).
+        round_finished: a Python bool (ONE host synchronisation), or with sync=False the 0-dim bool tensor it would be read from
+        (TransitionSink reads it a step late through pinned memory instead of stalling the step on it)."""
         curr_done = curr_done.to(torch.bool).clone()
         done_bool = curr_done.to(torch.float32)
         timeout = (self.episode_timesteps + 1) == self.max_episode_steps
@@ -284,7 +288,8 @@ class RoundCollector(object):
         store = ~self.done_list
         self.episode_timesteps += store.to(torch.long)
         self.done_list |= store & curr_done
-        return store, done_bool, bool(self.done_list.all())
+        fin = self.done_list.all()
+        return store, done_bool, (bool(fin) if sync else fin)
 
     def per_morph_iter(self):
         """Number of TD3 updates per morphology after the round (reference trainer.py:244)."""
@@ -305,7 +310,12 @@ class TransitionSink(object):
     (sgrl_amd.replay.DeviceReplayBuffer) on the learner rank, None elsewhere."""
 
     def __init__(self, env_morph, num_limbs, obs_max_len, action_max_len, max_episode_steps=1000, device="cpu", buffers=None,
-                 dst=0):
+                 dst=0, lag_flag=False):
+        """lag_flag: push() answers with the round-finished flag of the PREVIOUS step, fetched through pinned memory, instead of
+        synchronising the host with the device on every step (and, at N > 1, waiting for a 4-byte all-reduce).  The round then ends
+        one step late; that step's rows carry store = False on every rank (every environment had finished), so buffers, episode
+        statistics and update counts are exactly those of the immediate flag -- only the environments take one more, discarded,
+        step before the round's reset (reference trainer.py:205-275 has no observable for it)."""
         import torch.distributed as dist
         self.dist = dist
         self.device = torch.device(device)
@@ -318,6 +328,9 @@ class TransitionSink(object):
         self.buffers = buffers
         if self.is_learner and buffers is None:
             raise ValueError("the learner rank needs the per-morphology replay buffers")
+        self.lag_flag = bool(lag_flag) and self.device.type == "cuda"
+        self._lag = None            # (pinned int32 flag of the previous step, the event after its copy)
+        self._lag_spare = []
         self._stored = 0            # host-side count, current after fold_counters()
         # rows per morphology written by the one-launch ingest since the rings' host-side pointers were last brought up to date
         # (device tensor: the ingest itself never synchronises; readers of `curr` / `max_sample_size` / `stored` fold it in)
@@ -349,14 +362,32 @@ class TransitionSink(object):
 
     def begin_round(self):
         self.collector.begin_round()
+        if self._lag is not None:           # a flag of the round that just ended says nothing about the new one
+            self._lag_spare.append(self._lag)
+            self._lag = None
 
     def push(self, prev_obs, action, next_obs, reward, done):
-        """Returns True when every environment of every rank has finished its first episode of this round."""
-        store, done_bool, finished = self.collector.record(reward, done)
+        """Returns True when every environment of every rank has finished its first episode of this round (lag_flag: as of the
+        previous step)."""
+        store, done_bool, finished = self.collector.record(reward, done, sync=not self.lag_flag)
         self.gather.pack(prev_obs, action, next_obs, reward, done_bool, store, self.env_morph)
         blocks = self.gather.push()
         if self.is_learner:
             self.ingest(blocks)
+        if self.lag_flag:
+            flag = finished.to(torch.int32).reshape(1)
+            if self.gather.world > 1:
+                self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)      # on the stream; nobody waits for it on the host
+            host, ev = self._lag_spare.pop() if self._lag_spare else (torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+            host.copy_(flag, non_blocking=True)
+            ev.record(torch.cuda.current_stream(self.device))
+            prev, self._lag = self._lag, (host, ev)
+            if prev is None:
+                return False
+            prev[1].synchronize()           # recorded a whole step ago
+            out = bool(int(prev[0][0]))
+            self._lag_spare.append(prev)
+            return out
         if self.gather.world > 1:
             flag = torch.tensor([1 if finished else 0], dtype=torch.int32, device=self.device)
             self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
@@ -408,9 +439,9 @@ class TransitionSink(object):
                 else:
                     self._pend_buf.zero_()
                 self._pend = self._pend_buf
-            need = 2 * int(blk.shape[0]) + 64 + 16 * ((int(blk.shape[0]) + 255) // 256)      # include/sgrl.h sgrl_ingest_block: workspace
+            need = int(L.sgrl_ingest_ws_words(int(blk.shape[0])))      # include/sgrl.h sgrl_ingest_block: workspace
             if getattr(self, "_slot_ws", None) is None or self._slot_ws.numel() < need:
-                self._slot_ws = torch.zeros(need, dtype=torch.long, device=self.device)      # word 0 = the ticket: zero before the first call
+                self._slot_ws = torch.empty(need, dtype=torch.long, device=self.device)      # contents do not matter
             _lib.check(L.sgrl_ingest_block(ctypes.c_void_p(blk.data_ptr()), int(blk.shape[0]), int(self.gather.o), int(self.gather.a),
                                            ctypes.c_void_p(rings.data_ptr()), len(self.buffers), ctypes.c_void_p(self._pos_dev.data_ptr()),
                                            ctypes.c_void_p(self._ring_cap.data_ptr()), ctypes.c_void_p(self._pend.data_ptr()),

@@ -45,6 +45,7 @@ def soft_update_network(source_network, target_network, tau):
                 train_ops._check(L, L.sgrl_optim_lerp(ctypes.c_void_p(ent["dev_tab"].data_ptr()), ctypes.c_void_p(ent["dev_chunks"].data_ptr()),
                                                       ent["n_chunks"], float(tau), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
                                  "sgrl_optim_lerp")
+                _touched(list(target_network.parameters()))
                 return
         if targets and targets[0].is_cuda:
             torch._foreach_mul_(targets, 1 - tau)
@@ -61,6 +62,13 @@ _FUSED_ADAM = os.environ.get("SGRL_FUSED_ADAM", "1") != "0" and hasattr(torch, "
 _TABLE_OPT = os.environ.get("SGRL_TABLE_OPT", "1") != "0"
 _tables = {}          # key (kind, address tuple) -> dict(dev table, dev chunks, pinned copies, scratch): see _table()
 _capture_owner = None  # whoever is capturing a hipGraph right now (GraphedUpdates: (id, morphology key, flag)); see release_tables()
+
+
+def _touched(params):
+    """A kernel of this library wrote these tensors through raw pointers: bump their version counters, as an in-place PyTorch
+    operation would have, so that whoever fingerprints parameters (rollout.Rollout's held weight pack, autograd's saved-tensor
+    checks) sees the write.  Host-side only: 12 us for 300 tensors."""
+    torch.autograd.graph.increment_version(params)
 
 
 def _optim_lib():
@@ -193,6 +201,7 @@ def clip_and_step(opt, max_norm):
                                 float(max_norm) if (max_norm and max_norm > 0) else 0.0, ctypes.c_void_p(ent["scratch"].data_ptr()),
                                 ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     train_ops._check(L, rc, "sgrl_optim_clip_adam")
+    _touched(params)
 
 
 def adam_step(opt):
@@ -611,5 +620,11 @@ class GraphedUpdates(object):
             g[2].replay()
         else:
             g.replay()
+        # a replay runs no host code: the writes of its optimizer / soft-update kernels are announced here
+        touched = list(self.agent.critic.parameters())
+        if flag == 0:
+            for mod in (self.agent.actor, self.agent.actor_target, self.agent.critic_target):
+                touched.extend(mod.parameters())
+        _touched(touched)
         # the capture's output tensors are overwritten by the next replay: hand out copies
         return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in sl["out"][flag].items()}

@@ -23,11 +23,12 @@ from .td3 import Agent, default_train_args
 
 class DeviceTrainer(object):
     def __init__(self, env_names, envs_per_morph, args=None, seed=0, device="cuda:0", max_buffer_size=1000000,
-                 batch_size=None, dst=0, graph_updates=False, tune_gemms=False, rollout=None, **env_kw):
+                 batch_size=None, dst=0, graph_updates=False, tune_gemms=False, rollout=None, lag_flag=True, **env_kw):
         """graph_updates: replay the TD3 update from hipGraphs (td3.GraphedUpdates); tune_gemms: let PyTorch's TunableOp pick
         the rocBLAS / hipBLASLt algorithm per GEMM shape on first use (the defaults choose 256 x 256 tiles for the 700-row
         weight-gradient GEMMs of a 100-row update: 50 -> 38 ms per update, round 1).  batch_size: rows per TD3 update, default
-        args.agent_batch_size = 256 (the reference's trainer.py:289-291)."""
+        args.agent_batch_size = 256 (the reference's trainer.py:289-291).  lag_flag (GPU ranks): the round-finished flag is read one
+        step late instead of synchronising every collection step (rollout.TransitionSink); False = the immediate flag."""
         import torch.distributed as dist
         self.dist = dist
         self.rank = dist.get_rank() if dist.is_initialized() else 0
@@ -62,7 +63,7 @@ class DeviceTrainer(object):
             self.buffers = [DeviceReplayBuffer(41 * L, 3 * L, max_buffer_size, device=self.device) for L in env.num_limbs]
         self.sink = TransitionSink(env.env_morph, env.num_limbs, env.obs_max_len, env.action_max_len,
                                    max_episode_steps=self.args.max_episode_steps, device=self.device, buffers=self.buffers,
-                                   dst=dst)
+                                   dst=dst, lag_flag=lag_flag)
         self.prev_obs = torch.zeros_like(env.obs)
         self.num_envs_global = env.num_envs * self.world
         self._updates = 0            # TD3 updates so far (the reference adds them to tot_env_steps: trainer.py:250)
@@ -122,7 +123,7 @@ class DeviceTrainer(object):
             self.ro.actions.copy_(a)
             a = self.ro.actions
         obs, rew, done, _ = self.ro.step(a)
-        return self.sink.push(self.prev_obs, a, obs, rew, done)    # one host synchronisation per step: the round-finished flag
+        return self.sink.push(self.prev_obs, a, obs, rew, done)    # the round-finished flag (GPU: read one step late, no stall)
 
     def warmup(self, timesteps):
         """reference Trainer.warmup (trainer.py:90-138): `timesteps` batched steps of uniform random actions; finished

@@ -13,6 +13,7 @@ Two ways to drive it:
     immediately (reference trainer.py:105-106,121-123).
   * Device surface (hot path): step_device(actions: torch.cuda.FloatTensor[n, action_max_len]) -> tensors on the GPU.
 """
+import collections.abc
 import ctypes
 
 import numpy as np
@@ -34,6 +35,48 @@ class Box(object):
 
     def sample(self):
         return np.random.uniform(self.low, self.high).astype(self.dtype)
+
+
+class StepInfos(collections.abc.Sequence):
+    """The `infos` of one step: a sequence of n dicts {"dist": float[, "TimeLimit.truncated": True][, "constraint_rows_dropped": k]}
+    -- what the reference's workers send back (reference src/subproc_vec_env.py:12-16, the TimeLimit wrapper of utils.py:66-71) --
+    whose dicts are MADE WHEN READ.  The reference's trainer reads `infos[i]['dist']` in the video path only
+    (reference common/trainer.py:216); building 8192 dicts per step was 1.9 ms of a 4.6 ms step.  Indexing, slicing, iteration,
+    len() and equality with a list / tuple of dicts behave like the tuple the reference returns."""
+    __slots__ = ("_dist", "_trunc", "_extra")
+
+    def __init__(self, dist, trunc, extra=None):
+        self._dist, self._trunc, self._extra = dist, trunc, extra
+
+    def __len__(self):
+        return int(self._dist.shape[0])
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return tuple(self[j] for j in range(*i.indices(len(self))))
+        n = len(self)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError(i)
+        d = {"dist": float(self._dist[i])}
+        if self._trunc[i]:
+            d["TimeLimit.truncated"] = True
+        if self._extra and i in self._extra:
+            d.update(self._extra[i])
+        return d
+
+    def __eq__(self, other):
+        if isinstance(other, (list, tuple, StepInfos)):
+            return len(other) == len(self) and all(a == b for a, b in zip(self, other))
+        return NotImplemented
+
+    def __repr__(self):
+        return "StepInfos(n=%d)" % len(self)
+
+
+def _round_up(x, a=256):
+    return (x + a - 1) // a * a
 
 
 class VecEnv(object):
@@ -118,12 +161,23 @@ class BatchedModularVecEnv(VecEnv):
         self.fixed_dim_groups = L.sgrl_fixed_dim_groups(h)     # launch groups on a fixed-dimension kernel (csrc/step_spec.hip)
         self.paired_envs = L.sgrl_paired_envs(h)               # environments that step two to a wavefront (csrc/wave_half.h)
         dev = self.device
-        self.obs = torch.zeros((n, self.obs_max_len), dtype=torch.float32, device=dev)
-        self.rew = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.done = torch.zeros(n, dtype=torch.uint8, device=dev)
-        self.dist = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.trunc = torch.zeros(n, dtype=torch.uint8, device=dev)
+        # the step's outputs are views of ONE device buffer (sections 256-byte aligned): the NumPy surface fetches them with a
+        # single device-to-host copy per step (step_wait)
+        secs = [("obs", 4 * n * self.obs_max_len), ("rew", 4 * n), ("dist", 4 * n), ("done", n), ("trunc", n)]
+        self._out_off, off = {}, 0
+        for name, nbytes in secs:
+            self._out_off[name] = (off, nbytes)
+            off += _round_up(nbytes)
+        self._out = torch.zeros(off, dtype=torch.uint8, device=dev)
+        sec = lambda name: self._out[self._out_off[name][0]:self._out_off[name][0] + self._out_off[name][1]]
+        self.obs = sec("obs").view(torch.float32).view(n, self.obs_max_len)
+        self.rew = sec("rew").view(torch.float32)
+        self.dist = sec("dist").view(torch.float32)
+        self.done = sec("done")
+        self.trunc = sec("trunc")
         self._act = torch.zeros((n, self.action_max_len), dtype=torch.float32, device=dev)
+        self._act_host = None            # pinned staging for the NumPy surface's actions (made on first use)
+        self._fetch_event = torch.cuda.Event()
         self.obs64 = None
         self.rew64 = None
         self._overflow_seen = np.zeros(n, dtype=np.int64)
@@ -205,37 +259,72 @@ class BatchedModularVecEnv(VecEnv):
     # ---- NumPy / Gym surface (reference subproc_vec_env.py:54-90) -------------------------------------------
     def reset(self):
         self.reset_device()
-        return self.obs.cpu().numpy()
+        return self.obs.cpu().numpy()       # a fresh host array (the device buffer is overwritten by the next step)
+
+    def _host_actions(self, actions):
+        """[n, action_max_len] float32 from what a trainer hands to step(): an ndarray, or the reference's list of n arrays
+        (reference trainer.py:191-200).  A list of float32 arrays is flattened through the buffer protocol (bytes.join: 0.5 ms for
+        8192 arrays, where np.asarray walks them as nested sequences: 1.4 ms)."""
+        n, amax = self.num_envs, self.action_max_len
+        a = None
+        if not isinstance(actions, np.ndarray) and len(actions) == n and isinstance(actions[0], np.ndarray) \
+                and actions[0].dtype == np.float32:
+            try:
+                buf = b"".join(actions)
+                if len(buf) == 4 * n * amax:          # any float64 / longer / shorter row changes the total
+                    a = np.frombuffer(buf, dtype=np.float32).reshape(n, amax)
+            except (TypeError, BufferError, ValueError):
+                a = None
+        if a is None:
+            a = np.asarray(actions, dtype=np.float32)
+        if a.shape != (n, amax):
+            raise ValueError("actions must be %d arrays of length action_max_len=%d (reference trainer.py:191-195)" % (n, amax))
+        return a
 
     def step_async(self, actions):
-        a = np.asarray(actions, dtype=np.float32)
-        if a.shape != (self.num_envs, self.action_max_len):
-            raise ValueError("actions must be %d arrays of length action_max_len=%d (reference trainer.py:191-195)"
-                             % (self.num_envs, self.action_max_len))
-        self._act.copy_(self.torch.from_numpy(a))
+        t = self.torch
+        if t.is_tensor(actions) and actions.is_cuda:          # already on the device: no staging
+            self.step_device(actions.to(t.float32).contiguous(), True)
+            self.waiting = True
+            return
+        a = self._host_actions(actions)
+        if self._act_host is None:
+            self._act_host = t.empty((self.num_envs, self.action_max_len), dtype=t.float32).pin_memory()
+        self._act_host.numpy()[...] = a
+        self._act.copy_(self._act_host, non_blocking=True)
         self.step_device(self._act, True)
         self.waiting = True
 
     def step_wait(self):
-        obs = self.obs.cpu().numpy()
-        rews = self.rew.cpu().numpy()
-        dones = self.done.cpu().numpy().astype(bool)
-        dist = self.dist.cpu().numpy()
-        trunc = self.trunc.cpu().numpy()
-        infos = [{"dist": float(dist[i]), **({"TimeLimit.truncated": True} if trunc[i] else {})}
-                 for i in range(self.num_envs)]
+        """(obs f32 [n, obs_max_len], rews f32 [n], dones bool [n], infos) as fresh host arrays: ONE device-to-host copy of the
+        output buffer into a pinned block of PyTorch's caching host allocator (the arrays are views of it and own it: nothing
+        is overwritten by the next step), infos made when read (StepInfos)."""
+        t = self.torch
+        n = self.num_envs
+        host = t.empty(self._out.shape, dtype=t.uint8, pin_memory=True)
+        host.copy_(self._out, non_blocking=True)
+        self._fetch_event.record(t.cuda.current_stream(self.device))
+        self._fetch_event.synchronize()
+        h = host.numpy()
+        sec = lambda name: h[self._out_off[name][0]:self._out_off[name][0] + self._out_off[name][1]]
+        obs = sec("obs").view(np.float32).reshape(n, self.obs_max_len)
+        rews = sec("rew").view(np.float32)
+        dones = sec("done").view(np.bool_)
+        dist = sec("dist").view(np.float32)
+        trunc = sec("trunc")
+        extra = None
         # truncated contact sets must not go unnoticed: report newly dropped constraint rows in the info dict + a warning
-        over = self.get_counters()[:, 2].astype(np.int64)
-        new = np.nonzero(over > self._overflow_seen)[0]
-        if new.size:
+        over = self.get_counters()[:, 2]
+        if (over > self._overflow_seen).any():
             import warnings
-            for i in new:
-                infos[i]["constraint_rows_dropped"] = int(over[i] - self._overflow_seen[i])
+            over = over.astype(np.int64)
+            new = np.nonzero(over > self._overflow_seen)[0]
+            extra = {int(i): {"constraint_rows_dropped": int(over[i] - self._overflow_seen[i])} for i in new}
             warnings.warn("%d environment(s) exceeded max_rows in this step: contacts were dropped (raise max_rows)" % new.size,
                           RuntimeWarning)
             self._overflow_seen = np.maximum(self._overflow_seen, over)
         self.waiting = False
-        return obs, rews, dones, tuple(infos)
+        return obs, rews, dones, StepInfos(dist, trunc, extra)
 
     def reset_task(self):
         raise NotImplementedError("reset_task is not defined by the reference ModularEnv either (would raise in the worker)")

@@ -487,3 +487,31 @@ def test_rollout_notices_parameter_changes_under_a_weight_hold():
     assert not torch.equal(ro.policy_forward(), a1)
     pol.load_state_dict(sd)                                       # e.g. a snapshot restore
     assert torch.equal(ro.policy_forward(), a1)
+
+
+def test_rollout_notices_the_librarys_own_raw_pointer_updates():
+    """td3.clip_and_step (table Adam), the table soft update and a GraphedUpdates replay write parameters through raw
+    pointers; they bump the tensors' version counters (td3._touched), so a Rollout holding the actor's packed weights re-packs
+    without weights_changed()."""
+    import torch
+    from sgrl_amd import td3
+    from sgrl_amd.rollout import Rollout
+    from sgrl_amd.set_policy import make_policy
+    pol = make_policy(device="cuda:0").eval()
+    tgt = make_policy(device="cuda:0").eval()
+    ro = Rollout(["3d_walker_7_full", "3d_hopper_3_shin"], 3, policy=pol, seed=1, device="cuda:0", hold_weights=True)
+    ro.reset()
+    a0 = ro.policy_forward().clone()
+    opt = torch.optim.Adam(pol.parameters(), lr=1e-2)
+    for g in opt.param_groups:
+        g["capturable"] = True                                   # the table path's precondition (device-side step counters)
+    for p in pol.parameters():
+        p.grad = torch.ones_like(p)
+    v0 = [p._version for p in pol.parameters()]
+    td3.clip_and_step(opt, 0.0)
+    assert all(p._version > v for p, v in zip(pol.parameters(), v0))
+    a1 = ro.policy_forward().clone()
+    assert not torch.equal(a1, a0)                                # the held pack was rebuilt from the stepped parameters
+    v1 = [p._version for p in tgt.parameters()]
+    td3.soft_update_network(pol, tgt, 0.5)
+    assert all(p._version > v for p, v in zip(tgt.parameters(), v1))
