@@ -286,6 +286,22 @@ def main():
     # per-kernel timings with HIP events on the launch stream (rank 0 only; not part of the timed region above)
     extra = {}
     if rank == 0:
+        # the step kernel INSIDE the rollout's flow: one more region of `steps` steps with a HIP event pair around every sgrl_step
+        # (on torch's current stream, the stream sgrl_step launches on) -- fresh random actions, the forward between two steps
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        barrier()
+        for e0, e1 in evs:
+            a = ro.random_actions()
+            if gather is not None:
+                gather.stage_obs(env.obs)
+            e0.record()
+            obs, rew, done, _ = ro.step(a)
+            e1.record()
+            ro.policy_forward(obs)
+            if gather is not None:
+                gather.pack(None, a, obs, rew, done, morph_id=sink.env_morph)
+        torch.cuda.synchronize()
+        ms_step_in_rollout = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
         a = ro.random_actions()
         ms_step = env.time_steps(a, 10)
         ms_set = ro.actor.time_forward(env.obs, ro.policy_actions, 5)
@@ -304,13 +320,18 @@ def main():
                              "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                              "algorithmic_bytes_per_launch": int(bytes_step * n_local),
                              "ms_per_launch": round(ms_step, 4),
+                             "ms_per_launch_in_rollout": round(ms_step_in_rollout, 4),
+                             "achieved_in_rollout": round(bytes_step * n_local / (ms_step_in_rollout * 1e-3) / 1e9, 3),
                              "dispatches_per_launch": env.launch_groups, "fixed_dimension_kernels": env.fixed_dim_groups,
                              "note": "latency/VALU-bound FP64 rigid-body kernel: ~2 KB of HBM traffic per env-step "
                                      "against ~1e6 FP64 operations; see DESIGN.md (roofline).  One launch = one "
                                      "sgrl_step = dispatches_per_launch concurrent step-kernel dispatches (one per kernel "
                                      "family / LDS occupancy class; this workload: ONE dispatch of the walker family's "
-                                     "fixed-dimension kernel k_env_step_spec, csrc/step_spec.hip); ms_per_launch is the HIP-event "
-                                     "time of the whole launch"}
+                                     "fixed-dimension kernel k_env_step_spec, csrc/step_spec.hip); ms_per_launch (what `achieved` and "
+                                     "`frac` are made of) is the HIP-event mean of ten back-to-back launches on ONE repeated action after "
+                                     "the run; ms_per_launch_in_rollout is the HIP-event mean around every sgrl_step of one more region "
+                                     "of `steps` rollout steps (fresh actions, the forward between two steps): the time ms_per_step is "
+                                     "made of, and what the rocprofv3 kernel trace of this command averages"}
         # the VALU view of the same kernel (it is issue / latency bound, not HBM bound): SQ counters of a separate
         # rocprofv3 --pmc pass of this command, committed under profiles/
         sq = os.path.join(REPO, "profiles", "sq_pmc.json")
@@ -319,6 +340,11 @@ def main():
                 sj = json.load(f)
             if sj.get("envs_per_gpu") == n_local:
                 extra["roofline_valu"] = sj.get("k_env_step")
+                rv = extra["roofline_valu"]
+                if rv and "valu_issue_fraction" in rv and "active_lane_fraction" in rv:
+                    # the share of the chip's FP64 lane-slots the kernel fills: cycles a SIMD issues a vector instruction x lanes live in it
+                    rv["fp64_lane_slot_fraction"] = round(rv["valu_issue_fraction"] * rv["active_lane_fraction"], 4)
+                    rv["source"] = "profiles/sq_pmc.json (build %s): separate rocprofv3 --pmc passes of this command; not re-measured in this run" % sj.get("build")
         nodes = ro.actor.num_nodes
         ex = set_executed_flops_per_node()
         # outside the timed region: the forward on this run's last observations in BOTH product forms (two-piece f16 = what was

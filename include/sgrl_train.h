@@ -65,6 +65,14 @@ int sgrl_linear_backward_xrelu(const float* dy, int lddy, const float* y, int ld
                                int ldx, const float* w, int ldw, float* dx, int lddx, float* dw, int lddw, float* db,
                                float* drowdiv, int M, int N, int K, int x_relu, float* ws, void* stream);
 
+/* The same with the input gradient ACCUMULATED: acc_dx != 0 adds g . w (masked as above) onto what dx already holds instead of
+ * overwriting it -- a tensor that feeds several linear layers (the vector stream g into g_proj and vg_proj, the invariant features c
+ * into linear3 and linear1: reference SEActor.py:93-121) collects their input gradients in one buffer, product by product, without
+ * the element-wise additions autograd would launch (sgrl_amd/train_ops.py fan_out).  Same stream: the products run in order. */
+int sgrl_linear_backward_acc(const float* dy, int lddy, const float* y, int ldyo, int relu, const float* rowdiv, const float* x,
+                             int ldx, const float* w, int ldw, float* dx, int lddx, float* dw, int lddw, float* db,
+                             float* drowdiv, int M, int N, int K, int x_relu, int acc_dx, float* ws, void* stream);
+
 /* The weight (+ bias) gradients of several layers in one launch per 12 layers: dw = g^T x, db = column sums of g, g as in
  * sgrl_linear_backward (which then is called with dw = db = null).  They are not on the backward pass's critical path -- only the
  * optimizer needs them -- so a caller may collect the descriptors during the pass and issue them together at its end. */
@@ -90,6 +98,10 @@ int sgrl_linear_dgrad_twin_xrelu(const float* dy0, const float* dy1, int lddy, c
                                  const float* rd0, const float* rd1, const float* w0, const float* w1, int ldw, float* dx0, float* dx1,
                                  int lddx, float* drd0, float* drd1, const float* x0, const float* x1, int ldx, int M, int N, int K,
                                  void* stream);
+int sgrl_linear_dgrad_twin_acc(const float* dy0, const float* dy1, int lddy, const float* y0, const float* y1, int ldyo, int relu,
+                               const float* rd0, const float* rd1, const float* w0, const float* w1, int ldw, float* dx0, float* dx1,
+                               int lddx, float* drd0, float* drd1, const float* x0, const float* x1, int ldx, int M, int N, int K,
+                               int acc_dx, void* stream);
 
 /* Gram invariants of M nodes' three 32-vectors z[M, 3, 32] (reference SEActor.py:94-98): gram[M, 1024] = vec(Z'Z),
  * fn[M] = ||Z'Z||_F + 1; and their backward: dz = Z (D + D'), D = dgram + (dfn / ||Z'Z||_F) Z'Z (dgram or dfn may be null). */

@@ -6,6 +6,9 @@
 
 #include <stdint.h>
 
+#ifndef SGRL_ITAB_GLOBAL
+#define SGRL_ITAB_GLOBAL 0
+#endif
 #ifndef SGRL_STAGE_FLOATS
 #define SGRL_STAGE_FLOATS 0   // 1: also stage the float model tables in LDS (costs ~6 KB of slab per workgroup)
 #endif
@@ -13,7 +16,14 @@
 // address spaces of the model view (include/sgrl_model.h): header copies in constant memory (uniform -> s_load),
 // int tables in LDS, float tables in constant memory (or LDS when staged)
 #define SGRL_CONST_AS __attribute__((address_space(4)))
+// SGRL_ITAB_GLOBAL=1 (a per-family compile flag, sgrl_amd/_lib.py ITAB_GLOBAL): the int tables are read where they lie (constant
+// address space: L2 / scalar cache) instead of from an LDS copy -- 2.4-3.4 KB less slab for the families whose resident count hangs
+// on it; the host computes the same layout (engine.hip: n_int = 0 for such a family's members)
+#if SGRL_ITAB_GLOBAL
+#define SGRL_ITAB_AS __attribute__((address_space(4)))
+#else
 #define SGRL_ITAB_AS __attribute__((address_space(3)))
+#endif
 #if SGRL_STAGE_FLOATS
 #define SGRL_FTAB_AS __attribute__((address_space(3)))
 #else
@@ -93,12 +103,14 @@ __device__ __forceinline__ void setup(const BatchArgs& a, int env, SgrlModelView
   sgrl_model_blob_sizes(hdr, &n_int, &n_f64);
   // integer tables (paths, masks, parents: walked in inner loops) are staged in LDS; the float tables are read once
   // per evaluation per lane and stay in L2 -- the 6 KB they would cost in LDS buy a fifth workgroup per CU instead
-  sgrl::make_layout(hdr, o, n_int, SGRL_STAGE_FLOATS ? n_f64 : 0);
+  sgrl::make_layout(hdr, o, (D::kFixed && SGRL_ITAB_GLOBAL) ? 0 : n_int, SGRL_STAGE_FLOATS ? n_f64 : 0);
   double* s = sgrl_lds;
   int32_t* ii = reinterpret_cast<int32_t*>(sgrl_lds + o->s_total);
   const int lane = threadIdx.x;
   if (SGRL_STAGE_FLOATS) for (int k = lane; k < n_f64; k += 64) s[o->model_f + k] = md.fb[k];
+#if !SGRL_ITAB_GLOBAL
   for (int k = lane; k < n_int; k += 64) ii[o->model_i + k] = md.ib[k];
+#endif
   __syncthreads();
   // the view: sizes from the scalar header, header constants through constant-memory pointers (scalar loads), int
   // tables from the LDS copy
@@ -107,7 +119,11 @@ __device__ __forceinline__ void setup(const BatchArgs& a, int env, SgrlModelView
 #else
   sgrl_ftab_t ftab = (sgrl_ftab_t)md.fb;
 #endif
+#if SGRL_ITAB_GLOBAL
+  sgrl_model_view_dims(hdr, (sgrl_hdr_t)md.ib, (sgrl_fhdr_t)md.fb, (sgrl_itab_t)md.ib, ftab, m);
+#else
   sgrl_model_view_dims(hdr, (sgrl_hdr_t)md.ib, (sgrl_fhdr_t)md.fb, (sgrl_itab_t)(ii + o->model_i), ftab, m);
+#endif
   *S = s;
   *I = ii;
 }
@@ -156,7 +172,7 @@ __device__ __forceinline__ void env_step_wave(const BatchArgs& a, const StepOut&
 // the layout and every dimension stay wave-uniform; the slab pointers and the StepIO are per lane.
 template <class D, class W>
 __device__ __forceinline__ void env_step_pair(const BatchArgs& a, const StepOut& out, int env_a, int env_b) {
-  static_assert(!SGRL_STAGE_FLOATS, "the pair layout shares the int tables only");
+  static_assert(!SGRL_STAGE_FLOATS && !SGRL_ITAB_GLOBAL, "the pair layout shares the LDS copy of the int tables only");
   const int mi = __builtin_amdgcn_readfirstlane(a.env_morph[env_a]);     // the host pairs environments of ONE morphology
   const MorphDev md = a.morphs[mi];
   int32_t hdr[SGRL_NHDR];

@@ -64,7 +64,7 @@ constexpr int kScratchDoublesMax = 2080 + 257 * 47 + 7 * 256 + 256 + 129 + 8 + 4
 struct Layout {
   int nb, nj, nq, nv, nu, np, ncon, maxrows, lrows, ld, ldy;
   int prevcap;     // warm-start rows remembered in LDS (the rest: the HBM slab): min(maxrows, kPrevRows); paired layouts: no more than lrows
-  int fstride;     // doubles per contact frame slot: 9 (normal, tangent 1, [tangent 2: recomputed, slot unused]); paired layouts 6
+  int fstride;     // doubles per contact frame slot: 9 (normal, tangent 1, [tangent 2: recomputed, slot unused]); paired layouts and layouts without an LDS copy of the int tables: 6
   // S
   int qpos, qvel, q0, v0, xv, fq, dvacc, daacc, ctrl, act;
   int xpos, xquat, xmat, xipos, xanchor, xaxis;
@@ -122,7 +122,7 @@ SGRL_HD void make_layout_rows(const int32_t* hdr, Layout* o, int n_int, int n_f6
   // LCP solver reuses the span as scratch for its Cholesky factor
   o->dead = p;
   o->xquat = p; p += 4 * nb; o->xmat = p; p += 9 * nb; o->xipos = p; p += 3 * nb; o->xanchor = p; p += 3 * nj;
-  o->fstride = pair ? 6 : 9;
+  o->fstride = (pair || n_int == 0) ? 6 : 9;     // (n_int == 0: a kernel that reads the int tables from global memory -- the dieted slabs)
   o->cinert = p; p += 10 * nb; o->crb = p; p += pair ? 0 : 10 * nb; o->cfrc = p; p += 6 * nb;
   o->con_pos = p; p += 3 * o->ncon; o->con_frame = p; p += o->fstride * o->ncon; o->con_dist = p; p += o->ncon;
   o->dead_len = p - o->dead;

@@ -63,7 +63,8 @@ struct SArgs {
   int kper;                         // contraction length per split (multiple of BK); gridDim.z splits
   float* ws; unsigned* counters;    // split scratch: [split][tile][TILE_WS] floats, one counter per tile (zero between calls)
   // forward only (both optional, last so that the other products' initialisers leave them null):
-  const float* addend; int ldadd;   // C[m][n] += addend[m][n] after the epilogue (a residual stream: g + linear5(...))
+  const float* addend; int ldadd;   // C[m][n] += addend[m][n] after the epilogue (forward: a residual stream, g + linear5(...);
+                                    // input gradient: accumulate onto what is already in C -- sgrl_linear_backward_acc)
   const float* tail; int ntail;     // C[m][N + j] = tail[m][j], j < ntail: columns appended to the product's N (z = [proj(x) | gdir],
                                     // c = [inv | ng]): the last column tile's spare columns, then column tiles of their own
   const float* omask; int ldomask;  // C[m][n] = 0 where omask[m][n] <= 0 (same layout as C): the ReLU mask of the layer BELOW applied
@@ -334,8 +335,10 @@ __device__ __forceinline__ void sgemm_tile(const SArgs& a, float (*As)[LDP], flo
     float o = v[j] + (a.bias ? a.bias[n] : 0.f);
     if (a.relu) o = fmaxf(o, 0.f);
     if (!AT && a.rowdiv) o = o / a.rowdiv[m];          // forward: y / fn; input gradient: (dy / fn) . w = (dy . w) / fn, row by row
-    if (!AT && !BTR && a.addend) o += a.addend[(size_t)m * a.ldadd + n];
     if (!AT && BTR && a.omask && !(a.omask[(size_t)m * a.ldomask + n] > 0.f)) o = 0.f;
+    // forward: a residual stream; input gradient: the gradient other consumers of the same input have already left in C
+    // (addend == C: every element is read and written by this one thread)
+    if (!AT && a.addend) o += a.addend[(size_t)m * a.ldadd + n];
     a.C[(size_t)m * a.ldc + n] = o;
   }
 }
@@ -1147,6 +1150,12 @@ int sgrl_linear_backward(const float* dy, int lddy, const float* y, int ldyo, in
 int sgrl_linear_backward_xrelu(const float* dy, int lddy, const float* y, int ldyo, int relu, const float* rowdiv, const float* x,
                                int ldx, const float* w, int ldw, float* dx, int lddx, float* dw, int lddw, float* db,
                                float* drowdiv, int M, int N, int K, int x_relu, float* ws, void* stream) {
+  return sgrl_linear_backward_acc(dy, lddy, y, ldyo, relu, rowdiv, x, ldx, w, ldw, dx, lddx, dw, lddw, db, drowdiv, M, N, K, x_relu, 0, ws, stream);
+}
+
+int sgrl_linear_backward_acc(const float* dy, int lddy, const float* y, int ldyo, int relu, const float* rowdiv, const float* x,
+                             int ldx, const float* w, int ldw, float* dx, int lddx, float* dw, int lddw, float* db,
+                             float* drowdiv, int M, int N, int K, int x_relu, int acc_dx, float* ws, void* stream) {
   if (x_relu && dx && (!x || ldx < K)) return tfail(SGRL_ERR_ARG, "sgrl_linear_backward_xrelu: x_relu needs the layer's input");
   if (!dy || M <= 0 || N <= 0 || K <= 0 || lddy < N || ((relu || drowdiv) && (!y || ldyo < N)) || (drowdiv && !rowdiv) ||
       (relu && rowdiv))
@@ -1163,6 +1172,7 @@ int sgrl_linear_backward_xrelu(const float* dy, int lddy, const float* y, int ld
   // dx[M][K] = g[M][N] . w[N][K]: contraction N, contiguous in g, the row index of w
   SArgs ad{dy, lddy, mask, ldyo, w, ldw, nullptr, 0, rowdiv, dx, lddx, nullptr, M, K, N, 0, nullptr, nullptr};
   if (x_relu) { ad.omask = x; ad.ldomask = ldx; }
+  if (acc_dx && dx) { ad.addend = dx; ad.ldadd = lddx; }
   // dw[N][K] = g^T . x: contraction M, the row index of both operands; db rides along
   SArgs aw{dy, lddy, mask, ldyo, x, ldx, nullptr, 0, rowdiv, dw, lddw, db, N, K, M, 0, nullptr, nullptr};
   if (dx && dw) {
@@ -1229,6 +1239,14 @@ int sgrl_linear_dgrad_twin_xrelu(const float* dy0, const float* dy1, int lddy, c
                                  const float* rd0, const float* rd1, const float* w0, const float* w1, int ldw, float* dx0, float* dx1,
                                  int lddx, float* drd0, float* drd1, const float* x0, const float* x1, int ldx, int M, int N, int K,
                                  void* stream) {
+  return sgrl_linear_dgrad_twin_acc(dy0, dy1, lddy, y0, y1, ldyo, relu, rd0, rd1, w0, w1, ldw, dx0, dx1, lddx, drd0, drd1, x0, x1, ldx, M, N, K,
+                                    0, stream);
+}
+
+int sgrl_linear_dgrad_twin_acc(const float* dy0, const float* dy1, int lddy, const float* y0, const float* y1, int ldyo, int relu,
+                               const float* rd0, const float* rd1, const float* w0, const float* w1, int ldw, float* dx0, float* dx1,
+                               int lddx, float* drd0, float* drd1, const float* x0, const float* x1, int ldx, int M, int N, int K,
+                               int acc_dx, void* stream) {
   if ((!x0) != (!x1) || (x0 && ldx < K)) return tfail(SGRL_ERR_ARG, "sgrl_linear_dgrad_twin_xrelu: bad input-mask argument");
   if (!dy0 || !dy1 || !w0 || !w1 || !dx0 || !dx1 || M <= 0 || N <= 0 || K <= 0 || lddy < N || ldw < K || lddx < K ||
       ((relu || drd0) && (!y0 || !y1 || ldyo < N)) || (!rd0) != (!rd1) || (!drd0) != (!drd1) || (drd0 && !rd0) || (relu && rd0))
@@ -1242,6 +1260,7 @@ int sgrl_linear_dgrad_twin_xrelu(const float* dy0, const float* dy1, int lddy, c
   p.a[0] = SArgs{dy0, lddy, relu ? y0 : nullptr, ldyo, w0, ldw, nullptr, 0, rd0, dx0, lddx, nullptr, M, K, N, 0, nullptr, nullptr};
   p.a[1] = SArgs{dy1, lddy, relu ? y1 : nullptr, ldyo, w1, ldw, nullptr, 0, rd1, dx1, lddx, nullptr, M, K, N, 0, nullptr, nullptr};
   if (x0) { p.a[0].omask = x0; p.a[1].omask = x1; p.a[0].ldomask = p.a[1].ldomask = ldx; }
+  if (acc_dx) { p.a[0].addend = dx0; p.a[1].addend = dx1; p.a[0].ldadd = p.a[1].ldadd = lddx; }
   int tn, tm, splits;
   for (int i = 0; i < 2; i++) { const int rc = plan<false>(p.a[i], nullptr, &tn, &tm, &splits); if (rc != SGRL_OK) return rc; }
   if (row_major_staging()) hipLaunchKernelGGL((k_sgemm_twin<true, true>), dim3(tn, tm, 2), dim3(256), 0, st, p);

@@ -35,14 +35,15 @@ class Linear(nn.Linear):
     weight / bias gradient -- runs on this library's small-product kernels (train_ops.linear, csrc/train_gemm.hip); `relu`
     folds the activation that follows the layer into the product's epilogue and its mask into the backward products."""
 
-    def forward(self, x, relu=False, rowdiv=None, addend=None, tail=None, x_relu=False, premasked=False):
-        return train_ops.linear(x, self.weight, self.bias, relu, rowdiv, addend, tail, x_relu, premasked)
+    def forward(self, x, relu=False, rowdiv=None, addend=None, tail=None, x_relu=False, premasked=False, slot=None):
+        return train_ops.linear(x, self.weight, self.bias, relu, rowdiv, addend, tail, x_relu, premasked, slot)
 
 
-def _mlp(lin1, lin2, x, rowdiv=None, tail=None):
+def _mlp(lin1, lin2, x, rowdiv=None, tail=None, slot=None):
     """lin2(relu(lin1(x))) (/ rowdiv, | tail): the reference's feed-forward pairs (SEActor.py:101-121).  The hidden activation has
-    no other consumer, so its ReLU mask is applied once, in the epilogue of lin2's input gradient (train_ops.linear x_relu / premasked)."""
-    return lin2(lin1(x, relu=True, premasked=True), rowdiv=rowdiv, tail=tail, x_relu=True)
+    no other consumer, so its ReLU mask is applied once, in the epilogue of lin2's input gradient (train_ops.linear x_relu / premasked).
+    slot: x is an alias handed out by train_ops.fan_out (lin1's input gradient is summed in the fan-out's buffer)."""
+    return lin2(lin1(x, relu=True, premasked=True, slot=slot), rowdiv=rowdiv, tail=tail, x_relu=True)
 
 
 class ConcatPositionalEmbedding(nn.Module):
@@ -58,10 +59,10 @@ class ConcatPositionalEmbedding(nn.Module):
         return train_ops.embed3(self.embeddings, positional_indices)
 
 
-def _invariants(x, gdir, proj, lin1, lin2, tail=None, w1tri=None):
+def _invariants(x, gdir, proj, lin1, lin2, tail=None, w1tri=None, slot=None):
     """x [B,L,3,C] -> (features [B,L,out] (| tail), F_norm [B,L,1]).  w1tri: lin1's weight folded onto the lower triangle of the
     symmetric Z'Z (train_ops.tri_weights): lin1 then contracts over 528 invariants instead of 1 024, same sum."""
-    z = proj(x, tail=gdir)                      # [proj(x) | gdir]: the appended pair rides on the projection's launch
+    z = proj(x, tail=gdir, slot=slot)           # [proj(x) | gdir]: the appended pair rides on the projection's launch
     if w1tri is not None:
         tri, fn = train_ops.gram_tri_fn(z)
         h = train_ops.linear(tri, w1tri, lin1.bias, relu=True, premasked=True)
@@ -135,17 +136,20 @@ class SubequivariantAttention(nn.Module):
         return (train_ops.stacked3(self.q_proj.weight, self.k_proj.weight, self.v_proj.weight),
                 train_ops.stacked3(self.q_proj.bias, self.k_proj.bias, self.v_proj.bias))
 
-    def forward(self, g, ng, gdir, bias=None, w1tri=None):
+    def forward(self, g, ng, gdir, bias=None, w1tri=None, g_vg=None, slot=None):
+        """g_vg / slot: a second alias of g for the value projection and the fan-out slot both projections of g share
+        (train_ops.fan_out; the caller keeps a third alias for the residual)."""
         B, L = ng.shape[:2]
         H = self.num_heads
         hd2 = 2 * (self.embed_dim // H)
-        c, fn = _invariants(g, gdir, self.g_proj, self.linear_g1, self.linear_g2, tail=ng, w1tri=w1tri)      # [inv | ng]
+        g_vg = g if g_vg is None else g_vg
+        c, fn = _invariants(g, gdir, self.g_proj, self.linear_g1, self.linear_g2, tail=ng, w1tri=w1tri, slot=slot)      # [inv | ng]
         # q, k, v share their input and their row divisor: ONE product over the stacked weights
         qw, qb = self.qkv_stacked()
         qkv = train_ops.linear(c, qw, qb, rowdiv=fn)
         # H = 2 heads of hd2 = 128 channels (the SET configuration): scores, softmax and both weighted sums in one operation on the
         # stacked qkv and on the vector values in parts (projected channels | the node's gravity / direction pair)
-        o, og = train_ops.set_attention(qkv, self.vg_proj(g), gdir, bias, float(hd2) ** -0.5)
+        o, og = train_ops.set_attention(qkv, self.vg_proj(g_vg, slot=slot), gdir, bias, float(hd2) ** -0.5)
         return self.g_out(og), self.ng_out(o)
 
 
@@ -168,14 +172,19 @@ class SubequivariantEncoderLayer(nn.Module):
         self.linear5 = Linear(Z_DIM, d_model, bias=False)
 
     def forward(self, g, ng, gdir, bias=None, w1tri=(None, None)):
-        g1, ng1 = self.self_attn(g, ng, gdir, bias, w1tri[0])
-        g = g + g1
+        # tensors with several consumers are handed out as aliases (train_ops.fan_out): the linear layers among the consumers sum
+        # their input gradients in one buffer instead of leaving one element-wise addition per extra consumer to autograd
+        sg, (ga, gb, gc) = train_ops.fan_out(g, 3)              # g_proj, vg_proj, the residual
+        g1, ng1 = self.self_attn(ga, ng, gdir, bias, w1tri[0], g_vg=gb, slot=sg)
+        s1, (g1a, g1b, g1c) = train_ops.fan_out(g1, 3)          # the residual, g_proj2, g_proj3
+        g = gc + g1a
         ng = train_ops.add_layer_norm(ng, ng1, self.norm1)
-        c, fn = _invariants(g1, gdir, self.g_proj2, self.linear_g1, self.linear_g2, tail=ng, w1tri=w1tri[1])   # [inv | ng]
-        mat = _mlp(self.linear3, self.linear4, c, rowdiv=fn).view(*ng.shape[:2], Z_DIM, Z_DIM)
-        z3 = self.g_proj3(g1, tail=gdir)
+        c, fn = _invariants(g1b, gdir, self.g_proj2, self.linear_g1, self.linear_g2, tail=ng, w1tri=w1tri[1], slot=s1)   # [inv | ng]
+        sc, (ca, cb) = train_ops.fan_out(c, 2)                  # linear3, linear1
+        mat = _mlp(self.linear3, self.linear4, ca, rowdiv=fn, slot=sc).view(*ng.shape[:2], Z_DIM, Z_DIM)
+        z3 = self.g_proj3(g1c, tail=gdir, slot=s1)
         g = self.linear5(train_ops.zmat(z3, mat), addend=g)
-        ng = train_ops.add_layer_norm(ng, _mlp(self.linear1, self.linear2, c, rowdiv=fn), self.norm2)
+        ng = train_ops.add_layer_norm(ng, _mlp(self.linear1, self.linear2, cb, rowdiv=fn, slot=sc), self.norm2)
         return g, ng
 
 
@@ -273,21 +282,21 @@ class TransformerModel(nn.Module):
 # is one launch for the pair (train_ops.linear2), and the weight-free operations (Gram invariants, attention, the equivariant
 # contraction, residual adds, concatenations) simply see twice the nodes.  Same arithmetic per network as
 # TransformerModel.forward, operation by operation (tests/test_set_critic.py, tests/test_train_ops_gpu.py).
-def _lin2(l0, l1, x, relu=False, rowdiv=None, shared=False, addend=None, tail=None, x_relu=False, premasked=False):
-    return train_ops.linear2(x, l0.weight, l1.weight, l0.bias, l1.bias, relu, rowdiv, shared, addend, tail, x_relu, premasked)
+def _lin2(l0, l1, x, relu=False, rowdiv=None, shared=False, addend=None, tail=None, x_relu=False, premasked=False, slot=None):
+    return train_ops.linear2(x, l0.weight, l1.weight, l0.bias, l1.bias, relu, rowdiv, shared, addend, tail, x_relu, premasked, slot)
 
 
-def _mlp2(lin1, lin2, x, rowdiv=None, tail=None):
+def _mlp2(lin1, lin2, x, rowdiv=None, tail=None, slot=None):
     """`_mlp` for the two critics at once (lin1 / lin2: pairs of layers)."""
-    return _lin2(lin2[0], lin2[1], _lin2(lin1[0], lin1[1], x, relu=True, premasked=True), rowdiv=rowdiv, tail=tail, x_relu=True)
+    return _lin2(lin2[0], lin2[1], _lin2(lin1[0], lin1[1], x, relu=True, premasked=True, slot=slot), rowdiv=rowdiv, tail=tail, x_relu=True)
 
 
 def _norm2(n0, n1, x, res=None):
     return train_ops.add_layer_norm2(x, res, n0, n1)
 
 
-def _invariants2(x, gdir2, proj, lin1, lin2, tail=None, w1tri=None):
-    z = _lin2(proj[0], proj[1], x, tail=gdir2)
+def _invariants2(x, gdir2, proj, lin1, lin2, tail=None, w1tri=None, slot=None):
+    z = _lin2(proj[0], proj[1], x, tail=gdir2, slot=slot)
     if w1tri is not None:        # (folded lin1 weight of network 0, of network 1): train_ops.tri_weights
         tri, fn = train_ops.gram_tri_fn(z)
         h = train_ops.linear2(tri, w1tri[0], w1tri[1], lin1[0].bias, lin1[1].bias, relu=True, premasked=True)
@@ -296,15 +305,15 @@ def _invariants2(x, gdir2, proj, lin1, lin2, tail=None, w1tri=None):
     return _mlp2(lin1, lin2, gram, tail=tail), fn
 
 
-def _attention2(a, g, ng, gdir, gdir2, bias, w1tri=None):
+def _attention2(a, g, ng, gdir, gdir2, bias, w1tri=None, g_vg=None, slot=None):
     """a = (SubequivariantAttention of network 0, of network 1); g [2,B,L,3,128], ng [2,B,L,128]; bias: None or a pair."""
     _, B, L = ng.shape[:3]
     hd2 = 2 * (a[0].embed_dim // a[0].num_heads)
     c, fn = _invariants2(g, gdir2, (a[0].g_proj, a[1].g_proj), (a[0].linear_g1, a[1].linear_g1), (a[0].linear_g2, a[1].linear_g2), tail=ng,
-                         w1tri=w1tri)
+                         w1tri=w1tri, slot=slot)
     (qw0, qb0), (qw1, qb1) = a[0].qkv_stacked(), a[1].qkv_stacked()
     qkv = train_ops.linear2(c, qw0, qw1, qb0, qb1, rowdiv=fn)
-    vg = _lin2(a[0].vg_proj, a[1].vg_proj, g)
+    vg = _lin2(a[0].vg_proj, a[1].vg_proj, g if g_vg is None else g_vg, slot=slot)
     scale = float(hd2) ** -0.5
     if bias is None:            # the two networks' environments as one batch of 2 B
         o, og = train_ops.set_attention(qkv.reshape(2 * B, L, -1), vg.reshape(2 * B, L, 3, -1),
@@ -317,16 +326,19 @@ def _attention2(a, g, ng, gdir, gdir2, bias, w1tri=None):
 
 
 def _layer2(l, g, ng, gdir, gdir2, bias, w1tri=(None, None)):
-    g1, ng1 = _attention2((l[0].self_attn, l[1].self_attn), g, ng, gdir, gdir2, bias, w1tri[0])
-    g = g + g1
+    sg, (ga, gb, gc) = train_ops.fan_out(g, 3)                  # as in SubequivariantEncoderLayer.forward
+    g1, ng1 = _attention2((l[0].self_attn, l[1].self_attn), ga, ng, gdir, gdir2, bias, w1tri[0], g_vg=gb, slot=sg)
+    s1, (g1a, g1b, g1c) = train_ops.fan_out(g1, 3)
+    g = gc + g1a
     ng = _norm2(l[0].norm1, l[1].norm1, ng, ng1)
-    c, fn = _invariants2(g1, gdir2, (l[0].g_proj2, l[1].g_proj2), (l[0].linear_g1, l[1].linear_g1), (l[0].linear_g2, l[1].linear_g2), tail=ng,
-                         w1tri=w1tri[1])
-    mat = _mlp2((l[0].linear3, l[1].linear3), (l[0].linear4, l[1].linear4), c, rowdiv=fn)
+    c, fn = _invariants2(g1b, gdir2, (l[0].g_proj2, l[1].g_proj2), (l[0].linear_g1, l[1].linear_g1), (l[0].linear_g2, l[1].linear_g2), tail=ng,
+                         w1tri=w1tri[1], slot=s1)
+    sc, (ca, cb) = train_ops.fan_out(c, 2)
+    mat = _mlp2((l[0].linear3, l[1].linear3), (l[0].linear4, l[1].linear4), ca, rowdiv=fn, slot=sc)
     mat = mat.view(*ng.shape[:3], Z_DIM, Z_DIM)
-    z3 = _lin2(l[0].g_proj3, l[1].g_proj3, g1, tail=gdir2)
+    z3 = _lin2(l[0].g_proj3, l[1].g_proj3, g1c, tail=gdir2, slot=s1)
     g = _lin2(l[0].linear5, l[1].linear5, train_ops.zmat(z3, mat), addend=g)
-    ng = _norm2(l[0].norm2, l[1].norm2, ng, _mlp2((l[0].linear1, l[1].linear1), (l[0].linear2, l[1].linear2), c, rowdiv=fn))
+    ng = _norm2(l[0].norm2, l[1].norm2, ng, _mlp2((l[0].linear1, l[1].linear1), (l[0].linear2, l[1].linear2), cb, rowdiv=fn, slot=sc))
     return g, ng
 
 

@@ -32,6 +32,8 @@ def _L():
         L.sgrl_linear_backward.argtypes = [vp, ci, vp, ci, ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, vp, vp]
         L.sgrl_linear_backward_xrelu.argtypes = [vp, ci, vp, ci, ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp]
         L.sgrl_linear_dgrad_twin_xrelu.argtypes = [vp, vp, ci, vp, vp, ci, ci, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp]
+        L.sgrl_linear_backward_acc.argtypes = [vp, ci, vp, ci, ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, vp, vp]
+        L.sgrl_linear_dgrad_twin_acc.argtypes = [vp, vp, ci, vp, vp, ci, ci, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
         L.sgrl_linear_forward_twin.argtypes = [vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
         L.sgrl_linear_dgrad_twin.argtypes = [vp, vp, ci, vp, vp, ci, ci, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, vp]
         L.sgrl_gram_forward.argtypes = [vp, vp, vp, ci, vp]
@@ -138,7 +140,9 @@ def _p(t):
 
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, relu, rowdiv, addend=None, tail=None, x_relu=False, premasked=False):
+    def forward(ctx, x, weight, bias, relu, rowdiv, addend=None, tail=None, x_relu=False, premasked=False, slot=None):
+        # slot: x is one output of fan_out() -- this layer's input gradient is written into / accumulated onto the fan-out's shared
+        # buffer (sgrl_linear_backward_acc) instead of travelling through autograd's own additions.
         # x_relu: x is the output of a ReLU layer whose backward is told `premasked` -- this layer's input gradient comes out masked
         # by x > 0 (the dgrad kernel's epilogue), and THAT layer's two backward products read no mask (include/sgrl_train.h
         # sgrl_linear_backward_xrelu).  Valid when nothing else consumes the ReLU layer's output (the SET feed-forward pairs).
@@ -187,6 +191,7 @@ class _LinearFn(torch.autograd.Function):
         ctx.bias_leaf = bias if (bias is not None and bias.is_leaf) else None
         ctx.x_shape = x.shape
         ctx.rd_shape = None if rowdiv is None else rowdiv.shape
+        ctx.slot = slot
         return y.view(*x.shape[:-1], N + nt)
 
     @staticmethod
@@ -205,7 +210,14 @@ class _LinearFn(torch.autograd.Function):
         need_rd = rd is not None and ctx.needs_input_grad[4]
         if need_b and not need_w:
             need_w = True                       # the bias gradient rides on the weight-gradient kernel
-        dx = torch.empty((M, K), dtype=torch.float32, device=dy.device) if need_x else None
+        acc_dx = False
+        slot = ctx.slot if need_x else None
+        if slot is not None and slot.buf is not None:          # a sibling consumer was here first: add onto its gradient
+            dx, acc_dx = slot.buf.view(M, K), True
+        else:
+            dx = torch.empty((M, K), dtype=torch.float32, device=dy.device) if need_x else None
+            if slot is not None:
+                slot.buf = dx
         dw = torch.empty((N, K), dtype=torch.float32, device=dy.device) if need_w else None
         db = torch.empty((N,), dtype=torch.float32, device=dy.device) if need_b else None
         drd = torch.empty((M,), dtype=torch.float32, device=dy.device) if need_rd else None
@@ -222,13 +234,15 @@ class _LinearFn(torch.autograd.Function):
                              "b_param": (ctx.bias_leaf if need_b else None)})
             now_w = now_b = None
         if dx is not None or now_w is not None or now_b is not None or drd is not None:
-            _check(L, L.sgrl_linear_backward_xrelu(_p(dy2), dy2.stride(0), _p(yo), ldyo, 1 if ctx.mask else 0, _p(rd), _p(x2), x2.stride(0),
-                                                   _p(w), K, _p(dx), K, _p(now_w), K, _p(now_b), _p(drd), M, N, K, 1 if ctx.x_relu else 0,
-                                                   _p(_scratch(dy.device)), st), "sgrl_linear_backward_xrelu")
+            _check(L, L.sgrl_linear_backward_acc(_p(dy2), dy2.stride(0), _p(yo), ldyo, 1 if ctx.mask else 0, _p(rd), _p(x2), x2.stride(0),
+                                                 _p(w), K, _p(dx), K, _p(now_w), K, _p(now_b), _p(drd), M, N, K, 1 if ctx.x_relu else 0,
+                                                 1 if acc_dx else 0, _p(_scratch(dy.device)), st), "sgrl_linear_backward_acc")
         dadd = dy.reshape(ctx.ad_shape) if (ctx.ad_shape is not None and ctx.needs_input_grad[5]) else None
         dtail = dyf[:, N:].reshape(ctx.tail_shape) if (nt and ctx.needs_input_grad[6]) else None
-        return (dx.view(ctx.x_shape) if need_x else None), (None if deferred else (dw if ctx.needs_input_grad[1] else None)), \
-               (None if deferred else db), None, (drd.view(ctx.rd_shape) if need_rd else None), dadd, dtail, None, None
+        # (a slot consumer hands its gradient to the fan-out through the slot: the first one also returns it so that the fan-out's
+        # backward is certain to run; the others return nothing)
+        return (dx.view(ctx.x_shape) if (need_x and not acc_dx) else None), (None if deferred else (dw if ctx.needs_input_grad[1] else None)), \
+               (None if deferred else db), None, (drd.view(ctx.rd_shape) if need_rd else None), dadd, dtail, None, None, None
 
 
 class _Linear2Fn(torch.autograd.Function):
@@ -236,8 +250,9 @@ class _Linear2Fn(torch.autograd.Function):
     x is either ONE input both share, [..., K], or their two inputs stacked, [2, ..., K]; the result is stacked, [2, ..., N]."""
 
     @staticmethod
-    def forward(ctx, x, w0, w1, b0, b1, relu, rowdiv, shared, addend=None, tail=None, x_relu=False, premasked=False):
+    def forward(ctx, x, w0, w1, b0, b1, relu, rowdiv, shared, addend=None, tail=None, x_relu=False, premasked=False, slot=None):
         L = _L()
+        assert slot is None or not shared
         N, K = w0.shape
         assert w1.shape == w0.shape and (b0 is None) == (b1 is None)
         assert (not premasked or relu) and not (x_relu and shared)        # x_relu / premasked: see _LinearFn
@@ -291,6 +306,7 @@ class _Linear2Fn(torch.autograd.Function):
         ctx.params = params
         ctx.x_shape = x.shape
         ctx.rd_shape = None if rowdiv is None else rowdiv.shape
+        ctx.slot = slot
         return y.view(2, *lead, N + nt)
 
     @staticmethod
@@ -313,16 +329,23 @@ class _Linear2Fn(torch.autograd.Function):
         dev = dy.device
         stream = torch.cuda.current_stream(dev).cuda_stream
         st = ctypes.c_void_p(stream)
-        dx = torch.empty((2, M, K), dtype=torch.float32, device=dev) if need_x else None
+        acc_dx = False
+        slot = ctx.slot if need_x else None
+        if slot is not None and slot.buf is not None:
+            dx, acc_dx = slot.buf.view(2, M, K), True
+        else:
+            dx = torch.empty((2, M, K), dtype=torch.float32, device=dev) if need_x else None
+            if slot is not None:
+                slot.buf = dx
         drd = torch.empty((2, M), dtype=torch.float32, device=dev) if need_rd else None
         if need_x:
             xm = (xs[0], xs[1]) if ctx.x_relu else (None, None)
-            _check(L, L.sgrl_linear_dgrad_twin_xrelu(_p(dy2[0]), _p(dy2[1]), lddy, _p(None if yo is None else yo[0]),
-                                                     _p(None if yo is None else yo[1]), ldyo, 1 if ctx.mask else 0,
-                                                     _p(None if rd is None else rd[0]), _p(None if rd is None else rd[1]),
-                                                     _p(w0), _p(w1), K, _p(dx[0]), _p(dx[1]), K, _p(None if drd is None else drd[0]),
-                                                     _p(None if drd is None else drd[1]), _p(xm[0]), _p(xm[1]), xs.stride(-2), M, N, K, st),
-                   "sgrl_linear_dgrad_twin_xrelu")
+            _check(L, L.sgrl_linear_dgrad_twin_acc(_p(dy2[0]), _p(dy2[1]), lddy, _p(None if yo is None else yo[0]),
+                                                   _p(None if yo is None else yo[1]), ldyo, 1 if ctx.mask else 0,
+                                                   _p(None if rd is None else rd[0]), _p(None if rd is None else rd[1]),
+                                                   _p(w0), _p(w1), K, _p(dx[0]), _p(dx[1]), K, _p(None if drd is None else drd[0]),
+                                                   _p(None if drd is None else drd[1]), _p(xm[0]), _p(xm[1]), xs.stride(-2), M, N, K,
+                                                   1 if acc_dx else 0, st), "sgrl_linear_dgrad_twin_acc")
         elif need_rd:                               # the row divisor's gradient without an input gradient: the single-network kernel twice
             for i in range(2):
                 _check(L, L.sgrl_linear_backward(_p(dy2[i]), lddy, _p(yo[i]), ldyo, 0, _p(rd[i]), _p(None), 0, _p(None), 0, _p(None), 0,
@@ -350,14 +373,14 @@ class _Linear2Fn(torch.autograd.Function):
         if recs:
             flush_wgrads(recs)                      # w_param / b_param are None: nothing is stored, the gradients are returned below
         dx_out = None
-        if need_x:
+        if need_x and not acc_dx:
             dx_out = (dx[0] + dx[1]).view(ctx.x_shape) if ctx.shared else dx.view(ctx.x_shape)
         dadd = dy.reshape(ctx.ad_shape) if (ctx.ad_shape is not None and ctx.needs_input_grad[8]) else None
         dtail = None
         if nt and ctx.needs_input_grad[9]:
             dtail = dyf[:, :, N:].reshape(2, *ctx.x_shape[(0 if ctx.shared else 1):-1], nt).sum_to_size(ctx.tail_shape)
         return dx_out, grads_w[0], grads_w[1], grads_b[0], grads_b[1], None, (drd.view(ctx.rd_shape) if need_rd else None), None, dadd, dtail, \
-            None, None
+            None, None, None
 
 
 class _GramFn(torch.autograd.Function):
@@ -634,7 +657,57 @@ def _on_device_with_grad(*ts):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
 
 
-def linear(x, weight, bias=None, relu=False, rowdiv=None, addend=None, tail=None, x_relu=False, premasked=False):
+class _Slot(object):
+    """What the consumers of one fan_out() share during a backward pass: the buffer their input gradients are summed in."""
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+
+class _FanOutFn(torch.autograd.Function):
+    """x -> n aliases of x, one per consumer.  Consumers that are this module's linear layers are handed the slot and sum their
+    input gradients IN the slot's buffer, product by product (the input-gradient kernel's accumulate epilogue); whatever the other
+    consumers return is added here.  Without it autograd launches one element-wise addition per extra consumer: eight per SET layer
+    and pass (the vector stream feeds two projections and the residual, the invariant features two feed-forward pairs, ...)."""
+
+    @staticmethod
+    def forward(ctx, x, slot, n):
+        ctx.slot, ctx.x_shape = slot, x.shape
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        slot = ctx.slot
+        buf, slot.buf = slot.buf, None
+        total, owned = buf, buf is not None          # the slot's buffer is ours to add onto; a consumer's own gradient is not
+        for g in gs:
+            if g is None or (buf is not None and g.data_ptr() == buf.data_ptr() and g.numel() == buf.numel()):
+                continue                    # nothing, or the slot's own buffer as returned by its first consumer
+            g = g.reshape(ctx.x_shape)
+            if total is None:
+                total = g
+            elif owned:
+                total = total.view(ctx.x_shape).add_(g)
+            else:
+                total, owned = total + g, True
+        return (None if total is None else total.view(ctx.x_shape)), None, None
+
+
+_FAN_OUT = os.environ.get("SGRL_FAN_OUT", "1") != "0"       # A/B probe of round 6 (to be removed with the measurement)
+
+
+def fan_out(x, n):
+    """(slot, [n aliases of x]) where the own kernels differentiate x on the GPU, (None, [x] * n) otherwise.  Pass the slot to the
+    linear layers among x's consumers (linear / linear2 `slot=`), each with its OWN alias; any other consumer takes an alias too."""
+    if n > 1 and _FAN_OUT and _on_device_with_grad(x) and x.requires_grad:
+        slot = _Slot()
+        return slot, list(_FanOutFn.apply(x, slot, n))
+    return None, [x] * n
+
+
+def linear(x, weight, bias=None, relu=False, rowdiv=None, addend=None, tail=None, x_relu=False, premasked=False, slot=None):
     """act(x @ weight.T + bias) / rowdiv, differentiable in x, weight, bias and rowdiv (act = ReLU if relu; rowdiv: one value
     per row, broadcast over the output features -- the `/ F_norm` of the reference's SET layers).  Two followers can ride on
     the product's launch: `addend` (same shape as the result) is added to it -- a residual --, `tail` [..., t] is appended to it
@@ -643,8 +716,8 @@ def linear(x, weight, bias=None, relu=False, rowdiv=None, addend=None, tail=None
     layer's input gradient (_LinearFn); they change nothing in the forward and nothing outside the HIP path."""
     if _on_device_with_grad(x, weight, bias, rowdiv, addend, tail):
         if addend is None or (not relu and rowdiv is None and tail is None):
-            return _LinearFn.apply(x, weight, bias, bool(relu), rowdiv, addend, tail, bool(x_relu), bool(premasked))
-        y = _LinearFn.apply(x, weight, bias, bool(relu), rowdiv, None, None, bool(x_relu), bool(premasked))     # a follower the kernel does not take: own launches
+            return _LinearFn.apply(x, weight, bias, bool(relu), rowdiv, addend, tail, bool(x_relu), bool(premasked), slot)
+        y = _LinearFn.apply(x, weight, bias, bool(relu), rowdiv, None, None, bool(x_relu), bool(premasked), slot)     # a follower the kernel does not take: own launches
     else:
         y = F.linear(x, weight, bias)
         y = F.relu(y) if relu else y
@@ -686,14 +759,15 @@ def stacked3(a, b, c):
     return torch.cat([a, b, c], dim=0)
 
 
-def linear2(x, w0, w1, b0=None, b1=None, relu=False, rowdiv=None, shared=False, addend=None, tail=None, x_relu=False, premasked=False):
+def linear2(x, w0, w1, b0=None, b1=None, relu=False, rowdiv=None, shared=False, addend=None, tail=None, x_relu=False, premasked=False,
+            slot=None):
     """`linear` for the same layer of two networks at once: returns [2, ..., N]; x = the input both share ([..., K], shared=True) or
     their inputs stacked ([2, ..., K]); rowdiv stacked [2, ..., 1]; addend stacked [2, ..., N]; tail [2, ..., t] (or one both share,
     [..., t] / expanded)."""
     if _on_device_with_grad(x, w0, w1, b0, b1, rowdiv, addend, tail) and (addend is None or (not relu and rowdiv is None and tail is None)):
         if tail is not None and tail.dim() == x.dim() + (1 if shared else 0) and tail.stride(0) == 0:
             tail = tail[0]                          # an expanded pair: the one tensor both networks share
-        return _Linear2Fn.apply(x, w0, w1, b0, b1, bool(relu), rowdiv, bool(shared), addend, tail, bool(x_relu), bool(premasked))
+        return _Linear2Fn.apply(x, w0, w1, b0, b1, bool(relu), rowdiv, bool(shared), addend, tail, bool(x_relu), bool(premasked), slot)
     xs = (x, x) if shared else (x[0], x[1])
     ts = (None, None) if tail is None else ((tail[0], tail[1]) if tail.dim() == xs[0].dim() + 1 else (tail, tail))
     return torch.stack([linear(xs[0], w0, b0, relu, None if rowdiv is None else rowdiv[0], None if addend is None else addend[0], ts[0]),

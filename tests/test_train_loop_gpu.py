@@ -11,13 +11,15 @@ NAMES = ["3d_cheetah_10_tail_leftbleg", "3d_hopper_3_shin", "3d_humanoid_7_left_
 PER = [2, 3, 2, 3]
 
 
-def _trainer(max_episode_steps=40, seed=3):
+def _trainer(max_episode_steps=40, seed=3, lag_flag=False):
+    """lag_flag=False: the immediate round-finished flag, which the step-by-step re-enactments below follow (the trainer's default
+    reads it one step late: test_lagged_round_flag_stores_the_same_rows)."""
     import torch
     from sgrl_amd.td3 import default_train_args
     from sgrl_amd.train_loop import DeviceTrainer
     assert torch.cuda.is_available()
     args = default_train_args(max_episode_steps=max_episode_steps, batch_size=16)
-    return torch, DeviceTrainer(NAMES, PER, args=args, seed=seed, device="cuda:0", max_buffer_size=256)
+    return torch, DeviceTrainer(NAMES, PER, args=args, seed=seed, device="cuda:0", max_buffer_size=256, lag_flag=lag_flag)
 
 
 class _Tape(object):
@@ -316,3 +318,27 @@ def test_whole_gather_ingest_equals_block_by_block():
         assert a[5:] == b[5:]
         for ta, tb in zip(a[:5], b[:5]):
             assert torch.equal(ta, tb)
+
+
+def test_lagged_round_flag_stores_the_same_rows():
+    """DeviceTrainer's default reads the round-finished flag one step late (rollout.TransitionSink lag_flag: no host synchronisation
+    per collection step).  The late step's rows carry store = False everywhere, so warm-up rounds driven by the same seeds fill the
+    replay rings with exactly the rows of the immediate flag, end every round one step later, and report the same statistics."""
+    torch, a = _trainer(max_episode_steps=25, seed=9, lag_flag=False)
+    _, b = _trainer(max_episode_steps=25, seed=9, lag_flag=True)
+    assert b.sink.lag_flag and not a.sink.lag_flag
+    ends = {"a": [], "b": []}
+    stats = {"a": [], "b": []}
+    for key, tr in (("a", a), ("b", b)):
+        for t in range(1, 28 if key == "a" else 29):      # exactly one round: every environment is done by step 25 (time limit)
+            if tr.collect_step(random_actions=True):
+                ends[key].append(t)
+                stats[key].append((tr.sink.collector.episode_timesteps.clone(), tr.sink.collector.episode_reward.clone()))
+                break
+    assert len(ends["a"]) == 1 and ends["b"] == [ends["a"][0] + 1]
+    assert torch.equal(stats["a"][0][0], stats["b"][0][0]) and torch.equal(stats["a"][0][1], stats["b"][0][1])
+    for ba, bb in zip(a.buffers, b.buffers):
+        assert ba.max_sample_size == bb.max_sample_size and ba.curr == bb.curr and ba.max_sample_size > 0
+        n = ba.max_sample_size
+        for name in ("obs_buffer", "action_buffer", "next_obs_buffer", "reward_buffer", "done_buffer"):
+            assert torch.equal(getattr(ba, name)[:n], getattr(bb, name)[:n]), name

@@ -630,3 +630,61 @@ def test_triangular_gram_and_folded_weights_match_the_full_form(deferred):
     # the folded weight's gradient lands on both mirror columns
     gw = wd.grad.view(256, 32, 32)
     assert torch.equal(gw, gw.transpose(1, 2))
+
+
+@pytest.mark.parametrize("twin", [False, True], ids=["one_network", "twin"])
+def test_fan_out_sums_the_consumers_input_gradients_in_one_buffer(twin):
+    """train_ops.fan_out: a tensor feeding two linear layers (one behind a ReLU pair, one with appended columns) and a residual --
+    the SET layer's pattern (reference SEActor.py:93-121) -- gets the gradient autograd's own additions give it (float64 reference),
+    with the two products accumulating in one buffer (sgrl_linear_backward_acc / sgrl_linear_dgrad_twin_acc)."""
+    from sgrl_amd import train_ops
+    torch.manual_seed(11)
+    lead = (2,) if twin else ()
+    M, K = 333, 128
+    x0 = torch.randn(*lead, M, K)
+    wa, wb, wc = torch.randn(2, 64, K) / 11, torch.randn(2, 30, K) / 11, torch.randn(2, 40, 64) / 8
+    tail = torch.randn(*lead, M, 2)
+    da, db, dres = torch.randn(*lead, M, 40), torch.randn(*lead, M, 32), torch.randn(*lead, M, K)
+
+    def ref():
+        x = x0.double().requires_grad_()
+        tot = 0.0
+        for i in range(2 if twin else 1):
+            xi = x[i] if twin else x
+            ya = torch.relu(xi @ wa[i].double().T) @ wc[i].double().T
+            yb = torch.cat([xi @ wb[i].double().T, (tail[i] if twin else tail).double()], -1)
+            tot = tot + (ya * (da[i] if twin else da).double()).sum() + (yb * (db[i] if twin else db).double()).sum()
+        tot = tot + ((x * 3.0) * dres.double()).sum()
+        tot.backward()
+        return x.grad
+
+    def run(use_fan_out):
+        x = x0.cuda().requires_grad_()
+        h = x * 1.0                                           # a non-leaf, as inside a network
+        if use_fan_out:
+            slot, (h1, h2, h3) = train_ops.fan_out(h, 3)
+            assert slot is not None
+        else:
+            slot, (h1, h2, h3) = None, (h, h, h)
+        W = [[w[i].cuda().requires_grad_() for i in range(2)] for w in (wa, wb, wc)]
+        if twin:
+            hid = train_ops.linear2(h1, W[0][0], W[0][1], relu=True, premasked=True, slot=slot)
+            ya = train_ops.linear2(hid, W[2][0], W[2][1], x_relu=True)
+            yb = train_ops.linear2(h2, W[1][0], W[1][1], tail=tail.cuda(), slot=slot)
+        else:
+            hid = train_ops.linear(h1, W[0][0], relu=True, premasked=True, slot=slot)
+            ya = train_ops.linear(hid, W[2][0], x_relu=True)
+            yb = train_ops.linear(h2, W[1][0], tail=tail.cuda(), slot=slot)
+        ((ya * da.cuda()).sum() + (yb * db.cuda()).sum() + ((h3 * 3.0) * dres.cuda()).sum()).backward()
+        return x.grad, [w.grad for ws in W for w in ws if w.grad is not None]
+
+    gr = ref()
+    g1, w1 = run(True)
+    g0, w0 = run(False)
+    scale = float(gr.abs().max()) + 1.0
+    assert float((g1.cpu().double() - gr).abs().max()) < 3e-6 * scale
+    assert float((g0.cpu().double() - gr).abs().max()) < 3e-6 * scale
+    for a, b in zip(w1, w0):
+        assert torch.equal(a, b)                              # the weight gradients do not know about the fan-out
+    g1b, _ = run(True)
+    assert torch.equal(g1, g1b)                               # same order of accumulation every time: bit-reproducible

@@ -15,6 +15,7 @@ summary to ..._summary.json; the parent prints a progress line per minute and, a
 take-off := mean train return of the last five rounds > 1.5 x the random policy's (the warm-up rounds of the same process).
 
 usage: takeoff_table.py <arm> <rounds> <wall_cap_s> <seed> [<seed> ...]          (parent)
+       takeoff_table.py cells <rounds> <wall_cap_s> <arm>:<seed> [...]             (parent, mixed arms)
        takeoff_table.py --child <arm> <rounds> <wall_cap_s> <seed> <tag>          (one cell)
 """
 import json
@@ -28,7 +29,19 @@ OUT = os.path.join(REPO, "gpurun_out")
 ARMS = {
     "shipped": {},
     "control": {"SGRL_TRAIN_GEMM": "0", "SGRL_SET_GEMM": "f32"},
+    # the bisection of the gap the two arms above showed (the control takes off within 5-9 rounds, shipped within 25-30 or not at all)
+    "eager": {},                                             # own kernels, eager updates: plain Agent.update, torch's Adam
+    "vendor_graphed": {"SGRL_TRAIN_GEMM": "0"},              # vendor training ops under hipGraph replay + table optimizer
+    "setf32": {"SGRL_SET_GEMM": "f32"},                      # exact-f32 rollout / target products, everything else shipped
+    "vendor_eager": {"SGRL_TRAIN_GEMM": "0"},                # the control with the shipped rollout products
+    # the perturbation test: the same arms with every initial weight multiplied by (1 + 1e-6 N(0, 1)) -- no arithmetic changes, only
+    # a rounding-sized nudge of the starting point: does an arm's take-off survive it?
+    "control_p": {"SGRL_TRAIN_GEMM": "0", "SGRL_SET_GEMM": "f32", "TAKEOFF_PERTURB": "1e-6"},
+    "shipped_p": {"TAKEOFF_PERTURB": "1e-6"},
+    "eager_f32": {"SGRL_SET_GEMM": "f32"},                   # own training kernels, eager, exact-f32 rollout / target products
+    "eager_tableopt": {},                                    # own kernels, eager, but the trainer-path keywords + table optimizer
 }
+EAGER = {"control", "control_p", "eager", "vendor_eager", "eager_tableopt", "eager_f32"}
 PER_MORPH = 24
 HELD = {"3d_walker_3_left_knee_right_knee", "3d_walker_6_right_foot", "3d_humanoid_7_left_leg", "3d_humanoid_8_right_knee",
         "3d_cheetah_11_leftbkneen_rightffoot", "3d_cheetah_12_tail_leftffoot"}
@@ -44,7 +57,22 @@ def child(arm, rounds, cap, seed, tag):
     names = sorted(n for n in mjcf.list_assets() if n not in HELD)
     t0 = time.time()
     tr = DeviceTrainer(names, PER_MORPH, args=default_train_args(), seed=seed, device="cuda:0", max_buffer_size=100000,
-                       graph_updates=(arm != "control"))
+                       graph_updates=(arm not in EAGER), lag_flag=False)      # the immediate round flag in every cell: same collection schedule
+    if os.environ.get("TAKEOFF_PERTURB"):
+        eps = float(os.environ["TAKEOFF_PERTURB"])
+        g = torch.Generator(device="cuda").manual_seed(4242)
+        with torch.no_grad():
+            for src, tgt in ((tr.agent.actor, tr.agent.actor_target), (tr.agent.critic, tr.agent.critic_target)):
+                for p, q in zip(src.parameters(), tgt.parameters()):
+                    p.mul_(1.0 + eps * torch.randn(p.shape, device=p.device, generator=g))
+                    q.copy_(p)
+        tr.ro.weights_changed()
+    if arm == "eager_tableopt":
+        for opt in (tr.agent.actor_optimizer, tr.agent.critic_optimizer):
+            for g in opt.param_groups:
+                g["capturable"] = True
+        real_update = tr.agent.update
+        tr.agent.update = lambda batch, it, **kw: real_update(batch, it, lazy_stats=True, skip_unused_critic_grads=True)
     rand = []
     for _ in range(400):            # the random policy's level: warm-up rounds with uniform actions (trainer.py:90-138)
         if tr.collect_step(random_actions=True):
@@ -64,7 +92,7 @@ def child(arm, rounds, cap, seed, tag):
             f.write(json.dumps(rec) + "\n")
             f.flush()
     last5 = float(np.mean([r["return"] for r in curve[-5:]])) if curve else None
-    out = {"arm": arm, "env": ARMS[arm], "graphed_updates": arm != "control", "seed": seed, "rounds_done": len(curve),
+    out = {"arm": arm, "env": ARMS[arm], "graphed_updates": arm not in EAGER, "seed": seed, "rounds_done": len(curve),
            "random_policy_return": rand_mean, "first5_return": float(np.mean([r["return"] for r in curve[:5]])) if curve else None,
            "last5_return": last5, "last5_length": float(np.mean([r["length"] for r in curve[-5:]])) if curve else None,
            "took_off": bool(curve and rand_mean and last5 > 1.5 * rand_mean), "wall_s": round(time.time() - t0, 1),
@@ -74,28 +102,31 @@ def child(arm, rounds, cap, seed, tag):
 
 
 def parent(arm, rounds, cap, seeds, tag="r6_takeoff"):
+    """arm: one arm for every seed, or "cells" with seeds given as arm:seed pairs (at most six processes may use the GPU)."""
     os.makedirs(OUT, exist_ok=True)
-    env = dict(os.environ)
-    env.update(ARMS[arm])
+    cells = [(arm, int(s)) for s in seeds] if arm != "cells" else [(c.split(":")[0], int(c.split(":")[1])) for c in seeds]
+    assert len(cells) <= 6
     procs = []
-    for s in seeds:
+    for arm, s in cells:
+        env = dict(os.environ)
+        env.update(ARMS[arm])
         log = open(os.path.join(OUT, "%s_%s_s%d.log" % (tag, arm, s)), "w")
-        procs.append((s, subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child", arm, str(rounds), str(cap), str(s), tag],
-                                          env=env, stdout=log, stderr=subprocess.STDOUT), log))
+        procs.append(((arm, s), subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child", arm, str(rounds), str(cap), str(s), tag],
+                                                 env=env, stdout=log, stderr=subprocess.STDOUT), log))
     t0 = time.time()
     while any(p.poll() is None for _, p, _ in procs):
         time.sleep(60)
         state = []
-        for s, p, _ in procs:
+        for (arm, s), p, _ in procs:
             path = os.path.join(OUT, "%s_%s_s%d.jsonl" % (tag, arm, s))
             last = None
             if os.path.exists(path):
                 lines = open(path).read().strip().splitlines()
                 last = json.loads(lines[-1]) if lines else None
-            state.append("s%d:%s" % (s, "r%d %.1f" % (last["round"], last["return"]) if last else "-"))
+            state.append("%s/s%d:%s" % (arm[:8], s, "r%d %.1f" % (last["round"], last["return"]) if last else "-"))
         print("[%4.0f s] %s" % (time.time() - t0, "  ".join(state)), flush=True)
     rc = 0
-    for s, p, log in procs:
+    for (arm, s), p, log in procs:
         log.close()
         rc |= p.returncode
         sp = os.path.join(OUT, "%s_%s_s%d_summary.json" % (tag, arm, s))
@@ -113,4 +144,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "--child":
         child(sys.argv[2], int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]), sys.argv[6])
     else:
-        sys.exit(parent(sys.argv[1], int(sys.argv[2]), float(sys.argv[3]), [int(s) for s in sys.argv[4:]]))
+        sys.exit(parent(sys.argv[1], int(sys.argv[2]), float(sys.argv[3]), sys.argv[4:]))
