@@ -870,8 +870,7 @@ int launch_chain_ng(hipStream_t st, const float* A, int lda, int K1, const float
 // qkv | vg block (contiguous, 1536 floats per node), idle whenever these run.
 constexpr int kSmallNodesDefault = 2048;
 int small_nodes() {
-  static const int v = [] { const char* e = getenv("SGRL_SET_SMALL_NODES"); return e ? atoi(e) : kSmallNodesDefault; }();
-  return v;
+  return kSmallNodesDefault;       // (tests move the threshold per handle: sgrl_set_debug_small_nodes)
 }
 
 // A[n][0:576] = blocked lower triangle of Z'Z (order of the folded weights), fn[n] = ||Z'Z||_F + 1; one wave per node
@@ -1003,9 +1002,10 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   // float64) but LOSES to the two launches: a 64-row workgroup streams the 1 MB of linear4 words out of L2 twice as often as the
   // 128-row tiles do (587 MB per launch) and its three-instruction k-steps are barrier-bound -- 151 us against 135 us
   // (profiles/r4_chain_lab_ffn.txt).  SGRL_SET_CHAIN_EQ=1 selects it for A/B runs (SGRL_SET_FUSE_UPDATE=0: k_equiv stays a launch).
-  static const bool chain_eq = [] { const char* e = getenv("SGRL_SET_CHAIN_EQ"); return e && e[0] == '1'; }();
-  static const bool head_fold = [] { const char* e = getenv("SGRL_SET_HEAD_FOLD"); return !(e && e[0] == '0'); }();     // A/B: the unfolded head
-  static const bool fuse_update = [] { const char* e = getenv("SGRL_SET_FUSE_UPDATE"); return !(e && e[0] == '0'); }();
+  // linear3 -> ReLU -> linear4 -> contraction as ONE kernel (launch_chain_equiv) is written, tested in tools/chain_lab.hip and 12 % slower
+  // than its two launches (profiles/r4_chain_lab_ffn.txt): not part of the forward; the head folded through linear2_m and the fused
+  // residual update are (the A/B switches of rounds 4-5 are gone, their numbers are in LAB_LOG)
+  constexpr bool chain_eq = false, head_fold = true, fuse_update = true;
   float* const scratch = s->qkv;      // small path: [N, 576] Gram triangle / [N, 1024] per-node matrices (spans qkv | vg)
 #define G(...) do { rc = small ? small_gemm(st, __VA_ARGS__) : launch_gemm(st, __VA_ARGS__); if (rc != SGRL_OK) return rc; } while (0)
   auto gram_gemm = [&](const float* W_, const float* b_, float* C_, int ldc_, int N_) -> int {

@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(256) void k_opt_lerp(const OptRow* __restrict__ tab
 // grid of one product: tiles + the contraction split (weight gradient only, see above); fills a.kper / a.ws / a.counters
 // SGRL_TRAIN_RM=0 (probe): the transposing staging of rounds 2-4 instead of the row-major one
 bool row_major_staging() {
-  static const bool on = [] { const char* e = getenv("SGRL_TRAIN_RM"); return !(e && e[0] == '0'); }();
+  constexpr bool on = true;
   return on;
 }
 template <bool AT>
@@ -1353,7 +1353,7 @@ int sgrl_linear_wgrad_group(int n, const sgrl_wgrad_desc* d, float* ws, void* st
     // output tiles).
     int kt_min = 1 << 30;
     for (int g = 0; g < p.n; g++) kt_min = std::min(kt_min, (d[i0 + g].M + BKW - 1) / BKW);
-    static const bool big_on = [] { const char* e = getenv("SGRL_TRAIN_WGRAD64"); return !(e && e[0] == '0'); }();   // =0: probe, 32 x 32 tiles only
+    constexpr bool big_on = true;       // (round 5's probe switch SGRL_TRAIN_WGRAD64 is gone: the 64 x 64 tile is the product path)
     for (int g = 0; g < p.n; g++) {
       const sgrl_wgrad_desc& q = d[i0 + g];
       if (!q.dy || !q.x || !q.dw || q.M <= 0 || q.N <= 0 || q.K <= 0 || q.lddy < q.N || q.ldx < q.K || q.lddw < q.K ||
@@ -1370,7 +1370,7 @@ int sgrl_linear_wgrad_group(int n, const sgrl_wgrad_desc* d, float* ws, void* st
         // every workgroup of the launch walks about the same short chain of k-tiles whatever its product's size: in twelve EQUAL
         // products fewer, longer pieces win for the large outputs (1 024 x 256 unsplit: 127 us against 177), but in the update's mixed
         // groups the longest chain is the launch (7.31 ms per update with pieces of seven k-tiles, 7.69 with ~64 workgroups per product)
-        static const int per_split = [] { const char* e = getenv("SGRL_W64_KT"); return e ? std::max(1, atoi(e)) : 7; }();   // probe
+        constexpr int per_split = 7;
         const int splits = std::max(1, std::min(kt64 / per_split, 16));
         if (slot + (int64_t)tiles * splits * kSlots64 <= kWsTiles && counter + tiles <= kCounters) {
           p.big[g] = 1;
@@ -1383,11 +1383,11 @@ int sgrl_linear_wgrad_group(int n, const sgrl_wgrad_desc* d, float* ws, void* st
         }
       }
       if (!p.big[g]) {
-        // SGRL_W32_KT=7 (opt-in): since a split no longer costs fences, every 32 x 32-tile product of a group cut into pieces of about
-        // seven k-tiles as well: 7.28 -> 7.13 ms per update, same results to rounding (tests/test_wgrad_stress_gpu.py).  Not the
-        // default only because the committed config-5 learning curves (seed 3) were produced with the unsplit sums, and that
-        // configuration's take-off turned out to depend on rounding-level differences (LAB_LOG round 5, "a learning run ...")
-        static const int kt32 = [] { const char* e = getenv("SGRL_W32_KT"); return e ? atoi(e) : 0; }();
+        // since a split no longer costs fences, every 32 x 32-tile product of a group is cut into pieces of about seven k-tiles as
+        // well: 7.28 -> 7.13 ms per update, same results to rounding (tests/test_wgrad_stress_gpu.py).  Round 5 parked this behind
+        // SGRL_W32_KT because config 5's take-off had turned out to hang on rounding-level differences; round 6's take-off table
+        // (profiles/r6_takeoff) showed that it does so on EVERY arithmetic, the vendor libraries' included: the default since.
+        constexpr int kt32 = 7;
         int even = (!ws_eff && ws && kt_min >= 4 && kt >= 2 * kt_min) ? kt / kt_min : 0;
         if (kt32 > 0 && ws && kt >= 2 * kt32) even = kt / kt32;
         const int rc = plan<true>(a, even ? ws : ws_eff, &p.gx[g], &p.gy[g], &p.nz[g], slot, counter, even);

@@ -4,7 +4,6 @@ and the random-action warm-up loop trainer.py:90-138), with the same per-environ
 launch and ONE batched SET forward per time step, plus the replay push as a single gather to the learner rank.
 """
 import ctypes
-import os
 
 import numpy as np
 import torch
@@ -15,8 +14,7 @@ from .set_hip import HipSetActor
 from .vec_env import BatchedModularVecEnv
 
 TRAV = ["pre", "inlcrs", "postlcrs"]
-# SGRL_FUSED_INGEST=0: the learner writes a gathered block morphology by morphology with indexed copies (the CPU path) on the GPU too
-FUSED_INGEST = os.environ.get("SGRL_FUSED_INGEST", "1") != "0"
+FUSED_INGEST = True      # False (tests): the learner writes a gathered block morphology by morphology with indexed copies (the CPU path) on the GPU too
 
 
 class Rollout(object):

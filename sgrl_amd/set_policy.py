@@ -22,10 +22,7 @@ import torch.nn.functional as F
 
 from . import train_ops
 
-import os
-
-# SGRL_TWIN_CRITICS=0: the two critics one after the other, as the reference runs them (A/B comparisons)
-TWIN_CRITICS = os.environ.get("SGRL_TWIN_CRITICS", "1") != "0"
+TWIN_CRITICS = True      # False (tests): the two critics one after the other, as the reference runs them
 G_NUM = 8          # 3-vectors per limb observation (reference SEActor.py:205)
 Z_DIM = 32         # invariant channel count (30 projected + gravity + direction)
 
@@ -441,12 +438,13 @@ def make_policy(device=None, use_hip=True, max_action=1.0):
     return SEPolicy(41, 3, 32, 1, max_action, 3, True, False, False, default_args(), device=device, use_hip=use_hip)
 
 
-# SGRL_TWIN_TARGETS=1: the no-grad target critics through twin_forward (one pass of the training kernels for both networks) instead of
-# two passes of set_actor.hip: same values (tests/test_set_gpu.py, tools/diag/twin_target_check.py: 1e-6 of the scale on every
-# shipped morphology, synthetic and real replay rows) and 0.11 ms faster per update.  Opt-in only because the committed config-5
-# learning curves (seed 3) were produced without it and that configuration's take-off depends on rounding-level differences
-# (LAB_LOG round 5: seed 4 does not take off with the shipped arithmetic either).
-TWIN_TARGETS = os.environ.get("SGRL_TWIN_TARGETS", "0") == "1"
+# The no-grad target critics walk twin_forward (one pass of the training kernels for both networks) instead of two passes of
+# set_actor.hip: same values (tests/test_set_gpu.py, tools/diag/twin_target_check.py: 1e-6 of the scale on every shipped morphology,
+# synthetic and real replay rows) and 0.11 ms faster per update.  Round 5 parked it behind SGRL_TWIN_TARGETS because a config-5 run
+# with it had stayed flat; round 6's take-off table (profiles/r6_takeoff: five seeds x two arithmetic arms + bisection cells and a
+# 1e-6 perturbation of the initial weights) showed that this configuration's take-off flips with rounding-sized nudges on every
+# arithmetic, the vendor libraries' included -- the switch is gone.  False (tests): two passes of the rollout kernels.
+TWIN_TARGETS = True
 
 
 class SECritic(nn.Module):

@@ -55,11 +55,11 @@ def soft_update_network(source_network, target_network, tau):
                 t.copy_(tau * l + (1 - tau) * t)
 
 
-# SGRL_FUSED_ADAM=0: the foreach chain (bit-compatible with torch.optim.Adam's multi-tensor path) instead of the fused kernel
-_FUSED_ADAM = os.environ.get("SGRL_FUSED_ADAM", "1") != "0" and hasattr(torch, "_fused_adam_")
+# False: the foreach chain (bit-compatible with torch.optim.Adam's multi-tensor path) instead of the fused kernel
+_FUSED_ADAM = hasattr(torch, "_fused_adam_")
 # Gradient clipping + Adam, and the soft target update, over a device TABLE of tensor addresses (csrc/train_gemm.hip k_opt_*,
 # include/sgrl_train.h sgrl_optim_*): three launches and one instead of torch's ~50 multi-tensor launches of ~18 us per update.
-_TABLE_OPT = os.environ.get("SGRL_TABLE_OPT", "1") != "0"
+_TABLE_OPT = True
 _tables = {}          # key (kind, address tuple) -> dict(dev table, dev chunks, pinned copies, scratch): see _table()
 _capture_owner = None  # whoever is capturing a hipGraph right now (GraphedUpdates: (id, morphology key, flag)); see release_tables()
 
@@ -500,8 +500,9 @@ class GraphedUpdates(object):
                 g["capturable"] = True
         self.slots = {}            # key -> dict(static tensors, graphs)
         self.warmed = set()
-        # SGRL_SPLIT_UPDATE_GRAPHS=1: target chain and critic forward as graphs of their own, replayed on two streams
-        self.split = os.environ.get("SGRL_SPLIT_UPDATE_GRAPHS", "0") == "1"
+        # True (tools/diag/split_update_graphs_probe.py): target chain and critic forward as graphs of their own, replayed on two
+        # streams -- measured 1-2 % faster per update (LAB_LOG round 3), not the default
+        self.split = False
         self._cap_stream = self._side = None
 
     def _slot(self, key, graph, L):

@@ -695,7 +695,7 @@ class _FanOutFn(torch.autograd.Function):
         return (None if total is None else total.view(ctx.x_shape)), None, None
 
 
-_FAN_OUT = os.environ.get("SGRL_FAN_OUT", "1") != "0"       # A/B probe of round 6 (to be removed with the measurement)
+_FAN_OUT = True      # False (tests, A/B): every consumer's input gradient through autograd's own additions
 
 
 def fan_out(x, n):
@@ -782,7 +782,7 @@ def gram_fn(z):
     return gram, gram.norm(dim=-1, keepdim=True) + 1.0
 
 
-TRI_GRAM = os.environ.get("SGRL_TRI_GRAM", "1") != "0"      # 0: the invariant layers on all 1 024 entries of Z'Z (rounds 2-4)
+TRI_GRAM = True      # False (tests): the invariant layers on all 1 024 entries of Z'Z (rounds 2-4)
 
 
 def tri_weights(weights, like):

@@ -132,18 +132,14 @@ def test_teacher_forced_parity_with_divergent_halves(monkeypatch):
 def test_all_light_batches_take_the_paired_family_kernels(monkeypatch):
     """A batch of light morphologies only used to run on the four-waves-per-SIMD light kernel; with every morphology pairable it
     now takes the family kernels two environments per wavefront (profiles/r5_light_pair_probe.txt: 21-28 % faster).
-    SGRL_LIGHT_KERNEL=1 keeps the light kernel.  Both agree with the oracle."""
+    SGRL_PAIR=0 keeps the light kernel.  Both agree with the oracle."""
     import torch
     from sgrl_amd.vec_env import BatchedModularVecEnv
     names = ["3d_hopper_3_shin", "3d_walker_3_left_knee_right_knee"]
     monkeypatch.delenv("SGRL_SPECS", raising=False)
-    monkeypatch.setenv("SGRL_PAIR", "1")
     outs = []
     for lk in (None, "1"):
-        if lk is None:
-            monkeypatch.delenv("SGRL_LIGHT_KERNEL", raising=False)
-        else:
-            monkeypatch.setenv("SGRL_LIGHT_KERNEL", lk)
+        monkeypatch.setenv("SGRL_PAIR", "1" if lk is None else "0")
         env = BatchedModularVecEnv(names, 4, seed=6, device="cuda:0")
         assert env.fixed_dim_groups == 2 and env.paired_envs == (8 if lk is None else 0)
         env.enable_f64_outputs()

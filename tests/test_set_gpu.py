@@ -160,7 +160,7 @@ def test_critic_hip_path_matches_reference_fixtures_and_torch_path():
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "critic_forward.npz"))
     crit = make_critic(device="cuda:0").eval()
     apply_formula_(crit)
-    set_policy.TWIN_TARGETS = True        # (off by default: see set_policy.py; the values of both paths are checked here)
+    assert set_policy.TWIN_TARGETS           # the default since round 6 (set_policy.py); the values of both paths are checked here
     for name in sorted({k.split("/")[0] for k in z.files}):
         m = mjcf.load_asset(name)
         crit.change_morphology(G.getGraphDict(m.parents, ["pre", "inlcrs", "postlcrs"], [], device=torch.device("cuda:0")))
@@ -196,7 +196,7 @@ def test_critic_hip_path_matches_reference_fixtures_and_torch_path():
     crit.use_hip = True
     q = crit.Q1(obs, act.clone().requires_grad_(True))
     assert q.requires_grad
-    set_policy.TWIN_TARGETS = False
+    assert set_policy.TWIN_TARGETS
 
 
 def _soft_update_like_the_reference(source, target, tau):

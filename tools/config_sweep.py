@@ -22,7 +22,10 @@ CONFIGS = {
 }
 pol = make_policy(device="cuda:0").eval()
 out = {}
+out["_lib"] = os.environ.get("SGRL_HIP_LIB", "sgrl_amd/libsgrl_hip.so")
 for name, (names, counts) in CONFIGS.items():
+    if os.environ.get("SWEEP_ONLY") and not any(k in name for k in os.environ["SWEEP_ONLY"].split(",")):
+        continue
     ro = Rollout(names, counts, policy=pol, seed=3, device="cuda:0")
     env = ro.env
     ro.reset()
@@ -50,5 +53,5 @@ for name, (names, counts) in CONFIGS.items():
     env.close()
     del ro
 os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-with open(os.path.join(REPO, "gpurun_out", "config_sweep.json"), "w") as f:
+with open(os.path.join(REPO, "gpurun_out", os.environ.get("SWEEP_OUT", "config_sweep.json")), "w") as f:
     json.dump(out, f, indent=1)

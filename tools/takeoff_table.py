@@ -55,8 +55,12 @@ def child(arm, rounds, cap, seed, tag):
     from sgrl_amd.td3 import default_train_args
     from sgrl_amd.train_loop import DeviceTrainer
     names = sorted(n for n in mjcf.list_assets() if n not in HELD)
+    per = PER_MORPH
+    if os.environ.get("TAKEOFF_FAMILY"):          # a cheaper proxy: one family (BASELINE config 2 / 3 / 4), 64 environments per morphology
+        names = sorted(n for n in mjcf.list_assets() if os.environ["TAKEOFF_FAMILY"] in n and n not in HELD)
+        per = int(os.environ.get("TAKEOFF_PER_MORPH", "64"))
     t0 = time.time()
-    tr = DeviceTrainer(names, PER_MORPH, args=default_train_args(), seed=seed, device="cuda:0", max_buffer_size=100000,
+    tr = DeviceTrainer(names, per, args=default_train_args(), seed=seed, device="cuda:0", max_buffer_size=100000,
                        graph_updates=(arm not in EAGER), lag_flag=False)      # the immediate round flag in every cell: same collection schedule
     if os.environ.get("TAKEOFF_PERTURB"):
         eps = float(os.environ["TAKEOFF_PERTURB"])
@@ -101,7 +105,7 @@ def child(arm, rounds, cap, seed, tag):
     print(json.dumps(out), flush=True)
 
 
-def parent(arm, rounds, cap, seeds, tag="r6_takeoff"):
+def parent(arm, rounds, cap, seeds, tag=os.environ.get("TAKEOFF_TAG", "r6_takeoff")):
     """arm: one arm for every seed, or "cells" with seeds given as arm:seed pairs (at most six processes may use the GPU)."""
     os.makedirs(OUT, exist_ok=True)
     cells = [(arm, int(s)) for s in seeds] if arm != "cells" else [(c.split(":")[0], int(c.split(":")[1])) for c in seeds]
