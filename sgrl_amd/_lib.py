@@ -26,9 +26,13 @@ class SgrlError(RuntimeError):
 # ---- fixed-dimension instances of the step kernel (csrc/step_spec.hip) -----------------------------------------------------
 HDR_DIM_FIELDS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 16, 18)   # NBODY NJNT NQ NV NU NGEOM NPAIR INTEGRATOR FRAME_SKIP MAX_ROWS SOLVER
 LIGHT_NV = 12                                           # dimension sets up to this many dofs form the "light" kernels (4 waves per SIMD)
-# families whose step kernel reads the int tables where they lie (constant address space) instead of from an LDS copy
-# (csrc/engine_kernel.h SGRL_ITAB_GLOBAL): the slab shrinks by the tables' 2.4-3.4 KB
-ITAB_GLOBAL = set(x for x in os.environ.get("SGRL_BUILD_ITAB_GLOBAL", "").split(",") if x)
+# Families whose step kernel reads the int tables where they lie (constant address space) instead of from an LDS copy
+# (csrc/engine_kernel.h SGRL_ITAB_GLOBAL): the slab loses the tables' 2.2-3.4 KB, keeps its contact frames as 6 doubles and takes the row
+# cut that gives the MOST resident workgroups (step_body.h make_layout, floor 19).  Round 6 measured it (profiles/r6_slab_diet.json):
+# humanoid++ gains a seventh resident (humanoid_9 26 672 -> 23 008 B) and 2 % (k_env_step 2.53 -> 2.48 ms, step + forward 4.47 -> 4.38);
+# the cheetah family gains nothing (cheetah_14 stays at four residents: 39 208 B against the 32 000 five would need) and loses 4 % to
+# the global reads -- so: the humanoid family only.  SGRL_BUILD_ITAB_GLOBAL=<family,...> (or "none") at build time overrides.
+ITAB_GLOBAL = set(x for x in os.environ.get("SGRL_BUILD_ITAB_GLOBAL", "humanoid").split(",") if x and x != "none")
 PAIR_NV = {"walker": 15, "hopper": 15}                              # sets up to this many dofs get the two-environments-per-wavefront instance (default LIGHT_NV)
 
 

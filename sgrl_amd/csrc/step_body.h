@@ -211,10 +211,16 @@ SGRL_HD void make_layout(const int32_t* hdr, Layout* o, int n_int = 0, int n_f64
     }
     return;
   }
-  for (int cut = 1; cut <= kMaxRowCut && o->lrows - cut >= 20; cut++) {
+  // (dieted layouts -- n_int == 0: a kernel that reads the int tables from global memory -- may go down to 19 rows: humanoid_9 then
+  // fits seven times into a CU's LDS, 23 008 B, where its default layout already runs at 21 rows for six)
+  const int floor_rows = n_int == 0 ? 19 : 20;
+  int best = base;
+  const int natural = o->lrows;
+  for (int cut = 1; cut <= kMaxRowCut && natural - cut >= floor_rows; cut++) {
     Layout t;
     make_layout_rows(hdr, &t, n_int, n_f64, cut, pair);
-    if (workgroups_per_cu(layout_bytes(&t)) > base) { *o = t; return; }
+    const int w = workgroups_per_cu(layout_bytes(&t));
+    if (w > best) { *o = t; best = w; if (n_int != 0) return; }      // default layouts: the first step up (as tuned in rounds 3-4); dieted: the highest
   }
 }
 
