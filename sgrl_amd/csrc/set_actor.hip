@@ -935,6 +935,12 @@ int run_forward(sgrl_set* s, const float* obs, int obs_ld, float* act, int act_l
   const int ngf = critic ? 20 : 17;
   g_gemm.form = s->gemm_form ? s->gemm_form : gemm_default_form();
   if (!s->live || !s->wwords) g_gemm.form = SGRL_SET_FORM_BF16X6;   // the two-piece form takes W pre-split by k_pack (bound parameters)
+  // SGRL_SET_GEMM=f32: the plain products run on the exact-f32 kernels and nobody encodes the weights' words -- the generated-operand
+  // products (Gram, equivariant, LayerNorm epilogue), which are always split kernels, must then take the three-piece form, which
+  // splits the f32 weights itself.  (Rounds 4-5 left them on the two-piece form in that mode: they read words that had never been
+  // written, and every forward of 2 048 nodes or more under SGRL_SET_GEMM=f32 returned garbage -- found in round 6 through the
+  // "control" arm of the learning A/B, tools/diag/stale_pack_probe.py; tests/test_set_gpu.py now runs the mode.)
+  if (!gemm_use_split()) g_gemm.form = SGRL_SET_FORM_BF16X6;
   g_gemm.w_base = s->w;
   g_gemm.w_words = s->wwords;
   g_gemm.wsc = s->wsc;

@@ -515,3 +515,22 @@ def test_rollout_notices_the_librarys_own_raw_pointer_updates():
     v1 = [p._version for p in tgt.parameters()]
     td3.soft_update_network(pol, tgt, 0.5)
     assert all(p._version > v for p, v in zip(tgt.parameters(), v1))
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x6"])
+def test_the_ab_product_forms_of_the_environment_are_forwards_too(mode):
+    """SGRL_SET_GEMM=f32 / bf16x6 (read once per process: a child process each) on both sides of the small-batch threshold, with and
+    without a weight hold, before and after a parameter change: the HIP forward equals the PyTorch path.  Round 6 found the f32 mode
+    returning garbage from 2 048 nodes on (its generated-operand products read weight words nobody had encoded) -- the arm the
+    learning A/B had used as its control."""
+    import re
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "diag", "stale_pack_probe.py")], env=dict(os.environ, SGRL_SET_GEMM=mode),
+                       capture_output=True, text=True, timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("SGRL_SET_GEMM=" + mode)]
+    assert len(lines) == 3, r.stdout + r.stderr
+    for l in lines:
+        before, after = (float(x) for x in re.findall(r"(?:before the change|weights_changed\(\)) ([0-9.e+-]+|nan)", l))
+        assert before < 2e-6 and after < 2e-6, l
