@@ -20,8 +20,9 @@ for f in sorted(glob.glob(os.path.join(root, "**", prefix + "*.jsonl"), recursiv
     up = ret > 1.5 * rnd
     take = next((i + 1 for i in range(len(up) - 2) if up[i] and up[i + 1] and up[i + 2]), None)
     m = lambda a: ("%.0f" % np.nanmean(a)) if len(a) else "-"
-    rows.append((arm, int(seed), len(ret), rnd, m(ret[:5]), m(ret[5:10]), m(ret[-5:]), np.nanmax(ret), take, summ.get("updates"), summ.get("wall_s")))
-print("| arm | seed | rounds | random | rounds 1-5 | rounds 6-10 | last 5 | best round | take-off round | updates | wall s |")
-print("|---|---|---|---|---|---|---|---|---|---|---|")
-for r in rows:
-    print("| %s | %d | %d | %.1f | %s | %s | %s | %.0f | %s | %s | %s |" % (r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8] if r[8] else "-", r[9], ("%.0f" % r[10]) if r[10] else "-"))
+    where = os.path.relpath(os.path.dirname(f), root)
+    rows.append((where if where != "." else "main", arm, int(seed), len(ret), rnd, m(ret[:5]), m(ret[5:10]), m(ret[-5:]), np.nanmax(ret), take, summ.get("updates"), summ.get("wall_s")))
+print("| set | arm | seed | rounds | random | rounds 1-5 | rounds 6-10 | last 5 | best round | take-off round | updates | wall s |")
+print("|---|---|---|---|---|---|---|---|---|---|---|---|")
+for r in sorted(rows):
+    print("| %s | %s | %d | %d | %.1f | %s | %s | %s | %.0f | %s | %s | %s |" % (r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9] if r[9] else "-", r[10], ("%.0f" % r[11]) if r[11] else "-"))
