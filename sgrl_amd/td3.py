@@ -493,6 +493,11 @@ class GraphedUpdates(object):
         dev = agent.device
         if dev.type != "cuda":
             raise RuntimeError("GraphedUpdates needs the agent on the GPU")
+        if not train_ops.ENABLED:
+            # round 6: a config-5 run of this combination went NaN in its third round (profiles/r6_takeoff/bisect
+            # r6_takeoff_vendor_graphed_*); the vendor path is an A/B arm for EAGER updates, nobody has made its capture sound
+            raise RuntimeError("GraphedUpdates replays this library's own training kernels: with SGRL_TRAIN_GEMM=0 (vendor kernels) run the "
+                               "updates eagerly (DeviceTrainer(graph_updates=False))")
         for opt in (agent.actor_optimizer, agent.critic_optimizer):
             if opt.state:
                 raise RuntimeError("switch to graphed updates before the first optimizer step (Adam's step counters must be device tensors)")

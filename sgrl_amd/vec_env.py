@@ -181,6 +181,7 @@ class BatchedModularVecEnv(VecEnv):
         self.obs64 = None
         self.rew64 = None
         self._overflow_seen = np.zeros(n, dtype=np.int64)
+        self.overflow_check_every, self._steps_since_overflow_check = 16, 0
 
     # ---- device surface ---------------------------------------------------------------------------
     def _stream(self):
@@ -313,9 +314,15 @@ class BatchedModularVecEnv(VecEnv):
         dist = sec("dist").view(np.float32)
         trunc = sec("trunc")
         extra = None
-        # truncated contact sets must not go unnoticed: report newly dropped constraint rows in the info dict + a warning
-        over = self.get_counters()[:, 2]
-        if (over > self._overflow_seen).any():
+        # truncated contact sets must not go unnoticed: newly dropped constraint rows are reported in the info dict + a warning.  The
+        # counters live in engine memory (a synchronous 128 KB copy of their own): looked at every 16th step -- a report comes at most
+        # 15 steps late, the counts themselves lose nothing (row_overflow_envs() reads them at any time)
+        self._steps_since_overflow_check += 1
+        over = None
+        if self._steps_since_overflow_check >= self.overflow_check_every:
+            self._steps_since_overflow_check = 0
+            over = self.get_counters()[:, 2]
+        if over is not None and (over > self._overflow_seen).any():
             import warnings
             over = over.astype(np.int64)
             new = np.nonzero(over > self._overflow_seen)[0]

@@ -171,10 +171,29 @@ def test_numpy_vecenv_surface_matches_reference_conventions():
     r.astype(np.float32)
     d2 = d.astype(np.float32)
     d2[0] = True  # item assignment like trainer.py:212
-    o2, r2, d3, _ = env.step(acts)
+    o_keep, r_keep, dist_keep = o.copy(), r.copy(), [infos[i]["dist"] for i in range(8)]
+    o2, r2, d3, infos2 = env.step(acts)
     assert np.isfinite(o2).all()
+    # every step hands out its OWN host arrays (views of one pinned block per step): the previous step's are untouched
+    assert np.array_equal(o, o_keep) and np.array_equal(r, r_keep) and [infos[i]["dist"] for i in range(8)] == dist_keep
+    assert not np.array_equal(o2, o) and isinstance(infos2[3], dict) and len(tuple(infos2)) == 8
+    # the three forms a trainer may hand actions in: a list of float32 arrays (buffer-protocol flatten), of float64 arrays, an ndarray
+    env_b = BatchedModularVecEnv(names, 1, seed=0, device="cuda:0")
+    env_c = BatchedModularVecEnv(names, 1, seed=0, device="cuda:0")
+    env_d = BatchedModularVecEnv(names, 1, seed=0, device="cuda:0")
+    for e in (env_b, env_c, env_d):
+        e.reset()
+    a32 = [np.random.RandomState(i).uniform(-1, 1, size=env.action_max_len).astype(np.float32) for i in range(8)]
+    ob, rb, _, _ = env_b.step(a32)
+    oc, rc, _, _ = env_c.step([x.astype(np.float64) for x in a32])
+    od, rd, _, _ = env_d.step(np.stack(a32))
+    assert np.array_equal(ob, oc) and np.array_equal(ob, od) and np.array_equal(rb, rc) and np.array_equal(rb, rd)
+    for e in (env_b, env_c, env_d):
+        e.close()
     with pytest.raises(ValueError):
         env.step_async([np.zeros(5)] * 8)
+    with pytest.raises(ValueError):
+        env.step_async([np.zeros(env.action_max_len, dtype=np.float32)] * 7)
     env.close()
     assert env.closed
 
