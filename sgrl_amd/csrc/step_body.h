@@ -211,16 +211,32 @@ SGRL_HD void make_layout(const int32_t* hdr, Layout* o, int n_int = 0, int n_f64
     }
     return;
   }
-  // (dieted layouts -- n_int == 0: a kernel that reads the int tables from global memory -- may go down to 19 rows: humanoid_9 then
-  // fits seven times into a CU's LDS, 23 008 B, where its default layout already runs at 21 rows for six)
-  const int floor_rows = n_int == 0 ? 19 : 20;
-  int best = base;
-  const int natural = o->lrows;
-  for (int cut = 1; cut <= kMaxRowCut && natural - cut >= floor_rows; cut++) {
+  if (n_int == 0) {
+    // Dieted layouts (a kernel that reads the int tables from global memory: engine_kernel.h SGRL_ITAB_GLOBAL): the row cut that gives
+    // the MOST residents, down to 19 rows -- humanoid_9 then fits seven times into a CU's LDS (23 008 B) where its default layout
+    // already runs at 21 rows for six.  Two plain loops (the highest count, then the first cut that reaches it) so that a
+    // fixed-dimension kernel still folds the whole layout into constants; the default layouts below keep the loop rounds 3-4 tuned
+    // (any other shape of it cost the walker kernel its constant layout: 71 spilled registers, twice the store traffic).
+    const int natural = o->lrows;
+    int best = base;
+    for (int cut = 1; cut <= kMaxRowCut && natural - cut >= 19; cut++) {
+      Layout t;
+      make_layout_rows(hdr, &t, n_int, n_f64, cut, pair);
+      const int w = workgroups_per_cu(layout_bytes(&t));
+      if (w > best) best = w;
+    }
+    if (best == base) return;
+    for (int cut = 1; cut <= kMaxRowCut && natural - cut >= 19; cut++) {
+      Layout t;
+      make_layout_rows(hdr, &t, n_int, n_f64, cut, pair);
+      if (workgroups_per_cu(layout_bytes(&t)) == best) { *o = t; return; }
+    }
+    return;
+  }
+  for (int cut = 1; cut <= kMaxRowCut && o->lrows - cut >= 20; cut++) {
     Layout t;
     make_layout_rows(hdr, &t, n_int, n_f64, cut, pair);
-    const int w = workgroups_per_cu(layout_bytes(&t));
-    if (w > best) { *o = t; best = w; if (n_int != 0) return; }      // default layouts: the first step up (as tuned in rounds 3-4); dieted: the highest
+    if (workgroups_per_cu(layout_bytes(&t)) > base) { *o = t; return; }
   }
 }
 
