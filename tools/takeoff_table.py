@@ -61,7 +61,7 @@ def child(arm, rounds, cap, seed, tag):
         per = int(os.environ.get("TAKEOFF_PER_MORPH", "64"))
     t0 = time.time()
     tr = DeviceTrainer(names, per, args=default_train_args(), seed=seed, device="cuda:0", max_buffer_size=100000,
-                       graph_updates=(arm not in EAGER), lag_flag=False)      # the immediate round flag in every cell: same collection schedule
+                       graph_updates=(arm not in EAGER), lag_flag=os.environ.get("TAKEOFF_LAG", "0") == "1")      # the immediate round flag in every cell of the table (same collection schedule); TAKEOFF_LAG=1: the trainer's default
     if os.environ.get("TAKEOFF_PERTURB"):
         eps = float(os.environ["TAKEOFF_PERTURB"])
         g = torch.Generator(device="cuda").manual_seed(4242)
