@@ -100,6 +100,15 @@ int sgrl_pack_transitions(const float* obs, int ld_obs, const float* action, int
                           const float* reward, const float* done_f32, const uint8_t* done_u8, const uint8_t* store,
                           const int64_t* morph_id, float* block, int n_env, int obs_len, int act_len, void* stream);
 
+/* The collection-round bookkeeping of the reference's loop (reference src/trainer.py:205-232: episode_timesteps_list, done_list, the
+ * time-limit rule `done_bool = 0 if episode_timesteps + 1 == max_episode_steps`, episode_reward_list / its buffer) for all n_env
+ * environments of a rank in one launch, on DEVICE arrays the caller owns: reward f32 / done u8 as sgrl_step wrote them; state
+ * done_list u8, ep_steps int64, ep_reward f32, reward_buf f32 (all zero at the start of a round); outputs store u8 (the row belongs to
+ * the environment's first episode of the round) and done_bool f32 (the `done` to store) -- what sgrl_pack_transitions takes -- and
+ * all_done (one int32: non-zero when every environment has finished its first episode). */
+int sgrl_round_record(const float* reward, const uint8_t* done, uint8_t* done_list, int64_t* ep_steps, float* ep_reward, float* reward_buf,
+                      uint8_t* store, float* done_bool, int32_t* all_done, int n_env, int max_episode_steps, void* stream);
+
 /* The learner's side of the replay push: the kept rows of one gathered block (format above) go into the ring buffers of their
  * morphologies -- reference common/buffer.py:75-84 `add_transition` once per stored row, one buffer per morphology
  * (main.py:141-155), the block walked in global environment order (trainer.py:205-236) -- in ONE launch.  Row r is written to

@@ -183,6 +183,7 @@ def lib():
     L.sgrl_pack_transitions.argtypes = [vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]
     L.sgrl_ingest_rows.argtypes = [vp, ci, ci, ci, vp, vp, ci, vp]
     L.sgrl_ingest_block.argtypes = [vp, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp]
+    L.sgrl_round_record.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]
     L.sgrl_ingest_ws_words.argtypes = [ci]
     L.sgrl_ingest_ws_words.restype = ctypes.c_int64
     _lib = L
@@ -190,7 +191,7 @@ def lib():
 
 
 EXPORTS = ["sgrl_engine_create", "sgrl_engine_destroy", "sgrl_num_envs", "sgrl_record_stride", "sgrl_lds_bytes", "sgrl_launch_groups", "sgrl_fixed_dim_groups", "sgrl_paired_envs",
-           "sgrl_reset", "sgrl_step", "sgrl_get_records", "sgrl_set_records", "sgrl_refresh", "sgrl_time_steps", "sgrl_pack_transitions", "sgrl_ingest_rows", "sgrl_ingest_block", "sgrl_ingest_ws_words",
+           "sgrl_reset", "sgrl_step", "sgrl_get_records", "sgrl_set_records", "sgrl_refresh", "sgrl_time_steps", "sgrl_pack_transitions", "sgrl_round_record", "sgrl_ingest_rows", "sgrl_ingest_block", "sgrl_ingest_ws_words",
            "sgrl_last_error", "sgrl_version"]
 
 

@@ -14,6 +14,7 @@ from .set_hip import HipSetActor
 from .vec_env import BatchedModularVecEnv
 
 TRAV = ["pre", "inlcrs", "postlcrs"]
+FUSED_RECORD = True      # False (tests): RoundCollector's bookkeeping as tensor operations on the GPU too
 FUSED_INGEST = True      # False (tests): the learner writes a gathered block morphology by morphology with indexed copies (the CPU path) on the GPU too
 
 
@@ -274,6 +275,8 @@ class RoundCollector(object):
         done_to_store float[n], round_finished).  Rows where store_mask is False are dropped (trainer.py:218).
         round_finished: a Python bool (ONE host synchronisation), or with sync=False the 0-dim bool tensor it would be read from
         (TransitionSink reads it a step late through pinned memory instead of stalling the step on it)."""
+        if self.device.type == "cuda" and FUSED_RECORD:
+            return self._record_hip(reward, curr_done, sync)
         curr_done = curr_done.to(torch.bool).clone()
         done_bool = curr_done.to(torch.float32)
         timeout = (self.episode_timesteps + 1) == self.max_episode_steps
@@ -288,6 +291,26 @@ class RoundCollector(object):
         self.done_list |= store & curr_done
         fin = self.done_list.all()
         return store, done_bool, (bool(fin) if sync else fin)
+
+    def _record_hip(self, reward, curr_done, sync):
+        """The same rule as one launch (include/sgrl.h sgrl_round_record; the tensor form above is ~15 small launches per step)."""
+        from . import _lib
+        L = _lib.lib()
+        r = reward if (reward.dtype == torch.float32 and reward.is_contiguous()) else reward.to(torch.float32).contiguous()
+        d = curr_done
+        if d.dtype == torch.bool:
+            d = d.contiguous().view(torch.uint8)
+        elif d.dtype != torch.uint8 or not d.is_contiguous():
+            d = (d != 0).contiguous().view(torch.uint8)
+        if getattr(self, "_store_u8", None) is None:
+            self._store_u8 = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
+            self._done_bool = torch.zeros(self.n, dtype=torch.float32, device=self.device)
+            self._all_done = torch.zeros(1, dtype=torch.int32, device=self.device)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        _lib.check(L.sgrl_round_record(p(r), p(d), p(self.done_list), p(self.episode_timesteps), p(self.episode_reward), p(self._reward_buf),
+                                       p(self._store_u8), p(self._done_bool), p(self._all_done), self.n, self.max_episode_steps,
+                                       ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "sgrl_round_record")
+        return self._store_u8.view(torch.bool), self._done_bool, (bool(self._all_done.item()) if sync else self._all_done)
 
     def per_morph_iter(self):
         """Number of TD3 updates per morphology after the round (reference trainer.py:244)."""
@@ -373,7 +396,7 @@ class TransitionSink(object):
         if self.is_learner:
             self.ingest(blocks)
         if self.lag_flag:
-            flag = finished.to(torch.int32).reshape(1)
+            flag = finished if finished.dtype == torch.int32 else finished.to(torch.int32).reshape(1)      # (the fused record hands out its int32 flag)
             if self.gather.world > 1:
                 self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)      # on the stream; nobody waits for it on the host
             host, ev = self._lag_spare.pop() if self._lag_spare else (torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())

@@ -342,3 +342,31 @@ def test_lagged_round_flag_stores_the_same_rows():
         n = ba.max_sample_size
         for name in ("obs_buffer", "action_buffer", "next_obs_buffer", "reward_buffer", "done_buffer"):
             assert torch.equal(getattr(ba, name)[:n], getattr(bb, name)[:n]), name
+
+
+def test_fused_round_record_equals_the_tensor_form():
+    """include/sgrl.h sgrl_round_record (one launch) against RoundCollector's tensor operations (the statement of the reference's rule,
+    trainer.py:205-232) on random reward / done sequences incl. the time limit: store masks, stored `done`, episode statistics and the
+    round-finished flag agree step by step, exactly."""
+    import torch
+    from sgrl_amd import rollout
+    n, T = 1000, 12
+    g = torch.Generator(device="cuda").manual_seed(4)
+    a = rollout.RoundCollector(n, max_episode_steps=T, device="cuda:0")
+    b = rollout.RoundCollector(n, max_episode_steps=T, device="cuda:0")
+    fin_a = fin_b = False
+    for t in range(T + 3):
+        rew = torch.randn(n, device="cuda", generator=g)
+        done = (torch.rand(n, device="cuda", generator=g) < 0.08).to(torch.uint8)
+        rollout.FUSED_RECORD = True
+        sa, da, fin_a = a.record(rew, done)
+        sa, da = sa.clone(), da.clone()
+        rollout.FUSED_RECORD = False
+        try:
+            sb, db, fin_b = b.record(rew, done)
+        finally:
+            rollout.FUSED_RECORD = True
+        assert torch.equal(sa, sb) and torch.equal(da, db) and fin_a == fin_b, t
+        assert torch.equal(a.done_list, b.done_list) and torch.equal(a.episode_timesteps, b.episode_timesteps)
+        assert torch.equal(a.episode_reward, b.episode_reward) and torch.equal(a._reward_buf, b._reward_buf)
+    assert fin_a and a.per_morph_iter() == b.per_morph_iter()
