@@ -1,5 +1,7 @@
 #!/bin/bash
 # round-6 GPU session A: GPU suite on the current tree, the graphed update in four arms, launch sources, the NumPy surface, one bench line
+# (HISTORICAL: the switches its arms toggle -- SGRL_FAN_OUT, SGRL_TWIN_TARGETS, SGRL_W32_KT -- were removed after this measurement,
+# profiles/r6_update_arms.txt; today all four arms run the same code)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r6a
 mkdir -p $O
