@@ -289,7 +289,10 @@ def main():
         # the step kernel INSIDE the rollout's flow: one more region of `steps` steps with a HIP event pair around every sgrl_step
         # (on torch's current stream, the stream sgrl_step launches on) -- fresh random actions, the forward between two steps
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-        barrier()
+        if gather is not None:             # rank-local only: NO collective may run in this rank-0 block (the other ranks are not here)
+            ingest_pending()
+            gather.drain()
+        torch.cuda.synchronize()
         for e0, e1 in evs:
             a = ro.random_actions()
             if gather is not None:
