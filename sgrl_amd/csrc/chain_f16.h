@@ -60,6 +60,7 @@ struct ChainArgs {
   // rows r = 3 m + s (W5 as row-scaled words, ws5 its inverse scales); outg != null: the new g also into outg[r][8:136] (row
   // stride outg_ld, zero K-padding columns 136 .. outg_ld - 1)
   float* g; const float* g1; const unsigned* W5; const float* ws5; float* outg; int outg_ld;
+  const float* xsc;                   // lab form only (DBG & 8): X arrives as row-scaled words, xsc [3 M] undoes the rows' scales
 };
 
 constexpr int kChainRows = 64;
@@ -70,7 +71,9 @@ constexpr int kChainEqSub = 2 * kChainRows * 80, kChainEqW2 = 2 * kChainEqSub, k
 
 // SRC: 0 loaded operand, 1 Gram operand.  PROJ: 0 none, 1 one projection (zc), 2 two (zc and z2).
 // DBG (tools/chain_lab.hip only; the results are wrong): 1 = no sub-slice hand-over inside the passes, 2 = no contraction epilogue,
-// 4 = no W2 staging inside the passes -- what each part of the equivariant phase costs
+// 4 = no W2 staging inside the passes -- what each part of the equivariant phase costs; 8 (PROJ kernels; results RIGHT, but the
+// forward has no producer that writes such an operand): the prologue's X arrives as row-scaled words + ChainArgs::xsc -- no estimate,
+// no vote, no split in its k-loop (what the site kernel gains when its producer emits the split form)
 template <int SRC, int HID, int EPI2, int PROJ, int DBG = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k_chain(ChainArgs a) {
   static_assert(HID == 256 || HID == 128, "hidden width 256 or 128");
@@ -135,10 +138,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
       x1v = lowh ? *reinterpret_cast<const float4*>(xr1 + k0) : *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(wr) + k0);
     };
     float psc[2] = {1.f, 1.f}, pmx[2] = {0.f, 0.f};     // scale / true maximum of X rows r4 and (threads 0..255) 128 + r4
+    constexpr bool XW = (DBG & 8) != 0;
     auto pstore = [&](int st) {
       char* base = lds + st * kPStage;
-      put(base, kPXA, r4, x0v, psc[0], &pmx[0]);
-      if (lowh) put(base, kPXA, 128 + r4, x1v, psc[1], &pmx[1]);
+      if (XW) put_words(base, kPXA, r4, x0v);
+      else put(base, kPXA, r4, x0v, psc[0], &pmx[0]);
+      if (lowh) { if (XW) put_words(base, kPXA, 128 + r4, x1v); else put(base, kPXA, 128 + r4, x1v, psc[1], &pmx[1]); }
       else put_words(base + 2 * kPXA, kPXW, r4 & 63, x1v);
     };
     f32x16 pacc[PROJ ? PROJ : 1], pcor[PROJ ? PROJ : 1];
@@ -152,19 +157,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
         for (int e = 0; e < 16; e++) { pacc[j][e] = 0.f; pcor[j][e] = 0.f; }
       // samples of each row's middle (staging thread 0 of the row) and last k-tile (thread 1), four values each, in flight with tile 0
       float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-      if (attempt == 0 && kq < 2) {
+      if (attempt == 0 && kq < 2 && !XW) {
         const int ks = (kq == 0 ? (nkp >> 1) : nkp - 1) * 16 - 4 * kq;
         s0 = *reinterpret_cast<const float4*>(xr0 + ks);
         if (lowh) s1 = *reinterpret_cast<const float4*>(xr1 + ks);
       }
       pload(0);
-      if (attempt == 0) {                     // estimates of the rows' magnitudes (gemm_f32.h, pow2_scale)
+      if (attempt == 0 && !XW) {              // estimates of the rows' magnitudes (gemm_f32.h, pow2_scale)
         auto m4 = [](const float4& v, float m) { m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), m); return fmaxf(fmaxf(fabsf(v.z), fabsf(v.w)), m); };
         float e0 = m4(s0, m4(x0v, 0.f)), e1 = lowh ? m4(s1, m4(x1v, 0.f)) : 0.f;
         psc[0] = pow2_scale(quad_max(e0), kScaleEstimate);
         psc[1] = pow2_scale(quad_max(e1), kScaleEstimate);
       }
-      if (kq == 0) { px_sh[r4] = pow2_inv(psc[0]); if (lowh) px_sh[128 + r4] = pow2_inv(psc[1]); }
+      if (XW) { if (kq == 0) { px_sh[r4] = a.xsc[min(x0 + r4, rows3 - 1)]; if (lowh) px_sh[128 + r4] = a.xsc[min(x0 + 128 + (r4 & 63), rows3 - 1)]; } }
+      else if (kq == 0) { px_sh[r4] = pow2_inv(psc[0]); if (lowh) px_sh[128 + r4] = pow2_inv(psc[1]); }
       pstore(0);
       __syncthreads();
       if (nkp > 1) pload(16);

@@ -45,6 +45,8 @@ struct GemmArgs {
   int phase_sleep = 0;                // k_gemm3: blocks of odd dispatch rounds start this many x 64 clocks late (see the kernel)
   // two-piece f16 form: W arrives as words of its rows PRE-SCALED by powers of two (k_encode_rows); wscale[n] undoes row n's scale
   const float* wscale = nullptr;
+  // lab form only (k_gemm3 WORDS = 3, tools/chain_lab.hip): A arrives as row-scaled words too; ascale[m] undoes row m's scale
+  const float* ascale = nullptr;
 };
 
 // BKT = k extent of an LDS tile (16 or 32); row stride BKT + 4 floats (conflict-free ds_read_b128, see above).
@@ -362,9 +364,11 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
   auto fin = [&](float hi, float co) -> float { return NPL == 2 ? hi + co * kCorW : hi + co; };
   static_assert(!SKEW || (!LATE && ABL == 0 && WM * WN == 8), "the skew assumes eight waves (w and w + 4 on one SIMD)");
   // WORDS: bit 1 = W arrives as pre-scaled, pre-split words (k_encode_rows); an f32 W of the two-piece form is split as it stands
-  // (lab / diagnostics only: no row scaling on that side)
-  static_assert(WORDS == 0 || (NPL == 2 && WORDS == 2), "pre-split words: the W operand of the two-piece form");
-  constexpr bool WWD = (WORDS & 2) != 0;
+  // (lab / diagnostics only: no row scaling on that side).  Bit 0 (WORDS = 3, LAB ONLY -- the forward has no producer that writes
+  // such an operand): A arrives as words too, with GemmArgs::ascale; nothing of the row-scale estimate / vote / split is left in
+  // the k-loop (what a consumer gains when its producer emits the split form)
+  static_assert(WORDS == 0 || (NPL == 2 && (WORDS == 2 || (WORDS == 3 && !GRAM && !PLA))), "pre-split words: operands of the two-piece form");
+  constexpr bool WWD = (WORDS & 2) != 0, AWD = (WORDS & 1) != 0;
   constexpr int T = Cfg::kThreads, BMT = Cfg::kBM, BNT = Cfg::kBN, RB = Cfg::kRowBytes;
   constexpr int QPR = BKT / 4;                // float4 per tile row
   constexpr int RPP = T / QPR;                // tile rows covered per staging pass
@@ -511,6 +515,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
                                         za0 * b0.z + za1 * b1.z + za2 * b2.z, za0 * b0.w + za1 * b1.w + za2 * b2.w);
           put(base, Cfg::kPlaneA, r0, gv);      // (scaled through gza; bounded by the row's ||Z'Z||_F)
         } else if (PLA) put_planes(base, Cfg::kPlaneA, r0 + RPP * i, pa[slot][PLA ? i : 0]);
+        else if (AWD) put_words(base, Cfg::kPlaneA, r0 + RPP * i, ra[slot][i]);
         else put(base, Cfg::kPlaneA, r0 + RPP * i, ra[slot][i], asc[i], &amx[i]);
       }
 #pragma unroll
@@ -562,7 +567,12 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(SG
   const int aoff = lds_rd<RB>(wm * 32 * TM + li, lh);        // this lane's 8 bf16 of k-step 0; k-step 1 (32-wide k-tiles) is 32 bytes on
   const int boff = NPL * Cfg::kPlaneA + lds_rd<RB>(wn * 32 * TN + li, lh);
   const bool late = SKEW ? (wave >= 4) : LATE;                   // wave-uniform
-  constexpr bool EST = SCL && !GRAM && !PLA;  // loaded f32 activation rows: scaled by an estimate, repeated with the exact maxima if it fell short
+  if (AWD && kq == 0) {
+#pragma unroll
+    for (int i = 0; i < NPA; i++)
+      if (BMT % RPP == 0 || r0 + RPP * i < BMT) rs_sh[r0 + RPP * i] = a.ascale[min(m0 + r0 + RPP * i, a.M - 1)];
+  }
+  constexpr bool EST = SCL && !GRAM && !PLA && !AWD;  // loaded f32 activation rows: scaled by an estimate, repeated with the exact maxima if it fell short
   auto body = [&](int kt, int slot) {
     const int st = kt & 1;
     if (!late && ABL != 1) {

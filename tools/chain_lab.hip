@@ -5,6 +5,7 @@
 //   ... -DSGRL_CHAIN_PROF -o tools/chain_lab_prof.exe: also prints the per-phase cycle shares of the site kernel (s_memtime stamps)
 #include "../sgrl_amd/csrc/chain_f16.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -69,12 +70,14 @@ static Host dev(size_t n, float scale, float offset = 0.f) {
 }
 // weights as k_encode_rows leaves them: words of the rows scaled by powers of two + the inverse scales
 struct Wt { unsigned* w; float* sc; };
+static EncMat* g_lab_mat;      // the descriptor of the last words() call (device)
 static Wt words(const float* w, int rows, int K) {
   Wt r;
   CK(hipMalloc(&r.w, (size_t)rows * K * 4)); CK(hipMalloc(&r.sc, (size_t)rows * 4));
   EncMat m{0, rows, K, 0, 1};
   EncMat* dm; CK(hipMalloc(&dm, sizeof(EncMat))); CK(hipMemcpy(dm, &m, sizeof(EncMat), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_encode_rows, dim3((rows + 3) / 4), dim3(256), 0, 0, w, r.w, r.sc, dm, 1, rows);
+  g_lab_mat = dm;
   return r;
 }
 static GemmArgs gemm(const float* A, int lda, const Wt& W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K, int flags,
@@ -232,6 +235,26 @@ int main(int argc, char** argv) {
       const float t2 = time_us([&] { hipLaunchKernelGGL(kGram, dim3(tiles * 2), dim3(512), kLds128, 0, gg); });
       const float t3 = time_us([&] { hipLaunchKernelGGL(kSplitPlain, dim3(tiles), dim3(512), kLds128, 0, g2p); });
       const float ts = time_us(single), tf = time_us(fused);
+      if (nz == 2) {
+        // round 6: the same site kernel with the prologue's X arriving as row-scaled words (k_chain DBG = 8, lab only)
+        Wt gw = words(g.d, N3, 128);
+        ChainArgs cw = c; cw.X = reinterpret_cast<const float*>(gw.w); cw.xsc = gw.sc;
+        float *zc_w, *z2_w, *out_w;
+        CK(hipMalloc(&zc_w, (size_t)N3 * 32 * 4)); CK(hipMalloc(&z2_w, (size_t)N3 * 32 * 4)); CK(hipMalloc(&out_w, (size_t)N * 256 * 4));
+        CK(hipMemset(out_w, 0, (size_t)N * 256 * 4));
+        CK(hipMemcpy(zc_w, zc0.d, (size_t)N3 * 32 * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(z2_w, zc0.d, (size_t)N3 * 32 * 4, hipMemcpyDeviceToDevice));   // (columns 30, 31 are never written)
+        cw.zc = zc_w; cw.z2 = z2_w; cw.A = zc_w; cw.C = out_w;
+        raise(k_chain<1, 256, 0, 2, 8>, kChainLds);
+        auto fusedw = [&] { hipLaunchKernelGGL((k_chain<1, 256, 0, 2, 8>), dim3(blocks), dim3(512), kChainLds, 0, cw); };
+        fusedw();
+        CK(hipDeviceSynchronize());
+        report("zc, X as words vs X as f32", fetch(zc_b, (size_t)N3 * 32), fetch(zc_w, (size_t)N3 * 32), 32, 32);
+        report("site output, X as words", fetch(out_b, (size_t)N * 256), fetch(out_w, (size_t)N * 256), 256, 128);
+        std::vector<float> a7, b7;
+        for (int r = 0; r < 7; r++) { a7.push_back(time_us(fused, 40)); b7.push_back(time_us(fusedw, 40)); }
+        std::sort(a7.begin(), a7.end()); std::sort(b7.begin(), b7.end());
+        printf("    site kernel (two projections), alternating 7 x 40 launches: median %.1f us, best %.1f | X as words: median %.1f us, best %.1f\n", a7[3], a7[0], b7[3], b7[0]);
+      }
       ChainArgs c0 = c; c0.A = zc_a;
       const float tf0 = time_us([&] { hipLaunchKernelGGL((k_chain<1, 256, 0, 0>), dim3(blocks), dim3(512), kChainLds, 0, c0); });
       printf("    single products proj %.1f + lg1 %.1f + lg2 %.1f us (back to back %.1f) | fused site %.1f us | fused lg1 -> lg2 without the projection %.1f us\n",
@@ -324,18 +347,43 @@ int main(int argc, char** argv) {
            time_us([&] { hipLaunchKernelGGL((EQ(7)), dim3(blocks), dim3(512), kChainEqLds, 0, c); }));
   }
   // ---- (3) the wide single products (reference timings for the forward's budget) -------------------------------------------------
+  // ... and (round 6) the same products with the ACTIVATION operand arriving as row-scaled words too, as if its
+  // producer had emitted the split form: no estimate, no vote, no split in the consumer's k-loop (k_gemm3 WORDS = 3, lab only).
+  // The words are made here by k_encode_rows (exact row maxima); the f32 form scales by its sampled estimate: same value to rounding.
   {
+    constexpr auto kWordsRowdiv = k_gemm3<EPI_ROWDIV, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2, true, 3>;
+    constexpr auto kWordsRelu = k_gemm3<EPI_RELU, 4, 2, 1, 2, 16, 2, false, false, false, 0, false, 2, true, 3>;
+    raise(kWordsRowdiv, kLds128); raise(kWordsRelu, kLds128);
     Host Wq = dev(1024 * 256, 0.2f), bq = dev(1024, 1.0f);
     Wt Wqw = words(Wq.d, 1024, 256);
-    float* big; CK(hipMalloc(&big, (size_t)N * 1024 * 4));
+    Wt catw = words(cat.d, N, 256);
+    float *big, *big2; CK(hipMalloc(&big, (size_t)N * 1024 * 4)); CK(hipMalloc(&big2, (size_t)N * 1024 * 4));
     for (int Nx : {1024, 768, 256}) {
       GemmArgs q = gemm(cat.d, 256, Wqw, 256, bq.d, big, Nx, N, Nx, 256, EPI_ROWDIV, fn.d);
       GemmArgs q2 = q; q2.flags = EPI_RELU;
-      const float tq = time_us([&] { hipLaunchKernelGGL(kSplitRowdiv, dim3(tiles * (Nx / 128)), dim3(512), kLds128, 0, q); });
-      const float tr = time_us([&] { hipLaunchKernelGGL(kSplitRelu, dim3(tiles * (Nx / 128)), dim3(512), kLds128, 0, q2); });
-      const float tq2 = time_us([&] { hipLaunchKernelGGL(kSplitRowdiv, dim3(tiles * (Nx / 128)), dim3(512), kLds128, 0, q); });
-      printf("  product M %d N %4d K 256: row division %.1f us | ReLU %.1f us | row division again %.1f us\n", N, Nx, tq, tr, tq2);
+      GemmArgs qw = q; qw.A = reinterpret_cast<const float*>(catw.w); qw.ascale = catw.sc; qw.C = big2;
+      GemmArgs qw2 = qw; qw2.flags = EPI_RELU;
+      const dim3 grid(tiles * (Nx / 128));
+      hipLaunchKernelGGL(kSplitRowdiv, grid, dim3(512), kLds128, 0, q);
+      hipLaunchKernelGGL(kWordsRowdiv, grid, dim3(512), kLds128, 0, qw);
+      CK(hipDeviceSynchronize());
+      report("A as words vs A as f32", fetch(big, (size_t)N * Nx), fetch(big2, (size_t)N * Nx), Nx, Nx);
+      // alternating, seven rounds of 40 launches each: median and best of each form (the first window after a switch of kernels runs
+      // slow on this part -- single windows of 20 launches spread over 15 %)
+      std::vector<float> tf[2], tw[2];
+      for (int r = 0; r < 7; r++) {
+        tf[0].push_back(time_us([&] { hipLaunchKernelGGL(kSplitRowdiv, grid, dim3(512), kLds128, 0, q); }, 40));
+        tw[0].push_back(time_us([&] { hipLaunchKernelGGL(kWordsRowdiv, grid, dim3(512), kLds128, 0, qw); }, 40));
+        tf[1].push_back(time_us([&] { hipLaunchKernelGGL(kSplitRelu, grid, dim3(512), kLds128, 0, q2); }, 40));
+        tw[1].push_back(time_us([&] { hipLaunchKernelGGL(kWordsRelu, grid, dim3(512), kLds128, 0, qw2); }, 40));
+      }
+      auto med = [](std::vector<float> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+      auto best = [](std::vector<float> v) { std::sort(v.begin(), v.end()); return v[0]; };
+      printf("  product M %d N %4d K 256: row division median %.1f us, best %.1f (A as words %.1f, %.1f) | ReLU %.1f, %.1f (A as words %.1f, %.1f)\n",
+             N, Nx, med(tf[0]), best(tf[0]), med(tw[0]), best(tw[0]), med(tf[1]), best(tf[1]), med(tw[1]), best(tw[1]));
     }
+    const float te = time_us([&] { hipLaunchKernelGGL(k_encode_rows, dim3((N + 3) / 4), dim3(256), 0, 0, cat.d, catw.w, catw.sc, g_lab_mat, 1, N); });
+    printf("  (a separate pass that turns a [%d, 256] f32 operand into words + row scales: %.1f us)\n", N, te);
   }
   return 0;
 }
