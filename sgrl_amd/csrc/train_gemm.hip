@@ -692,34 +692,49 @@ __global__ __launch_bounds__(256) void k_unfold_sym(FoldArgs p) {
 // here); the vector values vg[j][s][h][d] are vgp [B, L, 3, 252] (d < 126: the projected part, 126 per head) and the node's
 // gravity / direction pair gdir [B, L, 3, 2] (d = 126, 127) -- the concatenation is never built; bias [2, L, L] or null.
 //   w = softmax_j(scale q_i . k_j + bias);   o[i][c] = sum_j w[h(c)][i][j] v[j][c];   og[i][s][c] = sum_j w[h(c)][i][j] vg[j][s][c]
-// One 256-thread workgroup per environment; scores by a thread per (head, i, j) from LDS-resident q / k rows (pitch 257: the
-// rows of different limbs fall on different banks), outputs by a thread per channel.  w is kept for the backward.
-constexpr int AL = 14, AP = 257;
-__device__ __forceinline__ float vg_at(const float* vgp, const float* gdir, size_t node, int sx, int t) {
-  const int h = t >> 7, d = t & 127;
+// One 128-thread workgroup per (environment, head) -- round 6; rounds 3-5 ran one 256-thread workgroup per environment and went to
+// memory up to ten times in a row (the backward: four operand passes, then q, k, do and the three dog slices again).  A workgroup is
+// bound by those round trips, not by its arithmetic: EVERY global load of a kernel is now issued in one batch at its top (14 x 10
+// registers at most), and the backward keeps its eight operand slices in LDS for both of its halves.  Scores by a pair of lanes per
+// (i, j) entry (half of the 128 channels each) from LDS rows of pitch 129 (the rows of different limbs start on different banks),
+// outputs by a thread per channel.  w is kept for the backward.
+constexpr int AL = 14, AQ = 129;
+__device__ __forceinline__ float vg_at(const float* vgp, const float* gdir, size_t node, int sx, int h, int d) {
   return d < 126 ? vgp[(node * 3 + sx) * 252 + h * 126 + d] : gdir[(node * 3 + sx) * 2 + (d - 126)];
 }
-__global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ qkv, const float* __restrict__ vgp,
+__global__ __launch_bounds__(128) void k_attn_fwd(const float* __restrict__ qkv, const float* __restrict__ vgp,
                                                   const float* __restrict__ gdir, const float* __restrict__ bias, float scale,
                                                   float* wout, float* o, float* og, int L) {
-  __shared__ float qs[AL * AP], ks[AL * AP];
-  __shared__ float sc[2 * AL * AL];
-  const int b = blockIdx.x, t = threadIdx.x;
+  __shared__ float qs[AL * AQ], ks[AL * AQ];
+  __shared__ float sc[AL * AL];
+  const int b = blockIdx.x >> 1, h = blockIdx.x & 1, d = threadIdx.x, c = 128 * h + d;
   const size_t n0 = (size_t)b * L;
-  for (int i = 0; i < L; i++) { qs[i * AP + t] = qkv[(n0 + i) * 768 + t] * scale; ks[i * AP + t] = qkv[(n0 + i) * 768 + 256 + t]; }
+  float qv[AL], kv[AL], vv[4][AL];
+#pragma unroll
+  for (int i = 0; i < AL; i++)
+    if (i < L) {
+      const float* row = qkv + (n0 + i) * 768 + c;
+      qv[i] = row[0]; kv[i] = row[256]; vv[0][i] = row[512];
+#pragma unroll
+      for (int sx = 0; sx < 3; sx++) vv[1 + sx][i] = vg_at(vgp, gdir, n0 + i, sx, h, d);
+    }
+#pragma unroll
+  for (int i = 0; i < AL; i++)
+    if (i < L) { qs[i * AQ + d] = qv[i] * scale; ks[i * AQ + d] = kv[i]; }
   __syncthreads();
-  for (int idx = t; idx < 2 * L * L; idx += 256) {
-    const int h = idx / (L * L), i = (idx / L) % L, j = idx % L;
-    const float* a = qs + i * AP + 128 * h;
-    const float* c = ks + j * AP + 128 * h;
+  const int half = d & 1;
+  for (int e = d >> 1; e < L * L; e += 64) {        // (both lanes of a pair run the same trips)
+    const float* a = qs + (e / L) * AQ + 64 * half;
+    const float* k = ks + (e % L) * AQ + 64 * half;
     float acc = 0.f;
 #pragma unroll 8
-    for (int d = 0; d < 128; d++) acc += a[d] * c[d];
-    sc[idx] = bias ? acc + bias[idx] : acc;
+    for (int x = 0; x < 64; x++) acc += a[x] * k[x];
+    acc += __shfl_xor(acc, 1, 64);
+    if (half == 0) sc[e] = bias ? acc + bias[h * L * L + e] : acc;
   }
   __syncthreads();
-  if (t < 2 * L) {
-    float* row = sc + t * L;
+  if (d < L) {
+    float* row = sc + d * L;
     float mx = row[0];
     for (int j = 1; j < L; j++) mx = fmaxf(mx, row[j]);
     float sum = 0.f;
@@ -727,123 +742,119 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ qkv,
     for (int j = 0; j < L; j++) row[j] = row[j] / sum;
   }
   __syncthreads();
-  for (int idx = t; idx < 2 * L * L; idx += 256) wout[(size_t)b * 2 * L * L + idx] = sc[idx];
-  const int h = t >> 7;
-  const float* w = sc + h * L * L;
-  float vv[AL];
-#pragma unroll
-  for (int j = 0; j < AL; j++) vv[j] = j < L ? qkv[(n0 + j) * 768 + 512 + t] : 0.f;
+  for (int idx = d; idx < L * L; idx += 128) wout[((size_t)b * 2 + h) * L * L + idx] = sc[idx];
 #pragma unroll
   for (int i = 0; i < AL; i++)
     if (i < L) {
-      float acc = 0.f;
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < AL; j++) if (j < L) acc += w[i * L + j] * vv[j];
-      o[(n0 + i) * 256 + t] = acc;
+      for (int j = 0; j < AL; j++)
+        if (j < L) {
+          const float wij = sc[i * L + j];
+#pragma unroll
+          for (int q = 0; q < 4; q++) acc[q] += wij * vv[q][j];
+        }
+      o[(n0 + i) * 256 + c] = acc[0];
+#pragma unroll
+      for (int sx = 0; sx < 3; sx++) og[((n0 + i) * 3 + sx) * 256 + c] = acc[1 + sx];
     }
-  for (int sx = 0; sx < 3; sx++) {
-#pragma unroll
-    for (int j = 0; j < AL; j++) vv[j] = j < L ? vg_at(vgp, gdir, n0 + j, sx, t) : 0.f;
-#pragma unroll
-    for (int i = 0; i < AL; i++)
-      if (i < L) {
-        float acc = 0.f;
-#pragma unroll
-        for (int j = 0; j < AL; j++) if (j < L) acc += w[i * L + j] * vv[j];
-        og[((n0 + i) * 3 + sx) * 256 + t] = acc;
-      }
-  }
 }
 // Backward: dw = do v' + sum_s dog_s vg_s' (per head), ds = w (dw - sum_j w dw), dq = scale ds k, dk = ds' (scale q), dv = w' do,
 // dvg = w' dog.  dqkv [B, L, 768] is written packed; dvg goes to dvgp [B, L, 3, 252] and, per head, dgdh [B, L, 3, 2 heads, 2];
 // ds [B, 2, L, L] is written out as well (its sum over the environments is the gradient of the relation bias).
-__global__ __launch_bounds__(256) void k_attn_bwd(const float* __restrict__ qkv, const float* __restrict__ vgp,
+// Dynamic LDS (attn_bwd_lds_bytes): A [4][L][AQ] = do | dog_0..2, V [4][L][AQ] = v | vg_0..2 (this head's channels), w, dw [L][L].
+__host__ __device__ constexpr int attn_bwd_lds_bytes(int L) { return (8 * L * AQ + 2 * L * L) * (int)sizeof(float); }
+__global__ __launch_bounds__(128) void k_attn_bwd(const float* __restrict__ qkv, const float* __restrict__ vgp,
                                                   const float* __restrict__ gdir, float scale, const float* __restrict__ win,
                                                   const float* __restrict__ dout, const float* __restrict__ dog, float* dqkv,
                                                   float* dvgp, float* dgdh, float* ds_out, int L) {
-  __shared__ float as[AL * AP], bs[AL * AP];
-  __shared__ float w[2 * AL * AL], dw[2 * AL * AL];
-  const int b = blockIdx.x, t = threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) float attn_lds[];
+  float* A = attn_lds;
+  float* V = A + 4 * L * AQ;
+  float* w = V + 4 * L * AQ;
+  float* dw = w + L * L;
+  const int b = blockIdx.x >> 1, h = blockIdx.x & 1, d = threadIdx.x, c = 128 * h + d;
   const size_t n0 = (size_t)b * L;
-  for (int idx = t; idx < 2 * L * L; idx += 256) { w[idx] = win[(size_t)b * 2 * L * L + idx]; dw[idx] = 0.f; }
-  // dw, four passes: (do, v), (dog_s, vg_s) for s = 0..2, each staged in LDS
-  for (int pass = 0; pass < 4; pass++) {
-    __syncthreads();
-    for (int i = 0; i < L; i++) {
-      if (pass == 0) { as[i * AP + t] = dout[(n0 + i) * 256 + t]; bs[i * AP + t] = qkv[(n0 + i) * 768 + 512 + t]; }
-      else { as[i * AP + t] = dog[((n0 + i) * 3 + (pass - 1)) * 256 + t]; bs[i * AP + t] = vg_at(vgp, gdir, n0 + i, pass - 1, t); }
+  float qv[AL], kv[AL], ra[4][AL], rv[4][AL];
+#pragma unroll
+  for (int i = 0; i < AL; i++)
+    if (i < L) {
+      const float* row = qkv + (n0 + i) * 768 + c;
+      qv[i] = row[0]; kv[i] = row[256]; rv[0][i] = row[512];
+      ra[0][i] = dout[(n0 + i) * 256 + c];
+#pragma unroll
+      for (int sx = 0; sx < 3; sx++) {
+        ra[1 + sx][i] = dog[((n0 + i) * 3 + sx) * 256 + c];
+        rv[1 + sx][i] = vg_at(vgp, gdir, n0 + i, sx, h, d);
+      }
     }
-    __syncthreads();
-    for (int idx = t; idx < 2 * L * L; idx += 256) {
-      const int h = idx / (L * L), i = (idx / L) % L, j = idx % L;
-      const float* a = as + i * AP + 128 * h;
-      const float* c = bs + j * AP + 128 * h;
-      float acc = 0.f;
+  for (int idx = d; idx < L * L; idx += 128) w[idx] = win[((size_t)b * 2 + h) * L * L + idx];
+#pragma unroll
+  for (int i = 0; i < AL; i++)
+    if (i < L) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) { A[(q * L + i) * AQ + d] = ra[q][i]; V[(q * L + i) * AQ + d] = rv[q][i]; }
+    }
+  __syncthreads();
+  const int half = d & 1;
+  for (int e = d >> 1; e < L * L; e += 64) {        // dw[i][j]: a pair of lanes per entry, half of the channels each, all four slices
+    const int i = e / L, j = e % L;
+    float acc = 0.f;
+    for (int q = 0; q < 4; q++) {
+      const float* a = A + (q * L + i) * AQ + 64 * half;
+      const float* v = V + (q * L + j) * AQ + 64 * half;
 #pragma unroll 8
-      for (int d = 0; d < 128; d++) acc += a[d] * c[d];
-      dw[idx] += acc;
+      for (int x = 0; x < 64; x++) acc += a[x] * v[x];
     }
+    acc += __shfl_xor(acc, 1, 64);
+    if (half == 0) dw[e] = acc;
   }
   __syncthreads();
-  if (t < 2 * L) {                                   // softmax backward, one thread per (head, i) row; dw becomes ds in place
-    float* wr = w + t * L;
-    float* dr = dw + t * L;
+  if (d < L) {                                       // softmax backward, one thread per row i; dw becomes ds in place
+    float* wr = w + d * L;
+    float* dr = dw + d * L;
     float dot = 0.f;
     for (int j = 0; j < L; j++) dot += wr[j] * dr[j];
     for (int j = 0; j < L; j++) dr[j] = wr[j] * (dr[j] - dot);
   }
   __syncthreads();
-  for (int idx = t; idx < 2 * L * L; idx += 256) ds_out[(size_t)b * 2 * L * L + idx] = dw[idx];
-  const int h = t >> 7, d = t & 127;
-  const float* wh = w + h * L * L;
-  const float* dsh = dw + h * L * L;
-  float col[AL];
-  // dq[i] = scale sum_j ds[i][j] k[j]
-#pragma unroll
-  for (int j = 0; j < AL; j++) col[j] = j < L ? qkv[(n0 + j) * 768 + 256 + t] : 0.f;
+  for (int idx = d; idx < L * L; idx += 128) ds_out[((size_t)b * 2 + h) * L * L + idx] = dw[idx];
+  // dq[i] = scale sum_j ds[i][j] k[j];  dk[j] = sum_i ds[i][j] (scale q[i])
 #pragma unroll
   for (int i = 0; i < AL; i++)
     if (i < L) {
       float acc = 0.f;
 #pragma unroll
-      for (int j = 0; j < AL; j++) if (j < L) acc += dsh[i * L + j] * col[j];
-      dqkv[(n0 + i) * 768 + t] = acc * scale;
+      for (int j = 0; j < AL; j++) if (j < L) acc += dw[i * L + j] * kv[j];
+      dqkv[(n0 + i) * 768 + c] = acc * scale;
     }
-  // dk[j] = sum_i ds[i][j] (scale q[i])
-#pragma unroll
-  for (int i = 0; i < AL; i++) col[i] = i < L ? qkv[(n0 + i) * 768 + t] * scale : 0.f;
 #pragma unroll
   for (int j = 0; j < AL; j++)
     if (j < L) {
       float acc = 0.f;
 #pragma unroll
-      for (int i = 0; i < AL; i++) if (i < L) acc += dsh[i * L + j] * col[i];
-      dqkv[(n0 + j) * 768 + 256 + t] = acc;
+      for (int i = 0; i < AL; i++) if (i < L) acc += dw[i * L + j] * (qv[i] * scale);
+      dqkv[(n0 + j) * 768 + 256 + c] = acc;
     }
-  // dv[j] = sum_i w[i][j] do[i];  dvg[j][s] = sum_i w[i][j] dog[i][s]
-#pragma unroll
-  for (int i = 0; i < AL; i++) col[i] = i < L ? dout[(n0 + i) * 256 + t] : 0.f;
+  // dv[j] = sum_i w[i][j] do[i];  dvg[j][s] = sum_i w[i][j] dog[i][s] -- do / dog are still in this thread's registers
 #pragma unroll
   for (int j = 0; j < AL; j++)
     if (j < L) {
-      float acc = 0.f;
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < AL; i++) if (i < L) acc += wh[i * L + j] * col[i];
-      dqkv[(n0 + j) * 768 + 512 + t] = acc;
-    }
-  for (int sx = 0; sx < 3; sx++) {
+      for (int i = 0; i < AL; i++)
+        if (i < L) {
+          const float wij = w[i * L + j];
 #pragma unroll
-    for (int i = 0; i < AL; i++) col[i] = i < L ? dog[((n0 + i) * 3 + sx) * 256 + t] : 0.f;
+          for (int q = 0; q < 4; q++) acc[q] += wij * ra[q][i];
+        }
+      dqkv[(n0 + j) * 768 + 512 + c] = acc[0];
 #pragma unroll
-    for (int j = 0; j < AL; j++)
-      if (j < L) {
-        float acc = 0.f;
-#pragma unroll
-        for (int i = 0; i < AL; i++) if (i < L) acc += wh[i * L + j] * col[i];
-        if (d < 126) dvgp[((n0 + j) * 3 + sx) * 252 + h * 126 + d] = acc;
-        else dgdh[(((n0 + j) * 3 + sx) * 2 + h) * 2 + (d - 126)] = acc;
+      for (int sx = 0; sx < 3; sx++) {
+        if (d < 126) dvgp[((n0 + j) * 3 + sx) * 252 + h * 126 + d] = acc[1 + sx];
+        else dgdh[(((n0 + j) * 3 + sx) * 2 + h) * 2 + (d - 126)] = acc[1 + sx];
       }
-  }
+    }
 }
 
 // Equivariant contraction of a node's three 32-vectors with its 32 x 32 matrix (reference SEActor.py:108-110, 262-264):
@@ -1318,7 +1329,7 @@ int sgrl_sym_fold(int n, const float* const* w, float* const* wtri, const int* r
 int sgrl_attention_forward(const float* qkv, const float* vgp, const float* gdir, const float* bias, float scale, float* w,
                            float* o, float* og, int B, int L, void* stream) {
   if (!qkv || !vgp || !gdir || !w || !o || !og || B <= 0 || L < 1 || L > AL) return tfail(SGRL_ERR_ARG, "sgrl_attention_forward: bad argument");
-  hipLaunchKernelGGL(k_attn_fwd, dim3(B), dim3(256), 0, (hipStream_t)stream, qkv, vgp, gdir, bias, scale, w, o, og, L);
+  hipLaunchKernelGGL(k_attn_fwd, dim3(2 * B), dim3(128), 0, (hipStream_t)stream, qkv, vgp, gdir, bias, scale, w, o, og, L);
   { int lrc = SGRL_OK; if (!launched("k_attn_fwd launch failed", &lrc)) return lrc; }
   return SGRL_OK;
 }
@@ -1327,7 +1338,11 @@ int sgrl_attention_backward(const float* qkv, const float* vgp, const float* gdi
                             const float* d_og, float* dqkv, float* dvgp, float* dgdh, float* ds, int B, int L, void* stream) {
   if (!qkv || !vgp || !gdir || !w || !d_o || !d_og || !dqkv || !dvgp || !dgdh || !ds || B <= 0 || L < 1 || L > AL)
     return tfail(SGRL_ERR_ARG, "sgrl_attention_backward: bad argument");
-  hipLaunchKernelGGL(k_attn_bwd, dim3(B), dim3(256), 0, (hipStream_t)stream, qkv, vgp, gdir, scale, w, d_o, d_og, dqkv, dvgp, dgdh, ds, L);
+  static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 attn_bwd_lds_bytes(AL)) == hipSuccess;
+  if (!lds_ok) return tfail(SGRL_ERR_HIP, "sgrl_attention_backward: the kernel's dynamic LDS size was refused");
+  hipLaunchKernelGGL(k_attn_bwd, dim3(2 * B), dim3(128), attn_bwd_lds_bytes(L), (hipStream_t)stream, qkv, vgp, gdir, scale, w, d_o, d_og, dqkv, dvgp,
+                     dgdh, ds, L);
   { int lrc = SGRL_OK; if (!launched("k_attn_bwd launch failed", &lrc)) return lrc; }
   return SGRL_OK;
 }
