@@ -926,12 +926,15 @@ __global__ __launch_bounds__(256) void k_add_ln_fwd(const float* __restrict__ x,
     if (lane == 0) rstd[row] = r;
   }
 }
-// workgroups [0, nrow_blocks): dx of four rows each; the rest: (network, 32 columns) -> dw = sum_rows dy xhat, db = sum_rows dy, the
-// rows summed in a fixed order (eight interleaved row groups, then the groups in order): bit-reproducible, no atomics
+// workgroups [0, nrow_blocks): dx of four rows each; the rest: (network, 16 columns) -> dw = sum_rows dy xhat, db = sum_rows dy, the
+// rows summed in a fixed order (sixteen interleaved row groups, then the groups in order): bit-reproducible, no atomics.  (Rounds 4-5:
+// 32 columns x eight groups with eight rows in flight -- at the update's 1 792 rows a thread then made 28 dependent trips to memory,
+// 12.4 us per launch; sixteen groups with sixteen rows in flight make 7.)
+constexpr int kLnCols = 16, kLnGroups = 16, kLnFlight = 16;
 __global__ __launch_bounds__(256) void k_add_ln_bwd(const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ rstd,
                                                     const float* __restrict__ w0, const float* __restrict__ w1, float* __restrict__ dx,
                                                     float* dw0, float* db0, float* dw1, float* db1, int rows, int total, int nrow_blocks) {
-  __shared__ float red[2][8][32];
+  __shared__ float red[2][kLnGroups][kLnCols];
   if ((int)blockIdx.x < nrow_blocks) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= total) return;
@@ -946,32 +949,33 @@ __global__ __launch_bounds__(256) void k_add_ln_bwd(const float* __restrict__ dy
     *reinterpret_cast<float2*>(dx + (size_t)row * 128 + 2 * lane) = make_float2(r * (gx - c1 - xh.x * c2), r * (gy - c1 - xh.y * c2));
     return;
   }
-  const int q = blockIdx.x - nrow_blocks, net = q >> 2, c = 32 * (q & 3) + (threadIdx.x & 31), grp = threadIdx.x >> 5;
+  constexpr int kPer = 128 / kLnCols;          // workgroups per network
+  const int q = blockIdx.x - nrow_blocks, net = q / kPer, col = threadIdx.x % kLnCols, c = kLnCols * (q % kPer) + col, grp = threadIdx.x / kLnCols;
   float* dw = net ? dw1 : dw0;
   float* db = net ? db1 : db0;
   if (!dw && !db) return;
   float aw = 0.f, ab = 0.f;
   const size_t base = (size_t)net * rows * 128 + c;
   int r = grp;
-  for (; r + 56 < rows; r += 64) {       // eight of this group's rows in flight; summed in the same order as one at a time
-    float g[8], xh[8];                   // (26 -> 7 us for the update's 700 rows: the loop was a chain of dependent-latency loads)
+  for (; r + kLnGroups * (kLnFlight - 1) < rows; r += kLnGroups * kLnFlight) {       // kLnFlight of this group's rows in flight; summed in the same order as one at a time
+    float g[kLnFlight], xh[kLnFlight];
 #pragma unroll
-    for (int u = 0; u < 8; u++) { g[u] = dy[base + (size_t)(r + 8 * u) * 128]; xh[u] = xhat[base + (size_t)(r + 8 * u) * 128]; }
+    for (int u = 0; u < kLnFlight; u++) { g[u] = dy[base + (size_t)(r + kLnGroups * u) * 128]; xh[u] = xhat[base + (size_t)(r + kLnGroups * u) * 128]; }
 #pragma unroll
-    for (int u = 0; u < 8; u++) { aw += g[u] * xh[u]; ab += g[u]; }
+    for (int u = 0; u < kLnFlight; u++) { aw += g[u] * xh[u]; ab += g[u]; }
   }
-  for (; r < rows; r += 8) {
+  for (; r < rows; r += kLnGroups) {
     const float g = dy[base + (size_t)r * 128];
     aw += g * xhat[base + (size_t)r * 128];
     ab += g;
   }
-  red[0][grp][threadIdx.x & 31] = aw;
-  red[1][grp][threadIdx.x & 31] = ab;
+  red[0][grp][col] = aw;
+  red[1][grp][col] = ab;
   __syncthreads();
   if (grp == 0) {
     float sw = 0.f, sb = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; k++) { sw += red[0][k][threadIdx.x]; sb += red[1][k][threadIdx.x]; }
+    for (int k = 0; k < kLnGroups; k++) { sw += red[0][k][col]; sb += red[1][k][col]; }
     if (dw) dw[c] = sw;
     if (db) db[c] = sb;
   }
@@ -1450,7 +1454,7 @@ int sgrl_add_ln_backward(const float* dy, const float* xhat, const float* rstd, 
     return tfail(SGRL_ERR_ARG, "sgrl_add_ln_backward: bad argument");
   const int total = rows * nets, nrow_blocks = (total + 3) / 4;
   const bool params = dw0 || db0 || dw1 || db1;
-  hipLaunchKernelGGL(k_add_ln_bwd, dim3(nrow_blocks + (params ? 4 * nets : 0)), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, w0, w1, dx,
+  hipLaunchKernelGGL(k_add_ln_bwd, dim3(nrow_blocks + (params ? (128 / kLnCols) * nets : 0)), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, w0, w1, dx,
                      dw0, db0, dw1, db1, rows, total, nrow_blocks);
   { int lrc = SGRL_OK; if (!launched("k_add_ln_bwd launch failed", &lrc)) return lrc; }
   return SGRL_OK;
