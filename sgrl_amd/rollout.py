@@ -14,10 +14,8 @@ from .set_hip import HipSetActor
 from .vec_env import BatchedModularVecEnv
 
 TRAV = ["pre", "inlcrs", "postlcrs"]
-FUSED_RECORD = False     # True: RoundCollector's bookkeeping as ONE launch of the C ABI (sgrl_round_record) instead of ~15 tensor operations.  Bit-equal
-                         # (tests/test_train_loop_gpu.py), and SLOWER inside the trainer: config-5 collection 10.7-11.0 ms per step against 9.85 with the
-                         # tensor form, alternating on one box, with and without the call's 4-byte memset (tools/diag/train_bench_ab.sh; cause not found).
-                         # The entry point stays for callers of the C ABI that have no tensor library
+FUSED_RECORD = True      # False (tests, A/B): RoundCollector's bookkeeping as ~15 tensor operations on the GPU too.  Same rows, same flags; the config-5
+                         # collection step is the same 9.68 ms either way (GPU-bound), the one launch saves 95 us of host time per step
 FUSED_INGEST = True      # False (tests): the learner writes a gathered block morphology by morphology with indexed copies (the CPU path) on the GPU too
 
 

@@ -359,12 +359,13 @@ def test_fused_round_record_equals_the_tensor_form():
         rew = torch.randn(n, device="cuda", generator=g)
         done = (torch.rand(n, device="cuda", generator=g) < 0.08).to(torch.uint8)
         rollout.FUSED_RECORD = True
-        try:
-            sa, da, fin_a = a.record(rew, done)
-        finally:
-            rollout.FUSED_RECORD = False
+        sa, da, fin_a = a.record(rew, done)
         sa, da = sa.clone(), da.clone()
-        sb, db, fin_b = b.record(rew, done)
+        rollout.FUSED_RECORD = False
+        try:
+            sb, db, fin_b = b.record(rew, done)
+        finally:
+            rollout.FUSED_RECORD = True
         assert torch.equal(sa, sb) and torch.equal(da, db) and fin_a == fin_b, t
         assert torch.equal(a.done_list, b.done_list) and torch.equal(a.episode_timesteps, b.episode_timesteps)
         assert torch.equal(a.episode_reward, b.episode_reward) and torch.equal(a._reward_buf, b._reward_buf)

@@ -26,4 +26,4 @@ for rep in range(2):
         tr.ro.env.close()
         del tr
         torch.cuda.empty_cache()
-rollout.FUSED_RECORD = False
+rollout.FUSED_RECORD = True

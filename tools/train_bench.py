@@ -20,6 +20,9 @@ TUNE = os.environ.get("SGRL_TUNE_GEMMS", "1") != "0"
 tr = DeviceTrainer(names, per, args=args, seed=1, device="cuda:0", max_buffer_size=200000, graph_updates=GRAPH, tune_gemms=TUNE)
 n = tr.ro.env.num_envs
 tr.warmup(60)                      # fills the buffers (random actions), several rounds
+for _ in range(8):                 # untimed POLICY steps: the first one loads code objects (PyTorch's noise / clamp kernels, the SET forward's
+    if tr.collect_step():          # stream probe) and packs the weights -- 16 to 64 ms once, which a 40-step window would book as 0.4 to 1.6 ms
+        tr.begin_round()           # per step (round 6: that is what made the one-launch round bookkeeping look 1 ms slower than it is faster)
 torch.cuda.synchronize()
 t0 = time.time(); K = 40
 for _ in range(K):
